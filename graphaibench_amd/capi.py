@@ -1,0 +1,332 @@
+"""ctypes binding of the C ABI in include/gaib.h (libgaib_hip.so).
+
+This is plumbing for tests/, bench.py and the multi-GPU driver: torch supplies device memory
+(`tensor.data_ptr()`), streams and torch.distributed; every compute call goes through the C ABI
+into the hand-written gfx950 kernels.  There is NO fallback: if the library is missing or a call
+fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_DIR = Path(__file__).resolve().parent / "lib"
+LIB_PATH = LIB_DIR / "libgaib_hip.so"
+
+# gaib_weight_kind
+W_GCN, W_MEAN, W_MEAN_T, W_EDGE, W_EDGE_T = 0, 1, 2, 3, 4
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); kept in sync with include/gaib.h (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "gaib_last_error": (C.c_char_p, []),
+    "gaib_version": (C.c_char_p, []),
+    "gaib_ctx_create": (_i, [_i, _vp, _pp]),
+    "gaib_ctx_destroy": (_i, [_vp]),
+    "gaib_ctx_set_stream": (_i, [_vp, _vp]),
+    "gaib_sync": (_i, [_vp]),
+    "gaib_malloc": (_i, [_vp, C.c_size_t, _pp]),
+    "gaib_free": (_i, [_vp, _vp]),
+    "gaib_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "gaib_memcpy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "gaib_memcpy_d2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "gaib_fill_f32": (_i, [_vp, _i64, _f, _vp]),
+    "gaib_graph_create": (_i, [_vp, _i64, _i64, _vp, _i, _vp, _i, _pp]),
+    "gaib_graph_create_rect": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _vp, _i, _pp]),
+    "gaib_graph_destroy": (_i, [_vp]),
+    "gaib_graph_add_selfloop": (_i, [_vp, _vp, _pp]),
+    "gaib_graph_nv": (_i64, [_vp]),
+    "gaib_graph_ne": (_i64, [_vp]),
+    "gaib_graph_rowptr": (_vp, [_vp]),
+    "gaib_graph_colidx": (_vp, [_vp]),
+    "gaib_graph_compute_vertex_data": (_i, [_vp, _vp]),
+    "gaib_graph_vertex_data": (_vp, [_vp]),
+    "gaib_graph_compute_edge_data": (_i, [_vp, _vp]),
+    "gaib_graph_edge_data": (_vp, [_vp]),
+    "gaib_graph_set_vertex_norm": (_i, [_vp, _vp, _vp, _vp]),
+    "gaib_graph_device_bytes": (_i64, [_vp]),
+    "gaib_spmm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "gaib_gat_softmax_bwd_alpha": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "gaib_edge_transpose": (_i, [_vp, _vp, _vp, _vp]),
+    "gaib_sgemm": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
+    "gaib_relu": (_i, [_vp, _i64, _vp, _vp]),
+    "gaib_d_relu": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "gaib_dropout": (_i, [_vp, _i64, _f, _f, _u64, _vp, _vp, _vp]),
+    "gaib_d_dropout": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
+    "gaib_softmax_xent": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gaib_d_softmax_xent": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gaib_masked_avg_loss": (_i, [_vp, _i64, _i64, _vp, _vp, C.POINTER(_f)]),
+    "gaib_masked_accuracy_single": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, C.POINTER(_f)]),
+    "gaib_l2norm": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "gaib_d_l2norm": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "gaib_adam_step": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]),
+    "gaib_gather_rows": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
+    "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
+}
+
+
+class GaibError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libgaib_hip.so and attach prototypes.  Raises if the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise GaibError(
+            f"{LIB_PATH} is missing: build it with `python -m graphaibench_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gaib_last_error().decode(errors="replace")
+        raise GaibError(f"{what} failed (status {rc}): {msg}")
+
+
+def _ptr(x) -> int | None:
+    """torch tensor / int / None -> raw pointer."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+class Context:
+    """gaib_ctx bound to one device and one HIP stream (default: torch's current stream)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        import torch
+
+        self.lib = load()
+        self.device = device
+        torch.cuda.set_device(device)
+        if stream is None:
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        _check(self.lib.gaib_ctx_create(device, C.c_void_p(stream), C.byref(h)), "gaib_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gaib_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(self.lib.gaib_sync(self.h), "gaib_sync")
+
+    def set_option(self, key: str, value: int):
+        _check(self.lib.gaib_set_option(self.h, key.encode(), int(value)), f"gaib_set_option({key})")
+
+    # ---- graph ------------------------------------------------------------------------
+    def graph(self, rowptr, colidx, ncols: int | None = None) -> "Graph":
+        return Graph(self, rowptr, colidx, ncols)
+
+    # ---- aggregation --------------------------------------------------------------------
+    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None):
+        assert x.is_contiguous() and out.is_contiguous() and x.dim() == 2
+        _check(self.lib.gaib_spmm(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(out)),
+               "gaib_spmm")
+        return out
+
+    def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2):
+        _check(self.lib.gaib_gat_scores(self.h, g.h, h.shape[1], _ptr(h), _ptr(alpha_l), _ptr(alpha_r),
+                                        eps, _ptr(temp), _ptr(scores), _ptr(norm)), "gaib_gat_scores")
+
+    def sddmm(self, g, grad, feat, out_e):
+        _check(self.lib.gaib_sddmm(self.h, g.h, grad.shape[1], _ptr(grad), _ptr(feat), _ptr(out_e)),
+               "gaib_sddmm")
+
+    def gat_softmax_bwd_alpha(self, g, feat, norm, norm_grad, temp, scores, lgrad, rgrad, eps: float = 0.2):
+        _check(self.lib.gaib_gat_softmax_bwd_alpha(self.h, g.h, feat.shape[1], _ptr(feat), _ptr(norm),
+                                                   _ptr(norm_grad), _ptr(temp), eps, _ptr(scores),
+                                                   _ptr(lgrad), _ptr(rgrad)), "gaib_gat_softmax_bwd_alpha")
+
+    def edge_transpose(self, g, in_e, out_e):
+        _check(self.lib.gaib_edge_transpose(self.h, g.h, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")
+
+    # ---- dense ----------------------------------------------------------------------------
+    def sgemm(self, A, B, Cm, transA=False, transB=False, accum=False):
+        """row-major C[M x N] (=|+=) op(A) . op(B); shapes follow the reference's matmul()."""
+        M, N = Cm.shape
+        K = A.shape[0] if transA else A.shape[1]
+        _check(self.lib.gaib_sgemm(self.h, int(transA), int(transB), M, N, K, _ptr(A), _ptr(B),
+                                   int(accum), _ptr(Cm)), "gaib_sgemm")
+        return Cm
+
+    # ---- elementwise / loss / optimizer -----------------------------------------------------
+    def relu(self, x, out):
+        _check(self.lib.gaib_relu(self.h, x.numel(), _ptr(x), _ptr(out)), "gaib_relu")
+
+    def d_relu(self, grad, data, out):
+        _check(self.lib.gaib_d_relu(self.h, grad.numel(), _ptr(grad), _ptr(data), _ptr(out)), "gaib_d_relu")
+
+    def dropout(self, x, masks, out, rate: float, seed: int):
+        scale = 1.0 / (1.0 - rate)
+        _check(self.lib.gaib_dropout(self.h, x.numel(), scale, rate, seed, _ptr(x), _ptr(masks), _ptr(out)),
+               "gaib_dropout")
+
+    def d_dropout(self, x, masks, out, rate: float):
+        scale = 1.0 / (1.0 - rate)
+        _check(self.lib.gaib_d_dropout(self.h, x.numel(), scale, _ptr(x), _ptr(masks), _ptr(out)),
+               "gaib_d_dropout")
+
+    def softmax_xent(self, logits, labels, loss, probs, begin, end, masks=None):
+        _check(self.lib.gaib_softmax_xent(self.h, logits.shape[1], begin, end, _ptr(logits), _ptr(masks),
+                                          _ptr(labels), _ptr(loss), _ptr(probs)), "gaib_softmax_xent")
+
+    def d_softmax_xent(self, probs, labels, diff, begin, end, masks=None):
+        _check(self.lib.gaib_d_softmax_xent(self.h, probs.shape[1], begin, end, _ptr(masks), _ptr(labels),
+                                            _ptr(probs), _ptr(diff)), "gaib_d_softmax_xent")
+
+    def masked_avg_loss(self, loss, begin, end, masks=None) -> float:
+        r = C.c_float()
+        _check(self.lib.gaib_masked_avg_loss(self.h, begin, end, _ptr(masks), _ptr(loss), C.byref(r)),
+               "gaib_masked_avg_loss")
+        return r.value
+
+    def masked_accuracy_single(self, preds, labels, begin, end, masks=None) -> float:
+        r = C.c_float()
+        _check(self.lib.gaib_masked_accuracy_single(self.h, begin, end, preds.shape[1], _ptr(masks),
+                                                    _ptr(preds), _ptr(labels), C.byref(r)),
+               "gaib_masked_accuracy_single")
+        return r.value
+
+    def l2norm(self, x, out):
+        _check(self.lib.gaib_l2norm(self.h, x.shape[0], x.shape[1], _ptr(x), _ptr(out)), "gaib_l2norm")
+
+    def d_l2norm(self, feat, grad, out):
+        _check(self.lib.gaib_d_l2norm(self.h, feat.shape[0], feat.shape[1], _ptr(feat), _ptr(grad), _ptr(out)),
+               "gaib_d_l2norm")
+
+    def adam_step(self, dW, W, m, v, alpha, b1_t, b2_t, b1=0.9, b2=0.999, eps=1e-8):
+        _check(self.lib.gaib_adam_step(self.h, W.numel(), _ptr(dW), _ptr(W), _ptr(m), _ptr(v), alpha, b1, b2,
+                                       b1_t, b2_t, eps), "gaib_adam_step")
+
+    def gather_rows(self, idx, x, out):
+        _check(self.lib.gaib_gather_rows(self.h, idx.numel(), _ptr(idx), x.shape[1], _ptr(x), _ptr(out)),
+               "gaib_gather_rows")
+
+
+class Graph:
+    """gaib_graph: CSR resident in HBM.  rowptr: int64 or int32/uint32 tensor/array [nv+1];
+    colidx: int32/uint32 [ne].  Host (numpy / cpu tensor) or device (cuda tensor) sources."""
+
+    def __init__(self, ctx: Context, rowptr=None, colidx=None, ncols: int | None = None, _handle=None):
+        import numpy as np
+        import torch
+
+        self.ctx = ctx
+        self.lib = ctx.lib
+        if _handle is not None:
+            self.h = _handle
+            return
+        if isinstance(rowptr, np.ndarray):
+            rowptr = torch.from_numpy(np.ascontiguousarray(rowptr))
+        if isinstance(colidx, np.ndarray):
+            colidx = torch.from_numpy(np.ascontiguousarray(colidx.view(np.int32) if colidx.dtype == np.uint32 else colidx))
+        assert rowptr.dtype in (torch.int64, torch.int32), rowptr.dtype
+        assert colidx.dtype == torch.int32, colidx.dtype
+        assert rowptr.is_cuda == colidx.is_cuda or colidx.numel() == 0
+        rowptr = rowptr.contiguous()
+        colidx = colidx.contiguous()
+        nv = rowptr.numel() - 1
+        ne = colidx.numel()
+        bits = 64 if rowptr.dtype == torch.int64 else 32
+        h = C.c_void_p()
+        if ncols is None:
+            rc = self.lib.gaib_graph_create(ctx.h, nv, ne, _ptr(rowptr), bits, _ptr(colidx),
+                                            int(rowptr.is_cuda), C.byref(h))
+        else:
+            rc = self.lib.gaib_graph_create_rect(ctx.h, nv, ncols, ne, _ptr(rowptr), bits, _ptr(colidx),
+                                                 int(rowptr.is_cuda), C.byref(h))
+        _check(rc, "gaib_graph_create")
+        self.h = h
+
+    @property
+    def nv(self) -> int:
+        return self.lib.gaib_graph_nv(self.h)
+
+    @property
+    def ne(self) -> int:
+        return self.lib.gaib_graph_ne(self.h)
+
+    def add_selfloop(self) -> "Graph":
+        h = C.c_void_p()
+        _check(self.lib.gaib_graph_add_selfloop(self.ctx.h, self.h, C.byref(h)), "gaib_graph_add_selfloop")
+        return Graph(self.ctx, _handle=h)
+
+    def compute_vertex_data(self):
+        _check(self.lib.gaib_graph_compute_vertex_data(self.ctx.h, self.h), "gaib_graph_compute_vertex_data")
+
+    def compute_edge_data(self):
+        _check(self.lib.gaib_graph_compute_edge_data(self.ctx.h, self.h), "gaib_graph_compute_edge_data")
+
+    def set_vertex_norm(self, row_vdata, col_vdata, col_inv_deg):
+        """rectangular (partitioned) graphs: normalisers come from the GLOBAL degrees."""
+        _check(self.lib.gaib_graph_set_vertex_norm(self.ctx.h, self.h, _ptr(row_vdata), _ptr(col_vdata),
+                                                   _ptr(col_inv_deg)), "gaib_graph_set_vertex_norm")
+
+    def _dev_tensor(self, ptr, n, dtype):
+        """copy a device array owned by the graph into a fresh torch tensor"""
+        import torch
+
+        out = torch.empty(n, dtype=dtype, device=f"cuda:{self.ctx.device}")
+        if n:
+            _check(self.lib.gaib_memcpy_d2d(self.ctx.h, _ptr(out), ptr, out.numel() * out.element_size()),
+                   "gaib_memcpy_d2d")
+        self.ctx.sync()
+        return out
+
+    def rowptr(self):
+        import torch
+        return self._dev_tensor(self.lib.gaib_graph_rowptr(self.h), self.nv + 1, torch.int64)
+
+    def colidx(self):
+        import torch
+        return self._dev_tensor(self.lib.gaib_graph_colidx(self.h), self.ne, torch.int32)
+
+    def vertex_data(self):
+        import torch
+        return self._dev_tensor(self.lib.gaib_graph_vertex_data(self.h), self.nv, torch.float32)
+
+    def edge_data(self):
+        import torch
+        return self._dev_tensor(self.lib.gaib_graph_edge_data(self.h), self.ne, torch.float32)
+
+    def device_bytes(self) -> int:
+        return self.lib.gaib_graph_device_bytes(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gaib_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

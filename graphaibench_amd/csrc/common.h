@@ -1,0 +1,102 @@
+// common.h -- internal definitions shared by the HIP translation units behind include/gaib.h.
+// gfx950 (MI355X / CDNA4) only: wave64, 256 CUs in 8 XCDs, 160 KB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <string.h>
+#include "gaib.h"
+
+#define GAIB_WAVE 64
+
+void gaib_set_error(const char* fmt, ...);
+
+#define GAIB_HIP(call)                                                                    \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      gaib_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return GAIB_ERR_HIP;                                                                \
+    }                                                                                     \
+  } while (0)
+
+#define GAIB_CHECK(cond, ...)       \
+  do {                              \
+    if (!(cond)) {                  \
+      gaib_set_error(__VA_ARGS__);  \
+      return GAIB_ERR_INVALID;      \
+    }                               \
+  } while (0)
+
+#define GAIB_TRY(call)         \
+  do {                         \
+    int rc_ = (call);          \
+    if (rc_ != GAIB_OK) return rc_; \
+  } while (0)
+
+#define GAIB_LAUNCH_CHECK() GAIB_HIP(hipGetLastError())
+
+struct gaib_ctx {
+  int device;
+  hipStream_t stream;
+  int num_cus;
+  // growable scratch (split-K partials, per-vertex scores, ...); never shrinks
+  void* ws;
+  size_t ws_bytes;
+  // tuning knobs
+  int spmm_heavy_threshold;  // rows with more edges go to the workgroup-per-row kernel
+  int spmm_variant;          // 0 = auto, see spmm.hip
+  int spmm_xcd_swizzle;      // 1 = consecutive row blocks share an XCD
+  int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8
+  int spmm_addr_mode;        // 0 = auto (buffer loads when the table is < 4 GB), 2 = force 64-bit global
+  int sgemm_variant;         // 0 = auto
+  int gat_fast;              // reserved
+};
+
+int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes);
+
+struct gaib_graph {
+  int device;
+  int64_t nv, ne;
+  int64_t nc;        // number of columns == rows of the feature table (nv unless rectangular)
+  int64_t* rowptr;   // [nv+1]
+  uint32_t* colidx;  // [ne]
+  float* vdata;      // [nv] deg^-1/2            (compute_vertex_data)
+  float* edata;      // [ne] 1/(sqrt d_i sqrt d_j) (compute_edge_data)
+  float* inv_deg;    // [nv] (float)(1.0/(float)deg)            lazily
+  float* col_vdata;    // [nc] set_vertex_norm only (else the column side uses vdata)
+  float* col_inv_deg;  // [nc] set_vertex_norm only (else inv_deg)
+  float* w_gcn;      // [ne] vdata[i]*vdata[col]                lazily
+  float* w_mean_t;   // [ne] inv_deg[col]                       lazily
+  uint32_t* rev;     // [ne] index of the reverse edge          lazily
+  // rows with degree > heavy_thr (built for the threshold the list was made with)
+  uint32_t* heavy_rows;
+  int64_t n_heavy;
+  int heavy_thr;
+  int64_t max_degree;
+  int64_t dev_bytes;
+};
+
+int gaib_graph_ensure_inv_deg(gaib_ctx* ctx, gaib_graph* g);
+int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g);
+int gaib_graph_ensure_w_mean_t(gaib_ctx* ctx, gaib_graph* g);
+int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g);
+int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr);
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// wave-level helpers -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}

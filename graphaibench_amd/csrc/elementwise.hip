@@ -1,0 +1,408 @@
+// elementwise.hip -- relu / dropout / loss / l2norm / adam / row gather for gfx950.
+// All of these are HBM-streaming: 16 B per lane, grid capped at 2048 workgroups with a
+// grid-stride loop (cdna guide, Guideline 11/13).
+//
+// replaces relu_gpu / d_relu_gpu / dropout_gpu / d_dropout_gpu / init_const_gpu /
+// softmax_cross_entropy_gpu / d_softmax_cross_entropy_gpu / masked_avg_loss_gpu /
+// masked_accuracy_single / l2norm / d_l2norm (src/utilities/math_functions.cu:12-14,
+// 114-146, 158-196, 242-268, 516-564, 749-761, 886-942) and adam::update_gpu
+// (src/utilities/optimizer.cu:5-36).
+#include "common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+inline unsigned stream_grid(int64_t n_items, int block) {
+  int64_t b = cdiv64(n_items > 0 ? n_items : 1, block);
+  return (unsigned)(b < 2048 ? b : 2048);
+}
+
+__global__ void fill_kernel(int64_t n, float v, float* x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = v;
+}
+
+// relu_cpu / relu_kernel: max(x, 0)    (math_functions.cpp:442-451; .cu:242)
+__global__ void relu_kernel(int64_t n, const float* in, float* out, int vec_ok) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec_ok) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += stride) {
+      f4 v = reinterpret_cast<const f4*>(in)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      reinterpret_cast<f4*>(out)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + tid; i < n; i += stride) out[i] = in[i] > 0.f ? in[i] : 0.f;
+  } else {
+    for (int64_t i = tid; i < n; i += stride) out[i] = in[i] > 0.f ? in[i] : 0.f;
+  }
+}
+
+// d_relu: out = data > 0 ? in : 0     (math_functions.cpp:453-463; .cu:255)
+__global__ void d_relu_kernel(int64_t n, const float* in, const float* data, float* out, int vec_ok) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec_ok) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += stride) {
+      f4 g = reinterpret_cast<const f4*>(in)[i];
+      f4 d = reinterpret_cast<const f4*>(data)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = d[k] > 0.f ? g[k] : 0.f;
+      reinterpret_cast<f4*>(out)[i] = g;
+    }
+    for (int64_t i = (n4 << 2) + tid; i < n; i += stride) out[i] = data[i] > 0.f ? in[i] : 0.f;
+  } else {
+    for (int64_t i = tid; i < n; i += stride) out[i] = data[i] > 0.f ? in[i] : 0.f;
+  }
+}
+
+// counter-based uniform in [0,1): splitmix64 of (seed, index).  The reference draws from
+// cuRAND XORWOW (GPU, math_functions.cu:123-132) or boost mt19937 (CPU, :390-429); masks are
+// therefore not comparable across implementations, only their statistics and the replay.
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+// dropout_kernel: mask = rand > p; out = in * mask * scale   (math_functions.cu:114-121)
+__global__ void dropout_kernel(int64_t n, float scale, float rate, uint64_t seed, const float* in,
+                               uint8_t* masks, float* out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint8_t m = u01(seed, (uint64_t)i) > rate ? 1 : 0;
+    masks[i] = m;
+    out[i] = in[i] * (float)m * scale;
+  }
+}
+__global__ void d_dropout_kernel(int64_t n, float scale, const float* in, const uint8_t* masks,
+                                 float* out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = in[i] * (float)masks[i] * scale;
+}
+
+// softmax + cross entropy per vertex (softmax_loss_layer.cpp:4-21; math_functions.cpp:485-494,
+// 533-544).  One wave per vertex, classes across lanes (num_cls is small: 7..172).
+__global__ __launch_bounds__(256) void softmax_xent_kernel(int num_cls, int64_t begin, int64_t end,
+                                                           const float* in, const uint8_t* masks,
+                                                           const uint8_t* labels, float* loss,
+                                                           float* out) {
+  const int64_t i = begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= end) return;
+  if (masks && masks[i] != 1) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = in + i * (int64_t)num_cls;
+  float* y = out + i * (int64_t)num_cls;
+  float mx = -INFINITY;
+  for (int c = lane; c < num_cls; c += 64) mx = fmaxf(mx, x[c]);
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int c = lane; c < num_cls; c += 64) den += expf(x[c] - mx);
+  den = wave_sum(den);
+  const int lab = labels[i];
+  float pl = 0.f;
+  for (int c = lane; c < num_cls; c += 64) {
+    const float p = expf(x[c] - mx) / den;
+    y[c] = p;
+    if (c == lab) pl = p;
+  }
+  pl = wave_sum(pl);  // exactly one lane holds it
+  if (lane == 0) loss[i] = (pl == 0.0f) ? -logf(1e-10f) : -logf(pl);
+}
+
+// (p - onehot) / (end - begin)   (softmax_loss_layer.cpp:23-37, Q8)
+__global__ void d_softmax_xent_kernel(int num_cls, int64_t begin, int64_t end,
+                                      const uint8_t* masks, const uint8_t* labels,
+                                      const float* out, float* diff) {
+  const int64_t n = (end - begin) * num_cls;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double inv = (double)(end - begin);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const int64_t i = begin + t / num_cls;
+    const int j = (int)(t % num_cls);
+    if (masks && masks[i] != 1) continue;
+    const float pred = out[i * num_cls + j];
+    diff[i * num_cls + j] = (float)(((double)pred - (labels[i] == j ? 1.0 : 0.0)) / inv);
+  }
+}
+
+// two-level deterministic masked reductions ------------------------------------------------
+// partial[b] = {sum, count} over a strip; final sum over b in order on the host side of the
+// C ABI (nblocks <= 1024 values).
+__global__ __launch_bounds__(256) void masked_loss_partial_kernel(int64_t begin, int64_t end,
+                                                                  const uint8_t* masks,
+                                                                  const float* loss, float* part) {
+  __shared__ float ssum[4], scnt[4];
+  float s = 0.f, c = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride)
+    if (!masks || masks[i] == 1) {
+      s += loss[i];
+      c += 1.f;
+    }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    ssum[threadIdx.x >> 6] = s;
+    scnt[threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    part[2 * blockIdx.x + 1] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+  }
+}
+
+// argmax (first maximum, math_functions.cpp:127-137) == label ?   one thread per vertex
+__global__ __launch_bounds__(256) void masked_acc_partial_kernel(int64_t begin, int64_t end,
+                                                                 int num_cls, const uint8_t* masks,
+                                                                 const float* preds,
+                                                                 const uint8_t* labels, float* part) {
+  __shared__ float ssum[4], scnt[4];
+  float s = 0.f, c = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride)
+    if (!masks || masks[i] == 1) {
+      const float* p = preds + i * (int64_t)num_cls;
+      int best = -1;
+      float mx = -INFINITY;
+      for (int j = 0; j < num_cls; ++j)
+        if (p[j] > mx) {
+          mx = p[j];
+          best = j;
+        }
+      if (best == (int)labels[i]) s += 1.f;
+      c += 1.f;
+    }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    ssum[threadIdx.x >> 6] = s;
+    scnt[threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    part[2 * blockIdx.x + 1] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+  }
+}
+
+// l2norm_layer forward/backward (src/layers/l2norm_layer.cpp:19-64), one wave per row
+__global__ __launch_bounds__(256) void l2norm_kernel(int64_t n, int dim, const float* in, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = in + i * (int64_t)dim;
+  float s = 0.f;
+  for (int c = lane; c < dim; c += 64) s += x[c] * x[c];
+  s = wave_sum(s);
+  s = s < 1.0e-12f ? 1.0e-12f : s;
+  s = sqrtf(s);
+  for (int c = lane; c < dim; c += 64) out[i * (int64_t)dim + c] = x[c] / s;
+}
+__global__ __launch_bounds__(256) void d_l2norm_kernel(int64_t n, int dim, const float* fin,
+                                                       const float* gin, float* gout) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = fin + i * (int64_t)dim;
+  const float* g = gin + i * (int64_t)dim;
+  float s2 = 0.f, c0 = 0.f;
+  for (int c = lane; c < dim; c += 64) {
+    s2 += x[c] * x[c];
+    c0 -= x[c] * g[c];
+  }
+  s2 = wave_sum(s2);
+  c0 = wave_sum(c0);
+  s2 = s2 < 1.0e-12f ? 1.0e-12f : s2;
+  const float c1 = powf(s2, -1.5f);
+  for (int c = lane; c < dim; c += 64)
+    gout[i * (int64_t)dim + c] = x[c] * c0 * c1 + g[c] * s2 * c1;
+}
+
+// adam::update (src/utilities/optimizer.cpp:22-35; update_kernel optimizer.cu:5-15):
+// eps inside the sqrt; the caller advances b1_t/b2_t once per call.
+__global__ void adam_kernel(int64_t n, const float* dW, float* W, float* m, float* v, float alpha,
+                            float b1, float b2, float b1_t, float b2_t, float eps) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float g = dW[i];
+    const float mt = b1 * m[i] + (1.0f - b1) * g;
+    const float vt = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mt;
+    v[i] = vt;
+    W[i] -= alpha * (mt / (1.0f - b1_t)) / sqrtf((vt / (1.0f - b2_t)) + eps);
+  }
+}
+
+// out[k,:] = in[idx[k],:]   (halo send-buffer packing)
+__global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n_idx, const int64_t* idx, int len,
+                                                          const float* in, float* out) {
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_idx) return;
+  const int lane = threadIdx.x & 63;
+  const float* src = in + idx[k] * (int64_t)len;
+  float* dst = out + k * (int64_t)len;
+  for (int c = lane; c < len; c += 64) dst[c] = src[c];
+}
+
+int finish_partial(gaib_ctx* ctx, int nblocks, float* d_part, float* h_result) {
+  float h[2 * 1024];
+  GAIB_HIP(hipMemcpyAsync(h, d_part, sizeof(float) * 2 * nblocks, hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  float s = 0.f, c = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    s += h[2 * b];
+    c += h[2 * b + 1];
+  }
+  *h_result = c > 0.f ? s / c : 0.f;
+  return GAIB_OK;
+}
+
+}  // namespace
+
+extern "C" int gaib_fill_f32(gaib_ctx* ctx, int64_t n, float value, float* d_x) {
+  GAIB_CHECK(ctx && (d_x || n == 0), "gaib_fill_f32: NULL argument");
+  if (n <= 0) return GAIB_OK;
+  fill_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, value, d_x);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_relu(gaib_ctx* ctx, int64_t n, const float* d_in, float* d_out) {
+  GAIB_CHECK(ctx && ((d_in && d_out) || n == 0), "gaib_relu: NULL argument");
+  if (n <= 0) return GAIB_OK;
+  const int vec_ok = ((((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0);
+  relu_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, ctx->stream>>>(n, d_in, d_out, vec_ok);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_d_relu(gaib_ctx* ctx, int64_t n, const float* d_in_diff, const float* d_data,
+                           float* d_out_diff) {
+  GAIB_CHECK(ctx && ((d_in_diff && d_data && d_out_diff) || n == 0), "gaib_d_relu: NULL argument");
+  if (n <= 0) return GAIB_OK;
+  const int vec_ok = ((((uintptr_t)d_in_diff | (uintptr_t)d_data | (uintptr_t)d_out_diff) & 15) == 0);
+  d_relu_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, ctx->stream>>>(n, d_in_diff, d_data,
+                                                                     d_out_diff, vec_ok);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_dropout(gaib_ctx* ctx, int64_t n, float scale, float drop_rate, uint64_t seed,
+                            const float* d_in, uint8_t* d_masks, float* d_out) {
+  GAIB_CHECK(ctx && ((d_in && d_masks && d_out) || n == 0), "gaib_dropout: NULL argument");
+  GAIB_CHECK(drop_rate >= 0.f && drop_rate < 1.f, "gaib_dropout: rate must be in [0,1)");
+  if (n <= 0) return GAIB_OK;
+  dropout_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, scale, drop_rate, seed, d_in,
+                                                               d_masks, d_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_d_dropout(gaib_ctx* ctx, int64_t n, float scale, const float* d_in,
+                              const uint8_t* d_masks, float* d_out) {
+  GAIB_CHECK(ctx && ((d_in && d_masks && d_out) || n == 0), "gaib_d_dropout: NULL argument");
+  if (n <= 0) return GAIB_OK;
+  d_dropout_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, scale, d_in, d_masks, d_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                                 const float* d_in, const uint8_t* d_masks, const uint8_t* d_labels,
+                                 float* d_loss, float* d_out) {
+  GAIB_CHECK(ctx && d_in && d_labels && d_loss && d_out, "gaib_softmax_xent: NULL argument");
+  GAIB_CHECK(num_cls > 0 && begin >= 0 && end >= begin, "gaib_softmax_xent: bad range");
+  if (end == begin) return GAIB_OK;
+  softmax_xent_kernel<<<(unsigned)cdiv64(end - begin, 4), 256, 0, ctx->stream>>>(
+      num_cls, begin, end, d_in, d_masks, d_labels, d_loss, d_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_d_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                                   const uint8_t* d_masks, const uint8_t* d_labels,
+                                   const float* d_out, float* d_diff) {
+  GAIB_CHECK(ctx && d_labels && d_out && d_diff, "gaib_d_softmax_xent: NULL argument");
+  GAIB_CHECK(num_cls > 0 && begin >= 0 && end >= begin, "gaib_d_softmax_xent: bad range");
+  if (end == begin) return GAIB_OK;
+  d_softmax_xent_kernel<<<stream_grid((end - begin) * num_cls, 256), 256, 0, ctx->stream>>>(
+      num_cls, begin, end, d_masks, d_labels, d_out, d_diff);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_masked_avg_loss(gaib_ctx* ctx, int64_t begin, int64_t end,
+                                    const uint8_t* d_masks, const float* d_loss, float* h_result) {
+  GAIB_CHECK(ctx && d_loss && h_result, "gaib_masked_avg_loss: NULL argument");
+  GAIB_CHECK(begin >= 0 && end >= begin, "gaib_masked_avg_loss: bad range");
+  *h_result = 0.f;
+  if (end == begin) return GAIB_OK;
+  const int nblocks = (int)stream_grid(end - begin, 256) > 1024 ? 1024 : (int)stream_grid(end - begin, 256);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * 1024));
+  masked_loss_partial_kernel<<<nblocks, 256, 0, ctx->stream>>>(begin, end, d_masks, d_loss,
+                                                               (float*)ctx->ws);
+  GAIB_LAUNCH_CHECK();
+  return finish_partial(ctx, nblocks, (float*)ctx->ws, h_result);
+}
+
+extern "C" int gaib_masked_accuracy_single(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                                           const uint8_t* d_masks, const float* d_preds,
+                                           const uint8_t* d_labels, float* h_result) {
+  GAIB_CHECK(ctx && d_preds && d_labels && h_result, "gaib_masked_accuracy_single: NULL argument");
+  GAIB_CHECK(begin >= 0 && end >= begin && num_cls > 0, "gaib_masked_accuracy_single: bad range");
+  *h_result = 0.f;
+  if (end == begin) return GAIB_OK;
+  const int nblocks = (int)stream_grid(end - begin, 256) > 1024 ? 1024 : (int)stream_grid(end - begin, 256);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * 1024));
+  masked_acc_partial_kernel<<<nblocks, 256, 0, ctx->stream>>>(begin, end, num_cls, d_masks, d_preds,
+                                                              d_labels, (float*)ctx->ws);
+  GAIB_LAUNCH_CHECK();
+  return finish_partial(ctx, nblocks, (float*)ctx->ws, h_result);
+}
+
+extern "C" int gaib_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_in, float* d_out) {
+  GAIB_CHECK(ctx && ((d_in && d_out) || n == 0), "gaib_l2norm: NULL argument");
+  if (n <= 0 || dim <= 0) return GAIB_OK;
+  l2norm_kernel<<<(unsigned)cdiv64(n, 4), 256, 0, ctx->stream>>>(n, dim, d_in, d_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_d_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_feat_in,
+                             const float* d_grad_in, float* d_grad_out) {
+  GAIB_CHECK(ctx && ((d_feat_in && d_grad_in && d_grad_out) || n == 0), "gaib_d_l2norm: NULL argument");
+  if (n <= 0 || dim <= 0) return GAIB_OK;
+  d_l2norm_kernel<<<(unsigned)cdiv64(n, 4), 256, 0, ctx->stream>>>(n, dim, d_feat_in, d_grad_in,
+                                                                   d_grad_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_adam_step(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, float* d_m,
+                              float* d_v, float alpha, float b1, float b2, float b1_t, float b2_t,
+                              float eps) {
+  GAIB_CHECK(ctx && ((d_dW && d_W && d_m && d_v) || n == 0), "gaib_adam_step: NULL argument");
+  if (n <= 0) return GAIB_OK;
+  adam_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, d_dW, d_W, d_m, d_v, alpha, b1, b2,
+                                                            b1_t, b2_t, eps);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_idx, int len,
+                                const float* d_in, float* d_out) {
+  GAIB_CHECK(ctx && ((d_idx && d_in && d_out) || n_idx == 0), "gaib_gather_rows: NULL argument");
+  if (n_idx <= 0 || len <= 0) return GAIB_OK;
+  gather_rows_kernel<<<(unsigned)cdiv64(n_idx, 4), 256, 0, ctx->stream>>>(n_idx, d_idx, len, d_in,
+                                                                          d_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}

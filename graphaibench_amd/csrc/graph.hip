@@ -1,0 +1,381 @@
+// graph.hip -- device half of LearningGraph (include/gnn/lgraph.h:20-277 in the reference):
+// CSR upload, add_selfloop, normalisers, and the once-per-graph schedules the aggregation
+// kernels use (heavy-row list, per-edge weights, reverse-edge permutation).
+//
+// HBM layout: rowptr int64[nv+1] | colidx uint32[ne] | vdata/inv_deg fp32[nv] |
+// w_gcn / w_mean_t / edata fp32[ne] | rev uint32[ne].  Everything is streamed linearly by the
+// kernels that use it; only the feature rows are gathered.
+#include "common.h"
+
+namespace {
+
+__global__ void widen_rowptr_kernel(int64_t n, const uint32_t* in, int64_t* out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int64_t)in[i];
+}
+
+// compute_vertex_data: src/gnn/lgraph.cpp:22-34 (kernel: lgraph.cu:6-12)
+__global__ void vertex_data_kernel(int64_t nv, const int64_t* rowptr, float* vd) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  uint32_t deg = (uint32_t)(rowptr[v + 1] - rowptr[v]);
+  float temp = sqrtf((float)deg);
+  vd[v] = (temp == 0.0f) ? 0.0f : (float)(1.0 / (double)temp);
+}
+
+// (float)(1.0 / float(deg)) as sage_aggregator.cpp:18,44 evaluate it
+__global__ void inv_deg_kernel(int64_t nv, const int64_t* rowptr, float* inv) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  uint32_t deg = (uint32_t)(rowptr[v + 1] - rowptr[v]);
+  inv[v] = (float)(1.0 / (double)(float)deg);
+}
+
+// one wave per row; lanes stride the row's edges
+template <int KIND>  // 0: edge_data (lgraph.cpp:6-20)  1: w_gcn = vd[i]*vd[j] (gcn_aggregator.cpp:61-66)
+__global__ __launch_bounds__(256) void edge_weight_kernel(int64_t nv, const int64_t* rowptr,
+                                                          const uint32_t* col, const float* vd,
+                                                          const float* cvd, float* ew) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  if (KIND == 0) {
+    float c_i = sqrtf((float)(uint32_t)(e1 - e0));
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      uint32_t j = col[e];
+      float c_j = sqrtf((float)(uint32_t)(rowptr[j + 1] - rowptr[j]));
+      ew[e] = (c_i == 0.0f || c_j == 0.0f) ? 0.0f : (float)(1.0 / (double)(c_i * c_j));
+    }
+  } else {
+    float a = vd[row];
+    for (int64_t e = e0 + lane; e < e1; e += 64) ew[e] = a * cvd[col[e]];
+  }
+}
+
+__global__ void gather_by_col_kernel(int64_t ne, const uint32_t* col, const float* pv, float* ew) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) ew[e] = pv[col[e]];
+}
+
+// reverse-edge permutation: rev[e] = position of (dst -> src) in row dst
+// (binary search as math_functions.cpp:32-44,60-73; graph_operations.h:340-361)
+__global__ __launch_bounds__(256) void rev_kernel(int64_t nv, const int64_t* rowptr,
+                                                  const uint32_t* col, uint32_t* rev, int* bad) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    uint32_t dst = col[e];
+    int64_t l = rowptr[dst], r = rowptr[dst + 1] - 1, idx = -1;
+    while (r >= l) {
+      int64_t mid = l + (r - l) / 2;
+      uint32_t v = col[mid];
+      if (v == (uint32_t)row) { idx = mid; break; }
+      if (v < (uint32_t)row) l = mid + 1;
+      else r = mid - 1;
+    }
+    if (idx < 0) { *bad = 1; rev[e] = (uint32_t)e; }
+    else rev[e] = (uint32_t)idx;
+  }
+}
+
+__global__ void heavy_rows_kernel(int64_t nv, const int64_t* rowptr, int thr, uint32_t* list,
+                                  unsigned long long* count, unsigned long long* maxdeg) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  int64_t deg = rowptr[v + 1] - rowptr[v];
+  if (deg > thr) {
+    unsigned long long p = atomicAdd(count, 1ull);
+    if (list) list[p] = (uint32_t)v;
+  }
+  if (maxdeg) atomicMax(maxdeg, (unsigned long long)deg);
+}
+
+// add_selfloop (include/gnn/lgraph.h:185-218): row i keeps its sorted order with i inserted
+// after the last entry <= i; new rowptr[i] = rowptr[i] + i.
+__global__ __launch_bounds__(256) void selfloop_kernel(int64_t nv, const int64_t* rowptr,
+                                                       const uint32_t* col, int64_t* rowptr_out,
+                                                       uint32_t* col_out) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row > nv) return;
+  const int lane = threadIdx.x & 63;
+  if (row == nv) {
+    if (lane == 0) rowptr_out[nv] = rowptr[nv] + nv;
+    return;
+  }
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  int cnt = 0;
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    uint32_t dst = col[e];
+    bool after = dst > (uint32_t)row;
+    col_out[e + row + (after ? 1 : 0)] = dst;
+    cnt += after ? 0 : 1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) {
+    col_out[e0 + row + cnt] = (uint32_t)row;
+    rowptr_out[row] = e0 + row;
+  }
+}
+
+inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)cdiv64(n > 0 ? n : 1, block)); }
+
+int new_graph(int64_t nv, int64_t ne, int device, gaib_graph** out) {
+  gaib_graph* g = new gaib_graph();
+  memset(g, 0, sizeof(*g));
+  g->device = device;
+  g->nv = nv;
+  g->nc = nv;
+  g->ne = ne;
+  g->heavy_thr = -1;
+  g->max_degree = -1;
+  GAIB_HIP(hipMalloc(&g->rowptr, sizeof(int64_t) * (size_t)(nv + 1)));
+  GAIB_HIP(hipMalloc(&g->colidx, sizeof(uint32_t) * (size_t)(ne > 0 ? ne : 1)));
+  g->dev_bytes = sizeof(int64_t) * (nv + 1) + sizeof(uint32_t) * ne;
+  *out = g;
+  return GAIB_OK;
+}
+
+}  // namespace
+
+extern "C" int gaib_graph_create(gaib_ctx* ctx, int64_t nv, int64_t ne, const void* rowptr,
+                                 int rowptr_bits, const uint32_t* colidx, int src_on_device,
+                                 gaib_graph** out) {
+  return gaib_graph_create_rect(ctx, nv, nv, ne, rowptr, rowptr_bits, colidx, src_on_device, out);
+}
+
+extern "C" int gaib_graph_set_vertex_norm(gaib_ctx* ctx, gaib_graph* g, const float* d_row_vdata,
+                                          const float* d_col_vdata, const float* d_col_inv_deg) {
+  GAIB_CHECK(ctx && g && d_col_vdata && d_col_inv_deg, "gaib_graph_set_vertex_norm: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const size_t nc = (size_t)(g->nc > 0 ? g->nc : 1), nv = (size_t)(g->nv > 0 ? g->nv : 1);
+  if (!g->col_vdata) {
+    GAIB_HIP(hipMalloc(&g->col_vdata, sizeof(float) * nc));
+    GAIB_HIP(hipMalloc(&g->col_inv_deg, sizeof(float) * nc));
+    g->dev_bytes += 2 * sizeof(float) * g->nc;
+  }
+  GAIB_HIP(hipMemcpyAsync(g->col_vdata, d_col_vdata, sizeof(float) * g->nc, hipMemcpyDeviceToDevice, ctx->stream));
+  GAIB_HIP(hipMemcpyAsync(g->col_inv_deg, d_col_inv_deg, sizeof(float) * g->nc, hipMemcpyDeviceToDevice, ctx->stream));
+  if (!g->vdata) {
+    GAIB_HIP(hipMalloc(&g->vdata, sizeof(float) * nv));
+    g->dev_bytes += sizeof(float) * g->nv;
+  }
+  if (d_row_vdata)
+    GAIB_HIP(hipMemcpyAsync(g->vdata, d_row_vdata, sizeof(float) * g->nv, hipMemcpyDeviceToDevice, ctx->stream));
+  else
+    vertex_data_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->vdata);
+  GAIB_LAUNCH_CHECK();
+  // cached per-edge weights derive from these
+  if (g->w_gcn) {
+    edge_weight_kernel<1><<<grid1d(g->nv, 4), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx,
+                                                                     g->vdata, g->col_vdata, g->w_gcn);
+    GAIB_LAUNCH_CHECK();
+  }
+  if (g->w_mean_t) {
+    gather_by_col_kernel<<<grid1d(g->ne, 256), 256, 0, ctx->stream>>>(g->ne, g->colidx, g->col_inv_deg,
+                                                                      g->w_mean_t);
+    GAIB_LAUNCH_CHECK();
+  }
+  return GAIB_OK;
+}
+
+extern "C" int gaib_graph_create_rect(gaib_ctx* ctx, int64_t nv, int64_t nc, int64_t ne,
+                                      const void* rowptr, int rowptr_bits, const uint32_t* colidx,
+                                      int src_on_device, gaib_graph** out) {
+  GAIB_CHECK(ctx && out && rowptr, "gaib_graph_create: NULL argument");
+  GAIB_CHECK(nc >= nv && nc < (int64_t)1 << 32, "gaib_graph_create_rect: need nv <= nc < 2^32");
+  GAIB_CHECK(nv >= 0 && ne >= 0, "gaib_graph_create: negative size");
+  GAIB_CHECK(nv < (int64_t)1 << 31, "gaib_graph_create: nv must be < 2^31");
+  GAIB_CHECK(ne < (int64_t)1 << 32, "gaib_graph_create: ne must be < 2^32 (edge ids are uint32)");
+  GAIB_CHECK(rowptr_bits == 32 || rowptr_bits == 64, "gaib_graph_create: rowptr_bits must be 32 or 64");
+  GAIB_CHECK(ne == 0 || colidx, "gaib_graph_create: colidx is NULL");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  gaib_graph* g = nullptr;
+  GAIB_TRY(new_graph(nv, ne, ctx->device, &g));
+  g->nc = nc;
+  hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (rowptr_bits == 64) {
+    GAIB_HIP(hipMemcpyAsync(g->rowptr, rowptr, sizeof(int64_t) * (nv + 1), kind, ctx->stream));
+  } else {
+    uint32_t* tmp = nullptr;
+    GAIB_HIP(hipMalloc(&tmp, sizeof(uint32_t) * (nv + 1)));
+    GAIB_HIP(hipMemcpyAsync(tmp, rowptr, sizeof(uint32_t) * (nv + 1), kind, ctx->stream));
+    widen_rowptr_kernel<<<grid1d(nv + 1, 256), 256, 0, ctx->stream>>>(nv + 1, tmp, g->rowptr);
+    GAIB_LAUNCH_CHECK();
+    GAIB_HIP(hipStreamSynchronize(ctx->stream));
+    GAIB_HIP(hipFree(tmp));
+  }
+  if (ne > 0)
+    GAIB_HIP(hipMemcpyAsync(g->colidx, colidx, sizeof(uint32_t) * ne, kind, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  // validate the two ends of rowptr (cheap; the kernels trust the rest)
+  int64_t ends[2] = {0, 0};
+  GAIB_HIP(hipMemcpy(&ends[0], g->rowptr, sizeof(int64_t), hipMemcpyDeviceToHost));
+  GAIB_HIP(hipMemcpy(&ends[1], g->rowptr + nv, sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (ends[0] != 0 || ends[1] != ne) {
+    gaib_set_error("gaib_graph_create: rowptr[0]=%lld rowptr[nv]=%lld but ne=%lld",
+                   (long long)ends[0], (long long)ends[1], (long long)ne);
+    gaib_graph_destroy(g);
+    return GAIB_ERR_INVALID;
+  }
+  *out = g;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_graph_destroy(gaib_graph* g) {
+  if (!g) return GAIB_OK;
+  (void)hipSetDevice(g->device);
+  void* ptrs[] = {g->rowptr, g->colidx,   g->vdata, g->edata,      g->inv_deg,  g->col_vdata,
+                  g->col_inv_deg, g->w_gcn, g->w_mean_t, g->rev,   g->heavy_rows};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete g;
+  return GAIB_OK;
+}
+
+extern "C" int64_t gaib_graph_nv(const gaib_graph* g) { return g ? g->nv : -1; }
+extern "C" int64_t gaib_graph_ne(const gaib_graph* g) { return g ? g->ne : -1; }
+extern "C" const int64_t* gaib_graph_rowptr(const gaib_graph* g) { return g ? g->rowptr : nullptr; }
+extern "C" const uint32_t* gaib_graph_colidx(const gaib_graph* g) { return g ? g->colidx : nullptr; }
+extern "C" const float* gaib_graph_vertex_data(const gaib_graph* g) { return g ? g->vdata : nullptr; }
+extern "C" const float* gaib_graph_edge_data(const gaib_graph* g) { return g ? g->edata : nullptr; }
+extern "C" int64_t gaib_graph_device_bytes(const gaib_graph* g) { return g ? g->dev_bytes : -1; }
+
+extern "C" int gaib_graph_add_selfloop(gaib_ctx* ctx, const gaib_graph* g, gaib_graph** out) {
+  GAIB_CHECK(ctx && g && out, "gaib_graph_add_selfloop: NULL argument");
+  GAIB_CHECK(g->nc == g->nv, "gaib_graph_add_selfloop: square graphs only");
+  GAIB_CHECK(g->ne + g->nv < (int64_t)1 << 32, "gaib_graph_add_selfloop: ne+nv must be < 2^32");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  gaib_graph* n = nullptr;
+  GAIB_TRY(new_graph(g->nv, g->ne + g->nv, ctx->device, &n));
+  selfloop_kernel<<<grid1d(g->nv + 1, 4), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx,
+                                                                 n->rowptr, n->colidx);
+  GAIB_LAUNCH_CHECK();
+  *out = n;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_graph_compute_vertex_data(gaib_ctx* ctx, gaib_graph* g) {
+  GAIB_CHECK(ctx && g, "gaib_graph_compute_vertex_data: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (!g->vdata) {
+    GAIB_HIP(hipMalloc(&g->vdata, sizeof(float) * (size_t)(g->nv > 0 ? g->nv : 1)));
+    g->dev_bytes += sizeof(float) * g->nv;
+  }
+  vertex_data_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->vdata);
+  GAIB_LAUNCH_CHECK();
+  // the cached per-edge GCN weights derive from vdata
+  if (g->w_gcn) {
+    edge_weight_kernel<1><<<grid1d(g->nv, 4), 256, 0, ctx->stream>>>(
+        g->nv, g->rowptr, g->colidx, g->vdata, g->col_vdata ? g->col_vdata : g->vdata, g->w_gcn);
+    GAIB_LAUNCH_CHECK();
+  }
+  return GAIB_OK;
+}
+
+extern "C" int gaib_graph_compute_edge_data(gaib_ctx* ctx, gaib_graph* g) {
+  GAIB_CHECK(ctx && g, "gaib_graph_compute_edge_data: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (!g->edata) {
+    GAIB_HIP(hipMalloc(&g->edata, sizeof(float) * (size_t)(g->ne > 0 ? g->ne : 1)));
+    g->dev_bytes += sizeof(float) * g->ne;
+  }
+  GAIB_CHECK(g->nc == g->nv, "gaib_graph_compute_edge_data: square graphs only");
+  edge_weight_kernel<0><<<grid1d(g->nv, 4), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx,
+                                                                   nullptr, nullptr, g->edata);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+int gaib_graph_ensure_inv_deg(gaib_ctx* ctx, gaib_graph* g) {
+  if (g->inv_deg) return GAIB_OK;
+  GAIB_HIP(hipMalloc(&g->inv_deg, sizeof(float) * (size_t)(g->nv > 0 ? g->nv : 1)));
+  g->dev_bytes += sizeof(float) * g->nv;
+  inv_deg_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->inv_deg);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g) {
+  if (g->w_gcn) return GAIB_OK;
+  if (!g->vdata) GAIB_TRY(gaib_graph_compute_vertex_data(ctx, g));
+  GAIB_HIP(hipMalloc(&g->w_gcn, sizeof(float) * (size_t)(g->ne > 0 ? g->ne : 1)));
+  g->dev_bytes += sizeof(float) * g->ne;
+  GAIB_CHECK(g->nc == g->nv || g->col_vdata,
+             "rectangular graph: call gaib_graph_set_vertex_norm before GAIB_W_GCN");
+  edge_weight_kernel<1><<<grid1d(g->nv, 4), 256, 0, ctx->stream>>>(
+      g->nv, g->rowptr, g->colidx, g->vdata, g->col_vdata ? g->col_vdata : g->vdata, g->w_gcn);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+int gaib_graph_ensure_w_mean_t(gaib_ctx* ctx, gaib_graph* g) {
+  if (g->w_mean_t) return GAIB_OK;
+  GAIB_TRY(gaib_graph_ensure_inv_deg(ctx, g));
+  GAIB_HIP(hipMalloc(&g->w_mean_t, sizeof(float) * (size_t)(g->ne > 0 ? g->ne : 1)));
+  g->dev_bytes += sizeof(float) * g->ne;
+  GAIB_CHECK(g->nc == g->nv || g->col_inv_deg,
+             "rectangular graph: call gaib_graph_set_vertex_norm before GAIB_W_MEAN_T");
+  gather_by_col_kernel<<<grid1d(g->ne, 256), 256, 0, ctx->stream>>>(
+      g->ne, g->colidx, g->col_inv_deg ? g->col_inv_deg : g->inv_deg, g->w_mean_t);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g) {
+  if (g->rev) return GAIB_OK;
+  GAIB_CHECK(g->nc == g->nv, "reverse-edge permutation: square graphs only");
+  uint32_t* rev = nullptr;
+  int* bad = nullptr;
+  GAIB_HIP(hipMalloc(&rev, sizeof(uint32_t) * (size_t)(g->ne > 0 ? g->ne : 1)));
+  GAIB_HIP(hipMalloc(&bad, sizeof(int)));
+  GAIB_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+  rev_kernel<<<grid1d(g->nv, 4), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx, rev, bad);
+  GAIB_LAUNCH_CHECK();
+  int hbad = 0;
+  GAIB_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  GAIB_HIP(hipFree(bad));
+  if (hbad) {
+    (void)hipFree(rev);
+    gaib_set_error("graph is not structurally symmetric: a reverse edge is missing "
+                   "(reference asserts, math_functions.cpp:70)");
+    return GAIB_ERR_ASYMMETRIC;
+  }
+  g->rev = rev;
+  g->dev_bytes += sizeof(uint32_t) * g->ne;
+  return GAIB_OK;
+}
+
+int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
+  if (g->heavy_thr == thr) return GAIB_OK;
+  unsigned long long* cnt = nullptr;
+  GAIB_HIP(hipMalloc(&cnt, 2 * sizeof(unsigned long long)));
+  GAIB_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  heavy_rows_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, thr, nullptr,
+                                                                 cnt, cnt + 1);
+  GAIB_LAUNCH_CHECK();
+  unsigned long long h[2] = {0, 0};
+  GAIB_HIP(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  if (g->heavy_rows) {
+    GAIB_HIP(hipFree(g->heavy_rows));
+    g->heavy_rows = nullptr;
+  }
+  g->n_heavy = (int64_t)h[0];
+  g->max_degree = (int64_t)h[1];
+  if (g->n_heavy > 0) {
+    GAIB_HIP(hipMalloc(&g->heavy_rows, sizeof(uint32_t) * (size_t)g->n_heavy));
+    GAIB_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
+    heavy_rows_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, thr,
+                                                                   g->heavy_rows, cnt, nullptr);
+    GAIB_LAUNCH_CHECK();
+    GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  GAIB_HIP(hipFree(cnt));
+  g->heavy_thr = thr;
+  return GAIB_OK;
+}

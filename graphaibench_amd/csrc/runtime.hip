@@ -1,0 +1,148 @@
+// runtime.hip -- context, memory and option entry points of include/gaib.h.
+// Replaces the reference's gpu_context statics (include/gnn/gpu_context.h:4-16,
+// src/utilities/random.cpp:62-80) and the malloc/copy helpers
+// (include/utils/math_functions.hh:161-173, include/utils/cutils.h:193-202).
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void gaib_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* gaib_last_error(void) { return g_err; }
+extern "C" const char* gaib_version(void) { return "graphaibench_amd 0.1 (gfx950)"; }
+
+extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
+  GAIB_CHECK(out != nullptr, "gaib_ctx_create: out is NULL");
+  int ndev = 0;
+  GAIB_HIP(hipGetDeviceCount(&ndev));
+  GAIB_CHECK(device >= 0 && device < ndev, "gaib_ctx_create: device %d out of range (%d)", device, ndev);
+  GAIB_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  GAIB_HIP(hipGetDeviceProperties(&prop, device));
+  gaib_ctx* c = new gaib_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->num_cus = prop.multiProcessorCount;
+  c->ws = nullptr;
+  c->ws_bytes = 0;
+  c->spmm_heavy_threshold = 1024;
+  c->spmm_variant = 0;
+  c->spmm_xcd_swizzle = 1;
+  c->spmm_unroll = 0;
+  c->spmm_addr_mode = 0;
+  c->sgemm_variant = 0;
+  c->gat_fast = 1;
+  *out = c;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_ctx_destroy(gaib_ctx* ctx) {
+  if (!ctx) return GAIB_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  delete ctx;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream) {
+  GAIB_CHECK(ctx, "gaib_ctx_set_stream: ctx is NULL");
+  ctx->stream = (hipStream_t)stream;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_sync(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_sync: ctx is NULL");
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  return GAIB_OK;
+}
+
+int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return GAIB_OK;
+  // the old buffer may still be in use by enqueued kernels
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) GAIB_HIP(hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  size_t want = bytes + (bytes >> 2);
+  hipError_t e = hipMalloc(&ctx->ws, want);
+  if (e != hipSuccess) {
+    gaib_set_error("workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    return GAIB_ERR_NOMEM;
+  }
+  ctx->ws_bytes = want;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_malloc(gaib_ctx* ctx, size_t bytes, void** d_ptr) {
+  GAIB_CHECK(ctx && d_ptr, "gaib_malloc: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  *d_ptr = nullptr;
+  if (bytes == 0) return GAIB_OK;
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if (e != hipSuccess) {
+    gaib_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return GAIB_ERR_NOMEM;
+  }
+  return GAIB_OK;
+}
+
+extern "C" int gaib_free(gaib_ctx* ctx, void* d_ptr) {
+  GAIB_CHECK(ctx, "gaib_free: ctx is NULL");
+  if (d_ptr) GAIB_HIP(hipFree(d_ptr));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_memcpy_h2d(gaib_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  GAIB_CHECK(ctx, "gaib_memcpy_h2d: ctx is NULL");
+  if (bytes == 0) return GAIB_OK;
+  GAIB_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // pageable source: make the call safe to return from (source may be freed by caller)
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_memcpy_d2h(gaib_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  GAIB_CHECK(ctx, "gaib_memcpy_d2h: ctx is NULL");
+  if (bytes == 0) return GAIB_OK;
+  GAIB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_memcpy_d2d(gaib_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  GAIB_CHECK(ctx, "gaib_memcpy_d2d: ctx is NULL");
+  if (bytes == 0) return GAIB_OK;
+  GAIB_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
+  GAIB_CHECK(ctx && key, "gaib_set_option: NULL argument");
+  if (!strcmp(key, "spmm_heavy_threshold")) {
+    GAIB_CHECK(value >= 1 && value <= (1 << 30), "spmm_heavy_threshold out of range");
+    ctx->spmm_heavy_threshold = (int)value;
+  } else if (!strcmp(key, "spmm_variant"))
+    ctx->spmm_variant = (int)value;
+  else if (!strcmp(key, "spmm_xcd_swizzle"))
+    ctx->spmm_xcd_swizzle = (int)value;
+  else if (!strcmp(key, "spmm_unroll"))
+    ctx->spmm_unroll = (int)value;
+  else if (!strcmp(key, "spmm_addr_mode"))
+    ctx->spmm_addr_mode = (int)value;
+  else if (!strcmp(key, "sgemm_variant"))
+    ctx->sgemm_variant = (int)value;
+  else if (!strcmp(key, "gat_fast"))
+    ctx->gat_fast = (int)value;
+  else {
+    gaib_set_error("gaib_set_option: unknown key '%s'", key);
+    return GAIB_ERR_INVALID;
+  }
+  return GAIB_OK;
+}

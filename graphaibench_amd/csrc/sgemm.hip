@@ -1,0 +1,308 @@
+// sgemm.hip -- fp32 dense update on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// replaces matmul -> sgemm_gpu -> cublasSgemm (src/utilities/math_functions.cu:321-343;
+// CPU: matmul -> cblas_sgemm, math_functions.cpp:142-171):
+//     row-major  C[M x N] (=|+=) op(A)[M x K] . op(B)[K x N]
+// The three shapes on the GNN layer path:
+//     NN  forward        X[N_v x din]  . W[din x dout]
+//     NT  input gradient G[N_v x dout] . W[din x dout]^T
+//     TN  weight grad    X[N_v x din]^T . G[N_v x dout]      (K = N_v: split-K, fixed-order reduce)
+//
+// f32-input MFMA is exact fp32 (a k-ordered fmaf chain, one rounding per product) at the
+// fp32 vector peak (157 TF); there is no xf32/TF32 on gfx950, and the north-star tolerance
+// (1e-4 vs the OpenMP path) rules out bf16 operands.
+//
+// Kernel: 256 threads = 4 waves; each wave owns WM x WN tiles of 32x32; operands are staged
+// global -> registers (16-B loads, prefetched one K-step ahead) -> LDS.  LDS images:
+//   "x-major" [rows][BK+4]  (operand stored with k contiguous): fragments by ds_read_b128,
+//             conflict-free at row stride 36 floats;
+//   "k-major" [BK][cols+4]  (operand stored with k as the slow index): fragments by 4 ds_read_b32.
+// Lane (i = l&31, h = l>>5) of MFMA t in k-group kk consumes k = kk*8 + 4h + t for BOTH
+// operands (the sum over k is order-free as long as A and B agree).
+#include "common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int THREADS = 256;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;        // output (or split-K partial slab base)
+  int64_t M, N, K;
+  int64_t k_chunk;  // K range per blockIdx.y (multiple of BK); == K when not split
+  int accum;        // C += (ignored when writing split-K partials)
+  int64_t slab;     // M*N when writing partials (C + blockIdx.y*slab), else 0
+  int tiles_n;
+};
+
+// Load a TR x TC tile (TC % 4 == 0) of a row-major matrix [R][Cc] (leading dim ld) starting at
+// (r0, c0) into registers; element (r, c) outside the matrix reads as 0.
+template <int TR, int TC, bool VEC4>
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t R, int64_t Cc,
+                                          int64_t ld, int64_t r0, int64_t c0,
+                                          f4 (&regs)[TR * TC / 4 / THREADS]) {
+  constexpr int CPR = TC / 4;  // float4 chunks per tile row
+  constexpr int NCH = TR * TC / 4 / THREADS;
+#pragma unroll
+  for (int s = 0; s < NCH; ++s) {
+    const int q = threadIdx.x + s * THREADS;
+    const int r = q / CPR, cq = q % CPR;
+    const int64_t gr = r0 + r, gc = c0 + cq * 4;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (gr < R) {
+      const float* p = src + gr * ld + gc;
+      if (VEC4 && gc + 3 < Cc) {
+        v = *reinterpret_cast<const f4*>(p);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gc + e < Cc) v[e] = p[e];
+      }
+    }
+    regs[s] = v;
+  }
+}
+
+template <int TR, int TC>
+__device__ __forceinline__ void tile_store_lds(float* lds, const f4 (&regs)[TR * TC / 4 / THREADS]) {
+  constexpr int CPR = TC / 4;
+  constexpr int NCH = TR * TC / 4 / THREADS;
+  constexpr int LD = TC + 4;
+#pragma unroll
+  for (int s = 0; s < NCH; ++s) {
+    const int q = threadIdx.x + s * THREADS;
+    const int r = q / CPR, cq = q % CPR;
+    *reinterpret_cast<f4*>(&lds[r * LD + cq * 4]) = regs[s];
+  }
+}
+
+// WAVES_M x WAVES_N waves, each WM x WN tiles of 32x32.
+// A_KMAJOR: op(A) is stored [K][M] (transA);  B_KMAJOR: op(B) is stored [K][N] (no transB).
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC>
+__global__ __launch_bounds__(THREADS) void sgemm_mfma_kernel(GemmArgs g) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int BM = WAVES_M * WM * 32;
+  constexpr int BN = WAVES_N * WN * 32;
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
+  constexpr int A_LD = A_KMAJOR ? BM + 4 : BK + 4;
+  constexpr int B_LD = B_KMAJOR ? BN + 4 : BK + 4;
+  constexpr int A_LDS = A_KMAJOR ? BK * A_LD : BM * A_LD;
+  constexpr int B_LDS = B_KMAJOR ? BK * B_LD : BN * B_LD;
+  __shared__ __attribute__((aligned(16))) float lds[A_LDS + B_LDS];
+  float* As = lds;
+  float* Bs = lds + A_LDS;
+
+  const int tile = blockIdx.x;
+  const int64_t m0 = (int64_t)(tile / g.tiles_n) * BM;
+  const int64_t n0 = (int64_t)(tile % g.tiles_n) * BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * g.k_chunk;
+  const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f16v acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f4 ra[A_ELEMS / 4 / THREADS], rb[B_ELEMS / 4 / THREADS];
+
+  auto load_tiles = [&](int64_t k0) {
+    if constexpr (A_KMAJOR) tile_load<BK, BM, AVEC>(g.A, g.K, g.M, g.M, k0, m0, ra);
+    else tile_load<BM, BK, AVEC>(g.A, g.M, g.K, g.K, m0, k0, ra);
+    if constexpr (B_KMAJOR) tile_load<BK, BN, BVEC>(g.B, g.K, g.N, g.N, k0, n0, rb);
+    else tile_load<BN, BK, BVEC>(g.B, g.N, g.K, g.K, n0, k0, rb);
+  };
+  auto store_tiles = [&]() {
+    if constexpr (A_KMAJOR) tile_store_lds<BK, BM>(As, ra);
+    else tile_store_lds<BM, BK>(As, ra);
+    if constexpr (B_KMAJOR) tile_store_lds<BK, BN>(Bs, rb);
+    else tile_store_lds<BN, BK>(Bs, rb);
+  };
+
+  // note: rows of the K range beyond kend must read as zero -> clamp through the R/Cc bound
+  // (g.K is the true extent; a split's kend <= g.K and k_chunk % BK == 0, so a tile never
+  // straddles two splits).
+  if (kbeg < kend) {
+    load_tiles(kbeg);
+    store_tiles();
+  }
+  __syncthreads();
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) load_tiles(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float af[WM][4], bf[WN][4];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const int m = (wm * WM + a) * 32 + li;
+        if constexpr (A_KMAJOR) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) af[a][t] = As[(kk * 8 + 4 * lh + t) * A_LD + m];
+        } else {
+          const f4 v = *reinterpret_cast<const f4*>(&As[m * A_LD + kk * 8 + 4 * lh]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) af[a][t] = v[t];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        const int n = (wn * WN + b) * 32 + li;
+        if constexpr (B_KMAJOR) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[b][t] = Bs[(kk * 8 + 4 * lh + t) * B_LD + n];
+        } else {
+          const f4 v = *reinterpret_cast<const f4*>(&Bs[n * B_LD + kk * 8 + 4 * lh]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[b][t] = v[t];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+          for (int b = 0; b < WN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* C = g.C + (g.slab ? (int64_t)blockIdx.y * g.slab : 0);
+  const bool accum = g.accum && !g.slab;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      const int64_t nn = n0 + (wn * WN + b) * 32 + li;
+      if (nn < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t mm = m0 + (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (mm < g.M) {
+            float* p = C + mm * g.N + nn;
+            *p = accum ? (*p + acc[a][b][r]) : acc[a][b][r];
+          }
+        }
+      }
+    }
+}
+
+// C[i] = (accum ? C[i] : 0) + sum_s partial[s][i], s in order (deterministic)
+__global__ void splitk_reduce_kernel(int64_t n, int splits, const float* partial, int accum,
+                                     float* C) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float s = accum ? C[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * n + i];
+    C[i] = s;
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool AK, bool BKM>
+int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+  const int64_t tiles_m = cdiv64(g.M, BM), tiles_n = cdiv64(g.N, BN);
+  g.tiles_n = (int)tiles_n;
+  const int64_t tiles = tiles_m * tiles_n;
+  GAIB_CHECK(tiles < (int64_t)1 << 31, "gaib_sgemm: too many tiles");
+  // split K when the output has too few tiles to fill 256 CUs and K is long (weight grads)
+  int splits = 1;
+  if (tiles < 2 * ctx->num_cus && g.K >= 8192) {
+    int64_t want = cdiv64(4 * (int64_t)ctx->num_cus, tiles);
+    int64_t maxs = g.K / (8 * BK);
+    splits = (int)(want < maxs ? want : maxs);
+    if (splits < 1) splits = 1;
+  }
+  float* Cout = g.C;
+  const int accum = g.accum;
+  if (splits > 1) {
+    g.k_chunk = cdiv64(cdiv64(g.K, splits), BK) * BK;
+    splits = (int)cdiv64(g.K, g.k_chunk);
+    g.slab = g.M * g.N;
+    GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)splits * g.slab));
+    g.C = (float*)ctx->ws;
+  } else {
+    g.k_chunk = cdiv64(g.K > 0 ? g.K : 1, BK) * BK;
+    g.slab = 0;
+  }
+  dim3 grid((unsigned)tiles, (unsigned)splits);
+#define GAIB_GEMM_LAUNCH(AV, BV)                                                         \
+  sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV><<<grid, THREADS, 0, ctx->stream>>>(g)
+  if (avec && bvec) GAIB_GEMM_LAUNCH(true, true);
+  else if (avec) GAIB_GEMM_LAUNCH(true, false);
+  else if (bvec) GAIB_GEMM_LAUNCH(false, true);
+  else GAIB_GEMM_LAUNCH(false, false);
+#undef GAIB_GEMM_LAUNCH
+  GAIB_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t n = g.M * g.N;
+    unsigned rg = (unsigned)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
+    splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, splits, (const float*)ctx->ws, accum, Cout);
+    GAIB_LAUNCH_CHECK();
+  }
+  return GAIB_OK;
+}
+
+template <bool AK, bool BKM>
+int dispatch_shape(gaib_ctx* ctx, const GemmArgs& g, bool avec, bool bvec) {
+  if (g.N > 64) return launch<2, 2, 2, 2, AK, BKM>(ctx, g, avec, bvec);  // 128 x 128
+  if (g.N > 32) return launch<4, 1, 2, 2, AK, BKM>(ctx, g, avec, bvec);  // 256 x 64
+  return launch<4, 1, 2, 1, AK, BKM>(ctx, g, avec, bvec);                // 256 x 32
+}
+
+}  // namespace
+
+extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                          const float* d_A, const float* d_B, int accum, float* d_C) {
+  GAIB_CHECK(ctx, "gaib_sgemm: ctx is NULL");
+  GAIB_CHECK(M >= 0 && N >= 0 && K >= 0, "gaib_sgemm: negative dimension");
+  if (M == 0 || N == 0) return GAIB_OK;
+  GAIB_CHECK(d_C, "gaib_sgemm: C is NULL");
+  GAIB_CHECK(K == 0 || (d_A && d_B), "gaib_sgemm: A/B is NULL");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (K == 0) {
+    if (!accum) return gaib_fill_f32(ctx, M * N, 0.f, d_C);
+    return GAIB_OK;
+  }
+  if (transA && transB) {
+    gaib_set_error("gaib_sgemm: transA && transB is not on the GNN path (unsupported)");
+    return GAIB_ERR_UNSUPPORTED;
+  }
+  GemmArgs g;
+  g.A = d_A;
+  g.B = d_B;
+  g.C = d_C;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.k_chunk = K;
+  g.accum = accum ? 1 : 0;
+  g.slab = 0;
+  g.tiles_n = 1;
+  // 16-B loads need an aligned base and a leading dimension that keeps rows aligned
+  const int64_t lda = transA ? M : K;
+  const int64_t ldb = transB ? K : N;
+  const bool avec = (((uintptr_t)d_A & 15) == 0) && (lda % 4 == 0);
+  const bool bvec = (((uintptr_t)d_B & 15) == 0) && (ldb % 4 == 0);
+  if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
+  if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);
+  return dispatch_shape<true, true>(ctx, g, avec, bvec);
+}

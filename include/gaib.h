@@ -1,0 +1,198 @@
+/*
+ * gaib.h -- C ABI of the MI355X (gfx950) GNN aggregation engine.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its
+ * "operator API" is a set of C++ declarations whose definitions the GPU Makefile target
+ * takes from .cu files (src/gnn/Makefile:56-77).  The host-side C++ mirror of those
+ * declarations lives in include/{gnn,layers,utils}/ of this repo and is implemented
+ * ENTIRELY on top of the functions below; every entry point cites the reference
+ * interface (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain C types only; all pointers named d_* are DEVICE pointers (HBM), h_* host.
+ *   - every function returns GAIB_OK (0) or a negative gaib_status; gaib_last_error()
+ *     gives the message.  The C++ mirror turns non-zero into the reference's
+ *     print-and-exit (include/utils/cutils.h:18-28,133-174).
+ *   - all work is enqueued on the context's HIP stream; nothing synchronises unless
+ *     the name says so (the reference syncs after every launch: cutils.h:18-28).
+ *   - feature matrices are row-major fp32 [nv x len]; row offsets are 64-bit (the
+ *     reference's uint32 `dst*len`, graph_operations.h:100,105, overflows at N*D>2^32).
+ */
+#ifndef GAIB_H
+#define GAIB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GAIB_OK = 0,
+  GAIB_ERR_INVALID = -1, /* bad argument / shape */
+  GAIB_ERR_HIP = -2,     /* a HIP runtime call failed */
+  GAIB_ERR_NOMEM = -3,
+  GAIB_ERR_ASYMMETRIC = -4, /* edge_transpose: reverse edge missing (math_functions.cpp:70 assert) */
+  GAIB_ERR_UNSUPPORTED = -5
+} gaib_status;
+
+typedef struct gaib_ctx gaib_ctx;     /* device + stream + workspace              */
+typedef struct gaib_graph gaib_graph; /* CSR in HBM + normalisers + row schedules */
+
+const char* gaib_last_error(void);
+const char* gaib_version(void);
+
+/* ---- context -------------------------------------------------------------------------
+ * replaces the static cuBLAS/cuSPARSE/cuRAND handle holder `gpu_context`
+ * (include/gnn/gpu_context.h:4-16, src/utilities/random.cpp:62-80).
+ * `stream` is a hipStream_t (NULL = the device's null stream); it is borrowed. */
+int gaib_ctx_create(int device, void* stream, gaib_ctx** out);
+int gaib_ctx_destroy(gaib_ctx* ctx);
+int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream);
+int gaib_sync(gaib_ctx* ctx); /* CudaTest()'s cudaDeviceSynchronize, cutils.h:18-28 */
+
+/* ---- memory: float/uint/uint8_malloc_device, *_free_device, copy_*_device, copy_float_host,
+ * init_const_gpu  (include/utils/math_functions.hh:161-173, math_functions.cu:12-14;
+ * templates malloc_device<T>/copy_async_device<T>, include/utils/cutils.h:193-202) ---- */
+int gaib_malloc(gaib_ctx* ctx, size_t bytes, void** d_ptr);
+int gaib_free(gaib_ctx* ctx, void* d_ptr);
+int gaib_memcpy_h2d(gaib_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int gaib_memcpy_d2h(gaib_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* syncs */
+int gaib_memcpy_d2d(gaib_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int gaib_fill_f32(gaib_ctx* ctx, int64_t n, float value, float* d_x);
+
+/* ---- graph: LearningGraph's device half (include/gnn/lgraph.h:20-277) ------------------
+ * gaib_graph_create  = alloc_on_device + copy_to_gpu (src/gnn/lgraph.cu:51-92).
+ *   rowptr: nv+1 entries of `rowptr_bits` (32: index_t as LearningGraph holds it; 64: as
+ *   graph.vertex.bin stores it, reader.cpp:446-454); colidx: ne uint32 (graph.edge.bin).
+ *   src_on_device != 0 means the two arrays are already in HBM (they are copied).
+ *   Rows must be sorted by column id (lgraph.h:185 / math_functions.cpp:32-44 need it). */
+int gaib_graph_create(gaib_ctx* ctx, int64_t nv, int64_t ne, const void* rowptr, int rowptr_bits,
+                      const uint32_t* colidx, int src_on_device, gaib_graph** out);
+/* Rectangular variant for a vertex-range partition (modelled on
+ * PartitionedGraph::edgecut_induced_partition1D, src/partitioner/graph_partition.cc:128-178):
+ * nv owned rows, column ids index a feature table of nc >= nv rows (owned rows first, halo
+ * rows after).  add_selfloop / edge_transpose / GAT need a square graph. */
+int gaib_graph_create_rect(gaib_ctx* ctx, int64_t nv, int64_t nc, int64_t ne, const void* rowptr,
+                           int rowptr_bits, const uint32_t* colidx, int src_on_device,
+                           gaib_graph** out);
+/* Partitioned graphs: a halo column's local degree is truncated, so the normalisers come from
+ * the GLOBAL graph: d_row_vdata [nv] (NULL = derive from rowptr), d_col_vdata [nc] (deg^-1/2),
+ * d_col_inv_deg [nc] (1/deg).  Arrays are copied. */
+int gaib_graph_set_vertex_norm(gaib_ctx* ctx, gaib_graph* g, const float* d_row_vdata,
+                               const float* d_col_vdata, const float* d_col_inv_deg);
+int gaib_graph_destroy(gaib_graph* g);
+/* LearningGraph::add_selfloop (lgraph.h:185-218) as a device-side rebuild. */
+int gaib_graph_add_selfloop(gaib_ctx* ctx, const gaib_graph* g, gaib_graph** out);
+int64_t gaib_graph_nv(const gaib_graph* g);
+int64_t gaib_graph_ne(const gaib_graph* g);
+const int64_t* gaib_graph_rowptr(const gaib_graph* g);  /* device, int64[nv+1] */
+const uint32_t* gaib_graph_colidx(const gaib_graph* g); /* device, uint32[ne]  */
+/* compute_vertex_data (lgraph.cpp:22-34 / lgraph.cu:94-105): deg^-1/2, 0 for isolated. */
+int gaib_graph_compute_vertex_data(gaib_ctx* ctx, gaib_graph* g);
+const float* gaib_graph_vertex_data(const gaib_graph* g); /* device float[nv] or NULL */
+/* compute_edge_data (lgraph.cpp:6-20 / lgraph.cu:107-140): 1/(sqrt(d_i)*sqrt(d_j)). */
+int gaib_graph_compute_edge_data(gaib_ctx* ctx, gaib_graph* g);
+const float* gaib_graph_edge_data(const gaib_graph* g); /* device float[ne] or NULL */
+/* device bytes held by the graph (CSR + normalisers + schedules) */
+int64_t gaib_graph_device_bytes(const gaib_graph* g);
+
+/* ---- sparse aggregation (the hot loop) -------------------------------------------------
+ * out[i,:] = sum_{e in row i} w_e * in[col_e,:]      (out is fully overwritten)
+ *   GAIB_W_GCN    w_e = vd[i]*vd[col_e]      GCN_Aggregator::aggregate/d_aggregate
+ *                                            (gcn_aggregator.cpp:23-77; .cu:14-51)
+ *   GAIB_W_MEAN   w_e = 1/deg(i)             SAGE_Aggregator::aggregate   (sage_aggregator.cpp:7-30)
+ *   GAIB_W_MEAN_T w_e = 1/deg(col_e)         SAGE_Aggregator::d_aggregate (sage_aggregator.cpp:32-54)
+ *   GAIB_W_EDGE   w_e = d_edge_w[e]          update_all (gat_aggregator.cpp:26-45), spmm()
+ *                                            (math_functions.cpp:207-220; cusparseSpMM .cu:407-410)
+ *   GAIB_W_EDGE_T w_e = d_edge_w[rev(e)]     symmetric_csr_transpose + update_all fused
+ *                                            (gat_aggregator.cpp:175,198)
+ * Rows of degree <= the heavy-row threshold are summed in CSR order with a separate
+ * multiply and add (bit-identical to the OpenMP loop); longer rows are split over the
+ * waves of a workgroup and combined through LDS in a fixed order. */
+typedef enum {
+  GAIB_W_GCN = 0,
+  GAIB_W_MEAN = 1,
+  GAIB_W_MEAN_T = 2,
+  GAIB_W_EDGE = 3,
+  GAIB_W_EDGE_T = 4
+} gaib_weight_kind;
+int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
+              const float* d_in, float* d_out);
+
+/* ---- GAT attention pieces ---------------------------------------------------------------
+ * gaib_gat_scores: GAT_Aggregator::aggregate's score pass (gat_aggregator.cpp:60-92;
+ *   compute_attn_score_warp, graph_operations.h:250-337): per edge
+ *   temp = a_l.h[i] + a_r.h[col_e]; scores = leaky_relu(temp, eps); norm = row softmax.
+ *   All three d_* edge arrays [ne] are written. */
+int gaib_gat_scores(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_h, const float* d_alpha_l,
+                    const float* d_alpha_r, float epsilon, float* d_temp_scores, float* d_scores,
+                    float* d_norm_scores);
+/* SDDMM (gat_aggregator.cpp:106-113; compute_scores_grad_warp, graph_operations.h:191-223):
+ *   d_out_e[e] = <grad[i,:], feat[col_e,:]> */
+int gaib_sddmm(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_grad, const float* d_feat,
+               float* d_out_e);
+/* softmax backward + leaky-relu' + alpha gradients (gat_aggregator.cpp:121-167;
+ *   compute_alpha_grad_warp, graph_operations.h:396-467).  d_scores[e] is overwritten with
+ *   d(softmax) like the reference does; d_alpha_lgrad/d_alpha_rgrad [len] are overwritten.
+ *   Deterministic (no float atomics). */
+int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_feat,
+                               const float* d_norm_scores, const float* d_norm_scores_grad,
+                               const float* d_temp_scores, float epsilon, float* d_scores,
+                               float* d_alpha_lgrad, float* d_alpha_rgrad);
+/* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):
+ *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
+int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);
+
+/* ---- dense update: matmul -> sgemm_gpu -> cublasSgemm (math_functions.cu:321-343) --------
+ * row-major C[M x N] = op(A)[M x K] . op(B)[K x N]  (+ C if accum).  fp32 MFMA. */
+int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
+               const float* d_A, const float* d_B, int accum, float* d_C);
+
+/* ---- elementwise: relu_gpu / d_relu_gpu (math_functions.cu:242-268), dropout mask replay
+ * d_dropout_gpu (:134-146) ---- */
+int gaib_relu(gaib_ctx* ctx, int64_t n, const float* d_in, float* d_out);
+int gaib_d_relu(gaib_ctx* ctx, int64_t n, const float* d_in_diff, const float* d_data,
+                float* d_out_diff);
+int gaib_dropout(gaib_ctx* ctx, int64_t n, float scale, float drop_rate, uint64_t seed,
+                 const float* d_in, uint8_t* d_masks, float* d_out);
+int gaib_d_dropout(gaib_ctx* ctx, int64_t n, float scale, const float* d_in,
+                   const uint8_t* d_masks, float* d_out);
+
+/* ---- loss / metrics: softmax_cross_entropy_gpu, d_softmax_cross_entropy_gpu,
+ * masked_avg_loss_gpu, masked_accuracy_single (math_functions.cu:516-564,749-761,886-942) ---- */
+int gaib_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                      const float* d_in, const uint8_t* d_masks, const uint8_t* d_labels,
+                      float* d_loss, float* d_out);
+int gaib_d_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                        const uint8_t* d_masks, const uint8_t* d_labels, const float* d_out,
+                        float* d_diff);
+int gaib_masked_avg_loss(gaib_ctx* ctx, int64_t begin, int64_t end, const uint8_t* d_masks,
+                         const float* d_loss, float* h_result); /* syncs */
+int gaib_masked_accuracy_single(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                                const uint8_t* d_masks, const float* d_preds,
+                                const uint8_t* d_labels, float* h_result); /* syncs */
+
+/* ---- l2norm / d_l2norm (math_functions.cu:158-196) ---- */
+int gaib_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_in, float* d_out);
+int gaib_d_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_feat_in,
+                  const float* d_grad_in, float* d_grad_out);
+
+/* ---- optimizer: adam::update_gpu -> update_kernel (src/utilities/optimizer.cu:5-36).
+ * The caller owns m/v state and the beta powers (optimizer.h:99-116). ---- */
+int gaib_adam_step(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, float* d_m,
+                   float* d_v, float alpha, float b1, float b2, float b1_t, float b2_t, float eps);
+
+/* ---- multi-GPU helpers (no reference counterpart) --------------------------
+ * pack rows for the halo exchange: d_out[k,:] = d_in[d_idx[k],:] */
+int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_idx, int len,
+                     const float* d_in, float* d_out);
+
+/* ---- tuning knobs (benchmarks only; defaults are what ships) ---- */
+int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAIB_H */

@@ -1,0 +1,103 @@
+"""Kernel micro-benchmarks on the products-shaped synthetic graph (development aid; bench.py is
+the judged harness).  Times each gaib_spmm variant and the three layer GEMMs with HIP events on
+the context's stream.
+
+    python scripts/microbench.py [--scale 1.0] [--d 128] [--iters 5]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from graphaibench_amd import capi, synth  # noqa: E402
+
+
+def timeit(fn, iters, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--graph", default="ogbn-products")
+    args = ap.parse_args()
+    ctx = capi.Context(0)
+    t0 = time.time()
+    sg = synth.make(args.graph, device="cuda", scale=args.scale)
+    torch.cuda.synchronize()
+    print(f"graph {sg.name}: nv={sg.nv} ne={sg.ne} gen {time.time()-t0:.1f}s", flush=True)
+    g0 = ctx.graph(sg.rowptr, sg.colidx)
+    g = g0.add_selfloop()
+    ctx.sync()
+    nv, ne, d = g.nv, g.ne, args.d
+    deg = sg.rowptr[1:] - sg.rowptr[:-1]
+    print(f"with self loops ne={ne}; max deg {int(deg.max())}; rows>1024: {int((deg > 1024).sum())} "
+          f"holding {int(deg[deg > 1024].sum())} edges", flush=True)
+    x = torch.randn(nv, d, device="cuda")
+    out = torch.empty_like(x)
+    alg_bytes = ne * (4 * d + 4) + nv * 4 * d + (nv + 1) * 4 + 4 * ne
+    res = []
+
+    def run(tag, **opts):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            med, best = timeit(lambda: ctx.spmm(g, capi.W_GCN, x, out), args.iters)
+        finally:
+            for k in opts:
+                ctx.set_option(k, 1024 if k == "spmm_heavy_threshold" else (1 if k == "spmm_xcd_swizzle" else 0))
+        r = dict(kernel="spmm_gcn", tag=tag, d=d, ms=med, best_ms=best, gedges_s=ne / med / 1e6,
+                 alg_gbs=alg_bytes / med / 1e6, frac_8tbs=alg_bytes / med / 1e6 / 8000)
+        print(json.dumps(r), flush=True)
+        res.append(r)
+
+    run("default")
+    run("unroll8", spmm_unroll=8)
+    run("global_addr", spmm_addr_mode=2)
+    run("global_addr_unroll8", spmm_addr_mode=2, spmm_unroll=8)
+    run("no_xcd_swizzle", spmm_xcd_swizzle=0)
+    if d == 128:
+        run("vec4_sub32", spmm_variant=32)
+        run("vec4_w64", spmm_variant=4)
+        run("vec1_ct2", spmm_variant=1)
+    for thr in (256, 4096, 1 << 20):
+        run(f"heavy_thr_{thr}", spmm_heavy_threshold=thr)
+    # SAGE mean (row weight) for comparison
+    med, best = timeit(lambda: ctx.spmm(g0, capi.W_MEAN, x, out), args.iters)
+    print(json.dumps(dict(kernel="spmm_mean", d=d, ms=med, gedges_s=g0.ne / med / 1e6)), flush=True)
+
+    # the three GEMMs of a d x d hidden layer
+    W = torch.randn(d, d, device="cuda")
+    y = torch.empty(nv, d, device="cuda")
+    dW = torch.empty(d, d, device="cuda")
+    for tag, fn, flops in [
+        ("NN fwd", lambda: ctx.sgemm(x, W, y), 2 * nv * d * d),
+        ("NT dX", lambda: ctx.sgemm(x, W, y, False, True), 2 * nv * d * d),
+        ("TN dW", lambda: ctx.sgemm(x, y, dW, True, False), 2 * nv * d * d),
+    ]:
+        med, best = timeit(fn, args.iters)
+        print(json.dumps(dict(kernel="sgemm", tag=tag, ms=med, tflops=flops / med / 1e9)), flush=True)
+    med, _ = timeit(lambda: ctx.relu(x, out), args.iters)
+    print(json.dumps(dict(kernel="relu", ms=med, gbs=2 * x.numel() * 4 / med / 1e6)), flush=True)
+    med, _ = timeit(lambda: out.copy_(x), args.iters)
+    print(json.dumps(dict(kernel="torch_copy", ms=med, gbs=2 * x.numel() * 4 / med / 1e6)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
