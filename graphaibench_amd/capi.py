@@ -45,7 +45,7 @@ SIGNATURES = {
     "gaib_graph_vertex_data": (_vp, [_vp]),
     "gaib_graph_compute_edge_data": (_i, [_vp, _vp]),
     "gaib_graph_edge_data": (_vp, [_vp]),
-    "gaib_graph_set_vertex_norm": (_i, [_vp, _vp, _vp, _vp]),
+    "gaib_graph_set_vertex_norm": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "gaib_graph_device_bytes": (_i64, [_vp]),
     "gaib_spmm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -65,6 +65,10 @@ SIGNATURES = {
     "gaib_d_l2norm": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "gaib_adam_step": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]),
     "gaib_gather_rows": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
+    "gaib_prof_enable": (_i, [_vp, _i]),
+    "gaib_prof_reset": (_i, [_vp]),
+    "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
 }
 
@@ -140,6 +144,23 @@ class Context:
 
     def set_option(self, key: str, value: int):
         _check(self.lib.gaib_set_option(self.h, key.encode(), int(value)), f"gaib_set_option({key})")
+
+    # ---- in-stream kernel timing ----------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        _check(self.lib.gaib_prof_enable(self.h, int(on)), "gaib_prof_enable")
+
+    def prof_reset(self):
+        _check(self.lib.gaib_prof_reset(self.h), "gaib_prof_reset")
+
+    def prof_get(self, key: str):
+        n, ms = _i64(), C.c_double()
+        _check(self.lib.gaib_prof_get(self.h, key.encode(), C.byref(n), C.byref(ms)), "gaib_prof_get")
+        return n.value, ms.value
+
+    def graph_stats(self, g: "Graph"):
+        a, b, c = _i64(), _i64(), _i64()
+        _check(self.lib.gaib_graph_stats(self.h, g.h, C.byref(a), C.byref(b), C.byref(c)), "gaib_graph_stats")
+        return dict(n_heavy=a.value, heavy_edges=b.value, max_degree=c.value)
 
     # ---- graph ------------------------------------------------------------------------
     def graph(self, rowptr, colidx, ncols: int | None = None) -> "Graph":

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string>
 #include <string.h>
+#include <vector>
 #include "gaib.h"
 
 #define GAIB_WAVE 64
@@ -52,6 +53,28 @@ struct gaib_ctx {
   int spmm_addr_mode;        // 0 = auto (buffer loads when the table is < 4 GB), 2 = force 64-bit global
   int sgemm_variant;         // 0 = auto
   int gat_fast;              // reserved
+  // in-stream kernel timing (gaib_prof_*)
+  int prof_on;
+  struct ProfRec { const char* key; hipEvent_t a, b; };
+  std::vector<ProfRec> prof;
+};
+
+// RAII: event pair around a kernel launch when profiling is on
+struct ProfScope {
+  gaib_ctx* c;
+  size_t idx;
+  ProfScope(gaib_ctx* ctx, const char* key) : c(ctx), idx((size_t)-1) {
+    if (!c->prof_on) return;
+    gaib_ctx::ProfRec r;
+    r.key = key;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, c->stream);
+    c->prof.push_back(r);
+    idx = c->prof.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx != (size_t)-1) (void)hipEventRecord(c->prof[idx].b, c->stream);
+  }
 };
 
 int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes);
@@ -73,6 +96,7 @@ struct gaib_graph {
   // rows with degree > heavy_thr (built for the threshold the list was made with)
   uint32_t* heavy_rows;
   int64_t n_heavy;
+  int64_t heavy_edges;
   int heavy_thr;
   int64_t max_degree;
   int64_t dev_bytes;

@@ -89,6 +89,7 @@ __global__ void heavy_rows_kernel(int64_t nv, const int64_t* rowptr, int thr, ui
   if (deg > thr) {
     unsigned long long p = atomicAdd(count, 1ull);
     if (list) list[p] = (uint32_t)v;
+    else atomicAdd(count + 2, (unsigned long long)deg);  // counting pass: edges held by heavy rows
   }
   if (maxdeg) atomicMax(maxdeg, (unsigned long long)deg);
 }
@@ -353,12 +354,12 @@ int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g) {
 int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   if (g->heavy_thr == thr) return GAIB_OK;
   unsigned long long* cnt = nullptr;
-  GAIB_HIP(hipMalloc(&cnt, 2 * sizeof(unsigned long long)));
-  GAIB_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  GAIB_HIP(hipMalloc(&cnt, 3 * sizeof(unsigned long long)));
+  GAIB_HIP(hipMemsetAsync(cnt, 0, 3 * sizeof(unsigned long long), ctx->stream));
   heavy_rows_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, thr, nullptr,
                                                                  cnt, cnt + 1);
   GAIB_LAUNCH_CHECK();
-  unsigned long long h[2] = {0, 0};
+  unsigned long long h[3] = {0, 0, 0};
   GAIB_HIP(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
   if (g->heavy_rows) {
@@ -367,6 +368,7 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   }
   g->n_heavy = (int64_t)h[0];
   g->max_degree = (int64_t)h[1];
+  g->heavy_edges = (int64_t)h[2];
   if (g->n_heavy > 0) {
     GAIB_HIP(hipMalloc(&g->heavy_rows, sizeof(uint32_t) * (size_t)g->n_heavy));
     GAIB_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
@@ -377,5 +379,16 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   }
   GAIB_HIP(hipFree(cnt));
   g->heavy_thr = thr;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_graph_stats(gaib_ctx* ctx, gaib_graph* g, int64_t* h_n_heavy, int64_t* h_heavy_edges,
+                                int64_t* h_max_degree) {
+  GAIB_CHECK(ctx && g, "gaib_graph_stats: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
+  if (h_n_heavy) *h_n_heavy = g->n_heavy;
+  if (h_heavy_edges) *h_heavy_edges = g->heavy_edges;
+  if (h_max_degree) *h_max_degree = g->max_degree;
   return GAIB_OK;
 }

@@ -39,6 +39,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_addr_mode = 0;
   c->sgemm_variant = 0;
   c->gat_fast = 1;
+  c->prof_on = 0;
   *out = c;
   return GAIB_OK;
 }
@@ -120,6 +121,40 @@ extern "C" int gaib_memcpy_d2d(gaib_ctx* ctx, void* d_dst, const void* d_src, si
   GAIB_CHECK(ctx, "gaib_memcpy_d2d: ctx is NULL");
   if (bytes == 0) return GAIB_OK;
   GAIB_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_prof_enable(gaib_ctx* ctx, int on) {
+  GAIB_CHECK(ctx, "gaib_prof_enable: ctx is NULL");
+  ctx->prof_on = on ? 1 : 0;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_prof_reset(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_prof_reset: ctx is NULL");
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  ctx->prof.clear();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_total_ms) {
+  GAIB_CHECK(ctx && key && h_count && h_total_ms, "gaib_prof_get: NULL argument");
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t n = 0;
+  double ms = 0.0;
+  for (auto& r : ctx->prof) {
+    if (strcmp(r.key, key) != 0) continue;
+    float t = 0.f;
+    GAIB_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    n++;
+  }
+  *h_count = n;
+  *h_total_ms = ms;
   return GAIB_OK;
 }
 

@@ -244,6 +244,7 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
     g.slab = 0;
   }
   dim3 grid((unsigned)tiles, (unsigned)splits);
+  ProfScope ps(ctx, "sgemm");
 #define GAIB_GEMM_LAUNCH(AV, BV)                                                         \
   sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV><<<grid, THREADS, 0, ctx->stream>>>(g)
   if (avec && bvec) GAIB_GEMM_LAUNCH(true, true);

@@ -321,6 +321,7 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     SpmmArgs h = a;
     h.row_list = g->heavy_rows;
     size_t lds = sizeof(float) * HEAVY_WAVES * CT * 64 * VEC;
+    ProfScope ps(ctx, "spmm_heavy");
     spmm_heavy_kernel<VEC, CT, WMODE, U, BUF><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -332,6 +333,7 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     grid = (unsigned)a.per_xcd * 8u;
   }
   if (grid > 0) {
+    ProfScope ps(ctx, "spmm_light");
     spmm_w64_kernel<VEC, CT, WMODE, U, BUF><<<dim3(grid), 256, 0, ctx->stream>>>(a);
     GAIB_LAUNCH_CHECK();
   }
@@ -357,6 +359,7 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     SpmmArgs h = a;
     h.row_list = g->heavy_rows;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
+    ProfScope ps(ctx, "spmm_heavy");
     spmm_heavy_kernel<VEC, 1, WMODE, 8, false><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                  ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -369,6 +372,7 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     grid = (unsigned)a.per_xcd * 8u;
   }
   if (grid > 0) {
+    ProfScope ps(ctx, "spmm_sub");
     spmm_sub_kernel<VEC, G, WMODE><<<dim3(grid), 256, 0, ctx->stream>>>(a);
     GAIB_LAUNCH_CHECK();
   }

@@ -1,0 +1,108 @@
+// aggregators.cpp -- GCN / SAGE / GAT aggregators: each operator call is one or a few entries of
+// the C ABI (include/gaib.h) on the process context.
+#include "aggregator.h"
+#include "host_util.h"
+
+using gaib_host::OpTimer;
+static inline gaib_ctx* C() { return gpu_context::get(); }
+
+static gaib_graph* dev(Graph& g) {
+  if (!g.device_graph()) g.copy_to_gpu();
+  return g.device_graph();
+}
+
+// ---- GCN ---------------------------------------------------------------------------------------
+void GCN_Aggregator::init(int l, int nv, int, float, float) {
+  length = l;
+  n = nv;
+}
+void GCN_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, in, out));
+}
+// the normalised adjacency is symmetric, so the derivative is the same operator
+void GCN_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, grad_in, grad_out));
+}
+
+// ---- SAGE --------------------------------------------------------------------------------------
+void SAGE_Aggregator::init(int l, int nv, int, float, float) {
+  length = l;
+  n = nv;
+}
+void SAGE_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN, NULL, len, in, out));
+}
+void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN_T, NULL, len, grad_in, grad_out));
+}
+
+// ---- GAT ---------------------------------------------------------------------------------------
+GAT_Aggregator::GAT_Aggregator()
+    : epsilon(0.2f), attn_drop(0.f), num_edges(0), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
+      d_alpha_rgrad(NULL), d_scores(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
+      d_norm_scores_grad(NULL), alpha_opt(NULL) {}
+
+void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
+  length = l;
+  n = nv;
+  attn_drop = drop_rate;
+  assert(attn_drop >= 0. && attn_drop < 1.);
+  num_edges = (size_t)ne;
+  // alpha_l / alpha_r: Glorot over (l, 1) with seeds 2 and 3, as the reference's CPU path
+  // (gat_aggregator.cpp:11-12)
+  vec_t al, ar;
+  init_glorot(l, 1, al, 2);
+  init_glorot(l, 1, ar, 3);
+  d_alpha_l = gaib_host::dmalloc<float>(l);
+  d_alpha_r = gaib_host::dmalloc<float>(l);
+  d_alpha_lgrad = gaib_host::dmalloc<float>(l);
+  d_alpha_rgrad = gaib_host::dmalloc<float>(l);
+  copy_float_device(l, al.data(), d_alpha_l);
+  copy_float_device(l, ar.data(), d_alpha_r);
+  GAIB_OR_DIE(gaib_fill_f32(C(), l, 0.f, d_alpha_lgrad));
+  GAIB_OR_DIE(gaib_fill_f32(C(), l, 0.f, d_alpha_rgrad));
+  d_scores = gaib_host::dmalloc<float>(num_edges);
+  d_temp_scores = gaib_host::dmalloc<float>(num_edges);
+  d_norm_scores = gaib_host::dmalloc<float>(num_edges);
+  d_norm_scores_grad = gaib_host::dmalloc<float>(num_edges);
+  epsilon = 0.2f;
+  alpha_opt = new adam(lr);
+}
+
+void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
+  assert(g.sizeEdges() <= num_edges);
+  {
+    OpTimer t(OP_SCORE);
+    GAIB_OR_DIE(gaib_gat_scores(C(), dev(g), len, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,
+                                d_scores, d_norm_scores));
+  }
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_EDGE, d_norm_scores, len, in, out));
+}
+
+// feat_in and grad_out may be the same buffer (GAT_layer::backward passes out_temp for both):
+// feat_in is last read by the alpha-gradient step, grad_out is first written by the final SpMM.
+void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in,
+                                 float* grad_out) {
+  {
+    OpTimer t(OP_SCORE);
+    GAIB_OR_DIE(gaib_sddmm(C(), dev(g), len, grad_in, feat_in, d_norm_scores_grad));
+  }
+  {
+    OpTimer t(OP_ATTN);
+    GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha(C(), dev(g), len, feat_in, d_norm_scores, d_norm_scores_grad,
+                                           d_temp_scores, epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad));
+  }
+  // transpose + aggregation fused: w_e = norm_scores[rev(e)]
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_EDGE_T, d_norm_scores, len, grad_in, grad_out));
+}
+
+void GAT_Aggregator::update_weights(optimizer*) {
+  alpha_opt->update_gpu(length, d_alpha_lgrad, d_alpha_l);
+  alpha_opt->update_gpu(length, d_alpha_rgrad, d_alpha_r);
+}

@@ -1,0 +1,126 @@
+// capi_layers.cpp -- opaque-handle C API over the host C++ classes (include/gaib_layers.h).
+#include "gaib_layers.h"
+#include "graph_conv_layer.h"
+#include "host_util.h"
+
+namespace {
+struct LayerBox {
+  int kind;
+  GCN_layer* gcn;
+  SAGE_layer* sage;
+  GAT_layer* gat;
+};
+
+template <typename L>
+static float* common_ptr(L* l, int which) {
+  switch (which) {
+    case GAIBL_FEAT_IN: return l->get_feat_in();
+    case GAIBL_GRAD_IN: return l->get_grad_in();
+    case GAIBL_W_NEIGH: return l->weight_neigh_ptr();
+    case GAIBL_W_NEIGH_GRAD: return l->weight_neigh_grad_ptr();
+    case GAIBL_W_SELF: return l->weight_self_ptr();
+    case GAIBL_W_SELF_GRAD: return l->weight_self_grad_ptr();
+    default: return nullptr;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+void gaibl_init(int device, void* hip_stream) { gpu_context::set(device, hip_stream); }
+void* gaibl_ctx(void) { return gpu_context::get(); }
+void gaibl_sync(void) { gpu_context::sync(); }
+
+void* gaibl_graph_from_host(uint32_t nv, uint32_t ne, const uint32_t* rowptr, const uint32_t* colidx,
+                            int add_selfloop) {
+  Graph* g = new Graph(true);
+  g->allocateFrom(nv, ne);
+  memcpy(g->row_host_ptr(), rowptr, sizeof(uint32_t) * ((size_t)nv + 1));
+  if (ne) memcpy(g->edge_host_ptr(), colidx, sizeof(uint32_t) * ne);
+  if (add_selfloop) g->add_selfloop();
+  g->degree_counting();
+  g->alloc_on_device();
+  g->copy_to_gpu();
+  g->compute_vertex_data();
+  return g;
+}
+void* gaibl_graph_adopt(void* h) { return LearningGraph::adopt_device(static_cast<gaib_graph*>(h)); }
+void* gaibl_graph_device(void* graph) { return static_cast<Graph*>(graph)->device_graph(); }
+uint64_t gaibl_graph_num_edges(void* graph) { return static_cast<Graph*>(graph)->sizeEdges(); }
+void gaibl_graph_free(void* graph) {
+  Graph* g = static_cast<Graph*>(graph);
+  g->dealloc();
+  delete g;
+}
+
+void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
+                         float feat_drop, float score_drop) {
+  Graph* g = static_cast<Graph*>(graph);
+  LayerBox* b = new LayerBox{kind, nullptr, nullptr, nullptr};
+  if (kind == GAIBL_GCN) b->gcn = new GCN_layer(level, nv, din, dout, g, act != 0, lr, feat_drop, score_drop);
+  else if (kind == GAIBL_SAGE) b->sage = new SAGE_layer(level, nv, din, dout, g, act != 0, lr, feat_drop, score_drop);
+  else if (kind == GAIBL_GAT) b->gat = new GAT_layer(level, nv, din, dout, g, act != 0, lr, feat_drop, score_drop);
+  else {
+    fprintf(stderr, "gaibl_layer_create: unknown kind %d\n", kind);
+    exit(EXIT_FAILURE);
+  }
+  return b;
+}
+
+#define DISPATCH(b, call)                          \
+  do {                                             \
+    if ((b)->kind == GAIBL_GCN) (b)->gcn->call;    \
+    else if ((b)->kind == GAIBL_SAGE) (b)->sage->call; \
+    else (b)->gat->call;                           \
+  } while (0)
+
+void gaibl_layer_forward(void* layer, float* d_feat_out) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  DISPATCH(b, forward(d_feat_out));
+}
+void gaibl_layer_backward(void* layer, float* d_feat_out, float* d_grad_out) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  DISPATCH(b, backward(d_feat_out, d_grad_out));
+}
+void gaibl_layer_update_weight(void* layer, void* opt) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  DISPATCH(b, update_weight(static_cast<optimizer*>(opt)));
+}
+void gaibl_layer_set_feat_in(void* layer, float* p) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  DISPATCH(b, set_feat_in(p));
+}
+void gaibl_layer_set_phase(void* layer, int phase) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  net_phase ph = phase == 0 ? net_phase::TRAIN : (phase == 1 ? net_phase::TEST : net_phase::VAL);
+  DISPATCH(b, set_netphase(ph));
+}
+
+float* gaibl_layer_ptr(void* layer, int which) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  if (which <= GAIBL_W_SELF_GRAD) {
+    if (b->kind == GAIBL_GCN) return common_ptr(b->gcn, which);
+    if (b->kind == GAIBL_SAGE) return common_ptr(b->sage, which);
+    return common_ptr(b->gat, which);
+  }
+  if (b->kind != GAIBL_GAT) return nullptr;
+  GAT_Aggregator& a = b->gat->get_aggregator();
+  switch (which) {
+    case GAIBL_ALPHA_L: return a.alpha_l_ptr();
+    case GAIBL_ALPHA_R: return a.alpha_r_ptr();
+    case GAIBL_ALPHA_LGRAD: return a.alpha_lgrad_ptr();
+    case GAIBL_ALPHA_RGRAD: return a.alpha_rgrad_ptr();
+    case GAIBL_NORM_SCORES: return a.norm_scores_ptr();
+    case GAIBL_TEMP_SCORES: return a.temp_scores_ptr();
+    case GAIBL_SCORES: return a.scores_ptr();
+    case GAIBL_NORM_SCORES_GRAD: return a.norm_scores_grad_ptr();
+    default: return nullptr;
+  }
+}
+
+void* gaibl_adam_create(float lr) { return static_cast<optimizer*>(new adam(lr)); }
+void gaibl_adam_free(void* opt) { delete static_cast<optimizer*>(opt); }
+
+double gaibl_time_op(char op) { return time_ops[op]; }
+void gaibl_reset_timers(void) { time_ops.clear(); }
+}

@@ -1,0 +1,57 @@
+// context.cpp -- process-wide device context + per-op timers of the host API.
+#include <chrono>
+#include "gpu_context.h"
+#include "global.h"
+#include "host_util.h"
+
+std::map<char, double> time_ops;  // declared extern in include/gnn/global.h (reference: train.cpp:3)
+
+static gaib_ctx* g_ctx = nullptr;
+static bool g_sync_timers = false;
+
+void gpu_context::check(int status, const char* what) {
+  if (status == GAIB_OK) return;
+  // reference convention: report and exit (include/utils/cutils.h:18-28,133-174)
+  fprintf(stderr, "GPU error in %s: %s (status %d)\n", what, gaib_last_error(), status);
+  exit(EXIT_FAILURE);
+}
+
+void gpu_context::set(int device, void* hip_stream) {
+  if (g_ctx) {
+    gaib_ctx_destroy(g_ctx);
+    g_ctx = nullptr;
+  }
+  check(gaib_ctx_create(device, hip_stream, &g_ctx), "gaib_ctx_create");
+  const char* s = getenv("GAIB_SYNC_TIMERS");
+  g_sync_timers = s && atoi(s) != 0;
+}
+
+gaib_ctx* gpu_context::get() {
+  if (!g_ctx) {
+    int dev = 0;
+    if (const char* e = getenv("GAIB_DEVICE")) dev = atoi(e);
+    else if (const char* l = getenv("LOCAL_RANK")) dev = atoi(l);
+    set(dev, nullptr);
+  }
+  return g_ctx;
+}
+
+void gpu_context::sync() { check(gaib_sync(get()), "gaib_sync"); }
+
+namespace gaib_host {
+static double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+OpTimer::OpTimer(char op) : op_(op), t0_(0) {
+  if (g_sync_timers) {
+    gpu_context::sync();
+    t0_ = now();
+  }
+}
+OpTimer::~OpTimer() {
+  if (g_sync_timers) {
+    gpu_context::sync();
+    time_ops[op_] += now() - t0_;
+  }
+}
+}  // namespace gaib_host

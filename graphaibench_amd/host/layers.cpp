@@ -1,0 +1,183 @@
+// layers.cpp -- graph convolution layers (GCN / SAGE / GAT) over the aggregators and matmul.
+// Control flow follows the layer definitions of the reference (src/gnn/gconv/{gcn,sage,gat}_layer.cpp,
+// src/gnn/graph_conv_layer.cpp): which of GEMM / aggregation runs first, what is cached for the
+// weight gradient, the in-place d_relu on grad_in, and layer 0 skipping the input gradient.
+#include "graph_conv_layer.h"
+#include "host_util.h"
+#include "math_functions.hh"
+
+static inline gaib_ctx* C() { return gpu_context::get(); }
+
+template <typename Aggregator>
+graph_conv_layer<Aggregator>::graph_conv_layer(int id, int nv, int din, int dout, Graph* g, bool act,
+                                               bool concat, float lr, float feat_drop, float score_drop)
+    : level_(id), num_samples(nv), dim_in(din), dim_out(dout), graph(g), is_act(act), is_bias(false),
+      use_concat(concat), feat_dropout_rate(feat_drop), score_dropout_rate(score_drop),
+      phase_(net_phase::TRAIN), capacity_((size_t)nv), dropout_calls(0), feat_in(NULL), grad_in(NULL),
+      d_in_temp(NULL), d_in_temp1(NULL), d_out_temp(NULL), d_W_neigh(NULL), d_W_neigh_grad(NULL),
+      d_W_self(NULL), d_W_self_grad(NULL), dropout_mask(NULL), optm(NULL) {
+  assert(feat_dropout_rate >= 0. && feat_dropout_rate < 1.);
+  assert(score_dropout_rate >= 0. && score_dropout_rate < 1.);
+  feat_scale = 1. / (1. - feat_dropout_rate);
+  const size_t nin = (size_t)nv * din, nout = (size_t)nv * dout, nw = (size_t)din * dout;
+  // weights: Glorot with seed 1 for W_neigh of EVERY layer and seed 2 for W_self (Q7)
+  vec_t w;
+  init_glorot(din, dout, w, 1);
+  d_W_neigh = gaib_host::dmalloc<float>(nw);
+  d_W_neigh_grad = gaib_host::dmalloc<float>(nw);
+  GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_W_neigh, w.data(), sizeof(float) * nw));
+  GAIB_OR_DIE(gaib_fill_f32(C(), nw, 0.f, d_W_neigh_grad));
+  if (concat) {
+    init_glorot(din, dout, w, 2);
+    d_W_self = gaib_host::dmalloc<float>(nw);
+    d_W_self_grad = gaib_host::dmalloc<float>(nw);
+    GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_W_self, w.data(), sizeof(float) * nw));
+    GAIB_OR_DIE(gaib_fill_f32(C(), nw, 0.f, d_W_self_grad));
+  }
+  d_in_temp = gaib_host::dmalloc<float>(nin);
+  d_out_temp = gaib_host::dmalloc<float>(nout);
+  GAIB_OR_DIE(gaib_fill_f32(C(), nin, 0.f, d_in_temp));
+  GAIB_OR_DIE(gaib_fill_f32(C(), nout, 0.f, d_out_temp));
+  if (din <= dout) {
+    d_in_temp1 = gaib_host::dmalloc<float>(nin);
+    GAIB_OR_DIE(gaib_fill_f32(C(), nin, 0.f, d_in_temp1));
+  }
+  if (level_ > 0) {
+    feat_in = gaib_host::dmalloc<float>(nin);
+    GAIB_OR_DIE(gaib_fill_f32(C(), nin, 0.f, feat_in));
+  }
+  grad_in = gaib_host::dmalloc<float>(nout);
+  GAIB_OR_DIE(gaib_fill_f32(C(), nout, 0.f, grad_in));
+  if (feat_dropout_rate > 0.) dropout_mask = gaib_host::dmalloc<mask_t>(nin);
+  optm = new adam(lr);
+}
+
+template <typename Aggregator>
+void graph_conv_layer<Aggregator>::update_dim_size(size_t x) {
+  if (x > capacity_) {
+    fprintf(stderr, "update_dim_size(%zu): layer buffers were sized for %zu rows\n", x, capacity_);
+    exit(EXIT_FAILURE);
+  }
+  num_samples = (int)x;
+}
+
+template class graph_conv_layer<GCN_Aggregator>;
+template class graph_conv_layer<SAGE_Aggregator>;
+template class graph_conv_layer<GAT_Aggregator>;
+
+// ---- GCN ---------------------------------------------------------------------------------------
+void GCN_layer::forward(float* feat_out) {
+  const size_t x = num_samples, y = dim_in, z = dim_out;
+  float* in_data = feat_in;
+  if (feat_dropout_rate > 0. && phase_ == net_phase::TRAIN) {
+    dropout_gpu(x * y, feat_scale, feat_dropout_rate, in_data, dropout_mask, d_in_temp);
+    in_data = d_in_temp;
+  }
+  if (y > z) {  // shrink first, aggregate the narrow matrix
+    matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
+    aggr.aggregate(z, *graph, d_out_temp, feat_out);
+  } else {  // aggregate first; A.X is kept for the weight gradient
+    aggr.aggregate(y, *graph, in_data, d_in_temp1);
+    matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
+  }
+  if (is_act) relu_gpu(x * z, feat_out, feat_out);
+}
+
+void GCN_layer::backward(float* feat_out, float* grad_out) {
+  const size_t x = num_samples, y = dim_in, z = dim_out;
+  if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);  // in place, mask = post-activation output
+  if (y > z) {
+    aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
+    if (level_ > 0) matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);
+    float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
+    matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
+  } else {
+    if (level_ > 0) {
+      matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
+      aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+    }
+    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
+  }
+  if (level_ != 0 && feat_dropout_rate > 0.)
+    d_dropout_gpu(x * y, feat_scale, grad_out, dropout_mask, grad_out);
+}
+
+void GCN_layer::update_weight(optimizer* opt) {
+  opt->update_gpu((size_t)dim_in * dim_out, d_W_neigh_grad, d_W_neigh);  // the model's shared optimizer (Q6)
+}
+
+// ---- SAGE --------------------------------------------------------------------------------------
+void SAGE_layer::forward(float* feat_out) {
+  const size_t x = num_samples, y = dim_in, z = dim_out;
+  float* in_data = feat_in;
+  if (feat_dropout_rate > 0. && phase_ == net_phase::TRAIN) {
+    dropout_gpu(x * y, feat_scale, feat_dropout_rate, in_data, dropout_mask, d_in_temp);
+    in_data = d_in_temp;
+  }
+  if (y > z) {
+    matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
+    aggr.aggregate(z, *graph, d_out_temp, feat_out);
+  } else {
+    aggr.aggregate(y, *graph, in_data, d_in_temp1);
+    matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
+  }
+  matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);  // + X.W_self
+  if (is_act) relu_gpu(x * z, feat_out, feat_out);
+}
+
+void SAGE_layer::backward(float* feat_out, float* grad_out) {
+  const size_t x = num_samples, y = dim_in, z = dim_out;
+  if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
+  float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
+  matmul(y, z, x, in_data, grad_in, d_W_self_grad, true, false);
+  if (y > z) {
+    aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
+    if (level_ > 0) matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);
+    matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
+  } else {
+    if (level_ > 0) {
+      matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
+      aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+    }
+    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
+  }
+  if (level_ > 0) matmul(x, y, z, grad_in, d_W_self, grad_out, false, true, true);  // += g.W_self^T
+  if (level_ != 0 && feat_dropout_rate > 0.)
+    d_dropout_gpu(x * y, feat_scale, grad_out, dropout_mask, grad_out);
+}
+
+void SAGE_layer::update_weight(optimizer*) {
+  optm->update_gpu((size_t)dim_in * dim_out, d_W_neigh_grad, d_W_neigh);  // the layer's own optimizer
+  optm->update_gpu((size_t)dim_in * dim_out, d_W_self_grad, d_W_self);
+}
+
+// ---- GAT ---------------------------------------------------------------------------------------
+void GAT_layer::forward(float* feat_out) {
+  const size_t x = num_samples, y = dim_in, z = dim_out;
+  float* in_data = feat_in;
+  if (feat_dropout_rate > 0. && phase_ == net_phase::TRAIN) {
+    dropout_gpu(x * y, feat_scale, feat_dropout_rate, in_data, dropout_mask, d_in_temp);
+    in_data = d_in_temp;
+  }
+  matmul(x, z, y, in_data, d_W_neigh, d_out_temp);    // h = X.W
+  aggr.aggregate(z, *graph, d_out_temp, feat_out);    // attention over h
+  if (is_act) relu_gpu(x * z, feat_out, feat_out);
+}
+
+void GAT_layer::backward(float* feat_out, float* grad_out) {
+  const size_t x = num_samples, y = dim_in, z = dim_out;
+  if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
+  float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
+  // out_temp holds h on entry and the aggregated gradient on exit
+  aggr.d_aggregate(z, *graph, d_out_temp, grad_in, d_out_temp);
+  if (level_ != 0) {
+    matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);
+    if (feat_dropout_rate > 0.) d_dropout_gpu(x * y, feat_scale, grad_out, dropout_mask, grad_out);
+  }
+  matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true);
+}
+
+void GAT_layer::update_weight(optimizer* opt) {
+  opt->update_gpu((size_t)dim_in * dim_out, d_W_neigh_grad, d_W_neigh);
+  aggr.update_weights(opt);
+}

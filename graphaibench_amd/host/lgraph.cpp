@@ -1,0 +1,156 @@
+// lgraph.cpp -- LearningGraph: host CSR construction + HBM residency.
+// API parity with the reference class (include/gnn/lgraph.h, src/gnn/lgraph.{cpp,cu}); the
+// normalisers are computed by the device kernels behind gaib_graph_compute_*.
+#include "lgraph.h"
+#include "host_util.h"
+
+LearningGraph* LearningGraph::adopt_device(gaib_graph* g) {
+  LearningGraph* lg = new LearningGraph(true);
+  lg->num_vertices_ = (index_t)gaib_graph_nv(g);
+  lg->num_edges_ = (index_t)gaib_graph_ne(g);
+  lg->dev_ = g;
+  return lg;
+}
+
+void LearningGraph::allocateFrom(index_t nv, index_t ne) {
+  num_vertices_ = nv;
+  num_edges_ = ne;
+  rowptr_ = new index_t[(size_t)nv + 1];
+  colidx_ = new index_t[ne > 0 ? ne : 1];
+  rowptr_[0] = 0;
+}
+
+void LearningGraph::degree_counting() {
+  index_t m = 0;
+#pragma omp parallel for reduction(max : m)
+  for (int64_t v = 0; v < (int64_t)num_vertices_; v++) {
+    index_t d = rowptr_[v + 1] - rowptr_[v];
+    if (d > m) m = d;
+  }
+  max_degree = m;
+}
+
+// Insert v into row v, keeping the row sorted: entries <= v stay, v goes after them, the rest
+// shift by one; row v as a whole shifts by v.  Same result as the reference's single pass
+// (lgraph.h:185-218) for sorted rows without self loops (its precondition, Q16).
+void LearningGraph::add_selfloop() {
+  assert(rowptr_ && colidx_);
+  const size_t nv = num_vertices_;
+  index_t* nc = new index_t[(size_t)num_edges_ + nv];
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t v = 0; v < (int64_t)nv; v++) {
+    const index_t b = rowptr_[v], e = rowptr_[v + 1];
+    index_t* dst = nc + b + v;
+    index_t k = b;
+    while (k < e && colidx_[k] <= (index_t)v) *dst++ = colidx_[k++];
+    *dst++ = (index_t)v;
+    while (k < e) *dst++ = colidx_[k++];
+  }
+  for (size_t v = 0; v <= nv; v++) rowptr_[v] += (index_t)v;
+  delete[] colidx_;
+  colidx_ = nc;
+  num_edges_ += num_vertices_;
+  if (dev_) {  // the device copy is stale
+    gaib_graph_destroy(dev_);
+    dev_ = NULL;
+  }
+}
+
+LearningGraph* LearningGraph::generate_masked_graph(mask_t* masks) {
+  const size_t n = size();
+  LearningGraph* mg = new LearningGraph(is_device);
+  std::vector<index_t> off(n + 1, 0);
+  for (size_t s = 0; s < n; s++) {
+    index_t d = 0;
+    if (masks[s] == 1)
+      for (index_t e = rowptr_[s]; e < rowptr_[s + 1]; e++) d += masks[colidx_[e]] == 1;
+    off[s + 1] = off[s] + d;
+  }
+  mg->allocateFrom((index_t)n, off[n]);
+#pragma omp parallel for
+  for (int64_t s = 0; s < (int64_t)n; s++) {
+    mg->fixEndEdge((index_t)s, off[s + 1]);
+    if (masks[s] != 1) continue;
+    index_t idx = off[s];
+    for (index_t e = rowptr_[s]; e < rowptr_[s + 1]; e++)
+      if (masks[colidx_[e]] == 1) mg->constructEdge(idx++, colidx_[e]);
+  }
+  std::cout << "masked graph: num_vertices = " << mg->size() << ", num_edges = " << mg->sizeEdges() << "\n";
+  return mg;
+}
+
+void LearningGraph::alloc_on_device() { /* storage is created by copy_to_gpu (one hipMalloc set) */ }
+void LearningGraph::alloc_on_device(index_t) {}
+
+void LearningGraph::copy_to_gpu() {
+  assert(rowptr_ && colidx_);
+  if (dev_) gaib_graph_destroy(dev_);
+  dev_ = NULL;
+  GAIB_OR_DIE(gaib_graph_create(gpu_context::get(), num_vertices_, num_edges_, rowptr_, 32, colidx_, 0, &dev_));
+}
+
+void LearningGraph::copy_to_cpu() {
+  assert(dev_);
+  const int64_t nv = gaib_graph_nv(dev_), ne = gaib_graph_ne(dev_);
+  std::vector<int64_t> rp(nv + 1);
+  delete[] rowptr_;
+  delete[] colidx_;
+  allocateFrom((index_t)nv, (index_t)ne);
+  GAIB_OR_DIE(gaib_memcpy_d2h(gpu_context::get(), rp.data(), gaib_graph_rowptr(dev_), sizeof(int64_t) * (nv + 1)));
+  for (int64_t i = 0; i <= nv; i++) rowptr_[i] = (index_t)rp[i];
+  GAIB_OR_DIE(gaib_memcpy_d2h(gpu_context::get(), colidx_, gaib_graph_colidx(dev_), sizeof(index_t) * ne));
+}
+
+void LearningGraph::compute_vertex_data() {
+  if (!dev_) copy_to_gpu();
+  GAIB_OR_DIE(gaib_graph_compute_vertex_data(gpu_context::get(), dev_));
+  delete[] vertex_data_;
+  vertex_data_ = NULL;
+}
+
+void LearningGraph::compute_edge_data() {
+  if (!dev_) copy_to_gpu();
+  GAIB_OR_DIE(gaib_graph_compute_edge_data(gpu_context::get(), dev_));
+  delete[] edge_data_;
+  edge_data_ = NULL;
+}
+
+vdata_t LearningGraph::get_vertex_data(index_t vid) {
+  if (!vertex_data_) {
+    assert(dev_ && gaib_graph_vertex_data(dev_));
+    vertex_data_ = new vdata_t[num_vertices_];
+    GAIB_OR_DIE(gaib_memcpy_d2h(gpu_context::get(), vertex_data_, gaib_graph_vertex_data(dev_),
+                                sizeof(vdata_t) * num_vertices_));
+  }
+  return vertex_data_[vid];
+}
+
+edata_t LearningGraph::get_edge_data(index_t eid) {
+  if (!edge_data_) {
+    assert(dev_ && gaib_graph_edge_data(dev_));
+    edge_data_ = new edata_t[num_edges_];
+    GAIB_OR_DIE(gaib_memcpy_d2h(gpu_context::get(), edge_data_, gaib_graph_edge_data(dev_),
+                                sizeof(edata_t) * num_edges_));
+  }
+  return edge_data_[eid];
+}
+
+void LearningGraph::dealloc() {
+  delete[] rowptr_;
+  delete[] colidx_;
+  delete[] vertex_data_;
+  delete[] edge_data_;
+  rowptr_ = colidx_ = NULL;
+  vertex_data_ = edge_data_ = NULL;
+  if (dev_) gaib_graph_destroy(dev_);
+  dev_ = NULL;
+}
+
+void LearningGraph::print_graph() {
+  std::cout << "Printing the graph: \n";
+  for (index_t n = 0; n < num_vertices_; n++) {
+    std::cout << "vertex " << n << ": degree = " << get_degree(n) << " edgelist = [ ";
+    for (index_t e = rowptr_[n]; e != rowptr_[n + 1]; e++) std::cout << colidx_[e] << " ";
+    std::cout << "]\n";
+  }
+}

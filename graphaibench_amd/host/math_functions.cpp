@@ -1,0 +1,95 @@
+// math_functions.cpp -- the free-function math API of the layer path over include/gaib.h.
+#include <random>
+#include "math_functions.hh"
+#include "host_util.h"
+#include "lgraph.h"
+
+using gaib_host::OpTimer;
+static inline gaib_ctx* C() { return gpu_context::get(); }
+
+// Glorot-uniform from libstdc++'s default engine, seeded per weight matrix: the only way to get
+// the reference's exact initial weights (math_functions.cpp:11-18; golden: tests/golden/glorot_*).
+void init_glorot(size_t dim_x, size_t dim_y, vec_t& weight, unsigned seed) {
+  const float init_range = sqrt(6.0 / (dim_x + dim_y));
+  std::default_random_engine rng(seed);
+  std::uniform_real_distribution<float> dist(-init_range, init_range);
+  weight.resize(dim_x * dim_y);
+  for (size_t i = 0; i < dim_x * dim_y; ++i) weight[i] = dist(rng);
+}
+
+void matmul(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
+            float* C_, bool transA, bool transB, bool accum) {
+  OpTimer t(OP_DENSEMM);
+  GAIB_OR_DIE(gaib_sgemm(C(), transA, transB, (int64_t)x, (int64_t)y, (int64_t)z, A, B, accum, C_));
+}
+
+void init_const_gpu(int n, float_t value, float_t* array) { GAIB_OR_DIE(gaib_fill_f32(C(), n, value, array)); }
+void copy_gpu(int len, const float_t* in, float_t* out) {
+  GAIB_OR_DIE(gaib_memcpy_d2d(C(), out, in, sizeof(float) * (size_t)len));
+}
+void relu_gpu(const int n, const float_t* in, float_t* out) {
+  OpTimer t(OP_RELU);
+  GAIB_OR_DIE(gaib_relu(C(), n, in, out));
+}
+void d_relu_gpu(const int n, const float_t* in_diff, const float_t* data, float_t* out_diff) {
+  OpTimer t(OP_RELU);
+  GAIB_OR_DIE(gaib_d_relu(C(), n, in_diff, data, out_diff));
+}
+static uint64_t g_dropout_seed = 0x5EED;
+void dropout_gpu(int n, float scale, float drop_rate, const float* in, mask_t* masks, float* out) {
+  OpTimer t(OP_DROPOUT);
+  GAIB_OR_DIE(gaib_dropout(C(), n, scale, drop_rate, g_dropout_seed++, in, masks, out));
+}
+void d_dropout_gpu(int n, float scale, const float* in, const mask_t* masks, float* out) {
+  OpTimer t(OP_DROPOUT);
+  GAIB_OR_DIE(gaib_d_dropout(C(), n, scale, in, masks, out));
+}
+void l2norm(int n, int dim, const float* in, float* out) {
+  OpTimer t(OP_NORM);
+  GAIB_OR_DIE(gaib_l2norm(C(), n, dim, in, out));
+}
+void d_l2norm(int n, int dim, const float* feat_in, const float* grad_in, float* grad_out) {
+  OpTimer t(OP_NORM);
+  GAIB_OR_DIE(gaib_d_l2norm(C(), n, dim, feat_in, grad_in, grad_out));
+}
+void softmax_cross_entropy_gpu(int len, int begin, int end, const float_t* in_data, const mask_t* masks,
+                               const label_t* labels, float_t* loss, float_t* out_data) {
+  OpTimer t(OP_LOSS);
+  GAIB_OR_DIE(gaib_softmax_xent(C(), len, begin, end, in_data, masks, labels, loss, out_data));
+}
+void d_softmax_cross_entropy_gpu(int len, int begin, int end, const mask_t* masks, const label_t* labels,
+                                 const float_t* out_data, float_t* diff) {
+  OpTimer t(OP_LOSS);
+  GAIB_OR_DIE(gaib_d_softmax_xent(C(), len, begin, end, masks, labels, out_data, diff));
+}
+acc_t masked_avg_loss_gpu(int begin, int end, int, mask_t* masks, float_t* loss) {
+  float r = 0.f;
+  GAIB_OR_DIE(gaib_masked_avg_loss(C(), begin, end, masks, loss, &r));
+  return r;
+}
+float masked_accuracy_single(int begin, int end, int, int num_classes, mask_t* masks, float* preds,
+                             label_t* ground_truth) {
+  float r = 0.f;
+  GAIB_OR_DIE(gaib_masked_accuracy_single(C(), begin, end, num_classes, masks, preds, ground_truth, &r));
+  return r;
+}
+void symmetric_csr_transpose(LearningGraph& g, const float* A_nonzeros, float* B_nonzeros) {
+  OpTimer t(OP_TRANSPOSE);
+  GAIB_OR_DIE(gaib_edge_transpose(C(), g.device_graph(), A_nonzeros, B_nonzeros));
+}
+
+void float_malloc_device64(size_t n, float_t*& ptr) { ptr = gaib_host::dmalloc<float>(n); }
+void float_malloc_device(int n, float_t*& ptr) { ptr = gaib_host::dmalloc<float>((size_t)n); }
+void float_free_device(float_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }
+void copy_float_device(int n, float* h_ptr, float* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, sizeof(float) * (size_t)n)); }
+void copy_float_host(int n, const float* d_ptr, float* h_ptr) { GAIB_OR_DIE(gaib_memcpy_d2h(C(), h_ptr, d_ptr, sizeof(float) * (size_t)n)); }
+void uint_malloc_device(int n, uint32_t*& ptr) { ptr = gaib_host::dmalloc<uint32_t>((size_t)n); }
+void uint_free_device(uint32_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }
+void copy_uint_device(int n, uint32_t* h_ptr, uint32_t* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, sizeof(uint32_t) * (size_t)n)); }
+void uint8_malloc_device(int n, uint8_t*& ptr) { ptr = gaib_host::dmalloc<uint8_t>((size_t)n); }
+void uint8_free_device(uint8_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }
+void copy_uint8_device(int n, uint8_t* h_ptr, uint8_t* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, (size_t)n)); }
+void copy_masks_device(int n, mask_t* h_masks, mask_t*& d_masks) {
+  uint8_malloc_device(n, d_masks);
+  copy_uint8_device(n, h_masks, d_masks);
+}

@@ -189,6 +189,18 @@ int gaib_adam_step(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, floa
 int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_idx, int len,
                      const float* d_in, float* d_out);
 
+/* ---- in-stream kernel timing (measurement only) -----------------------------------------------
+ * When enabled, the aggregation entry points bracket each kernel launch with a HIP event pair
+ * on the context's stream (no host sync).  gaib_prof_get syncs the stream and returns the launch
+ * count and summed device time for a key: "spmm_light", "spmm_heavy", "spmm_sub", "sgemm". */
+int gaib_prof_enable(gaib_ctx* ctx, int on);
+int gaib_prof_reset(gaib_ctx* ctx);
+int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_total_ms);
+/* heavy-row split of a graph at the context's current threshold: rows / edges handled by the
+ * workgroup-per-row kernel, and the maximum degree */
+int gaib_graph_stats(gaib_ctx* ctx, gaib_graph* g, int64_t* h_n_heavy, int64_t* h_heavy_edges,
+                     int64_t* h_max_degree);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ---- */
 int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value);
 

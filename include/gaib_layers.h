@@ -1,0 +1,58 @@
+/*
+ * gaib_layers.h -- C handle API over the host C++ mirror (libgaib_gnn.so).
+ *
+ * The reference's layer/operator API is C++ (include/layers/graph_conv_layer.h,
+ * include/gnn/aggregator.h, include/gnn/lgraph.h); a C++ caller uses the classes of this repo's
+ * include/{gnn,layers,utils} directly.  This header exposes the SAME objects through opaque
+ * handles so that non-C++ harnesses (tests/, bench.py via ctypes) drive exactly the code path
+ * a linked GraphAIBench driver would: GCN_layer / SAGE_layer / GAT_layer ::forward / backward /
+ * update_weight on a LearningGraph.
+ */
+#ifndef GAIB_LAYERS_H
+#define GAIB_LAYERS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GAIBL_GCN = 0, GAIBL_SAGE = 1, GAIBL_GAT = 2 };
+/* gaibl_layer_ptr selectors (device pointers) */
+enum {
+  GAIBL_FEAT_IN = 0, GAIBL_GRAD_IN = 1, GAIBL_W_NEIGH = 2, GAIBL_W_NEIGH_GRAD = 3, GAIBL_W_SELF = 4,
+  GAIBL_W_SELF_GRAD = 5, GAIBL_ALPHA_L = 6, GAIBL_ALPHA_R = 7, GAIBL_ALPHA_LGRAD = 8,
+  GAIBL_ALPHA_RGRAD = 9, GAIBL_NORM_SCORES = 10, GAIBL_TEMP_SCORES = 11, GAIBL_SCORES = 12,
+  GAIBL_NORM_SCORES_GRAD = 13
+};
+
+void gaibl_init(int device, void* hip_stream); /* gpu_context::set */
+void* gaibl_ctx(void);                         /* gaib_ctx* of the process */
+void gaibl_sync(void);
+
+/* LearningGraph* built the way Model::load_data does (net.cpp:88-203): host CSR -> optional
+ * add_selfloop -> copy_to_gpu -> compute_vertex_data */
+void* gaibl_graph_from_host(uint32_t nv, uint32_t ne, const uint32_t* rowptr, const uint32_t* colidx,
+                            int add_selfloop);
+void* gaibl_graph_adopt(void* gaib_graph_handle); /* wrap a gaib_graph that already lives in HBM */
+void* gaibl_graph_device(void* graph);            /* gaib_graph* */
+uint64_t gaibl_graph_num_edges(void* graph);
+void gaibl_graph_free(void* graph);
+
+void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
+                         float feat_drop, float score_drop);
+void gaibl_layer_forward(void* layer, float* d_feat_out);
+void gaibl_layer_backward(void* layer, float* d_feat_out, float* d_grad_out);
+void gaibl_layer_update_weight(void* layer, void* optimizer);
+void gaibl_layer_set_feat_in(void* layer, float* d_ptr);
+void gaibl_layer_set_phase(void* layer, int phase); /* 0 TRAIN 1 TEST 2 VAL */
+float* gaibl_layer_ptr(void* layer, int which);
+
+void* gaibl_adam_create(float lr);
+void gaibl_adam_free(void* opt);
+
+double gaibl_time_op(char op); /* time_ops[op] (seconds); needs GAIB_SYNC_TIMERS=1 */
+void gaibl_reset_timers(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

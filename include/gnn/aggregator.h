@@ -1,0 +1,62 @@
+// include/gnn/aggregator.h -- the operator classes of the GNN layer path.
+// init / aggregate / d_aggregate (/ update_weights) with the reference's signatures
+// (include/gnn/aggregator.h:21-88); `in`/`out` are DEVICE pointers, `out` is fully overwritten.
+// Each call lowers to gaib_spmm / gaib_gat_* (include/gaib.h) on the process context.
+#pragma once
+#include "lgraph.h"
+#include "math_functions.hh"
+#include "optimizer.h"
+
+class aggregator {
+ public:
+  aggregator() : n(0), length(0) {}
+  void set_vlen(int vlen) { length = vlen; }
+
+ protected:
+  int n;
+  int length;  // feature vector length
+};
+
+// out[i,:] = sum_e (vd[i]*vd[col_e]) * in[col_e,:]; backward is the same operator (symmetric)
+class GCN_Aggregator : public aggregator {
+ public:
+  void init(int length, int nv, int ne = 0, float lr = 0.01, float drop_rate = 0.);
+  void aggregate(int len, Graph& g, const float* in, float* out);
+  void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
+};
+
+// forward: mean over neighbours (1/deg(i)); backward: its transpose (1/deg(col_e))
+class SAGE_Aggregator : public aggregator {
+ public:
+  void init(int length, int nv, int ne = 0, float lr = 0.01, float drop_rate = 0.);
+  void aggregate(int len, Graph& g, const float* in, float* out);
+  void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
+};
+
+// single-head attention: p = softmax_row(leaky_relu_0.2(a_l.h_i + a_r.h_j)); out = P h.
+// d_aggregate: alpha gradients + P^T g; no gradient through the scores into h (Q18).
+class GAT_Aggregator : public aggregator {
+ public:
+  GAT_Aggregator();
+  void init(int length, int nv, int ne = 0, float lr = 0.01, float drop_rate = 0.);
+  void aggregate(int len, Graph& g, const float* in, float* out);
+  void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
+  void update_weights(optimizer* opt);
+  // device state (tests / checkpoints)
+  float* alpha_l_ptr() { return d_alpha_l; }
+  float* alpha_r_ptr() { return d_alpha_r; }
+  float* alpha_lgrad_ptr() { return d_alpha_lgrad; }
+  float* alpha_rgrad_ptr() { return d_alpha_rgrad; }
+  float* norm_scores_ptr() { return d_norm_scores; }
+  float* temp_scores_ptr() { return d_temp_scores; }
+  float* scores_ptr() { return d_scores; }
+  float* norm_scores_grad_ptr() { return d_norm_scores_grad; }
+
+ private:
+  float epsilon;    // LeakyReLU negative slope (0.2)
+  float attn_drop;  // attention dropout: accepted, not applied (reference CPU path has it commented out)
+  size_t num_edges;
+  float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
+  float *d_scores, *d_temp_scores, *d_norm_scores, *d_norm_scores_grad;
+  optimizer* alpha_opt;
+};

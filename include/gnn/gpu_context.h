@@ -1,0 +1,16 @@
+// include/gnn/gpu_context.h -- process-wide device context of the host API.
+// Takes the place of the reference's static cuBLAS/cuSPARSE/cuRAND handle holder
+// (reference: include/gnn/gpu_context.h:4-16, src/utilities/random.cpp:62-80): one gaib_ctx
+// (device + HIP stream + workspace) per process, created on first use.  Device = $GAIB_DEVICE
+// or $LOCAL_RANK or 0 (one process per GPU).
+#pragma once
+#include "gaib.h"
+
+class gpu_context {
+ public:
+  static gaib_ctx* get();                        // lazily created
+  static void set(int device, void* hip_stream); // explicit (multi-GPU launchers, tests)
+  static void sync();                            // CudaTest() equivalent
+  static void check(int status, const char* what); // non-zero -> print + exit (cutils.h:18-28)
+};
+#define GAIB_OR_DIE(call) gpu_context::check((call), #call)

@@ -1,0 +1,83 @@
+// include/gnn/lgraph.h -- LearningGraph: CSR container of the GNN path, host arrays plus the
+// HBM-resident copy the aggregation kernels read.
+// API mirrors the reference class (include/gnn/lgraph.h:20-277): the reader writes through
+// row_host_ptr()/edge_host_ptr(), the model calls add_selfloop / alloc_on_device / copy_to_gpu /
+// compute_vertex_data / compute_edge_data, layers only hold a Graph*.
+// Not mirrored (dead or out of scope in the reference itself): CSR segmenting (lgraph.cpp:55-157
+// is commented out there), print_test.
+#pragma once
+#include <algorithm>
+#include "global.h"
+#include "gaib.h"
+
+class LearningGraph {
+ protected:
+  bool is_device;
+  index_t num_vertices_;
+  index_t num_edges_;
+  index_t max_degree;
+  index_t* rowptr_;  // host, [nv+1]
+  index_t* colidx_;  // host, [ne]
+  vdata_t* vertex_data_;  // host copies, filled on demand
+  edata_t* edge_data_;
+  gaib_graph* dev_;  // CSR + normalisers + kernel schedules in HBM
+
+ public:
+  typedef size_t iterator;
+  LearningGraph(bool use_gpu)
+      : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
+        colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL) {}
+  LearningGraph() : LearningGraph(true) {}
+  // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
+  static LearningGraph* adopt_device(gaib_graph* g);
+
+  size_t size() { return (size_t)num_vertices_; }
+  size_t sizeEdges() { return (size_t)num_edges_; }
+  bool on_device() { return is_device; }
+  index_t get_max_degree() { return max_degree; }
+  index_t get_degree(index_t v) { return rowptr_[v + 1] - rowptr_[v]; }
+  iterator begin() const { return iterator(0); }
+  iterator end() const { return iterator(num_vertices_); }
+
+  // construction on the host (what Reader::bin_read_graph drives, reader.cpp:414-457)
+  void allocateFrom(index_t nv, index_t ne);
+  void fixEndEdge(index_t vid, index_t row_end) { rowptr_[vid + 1] = row_end; }
+  void constructEdge(index_t eid, index_t dst) {
+    assert(dst < num_vertices_ && eid < num_edges_);
+    colidx_[eid] = dst;
+  }
+  index_t* row_start_host_ptr() { return rowptr_; }
+  index_t*& row_host_ptr() { return rowptr_; }
+  index_t* edge_dst_host_ptr() { return colidx_; }
+  index_t*& edge_host_ptr() { return colidx_; }
+  index_t getEdgeDstHost(index_t eid) { return colidx_[eid]; }
+  index_t edge_begin_host(index_t vid) { return rowptr_[vid]; }
+  index_t edge_end_host(index_t vid) { return rowptr_[vid + 1]; }
+  void degree_counting();
+  void add_selfloop();  // host CSR, sorted insert (rows must be sorted, no self loops)
+  LearningGraph* generate_masked_graph(mask_t* masks);
+
+  // device side
+  void alloc_on_device();
+  void alloc_on_device(index_t n);
+  void copy_to_gpu();
+  void copy_to_cpu();
+  void compute_vertex_data();
+  void compute_edge_data();
+  void dealloc();
+  gaib_graph* device_graph() { return dev_; }
+  // device pointers, as the reference's ENABLE_GPU accessors return them.  Row pointers are
+  // int64 in HBM (the reference's uint32 offsets overflow past 2^32 edges*features).
+  const int64_t* row_start_ptr() const { return gaib_graph_rowptr(dev_); }
+  const index_t* edge_dst_ptr() const { return gaib_graph_colidx(dev_); }
+  const edata_t* edge_data_ptr() const { return gaib_graph_edge_data(dev_); }
+  const vdata_t* vertex_data_ptr() const { return gaib_graph_vertex_data(dev_); }
+  // host-side values (copied back on first use; tests)
+  vdata_t get_vertex_data(index_t vid);
+  edata_t get_edge_data(index_t eid);
+  void print_graph();
+};
+
+typedef LearningGraph Graph;
+typedef LearningGraph GraphCPU;
+typedef LearningGraph GraphGPU;

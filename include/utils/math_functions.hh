@@ -1,0 +1,47 @@
+// include/utils/math_functions.hh -- free-function math API of the layer path, device pointers.
+// Same names and argument meaning as the reference's GPU build (include/utils/math_functions.hh:
+// 14-174, src/utilities/math_functions.cu); every function is a thin wrapper over include/gaib.h.
+// Errors follow the reference convention: message on stderr, then exit (cutils.h:18-28).
+#pragma once
+#include "global.h"
+
+void init_glorot(size_t dim_x, size_t dim_y, vec_t& weight, unsigned seed);  // host, libstdc++ RNG
+
+// C[x*y] (=|+=) op(A)[x*z] . op(B)[z*y], row-major, device pointers (math_functions.cpp:166-171)
+void matmul(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
+            float* C, bool transA = false, bool transB = false, bool accum = false);
+
+void init_const_gpu(int n, float_t value, float_t* array);
+void copy_gpu(int len, const float_t* in, float_t* out);
+void relu_gpu(const int n, const float_t* in, float_t* out);
+void d_relu_gpu(const int n, const float_t* in_diff, const float_t* data, float_t* out_diff);
+void dropout_gpu(int n, float scale, float drop_rate, const float* in, mask_t* masks, float* out);
+void d_dropout_gpu(int n, float scale, const float* in, const mask_t* masks, float* out);
+void l2norm(int n, int dim, const float* in, float* out);
+void d_l2norm(int n, int dim, const float* feat_in, const float* grad_in, float* grad_out);
+void softmax_cross_entropy_gpu(int len, int begin, int end, const float_t* in_data,
+                               const mask_t* masks, const label_t* labels, float_t* loss,
+                               float_t* out_data);
+void d_softmax_cross_entropy_gpu(int len, int begin, int end, const mask_t* masks,
+                                 const label_t* labels, const float_t* out_data, float_t* diff);
+acc_t masked_avg_loss_gpu(int begin, int end, int count, mask_t* masks, float_t* loss);
+float masked_accuracy_single(int begin, int end, int count, int num_classes, mask_t* masks,
+                             float* preds, label_t* ground_truth);
+// symmetric sparse transpose of per-edge values on the device graph (math_functions.cpp:46-74)
+class LearningGraph;
+void symmetric_csr_transpose(LearningGraph& g, const float* A_nonzeros, float* B_nonzeros);
+
+// memory helpers (math_functions.hh:161-173)
+void float_malloc_device(int n, float_t*& ptr);
+void float_free_device(float_t*& ptr);
+void copy_float_device(int n, float* h_ptr, float* d_ptr);
+void copy_float_host(int n, const float* d_ptr, float* h_ptr);
+void uint_malloc_device(int n, uint32_t*& ptr);
+void uint_free_device(uint32_t*& ptr);
+void copy_uint_device(int n, uint32_t* h_ptr, uint32_t* d_ptr);
+void uint8_malloc_device(int n, uint8_t*& ptr);
+void uint8_free_device(uint8_t*& ptr);
+void copy_uint8_device(int n, uint8_t* h_ptr, uint8_t* d_ptr);
+void copy_masks_device(int n, mask_t* h_masks, mask_t*& d_masks);
+// 64-bit element counts (N*D of the large graphs exceeds int)
+void float_malloc_device64(size_t n, float_t*& ptr);

@@ -1,0 +1,194 @@
+"""GPU parity suite, layer level: GCN_layer / SAGE_layer / GAT_layer ::forward / backward /
+update_weight (the host C++ mirror of include/layers/graph_conv_layer.h over the C ABI) against
+the oracle's layer compositions on the same seeded inputs and the same Glorot weights.
+Tolerance: the north star's 1e-4 (norm-wise), covering the GEMM summation-order difference."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from graphaibench_amd import layers as L
+from oracle import binding as orc
+from util import random_graph, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _ctx():
+    return L.init(0)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def feat(n, d, seed):
+    return np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+
+
+def cora():
+    rp = np.fromfile(GOLD / "cora" / "graph.vertex.bin", np.int64)
+    ci = np.fromfile(GOLD / "cora" / "graph.edge.bin", np.uint32)
+    return rp, ci
+
+
+def cora_features(seed=0):
+    """sparse-binary, row-normalised like the real cora matrix (F = 1433)"""
+    rng = np.random.default_rng(seed)
+    x = (rng.random((2708, 1433)) < 0.0127).astype(np.float32)
+    x[np.arange(2708), rng.integers(0, 1433, 2708)] = 1.0
+    return x / x.sum(1, keepdims=True)
+
+
+@pytest.mark.parametrize("din,dout,level,act", [(1433, 16, 0, True), (16, 7, 1, False), (16, 33, 1, True), (128, 128, 1, True)])
+def test_gcn_layer_cora(din, dout, level, act):
+    rp, ci = cora()
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
+    assert g_d.ne == g_o.ne
+    x = cora_features() if din == 1433 else feat(2708, din, 1)
+    lo = orc.GCNLayer(level, g_o, din, dout, act)
+    ld = L.Layer(L.GCN, level, 2708, din, dout, g_d, act)
+    # same initial weights: Glorot seed 1 (golden-pinned against libstdc++)
+    assert np.array_equal(ld.tensor(L.W_NEIGH, (din, dout)).cpu().numpy(), lo.W)
+    xd = dev(x)
+    if level == 0:
+        ld.set_feat_in(xd)
+    else:
+        ld.write(L.FEAT_IN, xd)
+    out = torch.empty(2708, dout, device="cuda")
+    ld.forward(out)
+    want = lo.forward(x)
+    assert rel_err(out.cpu().numpy(), want) < TOL
+    gin = feat(2708, dout, 2)
+    ld.write(L.GRAD_IN, dev(gin))
+    grad_out = torch.zeros(2708, din, device="cuda") if level > 0 else None
+    ld.backward(out, grad_out)
+    gin_o = gin.copy()
+    want_go = lo.backward(gin_o)
+    assert rel_err(ld.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), lo.W_grad) < TOL
+    # d_relu ran in place on grad_in (Q9)
+    assert rel_err(ld.tensor(L.GRAD_IN, (2708, dout)).cpu().numpy(), gin_o) < TOL
+    if level > 0:
+        assert rel_err(grad_out.cpu().numpy(), want_go) < TOL
+
+
+@pytest.mark.parametrize("din,dout,level", [(100, 128, 0), (128, 128, 1), (128, 47, 2), (47, 128, 1)])
+def test_sage_layer_powerlaw(din, dout, level):
+    rp, ci = random_graph(4096, 32, seed=5, power_law=True)
+    g_o = orc.Graph(rp, ci)
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=False)
+    n = g_o.nv
+    x = feat(n, din, 3)
+    lo = orc.SAGELayer(level, g_o, din, dout, True)
+    ld = L.Layer(L.SAGE, level, n, din, dout, g_d, True)
+    assert np.array_equal(ld.tensor(L.W_SELF, (din, dout)).cpu().numpy(), lo.W_self)
+    xd = dev(x)
+    ld.set_feat_in(xd) if level == 0 else ld.write(L.FEAT_IN, xd)
+    out = torch.empty(n, dout, device="cuda")
+    ld.forward(out)
+    assert rel_err(out.cpu().numpy(), lo.forward(x)) < TOL
+    gin = feat(n, dout, 4)
+    ld.write(L.GRAD_IN, dev(gin))
+    grad_out = torch.zeros(n, din, device="cuda") if level > 0 else None
+    ld.backward(out, grad_out)
+    want_go = lo.backward(gin.copy())
+    assert rel_err(ld.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), lo.W_neigh_grad) < TOL
+    assert rel_err(ld.tensor(L.W_SELF_GRAD, (din, dout)).cpu().numpy(), lo.W_self_grad) < TOL
+    if level > 0:
+        assert rel_err(grad_out.cpu().numpy(), want_go) < TOL
+
+
+@pytest.mark.parametrize("din,dout,level", [(100, 64, 0), (64, 64, 1), (64, 8, 1)])
+def test_gat_layer(din, dout, level):
+    rp, ci = random_graph(4096, 24, seed=9, power_law=True, hub_deg=1500)
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
+    n = g_o.nv
+    x = feat(n, din, 3)
+    lo = orc.GATLayer(level, g_o, din, dout, True, fast=True)
+    ld = L.Layer(L.GAT, level, n, din, dout, g_d, True)
+    assert np.array_equal(ld.tensor(L.ALPHA_L, (dout,)).cpu().numpy(), lo.alpha_l)
+    assert np.array_equal(ld.tensor(L.ALPHA_R, (dout,)).cpu().numpy(), lo.alpha_r)
+    xd = dev(x)
+    ld.set_feat_in(xd) if level == 0 else ld.write(L.FEAT_IN, xd)
+    out = torch.empty(n, dout, device="cuda")
+    ld.forward(out)
+    assert rel_err(out.cpu().numpy(), lo.forward(x)) < TOL
+    assert rel_err(ld.tensor(L.NORM_SCORES, (g_o.ne,)).cpu().numpy(), lo.norm_scores) < TOL
+    gin = feat(n, dout, 4)
+    ld.write(L.GRAD_IN, dev(gin))
+    grad_out = torch.zeros(n, din, device="cuda") if level > 0 else None
+    ld.backward(out, grad_out)
+    want_go = lo.backward(gin.copy())
+    assert rel_err(ld.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), lo.W_grad) < TOL
+    assert rel_err(ld.tensor(L.ALPHA_LGRAD, (dout,)).cpu().numpy(), lo.alpha_lgrad) < TOL
+    assert rel_err(ld.tensor(L.ALPHA_RGRAD, (dout,)).cpu().numpy(), lo.alpha_rgrad) < TOL
+    if level > 0:
+        assert rel_err(grad_out.cpu().numpy(), want_go) < TOL
+
+
+def test_gcn_training_steps_track_oracle():
+    """5 full-batch steps of a 2-layer GCN on cora topology (hidden 16): forward, softmax loss,
+    backward, shared-Adam update (Q6) -- loss curve and weights vs the oracle."""
+    from graphaibench_amd import capi
+
+    ctx = L.init(0)
+    rp, ci = cora()
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
+    n, F, H, Cn = 2708, 1433, 16, 7
+    x = cora_features()
+    labels = np.fromfile(GOLD / "cora" / "graph.vlabel.bin", np.uint8)
+    begin, end = 0, 140
+    masks = np.zeros(n, np.uint8)
+    masks[begin:end] = 1
+    lr = 0.01
+    # oracle model
+    o0, o1 = orc.GCNLayer(0, g_o, F, H, True), orc.GCNLayer(1, g_o, H, Cn, False)
+    oopt = orc.Adam(lr)
+    # device model
+    d0, d1 = L.Layer(L.GCN, 0, n, F, H, g_d, True, lr), L.Layer(L.GCN, 1, n, H, Cn, g_d, False, lr)
+    dopt = L.adam(lr)
+    xd, labd, md = dev(x), dev(labels), dev(masks)
+    d0.set_feat_in(xd)
+    h1 = torch.empty(0)  # layer 1's feat_in is owned by layer 1
+    logits = torch.zeros(n, Cn, device="cuda")
+    probs = torch.zeros(n, Cn, device="cuda")
+    loss_v = torch.zeros(n, device="cuda")
+    feat1_ptr = d1.ptr(L.FEAT_IN)
+    grad1_ptr = d1.ptr(L.GRAD_IN)
+    grad0_ptr = d0.ptr(L.GRAD_IN)
+    lib = L.load()
+    losses_o, losses_d = [], []
+    for step in range(5):
+        # oracle
+        a1 = o0.forward(x)
+        lg = o1.forward(a1)
+        p, lv = orc.softmax_xent_fwd(lg, labels, begin, end, masks)
+        losses_o.append(orc.masked_avg_loss(lv, begin, end, masks))
+        g1 = orc.softmax_xent_bwd(p, labels, begin, end, masks)
+        g0 = o1.backward(g1)
+        o0.backward(g0)
+        oopt.update("w0", o0.W_grad, o0.W)  # one shared optimizer, layer order 0..L-1 (net.cpp:229-234)
+        oopt.update("w1", o1.W_grad, o1.W)
+        # device: layer0.forward(layer1.feat_in); layer1.forward(logits)
+        lib.gaibl_layer_forward(d0.h, feat1_ptr)
+        d1.forward(logits)
+        ctx.softmax_xent(logits, labd, loss_v, probs, begin, end, md)
+        losses_d.append(ctx.masked_avg_loss(loss_v, begin, end, md))
+        capi._check(ctx.lib.gaib_fill_f32(ctx.h, n * Cn, 0.0, grad1_ptr), "fill")
+        capi._check(ctx.lib.gaib_d_softmax_xent(ctx.h, Cn, begin, end, md.data_ptr(), labd.data_ptr(),
+                                                probs.data_ptr(), grad1_ptr), "d_softmax_xent")
+        lib.gaibl_layer_backward(d1.h, logits.data_ptr(), grad0_ptr)
+        lib.gaibl_layer_backward(d0.h, feat1_ptr, None)
+        d0.update_weight(dopt)
+        d1.update_weight(dopt)
+    assert np.allclose(losses_o, losses_d, rtol=1e-4, atol=1e-5), (losses_o, losses_d)
+    assert losses_o[-1] < losses_o[0]
+    assert rel_err(d0.tensor(L.W_NEIGH, (F, H)).cpu().numpy(), o0.W) < 1e-3
+    assert rel_err(d1.tensor(L.W_NEIGH, (H, Cn)).cpu().numpy(), o1.W) < 1e-3
