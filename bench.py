@@ -111,11 +111,12 @@ def main():
 
     ctx = L.init(local_rank)
 
-    if world > 1:
+    if world > 1 or os.environ.get("GAIB_FORCE_DIST") == "1":  # the env knob runs the N>1 code on one GPU
         import torch.distributed as dist
         from graphaibench_amd import dist as gdist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log)
         if rank == 0:

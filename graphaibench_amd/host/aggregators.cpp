@@ -18,12 +18,12 @@ void GCN_Aggregator::init(int l, int nv, int, float, float) {
 }
 void GCN_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, in, out));
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, g.halo_prepare(len, in), out));
 }
 // the normalised adjacency is symmetric, so the derivative is the same operator
 void GCN_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, grad_in, grad_out));
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, g.halo_prepare(len, grad_in), grad_out));
 }
 
 // ---- SAGE --------------------------------------------------------------------------------------
@@ -33,11 +33,11 @@ void SAGE_Aggregator::init(int l, int nv, int, float, float) {
 }
 void SAGE_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN, NULL, len, in, out));
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN, NULL, len, g.halo_prepare(len, in), out));
 }
 void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN_T, NULL, len, grad_in, grad_out));
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN_T, NULL, len, g.halo_prepare(len, grad_in), grad_out));
 }
 
 // ---- GAT ---------------------------------------------------------------------------------------

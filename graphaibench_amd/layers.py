@@ -26,6 +26,7 @@ SIGNATURES = {
     "gaibl_graph_device": (_vp, [_vp]),
     "gaibl_graph_num_edges": (C.c_uint64, [_vp]),
     "gaibl_graph_free": (None, [_vp]),
+    "gaibl_graph_set_halo_hook": (None, [_vp, _vp, _vp]),
     "gaibl_layer_create": (_vp, [_i, _i, _i, _i, _i, _vp, _i, _f, _f, _f]),
     "gaibl_layer_forward": (None, [_vp, _vp]),
     "gaibl_layer_backward": (None, [_vp, _vp, _vp]),
@@ -114,6 +115,16 @@ class LGraph:
     @property
     def ne(self) -> int:
         return int(load().gaibl_graph_num_edges(self.h))
+
+    def set_halo_hook(self, fn):
+        """fn(len:int, d_in:int) -> int (device pointer of the [nc x len] feature table)"""
+        HOOK = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+        def tramp(_user, length, d_in):
+            return fn(int(length), int(d_in or 0))
+
+        self._hook = HOOK(tramp)  # keep the trampoline alive
+        load().gaibl_graph_set_halo_hook(self.h, C.cast(self._hook, C.c_void_p), None)
 
 
 class Layer:

@@ -98,3 +98,100 @@ def make(name: str, seed: int = 42, device="cuda", scale: float = 1.0) -> SynthG
     nnz_s = max(int(nnz * scale), 32)
     max_s = max(min(max_deg, nv_s // 4), 4)
     return chung_lu(name, nv_s, nnz_s, max_s, seed, device)
+
+
+# ---- block generator for the multi-GPU bench -------------------------------------------------------
+@dataclass
+class BlockRows:
+    """one rank's rows of a global graph made of `world` products-shaped vertex ranges"""
+    rowptr: torch.Tensor         # int64 [n_local+1]
+    colidx_global: torch.Tensor  # int64 [ne_local], GLOBAL column ids, rows sorted
+    n_global: int
+    n_local: int
+
+
+def _part_sampler(nv_p: int, nnz_p: int, max_deg: int, seed: int, p: int, device):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 1009 + p)
+    w = _weights(nv_p, nnz_p / nv_p, max_deg, device)
+    perm = torch.randperm(nv_p, generator=gen, device=device)
+    cdf = torch.cumsum(w, 0)
+    return cdf / cdf[-1], perm
+
+
+def _sample(cdf, perm, k: int, gen, device):
+    out = []
+    step = 1 << 24
+    for s in range(0, k, step):
+        r = torch.rand(min(step, k - s), dtype=torch.float64, generator=gen, device=device)
+        out.append(perm[torch.searchsorted(cdf, r).clamp_(max=perm.numel() - 1)])
+    return torch.cat(out) if out else torch.empty(0, dtype=torch.int64, device=device)
+
+
+def block_rows(name: str, rank: int, world: int, seed: int = 42, cut_fraction: float = 0.1, device="cuda",
+               scale: float = 1.0, selfloops: bool = False) -> BlockRows:
+    """Rows [rank*nv_p, (rank+1)*nv_p) of a symmetric global graph with world*nv_p vertices.  Each
+    vertex range is a Chung-Lu graph of the named shape; a fraction `cut_fraction` of a range's
+    stored entries point into the other ranges (spread evenly, endpoints drawn by the same
+    power-law weights).  Block (p, q) is generated from a seed shared by p and q, so both owners
+    see the same undirected edges.  cut_fraction models the partitioner: ~(world-1)/world is a
+    random vertex order, small values a locality-preserving (METIS-like) order."""
+    device = torch.device(device)
+    nv, nnz, max_deg, _, _ = SHAPES[name]
+    nv_p = max(int(nv * scale), 16)
+    nnz_p = max(int(nnz * scale), 32)
+    max_p = max(min(max_deg, nv_p // 4), 4)
+    n_global = nv_p * world
+    lo = rank * nv_p
+    cut = cut_fraction if world > 1 else 0.0
+    samplers = {}
+
+    def sampler(p):
+        if p not in samplers:
+            samplers[p] = _part_sampler(nv_p, nnz_p, max_p, seed, p, device)
+        return samplers[p]
+
+    keys = []
+    # intra-range block
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 7919 + rank * 65537 + rank)
+    cdf, perm = sampler(rank)
+    m_in = int((1.0 - cut) * nnz_p / 2)
+    u = _sample(cdf, perm, m_in, gen, device)
+    v = _sample(cdf, perm, m_in, gen, device)
+    keep = u != v
+    u, v = u[keep], v[keep]
+    keys.append(u * n_global + (v + lo))
+    keys.append(v * n_global + (u + lo))
+    del u, v
+    # cross blocks
+    if world > 1 and cut > 0:
+        m_x = int(cut * nnz_p / (world - 1))
+        for q in range(world):
+            if q == rank:
+                continue
+            a_p, b_p = min(rank, q), max(rank, q)
+            gen = torch.Generator(device=device)
+            gen.manual_seed(seed * 7919 + a_p * 65537 + b_p)
+            ca, pa = sampler(a_p)
+            cb, pb = sampler(b_p)
+            a = _sample(ca, pa, m_x, gen, device)  # local id in range a_p
+            b = _sample(cb, pb, m_x, gen, device)  # local id in range b_p
+            if rank == a_p:
+                keys.append(a * n_global + (b + b_p * nv_p))
+            else:
+                keys.append(b * n_global + (a + a_p * nv_p))
+            del a, b
+            if q != rank:
+                samplers.pop(q, None)
+    if selfloops:
+        i = torch.arange(nv_p, dtype=torch.int64, device=device)
+        keys.append(i * n_global + (i + lo))
+    key = torch.unique(torch.cat(keys))  # sorted by (row, col), duplicate-free
+    del keys
+    rows = key // n_global
+    cols = key - rows * n_global
+    counts = torch.bincount(rows, minlength=nv_p)
+    rowptr = torch.zeros(nv_p + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    return BlockRows(rowptr, cols, n_global, nv_p)

@@ -36,6 +36,9 @@ void* gaibl_graph_adopt(void* gaib_graph_handle); /* wrap a gaib_graph that alre
 void* gaibl_graph_device(void* graph);            /* gaib_graph* */
 uint64_t gaibl_graph_num_edges(void* graph);
 void gaibl_graph_free(void* graph);
+/* partitioned graphs: hook called before every aggregation (LearningGraph::set_halo_hook) */
+typedef const float* (*gaibl_halo_fn)(void* user, int len, const float* d_in);
+void gaibl_graph_set_halo_hook(void* graph, gaibl_halo_fn fn, void* user);
 
 void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
                          float feat_drop, float score_drop);

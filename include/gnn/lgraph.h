@@ -21,12 +21,18 @@ class LearningGraph {
   vdata_t* vertex_data_;  // host copies, filled on demand
   edata_t* edge_data_;
   gaib_graph* dev_;  // CSR + normalisers + kernel schedules in HBM
+  // vertex-range partitions: called before every aggregation with the owned rows [nv x len];
+  // returns the feature table [nc x len] (owned rows first, halo rows after) the local CSR's
+  // column ids index.  No reference counterpart.
+  const float* (*halo_hook_)(void* user, int len, const float* d_in);
+  void* halo_user_;
 
  public:
   typedef size_t iterator;
   LearningGraph(bool use_gpu)
       : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
-        colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL) {}
+        colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_hook_(NULL),
+        halo_user_(NULL) {}
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -66,6 +72,13 @@ class LearningGraph {
   void compute_edge_data();
   void dealloc();
   gaib_graph* device_graph() { return dev_; }
+  void set_halo_hook(const float* (*fn)(void*, int, const float*), void* user) {
+    halo_hook_ = fn;
+    halo_user_ = user;
+  }
+  const float* halo_prepare(int len, const float* d_in) {
+    return halo_hook_ ? halo_hook_(halo_user_, len, d_in) : d_in;
+  }
   // device pointers, as the reference's ENABLE_GPU accessors return them.  Row pointers are
   // int64 in HBM (the reference's uint32 offsets overflow past 2^32 edges*features).
   const int64_t* row_start_ptr() const { return gaib_graph_rowptr(dev_); }

@@ -1,0 +1,116 @@
+"""CPU suite, world_size 2 and 3 over gloo: vertex-range partitioning + halo exchange
+(graphaibench_amd/dist.py) reproduce the single-process result.  The local SpMM is done by the
+oracle here (no GPU in this container); the GPU path uses the same Partition / HaloExchanger."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphaibench_amd import dist as gd
+        from oracle import binding as orc
+        from util import random_graph, rel_err
+
+        rp, ci = random_graph(1500, 12, seed=77, power_law=True)
+        g = orc.Graph(rp, ci).add_selfloop()
+        n, D = g.nv, 24
+        x = np.random.default_rng(5).standard_normal((n, D)).astype(np.float32)
+        want_gcn = orc.gcn_aggregate(g, x)
+        want_mean_t = orc.sage_d_aggregate(g, x)
+        # this rank's rows of the global CSR
+        b = gd.partition_bounds(n, world)
+        lo, hi = b[rank], b[rank + 1]
+        e0, e1 = g.rowptr[lo], g.rowptr[hi]
+        rp_l = torch.from_numpy((g.rowptr[lo:hi + 1] - e0).astype(np.int64))
+        ci_g = torch.from_numpy(g.colidx[e0:e1].astype(np.int64))
+        part = gd.build_partition(rp_l, ci_g, n, rank, world)
+        assert part.n_own == hi - lo
+        # local -> global map round trip
+        l2g = torch.cat([torch.arange(lo, hi), part.halo_gids])
+        assert torch.equal(l2g[part.colidx.long()], ci_g)
+        ex = gd.HaloExchanger(part)
+        table = torch.zeros(part.n_table, D)
+        table[:part.n_own] = torch.from_numpy(x[lo:hi])
+        ex.exchange(table)
+        assert torch.equal(table, torch.from_numpy(x)[l2g]), "halo rows must equal their owners' rows"
+        vd, inv = gd.global_normalisers(part, ex)
+        vd_g = g.vertex_data()
+        assert np.array_equal(vd.numpy(), vd_g[l2g.numpy()])
+        # local aggregation over [owned | halo] == the rows of the global result
+        lg = orc.Graph(part.rowptr.numpy(), part.colidx.numpy().astype(np.uint32))
+        ew = vd.numpy()[:part.n_own].repeat(np.diff(part.rowptr.numpy())) * vd.numpy()[part.colidx.numpy()]
+        loc = np.zeros((part.n_table, D), np.float32)  # oracle expects square tables: pad rows
+        tab = table.numpy()
+        import ctypes as C
+        out = np.empty((part.n_own, D), np.float32)
+        orc.lib().orc_spmm_edge(C.c_int64(part.n_own), orc._p(lg.rowptr), orc._p(lg.colidx), orc._p(ew.astype(np.float32)),
+                                C.c_int(D), orc._p(tab), orc._p(out))
+        assert np.array_equal(out.view(np.uint32), want_gcn[lo:hi].view(np.uint32)), "same terms, same order"
+        ew2 = inv.numpy()[part.colidx.numpy()]
+        orc.lib().orc_spmm_edge(C.c_int64(part.n_own), orc._p(lg.rowptr), orc._p(lg.colidx), orc._p(ew2.astype(np.float32)),
+                                C.c_int(D), orc._p(tab), orc._p(out))
+        assert np.array_equal(out.view(np.uint32), want_mean_t[lo:hi].view(np.uint32))
+        # weight-gradient reduction: sum of per-rank X_own^T G_own == global X^T G
+        G = np.random.default_rng(6).standard_normal((n, D)).astype(np.float32)
+        dW = torch.from_numpy(x[lo:hi].astype(np.float64).T @ G[lo:hi].astype(np.float64))
+        dist.all_reduce(dW)
+        assert rel_err(dW.numpy(), x.astype(np.float64).T @ G.astype(np.float64)) < 1e-12
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_and_halo_exchange_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + world + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_block_rows_are_globally_symmetric():
+    """the multi-GPU bench generator: every rank's rows of one symmetric global graph"""
+    from graphaibench_amd import synth
+
+    world = 3
+    blocks = [synth.block_rows("tiny", r, world, seed=3, cut_fraction=0.3, device="cpu", scale=0.05, selfloops=True)
+              for r in range(world)]
+    n = blocks[0].n_global
+    pairs = set()
+    for r, b in enumerate(blocks):
+        rp, ci = b.rowptr.numpy(), b.colidx_global.numpy()
+        rows = np.repeat(np.arange(b.n_local), np.diff(rp)) + r * b.n_local
+        for u, v in zip(rows.tolist(), ci.tolist()):
+            pairs.add((u, v))
+        # rows sorted, no duplicates
+        for i in range(b.n_local):
+            seg = ci[rp[i]:rp[i + 1]]
+            assert np.all(np.diff(seg) > 0)
+    assert all((v, u) in pairs for (u, v) in pairs)
+    assert all((i, i) in pairs for i in range(n))
+    cross = sum(1 for (u, v) in pairs if u // blocks[0].n_local != v // blocks[0].n_local)
+    assert 0.15 < cross / len(pairs) < 0.40
