@@ -36,13 +36,32 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def usable_cores() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
     """The oracle (port of the reference's OpenMP GCN layer, oracle/gnn_oracle.c) timed on the host
     cores on a bounded row-prefix sample of the SAME graph: rows [0, R) forward + backward."""
     import numpy as np
     from oracle import binding as orc
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     orc.set_threads(cores)
     rp = sg_rowptr.cpu().numpy()
     ci = sg_colidx.cpu().numpy().view(np.uint32)

@@ -51,6 +51,12 @@ def set_threads(n: int) -> None:
     lib().orc_set_num_threads(int(n))
 
 
+def use_blas(on: bool) -> bool:
+    """route matmul through the reference's BLAS call (cblas_sgemm from MKL/OpenBLAS) if one can be
+    dlopen'ed; returns whether it is active.  Only the CPU-baseline timing turns this on."""
+    return bool(lib().orc_use_blas(int(on)))
+
+
 def num_threads() -> int:
     return int(lib().orc_num_threads())
 

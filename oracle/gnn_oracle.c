@@ -32,6 +32,8 @@
  *     run-to-run reproducible (gat_aggregator.cpp:124-165).
  *   - sgemm is our own blocked kernel (reference: cblas_sgemm, math_functions.cpp:142-151).
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -446,8 +448,39 @@ static void gemm_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
   }
 }
 
+/* Optional: the reference's own BLAS call.  sgemm_cpu does
+ *   cblas_sgemm(CblasRowMajor, TransA, TransB, M, N, K, alpha, A, lda, B, ldb, beta, C, N)
+ * (math_functions.cpp:142-151) against OpenBLAS or MKL (src/gnn/Makefile:50-54).  When a
+ * libmkl_rt / libopenblas is present it can be resolved at run time for the CPU-baseline timing
+ * (orc_use_blas(1)); parity tests keep the built-in kernel (deterministic, no external state). */
+typedef void (*cblas_sgemm_t)(int, int, int, int, int, int, float, const float*, int, const float*, int,
+                              float, float*, int);
+static cblas_sgemm_t g_sgemm = NULL;
+static int g_use_blas = 0;
+int orc_use_blas(int on) {
+  g_use_blas = 0;
+  if (!on) return 0;
+  if (!g_sgemm) {
+    const char* cands[] = {"libmkl_rt.so", "/opt/conda/lib/libmkl_rt.so", "libopenblas.so", "libopenblas.so.0",
+                           "libblas.so.3"};
+    setenv("MKL_THREADING_LAYER", "GNU", 0);
+    for (unsigned i = 0; i < sizeof(cands) / sizeof(cands[0]) && !g_sgemm; i++) {
+      void* h = dlopen(cands[i], RTLD_NOW | RTLD_GLOBAL);
+      if (h) g_sgemm = (cblas_sgemm_t)dlsym(h, "cblas_sgemm");
+    }
+  }
+  g_use_blas = g_sgemm != NULL;
+  return g_use_blas;
+}
+
 void orc_matmul(int64_t x, int64_t y, int64_t z, const float* A, const float* B, float* C,
                 int transA, int transB, int accum) {
+  if (g_use_blas && x < (1 << 30) && y < (1 << 30) && z < (1 << 30)) {
+    const int lda = transA ? (int)x : (int)z, ldb = transB ? (int)z : (int)y;
+    g_sgemm(101 /*CblasRowMajor*/, transA ? 112 : 111, transB ? 112 : 111, (int)x, (int)y, (int)z, 1.0f, A, lda, B,
+            ldb, accum ? 1.0f : 0.0f, C, (int)y);
+    return;
+  }
   if (!transA && !transB) {
     gemm_nn(x, y, z, A, z, B, y, C, accum);
   } else if (!transA && transB) {
