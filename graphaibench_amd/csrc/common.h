@@ -94,6 +94,10 @@ struct gaib_graph {
   float* w_mean_t;   // [ne] inv_deg[col]                       lazily
   uint32_t* rev;     // [ne] index of the reverse edge          lazily
   // rows with degree > heavy_thr (built for the threshold the list was made with)
+  // 64-edge chunks of the edge list (edge-parallel kernels: SDDMM), built lazily on the host
+  uint32_t* chunk_row;    // [n_chunks] row of each chunk
+  uint32_t* chunk_ebase;  // [n_chunks] first edge of each chunk
+  int64_t n_chunks;
   uint32_t* heavy_rows;
   int64_t n_heavy;
   int64_t heavy_edges;
@@ -107,6 +111,7 @@ int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_w_mean_t(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr);
+int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

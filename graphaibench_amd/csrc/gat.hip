@@ -148,6 +148,52 @@ __global__ __launch_bounds__(256) void sddmm_kernel(int64_t nv, const int64_t* r
   }
 }
 
+
+// SDDMM, edge-parallel: one wave per 64-edge chunk (gaib_graph_ensure_chunks), G lanes x float4 per
+// edge, so one wave instruction gathers 64/G feature rows (1 KB) and a dot product costs
+// 4 FMAs + log2(G) shuffles.  Group k of the wave owns edges k*G .. k*G+G-1 of the chunk; in step
+// j it reduces its j-th edge and lane k*G+j (which sits in group k) keeps the result, so after G
+// steps lane l holds edge l and the store is coalesced.  Perfectly balanced for power-law rows.
+template <int G, int U>
+__global__ __launch_bounds__(256) void sddmm_chunk_kernel(int64_t n_chunks, const uint32_t* chunk_row,
+                                                          const uint32_t* chunk_ebase,
+                                                          const int64_t* rowptr, const uint32_t* col,
+                                                          int len, const float* grad, const float* feat,
+                                                          float* out_e) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rem = rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const uint32_t cl = col[eb + (lane < n ? lane : 0)];
+  const bool colok = sl * 4 < len;
+  const int coff = colok ? sl * 4 : 0;
+  f4 g4 = {0.f, 0.f, 0.f, 0.f};
+  if (colok) g4 = *reinterpret_cast<const f4*>(grad + row * (int64_t)len + coff);
+  float res = 0.f;
+#pragma unroll
+  for (int j = 0; j < G; j += U) {
+    f4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t cj = (uint32_t)__shfl((int)cl, gbase + j + u, 64);
+      x[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float p = g4[0] * x[u][0] + g4[1] * x[u][1] + g4[2] * x[u][2] + g4[3] * x[u][3];
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+      if (sl == j + u) res = p;
+    }
+  }
+  if (lane < n) out_e[eb + lane] = res;
+}
+
 // softmax backward per row (math_functions.cpp:496-514, closed form of the :497-504 branch)
 // + leaky-relu' (gat_aggregator.cpp:145).  Writes ds into scores[], g into gbuf[], and the
 // row sum of g into rs[].
@@ -262,11 +308,15 @@ extern "C" int gaib_gat_scores(gaib_ctx* ctx, gaib_graph* g, int len, const floa
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)g->nv));
   float* sl = (float*)ctx->ws;
   float* sr = sl + g->nv;
+  { ProfScope ps(ctx, "gat_vertex_dots");
   vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, d_h, d_alpha_l,
                                                               d_alpha_r, sl, sr);
+  }
   GAIB_LAUNCH_CHECK();
+  { ProfScope ps(ctx, "gat_edge_softmax");
   edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
       g->nv, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+  }
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -278,6 +328,27 @@ extern "C" int gaib_sddmm(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_
   if (g->nv == 0 || g->ne == 0) return GAIB_OK;
   GAIB_CHECK(d_grad && d_feat && d_out_e, "gaib_sddmm: NULL pointer");
   GAIB_HIP(hipSetDevice(ctx->device));
+  const bool vec_ok = (len % 4 == 0) && len <= 256 &&
+                      ((((uintptr_t)d_grad | (uintptr_t)d_feat) & 15) == 0) && ctx->gat_fast;
+  if (vec_ok) {
+    GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+    ProfScope ps(ctx, "gat_sddmm");
+    const unsigned grid = (unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4);
+#define GAIB_SDDMM(G, U)                                                                             \
+  sddmm_chunk_kernel<G, U><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, \
+                                                          g->rowptr, g->colidx, len, d_grad, d_feat, d_out_e)
+    if (len <= 4) GAIB_SDDMM(1, 1);
+    else if (len <= 8) GAIB_SDDMM(2, 2);
+    else if (len <= 16) GAIB_SDDMM(4, 4);
+    else if (len <= 32) GAIB_SDDMM(8, 8);
+    else if (len <= 64) GAIB_SDDMM(16, 8);
+    else if (len <= 128) GAIB_SDDMM(32, 8);
+    else GAIB_SDDMM(64, 8);
+#undef GAIB_SDDMM
+    GAIB_LAUNCH_CHECK();
+    return GAIB_OK;
+  }
+  ProfScope ps(ctx, "gat_sddmm");
   if (len <= 64)
     sddmm_kernel<1><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx, len,
                                                              d_grad, d_feat, d_out_e);
@@ -313,6 +384,7 @@ extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len,
   float* rs = gbuf + g->ne;
   float* cs = rs + g->nv;
   float* partial = cs + g->nv;
+  ProfScope ps(ctx, "gat_softmax_bwd_alpha");
   softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
       g->nv, g->rowptr, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, d_scores, gbuf, rs);
   GAIB_LAUNCH_CHECK();

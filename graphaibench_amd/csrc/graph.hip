@@ -230,7 +230,8 @@ extern "C" int gaib_graph_destroy(gaib_graph* g) {
   if (!g) return GAIB_OK;
   (void)hipSetDevice(g->device);
   void* ptrs[] = {g->rowptr, g->colidx,   g->vdata, g->edata,      g->inv_deg,  g->col_vdata,
-                  g->col_inv_deg, g->w_gcn, g->w_mean_t, g->rev,   g->heavy_rows};
+                  g->col_inv_deg, g->w_gcn, g->w_mean_t, g->rev,   g->heavy_rows,
+                  g->chunk_row, g->chunk_ebase};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -379,6 +380,32 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   }
   GAIB_HIP(hipFree(cnt));
   g->heavy_thr = thr;
+  return GAIB_OK;
+}
+
+// 64-edge chunk list: chunk c covers edges [chunk_ebase[c], min(+64, row end)) of row chunk_row[c].
+// Built once per graph on the host (a prefix sum over ceil(deg/64)); rowptr is 8 B per vertex.
+int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g) {
+  if (g->chunk_row) return GAIB_OK;
+  std::vector<int64_t> rp((size_t)g->nv + 1);
+  GAIB_HIP(hipMemcpyAsync(rp.data(), g->rowptr, sizeof(int64_t) * (g->nv + 1), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t nch = 0;
+  for (int64_t v = 0; v < g->nv; ++v) nch += (rp[v + 1] - rp[v] + 63) / 64;
+  std::vector<uint32_t> crow((size_t)(nch > 0 ? nch : 1)), cbase((size_t)(nch > 0 ? nch : 1));
+  int64_t c = 0;
+  for (int64_t v = 0; v < g->nv; ++v)
+    for (int64_t e = rp[v]; e < rp[v + 1]; e += 64) {
+      crow[c] = (uint32_t)v;
+      cbase[c] = (uint32_t)e;
+      ++c;
+    }
+  GAIB_HIP(hipMalloc(&g->chunk_row, sizeof(uint32_t) * crow.size()));
+  GAIB_HIP(hipMalloc(&g->chunk_ebase, sizeof(uint32_t) * cbase.size()));
+  GAIB_HIP(hipMemcpy(g->chunk_row, crow.data(), sizeof(uint32_t) * crow.size(), hipMemcpyHostToDevice));
+  GAIB_HIP(hipMemcpy(g->chunk_ebase, cbase.data(), sizeof(uint32_t) * cbase.size(), hipMemcpyHostToDevice));
+  g->n_chunks = nch;
+  g->dev_bytes += 2 * sizeof(uint32_t) * nch;
   return GAIB_OK;
 }
 

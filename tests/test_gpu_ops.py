@@ -346,7 +346,7 @@ def test_gat_forward_pieces(ctx, d, hub):
     assert rel_err(out.cpu().numpy(), want_out) < TOL
 
 
-@pytest.mark.parametrize("d,hub", [(8, 0), (64, 0), (64, 900), (130, 0), (300, 0)])
+@pytest.mark.parametrize("d,hub", [(4, 0), (8, 0), (32, 0), (64, 0), (64, 900), (128, 0), (130, 0), (256, 0), (300, 0)])
 def test_gat_backward_pieces(ctx, d, hub):
     rp, ci = random_graph(1500, 8, seed=d + 1, power_law=True, hub_deg=hub)
     g_o, g_d = make(ctx, rp, ci, selfloop=True)
