@@ -74,7 +74,7 @@ def build_hip(force: bool = False) -> Path:
 
 def build_host(force: bool = False) -> Path | None:
     """libgaib_gnn.so: the host C++ mirror of the reference layer/operator API over the C ABI."""
-    srcs = sorted(HOST.glob("*.cpp"))
+    srcs = sorted(p for p in HOST.glob("*.cpp") if p.name != "train_main.cpp")
     if not srcs:
         return None
     out = LIB / "libgaib_gnn.so"
@@ -83,7 +83,25 @@ def build_host(force: bool = False) -> Path | None:
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wall",
               f"-I{INCLUDE}", f"-I{INCLUDE}/gnn", f"-I{INCLUDE}/layers", f"-I{INCLUDE}/utils",
               *srcs, f"-L{LIB}", "-lgaib_hip", "-Wl,-rpath,$ORIGIN", "-o", out])
+    build_drivers(force)
     return out
+
+
+def build_drivers(force: bool = False) -> None:
+    """bin/gpu_train_{gcn,sage,gat}: the trainer CLI (architecture is a -D choice like in the reference)."""
+    bindir = ROOT / "bin"
+    bindir.mkdir(exist_ok=True)
+    src = HOST / "train_main.cpp"
+    hdrs = list(INCLUDE.rglob("*.h")) + list(INCLUDE.rglob("*.hh"))
+    for name, flag in (("gcn", None), ("sage", "-DUSE_SAGE"), ("gat", "-DUSE_GAT")):
+        exe = bindir / f"gpu_train_{name}"
+        if force or _stale(exe, [src, *hdrs, LIB / "libgaib_gnn.so"]):
+            cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", f"-I{INCLUDE}", f"-I{INCLUDE}/gnn",
+                   f"-I{INCLUDE}/layers", f"-I{INCLUDE}/utils", src, f"-L{LIB}", "-lgaib_gnn", "-lgaib_hip",
+                   "-Wl,-rpath,$ORIGIN/../graphaibench_amd/lib", "-o", exe]
+            if flag:
+                cmd.insert(1, flag)
+            _run(cmd)
 
 
 def build_oracle(force: bool = False, ref: bool = True) -> Path:

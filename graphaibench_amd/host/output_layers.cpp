@@ -1,0 +1,118 @@
+// output_layers.cpp -- loss / l2norm / dense layers of the model head, device-resident.
+#include "dense_layer.h"
+#include "host_util.h"
+#include "l2norm_layer.h"
+#include "math_functions.hh"
+#include "sigmoid_loss_layer.h"
+#include "softmax_loss_layer.h"
+
+static inline gaib_ctx* C() { return gpu_context::get(); }
+
+// ---- loss_layer -----------------------------------------------------------------------------------
+loss_layer::loss_layer() : num_samples(0), num_cls(1), capacity_(0), phase_(net_phase::TRAIN), feat_in(NULL),
+                           feat_out(NULL), labels(NULL), d_losses(NULL) {}
+loss_layer::loss_layer(int nv, int ncls) : loss_layer(nv, ncls, NULL) {}
+loss_layer::loss_layer(int nv, int ncls, label_t* ptr)
+    : num_samples(nv), num_cls(ncls), capacity_(0), phase_(net_phase::TRAIN), feat_in(NULL), feat_out(NULL),
+      labels(ptr), d_losses(NULL) {
+  allocate(nv);
+}
+void loss_layer::allocate(int nv) {
+  const size_t n = (size_t)nv * num_cls;
+  if (feat_in) float_free_device(feat_in);
+  if (feat_out) float_free_device(feat_out);
+  if (d_losses) float_free_device(d_losses);
+  float_malloc_device64(n, feat_in);
+  float_malloc_device64(n, feat_out);
+  float_malloc_device64((size_t)nv, d_losses);
+  GAIB_OR_DIE(gaib_fill_f32(C(), n, 0.f, feat_in));
+  GAIB_OR_DIE(gaib_fill_f32(C(), n, 0.f, feat_out));
+  GAIB_OR_DIE(gaib_fill_f32(C(), nv, 0.f, d_losses));
+  capacity_ = nv;
+}
+void loss_layer::update_dim_size(int x) {
+  if (x > capacity_) allocate(x);
+  num_samples = x;
+}
+
+void softmax_loss_layer::forward(size_t begin, size_t end, mask_t* masks) {
+  softmax_cross_entropy_gpu(num_cls, begin, end, feat_in, masks, labels, d_losses, feat_out);
+}
+void softmax_loss_layer::backward(size_t begin, size_t end, mask_t* masks, float* grad_out) {
+  d_softmax_cross_entropy_gpu(num_cls, begin, end, masks, labels, feat_out, grad_out);
+}
+acc_t softmax_loss_layer::get_prediction_loss(size_t begin, size_t end, size_t count, mask_t* masks) {
+  return masked_avg_loss_gpu(begin, end, count, masks, d_losses);
+}
+
+static void sigmoid_unsupported() {
+  fprintf(stderr, "sigmoid (multi-label) loss is not supported by the MI355X backend yet\n");
+  exit(EXIT_FAILURE);
+}
+void sigmoid_loss_layer::forward(size_t, size_t, mask_t*) { sigmoid_unsupported(); }
+void sigmoid_loss_layer::backward(size_t, size_t, mask_t*, float*) { sigmoid_unsupported(); }
+acc_t sigmoid_loss_layer::get_prediction_loss(size_t, size_t, size_t, mask_t*) {
+  sigmoid_unsupported();
+  return 0;
+}
+float masked_accuracy_multi(int, int, int, int, mask_t*, float*, label_t*) {
+  sigmoid_unsupported();
+  return 0;
+}
+
+// ---- l2norm_layer ---------------------------------------------------------------------------------
+l2norm_layer::l2norm_layer(int nv, int len) : num_samples(nv), dim(len), capacity_(nv), feat_in(NULL), grad_in(NULL) {
+  float_malloc_device64((size_t)nv * dim, feat_in);
+  float_malloc_device64((size_t)nv * dim, grad_in);
+  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim, 0.f, feat_in));
+  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim, 0.f, grad_in));
+}
+void l2norm_layer::forward(float* feat_out) { l2norm(num_samples, dim, feat_in, feat_out); }
+void l2norm_layer::backward(float* grad_out) { d_l2norm(num_samples, dim, feat_in, grad_in, grad_out); }
+void l2norm_layer::update_dim_size(int x) {
+  if (x > capacity_) {
+    float_free_device(feat_in);
+    float_free_device(grad_in);
+    float_malloc_device64((size_t)x * dim, feat_in);
+    float_malloc_device64((size_t)x * dim, grad_in);
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim, 0.f, feat_in));
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim, 0.f, grad_in));
+    capacity_ = x;
+  }
+  num_samples = x;
+}
+
+// ---- dense_layer ----------------------------------------------------------------------------------
+dense_layer::dense_layer(int nv, int in_len, int out_len, float lr)
+    : is_bias(false), num_samples(nv), dim_in(in_len), dim_out(out_len), capacity_(nv), feat_in(NULL),
+      grad_in(NULL), optm(NULL), d_weight(NULL), d_weight_grad(NULL) {
+  float_malloc_device64((size_t)nv * dim_in, feat_in);
+  float_malloc_device64((size_t)nv * dim_out, grad_in);
+  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim_in, 0.f, feat_in));
+  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim_out, 0.f, grad_in));
+  vec_t w;
+  init_glorot(dim_in, dim_out, w, 1);  // the OpenMP path's init (dense_layer.cpp:30); its CUDA path draws from cuRAND
+  float_malloc_device64(w.size(), d_weight);
+  float_malloc_device64(w.size(), d_weight_grad);
+  copy_float_device((int)w.size(), w.data(), d_weight);
+  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)w.size(), 0.f, d_weight_grad));
+  optm = new adam(lr);
+}
+void dense_layer::forward(float* feat_out) { matmul(num_samples, dim_out, dim_in, feat_in, d_weight, feat_out); }
+void dense_layer::backward(float* grad_out) {
+  matmul(dim_in, dim_out, num_samples, feat_in, grad_in, d_weight_grad, true);
+  matmul(num_samples, dim_in, dim_out, grad_in, d_weight, grad_out, false, true);
+  optm->update_gpu((size_t)dim_in * dim_out, d_weight_grad, d_weight);
+}
+void dense_layer::update_dim_size(int x) {
+  if (x > capacity_) {
+    float_free_device(feat_in);
+    float_free_device(grad_in);
+    float_malloc_device64((size_t)x * dim_in, feat_in);
+    float_malloc_device64((size_t)x * dim_out, grad_in);
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim_in, 0.f, feat_in));
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim_out, 0.f, grad_in));
+    capacity_ = x;
+  }
+  num_samples = x;
+}

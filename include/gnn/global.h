@@ -10,12 +10,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iomanip>
 #include <iostream>
 #include <map>
 #include <string>
 #include <vector>
 
+#include <omp.h>
+
 #define DEFAULT_NUM_LAYER 2
+#define DEFAULT_SIZE_FRONTIER 3000
 #define DEFAULT_SIZE_HID 16
 #define DEFAULT_RATE_LEARN 0.02
 #define EVAL_INTERVAL 50

@@ -98,3 +98,5 @@ class GAT_layer : public graph_conv_layer<GAT_Aggregator> {
   void backward(float* feat_out, float* grad_out);
   void update_weight(optimizer* opt);
 };
+
+#include "ggnn_layer_stub.h"

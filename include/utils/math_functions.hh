@@ -25,6 +25,8 @@ void softmax_cross_entropy_gpu(int len, int begin, int end, const float_t* in_da
 void d_softmax_cross_entropy_gpu(int len, int begin, int end, const mask_t* masks,
                                  const label_t* labels, const float_t* out_data, float_t* diff);
 acc_t masked_avg_loss_gpu(int begin, int end, int count, mask_t* masks, float_t* loss);
+float masked_accuracy_multi(int begin, int end, int count, int num_classes, mask_t* masks, float* preds,
+                            label_t* ground_truth);
 float masked_accuracy_single(int begin, int end, int count, int num_classes, mask_t* masks,
                              float* preds, label_t* ground_truth);
 // symmetric sparse transpose of per-edge values on the device graph (math_functions.cpp:46-74)
