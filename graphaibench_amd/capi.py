@@ -45,9 +45,10 @@ SIGNATURES = {
     "gaib_graph_vertex_data": (_vp, [_vp]),
     "gaib_graph_compute_edge_data": (_i, [_vp, _vp]),
     "gaib_graph_edge_data": (_vp, [_vp]),
-    "gaib_graph_set_vertex_norm": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "gaib_graph_set_vertex_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gaib_graph_device_bytes": (_i64, [_vp]),
     "gaib_spmm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "gaib_spmm_acc": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -167,10 +168,10 @@ class Context:
         return Graph(self, rowptr, colidx, ncols)
 
     # ---- aggregation --------------------------------------------------------------------
-    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None):
+    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None, accumulate: bool = False):
         assert x.is_contiguous() and out.is_contiguous() and x.dim() == 2
-        _check(self.lib.gaib_spmm(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(out)),
-               "gaib_spmm")
+        fn = self.lib.gaib_spmm_acc if accumulate else self.lib.gaib_spmm
+        _check(fn(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(out)), "gaib_spmm")
         return out
 
     def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2):
@@ -306,10 +307,11 @@ class Graph:
     def compute_edge_data(self):
         _check(self.lib.gaib_graph_compute_edge_data(self.ctx.h, self.h), "gaib_graph_compute_edge_data")
 
-    def set_vertex_norm(self, row_vdata, col_vdata, col_inv_deg):
+    def set_vertex_norm(self, row_vdata, col_vdata, col_inv_deg, row_inv_deg=None):
         """rectangular (partitioned) graphs: normalisers come from the GLOBAL degrees."""
-        _check(self.lib.gaib_graph_set_vertex_norm(self.ctx.h, self.h, _ptr(row_vdata), _ptr(col_vdata),
-                                                   _ptr(col_inv_deg)), "gaib_graph_set_vertex_norm")
+        _check(self.lib.gaib_graph_set_vertex_norm(self.ctx.h, self.h, _ptr(row_vdata), _ptr(row_inv_deg),
+                                                   _ptr(col_vdata), _ptr(col_inv_deg)),
+               "gaib_graph_set_vertex_norm")
 
     def _dev_tensor(self, ptr, n, dtype):
         """copy a device array owned by the graph into a fresh torch tensor"""

@@ -149,7 +149,8 @@ extern "C" int gaib_graph_create(gaib_ctx* ctx, int64_t nv, int64_t ne, const vo
 }
 
 extern "C" int gaib_graph_set_vertex_norm(gaib_ctx* ctx, gaib_graph* g, const float* d_row_vdata,
-                                          const float* d_col_vdata, const float* d_col_inv_deg) {
+                                          const float* d_row_inv_deg, const float* d_col_vdata,
+                                          const float* d_col_inv_deg) {
   GAIB_CHECK(ctx && g && d_col_vdata && d_col_inv_deg, "gaib_graph_set_vertex_norm: NULL argument");
   GAIB_HIP(hipSetDevice(ctx->device));
   const size_t nc = (size_t)(g->nc > 0 ? g->nc : 1), nv = (size_t)(g->nv > 0 ? g->nv : 1);
@@ -169,6 +170,13 @@ extern "C" int gaib_graph_set_vertex_norm(gaib_ctx* ctx, gaib_graph* g, const fl
   else
     vertex_data_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->vdata);
   GAIB_LAUNCH_CHECK();
+  if (d_row_inv_deg) {
+    if (!g->inv_deg) {
+      GAIB_HIP(hipMalloc(&g->inv_deg, sizeof(float) * nv));
+      g->dev_bytes += sizeof(float) * g->nv;
+    }
+    GAIB_HIP(hipMemcpyAsync(g->inv_deg, d_row_inv_deg, sizeof(float) * g->nv, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   // cached per-edge weights derive from these
   if (g->w_gcn) {
     edge_weight_kernel<1><<<grid1d(g->nv, 4), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx,
@@ -187,7 +195,7 @@ extern "C" int gaib_graph_create_rect(gaib_ctx* ctx, int64_t nv, int64_t nc, int
                                       const void* rowptr, int rowptr_bits, const uint32_t* colidx,
                                       int src_on_device, gaib_graph** out) {
   GAIB_CHECK(ctx && out && rowptr, "gaib_graph_create: NULL argument");
-  GAIB_CHECK(nc >= nv && nc < (int64_t)1 << 32, "gaib_graph_create_rect: need nv <= nc < 2^32");
+  GAIB_CHECK(nc >= 0 && nc < (int64_t)1 << 32, "gaib_graph_create_rect: need 0 <= nc < 2^32");
   GAIB_CHECK(nv >= 0 && ne >= 0, "gaib_graph_create: negative size");
   GAIB_CHECK(nv < (int64_t)1 << 31, "gaib_graph_create: nv must be < 2^31");
   GAIB_CHECK(ne < (int64_t)1 << 32, "gaib_graph_create: ne must be < 2^32 (edge ids are uint32)");

@@ -44,6 +44,7 @@ struct SpmmArgs {
   int nblocks;               // light kernels: logical number of row blocks
   int per_xcd;               // ceil(nblocks/8) when swizzled, 0 otherwise
   uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)
+  int accumulate;            // out += instead of out = (second half of a split aggregation)
 };
 
 template <int VEC> struct VecT;
@@ -227,8 +228,13 @@ __global__ __launch_bounds__(256) void spmm_w64_kernel(SpmmArgs a) {
     acc[ct] = vzero<VEC>();
   }
   const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
-  wave_accumulate<VEC, CT, WMODE, U, BUF>(a, lane, e0, e1, 64, roww, voff, acc);
   float* o = a.out + (int64_t)row * a.ld + lane * VEC;
+  if (a.accumulate) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      if (colok[ct]) acc[ct] = *reinterpret_cast<const vec_t*>(o + ct * 64 * VEC);
+  }
+  wave_accumulate<VEC, CT, WMODE, U, BUF>(a, lane, e0, e1, 64, roww, voff, acc);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
     if (colok[ct]) *reinterpret_cast<vec_t*>(o + ct * 64 * VEC) = acc[ct];
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a
     *reinterpret_cast<vec_t*>(&red[wave * W + (ct * 64 + lane) * VEC]) = acc[ct];
   __syncthreads();
   for (int c = threadIdx.x; c < a.ncols; c += HEAVY_WAVES * 64) {
-    float s = red[c];
+    float s = a.accumulate ? a.out[(int64_t)row * a.ld + c] + red[c] : red[c];
 #pragma unroll
     for (int w = 1; w < HEAVY_WAVES; ++w) s = s + red[w * W + c];
     a.out[(int64_t)row * a.ld + c] = s;
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
   }
   const bool colok = sl * VEC < a.ncols;
   vec_t acc = vzero<VEC>();
+  if (a.accumulate && active && colok) acc = *reinterpret_cast<const vec_t*>(a.out + row * a.ld + sl * VEC);
   const float roww = (WMODE == 0 && active) ? a.rw[row] : 0.f;
   const float* inl = a.in + sl * VEC;
   for (int64_t e = e0; e < e1; e += U) {
@@ -446,8 +453,8 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
 
 }  // namespace
 
-extern "C" int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
-                         int len, const float* d_in, float* d_out) {
+static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
+                     const float* d_in, float* d_out, int accumulate) {
   GAIB_CHECK(ctx && g, "gaib_spmm: NULL ctx/graph");
   GAIB_CHECK(len >= 0, "gaib_spmm: len < 0");
   GAIB_CHECK(ctx->device == g->device, "gaib_spmm: graph lives on device %d, ctx on %d", g->device,
@@ -472,6 +479,7 @@ extern "C" int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const fl
   a.row_list = nullptr;
   a.nblocks = 0;
   a.per_xcd = 0;
+  a.accumulate = accumulate;
   // feature table = nc rows of len floats; the 32-bit buffer path needs it below 4 GB
   const int64_t table_bytes = g->nc * (int64_t)len * 4;
   a.in_bytes = table_bytes < ((int64_t)1 << 32) ? (uint32_t)table_bytes : 0u;
@@ -502,4 +510,14 @@ extern "C" int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const fl
       gaib_set_error("gaib_spmm: unknown weight_kind %d", weight_kind);
       return GAIB_ERR_INVALID;
   }
+}
+
+extern "C" int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                         int len, const float* d_in, float* d_out) {
+  return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, 0);
+}
+
+extern "C" int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                             int len, const float* d_in, float* d_out) {
+  return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, 1);
 }

@@ -68,20 +68,24 @@ def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_counts, in_counts
 
 @dataclass
 class Partition:
-    """one rank's share of a vertex-range partitioned graph"""
+    """one rank's share of a vertex-range partitioned graph.  The rows' edges are split by column
+    owner: `own` (columns in [0, n_own): this rank's vertices) and `halo` (columns in [0, n_halo):
+    index into halo_gids), so the owned part can be aggregated while the halo rows are in flight."""
     rank: int
     world: int
     n_global: int
     lo: int
     hi: int
-    rowptr: torch.Tensor        # int64 [n_own+1]
-    colidx: torch.Tensor        # int32 [ne_local], LOCAL ids: owned -> [0,n_own), halo -> n_own + k
+    rowptr_own: torch.Tensor    # int64 [n_own+1]
+    colidx_own: torch.Tensor    # int32, local ids in [0, n_own)
+    rowptr_halo: torch.Tensor   # int64 [n_own+1]
+    colidx_halo: torch.Tensor   # int32, ids in [0, n_halo)
+    degree: torch.Tensor        # int64 [n_own] full (global) degree of every owned row
     halo_gids: torch.Tensor     # int64 [n_halo] global ids, ascending (hence grouped by owner)
     recv_counts: list           # halo rows owned by rank q (contiguous segments of halo_gids)
     send_idx: torch.Tensor      # int64 [total_send] local row ids to ship, grouped by destination
     send_counts: list
     group: object = None
-    _sendbuf: dict = field(default_factory=dict)
 
     @property
     def n_own(self) -> int:
@@ -92,12 +96,8 @@ class Partition:
         return int(self.halo_gids.numel())
 
     @property
-    def n_table(self) -> int:
-        return self.n_own + self.n_halo
-
-    @property
     def ne(self) -> int:
-        return int(self.colidx.numel())
+        return int(self.colidx_own.numel() + self.colidx_halo.numel())
 
 
 def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_global: int, rank: int, world: int,
@@ -109,10 +109,22 @@ def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_g
     lo, hi = bounds[rank], bounds[rank + 1]
     n_own = hi - lo
     assert rowptr_local.numel() == n_own + 1
+    rowptr_local = rowptr_local.to(torch.int64)
     cols = colidx_global.to(torch.int64)
+    deg = rowptr_local[1:] - rowptr_local[:-1]
+    rows = torch.repeat_interleave(torch.arange(n_own, device=device), deg)
     own = (cols >= lo) & (cols < hi)
     halo = torch.unique(cols[~own])  # sorted
-    local = torch.where(own, cols - lo, n_own + torch.searchsorted(halo, cols))
+
+    def csr_of(mask, ids):
+        cnt = torch.bincount(rows[mask], minlength=n_own)
+        rp = torch.zeros(n_own + 1, dtype=torch.int64, device=device)
+        torch.cumsum(cnt, 0, out=rp[1:])
+        return rp, ids.to(torch.int32).contiguous()  # edge order inside a row is preserved
+
+    rp_own, ci_own = csr_of(own, cols[own] - lo)
+    rp_halo, ci_halo = csr_of(~own, torch.searchsorted(halo, cols[~own]))
+    del rows
     # owner of each halo vertex -> how many rows we receive from each rank
     bt = torch.tensor(bounds, dtype=torch.int64, device=device)
     owner = torch.searchsorted(bt, halo, right=True) - 1
@@ -125,84 +137,119 @@ def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_g
     _all_to_all_rows(want, halo.contiguous(), sc, rc, group)  # ids requested FROM us, grouped by requester
     send_idx = want - lo
     assert send_idx.numel() == 0 or (int(send_idx.min()) >= 0 and int(send_idx.max()) < n_own)
-    return Partition(rank, world, n_global, lo, hi, rowptr_local.to(torch.int64).contiguous(),
-                     local.to(torch.int32).contiguous(), halo, rc, send_idx.contiguous(), sc, group)
+    return Partition(rank, world, n_global, lo, hi, rp_own, ci_own, rp_halo, ci_halo, deg, halo, rc,
+                     send_idx.contiguous(), sc, group)
 
 
 class HaloExchanger:
-    """fills rows [n_own, n_own+n_halo) of a feature table from the owners of those vertices."""
+    """moves the feature rows of halo vertices from their owners into a [n_halo x D] table.
+    start() packs and launches the all-to-all (asynchronously on NCCL/RCCL), finish() waits."""
 
     def __init__(self, part: Partition, gather_rows=None):
         self.p = part
-        # gather_rows(idx[int64], src[n_own x D], out[k x D]) -- HIP kernel on GPU, index_select on CPU
-        self.gather_rows = gather_rows or (lambda idx, src, out: torch.index_select(src, 0, idx, out=out))
+        # gather_rows(idx[int64 tensor], src (tensor or raw device pointer), D, out tensor)
+        self.gather_rows = gather_rows or (lambda idx, src, D, out: torch.index_select(src, 0, idx, out=out))
         self.bytes_sent = 0
-        self.seconds = 0.0
+        self._buf = {}
+        self._pending = None
 
-    def exchange(self, table: torch.Tensor):
-        """table: [n_own + n_halo, D] contiguous; rows [0, n_own) are this rank's current values."""
+    def _bufs(self, D, dtype, device):
+        key = (D, dtype, str(device))
+        if key not in self._buf:
+            p = self.p
+            self._buf[key] = (torch.empty(max(p.send_idx.numel(), 1), D, dtype=dtype, device=device),
+                              torch.empty(max(p.n_halo, 1), D, dtype=dtype, device=device))
+        s, r = self._buf[key]
+        return s[:self.p.send_idx.numel()], r[:self.p.n_halo]
+
+    def start(self, src, D: int, dtype=torch.float32, device=None):
         p = self.p
-        D = table.shape[1]
-        key = (D, table.dtype, table.device)
-        if key not in p._sendbuf:
-            p._sendbuf[key] = torch.empty(max(p.send_idx.numel(), 1), D, dtype=table.dtype, device=table.device)
-        sendbuf = p._sendbuf[key][:p.send_idx.numel()]
+        device = device if device is not None else src.device
+        sendbuf, recvbuf = self._bufs(D, dtype, device)
         if p.send_idx.numel():
-            self.gather_rows(p.send_idx, table[:p.n_own], sendbuf)
-        recv = table[p.n_own:]
-        _all_to_all_rows(recv, sendbuf, p.recv_counts, p.send_counts, p.group)
+            self.gather_rows(p.send_idx, src, D, sendbuf)
         self.bytes_sent += sendbuf.numel() * sendbuf.element_size()
-        return table
+        work = None
+        if p.world > 1:
+            if sendbuf.is_cuda and dist.get_backend(p.group) != "gloo":
+                work = dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=list(p.recv_counts),
+                                              input_split_sizes=list(p.send_counts), group=p.group, async_op=True)
+            else:
+                _all_to_all_rows(recvbuf, sendbuf, p.recv_counts, p.send_counts, p.group)
+        self._pending = (work, recvbuf)
+
+    def finish(self) -> torch.Tensor:
+        work, recvbuf = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()  # the compute stream now waits for the exchange
+        return recvbuf
+
+    def exchange(self, src, D: int, dtype=torch.float32, device=None) -> torch.Tensor:
+        self.start(src, D, dtype, device)
+        return self.finish()
 
 
 def global_normalisers(part: Partition, ex: HaloExchanger):
-    """(vdata [n_table], inv_deg [n_table]) with the GLOBAL degree of every owned and halo vertex.
-    Owned rows are complete in a row partition, so their local degree is the global one."""
-    deg = (part.rowptr[1:] - part.rowptr[:-1]).to(torch.float32)
-    dev = deg.device
-    vd = torch.zeros(part.n_table, 1, dtype=torch.float32, device=dev)
-    inv = torch.zeros(part.n_table, 1, dtype=torch.float32, device=dev)
+    """deg^-1/2 and 1/deg from the GLOBAL degrees: (vd_own, inv_own, vd_halo, inv_halo).
+    Owned rows are complete in a row partition, so their local degree is the global one; halo
+    vertices' values come from their owners."""
+    deg = part.degree.to(torch.float32)
     # deg^-1/2 with 0 for isolated vertices (lgraph.cpp:22-34); 1/deg in double then narrowed
     # (sage_aggregator.cpp:18).  float64 arithmetic reproduces both roundings.
     d64 = deg.to(torch.float64)
     s = torch.sqrt(deg).to(torch.float64)
-    vd[:part.n_own, 0] = torch.where(s == 0, torch.zeros_like(s), 1.0 / s).to(torch.float32)
-    inv[:part.n_own, 0] = (1.0 / d64).to(torch.float32)
-    ex.exchange(vd)
-    ex.exchange(inv)
-    return vd[:, 0].contiguous(), inv[:, 0].contiguous()
+    vd = torch.where(s == 0, torch.zeros_like(s), 1.0 / s).to(torch.float32).reshape(-1, 1).contiguous()
+    inv = (1.0 / d64).to(torch.float32).reshape(-1, 1).contiguous()
+    vd_h = ex.exchange(vd, 1).clone()
+    inv_h = ex.exchange(inv, 1).clone()
+    return vd[:, 0].contiguous(), inv[:, 0].contiguous(), vd_h[:, 0].contiguous(), inv_h[:, 0].contiguous()
 
 
 # ---- GPU layer driver ----------------------------------------------------------------------------
 class DistLayerGraph:
-    """A LearningGraph over this rank's rectangular local CSR whose aggregations run the halo
-    exchange first (LearningGraph::set_halo_hook).  The C++ layer code is the single-GPU one."""
+    """A LearningGraph over this rank's owned-column CSR plus a halo-column CSR
+    (LearningGraph::set_halo): every aggregation packs + starts the halo all-to-all, sums the
+    owned-column edges meanwhile, then adds the halo-column edges.  The C++ layer code is the
+    single-GPU one."""
 
     def __init__(self, ctx, part: Partition):
         from . import capi, layers as L
 
         self.ctx, self.part = ctx, part
-        self.ex = HaloExchanger(part, gather_rows=lambda idx, src, out: ctx.gather_rows(idx, src, out))
-        g = ctx.graph(part.rowptr, part.colidx, ncols=part.n_table)
-        vd, inv = global_normalisers(part, self.ex)
-        g.set_vertex_norm(vd[:part.n_own].contiguous(), vd, inv)
-        self.lgraph = L.LGraph.adopt(g)
-        self.tables = {}
         self._capi = capi
-        self.lgraph.set_halo_hook(self._hook)
+        dev = f"cuda:{ctx.device}"
 
-    def _hook(self, length: int, d_in: int) -> int:
-        p = self.part
-        t = self.tables.get(length)
-        if t is None:
-            t = torch.empty(p.n_table, length, dtype=torch.float32, device=f"cuda:{self.ctx.device}")
-            self.tables[length] = t
-        # owned rows into the head of the table, then the halo rows from their owners
-        self._capi._check(self.ctx.lib.gaib_memcpy_d2d(self.ctx.h, t.data_ptr(), d_in, p.n_own * length * 4),
-                          "gaib_memcpy_d2d")
-        if p.world > 1:
-            self.ex.exchange(t)
-        return t.data_ptr()
+        def gather(idx, src, D, out):
+            ptr = src if isinstance(src, int) else src.data_ptr()
+            capi._check(ctx.lib.gaib_gather_rows(ctx.h, idx.numel(), idx.data_ptr(), D, ptr, out.data_ptr()),
+                        "gaib_gather_rows")
+
+        self.ex = HaloExchanger(part, gather_rows=gather)
+        vd, inv, vd_h, inv_h = global_normalisers(part, self.ex)
+        g_own = ctx.graph(part.rowptr_own, part.colidx_own)
+        g_own.set_vertex_norm(vd, vd, inv, row_inv_deg=inv)
+        self.lgraph = L.LGraph.adopt(g_own)
+        self.g_halo = None
+        if part.n_halo > 0:
+            self.g_halo = ctx.graph(part.rowptr_halo, part.colidx_halo, ncols=part.n_halo)
+            self.g_halo.set_vertex_norm(vd, vd_h, inv_h, row_inv_deg=inv)
+            self.lgraph.set_halo(self.g_halo, self._begin, self._end)
+        self._dev = dev
+
+    def _begin(self, length: int, d_in: int) -> None:
+        self.ex.start(d_in, length, torch.float32, self._dev)
+
+    def _end(self, length: int) -> int:
+        return self.ex.finish().data_ptr()
+
+    def stats(self):
+        """heavy-row split of both halves (roofline accounting)"""
+        st = self.ctx.graph_stats(self.lgraph.device_graph())
+        if self.g_halo is not None:
+            sh = self.ctx.graph_stats(self.g_halo)
+            st = {k: st[k] + sh[k] if k != "max_degree" else max(st[k], sh[k]) for k in st}
+        return st
 
 
 def allreduce_layer_grads(ctx, layer, which_list, shape, group=None):
@@ -236,7 +283,8 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     part = build_partition(rows.rowptr, rows.colidx_global, rows.n_global, rank, world)
     dg = DistLayerGraph(ctx, part)
     torch.cuda.synchronize()
-    log(f"[bench r{rank}] rows [{part.lo},{part.hi}) ne={part.ne} halo rows={part.n_halo} "
+    log(f"[bench r{rank}] rows [{part.lo},{part.hi}) ne={part.ne} (own-column {part.colidx_own.numel()}) "
+        f"halo rows={part.n_halo} "
         f"send rows={part.send_idx.numel()} setup {time.time()-t0:.1f}s")
     nv = part.n_own
     torch.manual_seed(43 + rank)
@@ -275,9 +323,14 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     dist.all_reduce(e, op=dist.ReduceOp.SUM)
     elapsed = float(t[0])
     total_edges = float(e[0])
-    stats = ctx.graph_stats(dg.lgraph.device_graph())
-    e_light = part.ne - stats["heavy_edges"]
-    alg_bytes = e_light * (4 * D + 8) + (nv - stats["n_heavy"]) * 4 * D + (nv + 1) * 8
+    # dominant kernel = the light SpMM over the owned-column edges (the first launch of each aggregation)
+    st_own = ctx.graph_stats(dg.lgraph.device_graph())
+    e_light = part.colidx_own.numel() - st_own["heavy_edges"]
+    alg_bytes = e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
+    if dg.g_halo is not None:  # launches alternate own / halo: average over both
+        st_h = ctx.graph_stats(dg.g_halo)
+        e_light_h = part.colidx_halo.numel() - st_h["heavy_edges"]
+        alg_bytes = (alg_bytes + e_light_h * (4 * D + 8) + 2 * (nv - st_h["n_heavy"]) * 4 * D + (nv + 1) * 8) / 2
     avg_ms = ms_light / max(n_light, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {

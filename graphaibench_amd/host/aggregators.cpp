@@ -11,6 +11,19 @@ static gaib_graph* dev(Graph& g) {
   return g.device_graph();
 }
 
+// One aggregation.  On a vertex-range partition the owned-column edges are summed while the halo
+// rows are in flight (separate RCCL stream), then the halo-column edges are added to the same rows.
+static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* out) {
+  if (!g.has_halo()) {
+    GAIB_OR_DIE(gaib_spmm(C(), dev(g), kind, NULL, len, in, out));
+    return;
+  }
+  g.halo_begin(len, in);
+  GAIB_OR_DIE(gaib_spmm(C(), dev(g), kind, NULL, len, in, out));
+  const float* halo = g.halo_end(len);
+  GAIB_OR_DIE(gaib_spmm_acc(C(), g.halo_graph(), kind, NULL, len, halo, out));
+}
+
 // ---- GCN ---------------------------------------------------------------------------------------
 void GCN_Aggregator::init(int l, int nv, int, float, float) {
   length = l;
@@ -18,12 +31,12 @@ void GCN_Aggregator::init(int l, int nv, int, float, float) {
 }
 void GCN_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, g.halo_prepare(len, in), out));
+  aggregate_rows(g, GAIB_W_GCN, len, in, out);
 }
 // the normalised adjacency is symmetric, so the derivative is the same operator
 void GCN_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_GCN, NULL, len, g.halo_prepare(len, grad_in), grad_out));
+  aggregate_rows(g, GAIB_W_GCN, len, grad_in, grad_out);
 }
 
 // ---- SAGE --------------------------------------------------------------------------------------
@@ -33,11 +46,11 @@ void SAGE_Aggregator::init(int l, int nv, int, float, float) {
 }
 void SAGE_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN, NULL, len, g.halo_prepare(len, in), out));
+  aggregate_rows(g, GAIB_W_MEAN, len, in, out);
 }
 void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_MEAN_T, NULL, len, g.halo_prepare(len, grad_in), grad_out));
+  aggregate_rows(g, GAIB_W_MEAN_T, len, grad_in, grad_out);
 }
 
 // ---- GAT ---------------------------------------------------------------------------------------

@@ -47,8 +47,9 @@ void* gaibl_graph_from_host(uint32_t nv, uint32_t ne, const uint32_t* rowptr, co
 void* gaibl_graph_adopt(void* h) { return LearningGraph::adopt_device(static_cast<gaib_graph*>(h)); }
 void* gaibl_graph_device(void* graph) { return static_cast<Graph*>(graph)->device_graph(); }
 uint64_t gaibl_graph_num_edges(void* graph) { return static_cast<Graph*>(graph)->sizeEdges(); }
-void gaibl_graph_set_halo_hook(void* graph, gaibl_halo_fn fn, void* user) {
-  static_cast<Graph*>(graph)->set_halo_hook(fn, user);
+void gaibl_graph_set_halo(void* graph, void* halo_graph, gaibl_halo_begin_fn begin, gaibl_halo_end_fn end,
+                          void* user) {
+  static_cast<Graph*>(graph)->set_halo(static_cast<gaib_graph*>(halo_graph), begin, end, user);
 }
 void gaibl_graph_free(void* graph) {
   Graph* g = static_cast<Graph*>(graph);

@@ -26,7 +26,7 @@ SIGNATURES = {
     "gaibl_graph_device": (_vp, [_vp]),
     "gaibl_graph_num_edges": (C.c_uint64, [_vp]),
     "gaibl_graph_free": (None, [_vp]),
-    "gaibl_graph_set_halo_hook": (None, [_vp, _vp, _vp]),
+    "gaibl_graph_set_halo": (None, [_vp, _vp, _vp, _vp, _vp]),
     "gaibl_layer_create": (_vp, [_i, _i, _i, _i, _i, _vp, _i, _f, _f, _f]),
     "gaibl_layer_forward": (None, [_vp, _vp]),
     "gaibl_layer_backward": (None, [_vp, _vp, _vp]),
@@ -116,15 +116,14 @@ class LGraph:
     def ne(self) -> int:
         return int(load().gaibl_graph_num_edges(self.h))
 
-    def set_halo_hook(self, fn):
-        """fn(len:int, d_in:int) -> int (device pointer of the [nc x len] feature table)"""
-        HOOK = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
-
-        def tramp(_user, length, d_in):
-            return fn(int(length), int(d_in or 0))
-
-        self._hook = HOOK(tramp)  # keep the trampoline alive
-        load().gaibl_graph_set_halo_hook(self.h, C.cast(self._hook, C.c_void_p), None)
+    def set_halo(self, halo_graph: capi.Graph, begin, end):
+        """begin(len:int, d_in:int) -> None ; end(len:int) -> int (device pointer of the halo table)"""
+        BEGIN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+        END = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int)
+        self._cb = (BEGIN(lambda _u, n, p: begin(int(n), int(p or 0))), END(lambda _u, n: end(int(n))))
+        self._halo_graph = halo_graph  # keep alive
+        load().gaibl_graph_set_halo(self.h, halo_graph.h, C.cast(self._cb[0], C.c_void_p),
+                                    C.cast(self._cb[1], C.c_void_p), None)
 
 
 class Layer:

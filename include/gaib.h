@@ -78,10 +78,12 @@ int gaib_graph_create_rect(gaib_ctx* ctx, int64_t nv, int64_t nc, int64_t ne, co
                            int rowptr_bits, const uint32_t* colidx, int src_on_device,
                            gaib_graph** out);
 /* Partitioned graphs: a halo column's local degree is truncated, so the normalisers come from
- * the GLOBAL graph: d_row_vdata [nv] (NULL = derive from rowptr), d_col_vdata [nc] (deg^-1/2),
- * d_col_inv_deg [nc] (1/deg).  Arrays are copied. */
+ * the GLOBAL graph: d_row_vdata / d_row_inv_deg [nv] (NULL = derive from this graph's rowptr; pass
+ * them when the rows hold only part of their edges, i.e. the owned-/halo-column split graphs),
+ * d_col_vdata [nc] (deg^-1/2), d_col_inv_deg [nc] (1/deg).  Arrays are copied. */
 int gaib_graph_set_vertex_norm(gaib_ctx* ctx, gaib_graph* g, const float* d_row_vdata,
-                               const float* d_col_vdata, const float* d_col_inv_deg);
+                               const float* d_row_inv_deg, const float* d_col_vdata,
+                               const float* d_col_inv_deg);
 int gaib_graph_destroy(gaib_graph* g);
 /* LearningGraph::add_selfloop (lgraph.h:185-218) as a device-side rebuild. */
 int gaib_graph_add_selfloop(gaib_ctx* ctx, const gaib_graph* g, gaib_graph** out);
@@ -120,6 +122,10 @@ typedef enum {
 } gaib_weight_kind;
 int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
               const float* d_in, float* d_out);
+/* out[i,:] += ... : the second half of a split aggregation (owned-column edges first with
+ * gaib_spmm, halo-column edges added once the halo rows have arrived). */
+int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
+                  const float* d_in, float* d_out);
 
 /* ---- GAT attention pieces ---------------------------------------------------------------
  * gaib_gat_scores: GAT_Aggregator::aggregate's score pass (gat_aggregator.cpp:60-92;

@@ -36,9 +36,12 @@ void* gaibl_graph_adopt(void* gaib_graph_handle); /* wrap a gaib_graph that alre
 void* gaibl_graph_device(void* graph);            /* gaib_graph* */
 uint64_t gaibl_graph_num_edges(void* graph);
 void gaibl_graph_free(void* graph);
-/* partitioned graphs: hook called before every aggregation (LearningGraph::set_halo_hook) */
-typedef const float* (*gaibl_halo_fn)(void* user, int len, const float* d_in);
-void gaibl_graph_set_halo_hook(void* graph, gaibl_halo_fn fn, void* user);
+/* vertex-range partitions (LearningGraph::set_halo): `halo_graph` is the gaib_graph of the
+ * halo-column edges; begin() packs + starts the exchange, end() waits and returns the halo table */
+typedef void (*gaibl_halo_begin_fn)(void* user, int len, const float* d_in);
+typedef const float* (*gaibl_halo_end_fn)(void* user, int len);
+void gaibl_graph_set_halo(void* graph, void* halo_graph, gaibl_halo_begin_fn begin, gaibl_halo_end_fn end,
+                          void* user);
 
 void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
                          float feat_drop, float score_drop);

@@ -21,18 +21,21 @@ class LearningGraph {
   vdata_t* vertex_data_;  // host copies, filled on demand
   edata_t* edge_data_;
   gaib_graph* dev_;  // CSR + normalisers + kernel schedules in HBM
-  // vertex-range partitions: called before every aggregation with the owned rows [nv x len];
-  // returns the feature table [nc x len] (owned rows first, halo rows after) the local CSR's
-  // column ids index.  No reference counterpart.
-  const float* (*halo_hook_)(void* user, int len, const float* d_in);
+  // vertex-range partitions (no reference counterpart): the rows' edges are split into
+  // an owned-column graph (dev_: column ids index the layer's own feature rows) and a halo-column
+  // graph (halo_dev_: column ids index the halo table).  halo_begin_ packs the rows other ranks need
+  // and starts the all-to-all; halo_end_ waits and returns the halo table [n_halo x len].
+  gaib_graph* halo_dev_;
+  void (*halo_begin_)(void* user, int len, const float* d_in);
+  const float* (*halo_end_)(void* user, int len);
   void* halo_user_;
 
  public:
   typedef size_t iterator;
   LearningGraph(bool use_gpu)
       : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
-        colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_hook_(NULL),
-        halo_user_(NULL) {}
+        colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_dev_(NULL),
+        halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL) {}
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -72,13 +75,17 @@ class LearningGraph {
   void compute_edge_data();
   void dealloc();
   gaib_graph* device_graph() { return dev_; }
-  void set_halo_hook(const float* (*fn)(void*, int, const float*), void* user) {
-    halo_hook_ = fn;
+  void set_halo(gaib_graph* halo_graph, void (*begin)(void*, int, const float*),
+                const float* (*end)(void*, int), void* user) {
+    halo_dev_ = halo_graph;
+    halo_begin_ = begin;
+    halo_end_ = end;
     halo_user_ = user;
   }
-  const float* halo_prepare(int len, const float* d_in) {
-    return halo_hook_ ? halo_hook_(halo_user_, len, d_in) : d_in;
-  }
+  bool has_halo() const { return halo_dev_ != NULL; }
+  gaib_graph* halo_graph() { return halo_dev_; }
+  void halo_begin(int len, const float* d_in) { halo_begin_(halo_user_, len, d_in); }
+  const float* halo_end(int len) { return halo_end_(halo_user_, len); }
   // device pointers, as the reference's ENABLE_GPU accessors return them.  Row pointers are
   // int64 in HBM (the reference's uint32 offsets overflow past 2^32 edges*features).
   const int64_t* row_start_ptr() const { return gaib_graph_rowptr(dev_); }

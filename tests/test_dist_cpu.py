@@ -38,32 +38,43 @@ def _worker(rank, world, port, q):
         rp_l = torch.from_numpy((g.rowptr[lo:hi + 1] - e0).astype(np.int64))
         ci_g = torch.from_numpy(g.colidx[e0:e1].astype(np.int64))
         part = gd.build_partition(rp_l, ci_g, n, rank, world)
-        assert part.n_own == hi - lo
-        # local -> global map round trip
-        l2g = torch.cat([torch.arange(lo, hi), part.halo_gids])
-        assert torch.equal(l2g[part.colidx.long()], ci_g)
+        assert part.n_own == hi - lo and part.ne == len(ci_g)
+        # owned-/halo-column split keeps every edge, in row order
+        own_g = part.colidx_own.long() + lo
+        halo_g = part.halo_gids[part.colidx_halo.long()]
+        for r in (0, part.n_own // 2, part.n_own - 1):
+            seg = ci_g[rp_l[r]:rp_l[r + 1]]
+            mine = torch.cat([own_g[part.rowptr_own[r]:part.rowptr_own[r + 1]],
+                              halo_g[part.rowptr_halo[r]:part.rowptr_halo[r + 1]]])
+            assert torch.equal(torch.sort(mine).values, seg)
         ex = gd.HaloExchanger(part)
-        table = torch.zeros(part.n_table, D)
-        table[:part.n_own] = torch.from_numpy(x[lo:hi])
-        ex.exchange(table)
-        assert torch.equal(table, torch.from_numpy(x)[l2g]), "halo rows must equal their owners' rows"
-        vd, inv = gd.global_normalisers(part, ex)
+        xt = torch.from_numpy(x)
+        halo_rows = ex.exchange(xt[lo:hi].contiguous(), D)
+        assert torch.equal(halo_rows, xt[part.halo_gids]), "halo rows must equal their owners' rows"
+        vd, inv, vd_h, inv_h = gd.global_normalisers(part, ex)
         vd_g = g.vertex_data()
-        assert np.array_equal(vd.numpy(), vd_g[l2g.numpy()])
-        # local aggregation over [owned | halo] == the rows of the global result
-        lg = orc.Graph(part.rowptr.numpy(), part.colidx.numpy().astype(np.uint32))
-        ew = vd.numpy()[:part.n_own].repeat(np.diff(part.rowptr.numpy())) * vd.numpy()[part.colidx.numpy()]
-        loc = np.zeros((part.n_table, D), np.float32)  # oracle expects square tables: pad rows
-        tab = table.numpy()
+        assert np.array_equal(vd.numpy(), vd_g[lo:hi]) and np.array_equal(vd_h.numpy(), vd_g[part.halo_gids.numpy()])
+        # owned-column edges first, then the halo-column edges accumulated onto the same rows ==
+        # the rows of the global result (same terms; order: owned then halo)
         import ctypes as C
-        out = np.empty((part.n_own, D), np.float32)
-        orc.lib().orc_spmm_edge(C.c_int64(part.n_own), orc._p(lg.rowptr), orc._p(lg.colidx), orc._p(ew.astype(np.float32)),
-                                C.c_int(D), orc._p(tab), orc._p(out))
-        assert np.array_equal(out.view(np.uint32), want_gcn[lo:hi].view(np.uint32)), "same terms, same order"
-        ew2 = inv.numpy()[part.colidx.numpy()]
-        orc.lib().orc_spmm_edge(C.c_int64(part.n_own), orc._p(lg.rowptr), orc._p(lg.colidx), orc._p(ew2.astype(np.float32)),
-                                C.c_int(D), orc._p(tab), orc._p(out))
-        assert np.array_equal(out.view(np.uint32), want_mean_t[lo:hi].view(np.uint32))
+
+        def spmm_edge(rp, ci, ew, table, out, nrows):
+            orc.lib().orc_spmm_edge(C.c_int64(nrows), orc._p(rp), orc._p(ci), orc._p(ew), C.c_int(D), orc._p(table),
+                                    orc._p(out))
+
+        rpo, cio = part.rowptr_own.numpy(), part.colidx_own.numpy().astype(np.uint32)
+        rph, cih = part.rowptr_halo.numpy(), part.colidx_halo.numpy().astype(np.uint32)
+        xo = np.ascontiguousarray(x[lo:hi])
+        xh = np.ascontiguousarray(halo_rows.numpy())
+        for vrow, vown, vhalo, want in [(vd.numpy(), vd.numpy(), vd_h.numpy(), want_gcn),
+                                        (np.ones(part.n_own, np.float32), inv.numpy(), inv_h.numpy(), want_mean_t)]:
+            ew_o = (vrow.repeat(np.diff(rpo)) * vown[cio]).astype(np.float32)
+            ew_h = (vrow.repeat(np.diff(rph)) * vhalo[cih]).astype(np.float32)
+            a = np.empty((part.n_own, D), np.float32)
+            b2 = np.empty((part.n_own, D), np.float32)
+            spmm_edge(rpo, cio, ew_o, xo, a, part.n_own)
+            spmm_edge(rph, cih, ew_h, xh, b2, part.n_own)
+            assert rel_err(a + b2, want[lo:hi]) < 1e-6
         # weight-gradient reduction: sum of per-rank X_own^T G_own == global X^T G
         G = np.random.default_rng(6).standard_normal((n, D)).astype(np.float32)
         dW = torch.from_numpy(x[lo:hi].astype(np.float64).T @ G[lo:hi].astype(np.float64))

@@ -207,6 +207,38 @@ def test_spmm_argument_errors(ctx):
         ctx.spmm(g, capi.W_EDGE, x, torch.empty_like(x))  # missing weights
 
 
+@pytest.mark.parametrize("d", [16, 128, 300])
+def test_spmm_accumulate_split_by_column(ctx, d):
+    """gaib_spmm on the low-column edges then gaib_spmm_acc on the high-column edges continues the
+    same CSR-order sum: bit-identical to one pass on light rows (the multi-GPU own/halo split)."""
+    rp, ci = random_graph(3000, 14, seed=3, power_law=True, hub_deg=2500)
+    g_o = orc.Graph(rp, ci)
+    n = g_o.nv
+    x = feat(n, d, 1)
+    ew = np.random.default_rng(2).random(g_o.ne).astype(np.float32)
+    want = orc.spmm_edge(g_o, ew, x)
+    t = n // 2
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    lo_mask = ci < t
+
+    def sub(mask):
+        cnt = np.bincount(rows[mask], minlength=n)
+        return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ci[mask], ew[mask]
+
+    rpa, cia, ewa = sub(lo_mask)
+    rpb, cib, ewb = sub(~lo_mask)
+    ga = ctx.graph(rpa, cia.view(np.int32))
+    gb = ctx.graph(rpb, cib.view(np.int32))
+    xd = dev(x)
+    out = torch.empty(n, d, device="cuda")
+    ctx.spmm(ga, capi.W_EDGE, xd, out, edge_w=dev(ewa))
+    ctx.spmm(gb, capi.W_EDGE, xd, out, edge_w=dev(ewb), accumulate=True)
+    got = out.cpu().numpy()
+    light = (np.diff(rpa) <= 1024) & (np.diff(rpb) <= 1024)
+    assert np.array_equal(got[light].view(np.uint32), want[light].view(np.uint32))
+    assert rel_err(got, want) < 1e-5
+
+
 def test_spmm_rectangular_partition_graph(ctx):
     """owned rows x (owned + halo) columns, global normalisers"""
     rp, ci = random_graph(1200, 10, seed=31, power_law=True)
