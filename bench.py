@@ -136,7 +136,11 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GAIB_DIST_BACKEND", "nccl")  # "gloo": several ranks on ONE GPU (tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log)
         if rank == 0:
             print(json.dumps(result), flush=True)

@@ -231,9 +231,12 @@ class DistLayerGraph:
         g_own.set_vertex_norm(vd, vd, inv, row_inv_deg=inv)
         self.lgraph = L.LGraph.adopt(g_own)
         self.g_halo = None
-        if part.n_halo > 0:
-            self.g_halo = ctx.graph(part.rowptr_halo, part.colidx_halo, ncols=part.n_halo)
-            self.g_halo.set_vertex_norm(vd, vd_h, inv_h, row_inv_deg=inv)
+        if part.world > 1:
+            # every rank takes part in every exchange, also one without halo rows of its own
+            nh = max(part.n_halo, 1)
+            pad = lambda t: t if part.n_halo > 0 else torch.zeros(1, dtype=torch.float32, device=dev)
+            self.g_halo = ctx.graph(part.rowptr_halo, part.colidx_halo, ncols=nh)
+            self.g_halo.set_vertex_norm(vd, pad(vd_h), pad(inv_h), row_inv_deg=inv)
             self.lgraph.set_halo(self.g_halo, self._begin, self._end)
         self._dev = dev
 
@@ -317,9 +320,10 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     n_light, ms_light = ctx.prof_get("spmm_light")
     ctx.prof_reset()
     # max time over ranks, total edges over ranks
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    e = torch.tensor([float(part.ne), float(part.n_halo), float(dg.ex.bytes_sent)], dtype=torch.float64, device="cuda")
+    e = torch.tensor([float(part.ne), float(part.n_halo), float(dg.ex.bytes_sent)], dtype=torch.float64, device=rdev)
     dist.all_reduce(e, op=dist.ReduceOp.SUM)
     elapsed = float(t[0])
     total_edges = float(e[0])

@@ -21,7 +21,8 @@ static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* 
   g.halo_begin(len, in);
   GAIB_OR_DIE(gaib_spmm(C(), dev(g), kind, NULL, len, in, out));
   const float* halo = g.halo_end(len);
-  GAIB_OR_DIE(gaib_spmm_acc(C(), g.halo_graph(), kind, NULL, len, halo, out));
+  if (gaib_graph_ne(g.halo_graph()) > 0)
+    GAIB_OR_DIE(gaib_spmm_acc(C(), g.halo_graph(), kind, NULL, len, halo, out));
 }
 
 // ---- GCN ---------------------------------------------------------------------------------------

@@ -73,3 +73,25 @@ def test_two_ranks_on_one_gpu_match_global_oracle():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """bench.py's N>1 leg end to end (block graph generator with cut edges, partition, split
+    aggregation, dW all-reduce, JSON line) with 2 ranks sharing cuda:0 over gloo at 2 % scale."""
+    import json
+    import subprocess
+
+    port = 29900 + (os.getpid() % 90)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GAIB_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+                                       "1", "--scale", "0.02", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["halo_rows_total"] > 0
+    assert res["scaling"] == "weak" and res["roofline"]["achieved"] > 0
