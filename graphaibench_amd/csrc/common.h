@@ -51,6 +51,8 @@ struct gaib_ctx {
   int spmm_xcd_swizzle;      // 1 = consecutive row blocks share an XCD
   int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8
   int spmm_addr_mode;        // 0 = auto (buffer loads when the table is < 4 GB), 2 = force 64-bit global
+  int spmm_gather_mode;      // 0/1 default cache policy, 2 = nt gathers, 3 = nt for cold columns only
+  int spmm_hot_bytes;        // L2 budget for the hot rows of gather mode 3
   int sgemm_variant;         // 0 = auto
   int gat_fast;              // reserved
   // in-stream kernel timing (gaib_prof_*)
@@ -98,6 +100,9 @@ struct gaib_graph {
   uint32_t* chunk_row;    // [n_chunks] row of each chunk
   uint32_t* chunk_ebase;  // [n_chunks] first edge of each chunk
   int64_t n_chunks;
+  uint32_t* colidx_flagged;  // gather mode 3: colidx with bit 31 set on cold (low-degree) columns
+  int64_t hot_threshold;     // degree threshold the flags were built with (-1 = none)
+  int64_t hot_rows;          // size of the hot set the flags were built for
   uint32_t* heavy_rows;
   int64_t n_heavy;
   int64_t heavy_edges;
@@ -112,6 +117,7 @@ int gaib_graph_ensure_w_mean_t(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr);
 int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g);
+int gaib_graph_ensure_hot_flags(gaib_ctx* ctx, gaib_graph* g, int len);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -5,6 +5,8 @@
 // HBM layout: rowptr int64[nv+1] | colidx uint32[ne] | vdata/inv_deg fp32[nv] |
 // w_gcn / w_mean_t / edata fp32[ne] | rev uint32[ne].  Everything is streamed linearly by the
 // kernels that use it; only the feature rows are gathered.
+#include <algorithm>
+#include <functional>
 #include "common.h"
 
 namespace {
@@ -132,6 +134,7 @@ int new_graph(int64_t nv, int64_t ne, int device, gaib_graph** out) {
   g->nc = nv;
   g->ne = ne;
   g->heavy_thr = -1;
+  g->hot_threshold = -1;
   g->max_degree = -1;
   GAIB_HIP(hipMalloc(&g->rowptr, sizeof(int64_t) * (size_t)(nv + 1)));
   GAIB_HIP(hipMalloc(&g->colidx, sizeof(uint32_t) * (size_t)(ne > 0 ? ne : 1)));
@@ -239,7 +242,7 @@ extern "C" int gaib_graph_destroy(gaib_graph* g) {
   (void)hipSetDevice(g->device);
   void* ptrs[] = {g->rowptr, g->colidx,   g->vdata, g->edata,      g->inv_deg,  g->col_vdata,
                   g->col_inv_deg, g->w_gcn, g->w_mean_t, g->rev,   g->heavy_rows,
-                  g->chunk_row, g->chunk_ebase};
+                  g->chunk_row, g->chunk_ebase, g->colidx_flagged};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -388,6 +391,44 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   }
   GAIB_HIP(hipFree(cnt));
   g->heavy_thr = thr;
+  return GAIB_OK;
+}
+
+// gather mode 3: flag cold columns.  The hot set is the highest-degree vertices whose feature rows
+// fit `spmm_hot_bytes` (default 3 MB of the 4 MB per-XCD L2); everything else is gathered with the
+// streaming (nt) policy so it does not push the hub rows out.
+__global__ void flag_cold_kernel(int64_t ne, const uint32_t* col, const int64_t* rowptr, int64_t thr,
+                                 uint32_t* out) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const uint32_t c = col[e];
+  const int64_t deg = rowptr[c + 1] - rowptr[c];
+  out[e] = deg >= thr ? c : (c | 0x80000000u);
+}
+
+int gaib_graph_ensure_hot_flags(gaib_ctx* ctx, gaib_graph* g, int len) {
+  int64_t hot_rows = (int64_t)ctx->spmm_hot_bytes / ((int64_t)len * 4);
+  if (hot_rows < 1) hot_rows = 1;
+  if (hot_rows > g->nv) hot_rows = g->nv;
+  // threshold = degree of the hot_rows-th highest-degree vertex
+  if (g->colidx_flagged && g->hot_rows == hot_rows) return GAIB_OK;
+  std::vector<int64_t> rp((size_t)g->nv + 1);
+  GAIB_HIP(hipMemcpyAsync(rp.data(), g->rowptr, sizeof(int64_t) * (g->nv + 1), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int64_t> deg((size_t)g->nv);
+  for (int64_t v = 0; v < g->nv; ++v) deg[v] = rp[v + 1] - rp[v];
+  std::nth_element(deg.begin(), deg.begin() + (hot_rows - 1), deg.end(), std::greater<int64_t>());
+  const int64_t thr = deg[hot_rows - 1];
+  if (!g->colidx_flagged) {
+    GAIB_HIP(hipMalloc(&g->colidx_flagged, sizeof(uint32_t) * (size_t)(g->ne > 0 ? g->ne : 1)));
+    g->dev_bytes += sizeof(uint32_t) * g->ne;
+  }
+  if (g->ne > 0) {
+    flag_cold_kernel<<<grid1d(g->ne, 256), 256, 0, ctx->stream>>>(g->ne, g->colidx, g->rowptr, thr, g->colidx_flagged);
+    GAIB_LAUNCH_CHECK();
+  }
+  g->hot_threshold = thr;
+  g->hot_rows = hot_rows;
   return GAIB_OK;
 }
 

@@ -37,6 +37,8 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_xcd_swizzle = 1;
   c->spmm_unroll = 0;
   c->spmm_addr_mode = 0;
+  c->spmm_gather_mode = 0;
+  c->spmm_hot_bytes = 3 << 20;
   c->sgemm_variant = 0;
   c->gat_fast = 1;
   c->prof_on = 0;
@@ -171,6 +173,10 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_unroll = (int)value;
   else if (!strcmp(key, "spmm_addr_mode"))
     ctx->spmm_addr_mode = (int)value;
+  else if (!strcmp(key, "spmm_gather_mode"))
+    ctx->spmm_gather_mode = (int)value;
+  else if (!strcmp(key, "spmm_hot_bytes"))
+    ctx->spmm_hot_bytes = (int)value;
   else if (!strcmp(key, "sgemm_variant"))
     ctx->sgemm_variant = (int)value;
   else if (!strcmp(key, "gat_fast"))

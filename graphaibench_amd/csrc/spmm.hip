@@ -44,6 +44,7 @@ struct SpmmArgs {
   int nblocks;               // light kernels: logical number of row blocks
   int per_xcd;               // ceil(nblocks/8) when swizzled, 0 otherwise
   uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)
+  const uint32_t* col_flagged;  // GM 3: column ids with the top bit set on cold columns
   int accumulate;            // out += instead of out = (second half of a split aggregation)
 };
 
@@ -97,8 +98,12 @@ typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 // base (col * row bytes) is a 32-bit SGPR offset against one descriptor for the whole table,
 // so a gather in flight costs only its VEC destination VGPRs (no 64-bit VGPR address pair).
 // Needs the table to be < 4 GB; larger tables use 64-bit global_load addresses.
-template <int VEC, bool BUF>
+// GM (gather mode): 0 = 64-bit global_load; 1 = buffer_load, default cache policy; 2 = buffer_load nt
+// (streaming) for every gather; 3 = buffer_load, nt only for COLD columns (top bit of the column id
+// set by gaib_graph_ensure_hot_flags), so the few thousand hub rows keep their place in the 4 MB L2.
+template <int VEC, int GM>
 struct RowGather {
+  static constexpr bool BUF = GM != 0;
   __amdgpu_buffer_rsrc_t rsrc;
   const char* inb;
   int64_t ldb;
@@ -109,26 +114,37 @@ struct RowGather {
   }
   __device__ __forceinline__ typename VecT<VEC>::type load(uint32_t cj, uint32_t voff) const {
     typedef typename VecT<VEC>::type vec_t;
-    if constexpr (BUF) {
-      const int soff = (int)(cj * (uint32_t)ldb);
-      if constexpr (VEC == 1) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, 0));
-      } else if constexpr (VEC == 2) {
-        u2_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, soff, 0);
-        vec_t v;
-        v[0] = __uint_as_float(r[0]);
-        v[1] = __uint_as_float(r[1]);
-        return v;
-      } else {
-        u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0);
-        vec_t v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
-        return v;
-      }
+    if constexpr (GM == 3) {
+      const uint32_t c = cj & 0x7fffffffu;
+      if (cj & 0x80000000u) return load_buf<2>(c, voff);  // wave-uniform branch (cj is scalar)
+      return load_buf<0>(c, voff);
+    } else if constexpr (GM == 2) {
+      return load_buf<2>(cj, voff);
+    } else if constexpr (GM == 1) {
+      return load_buf<0>(cj, voff);
     } else {
       const char* rowp = inb + (int64_t)cj * ldb;  // scalar base
       return *reinterpret_cast<const vec_t*>(rowp + voff);
+    }
+  }
+  template <int AUX>
+  __device__ __forceinline__ typename VecT<VEC>::type load_buf(uint32_t cj, uint32_t voff) const {
+    typedef typename VecT<VEC>::type vec_t;
+    const int soff = (int)(cj * (uint32_t)ldb);
+    if constexpr (VEC == 1) {
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, AUX));
+    } else if constexpr (VEC == 2) {
+      u2_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, soff, AUX);
+      vec_t v;
+      v[0] = __uint_as_float(r[0]);
+      v[1] = __uint_as_float(r[1]);
+      return v;
+    } else {
+      u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, AUX);
+      vec_t v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
+      return v;
     }
   }
 };
@@ -139,7 +155,7 @@ struct RowGather {
 // voff[ct] is the lane's BYTE offset inside a feature row; lanes whose columns fall outside
 // the row are pointed at offset 0, so every gather is unconditional (a predicated load makes
 // hipcc branch on EXEC and drain vmcnt after each one); what they accumulate is never stored.
-template <int VEC, int CT, int WMODE, int U, bool BUF>
+template <int VEC, int CT, int WMODE, int U, int BUF>
 __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int64_t eb, int64_t ee,
                                                 int64_t chunk_stride, float roww,
                                                 const uint32_t (&voff)[CT],
@@ -207,7 +223,7 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
 }
 
 // ---- light rows, one wave per row ------------------------------------------------------
-template <int VEC, int CT, int WMODE, int U, bool BUF>
+template <int VEC, int CT, int WMODE, int U, int BUF>
 __global__ __launch_bounds__(256) void spmm_w64_kernel(SpmmArgs a) {
   typedef typename VecT<VEC>::type vec_t;
   const int lane = threadIdx.x & 63;
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(256) void spmm_w64_kernel(SpmmArgs a) {
 
 // ---- heavy rows, one 1024-thread workgroup per row ------------------------------------
 constexpr int HEAVY_WAVES = 16;
-template <int VEC, int CT, int WMODE, int U, bool BUF>
+template <int VEC, int CT, int WMODE, int U, int BUF>
 __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a) {
   typedef typename VecT<VEC>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [HEAVY_WAVES][CT*64*VEC]
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
 }
 
 // ---- dispatch --------------------------------------------------------------------------
-template <int VEC, int CT, int WMODE, int U, bool BUF>
+template <int VEC, int CT, int WMODE, int U, int BUF>
 int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   // heavy rows first (few, long): their tail hides under the light kernel's start
   if (g->n_heavy > 0) {
@@ -351,13 +367,19 @@ template <int VEC, int CT, int WMODE>
 int launch_w64(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   // gathers in flight per wave: sized so the destination registers stay <= 32 VGPRs
   constexpr int U = (VEC * CT >= 8) ? 4 : (VEC * CT >= 4 ? 8 : 16);
-  const bool buf = a.in_bytes != 0 && ctx->spmm_addr_mode != 2;
-  if (buf) {
-    if (ctx->spmm_unroll == 8 && U > 8) return launch_w64_u<VEC, CT, WMODE, 8, true>(ctx, g, a);
-    return launch_w64_u<VEC, CT, WMODE, U, true>(ctx, g, a);
+  int gm = (a.in_bytes != 0 && ctx->spmm_addr_mode != 2) ? 1 : 0;
+  if (gm == 1 && ctx->spmm_gather_mode == 2) gm = 2;
+  if (gm == 1 && ctx->spmm_gather_mode == 3 && a.col_flagged) {
+    gm = 3;
+    a.col = a.col_flagged;
   }
-  if (ctx->spmm_unroll == 8 && U > 8) return launch_w64_u<VEC, CT, WMODE, 8, false>(ctx, g, a);
-  return launch_w64_u<VEC, CT, WMODE, U, false>(ctx, g, a);
+  const bool u8 = ctx->spmm_unroll == 8 && U > 8;
+  switch (gm) {
+    case 0: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 0>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 0>(ctx, g, a);
+    case 2: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 2>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 2>(ctx, g, a);
+    case 3: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 3>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 3>(ctx, g, a);
+    default: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 1>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 1>(ctx, g, a);
+  }
 }
 
 template <int VEC, int G, int WMODE>
@@ -367,7 +389,7 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     h.row_list = g->heavy_rows;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy");
-    spmm_heavy_kernel<VEC, 1, WMODE, 8, false><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
+    spmm_heavy_kernel<VEC, 1, WMODE, 8, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                  ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
   }
@@ -480,6 +502,11 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
   a.nblocks = 0;
   a.per_xcd = 0;
   a.accumulate = accumulate;
+  a.col_flagged = nullptr;
+  if (ctx->spmm_gather_mode == 3 && g->nc == g->nv && !g->col_vdata) {
+    GAIB_TRY(gaib_graph_ensure_hot_flags(ctx, g, len));
+    a.col_flagged = g->colidx_flagged;
+  }
   // feature table = nc rows of len floats; the 32-bit buffer path needs it below 4 GB
   const int64_t table_bytes = g->nc * (int64_t)len * 4;
   a.in_bytes = table_bytes < ((int64_t)1 << 32) ? (uint32_t)table_bytes : 0u;

@@ -68,6 +68,12 @@ def main():
         res.append(r)
 
     run("default")
+    run("gather_nt_all", spmm_gather_mode=2)
+    for hb in (64 << 20, 128 << 20, 192 << 20, 256 << 20, 384 << 20, 512 << 20, 768 << 20, 1024 << 20):
+        ctx.set_option("spmm_hot_bytes", hb)
+        run(f"gather_hotcold_{hb >> 20}MB", spmm_gather_mode=3)
+    ctx.set_option("spmm_hot_bytes", 3 << 20)
+    run("default_again")
     run("unroll8", spmm_unroll=8)
     run("global_addr", spmm_addr_mode=2)
     run("global_addr_unroll8", spmm_addr_mode=2, spmm_unroll=8)

@@ -231,3 +231,36 @@ def test_sage_layer_forward_backward_against_autograd():
         assert rel_err(grad_out, xt.grad.numpy()) < 1e-5
         assert rel_err(layer.W_neigh_grad, Wn.grad.numpy()) < 1e-5
         assert rel_err(layer.W_self_grad, Ws.grad.numpy()) < 1e-5
+
+
+def test_citeseer_plumbing_cpu_path():
+    """BASELINE config 0: citeseer GCN 2-layer hidden 16 on the CPU path (the shipped citeseer has
+    topology + labels only: features and the train range are synthesised)."""
+    from pathlib import Path
+
+    d = Path(__file__).resolve().parent / "golden" / "citeseer"
+    rp = np.fromfile(d / "graph.vertex.bin", np.int64)
+    ci = np.fromfile(d / "graph.edge.bin", np.uint32)
+    labels = np.fromfile(d / "graph.vlabel.bin", np.uint8)
+    n, F, H, C = len(rp) - 1, 64, 16, int(labels.max()) + 1
+    assert n == 3312 and len(ci) == 9072 and C == 6
+    g = orc.Graph(rp, ci).add_selfloop()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, F)).astype(np.float32) * 0.3
+    x[np.arange(n), labels.astype(int)] += 1.0
+    masks = np.zeros(n, np.uint8)
+    masks[:300] = 1
+    l0, l1 = orc.GCNLayer(0, g, F, H, True), orc.GCNLayer(1, g, H, C, False)
+    opt = orc.Adam(0.02)
+    losses = []
+    for _ in range(8):
+        a = l0.forward(x)
+        logits = l1.forward(a)
+        p, lv = orc.softmax_xent_fwd(logits, labels, 0, 300, masks)
+        losses.append(orc.masked_avg_loss(lv, 0, 300, masks))
+        g1 = orc.softmax_xent_bwd(p, labels, 0, 300, masks)
+        g0 = l1.backward(g1)
+        l0.backward(g0)
+        opt.update("w0", l0.W_grad, l0.W)
+        opt.update("w1", l1.W_grad, l1.W)
+    assert losses[-1] < losses[0] - 0.05 and all(np.isfinite(losses))
