@@ -49,11 +49,13 @@ SIGNATURES = {
     "gaib_graph_device_bytes": (_i64, [_vp]),
     "gaib_spmm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_spmm_acc": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "gaib_spmm_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_edge_transpose": (_i, [_vp, _vp, _vp, _vp]),
     "gaib_sgemm": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
+    "gaib_sgemm_ex": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
     "gaib_relu": (_i, [_vp, _i64, _vp, _vp]),
     "gaib_d_relu": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "gaib_dropout": (_i, [_vp, _i64, _f, _f, _u64, _vp, _vp, _vp]),
@@ -168,10 +170,11 @@ class Context:
         return Graph(self, rowptr, colidx, ncols)
 
     # ---- aggregation --------------------------------------------------------------------
-    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None, accumulate: bool = False):
+    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None, accumulate: bool = False, relu: bool = False):
         assert x.is_contiguous() and out.is_contiguous() and x.dim() == 2
-        fn = self.lib.gaib_spmm_acc if accumulate else self.lib.gaib_spmm
-        _check(fn(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(out)), "gaib_spmm")
+        flags = (1 if accumulate else 0) | (2 if relu else 0)
+        _check(self.lib.gaib_spmm_ex(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(out), flags),
+               "gaib_spmm")
         return out
 
     def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2):
@@ -191,12 +194,13 @@ class Context:
         _check(self.lib.gaib_edge_transpose(self.h, g.h, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")
 
     # ---- dense ----------------------------------------------------------------------------
-    def sgemm(self, A, B, Cm, transA=False, transB=False, accum=False):
+    def sgemm(self, A, B, Cm, transA=False, transB=False, accum=False, relu=False):
         """row-major C[M x N] (=|+=) op(A) . op(B); shapes follow the reference's matmul()."""
         M, N = Cm.shape
         K = A.shape[0] if transA else A.shape[1]
-        _check(self.lib.gaib_sgemm(self.h, int(transA), int(transB), M, N, K, _ptr(A), _ptr(B),
-                                   int(accum), _ptr(Cm)), "gaib_sgemm")
+        flags = (1 if accum else 0) | (2 if relu else 0)
+        _check(self.lib.gaib_sgemm_ex(self.h, int(transA), int(transB), M, N, K, _ptr(A), _ptr(B),
+                                      flags, _ptr(Cm)), "gaib_sgemm")
         return Cm
 
     # ---- elementwise / loss / optimizer -----------------------------------------------------

@@ -36,6 +36,7 @@ struct GemmArgs {
   int64_t M, N, K;
   int64_t k_chunk;  // K range per blockIdx.y (multiple of BK); == K when not split
   int accum;        // C += (ignored when writing split-K partials)
+  int relu;         // clamp at 0 in the epilogue (ignored when writing split-K partials)
   int64_t slab;     // M*N when writing partials (C + blockIdx.y*slab), else 0
   int tiles_n;
 };
@@ -83,8 +84,8 @@ __device__ __forceinline__ void tile_store_lds(float* lds, const f4 (&regs)[TR *
 
 // WAVES_M x WAVES_N waves, each WM x WN tiles of 32x32.
 // A_KMAJOR: op(A) is stored [K][M] (transA);  B_KMAJOR: op(B) is stored [K][N] (no transB).
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC>
-__global__ __launch_bounds__(THREADS) void sgemm_mfma_kernel(GemmArgs g) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC, int OCC>
+__global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int BM = WAVES_M * WM * 32;
   constexpr int BN = WAVES_N * WN * 32;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(THREADS) void sgemm_mfma_kernel(GemmArgs g) {
   // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (g.slab ? (int64_t)blockIdx.y * g.slab : 0);
   const bool accum = g.accum && !g.slab;
+  const bool relu = g.relu && !g.slab;
 #pragma unroll
   for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(THREADS) void sgemm_mfma_kernel(GemmArgs g) {
           const int64_t mm = m0 + (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (mm < g.M) {
             float* p = C + mm * g.N + nn;
-            *p = accum ? (*p + acc[a][b][r]) : acc[a][b][r];
+            float v = accum ? (*p + acc[a][b][r]) : acc[a][b][r];
+            if (relu && !(v > 0.f)) v = 0.f;
+            *p = v;
           }
         }
       }
@@ -206,13 +210,13 @@ __global__ __launch_bounds__(THREADS) void sgemm_mfma_kernel(GemmArgs g) {
 }
 
 // C[i] = (accum ? C[i] : 0) + sum_s partial[s][i], s in order (deterministic)
-__global__ void splitk_reduce_kernel(int64_t n, int splits, const float* partial, int accum,
+__global__ void splitk_reduce_kernel(int64_t n, int splits, const float* partial, int accum, int relu,
                                      float* C) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float s = accum ? C[i] : 0.f;
     for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * n + i];
-    C[i] = s;
+    C[i] = (relu && !(s > 0.f)) ? 0.f : s;
   }
 }
 
@@ -226,7 +230,7 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
   // split K when the output has too few tiles to fill 256 CUs and K is long (weight grads)
   int splits = 1;
   if (tiles < 2 * ctx->num_cus && g.K >= 8192) {
-    int64_t want = cdiv64(4 * (int64_t)ctx->num_cus, tiles);
+    int64_t want = cdiv64(2 * (int64_t)ctx->num_cus, tiles);
     int64_t maxs = g.K / (8 * BK);
     splits = (int)(want < maxs ? want : maxs);
     if (splits < 1) splits = 1;
@@ -245,18 +249,24 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
   }
   dim3 grid((unsigned)tiles, (unsigned)splits);
   ProfScope ps(ctx, "sgemm");
-#define GAIB_GEMM_LAUNCH(AV, BV)                                                         \
-  sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV><<<grid, THREADS, 0, ctx->stream>>>(g)
-  if (avec && bvec) GAIB_GEMM_LAUNCH(true, true);
-  else if (avec) GAIB_GEMM_LAUNCH(true, false);
-  else if (bvec) GAIB_GEMM_LAUNCH(false, true);
-  else GAIB_GEMM_LAUNCH(false, false);
+  // OCC = workgroups per CU the register allocation is held to (__launch_bounds__ 2nd argument):
+  // more resident blocks hide the staging / epilogue phases of one block under another's MFMAs.
+#define GAIB_GEMM_LAUNCH(AV, BV, OCC)                                                    \
+  sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV, OCC><<<grid, THREADS, 0, ctx->stream>>>(g)
+  const int occ = ctx->sgemm_variant == 2 ? 2 : (ctx->sgemm_variant == 4 ? 4 : 3);
+  if (avec && bvec) {
+    if (occ == 4) GAIB_GEMM_LAUNCH(true, true, 4);
+    else if (occ == 3) GAIB_GEMM_LAUNCH(true, true, 3);
+    else GAIB_GEMM_LAUNCH(true, true, 2);
+  } else if (avec) GAIB_GEMM_LAUNCH(true, false, 2);
+  else if (bvec) GAIB_GEMM_LAUNCH(false, true, 2);
+  else GAIB_GEMM_LAUNCH(false, false, 2);
 #undef GAIB_GEMM_LAUNCH
   GAIB_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t n = g.M * g.N;
     unsigned rg = (unsigned)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
-    splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, splits, (const float*)ctx->ws, accum, Cout);
+    splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, splits, (const float*)ctx->ws, accum, g.relu, Cout);
     GAIB_LAUNCH_CHECK();
   }
   return GAIB_OK;
@@ -273,6 +283,12 @@ int dispatch_shape(gaib_ctx* ctx, const GemmArgs& g, bool avec, bool bvec) {
 
 extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
                           const float* d_A, const float* d_B, int accum, float* d_C) {
+  return gaib_sgemm_ex(ctx, transA, transB, M, N, K, d_A, d_B, accum ? GAIB_ACCUMULATE : 0, d_C);
+}
+
+extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                             const float* d_A, const float* d_B, int flags, float* d_C) {
+  const int accum = (flags & GAIB_ACCUMULATE) ? 1 : 0;
   GAIB_CHECK(ctx, "gaib_sgemm: ctx is NULL");
   GAIB_CHECK(M >= 0 && N >= 0 && K >= 0, "gaib_sgemm: negative dimension");
   if (M == 0 || N == 0) return GAIB_OK;
@@ -281,6 +297,7 @@ extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
   GAIB_HIP(hipSetDevice(ctx->device));
   if (K == 0) {
     if (!accum) return gaib_fill_f32(ctx, M * N, 0.f, d_C);
+    if (flags & GAIB_RELU) return gaib_relu(ctx, M * N, d_C, d_C);
     return GAIB_OK;
   }
   if (transA && transB) {
@@ -296,6 +313,7 @@ extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
   g.K = K;
   g.k_chunk = K;
   g.accum = accum ? 1 : 0;
+  g.relu = (flags & GAIB_RELU) ? 1 : 0;
   g.slab = 0;
   g.tiles_n = 1;
   // 16-B loads need an aligned base and a leading dimension that keeps rows aligned

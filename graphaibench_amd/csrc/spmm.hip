@@ -46,6 +46,7 @@ struct SpmmArgs {
   uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)
   const uint32_t* col_flagged;  // GM 3: column ids with the top bit set on cold columns
   int accumulate;            // out += instead of out = (second half of a split aggregation)
+  int relu;                  // clamp at 0 on store (activation fused)
 };
 
 template <int VEC> struct VecT;
@@ -60,6 +61,15 @@ __device__ __forceinline__ typename VecT<VEC>::type vzero() {
   else
     for (int i = 0; i < VEC; ++i) z[i] = 0.f;
   return z;
+}
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type vrelu(typename VecT<VEC>::type v) {
+  if constexpr (VEC == 1) return v > 0.f ? v : 0.f;
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    return v;
+  }
 }
 template <int VEC>
 __device__ __forceinline__ void vacc(typename VecT<VEC>::type& acc, float w,
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(256) void spmm_w64_kernel(SpmmArgs a) {
   wave_accumulate<VEC, CT, WMODE, U, BUF>(a, lane, e0, e1, 64, roww, voff, acc);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
-    if (colok[ct]) *reinterpret_cast<vec_t*>(o + ct * 64 * VEC) = acc[ct];
+    if (colok[ct]) *reinterpret_cast<vec_t*>(o + ct * 64 * VEC) = a.relu ? vrelu<VEC>(acc[ct]) : acc[ct];
 }
 
 // ---- heavy rows, one 1024-thread workgroup per row ------------------------------------
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a
     float s = a.accumulate ? a.out[(int64_t)row * a.ld + c] + red[c] : red[c];
 #pragma unroll
     for (int w = 1; w < HEAVY_WAVES; ++w) s = s + red[w * W + c];
-    a.out[(int64_t)row * a.ld + c] = s;
+    a.out[(int64_t)row * a.ld + c] = (a.relu && !(s > 0.f)) ? 0.f : s;
   }
 }
 
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
     for (int u = 0; u < U; ++u)
       if (e + u < e1) vacc<VEC>(acc, wj[u], x[u]);
   }
-  if (active && colok) *reinterpret_cast<vec_t*>(a.out + row * a.ld + sl * VEC) = acc;
+  if (active && colok) *reinterpret_cast<vec_t*>(a.out + row * a.ld + sl * VEC) = a.relu ? vrelu<VEC>(acc) : acc;
 }
 
 // ---- dispatch --------------------------------------------------------------------------
@@ -476,7 +486,8 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
 }  // namespace
 
 static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
-                     const float* d_in, float* d_out, int accumulate) {
+                     const float* d_in, float* d_out, int flags) {
+  const int accumulate = (flags & GAIB_ACCUMULATE) ? 1 : 0;
   GAIB_CHECK(ctx && g, "gaib_spmm: NULL ctx/graph");
   GAIB_CHECK(len >= 0, "gaib_spmm: len < 0");
   GAIB_CHECK(ctx->device == g->device, "gaib_spmm: graph lives on device %d, ctx on %d", g->device,
@@ -502,6 +513,7 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
   a.nblocks = 0;
   a.per_xcd = 0;
   a.accumulate = accumulate;
+  a.relu = (flags & GAIB_RELU) ? 1 : 0;
   a.col_flagged = nullptr;
   if (ctx->spmm_gather_mode == 3 && g->nc == g->nv && !g->col_vdata) {
     GAIB_TRY(gaib_graph_ensure_hot_flags(ctx, g, len));
@@ -546,5 +558,10 @@ extern "C" int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const fl
 
 extern "C" int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
                              int len, const float* d_in, float* d_out) {
-  return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, 1);
+  return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, GAIB_ACCUMULATE);
+}
+
+extern "C" int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                            int len, const float* d_in, float* d_out, int flags) {
+  return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags);
 }

@@ -13,16 +13,18 @@ static gaib_graph* dev(Graph& g) {
 
 // One aggregation.  On a vertex-range partition the owned-column edges are summed while the halo
 // rows are in flight (separate RCCL stream), then the halo-column edges are added to the same rows.
-static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* out) {
+static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* out, bool relu = false) {
+  const int act = relu ? GAIB_RELU : 0;
   if (!g.has_halo()) {
-    GAIB_OR_DIE(gaib_spmm(C(), dev(g), kind, NULL, len, in, out));
+    GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, out, act));
     return;
   }
   g.halo_begin(len, in);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), kind, NULL, len, in, out));
+  const bool have_halo_edges = gaib_graph_ne(g.halo_graph()) > 0;
+  GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, out, have_halo_edges ? 0 : act));
   const float* halo = g.halo_end(len);
-  if (gaib_graph_ne(g.halo_graph()) > 0)
-    GAIB_OR_DIE(gaib_spmm_acc(C(), g.halo_graph(), kind, NULL, len, halo, out));
+  if (have_halo_edges)
+    GAIB_OR_DIE(gaib_spmm_ex(C(), g.halo_graph(), kind, NULL, len, halo, out, GAIB_ACCUMULATE | act));
 }
 
 // ---- GCN ---------------------------------------------------------------------------------------
@@ -32,7 +34,8 @@ void GCN_Aggregator::init(int l, int nv, int, float, float) {
 }
 void GCN_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   OpTimer t(OP_SPARSEMM);
-  aggregate_rows(g, GAIB_W_GCN, len, in, out);
+  aggregate_rows(g, GAIB_W_GCN, len, in, out, fuse_relu);
+  fuse_relu = false;
 }
 // the normalised adjacency is symmetric, so the derivative is the same operator
 void GCN_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
@@ -47,7 +50,8 @@ void SAGE_Aggregator::init(int l, int nv, int, float, float) {
 }
 void SAGE_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   OpTimer t(OP_SPARSEMM);
-  aggregate_rows(g, GAIB_W_MEAN, len, in, out);
+  aggregate_rows(g, GAIB_W_MEAN, len, in, out, fuse_relu);
+  fuse_relu = false;
 }
 void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* grad_in, float* grad_out) {
   OpTimer t(OP_SPARSEMM);
@@ -95,7 +99,8 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
                                 d_scores, d_norm_scores));
   }
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_EDGE, d_norm_scores, len, in, out));
+  GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), GAIB_W_EDGE, d_norm_scores, len, in, out, fuse_relu ? GAIB_RELU : 0));
+  fuse_relu = false;
 }
 
 // feat_in and grad_out may be the same buffer (GAT_layer::backward passes out_temp for both):

@@ -73,14 +73,16 @@ void GCN_layer::forward(float* feat_out) {
     dropout_gpu(x * y, feat_scale, feat_dropout_rate, in_data, dropout_mask, d_in_temp);
     in_data = d_in_temp;
   }
+  // the activation (relu_gpu, gcn_layer.cpp:27) is fused into whichever op produces feat_out
   if (y > z) {  // shrink first, aggregate the narrow matrix
     matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
+    if (is_act) aggr.fuse_relu_once();
     aggr.aggregate(z, *graph, d_out_temp, feat_out);
   } else {  // aggregate first; A.X is kept for the weight gradient
     aggr.aggregate(y, *graph, in_data, d_in_temp1);
-    matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
+    if (is_act) matmul_relu(x, z, y, d_in_temp1, d_W_neigh, feat_out);
+    else matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
   }
-  if (is_act) relu_gpu(x * z, feat_out, feat_out);
 }
 
 void GCN_layer::backward(float* feat_out, float* grad_out) {
@@ -121,8 +123,9 @@ void SAGE_layer::forward(float* feat_out) {
     aggr.aggregate(y, *graph, in_data, d_in_temp1);
     matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
   }
-  matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);  // + X.W_self
-  if (is_act) relu_gpu(x * z, feat_out, feat_out);
+  // + X.W_self, with the activation fused into this last product
+  if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
+  else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
 }
 
 void SAGE_layer::backward(float* feat_out, float* grad_out) {
@@ -160,8 +163,8 @@ void GAT_layer::forward(float* feat_out) {
     in_data = d_in_temp;
   }
   matmul(x, z, y, in_data, d_W_neigh, d_out_temp);    // h = X.W
-  aggr.aggregate(z, *graph, d_out_temp, feat_out);    // attention over h
-  if (is_act) relu_gpu(x * z, feat_out, feat_out);
+  if (is_act) aggr.fuse_relu_once();
+  aggr.aggregate(z, *graph, d_out_temp, feat_out);    // attention over h (+ relu)
 }
 
 void GAT_layer::backward(float* feat_out, float* grad_out) {

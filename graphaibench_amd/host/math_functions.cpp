@@ -23,6 +23,13 @@ void matmul(const size_t x, const size_t y, const size_t z, const float_t* A, co
   GAIB_OR_DIE(gaib_sgemm(C(), transA, transB, (int64_t)x, (int64_t)y, (int64_t)z, A, B, accum, C_));
 }
 
+void matmul_relu(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
+                 float* C_, bool transA, bool transB, bool accum) {
+  OpTimer t(OP_DENSEMM);
+  GAIB_OR_DIE(gaib_sgemm_ex(C(), transA, transB, (int64_t)x, (int64_t)y, (int64_t)z, A, B,
+                            (accum ? GAIB_ACCUMULATE : 0) | GAIB_RELU, C_));
+}
+
 void init_const_gpu(int n, float_t value, float_t* array) { GAIB_OR_DIE(gaib_fill_f32(C(), n, value, array)); }
 void copy_gpu(int len, const float_t* in, float_t* out) {
   GAIB_OR_DIE(gaib_memcpy_d2d(C(), out, in, sizeof(float) * (size_t)len));

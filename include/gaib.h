@@ -126,6 +126,12 @@ int gaib_spmm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge
  * gaib_spmm, halo-column edges added once the halo rows have arrived). */
 int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                   const float* d_in, float* d_out);
+/* general form: flags = GAIB_ACCUMULATE (out += ...) | GAIB_RELU (relu_gpu fused into the store:
+ * the layers apply the activation right after the aggregation / GEMM, gcn_layer.cpp:27) */
+#define GAIB_ACCUMULATE 1
+#define GAIB_RELU 2
+int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
+                 const float* d_in, float* d_out, int flags);
 
 /* ---- GAT attention pieces ---------------------------------------------------------------
  * gaib_gat_scores: GAT_Aggregator::aggregate's score pass (gat_aggregator.cpp:60-92;
@@ -155,6 +161,9 @@ int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float
  * row-major C[M x N] = op(A)[M x K] . op(B)[K x N]  (+ C if accum).  fp32 MFMA. */
 int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
                const float* d_A, const float* d_B, int accum, float* d_C);
+/* flags = GAIB_ACCUMULATE | GAIB_RELU (activation fused into the epilogue) */
+int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                  const float* d_A, const float* d_B, int flags, float* d_C);
 
 /* ---- elementwise: relu_gpu / d_relu_gpu (math_functions.cu:242-268), dropout mask replay
  * d_dropout_gpu (:134-146) ---- */

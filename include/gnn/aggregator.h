@@ -9,12 +9,16 @@
 
 class aggregator {
  public:
-  aggregator() : n(0), length(0) {}
+  aggregator() : n(0), length(0), fuse_relu(false) {}
   void set_vlen(int vlen) { length = vlen; }
+  // extension: the next aggregate() call clamps its output at 0 (the layer's relu_gpu fused
+  // into the aggregation's store); cleared by that call
+  void fuse_relu_once() { fuse_relu = true; }
 
  protected:
   int n;
   int length;  // feature vector length
+  bool fuse_relu;
 };
 
 // out[i,:] = sum_e (vd[i]*vd[col_e]) * in[col_e,:]; backward is the same operator (symmetric)

@@ -11,6 +11,10 @@ void init_glorot(size_t dim_x, size_t dim_y, vec_t& weight, unsigned seed);  // 
 void matmul(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
             float* C, bool transA = false, bool transB = false, bool accum = false);
 
+// extension: the same product with relu_gpu fused into the epilogue (C = max(0, ...))
+void matmul_relu(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
+                 float* C, bool transA = false, bool transB = false, bool accum = false);
+
 void init_const_gpu(int n, float_t value, float_t* array);
 void copy_gpu(int len, const float_t* in, float_t* out);
 void relu_gpu(const int n, const float_t* in, float_t* out);

@@ -92,13 +92,16 @@ def main():
     W = torch.randn(d, d, device="cuda")
     y = torch.empty(nv, d, device="cuda")
     dW = torch.empty(d, d, device="cuda")
-    for tag, fn, flops in [
-        ("NN fwd", lambda: ctx.sgemm(x, W, y), 2 * nv * d * d),
-        ("NT dX", lambda: ctx.sgemm(x, W, y, False, True), 2 * nv * d * d),
-        ("TN dW", lambda: ctx.sgemm(x, y, dW, True, False), 2 * nv * d * d),
-    ]:
-        med, best = timeit(fn, args.iters)
-        print(json.dumps(dict(kernel="sgemm", tag=tag, ms=med, tflops=flops / med / 1e9)), flush=True)
+    for variant in (0, 3, 4):
+        ctx.set_option("sgemm_variant", variant)
+        for tag, fn, flops in [
+            ("NN fwd", lambda: ctx.sgemm(x, W, y), 2 * nv * d * d),
+            ("NT dX", lambda: ctx.sgemm(x, W, y, False, True), 2 * nv * d * d),
+            ("TN dW", lambda: ctx.sgemm(x, y, dW, True, False), 2 * nv * d * d),
+        ]:
+            med, best = timeit(fn, args.iters)
+            print(json.dumps(dict(kernel="sgemm", variant=variant, tag=tag, ms=med, tflops=flops / med / 1e9)), flush=True)
+    ctx.set_option("sgemm_variant", 0)
     med, _ = timeit(lambda: ctx.relu(x, out), args.iters)
     print(json.dumps(dict(kernel="relu", ms=med, gbs=2 * x.numel() * 4 / med / 1e6)), flush=True)
     med, _ = timeit(lambda: out.copy_(x), args.iters)

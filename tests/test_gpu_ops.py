@@ -474,3 +474,32 @@ def test_gather_rows(ctx):
     out = torch.empty(333, 100, device="cuda")
     ctx.gather_rows(dev(idx.astype(np.int64)), dev(x), out)
     assert np.array_equal(out.cpu().numpy(), x[idx])
+
+
+# ---- fused activation ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tA,accum", [(0, 0), (0, 1), (1, 0)])
+def test_sgemm_relu_epilogue(ctx, tA, accum):
+    rng = np.random.default_rng(3)
+    x, y, z = 700, 96, (30000 if tA else 128)
+    A = rng.standard_normal((z, x) if tA else (x, z)).astype(np.float32)
+    B = rng.standard_normal((z, y)).astype(np.float32)
+    C0 = rng.standard_normal((x, y)).astype(np.float32)
+    want = orc.relu(orc.matmul(A, B, bool(tA), False, C0 if accum else None))
+    Cd = dev(C0.copy())
+    ctx.sgemm(dev(A), dev(B), Cd, bool(tA), False, bool(accum), relu=True)
+    got = Cd.cpu().numpy()
+    assert (got >= 0).all() and rel_err(got, want) < TOL
+
+
+@pytest.mark.parametrize("d", [16, 128, 300])
+def test_spmm_relu_store(ctx, d):
+    rp, ci = random_graph(2500, 12, seed=8, power_law=True, hub_deg=2000)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    x = feat(g_o.nv, d, 1)
+    want = orc.relu(orc.gcn_aggregate(g_o, x))
+    out = torch.empty(g_o.nv, d, device="cuda")
+    ctx.spmm(g_d, capi.W_GCN, dev(x), out, relu=True)
+    got = out.cpu().numpy()
+    light = np.diff(g_o.rowptr) <= 1024
+    assert np.array_equal(got[light].view(np.uint32), want[light].view(np.uint32))
+    assert rel_err(got, want) < 1e-5
