@@ -50,6 +50,11 @@ SIGNATURES = {
     "gaib_spmm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_spmm_acc": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_spmm_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i]),
+    "gaib_spmm_mh": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i]),
+    "gaib_gat_scores_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "gaib_sddmm_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "gaib_gat_softmax_bwd_alpha_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "gaib_edge_transpose_mh": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -170,28 +175,30 @@ class Context:
         return Graph(self, rowptr, colidx, ncols)
 
     # ---- aggregation --------------------------------------------------------------------
-    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None, accumulate: bool = False, relu: bool = False):
+    def spmm(self, g: "Graph", kind: int, x, out, edge_w=None, accumulate: bool = False, relu: bool = False,
+             heads: int = 1):
         assert x.is_contiguous() and out.is_contiguous() and x.dim() == 2
         flags = (1 if accumulate else 0) | (2 if relu else 0)
-        _check(self.lib.gaib_spmm_ex(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(out), flags),
+        _check(self.lib.gaib_spmm_mh(self.h, g.h, kind, _ptr(edge_w), heads, x.shape[1], _ptr(x), _ptr(out), flags),
                "gaib_spmm")
         return out
 
-    def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2):
-        _check(self.lib.gaib_gat_scores(self.h, g.h, h.shape[1], _ptr(h), _ptr(alpha_l), _ptr(alpha_r),
-                                        eps, _ptr(temp), _ptr(scores), _ptr(norm)), "gaib_gat_scores")
+    def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2, heads: int = 1):
+        _check(self.lib.gaib_gat_scores_mh(self.h, g.h, h.shape[1], heads, _ptr(h), _ptr(alpha_l), _ptr(alpha_r),
+                                           eps, _ptr(temp), _ptr(scores), _ptr(norm)), "gaib_gat_scores")
 
-    def sddmm(self, g, grad, feat, out_e):
-        _check(self.lib.gaib_sddmm(self.h, g.h, grad.shape[1], _ptr(grad), _ptr(feat), _ptr(out_e)),
+    def sddmm(self, g, grad, feat, out_e, heads: int = 1):
+        _check(self.lib.gaib_sddmm_mh(self.h, g.h, grad.shape[1], heads, _ptr(grad), _ptr(feat), _ptr(out_e)),
                "gaib_sddmm")
 
-    def gat_softmax_bwd_alpha(self, g, feat, norm, norm_grad, temp, scores, lgrad, rgrad, eps: float = 0.2):
-        _check(self.lib.gaib_gat_softmax_bwd_alpha(self.h, g.h, feat.shape[1], _ptr(feat), _ptr(norm),
-                                                   _ptr(norm_grad), _ptr(temp), eps, _ptr(scores),
-                                                   _ptr(lgrad), _ptr(rgrad)), "gaib_gat_softmax_bwd_alpha")
+    def gat_softmax_bwd_alpha(self, g, feat, norm, norm_grad, temp, scores, lgrad, rgrad, eps: float = 0.2,
+                              heads: int = 1):
+        _check(self.lib.gaib_gat_softmax_bwd_alpha_mh(self.h, g.h, feat.shape[1], heads, _ptr(feat), _ptr(norm),
+                                                      _ptr(norm_grad), _ptr(temp), eps, _ptr(scores),
+                                                      _ptr(lgrad), _ptr(rgrad)), "gaib_gat_softmax_bwd_alpha")
 
-    def edge_transpose(self, g, in_e, out_e):
-        _check(self.lib.gaib_edge_transpose(self.h, g.h, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")
+    def edge_transpose(self, g, in_e, out_e, heads: int = 1):
+        _check(self.lib.gaib_edge_transpose_mh(self.h, g.h, heads, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")
 
     # ---- dense ----------------------------------------------------------------------------
     def sgemm(self, A, B, Cm, transA=False, transB=False, accum=False, relu=False):

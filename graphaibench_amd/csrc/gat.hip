@@ -1,5 +1,7 @@
 // gat.hip -- GAT attention kernels for gfx950: edge scores + edge-softmax, SDDMM,
-// softmax-backward + alpha gradients, symmetric edge transpose.
+// softmax-backward + alpha gradients, symmetric edge transpose.  All kernels take a head count H
+// (the reference is single-head, H = 1; H > 1 = H independent single-head attentions on the column
+// slices [h*D/H, (h+1)*D/H), edge arrays laid out [ne][H]).
 //
 // replaces GAT_Aggregator::aggregate / d_aggregate (src/gnn/gconv/gat_aggregator.cpp:57-200)
 // and the CUDA kernels compute_attn_score_warp, compute_scores_grad_warp,
@@ -8,7 +10,8 @@
 //
 // Differences in HOW (results agree to fp32 rounding):
 //   * a_l.h[i] and a_r.h[j] are computed once per VERTEX (O(N*D)) and gathered per edge
-//     (4 B) instead of recomputing a_r.h[col_e] per EDGE (O(E*D), gat_aggregator.cpp:71).
+//     (4 B per head) instead of recomputing a_r.h[col_e] per EDGE (O(E*D), gat_aggregator.cpp:71).
+//   * SDDMM is edge-parallel over 64-edge chunks (balanced on power-law rows).
 //   * the alpha gradients  sum_e g_e*h[col_e]  and  sum_i (sum_e g_e)*h[i]  are regrouped by
 //     vertex using the reverse-edge permutation:  alpha_r' = sum_v cs[v]*h[v],
 //     alpha_l' = sum_v rs[v]*h[v]  with rs = row sums and cs = column sums of g
@@ -19,31 +22,36 @@
 
 namespace {
 
-// s[v] = <alpha, h[v,:]> for two alpha vectors at once.  One wave per row.
-__global__ __launch_bounds__(256) void vertex_dots_kernel(int64_t nv, int len, const float* h,
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// s[v,h] = <alpha[slice h], x[v, slice h]> for two alpha vectors at once.  One wave per row.
+__global__ __launch_bounds__(256) void vertex_dots_kernel(int64_t nv, int len, int H, const float* x,
                                                           const float* al, const float* ar,
                                                           float* sl, float* sr) {
   int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
-  const float* hr = h + row * (int64_t)len;
-  float pl = 0.f, pr = 0.f;
-  for (int c = lane; c < len; c += 64) {
-    float x = hr[c];
-    pl += al[c] * x;
-    pr += ar[c] * x;
-  }
-  pl = wave_sum(pl);
-  pr = wave_sum(pr);
-  if (lane == 0) {
-    sl[row] = pl;
-    sr[row] = pr;
+  const float* xr = x + row * (int64_t)len;
+  const int dh = len / H;
+  for (int h = 0; h < H; ++h) {
+    float pl = 0.f, pr = 0.f;
+    for (int c = h * dh + lane; c < (h + 1) * dh; c += 64) {
+      const float v = xr[c];
+      pl += al[c] * v;
+      pr += ar[c] * v;
+    }
+    pl = wave_sum(pl);
+    pr = wave_sum(pr);
+    if (lane == 0) {
+      sl[row * H + h] = pl;
+      sr[row * H + h] = pr;
+    }
   }
 }
 
-// per row: temp = sl[i] + sr[col]; scores = leaky_relu; norm = softmax over the row.
+// per (row, head): temp = sl[i,h] + sr[col,h]; scores = leaky_relu; norm = softmax over the row.
 // (gat_aggregator.cpp:64-77; softmax math_functions.cpp:485-494: max-subtracted, expf, divide)
-__global__ __launch_bounds__(256) void edge_softmax_kernel(int64_t nv, const int64_t* rowptr,
+__global__ __launch_bounds__(256) void edge_softmax_kernel(int64_t nv, int H, const int64_t* rowptr,
                                                            const uint32_t* col, const float* sl,
                                                            const float* sr, float eps, float* temp,
                                                            float* scores, float* norm) {
@@ -52,115 +60,86 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(int64_t nv, const int
   const int lane = threadIdx.x & 63;
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
   if (e0 == e1) return;
-  const float s_src = sl[row];
   if (e1 - e0 <= 64) {
-    // whole row in registers
+    // whole row in registers, one lane per edge
     const int64_t e = e0 + lane;
     const bool ok = e < e1;
-    float s = -INFINITY;
-    if (ok) {
-      float t = s_src + sr[col[e]];
-      temp[e] = t;
-      s = t > 0.0f ? t : eps * t;
-      scores[e] = s;
+    const int64_t c = ok ? (int64_t)col[e] : 0;
+    for (int h = 0; h < H; ++h) {
+      float s = -INFINITY;
+      if (ok) {
+        const float t = sl[row * H + h] + sr[c * H + h];
+        temp[e * H + h] = t;
+        s = t > 0.0f ? t : eps * t;
+        scores[e * H + h] = s;
+      }
+      const float mx = wave_max(s);
+      const float ex = ok ? expf(s - mx) : 0.f;
+      const float den = wave_sum(ex);
+      if (ok) norm[e * H + h] = ex / den;
     }
-    const float mx = wave_max(s);
-    const float ex = ok ? expf(s - mx) : 0.f;
-    const float den = wave_sum(ex);
-    if (ok) norm[e] = ex / den;
     return;
   }
-  float mx = -INFINITY;
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
-    float t = s_src + sr[col[e]];
-    temp[e] = t;
-    float s = t > 0.0f ? t : eps * t;
-    scores[e] = s;
-    mx = fmaxf(mx, s);
+  for (int h = 0; h < H; ++h) {
+    const float s_src = sl[row * H + h];
+    float mx = -INFINITY;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const float t = s_src + sr[(int64_t)col[e] * H + h];
+      temp[e * H + h] = t;
+      const float s = t > 0.0f ? t : eps * t;
+      scores[e * H + h] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {  // each lane re-reads only its own writes
+      const float ex = expf(scores[e * H + h] - mx);
+      norm[e * H + h] = ex;
+      den += ex;
+    }
+    den = wave_sum(den);
+    for (int64_t e = e0 + lane; e < e1; e += 64) norm[e * H + h] = norm[e * H + h] / den;
   }
-  mx = wave_max(mx);
-  float den = 0.f;
-  for (int64_t e = e0 + lane; e < e1; e += 64) {  // each lane re-reads only its own writes
-    float ex = expf(scores[e] - mx);
-    norm[e] = ex;
-    den += ex;
-  }
-  den = wave_sum(den);
-  for (int64_t e = e0 + lane; e < e1; e += 64) norm[e] = norm[e] / den;
 }
 
-// SDDMM: out[e] = <grad[i,:], feat[col_e,:]>.  One wave per row; the row's grad vector
-// stays in registers (up to 4 floats per lane = len 256), wider rows loop.
-template <int VEC>
-__global__ __launch_bounds__(256) void sddmm_kernel(int64_t nv, const int64_t* rowptr,
-                                                    const uint32_t* col, int len,
-                                                    const float* grad, const float* feat,
-                                                    float* out_e) {
+// SDDMM fallback: out[e,h] = <grad[i, slice h], feat[col_e, slice h]>.  One wave per row, one wave
+// reduction per (edge, head).  Used for shapes the chunk kernels below do not cover.
+__global__ __launch_bounds__(256) void sddmm_generic_kernel(int64_t nv, int H, const int64_t* rowptr,
+                                                            const uint32_t* col, int len,
+                                                            const float* grad, const float* feat,
+                                                            float* out_e) {
   int row32 = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
   if (row32 >= nv) return;
   const int64_t row = __builtin_amdgcn_readfirstlane(row32);  // wave-uniform -> scalar loads
   const int lane = threadIdx.x & 63;
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
   const float* gr = grad + row * (int64_t)len;
-  if (len <= 64 * VEC) {
-    float g[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      int c = lane * VEC + v;
-      g[v] = c < len ? gr[c] : 0.f;
-    }
-    for (int64_t base = e0; base < e1; base += 64) {
-      const int64_t rem = e1 - base;
-      const int n = rem < 64 ? (int)rem : 64;
-      uint32_t c = lane < n ? col[base + lane] : 0u;
-      float res = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
-        const float* fr = feat + (int64_t)cj * len;
-        float p = 0.f;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          int cc = lane * VEC + v;
-          float x = cc < len ? fr[cc] : 0.f;
-          p += g[v] * x;
-        }
-        p = wave_sum(p);
-        if (lane == j) res = p;
-      }
-      if (lane < n) out_e[base + lane] = res;
-    }
-  } else {
-    for (int64_t base = e0; base < e1; base += 64) {
-      const int64_t rem = e1 - base;
-      const int n = rem < 64 ? (int)rem : 64;
-      uint32_t c = lane < n ? col[base + lane] : 0u;
-      float res = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
-        const float* fr = feat + (int64_t)cj * len;
-        float p = 0.f;
-        for (int cc = lane; cc < len; cc += 64) p += gr[cc] * fr[cc];
-        p = wave_sum(p);
-        if (lane == j) res = p;
-      }
-      if (lane < n) out_e[base + lane] = res;
+  const int dh = len / H;
+  for (int64_t e = e0; e < e1; ++e) {
+    const float* fr = feat + (int64_t)col[e] * len;
+    for (int h = 0; h < H; ++h) {
+      float p = 0.f;
+      for (int c = h * dh + lane; c < (h + 1) * dh; c += 64) p += gr[c] * fr[c];
+      p = wave_sum(p);
+      if (lane == 0) out_e[e * H + h] = p;
     }
   }
 }
 
-
 // SDDMM, edge-parallel: one wave per 64-edge chunk (gaib_graph_ensure_chunks), G lanes x float4 per
 // edge, so one wave instruction gathers 64/G feature rows (1 KB) and a dot product costs
-// 4 FMAs + log2(G) shuffles.  Group k of the wave owns edges k*G .. k*G+G-1 of the chunk; in step
-// j it reduces its j-th edge and lane k*G+j (which sits in group k) keeps the result, so after G
-// steps lane l holds edge l and the store is coalesced.  Perfectly balanced for power-law rows.
-template <int G, int U>
+// 4 FMAs + log2 shuffles.  Group k of the wave owns edges k*G .. k*G+G-1 of the chunk; in step
+// j it reduces its j-th edge.
+//   single head (LH == G): lane k*G+j (which sits in group k) keeps the result, so after G steps
+//     lane l holds edge l and the store is coalesced.
+//   H heads (LH = lanes per head = (len/H)/4 < G): the reduction stops at LH lanes; the first lane
+//     of every head subgroup stores out[e,h] directly.
+template <int G, int U, int LH>
 __global__ __launch_bounds__(256) void sddmm_chunk_kernel(int64_t n_chunks, const uint32_t* chunk_row,
                                                           const uint32_t* chunk_ebase,
                                                           const int64_t* rowptr, const uint32_t* col,
-                                                          int len, const float* grad, const float* feat,
-                                                          float* out_e) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
+                                                          int len, int H, const float* grad,
+                                                          const float* feat, float* out_e) {
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
   const int lane = threadIdx.x & 63;
@@ -187,17 +166,24 @@ __global__ __launch_bounds__(256) void sddmm_chunk_kernel(int64_t n_chunks, cons
     for (int u = 0; u < U; ++u) {
       float p = g4[0] * x[u][0] + g4[1] * x[u][1] + g4[2] * x[u][2] + g4[3] * x[u][3];
 #pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-      if (sl == j + u) res = p;
+      for (int o = LH / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+      if constexpr (LH == G) {
+        if (sl == j + u) res = p;
+      } else {
+        const int ei = gbase + j + u;  // edge index inside the chunk handled by this group now
+        if (colok && (sl & (LH - 1)) == 0 && ei < n) out_e[(eb + ei) * H + sl / LH] = p;
+      }
     }
   }
-  if (lane < n) out_e[eb + lane] = res;
+  if constexpr (LH == G) {
+    if (lane < n) out_e[eb + lane] = res;
+  }
 }
 
-// softmax backward per row (math_functions.cpp:496-514, closed form of the :497-504 branch)
-// + leaky-relu' (gat_aggregator.cpp:145).  Writes ds into scores[], g into gbuf[], and the
+// softmax backward per (row, head) (math_functions.cpp:496-514, closed form of the :497-504
+// branch) + leaky-relu' (gat_aggregator.cpp:145).  Writes ds into scores[], g into gbuf[], and the
 // row sum of g into rs[].
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(int64_t nv, const int64_t* rowptr,
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int64_t nv, int H, const int64_t* rowptr,
                                                           const float* p, const float* dp,
                                                           const float* temp, float eps,
                                                           float* scores, float* gbuf, float* rs) {
@@ -205,57 +191,62 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int64_t nv, const int6
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-  float dot = 0.f;
-  for (int64_t e = e0 + lane; e < e1; e += 64) dot += p[e] * dp[e];
-  dot = wave_sum(dot);
-  float gs = 0.f;
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
-    const float pe = p[e], dpe = dp[e];
-    const float x = pe * (1.0f - pe) * dpe;
-    const float ds = x - (dot - pe * dpe) * pe;
-    scores[e] = ds;
-    const float ge = ds * (temp[e] > 0.0f ? 1.0f : eps);
-    gbuf[e] = ge;
-    gs += ge;
+  for (int h = 0; h < H; ++h) {
+    float dot = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) dot += p[e * H + h] * dp[e * H + h];
+    dot = wave_sum(dot);
+    float gs = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const float pe = p[e * H + h], dpe = dp[e * H + h];
+      const float x = pe * (1.0f - pe) * dpe;
+      const float ds = x - (dot - pe * dpe) * pe;
+      scores[e * H + h] = ds;
+      const float ge = ds * (temp[e * H + h] > 0.0f ? 1.0f : eps);
+      gbuf[e * H + h] = ge;
+      gs += ge;
+    }
+    gs = wave_sum(gs);
+    if (lane == 0) rs[row * H + h] = gs;
   }
-  gs = wave_sum(gs);
-  if (lane == 0) rs[row] = gs;
 }
 
-// cs[v] = sum_{e in row v} g[rev[e]]  == column sum of g (structurally symmetric graph)
-__global__ __launch_bounds__(256) void colsum_kernel(int64_t nv, const int64_t* rowptr,
+// cs[v,h] = sum_{e in row v} g[rev[e],h]  == column sum of g (structurally symmetric graph)
+__global__ __launch_bounds__(256) void colsum_kernel(int64_t nv, int H, const int64_t* rowptr,
                                                      const uint32_t* rev, const float* gbuf,
                                                      float* cs) {
   int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-  float s = 0.f;
-  for (int64_t e = e0 + lane; e < e1; e += 64) s += gbuf[rev[e]];
-  s = wave_sum(s);
-  if (lane == 0) cs[row] = s;
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) s += gbuf[(int64_t)rev[e] * H + h];
+    s = wave_sum(s);
+    if (lane == 0) cs[row * H + h] = s;
+  }
 }
 
-// partial[b][0][c] = sum_{v in strip b} rs[v]*h[v][c]; partial[b][1][c] likewise with cs.
-// 256 threads: thread t owns column (t % cw) of every (256/cw)-th row of the strip, where
-// cw = min(len,256) rounded to a divisor layout; generic: loop columns.
-__global__ __launch_bounds__(256) void alpha_partial_kernel(int64_t nv, int len, const float* h,
+// partial[b][0][c] = sum_{v in strip b} rs[v, head(c)]*x[v][c]; partial[b][1][c] likewise with cs.
+// 256 threads: thread t owns column (t % cw) of every (256/cw)-th row of the strip.
+__global__ __launch_bounds__(256) void alpha_partial_kernel(int64_t nv, int len, int H, const float* x,
                                                             const float* rs, const float* cs,
                                                             int64_t rows_per_block, float* partial) {
   extern __shared__ float sm[];  // [2][256]
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < nv) ? r0 + rows_per_block : nv;
   float* out = partial + (int64_t)blockIdx.x * 2 * len;
+  const int dh = len / H;
   for (int c0 = 0; c0 < len; c0 += 256) {
     const int cw = (len - c0 < 256) ? (len - c0) : 256;  // columns in this pass
     const int rpp = 256 / cw;                            // rows per pass (>=1)
     const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    const int hd = (c0 + tc) / dh;
     float al = 0.f, ar = 0.f;
     if (tr < rpp) {
       for (int64_t v = r0 + tr; v < r1; v += rpp) {
-        const float x = h[v * (int64_t)len + c0 + tc];
-        al += rs[v] * x;
-        ar += cs[v] * x;
+        const float xv = x[v * (int64_t)len + c0 + tc];
+        al += rs[v * H + hd] * xv;
+        ar += cs[v * H + hd] * xv;
       }
     }
     sm[threadIdx.x] = (tr < rpp) ? al : 0.f;
@@ -287,89 +278,126 @@ __global__ void alpha_final_kernel(int nblocks, int len, const float* partial, f
   rgrad[c] = sr_;
 }
 
-__global__ void edge_gather_kernel(int64_t ne, const uint32_t* rev, const float* in, float* out) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < ne) out[e] = in[rev[e]];
+__global__ void edge_gather_kernel(int64_t ne, int H, const uint32_t* rev, const float* in, float* out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ne * H) return;
+  const int64_t e = t / H;
+  const int h = (int)(t - e * H);
+  out[t] = in[(int64_t)rev[e] * H + h];
 }
 
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
 
+int check_heads(const char* who, int len, int heads) {
+  GAIB_CHECK(len > 0, "%s: len must be > 0", who);
+  GAIB_CHECK(heads >= 1 && len % heads == 0, "%s: heads (%d) must divide len (%d)", who, heads, len);
+  return GAIB_OK;
+}
+
 }  // namespace
+
+extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h,
+                                  const float* d_alpha_l, const float* d_alpha_r, float epsilon,
+                                  float* d_temp_scores, float* d_scores, float* d_norm_scores) {
+  GAIB_CHECK(ctx && g, "gaib_gat_scores: NULL ctx/graph");
+  GAIB_TRY(check_heads("gaib_gat_scores", len, heads));
+  if (g->nv == 0) return GAIB_OK;
+  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_temp_scores && d_scores && d_norm_scores,
+             "gaib_gat_scores: NULL pointer");
+  GAIB_CHECK(g->nc == g->nv, "gaib_gat_scores: square graphs only");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)g->nv * heads));
+  float* sl = (float*)ctx->ws;
+  float* sr = sl + g->nv * heads;
+  {
+    ProfScope ps(ctx, "gat_vertex_dots");
+    vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_h, d_alpha_l,
+                                                                d_alpha_r, sl, sr);
+  }
+  GAIB_LAUNCH_CHECK();
+  {
+    ProfScope ps(ctx, "gat_edge_softmax");
+    edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
+        g->nv, heads, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+  }
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
 
 extern "C" int gaib_gat_scores(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_h,
                                const float* d_alpha_l, const float* d_alpha_r, float epsilon,
                                float* d_temp_scores, float* d_scores, float* d_norm_scores) {
-  GAIB_CHECK(ctx && g, "gaib_gat_scores: NULL ctx/graph");
-  GAIB_CHECK(len > 0, "gaib_gat_scores: len must be > 0");
-  if (g->nv == 0) return GAIB_OK;
-  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_temp_scores && d_scores && d_norm_scores,
-             "gaib_gat_scores: NULL pointer");
+  return gaib_gat_scores_mh(ctx, g, len, 1, d_h, d_alpha_l, d_alpha_r, epsilon, d_temp_scores, d_scores,
+                            d_norm_scores);
+}
+
+extern "C" int gaib_sddmm_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_grad,
+                             const float* d_feat, float* d_out_e) {
+  GAIB_CHECK(ctx && g, "gaib_sddmm: NULL ctx/graph");
+  GAIB_TRY(check_heads("gaib_sddmm", len, heads));
+  if (g->nv == 0 || g->ne == 0) return GAIB_OK;
+  GAIB_CHECK(d_grad && d_feat && d_out_e, "gaib_sddmm: NULL pointer");
   GAIB_HIP(hipSetDevice(ctx->device));
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)g->nv));
-  float* sl = (float*)ctx->ws;
-  float* sr = sl + g->nv;
-  { ProfScope ps(ctx, "gat_vertex_dots");
-  vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, d_h, d_alpha_l,
-                                                              d_alpha_r, sl, sr);
+  const int dh = len / heads;
+  const int lh = dh / 4;  // lanes per head in the chunk kernels
+  const bool vec_ok = (len % 4 == 0) && len <= 256 && ((((uintptr_t)d_grad | (uintptr_t)d_feat) & 15) == 0) &&
+                      ctx->gat_fast && (heads == 1 || (dh % 4 == 0 && (lh & (lh - 1)) == 0));
+  if (vec_ok) {
+    GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+    ProfScope ps(ctx, "gat_sddmm");
+    const unsigned grid = (unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4);
+#define GAIB_SDDMM(G, U, LH)                                                                            \
+  sddmm_chunk_kernel<G, U, LH><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, \
+                                                              g->rowptr, g->colidx, len, heads, d_grad, d_feat, d_out_e)
+    if (heads == 1) {
+      if (len <= 4) GAIB_SDDMM(1, 1, 1);
+      else if (len <= 8) GAIB_SDDMM(2, 2, 2);
+      else if (len <= 16) GAIB_SDDMM(4, 4, 4);
+      else if (len <= 32) GAIB_SDDMM(8, 8, 8);
+      else if (len <= 64) GAIB_SDDMM(16, 8, 16);
+      else if (len <= 128) GAIB_SDDMM(32, 8, 32);
+      else GAIB_SDDMM(64, 8, 64);
+    } else {
+      // G = lanes per edge (power of two covering len/4), LH = lanes per head (< G since heads > 1)
+      if (len <= 8) GAIB_SDDMM(2, 2, 1);
+      else if (len <= 16) { if (lh == 1) GAIB_SDDMM(4, 4, 1); else GAIB_SDDMM(4, 4, 2); }
+      else if (len <= 32) { if (lh == 1) GAIB_SDDMM(8, 8, 1); else if (lh == 2) GAIB_SDDMM(8, 8, 2); else GAIB_SDDMM(8, 8, 4); }
+      else if (len <= 64) {
+        if (lh == 1) GAIB_SDDMM(16, 8, 1); else if (lh == 2) GAIB_SDDMM(16, 8, 2);
+        else if (lh == 4) GAIB_SDDMM(16, 8, 4); else GAIB_SDDMM(16, 8, 8);
+      } else if (len <= 128) {
+        if (lh == 1) GAIB_SDDMM(32, 8, 1); else if (lh == 2) GAIB_SDDMM(32, 8, 2);
+        else if (lh == 4) GAIB_SDDMM(32, 8, 4); else if (lh == 8) GAIB_SDDMM(32, 8, 8); else GAIB_SDDMM(32, 8, 16);
+      } else {
+        if (lh == 1) GAIB_SDDMM(64, 8, 1); else if (lh == 2) GAIB_SDDMM(64, 8, 2);
+        else if (lh == 4) GAIB_SDDMM(64, 8, 4); else if (lh == 8) GAIB_SDDMM(64, 8, 8);
+        else if (lh == 16) GAIB_SDDMM(64, 8, 16); else GAIB_SDDMM(64, 8, 32);
+      }
+    }
+#undef GAIB_SDDMM
+    GAIB_LAUNCH_CHECK();
+    return GAIB_OK;
   }
-  GAIB_LAUNCH_CHECK();
-  { ProfScope ps(ctx, "gat_edge_softmax");
-  edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
-      g->nv, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
-  }
+  ProfScope ps(ctx, "gat_sddmm");
+  sddmm_generic_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->colidx, len,
+                                                               d_grad, d_feat, d_out_e);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
 
 extern "C" int gaib_sddmm(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_grad,
                           const float* d_feat, float* d_out_e) {
-  GAIB_CHECK(ctx && g, "gaib_sddmm: NULL ctx/graph");
-  GAIB_CHECK(len > 0, "gaib_sddmm: len must be > 0");
-  if (g->nv == 0 || g->ne == 0) return GAIB_OK;
-  GAIB_CHECK(d_grad && d_feat && d_out_e, "gaib_sddmm: NULL pointer");
-  GAIB_HIP(hipSetDevice(ctx->device));
-  const bool vec_ok = (len % 4 == 0) && len <= 256 &&
-                      ((((uintptr_t)d_grad | (uintptr_t)d_feat) & 15) == 0) && ctx->gat_fast;
-  if (vec_ok) {
-    GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
-    ProfScope ps(ctx, "gat_sddmm");
-    const unsigned grid = (unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4);
-#define GAIB_SDDMM(G, U)                                                                             \
-  sddmm_chunk_kernel<G, U><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, \
-                                                          g->rowptr, g->colidx, len, d_grad, d_feat, d_out_e)
-    if (len <= 4) GAIB_SDDMM(1, 1);
-    else if (len <= 8) GAIB_SDDMM(2, 2);
-    else if (len <= 16) GAIB_SDDMM(4, 4);
-    else if (len <= 32) GAIB_SDDMM(8, 8);
-    else if (len <= 64) GAIB_SDDMM(16, 8);
-    else if (len <= 128) GAIB_SDDMM(32, 8);
-    else GAIB_SDDMM(64, 8);
-#undef GAIB_SDDMM
-    GAIB_LAUNCH_CHECK();
-    return GAIB_OK;
-  }
-  ProfScope ps(ctx, "gat_sddmm");
-  if (len <= 64)
-    sddmm_kernel<1><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx, len,
-                                                             d_grad, d_feat, d_out_e);
-  else if (len <= 128)
-    sddmm_kernel<2><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx, len,
-                                                             d_grad, d_feat, d_out_e);
-  else
-    sddmm_kernel<4><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->colidx, len,
-                                                             d_grad, d_feat, d_out_e);
-  GAIB_LAUNCH_CHECK();
-  return GAIB_OK;
+  return gaib_sddmm_mh(ctx, g, len, 1, d_grad, d_feat, d_out_e);
 }
 
-extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len,
-                                          const float* d_feat, const float* d_norm_scores,
-                                          const float* d_norm_scores_grad,
-                                          const float* d_temp_scores, float epsilon,
-                                          float* d_scores, float* d_alpha_lgrad,
-                                          float* d_alpha_rgrad) {
+extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
+                                             const float* d_feat, const float* d_norm_scores,
+                                             const float* d_norm_scores_grad,
+                                             const float* d_temp_scores, float epsilon,
+                                             float* d_scores, float* d_alpha_lgrad,
+                                             float* d_alpha_rgrad) {
   GAIB_CHECK(ctx && g, "gaib_gat_softmax_bwd_alpha: NULL ctx/graph");
-  GAIB_CHECK(len > 0, "gaib_gat_softmax_bwd_alpha: len must be > 0");
+  GAIB_TRY(check_heads("gaib_gat_softmax_bwd_alpha", len, heads));
   GAIB_CHECK(d_alpha_lgrad && d_alpha_rgrad, "gaib_gat_softmax_bwd_alpha: NULL alpha grad");
   GAIB_HIP(hipSetDevice(ctx->device));
   if (g->nv == 0) return GAIB_OK;
@@ -378,20 +406,21 @@ extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len,
   GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
   const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
-  const size_t ws_floats = (size_t)g->ne + 2 * (size_t)g->nv + (size_t)nblocks * 2 * len;
+  const size_t ws_floats = ((size_t)g->ne + 2 * (size_t)g->nv) * heads + (size_t)nblocks * 2 * len;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * ws_floats));
   float* gbuf = (float*)ctx->ws;
-  float* rs = gbuf + g->ne;
-  float* cs = rs + g->nv;
-  float* partial = cs + g->nv;
+  float* rs = gbuf + g->ne * heads;
+  float* cs = rs + g->nv * heads;
+  float* partial = cs + g->nv * heads;
   ProfScope ps(ctx, "gat_softmax_bwd_alpha");
-  softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
-      g->nv, g->rowptr, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, d_scores, gbuf, rs);
+  softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_norm_scores,
+                                                              d_norm_scores_grad, d_temp_scores, epsilon,
+                                                              d_scores, gbuf, rs);
   GAIB_LAUNCH_CHECK();
-  colsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs);
+  colsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->rev, gbuf, cs);
   GAIB_LAUNCH_CHECK();
-  alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(
-      g->nv, len, d_feat, rs, cs, rows_per_block, partial);
+  alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
+                                                                         rows_per_block, partial);
   GAIB_LAUNCH_CHECK();
   alpha_final_kernel<<<(unsigned)cdiv64(len, 256), 256, 0, ctx->stream>>>(nblocks, len, partial,
                                                                          d_alpha_lgrad, d_alpha_rgrad);
@@ -399,17 +428,33 @@ extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len,
   return GAIB_OK;
 }
 
-extern "C" int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e,
-                                   float* d_out_e) {
+extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_feat,
+                                          const float* d_norm_scores,
+                                          const float* d_norm_scores_grad,
+                                          const float* d_temp_scores, float epsilon,
+                                          float* d_scores, float* d_alpha_lgrad,
+                                          float* d_alpha_rgrad) {
+  return gaib_gat_softmax_bwd_alpha_mh(ctx, g, len, 1, d_feat, d_norm_scores, d_norm_scores_grad, d_temp_scores,
+                                       epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad);
+}
+
+extern "C" int gaib_edge_transpose_mh(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_in_e,
+                                      float* d_out_e) {
   GAIB_CHECK(ctx && g, "gaib_edge_transpose: NULL ctx/graph");
+  GAIB_CHECK(heads >= 1, "gaib_edge_transpose: heads must be >= 1");
   if (g->ne == 0) return GAIB_OK;
   GAIB_CHECK(d_in_e && d_out_e && d_in_e != d_out_e, "gaib_edge_transpose: bad pointers");
   GAIB_HIP(hipSetDevice(ctx->device));
   GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
   // rev is an involution on a structurally symmetric graph: out[rev[e]] = in[e]  <=>
   // out[e] = in[rev[e]]; the gather form keeps the stores coalesced.
-  edge_gather_kernel<<<(unsigned)cdiv64(g->ne, 256), 256, 0, ctx->stream>>>(g->ne, g->rev, d_in_e,
-                                                                          d_out_e);
+  edge_gather_kernel<<<(unsigned)cdiv64(g->ne * heads, 256), 256, 0, ctx->stream>>>(g->ne, heads, g->rev,
+                                                                                  d_in_e, d_out_e);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
+}
+
+extern "C" int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e,
+                                   float* d_out_e) {
+  return gaib_edge_transpose_mh(ctx, g, 1, d_in_e, d_out_e);
 }

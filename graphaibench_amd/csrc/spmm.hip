@@ -47,6 +47,8 @@ struct SpmmArgs {
   const uint32_t* col_flagged;  // GM 3: column ids with the top bit set on cold columns
   int accumulate;            // out += instead of out = (second half of a split aggregation)
   int relu;                  // clamp at 0 on store (activation fused)
+  int heads;                 // WMODE 3/4: edge weights are [ne][heads]; head of a column = col / dh
+  int dh;
 };
 
 template <int VEC> struct VecT;
@@ -94,10 +96,14 @@ __device__ __forceinline__ int logical_block(const SpmmArgs& a) {
   return b;
 }
 
+// WMODE: 0 per-row weight | 1 per-edge | 2 per-edge through the reverse permutation |
+//        3 per-(edge, head) | 4 per-(edge, head) through the reverse permutation
 template <int WMODE>
-__device__ __forceinline__ float load_edge_w(const SpmmArgs& a, int64_t e) {
+__device__ __forceinline__ float load_edge_w(const SpmmArgs& a, int64_t e, int head = 0) {
   if constexpr (WMODE == 1) return a.ew[e];
   else if constexpr (WMODE == 2) return a.ew[a.rev[e]];
+  else if constexpr (WMODE == 3) return a.ew[e * a.heads + head];
+  else if constexpr (WMODE == 4) return a.ew[(int64_t)a.rev[e] * a.heads + head];
   else return 0.f;
 }
 
@@ -173,6 +179,11 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
   typedef typename VecT<VEC>::type vec_t;
   const RowGather<VEC, BUF> gather(a);
   vec_t x[U][CT];  // gather destinations; the tail's piece p lives in x[p .. 2p-1]
+  constexpr bool MH = WMODE >= 3;  // multi-head: every lane fetches the weight of ITS head itself
+  int hd[CT];
+  float wv[MH ? U : 1][CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) hd[ct] = MH ? (int)((voff[ct] >> 2) / (uint32_t)a.dh) : 0;
   for (int64_t base = eb; base < ee; base += chunk_stride) {
     const int64_t rem = ee - base;
     const int n = rem < 64 ? (int)rem : 64;  // wave-uniform
@@ -180,7 +191,7 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
     float w = 0.f;
     if (lane < n) {
       c = a.col[base + lane];
-      if constexpr (WMODE != 0) w = load_edge_w<WMODE>(a, base + lane);
+      if constexpr (WMODE == 1 || WMODE == 2) w = load_edge_w<WMODE>(a, base + lane);
     }
     int j = 0;
     // full batches: U independent row gathers in flight, straight-line code
@@ -189,13 +200,20 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
       for (int u = 0; u < U; ++u) {
         const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j + u);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) x[u][ct] = gather.load(cj, voff[ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          x[u][ct] = gather.load(cj, voff[ct]);
+          if constexpr (MH) wv[u][ct] = load_edge_w<WMODE>(a, base + j + u, hd[ct]);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float wj = (WMODE == 0) ? roww : readlane_f(w, j + u);
+        const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, j + u));
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) vacc<VEC>(acc[ct], wj, x[u][ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          float wsel = wj;
+          if constexpr (MH) wsel = wv[u][ct];
+          vacc<VEC>(acc[ct], wsel, x[u][ct]);
+        }
       }
     }
     // tail: r = n - j < U edges, done as power-of-two pieces U/2, U/4, .., 1 (CSR order kept):
@@ -221,9 +239,14 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
         if (r & p) {
 #pragma unroll
           for (int u = 0; u < p; ++u) {
-            const float wj = (WMODE == 0) ? roww : readlane_f(w, jj + u);
+            const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, jj + u));
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) vacc<VEC>(acc[ct], wj, x[p + u][ct]);
+            for (int ct = 0; ct < CT; ++ct) {
+              // (the tail is short: its per-head weights are fetched at the point of use)
+              float wh = wj;
+              if constexpr (MH) wh = load_edge_w<WMODE>(a, base + jj + u, hd[ct]);
+              vacc<VEC>(acc[ct], wh, x[p + u][ct]);
+            }
           }
           jj += p;
         }
@@ -322,6 +345,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
   vec_t acc = vzero<VEC>();
   if (a.accumulate && active && colok) acc = *reinterpret_cast<const vec_t*>(a.out + row * a.ld + sl * VEC);
   const float roww = (WMODE == 0 && active) ? a.rw[row] : 0.f;
+  const int head = (WMODE >= 3 && colok) ? (sl * VEC) / a.dh : 0;
   const float* inl = a.in + sl * VEC;
   for (int64_t e = e0; e < e1; e += U) {
     // every lane of the group reads the same colidx/weight address (hardware broadcast)
@@ -332,7 +356,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
     for (int u = 0; u < U; ++u) {
       const bool ok = e + u < e1;
       cj[u] = ok ? a.col[e + u] : 0u;
-      wj[u] = (WMODE == 0) ? roww : (ok ? load_edge_w<WMODE>(a, e + u) : 0.f);
+      wj[u] = (WMODE == 0) ? roww : (ok ? load_edge_w<WMODE>(a, e + u, head) : 0.f);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -442,6 +466,9 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
   int vmax = 1;
   if (len % 4 == 0 && (al & 15) == 0) vmax = 4;
   else if (len % 2 == 0 && (al & 7) == 0) vmax = 2;
+  if (WMODE >= 3) {  // a lane's VEC columns must sit in one head
+    while (vmax > 1 && a0.dh % vmax != 0) vmax >>= 1;
+  }
   int variant = ctx->spmm_variant;
   // variant: 0 auto | 1 force w64 with VEC=1 | 2 force w64 VEC=2 | 4 force w64 VEC=4 |
   //          32 force sub-wave G=32 path with the widest vector (two 128-wide rows per wave)
@@ -453,6 +480,7 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
     if (len <= 64) vec = 1;
     else if (len <= 128 && vmax >= 2) vec = 2;
     else vec = vmax;
+    if (WMODE >= 3 && a0.dh % vec != 0) vec = vmax;
   }
   if (variant == 1) { use_sub = false; vec = 1; }
   if (variant == 2 && vmax >= 2) { use_sub = false; vec = 2; }
@@ -486,7 +514,7 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
 }  // namespace
 
 static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
-                     const float* d_in, float* d_out, int flags) {
+                     const float* d_in, float* d_out, int flags, int heads = 1) {
   const int accumulate = (flags & GAIB_ACCUMULATE) ? 1 : 0;
   GAIB_CHECK(ctx && g, "gaib_spmm: NULL ctx/graph");
   GAIB_CHECK(len >= 0, "gaib_spmm: len < 0");
@@ -514,6 +542,8 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
   a.per_xcd = 0;
   a.accumulate = accumulate;
   a.relu = (flags & GAIB_RELU) ? 1 : 0;
+  a.heads = heads;
+  a.dh = heads > 0 ? len / heads : len;
   a.col_flagged = nullptr;
   if (ctx->spmm_gather_mode == 3 && g->nc == g->nv && !g->col_vdata) {
     GAIB_TRY(gaib_graph_ensure_hot_flags(ctx, g, len));
@@ -538,12 +568,14 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
     case GAIB_W_EDGE:
       GAIB_CHECK(d_edge_w || g->ne == 0, "gaib_spmm: GAIB_W_EDGE needs d_edge_w");
       a.ew = d_edge_w;
+      if (heads > 1) return dispatch_vec<3>(ctx, g, a, len);
       return dispatch_vec<1>(ctx, g, a, len);
     case GAIB_W_EDGE_T:
       GAIB_CHECK(d_edge_w || g->ne == 0, "gaib_spmm: GAIB_W_EDGE_T needs d_edge_w");
       GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
       a.ew = d_edge_w;
       a.rev = g->rev;
+      if (heads > 1) return dispatch_vec<4>(ctx, g, a, len);
       return dispatch_vec<2>(ctx, g, a, len);
     default:
       gaib_set_error("gaib_spmm: unknown weight_kind %d", weight_kind);
@@ -564,4 +596,12 @@ extern "C" int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, cons
 extern "C" int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
                             int len, const float* d_in, float* d_out, int flags) {
   return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags);
+}
+
+extern "C" int gaib_spmm_mh(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                            int heads, int len, const float* d_in, float* d_out, int flags) {
+  GAIB_CHECK(heads >= 1 && len % heads == 0, "gaib_spmm_mh: heads (%d) must divide len (%d)", heads, len);
+  GAIB_CHECK(heads == 1 || weight_kind == GAIB_W_EDGE || weight_kind == GAIB_W_EDGE_T,
+             "gaib_spmm_mh: per-head weights need GAIB_W_EDGE or GAIB_W_EDGE_T");
+  return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags, heads);
 }

@@ -60,7 +60,7 @@ void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* 
 
 // ---- GAT ---------------------------------------------------------------------------------------
 GAT_Aggregator::GAT_Aggregator()
-    : epsilon(0.2f), attn_drop(0.f), num_edges(0), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
+    : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_scores(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
       d_norm_scores_grad(NULL), alpha_opt(NULL) {}
 
@@ -91,15 +91,30 @@ void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   alpha_opt = new adam(lr);
 }
 
+void GAT_Aggregator::set_num_heads(int h) {
+  if (h < 1 || length % h != 0) {
+    fprintf(stderr, "GAT_Aggregator::set_num_heads(%d): must divide the feature length %d\n", h, length);
+    exit(EXIT_FAILURE);
+  }
+  if (h == heads) return;
+  heads = h;
+  float** arrays[] = {&d_scores, &d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
+  for (float** a : arrays) {
+    float_free_device(*a);
+    *a = gaib_host::dmalloc<float>(num_edges * heads);
+  }
+}
+
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   assert(g.sizeEdges() <= num_edges);
   {
     OpTimer t(OP_SCORE);
-    GAIB_OR_DIE(gaib_gat_scores(C(), dev(g), len, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,
-                                d_scores, d_norm_scores));
+    GAIB_OR_DIE(gaib_gat_scores_mh(C(), dev(g), len, heads, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,
+                                   d_scores, d_norm_scores));
   }
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), GAIB_W_EDGE, d_norm_scores, len, in, out, fuse_relu ? GAIB_RELU : 0));
+  GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores, heads, len, in, out,
+                           fuse_relu ? GAIB_RELU : 0));
   fuse_relu = false;
 }
 
@@ -109,16 +124,16 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
                                  float* grad_out) {
   {
     OpTimer t(OP_SCORE);
-    GAIB_OR_DIE(gaib_sddmm(C(), dev(g), len, grad_in, feat_in, d_norm_scores_grad));
+    GAIB_OR_DIE(gaib_sddmm_mh(C(), dev(g), len, heads, grad_in, feat_in, d_norm_scores_grad));
   }
   {
     OpTimer t(OP_ATTN);
-    GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha(C(), dev(g), len, feat_in, d_norm_scores, d_norm_scores_grad,
-                                           d_temp_scores, epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad));
+    GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_mh(C(), dev(g), len, heads, feat_in, d_norm_scores, d_norm_scores_grad,
+                                              d_temp_scores, epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad));
   }
   // transpose + aggregation fused: w_e = norm_scores[rev(e)]
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm(C(), dev(g), GAIB_W_EDGE_T, d_norm_scores, len, grad_in, grad_out));
+  GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE_T, d_norm_scores, heads, len, grad_in, grad_out, 0));
 }
 
 void GAT_Aggregator::update_weights(optimizer*) {

@@ -94,6 +94,14 @@ void gaibl_layer_set_feat_in(void* layer, float* p) {
   LayerBox* b = static_cast<LayerBox*>(layer);
   DISPATCH(b, set_feat_in(p));
 }
+void gaibl_layer_set_heads(void* layer, int heads) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  if (b->kind != GAIBL_GAT) {
+    fprintf(stderr, "gaibl_layer_set_heads: not a GAT layer\n");
+    exit(EXIT_FAILURE);
+  }
+  b->gat->get_aggregator().set_num_heads(heads);
+}
 void gaibl_layer_set_phase(void* layer, int phase) {
   LayerBox* b = static_cast<LayerBox*>(layer);
   net_phase ph = phase == 0 ? net_phase::TRAIN : (phase == 1 ? net_phase::TEST : net_phase::VAL);

@@ -30,26 +30,26 @@ void matmul_relu(const size_t x, const size_t y, const size_t z, const float_t* 
                             (accum ? GAIB_ACCUMULATE : 0) | GAIB_RELU, C_));
 }
 
-void init_const_gpu(int n, float_t value, float_t* array) { GAIB_OR_DIE(gaib_fill_f32(C(), n, value, array)); }
-void copy_gpu(int len, const float_t* in, float_t* out) {
+void init_const_gpu(size_t n, float_t value, float_t* array) { GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)n, value, array)); }
+void copy_gpu(size_t len, const float_t* in, float_t* out) {
   GAIB_OR_DIE(gaib_memcpy_d2d(C(), out, in, sizeof(float) * (size_t)len));
 }
-void relu_gpu(const int n, const float_t* in, float_t* out) {
+void relu_gpu(const size_t n, const float_t* in, float_t* out) {
   OpTimer t(OP_RELU);
-  GAIB_OR_DIE(gaib_relu(C(), n, in, out));
+  GAIB_OR_DIE(gaib_relu(C(), (int64_t)n, in, out));
 }
-void d_relu_gpu(const int n, const float_t* in_diff, const float_t* data, float_t* out_diff) {
+void d_relu_gpu(const size_t n, const float_t* in_diff, const float_t* data, float_t* out_diff) {
   OpTimer t(OP_RELU);
-  GAIB_OR_DIE(gaib_d_relu(C(), n, in_diff, data, out_diff));
+  GAIB_OR_DIE(gaib_d_relu(C(), (int64_t)n, in_diff, data, out_diff));
 }
 static uint64_t g_dropout_seed = 0x5EED;
-void dropout_gpu(int n, float scale, float drop_rate, const float* in, mask_t* masks, float* out) {
+void dropout_gpu(size_t n, float scale, float drop_rate, const float* in, mask_t* masks, float* out) {
   OpTimer t(OP_DROPOUT);
-  GAIB_OR_DIE(gaib_dropout(C(), n, scale, drop_rate, g_dropout_seed++, in, masks, out));
+  GAIB_OR_DIE(gaib_dropout(C(), (int64_t)n, scale, drop_rate, g_dropout_seed++, in, masks, out));
 }
-void d_dropout_gpu(int n, float scale, const float* in, const mask_t* masks, float* out) {
+void d_dropout_gpu(size_t n, float scale, const float* in, const mask_t* masks, float* out) {
   OpTimer t(OP_DROPOUT);
-  GAIB_OR_DIE(gaib_d_dropout(C(), n, scale, in, masks, out));
+  GAIB_OR_DIE(gaib_d_dropout(C(), (int64_t)n, scale, in, masks, out));
 }
 void l2norm(int n, int dim, const float* in, float* out) {
   OpTimer t(OP_NORM);

@@ -130,6 +130,12 @@ struct Trainer {
                                score_drop));
     layers.push_back(gconv_t(num_layers - 1, num_samples, dim_hid, use_dense ? dim_hid : num_cls, graph, false, lrate,
                              feat_drop, score_drop));
+#if defined(USE_GAT)
+    if (const char* hs = getenv("GAIB_GAT_HEADS")) {  // extension: multi-head attention (default 1 = reference)
+      for (auto& l : layers) l.get_aggregator().set_num_heads(atoi(hs));
+      std::cout << "GAT attention heads: " << atoi(hs) << "\n";
+    }
+#endif
     if (use_l2norm) l2 = new l2norm_layer(num_samples, dim_hid);
     if (use_dense) dense = new dense_layer(num_samples, dim_hid, num_cls, lrate);
     layers[0].set_feat_in(d_features);

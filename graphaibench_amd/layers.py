@@ -33,6 +33,7 @@ SIGNATURES = {
     "gaibl_layer_update_weight": (None, [_vp, _vp]),
     "gaibl_layer_set_feat_in": (None, [_vp, _vp]),
     "gaibl_layer_set_phase": (None, [_vp, _i]),
+    "gaibl_layer_set_heads": (None, [_vp, _i]),
     "gaibl_layer_ptr": (_vp, [_vp, _i]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
@@ -144,6 +145,9 @@ class Layer:
 
     def update_weight(self, opt):
         self.lib.gaibl_layer_update_weight(self.h, opt)
+
+    def set_heads(self, heads: int):
+        self.lib.gaibl_layer_set_heads(self.h, heads)
 
     def set_feat_in(self, t):
         self._feat_keepalive = t

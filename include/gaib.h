@@ -132,6 +132,10 @@ int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_
 #define GAIB_RELU 2
 int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                  const float* d_in, float* d_out, int flags);
+/* multi-head attention weights: d_edge_w is [ne][heads]; column c uses head c / (len/heads).
+ * weight_kind must be GAIB_W_EDGE or GAIB_W_EDGE_T when heads > 1. */
+int gaib_spmm_mh(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int heads,
+                 int len, const float* d_in, float* d_out, int flags);
 
 /* ---- GAT attention pieces ---------------------------------------------------------------
  * gaib_gat_scores: GAT_Aggregator::aggregate's score pass (gat_aggregator.cpp:60-92;
@@ -141,6 +145,20 @@ int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_e
 int gaib_gat_scores(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_h, const float* d_alpha_l,
                     const float* d_alpha_r, float epsilon, float* d_temp_scores, float* d_scores,
                     float* d_norm_scores);
+/* Multi-head forms (BASELINE config "reddit GAT 2-layer 8-head"; the reference is single-head,
+ * include/gnn/aggregator.h:62-65): `heads` independent attentions on the column slices
+ * [h*len/heads, (h+1)*len/heads); alpha vectors stay [len]; every edge array is [ne][heads].
+ * heads == 1 is exactly the single-head entry point. */
+int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h,
+                       const float* d_alpha_l, const float* d_alpha_r, float epsilon,
+                       float* d_temp_scores, float* d_scores, float* d_norm_scores);
+int gaib_sddmm_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_grad,
+                  const float* d_feat, float* d_out_e);
+int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
+                                  const float* d_norm_scores, const float* d_norm_scores_grad,
+                                  const float* d_temp_scores, float epsilon, float* d_scores,
+                                  float* d_alpha_lgrad, float* d_alpha_rgrad);
+int gaib_edge_transpose_mh(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_in_e, float* d_out_e);
 /* SDDMM (gat_aggregator.cpp:106-113; compute_scores_grad_warp, graph_operations.h:191-223):
  *   d_out_e[e] = <grad[i,:], feat[col_e,:]> */
 int gaib_sddmm(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_grad, const float* d_feat,

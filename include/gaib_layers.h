@@ -50,6 +50,7 @@ void gaibl_layer_backward(void* layer, float* d_feat_out, float* d_grad_out);
 void gaibl_layer_update_weight(void* layer, void* optimizer);
 void gaibl_layer_set_feat_in(void* layer, float* d_ptr);
 void gaibl_layer_set_phase(void* layer, int phase); /* 0 TRAIN 1 TEST 2 VAL */
+void gaibl_layer_set_heads(void* layer, int heads); /* GAT only: GAT_Aggregator::set_num_heads */
 float* gaibl_layer_ptr(void* layer, int which);
 
 void* gaibl_adam_create(float lr);

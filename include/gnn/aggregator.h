@@ -46,6 +46,10 @@ class GAT_Aggregator : public aggregator {
   void aggregate(int len, Graph& g, const float* in, float* out);
   void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
   void update_weights(optimizer* opt);
+  // extension (BASELINE config "GAT 8-head"; the reference is single-head): h independent attentions
+  // on the column slices of width length/h.  Call right after init().
+  void set_num_heads(int h);
+  int num_heads() const { return heads; }
   // device state (tests / checkpoints)
   float* alpha_l_ptr() { return d_alpha_l; }
   float* alpha_r_ptr() { return d_alpha_r; }
@@ -60,6 +64,7 @@ class GAT_Aggregator : public aggregator {
   float epsilon;    // LeakyReLU negative slope (0.2)
   float attn_drop;  // attention dropout: accepted, not applied (reference CPU path has it commented out)
   size_t num_edges;
+  int heads;
   float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
   float *d_scores, *d_temp_scores, *d_norm_scores, *d_norm_scores_grad;
   optimizer* alpha_opt;

@@ -15,12 +15,12 @@ void matmul(const size_t x, const size_t y, const size_t z, const float_t* A, co
 void matmul_relu(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
                  float* C, bool transA = false, bool transB = false, bool accum = false);
 
-void init_const_gpu(int n, float_t value, float_t* array);
-void copy_gpu(int len, const float_t* in, float_t* out);
-void relu_gpu(const int n, const float_t* in, float_t* out);
-void d_relu_gpu(const int n, const float_t* in_diff, const float_t* data, float_t* out_diff);
-void dropout_gpu(int n, float scale, float drop_rate, const float* in, mask_t* masks, float* out);
-void d_dropout_gpu(int n, float scale, const float* in, const mask_t* masks, float* out);
+void init_const_gpu(size_t n, float_t value, float_t* array);  // element counts are size_t: N*D exceeds int at scale
+void copy_gpu(size_t len, const float_t* in, float_t* out);
+void relu_gpu(const size_t n, const float_t* in, float_t* out);
+void d_relu_gpu(const size_t n, const float_t* in_diff, const float_t* data, float_t* out_diff);
+void dropout_gpu(size_t n, float scale, float drop_rate, const float* in, mask_t* masks, float* out);
+void d_dropout_gpu(size_t n, float scale, const float* in, const mask_t* masks, float* out);
 void l2norm(int n, int dim, const float* in, float* out);
 void d_l2norm(int n, int dim, const float* feat_in, const float* grad_in, float* grad_out);
 void softmax_cross_entropy_gpu(int len, int begin, int end, const float_t* in_data,

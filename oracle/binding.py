@@ -195,6 +195,42 @@ def gat_d_aggregate(g: Graph, feat, grad_in, norm, temp, fast=False):
     return grad_out, scores, ngrad, lg, rg
 
 
+# ---- multi-head GAT = H independent single-head attentions on column slices (BASELINE config 4) ----
+def gat_aggregate_mh(g: Graph, h, alpha_l, alpha_r, heads: int):
+    """returns out [n,D], temp/scores/norm [ne,heads]"""
+    h = _f(h)
+    D = h.shape[1]
+    dh = D // heads
+    out = np.empty_like(h)
+    temp = np.empty((g.ne, heads), np.float32)
+    scores = np.empty((g.ne, heads), np.float32)
+    norm = np.empty((g.ne, heads), np.float32)
+    for k in range(heads):
+        sl = slice(k * dh, (k + 1) * dh)
+        o, t, s, p = gat_aggregate(g, np.ascontiguousarray(h[:, sl]), np.ascontiguousarray(alpha_l[sl]),
+                                   np.ascontiguousarray(alpha_r[sl]))
+        out[:, sl], temp[:, k], scores[:, k], norm[:, k] = o, t, s, p
+    return out, temp, scores, norm
+
+
+def gat_d_aggregate_mh(g: Graph, feat, grad_in, norm, temp, heads: int, fast=True):
+    feat, grad_in = _f(feat), _f(grad_in)
+    D = feat.shape[1]
+    dh = D // heads
+    grad_out = np.empty_like(feat)
+    ds = np.empty((g.ne, heads), np.float32)
+    ngrad = np.empty((g.ne, heads), np.float32)
+    lg = np.empty(D, np.float32)
+    rg = np.empty(D, np.float32)
+    for k in range(heads):
+        sl = slice(k * dh, (k + 1) * dh)
+        go, d_, ng, l_, r_ = gat_d_aggregate(g, np.ascontiguousarray(feat[:, sl]), np.ascontiguousarray(grad_in[:, sl]),
+                                             np.ascontiguousarray(norm[:, k]), np.ascontiguousarray(temp[:, k]),
+                                             fast=fast)
+        grad_out[:, sl], ds[:, k], ngrad[:, k], lg[sl], rg[sl] = go, d_, ng, l_, r_
+    return grad_out, ds, ngrad, lg, rg
+
+
 # ---- dense / elementwise / optimizer ---------------------------------------------------------
 def matmul(A, B, transA=False, transB=False, accum_into=None) -> np.ndarray:
     """reference signature matmul(x, y, z, A, B, C, transA, transB, accum)"""

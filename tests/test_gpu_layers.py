@@ -192,3 +192,34 @@ def test_gcn_training_steps_track_oracle():
     assert losses_o[-1] < losses_o[0]
     assert rel_err(d0.tensor(L.W_NEIGH, (F, H)).cpu().numpy(), o0.W) < 1e-3
     assert rel_err(d1.tensor(L.W_NEIGH, (H, Cn)).cpu().numpy(), o1.W) < 1e-3
+
+
+def test_gat_layer_8_heads():
+    """GAT_layer with 8 attention heads (GAT_Aggregator::set_num_heads): forward/backward equal 8
+    single-head oracles on the 8-column slices (BASELINE config 4 shape: hidden 64 = 8 x 8)."""
+    rp, ci = random_graph(4096, 24, seed=19, power_law=True, hub_deg=1500)
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
+    n, din, dout, H = g_o.nv, 100, 64, 8
+    x = feat(n, din, 3)
+    gin = feat(n, dout, 4)
+    ld = L.Layer(L.GAT, 1, n, din, dout, g_d, True)
+    ld.set_heads(H)
+    W = orc.init_glorot(din, dout, 1)
+    al, ar = orc.init_glorot(dout, 1, 2).ravel(), orc.init_glorot(dout, 1, 3).ravel()
+    ld.write(L.FEAT_IN, dev(x))
+    out = torch.empty(n, dout, device="cuda")
+    ld.forward(out)
+    hfeat = orc.matmul(x, W)
+    agg, temp, scores, norm = orc.gat_aggregate_mh(g_o, hfeat, al, ar, H)
+    want = orc.relu(agg)
+    assert rel_err(out.cpu().numpy(), want) < TOL
+    ld.write(L.GRAD_IN, dev(gin))
+    grad_out = torch.zeros(n, din, device="cuda")
+    ld.backward(out, grad_out)
+    g_act = orc.d_relu(gin, want)
+    T, ds, ng, lg, rg = orc.gat_d_aggregate_mh(g_o, hfeat, g_act, norm, temp, H)
+    assert rel_err(grad_out.cpu().numpy(), orc.matmul(T, W, False, True)) < TOL
+    assert rel_err(ld.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), orc.matmul(x, T, True, False)) < TOL
+    assert rel_err(ld.tensor(L.ALPHA_LGRAD, (dout,)).cpu().numpy(), lg) < TOL
+    assert rel_err(ld.tensor(L.ALPHA_RGRAD, (dout,)).cpu().numpy(), rg) < TOL

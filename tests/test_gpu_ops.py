@@ -503,3 +503,46 @@ def test_spmm_relu_store(ctx, d):
     light = np.diff(g_o.rowptr) <= 1024
     assert np.array_equal(got[light].view(np.uint32), want[light].view(np.uint32))
     assert rel_err(got, want) < 1e-5
+
+
+# ---- multi-head GAT (BASELINE config 4: 8 heads; each head == the single-head oracle on its slice) ----
+@pytest.mark.parametrize("d,heads,hub", [(64, 8, 0), (64, 8, 900), (64, 4, 0), (128, 8, 0), (32, 8, 0), (256, 8, 0),
+                                         (48, 3, 0), (24, 8, 0), (130, 2, 0)])
+def test_gat_multi_head(ctx, d, heads, hub):
+    rp, ci = random_graph(1800, 9, seed=d + heads, power_law=True, hub_deg=hub)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    n, ne = g_o.nv, g_o.ne
+    h = feat(n, d, 1)
+    gin = feat(n, d, 4)
+    al = feat(1, d, 2).ravel() * 0.2
+    ar = feat(1, d, 3).ravel() * 0.2
+    want_out, want_t, want_s, want_n = orc.gat_aggregate_mh(g_o, h, al, ar, heads)
+    hd, gd = dev(h), dev(gin)
+    t = torch.empty(ne, heads, device="cuda")
+    s = torch.empty_like(t)
+    p = torch.empty_like(t)
+    ctx.gat_scores(g_d, hd, dev(al), dev(ar), t, s, p, heads=heads)
+    assert rel_err(t.cpu().numpy(), want_t) < TOL
+    assert rel_err(p.cpu().numpy(), want_n) < TOL
+    out = torch.empty(n, d, device="cuda")
+    ctx.spmm(g_d, capi.W_EDGE, hd, out, edge_w=p, heads=heads)
+    assert rel_err(out.cpu().numpy(), want_out) < TOL
+    # backward pieces
+    want_go, want_ds, want_ng, want_lg, want_rg = orc.gat_d_aggregate_mh(g_o, h, gin, want_n, want_t, heads)
+    ng = torch.empty(ne, heads, device="cuda")
+    ctx.sddmm(g_d, gd, hd, ng, heads=heads)
+    assert rel_err(ng.cpu().numpy(), want_ng) < TOL
+    sc = torch.empty(ne, heads, device="cuda")
+    lg = torch.empty(d, device="cuda")
+    rg = torch.empty(d, device="cuda")
+    ctx.gat_softmax_bwd_alpha(g_d, hd, dev(want_n), dev(want_ng), dev(want_t), sc, lg, rg, heads=heads)
+    assert rel_err(sc.cpu().numpy(), want_ds) < TOL
+    assert rel_err(lg.cpu().numpy(), want_lg) < TOL
+    assert rel_err(rg.cpu().numpy(), want_rg) < TOL
+    go = torch.empty(n, d, device="cuda")
+    ctx.spmm(g_d, capi.W_EDGE_T, gd, go, edge_w=dev(want_n), heads=heads)
+    assert rel_err(go.cpu().numpy(), want_go) < TOL
+    pt = torch.empty(ne, heads, device="cuda")
+    ctx.edge_transpose(g_d, dev(want_n), pt, heads=heads)
+    want_pt = np.stack([orc.symmetric_csr_transpose(g_o, np.ascontiguousarray(want_n[:, k])) for k in range(heads)], 1)
+    assert np.array_equal(pt.cpu().numpy(), want_pt)
