@@ -286,6 +286,149 @@ __global__ void edge_gather_kernel(int64_t ne, int H, const uint32_t* rev, const
   out[t] = in[(int64_t)rev[e] * H + h];
 }
 
+// ---- head-vectorised variants (H in {2,4,8,16}): one lane owns ALL heads of an edge, so the
+// [ne][H] arrays are read and written as contiguous 4*H-byte records (the runtime-H kernels above
+// walk them with a 4*H-byte stride, 8x the traffic at H = 8) and row reductions run once per row.
+template <int H>
+struct HeadVec {
+  float v[H];
+  __device__ __forceinline__ void load(const float* p) {
+    if constexpr (H % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < H / 4; ++k) {
+        const f4 t = reinterpret_cast<const f4*>(p)[k];
+        v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < H; ++k) v[k] = p[k];
+    }
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    if constexpr (H % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < H / 4; ++k) {
+        f4 t = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        reinterpret_cast<f4*>(p)[k] = t;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < H; ++k) p[k] = v[k];
+    }
+  }
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void edge_softmax_hv_kernel(int64_t nv, const int64_t* rowptr,
+                                                              const uint32_t* col, const float* sl,
+                                                              const float* sr, float eps, float* temp,
+                                                              float* scores, float* norm) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  if (e0 == e1) return;
+  HeadVec<H> ssrc, mx, den;
+  ssrc.load(sl + row * H);
+#pragma unroll
+  for (int h = 0; h < H; ++h) { mx.v[h] = -INFINITY; den.v[h] = 0.f; }
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    HeadVec<H> t, s;
+    t.load(sr + (int64_t)col[e] * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      t.v[h] = ssrc.v[h] + t.v[h];
+      s.v[h] = t.v[h] > 0.0f ? t.v[h] : eps * t.v[h];
+      mx.v[h] = fmaxf(mx.v[h], s.v[h]);
+    }
+    t.store(temp + e * H);
+    s.store(scores + e * H);
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) mx.v[h] = wave_max(mx.v[h]);
+  for (int64_t e = e0 + lane; e < e1; e += 64) {  // each lane re-reads only its own writes
+    HeadVec<H> s;
+    s.load(scores + e * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      s.v[h] = expf(s.v[h] - mx.v[h]);
+      den.v[h] += s.v[h];
+    }
+    s.store(norm + e * H);
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) den.v[h] = wave_sum(den.v[h]);
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    HeadVec<H> p;
+    p.load(norm + e * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) p.v[h] = p.v[h] / den.v[h];
+    p.store(norm + e * H);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void softmax_bwd_hv_kernel(int64_t nv, const int64_t* rowptr,
+                                                             const float* p, const float* dp,
+                                                             const float* temp, float eps,
+                                                             float* scores, float* gbuf, float* rs) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  HeadVec<H> dot, gs;
+#pragma unroll
+  for (int h = 0; h < H; ++h) { dot.v[h] = 0.f; gs.v[h] = 0.f; }
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    HeadVec<H> a, b;
+    a.load(p + e * H);
+    b.load(dp + e * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) dot.v[h] += a.v[h] * b.v[h];
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) dot.v[h] = wave_sum(dot.v[h]);
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    HeadVec<H> a, b, t, ds, ge;
+    a.load(p + e * H);
+    b.load(dp + e * H);
+    t.load(temp + e * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float x = a.v[h] * (1.0f - a.v[h]) * b.v[h];
+      ds.v[h] = x - (dot.v[h] - a.v[h] * b.v[h]) * a.v[h];
+      ge.v[h] = ds.v[h] * (t.v[h] > 0.0f ? 1.0f : eps);
+      gs.v[h] += ge.v[h];
+    }
+    ds.store(scores + e * H);
+    ge.store(gbuf + e * H);
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) gs.v[h] = wave_sum(gs.v[h]);
+  if (lane == 0) gs.store(rs + row * H);
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void colsum_hv_kernel(int64_t nv, const int64_t* rowptr,
+                                                        const uint32_t* rev, const float* gbuf, float* cs) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  HeadVec<H> s;
+#pragma unroll
+  for (int h = 0; h < H; ++h) s.v[h] = 0.f;
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    HeadVec<H> g;
+    g.load(gbuf + (int64_t)rev[e] * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) s.v[h] += g.v[h];
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) s.v[h] = wave_sum(s.v[h]);
+  if (lane == 0) s.store(cs + row * H);
+}
+
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
 
 int check_heads(const char* who, int len, int heads) {
@@ -317,8 +460,18 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   GAIB_LAUNCH_CHECK();
   {
     ProfScope ps(ctx, "gat_edge_softmax");
-    edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
-        g->nv, heads, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+    const bool al16 = (((uintptr_t)d_temp_scores | (uintptr_t)d_scores | (uintptr_t)d_norm_scores) & 15) == 0;
+#define GAIB_ESM(HH)                                                                        \
+  edge_softmax_hv_kernel<HH><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(                     \
+      g->nv, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores)
+    if (heads == 2) GAIB_ESM(2);
+    else if (heads == 4 && al16) GAIB_ESM(4);
+    else if (heads == 8 && al16) GAIB_ESM(8);
+    else if (heads == 16 && al16) GAIB_ESM(16);
+    else
+      edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
+          g->nv, heads, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+#undef GAIB_ESM
   }
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
@@ -406,18 +559,34 @@ extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int l
   GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
   const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
-  const size_t ws_floats = ((size_t)g->ne + 2 * (size_t)g->nv) * heads + (size_t)nblocks * 2 * len;
+  auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };  // keep every slab 16-byte aligned
+  const size_t n_g = up4((size_t)g->ne * heads), n_v = up4((size_t)g->nv * heads);
+  const size_t ws_floats = n_g + 2 * n_v + (size_t)nblocks * 2 * len;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * ws_floats));
   float* gbuf = (float*)ctx->ws;
-  float* rs = gbuf + g->ne * heads;
-  float* cs = rs + g->nv * heads;
-  float* partial = cs + g->nv * heads;
+  float* rs = gbuf + n_g;
+  float* cs = rs + n_v;
+  float* partial = cs + n_v;
   ProfScope ps(ctx, "gat_softmax_bwd_alpha");
-  softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_norm_scores,
-                                                              d_norm_scores_grad, d_temp_scores, epsilon,
-                                                              d_scores, gbuf, rs);
-  GAIB_LAUNCH_CHECK();
-  colsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->rev, gbuf, cs);
+  const bool al16 = (((uintptr_t)d_norm_scores | (uintptr_t)d_norm_scores_grad | (uintptr_t)d_temp_scores |
+                      (uintptr_t)d_scores | (uintptr_t)gbuf | (uintptr_t)rs | (uintptr_t)cs) & 15) == 0;
+#define GAIB_SBW(HH)                                                                                         \
+  do {                                                                                                       \
+    softmax_bwd_hv_kernel<HH><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(                                      \
+        g->nv, g->rowptr, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, d_scores, gbuf, rs);    \
+    colsum_hv_kernel<HH><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs);       \
+  } while (0)
+  if (heads == 2) GAIB_SBW(2);
+  else if (heads == 4 && al16) GAIB_SBW(4);
+  else if (heads == 8 && al16) GAIB_SBW(8);
+  else if (heads == 16 && al16) GAIB_SBW(16);
+  else {
+    softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_norm_scores,
+                                                                d_norm_scores_grad, d_temp_scores, epsilon,
+                                                                d_scores, gbuf, rs);
+    colsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->rev, gbuf, cs);
+  }
+#undef GAIB_SBW
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
                                                                          rows_per_block, partial);

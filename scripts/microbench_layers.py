@@ -22,7 +22,7 @@ KEYS = ["spmm_light", "spmm_heavy", "spmm_sub", "sgemm", "relu", "d_relu", "gat_
         "gat_sddmm", "gat_softmax_bwd_alpha"]
 
 
-def run_layer(ctx, kind, name, graph_name, din, dout, selfloop, steps, scale):
+def run_layer(ctx, kind, name, graph_name, din, dout, selfloop, steps, scale, heads=1):
     sg = synth.make(graph_name, device="cuda", scale=scale)
     g = ctx.graph(sg.rowptr, sg.colidx)
     if selfloop:
@@ -32,6 +32,8 @@ def run_layer(ctx, kind, name, graph_name, din, dout, selfloop, steps, scale):
     nv, ne = g.nv, g.ne
     lg = L.LGraph.adopt(g)
     layer = L.Layer(kind, 1, nv, din, dout, lg, act=True)
+    if heads > 1:
+        layer.set_heads(heads)
     layer.write(L.FEAT_IN, torch.randn(nv, din, device="cuda"))
     layer.write(L.GRAD_IN, torch.randn(nv, dout, device="cuda"))
     out = torch.empty(nv, dout, device="cuda")
@@ -75,6 +77,7 @@ def main():
     run_layer(ctx, L.GCN, "GCN 128->47", "ogbn-products", 128, 47, True, args.steps, args.scale)
     run_layer(ctx, L.GAT, "GAT 64->64", "reddit", 64, 64, True, args.steps, args.scale)
     run_layer(ctx, L.GAT, "GAT 602->64 ", "reddit", 602, 64, True, args.steps, args.scale)
+    run_layer(ctx, L.GAT, "GAT 64->64 8 heads", "reddit", 64, 64, True, args.steps, args.scale, heads=8)
 
 
 if __name__ == "__main__":
