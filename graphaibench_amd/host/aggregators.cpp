@@ -106,7 +106,14 @@ void GAT_Aggregator::set_num_heads(int h) {
 }
 
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
-  assert(g.sizeEdges() <= num_edges);
+  if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
+    num_edges = g.sizeEdges();
+    float** arrays[] = {&d_scores, &d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
+    for (float** a : arrays) {
+      float_free_device(*a);
+      *a = gaib_host::dmalloc<float>(num_edges * heads);
+    }
+  }
   {
     OpTimer t(OP_SCORE);
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), dev(g), len, heads, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,

@@ -2,6 +2,7 @@
 #include "gaib_layers.h"
 #include "graph_conv_layer.h"
 #include "host_util.h"
+#include "sampler.h"
 
 namespace {
 struct LayerBox {
@@ -129,6 +130,40 @@ float* gaibl_layer_ptr(void* layer, int which) {
     default: return nullptr;
   }
 }
+
+uint32_t gaibl_sample_subgraph(uint32_t nv, uint32_t ne, const uint32_t* rowptr, const uint32_t* colidx,
+                               const uint8_t* train_masks, uint32_t n, uint32_t m, unsigned seed,
+                               uint32_t** sub_rowptr, uint32_t** sub_colidx, uint32_t** kept_ids) {
+  Graph full(false);
+  full.allocateFrom(nv, ne);
+  memcpy(full.row_host_ptr(), rowptr, sizeof(uint32_t) * ((size_t)nv + 1));
+  if (ne) memcpy(full.edge_host_ptr(), colidx, sizeof(uint32_t) * ne);
+  std::vector<mask_t> masks(train_masks, train_masks + nv);
+  Graph* tg = full.generate_masked_graph(masks.data());
+  size_t cnt = 0;
+  for (auto b : masks) cnt += b;
+  Sampler sampler(&full, tg, masks.data(), cnt);
+  sampler.set_frontier_size(m);
+  VertexSet st;
+  sampler.select_vertices(n, st, seed);
+  std::vector<mask_t> sm(nv);
+  Graph sg(false);
+  sampler.generateSubgraph(st, sm.data(), &sg);
+  const uint32_t snv = (uint32_t)sg.size(), sne = (uint32_t)sg.sizeEdges();
+  *sub_rowptr = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)snv + 1));
+  *sub_colidx = (uint32_t*)malloc(sizeof(uint32_t) * (sne ? sne : 1));
+  *kept_ids = (uint32_t*)malloc(sizeof(uint32_t) * (snv ? snv : 1));
+  memcpy(*sub_rowptr, sg.row_host_ptr(), sizeof(uint32_t) * ((size_t)snv + 1));
+  if (sne) memcpy(*sub_colidx, sg.edge_host_ptr(), sizeof(uint32_t) * sne);
+  uint32_t k = 0;
+  for (index_t v : st) (*kept_ids)[k++] = v;
+  tg->dealloc();
+  delete tg;
+  full.dealloc();
+  sg.dealloc();
+  return snv;
+}
+void gaibl_free_host(void* p) { free(p); }
 
 void* gaibl_adam_create(float lr) { return static_cast<optimizer*>(new adam(lr)); }
 void gaibl_adam_free(void* opt) { delete static_cast<optimizer*>(opt); }

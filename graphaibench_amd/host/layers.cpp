@@ -52,11 +52,28 @@ graph_conv_layer<Aggregator>::graph_conv_layer(int id, int nv, int din, int dout
   optm = new adam(lr);
 }
 
+// number of rows changes with subgraph sampling (training on subgraphs, evaluation on the full
+// graph); buffers grow when needed (reference GPU build: src/gnn/graph_conv_layer.cu:57-83)
 template <typename Aggregator>
 void graph_conv_layer<Aggregator>::update_dim_size(size_t x) {
   if (x > capacity_) {
-    fprintf(stderr, "update_dim_size(%zu): layer buffers were sized for %zu rows\n", x, capacity_);
-    exit(EXIT_FAILURE);
+    const size_t nin = x * dim_in, nout = x * dim_out;
+    auto regrow = [&](float*& p, size_t n) {
+      if (!p) return;
+      GAIB_OR_DIE(gaib_free(C(), p));
+      p = gaib_host::dmalloc<float>(n);
+      GAIB_OR_DIE(gaib_fill_f32(C(), n, 0.f, p));
+    };
+    regrow(d_in_temp, nin);
+    regrow(d_in_temp1, nin);
+    regrow(d_out_temp, nout);
+    if (level_ > 0) regrow(feat_in, nin);
+    regrow(grad_in, nout);
+    if (dropout_mask) {
+      GAIB_OR_DIE(gaib_free(C(), dropout_mask));
+      dropout_mask = gaib_host::dmalloc<mask_t>(nin);
+    }
+    capacity_ = x;
   }
   num_samples = (int)x;
 }

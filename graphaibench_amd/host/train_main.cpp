@@ -18,6 +18,7 @@
 #include "l2norm_layer.h"
 #include "math_functions.hh"
 #include "reader.h"
+#include "sampler.h"
 #include "softmax_loss_layer.h"
 
 #if defined(USE_GAT)
@@ -51,6 +52,17 @@ struct Trainer {
   float* d_features = nullptr;
   label_t* d_labels = nullptr;
   mask_t *d_masks_train = nullptr, *d_masks_val = nullptr, *d_masks_test = nullptr;
+  // sampling (GraphSAINT-style; net.cpp:156-176, 288-358)
+  Graph* training_graph = nullptr;
+  Sampler* sampler = nullptr;
+  std::vector<Graph*> subgs;
+  std::vector<mask_t> subg_masks;
+  std::vector<float> feats_host;
+  std::vector<label_t> labels_host;
+  std::vector<mask_t> masks_train_host;
+  int num_subgraphs = 1, subg_nv = 0;
+  float* d_feats_subg = nullptr;
+  label_t* d_labels_subg = nullptr;
   // network
   std::vector<gconv_t> layers;
   l2norm_layer* l2 = nullptr;
@@ -78,11 +90,9 @@ struct Trainer {
       inductive = atoi(argv[12]);
     }
     assert(num_layers >= 2);
-    if (subg_size > 0 || inductive) {
-      std::cerr << "subgraph sampling / inductive training is not implemented by the MI355X backend yet\n";
-      exit(1);
-    }
-    if (ARCH == gnn_arch::GAT) use_l2norm = use_dense = true;  // net.cpp:69-71
+    // l2norm + dense head for sampling and GAT (net.cpp:69-71)
+    if (subg_size > 0 || ARCH == gnn_arch::GAT) use_l2norm = use_dense = true;
+    if (subg_size > 0) inductive = 1;  // net.cpp:160
   }
 
   void load() {
@@ -121,14 +131,95 @@ struct Trainer {
     graph->alloc_on_device();
     graph->copy_to_gpu();
     graph->compute_vertex_data();
+    training_graph = graph;
+    if (inductive) {
+      training_graph = graph->generate_masked_graph(mtrain.data());
+      training_graph->copy_to_gpu();
+      training_graph->compute_vertex_data();
+    }
+    if (subg_size > 0) {
+      if ((size_t)subg_size > train_count) {
+        std::cerr << "subg_size " << subg_size << " exceeds the training set (" << train_count << ")\n";
+        exit(1);
+      }
+      if (val_interval < num_epochs) {
+        std::cout << "disabling validation for subgraph sampling on GPU\n";
+        val_interval = num_epochs;
+      }
+      feats_host = feats;
+      labels_host = labels;
+      masks_train_host = mtrain;
+      num_subgraphs = num_threads > 0 ? num_threads : 1;
+      sampler = new Sampler(graph, training_graph, masks_train_host.data(), train_count);
+      subgs.resize(num_subgraphs);
+      for (auto& g : subgs) g = new Graph(true);
+      subg_masks.resize((size_t)num_samples * num_subgraphs);
+      float_malloc_device64((size_t)subg_size * dim_init, d_feats_subg);
+      uint8_malloc_device(subg_size, d_labels_subg);
+    }
+  }
+
+  // one epoch's subgraph: (re)sample num_subgraphs of them when none is left, then take one
+  void subgraph_sampling(int& num_subg_remain) {
+    if (num_subg_remain == 0) {
+#pragma omp parallel for
+      for (int sid = 0; sid < num_subgraphs; sid++) {
+        VertexSet set;
+        sampler->select_vertices(subg_size, set, (unsigned)omp_get_thread_num());  // seed = thread id, as net.cpp:298
+        sampler->generateSubgraph(set, &subg_masks[(size_t)sid * num_samples], subgs[sid]);
+      }
+      num_subg_remain = num_subgraphs;
+    }
+    const int sg_id = --num_subg_remain;
+    Graph* sg = subgs[sg_id];
+    sg->degree_counting();
+    subg_nv = sg->size();
+    sg->copy_to_gpu();  // subgraphs of the self-looped full graph already carry their self loops
+    sg->compute_vertex_data();
+    for (auto& l : layers) {
+      l.update_dim_size(subg_nv);
+      l.set_graph_ptr(sg);
+    }
+    if (use_l2norm) l2->update_dim_size(subg_nv);
+    if (use_dense) dense->update_dim_size(subg_nv);
+    loss->update_dim_size(subg_nv);
+    // features / labels of the kept vertices, in subgraph order
+    const mask_t* mk = &subg_masks[(size_t)sg_id * num_samples];
+    std::vector<float> f((size_t)subg_nv * dim_init);
+    std::vector<label_t> lab(subg_nv);
+    size_t k = 0;
+    for (int v = 0; v < num_samples; v++)
+      if (mk[v] == 1) {
+        std::copy(&feats_host[(size_t)v * dim_init], &feats_host[(size_t)(v + 1) * dim_init], &f[k * dim_init]);
+        lab[k++] = labels_host[v];
+      }
+    assert((int)k == subg_nv);
+    GAIB_OR_DIE(gaib_memcpy_h2d(gpu_context::get(), d_feats_subg, f.data(), sizeof(float) * f.size()));
+    copy_uint8_device(subg_nv, lab.data(), d_labels_subg);
+    layers[0].set_feat_in(d_feats_subg);
+    loss->set_labels_ptr(d_labels_subg);
+  }
+
+  // evaluation always runs on the full graph (net.cpp:505-540)
+  void use_full_graph() {
+    for (auto& l : layers) {
+      l.update_dim_size(num_samples);
+      l.set_graph_ptr(graph);
+    }
+    if (use_l2norm) l2->update_dim_size(num_samples);
+    if (use_dense) dense->update_dim_size(num_samples);
+    loss->update_dim_size(num_samples);
+    layers[0].set_feat_in(d_features);
+    loss->set_labels_ptr(d_labels);
   }
 
   void construct() {
     std::cout << "constructing neural network...\n";
+    const int nv = subg_size > 0 ? subg_size : num_samples;  // buffers grow on demand (update_dim_size)
     for (int l = 0; l < num_layers - 1; l++)
-      layers.push_back(gconv_t(l, num_samples, l == 0 ? dim_init : dim_hid, dim_hid, graph, true, lrate, feat_drop,
+      layers.push_back(gconv_t(l, nv, l == 0 ? dim_init : dim_hid, dim_hid, training_graph, true, lrate, feat_drop,
                                score_drop));
-    layers.push_back(gconv_t(num_layers - 1, num_samples, dim_hid, use_dense ? dim_hid : num_cls, graph, false, lrate,
+    layers.push_back(gconv_t(num_layers - 1, nv, dim_hid, use_dense ? dim_hid : num_cls, training_graph, false, lrate,
                              feat_drop, score_drop));
 #if defined(USE_GAT)
     if (const char* hs = getenv("GAIB_GAT_HEADS")) {  // extension: multi-head attention (default 1 = reference)
@@ -136,10 +227,10 @@ struct Trainer {
       std::cout << "GAT attention heads: " << atoi(hs) << "\n";
     }
 #endif
-    if (use_l2norm) l2 = new l2norm_layer(num_samples, dim_hid);
-    if (use_dense) dense = new dense_layer(num_samples, dim_hid, num_cls, lrate);
+    if (use_l2norm) l2 = new l2norm_layer(nv, dim_hid);
+    if (use_dense) dense = new dense_layer(nv, dim_hid, num_cls, lrate);
     layers[0].set_feat_in(d_features);
-    loss = new softmax_loss_layer(num_samples, num_cls, d_labels);
+    loss = new softmax_loss_layer(nv, num_cls, d_labels);
   }
 
   void set_phase(net_phase p) {
@@ -160,6 +251,11 @@ struct Trainer {
 
   acc_t forward_prop(acc_t& loss_value) {
     forward_layers();
+    if (subg_size > 0) {  // every vertex of the subgraph is a training vertex (net.cpp:478-488)
+      loss->forward(0, subg_nv, NULL);
+      loss_value = loss->get_prediction_loss(0, subg_nv, subg_nv, NULL);
+      return masked_accuracy_single(0, subg_nv, subg_nv, num_cls, NULL, loss->get_feat_in(), d_labels_subg);
+    }
     loss->forward(train_begin, train_end, d_masks_train);
     loss_value = loss->get_prediction_loss(train_begin, train_end, train_count, d_masks_train);
     return masked_accuracy_single(train_begin, train_end, train_count, num_cls, d_masks_train, loss->get_feat_in(),
@@ -167,13 +263,15 @@ struct Trainer {
   }
 
   void backward_prop() {
+    const size_t tb = subg_size > 0 ? 0 : train_begin, te = subg_size > 0 ? (size_t)subg_nv : train_end;
+    mask_t* tm = subg_size > 0 ? NULL : d_masks_train;
     if (use_dense) {
-      loss->backward(train_begin, train_end, d_masks_train, dense->get_grad_in());
+      loss->backward(tb, te, tm, dense->get_grad_in());
       dense->backward(l2->get_grad_in());
       l2->backward(layers[num_layers - 1].get_grad_in());
       layers[num_layers - 1].backward(l2->get_feat_in(), layers[num_layers - 2].get_grad_in());
     } else {
-      loss->backward(train_begin, train_end, d_masks_train, layers[num_layers - 1].get_grad_in());
+      loss->backward(tb, te, tm, layers[num_layers - 1].get_grad_in());
       layers[num_layers - 1].backward(loss->get_feat_in(), layers[num_layers - 2].get_grad_in());
     }
     for (int l = num_layers - 2; l > 0; l--) layers[l].backward(layers[l + 1].get_feat_in(), layers[l - 1].get_grad_in());
@@ -182,6 +280,7 @@ struct Trainer {
 
   acc_t evaluate(const std::string& type) {
     set_phase(net_phase::TEST);
+    if (subg_size > 0 || inductive) use_full_graph();
     forward_layers();
     if (type == "test")
       return masked_accuracy_single(test_begin, test_end, test_count, num_cls, d_masks_test, loss->get_feat_in(), d_labels);
@@ -192,7 +291,9 @@ struct Trainer {
     optimizer* opt = new adam(lrate);  // one instance for every layer's update_weight call (Q6)
     std::cout << "Start training...\n";
     double total = 0.0;
+    int num_subg_remain = 0;
     for (int itr = 0; itr < num_epochs; itr++) {
+      if (subg_size > 0) subgraph_sampling(num_subg_remain);
       std::cout << "Epoch " << std::setw(3) << itr << " ";
       set_phase(net_phase::TRAIN);
       acc_t train_loss = 0.0;
@@ -213,6 +314,8 @@ struct Trainer {
         std::cout << "val_acc " << std::setprecision(3) << std::fixed << val_acc << " ";
         std::cout << "time " << std::setprecision(3) << std::fixed << epoch_time + tv << " s (train_time " << epoch_time
                   << " val_time " << tv << ")\n";
+        if (inductive && subg_size == 0)  // back to the training graph
+          for (auto& l : layers) l.set_graph_ptr(training_graph);
       } else {
         std::cout << "train_time " << std::fixed << epoch_time << " s (fw " << fw << ", bw " << bw << ")\n";
       }

@@ -35,6 +35,9 @@ SIGNATURES = {
     "gaibl_layer_set_phase": (None, [_vp, _i]),
     "gaibl_layer_set_heads": (None, [_vp, _i]),
     "gaibl_layer_ptr": (_vp, [_vp, _i]),
+    "gaibl_sample_subgraph": (C.c_uint32, [C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint,
+                                           C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "gaibl_free_host": (None, [_vp]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
     "gaibl_time_op": (C.c_double, [C.c_char]),
@@ -180,3 +183,24 @@ class Layer:
 
 def adam(lr: float):
     return load().gaibl_adam_create(lr)
+
+
+def sample_subgraph(rowptr, colidx, train_masks, n: int, m: int, seed: int):
+    """host-only: GraphSAINT frontier sampling + induced subgraph (Sampler class); returns
+    (sub_rowptr uint32[snv+1], sub_colidx uint32[sne], kept_ids uint32[snv])"""
+    import numpy as np
+
+    lib = load()
+    rp = np.ascontiguousarray(rowptr, np.uint32)
+    ci = np.ascontiguousarray(colidx, np.uint32)
+    mk = np.ascontiguousarray(train_masks, np.uint8)
+    a, b, c = _vp(), _vp(), _vp()
+    snv = lib.gaibl_sample_subgraph(len(rp) - 1, len(ci), rp.ctypes.data, ci.ctypes.data, mk.ctypes.data, n, m, seed,
+                                    C.byref(a), C.byref(b), C.byref(c))
+    srp = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), (snv + 1,)).copy()
+    sne = int(srp[-1])
+    sci = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint32)), (max(sne, 1),))[:sne].copy()
+    ids = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint32)), (max(snv, 1),))[:snv].copy()
+    for p in (a, b, c):
+        lib.gaibl_free_host(p)
+    return srp, sci, ids

@@ -53,6 +53,14 @@ void gaibl_layer_set_phase(void* layer, int phase); /* 0 TRAIN 1 TEST 2 VAL */
 void gaibl_layer_set_heads(void* layer, int heads); /* GAT only: GAT_Aggregator::set_num_heads */
 float* gaibl_layer_ptr(void* layer, int which);
 
+/* host-only test hook for the GraphSAINT sampler (include/gnn/sampler.h): samples up to n vertices
+ * with frontier size m from the training-masked graph and builds the induced, re-indexed subgraph.
+ * Outputs are malloc'ed arrays the caller frees with gaibl_free_host. Returns the subgraph's nv. */
+uint32_t gaibl_sample_subgraph(uint32_t nv, uint32_t ne, const uint32_t* rowptr, const uint32_t* colidx,
+                               const uint8_t* train_masks, uint32_t n, uint32_t m, unsigned seed,
+                               uint32_t** sub_rowptr, uint32_t** sub_colidx, uint32_t** kept_ids);
+void gaibl_free_host(void* p);
+
 void* gaibl_adam_create(float lr);
 void gaibl_adam_free(void* opt);
 
