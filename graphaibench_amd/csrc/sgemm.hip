@@ -253,7 +253,7 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
   // more resident blocks hide the staging / epilogue phases of one block under another's MFMAs.
 #define GAIB_GEMM_LAUNCH(AV, BV, OCC)                                                    \
   sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV, OCC><<<grid, THREADS, 0, ctx->stream>>>(g)
-  const int occ = ctx->sgemm_variant == 2 ? 2 : (ctx->sgemm_variant == 4 ? 4 : 3);
+  const int occ = ctx->sgemm_variant == 2 ? 2 : ((ctx->sgemm_variant == 4 || ctx->sgemm_variant >= 10) ? 4 : 3);
   if (avec && bvec) {
     if (occ == 4) GAIB_GEMM_LAUNCH(true, true, 4);
     else if (occ == 3) GAIB_GEMM_LAUNCH(true, true, 3);
@@ -274,7 +274,16 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
 
 template <bool AK, bool BKM>
 int dispatch_shape(gaib_ctx* ctx, const GemmArgs& g, bool avec, bool bvec) {
-  if (g.N > 64) return launch<2, 2, 2, 2, AK, BKM>(ctx, g, avec, bvec);  // 128 x 128
+  // experimental tilings (sgemm_variant 10..12): smaller per-wave tiles, more resident waves
+  if (ctx->sgemm_variant == 10) return launch<2, 2, 2, 1, AK, BKM>(ctx, g, avec, bvec);  // 128 x 64
+  if (ctx->sgemm_variant == 11) return launch<2, 2, 1, 2, AK, BKM>(ctx, g, avec, bvec);  // 64 x 128
+  if (ctx->sgemm_variant == 12) return launch<2, 2, 1, 1, AK, BKM>(ctx, g, avec, bvec);  // 64 x 64
+  if (g.N > 64) {
+    // measured at 2.45 M x 128 x 128 (scripts/microbench.py): 64 x 128 blocks 0.86-0.87 ms vs 128 x 128 0.93-0.97 ms
+    // for the streaming-A shapes; the split-K weight gradient keeps the square tile (0.84 ms)
+    if (!AK && ctx->sgemm_variant != 13) return launch<2, 2, 1, 2, AK, BKM>(ctx, g, avec, bvec);  // 64 x 128
+    return launch<2, 2, 2, 2, AK, BKM>(ctx, g, avec, bvec);  // 128 x 128
+  }
   if (g.N > 32) return launch<4, 1, 2, 2, AK, BKM>(ctx, g, avec, bvec);  // 256 x 64
   return launch<4, 1, 2, 1, AK, BKM>(ctx, g, avec, bvec);                // 256 x 32
 }

@@ -1,10 +1,7 @@
 // output_layers.cpp -- loss / l2norm / dense layers of the model head, device-resident.
-#include "dense_layer.h"
 #include "host_util.h"
-#include "l2norm_layer.h"
 #include "math_functions.hh"
-#include "sigmoid_loss_layer.h"
-#include "softmax_loss_layer.h"
+#include "output_layers.h"
 
 static inline gaib_ctx* C() { return gpu_context::get(); }
 
@@ -60,59 +57,41 @@ float masked_accuracy_multi(int, int, int, int, mask_t*, float*, label_t*) {
   return 0;
 }
 
-// ---- l2norm_layer ---------------------------------------------------------------------------------
-l2norm_layer::l2norm_layer(int nv, int len) : num_samples(nv), dim(len), capacity_(nv), feat_in(NULL), grad_in(NULL) {
-  float_malloc_device64((size_t)nv * dim, feat_in);
-  float_malloc_device64((size_t)nv * dim, grad_in);
-  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim, 0.f, feat_in));
-  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim, 0.f, grad_in));
+// ---- row_block ------------------------------------------------------------------------------------
+row_block::row_block(int r, int wi, int wo) : rows(r), cap(0), win(wi), wout(wo), acts(NULL), grads(NULL) {
+  resize(r);
 }
-void l2norm_layer::forward(float* feat_out) { l2norm(num_samples, dim, feat_in, feat_out); }
-void l2norm_layer::backward(float* grad_out) { d_l2norm(num_samples, dim, feat_in, grad_in, grad_out); }
-void l2norm_layer::update_dim_size(int x) {
-  if (x > capacity_) {
-    float_free_device(feat_in);
-    float_free_device(grad_in);
-    float_malloc_device64((size_t)x * dim, feat_in);
-    float_malloc_device64((size_t)x * dim, grad_in);
-    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim, 0.f, feat_in));
-    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim, 0.f, grad_in));
-    capacity_ = x;
+void row_block::resize(int r) {
+  if (r > cap) {
+    if (acts) float_free_device(acts);
+    if (grads) float_free_device(grads);
+    float_malloc_device64((size_t)r * win, acts);
+    float_malloc_device64((size_t)r * wout, grads);
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)r * win, 0.f, acts));
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)r * wout, 0.f, grads));
+    cap = r;
   }
-  num_samples = x;
+  rows = r;
 }
 
-// ---- dense_layer ----------------------------------------------------------------------------------
+// ---- l2norm_layer (reference math: src/layers/l2norm_layer.cpp:19-64) -------------------------------
+l2norm_layer::l2norm_layer(int nv, int len) : buf(nv, len, len) {}
+void l2norm_layer::forward(float* feat_out) { l2norm(buf.rows, buf.win, buf.acts, feat_out); }
+void l2norm_layer::backward(float* grad_out) { d_l2norm(buf.rows, buf.win, buf.acts, buf.grads, grad_out); }
+
+// ---- dense_layer (reference math: src/layers/dense_layer.cpp:42-72) ---------------------------------
 dense_layer::dense_layer(int nv, int in_len, int out_len, float lr)
-    : is_bias(false), num_samples(nv), dim_in(in_len), dim_out(out_len), capacity_(nv), feat_in(NULL),
-      grad_in(NULL), optm(NULL), d_weight(NULL), d_weight_grad(NULL) {
-  float_malloc_device64((size_t)nv * dim_in, feat_in);
-  float_malloc_device64((size_t)nv * dim_out, grad_in);
-  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim_in, 0.f, feat_in));
-  GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)nv * dim_out, 0.f, grad_in));
+    : buf(nv, in_len, out_len), d_weight(NULL), d_weight_grad(NULL), optm(new adam(lr)) {
   vec_t w;
-  init_glorot(dim_in, dim_out, w, 1);  // the OpenMP path's init (dense_layer.cpp:30); its CUDA path draws from cuRAND
+  init_glorot(in_len, out_len, w, 1);  // the OpenMP path's init (dense_layer.cpp:30); its CUDA path draws from cuRAND
   float_malloc_device64(w.size(), d_weight);
   float_malloc_device64(w.size(), d_weight_grad);
   copy_float_device((int)w.size(), w.data(), d_weight);
   GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)w.size(), 0.f, d_weight_grad));
-  optm = new adam(lr);
 }
-void dense_layer::forward(float* feat_out) { matmul(num_samples, dim_out, dim_in, feat_in, d_weight, feat_out); }
+void dense_layer::forward(float* feat_out) { matmul(buf.rows, buf.wout, buf.win, buf.acts, d_weight, feat_out); }
 void dense_layer::backward(float* grad_out) {
-  matmul(dim_in, dim_out, num_samples, feat_in, grad_in, d_weight_grad, true);
-  matmul(num_samples, dim_in, dim_out, grad_in, d_weight, grad_out, false, true);
-  optm->update_gpu((size_t)dim_in * dim_out, d_weight_grad, d_weight);
-}
-void dense_layer::update_dim_size(int x) {
-  if (x > capacity_) {
-    float_free_device(feat_in);
-    float_free_device(grad_in);
-    float_malloc_device64((size_t)x * dim_in, feat_in);
-    float_malloc_device64((size_t)x * dim_out, grad_in);
-    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim_in, 0.f, feat_in));
-    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)x * dim_out, 0.f, grad_in));
-    capacity_ = x;
-  }
-  num_samples = x;
+  matmul(buf.win, buf.wout, buf.rows, buf.acts, buf.grads, d_weight_grad, true);
+  matmul(buf.rows, buf.win, buf.wout, buf.grads, d_weight, grad_out, false, true);
+  optm->update_gpu((size_t)buf.win * buf.wout, d_weight_grad, d_weight);
 }
