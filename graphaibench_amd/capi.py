@@ -27,6 +27,9 @@ SIGNATURES = {
     "gaib_ctx_destroy": (_i, [_vp]),
     "gaib_ctx_set_stream": (_i, [_vp, _vp]),
     "gaib_sync": (_i, [_vp]),
+    "gaib_side_begin": (_i, [_vp]),
+    "gaib_side_end": (_i, [_vp]),
+    "gaib_side_wait": (_i, [_vp]),
     "gaib_malloc": (_i, [_vp, C.c_size_t, _pp]),
     "gaib_free": (_i, [_vp, _vp]),
     "gaib_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
@@ -149,6 +152,15 @@ class Context:
 
     def sync(self):
         _check(self.lib.gaib_sync(self.h), "gaib_sync")
+
+    def side_begin(self):
+        _check(self.lib.gaib_side_begin(self.h), "gaib_side_begin")
+
+    def side_end(self):
+        _check(self.lib.gaib_side_end(self.h), "gaib_side_end")
+
+    def side_wait(self):
+        _check(self.lib.gaib_side_wait(self.h), "gaib_side_wait")
 
     def set_option(self, key: str, value: int):
         _check(self.lib.gaib_set_option(self.h, key.encode(), int(value)), f"gaib_set_option({key})")

@@ -45,6 +45,12 @@ struct gaib_ctx {
   // growable scratch (split-K partials, per-vertex scores, ...); never shrinks
   void* ws;
   size_t ws_bytes;
+  // side stream (gaib_stream_fork/join) with its own scratch
+  hipStream_t main_stream, side_stream;
+  hipEvent_t ev_fork, ev_join;
+  void* ws_side;
+  size_t ws_side_bytes;
+  int forked;
   // tuning knobs
   int spmm_heavy_threshold;  // rows with more edges go to the workgroup-per-row kernel
   int spmm_variant;          // 0 = auto, see spmm.hip

@@ -4,6 +4,7 @@
 // (include/utils/math_functions.hh:161-173, include/utils/cutils.h:193-202).
 #include <stdarg.h>
 #include <string.h>
+#include <utility>
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -32,6 +33,12 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->num_cus = prop.multiProcessorCount;
   c->ws = nullptr;
   c->ws_bytes = 0;
+  c->main_stream = c->stream;
+  c->side_stream = nullptr;
+  c->ev_fork = c->ev_join = nullptr;
+  c->ws_side = nullptr;
+  c->ws_side_bytes = 0;
+  c->forked = 0;
   c->spmm_heavy_threshold = 1024;
   c->spmm_variant = 0;
   c->spmm_xcd_swizzle = 1;
@@ -50,13 +57,56 @@ extern "C" int gaib_ctx_destroy(gaib_ctx* ctx) {
   if (!ctx) return GAIB_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ws_side) (void)hipFree(ctx->ws_side);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
   return GAIB_OK;
 }
 
 extern "C" int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream) {
   GAIB_CHECK(ctx, "gaib_ctx_set_stream: ctx is NULL");
+  GAIB_CHECK(!ctx->forked, "gaib_ctx_set_stream: a side section is open");
   ctx->stream = (hipStream_t)stream;
+  ctx->main_stream = ctx->stream;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_side_begin(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_side_begin: ctx is NULL");
+  GAIB_CHECK(ctx->forked == 0, "gaib_side_begin: a side section is already open or not waited for");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (!ctx->side_stream) {
+    GAIB_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    GAIB_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    GAIB_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  GAIB_HIP(hipEventRecord(ctx->ev_fork, ctx->main_stream));
+  GAIB_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+  ctx->stream = ctx->side_stream;
+  std::swap(ctx->ws, ctx->ws_side);
+  std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
+  ctx->forked = 1;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_side_end(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_side_end: ctx is NULL");
+  GAIB_CHECK(ctx->forked == 1, "gaib_side_end: no open side section");
+  GAIB_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+  ctx->stream = ctx->main_stream;
+  std::swap(ctx->ws, ctx->ws_side);
+  std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
+  ctx->forked = 2;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_side_wait(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_side_wait: ctx is NULL");
+  GAIB_CHECK(ctx->forked == 2, "gaib_side_wait: no ended side section");
+  GAIB_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->ev_join, 0));
+  ctx->forked = 0;
   return GAIB_OK;
 }
 

@@ -38,6 +38,24 @@ gaib_ctx* gpu_context::get() {
 
 void gpu_context::sync() { check(gaib_sync(get()), "gaib_sync"); }
 
+static bool overlap_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("GAIB_NO_OVERLAP");
+    on = (e && atoi(e) != 0) ? 0 : 1;
+  }
+  return on == 1;
+}
+void gpu_context::side_begin() {
+  if (overlap_enabled()) check(gaib_side_begin(get()), "gaib_side_begin");
+}
+void gpu_context::side_end() {
+  if (overlap_enabled()) check(gaib_side_end(get()), "gaib_side_end");
+}
+void gpu_context::side_wait() {
+  if (overlap_enabled()) check(gaib_side_wait(get()), "gaib_side_wait");
+}
+
 namespace gaib_host {
 static double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -111,11 +111,16 @@ void GCN_layer::backward(float* feat_out, float* grad_out) {
     float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
+    // the weight gradient (MFMA-bound) is independent of the input gradient (HBM-bound
+    // aggregation): it runs next to it on the side stream
+    if (level_ > 0) gpu_context::side_begin();
+    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
     if (level_ > 0) {
+      gpu_context::side_end();
       matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
       aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+      gpu_context::side_wait();
     }
-    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
   }
   if (level_ != 0 && feat_dropout_rate > 0.)
     d_dropout_gpu(x * y, feat_scale, grad_out, dropout_mask, grad_out);
@@ -136,30 +141,45 @@ void SAGE_layer::forward(float* feat_out) {
   if (y > z) {
     matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
     aggr.aggregate(z, *graph, d_out_temp, feat_out);
+    // + X.W_self, with the activation fused into this last product
+    if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
+    else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
   } else {
+    // X.W_self goes first, on the side stream next to the aggregation; the neighbour product then
+    // adds onto it (a+b == b+a bit for bit) with the activation fused
+    gpu_context::side_begin();
+    matmul(x, z, y, in_data, d_W_self, feat_out);
+    gpu_context::side_end();
     aggr.aggregate(y, *graph, in_data, d_in_temp1);
-    matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
+    gpu_context::side_wait();
+    if (is_act) matmul_relu(x, z, y, d_in_temp1, d_W_neigh, feat_out, false, false, true);
+    else matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out, false, false, true);
   }
-  // + X.W_self, with the activation fused into this last product
-  if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
-  else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
 }
 
 void SAGE_layer::backward(float* feat_out, float* grad_out) {
   const size_t x = num_samples, y = dim_in, z = dim_out;
   if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
   float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
+  // NB with feature dropout in_data == d_in_temp, which the else-branch below overwrites: the
+  // side section is only opened when the two do not alias
+  const bool overlap = (y > z) || (level_ > 0 && in_data != d_in_temp);
+  if (overlap) gpu_context::side_begin();
   matmul(y, z, x, in_data, grad_in, d_W_self_grad, true, false);
   if (y > z) {
+    gpu_context::side_end();
     aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
+    gpu_context::side_wait();
     if (level_ > 0) matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
+    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
+    if (overlap) gpu_context::side_end();
     if (level_ > 0) {
       matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
       aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
     }
-    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
+    if (overlap) gpu_context::side_wait();
   }
   if (level_ > 0) matmul(x, y, z, grad_in, d_W_self, grad_out, false, true, true);  // += g.W_self^T
   if (level_ != 0 && feat_dropout_rate > 0.)

@@ -51,6 +51,17 @@ int gaib_ctx_create(int device, void* stream, gaib_ctx** out);
 int gaib_ctx_destroy(gaib_ctx* ctx);
 int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream);
 int gaib_sync(gaib_ctx* ctx); /* CudaTest()'s cudaDeviceSynchronize, cutils.h:18-28 */
+/* Side stream for work that is independent of the calls that follow it (the weight-gradient GEMM
+ * next to the aggregation of the input gradient: an MFMA-bound and an HBM-bound kernel overlap).
+ *   gaib_side_begin: everything enqueued so far is a dependency of the side stream; calls go to the
+ *                    side stream (with its own scratch) from here ...
+ *   gaib_side_end:   ... to here; calls go to the main stream again, which does NOT wait.
+ *   gaib_side_wait:  the main stream waits for the side section.  Buffers the side section reads or
+ *                    writes must not be written on the main stream between end and wait.
+ * One side section at a time (begin after begin without wait is an error). */
+int gaib_side_begin(gaib_ctx* ctx);
+int gaib_side_end(gaib_ctx* ctx);
+int gaib_side_wait(gaib_ctx* ctx);
 
 /* ---- memory: float/uint/uint8_malloc_device, *_free_device, copy_*_device, copy_float_host,
  * init_const_gpu  (include/utils/math_functions.hh:161-173, math_functions.cu:12-14;

@@ -11,6 +11,10 @@ class gpu_context {
   static gaib_ctx* get();                        // lazily created
   static void set(int device, void* hip_stream); // explicit (multi-GPU launchers, tests)
   static void sync();                            // CudaTest() equivalent
+  // side stream for independent work (gaib_side_begin/end/wait); GAIB_NO_OVERLAP=1 turns all three into no-ops
+  static void side_begin();
+  static void side_end();
+  static void side_wait();
   static void check(int status, const char* what); // non-zero -> print + exit (cutils.h:18-28)
 };
 #define GAIB_OR_DIE(call) gpu_context::check((call), #call)

@@ -546,3 +546,36 @@ def test_gat_multi_head(ctx, d, heads, hub):
     ctx.edge_transpose(g_d, dev(want_n), pt, heads=heads)
     want_pt = np.stack([orc.symmetric_csr_transpose(g_o, np.ascontiguousarray(want_n[:, k])) for k in range(heads)], 1)
     assert np.array_equal(pt.cpu().numpy(), want_pt)
+
+
+def test_side_section_overlaps_and_orders(ctx):
+    """gaib_side_begin/end/wait: a split-K weight-gradient GEMM on the side stream next to an SpMM on the
+    main stream gives the sequential results bit for bit; misuse is rejected."""
+    rp, ci = random_graph(20000, 20, seed=77, power_law=True)
+    _, g_d = make(ctx, rp, ci, selfloop=True)
+    n, d = g_d.nv, 128
+    x = dev(feat(n, d, 1))
+    gr = dev(feat(n, d, 2))
+    seq_dw = torch.empty(d, d, device="cuda")
+    seq_out = torch.empty(n, d, device="cuda")
+    ctx.sgemm(x, gr, seq_dw, True, False)
+    ctx.spmm(g_d, capi.W_GCN, gr, seq_out)
+    for _ in range(3):
+        dw = torch.zeros(d, d, device="cuda")
+        out = torch.zeros(n, d, device="cuda")
+        ctx.side_begin()
+        ctx.sgemm(x, gr, dw, True, False)
+        ctx.side_end()
+        ctx.spmm(g_d, capi.W_GCN, gr, out)
+        ctx.side_wait()
+        ctx.sync()
+        assert torch.equal(dw, seq_dw) and torch.equal(out, seq_out)
+    with pytest.raises(RuntimeError):
+        ctx.side_end()
+    with pytest.raises(RuntimeError):
+        ctx.side_wait()
+    ctx.side_begin()
+    with pytest.raises(RuntimeError):
+        ctx.side_begin()
+    ctx.side_end()
+    ctx.side_wait()
