@@ -70,6 +70,9 @@ SIGNATURES = {
     "gaib_d_dropout": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
     "gaib_softmax_xent": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gaib_d_softmax_xent": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gaib_sigmoid_xent": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gaib_d_sigmoid_xent": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gaib_masked_f1_micro": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, C.POINTER(_f), C.POINTER(_i64)]),
     "gaib_masked_avg_loss": (_i, [_vp, _i64, _i64, _vp, _vp, C.POINTER(_f)]),
     "gaib_masked_accuracy_single": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, C.POINTER(_f)]),
     "gaib_l2norm": (_i, [_vp, _i64, _i, _vp, _vp]),
@@ -246,6 +249,22 @@ class Context:
     def d_softmax_xent(self, probs, labels, diff, begin, end, masks=None):
         _check(self.lib.gaib_d_softmax_xent(self.h, probs.shape[1], begin, end, _ptr(masks), _ptr(labels),
                                             _ptr(probs), _ptr(diff)), "gaib_d_softmax_xent")
+
+    def sigmoid_xent(self, logits, labels, loss, probs, begin, end, masks=None):
+        _check(self.lib.gaib_sigmoid_xent(self.h, logits.shape[1], begin, end, _ptr(logits), _ptr(masks),
+                                          _ptr(labels), _ptr(loss), _ptr(probs)), "gaib_sigmoid_xent")
+
+    def d_sigmoid_xent(self, probs, labels, diff, begin, end, masks=None):
+        _check(self.lib.gaib_d_sigmoid_xent(self.h, probs.shape[1], begin, end, _ptr(masks), _ptr(labels),
+                                            _ptr(probs), _ptr(diff)), "gaib_d_sigmoid_xent")
+
+    def masked_f1_micro(self, preds, labels, begin, end, masks=None):
+        """-> (f1_micro, (tp, fp, fn))"""
+        r = _f(0.0)
+        cnt = (_i64 * 3)()
+        _check(self.lib.gaib_masked_f1_micro(self.h, begin, end, preds.shape[1], _ptr(masks), _ptr(preds),
+                                             _ptr(labels), C.byref(r), cnt), "gaib_masked_f1_micro")
+        return float(r.value), tuple(int(x) for x in cnt)
 
     def masked_avg_loss(self, loss, begin, end, masks=None) -> float:
         r = C.c_float()

@@ -132,6 +132,85 @@ __global__ void d_softmax_xent_kernel(int num_cls, int64_t begin, int64_t end,
   }
 }
 
+// sigmoid + cross entropy per vertex for multi-label heads (sigmoid_loss_layer.cpp:4-17,
+// math_functions.cpp:517-521,553-559): labels are [n x num_cls] 0/1 bytes.  One wave per
+// vertex, classes across lanes; masked-out vertices of the range get loss 0 (the .cu layer
+// zeroes d_losses first, sigmoid_loss_layer.cu:6).
+__global__ __launch_bounds__(256) void sigmoid_xent_kernel(int num_cls, int64_t begin, int64_t end,
+                                                           const float* in, const uint8_t* masks,
+                                                           const uint8_t* labels, float* loss,
+                                                           float* out) {
+  const int64_t i = begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= end) return;
+  const int lane = threadIdx.x & 63;
+  if (masks && masks[i] != 1) {
+    if (lane == 0) loss[i] = 0.f;
+    return;
+  }
+  const float* x = in + i * (int64_t)num_cls;
+  const uint8_t* y = labels + i * (int64_t)num_cls;
+  float* o = out + i * (int64_t)num_cls;
+  float part = 0.f;
+  for (int c = lane; c < num_cls; c += 64) {
+    const float p = x[c];
+    o[c] = (float)(1. / (1. + (double)expf(-p)));
+    const float pos = p >= 0.f ? 1.f : 0.f;
+    const float e = expf((float)((double)p - 2. * (double)p * (double)pos));
+    part -= p * ((float)y[c] - pos) - logf((float)(1. + (double)e));
+  }
+  part = wave_sum(part);
+  if (lane == 0) loss[i] = part;
+}
+
+// (sigmoid - label) / (end - begin)   (sigmoid_loss_layer.cpp:19-33)
+__global__ void d_sigmoid_xent_kernel(int num_cls, int64_t begin, int64_t end,
+                                      const uint8_t* masks, const uint8_t* labels,
+                                      const float* out, float* diff) {
+  const int64_t n = (end - begin) * num_cls;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float inv = (float)(uint64_t)(end - begin);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const int64_t i = begin + t / num_cls;
+    if (masks && masks[i] != 1) continue;
+    const int64_t idx = begin * num_cls + t;
+    diff[idx] = (out[idx] - (float)labels[idx]) / inv;
+  }
+}
+
+// tp / fp / fn over every (vertex, class) cell of the masked range (math_functions.cpp:580-603):
+// integer counts, so the atomics are order-independent.
+__global__ __launch_bounds__(256) void f1_counts_kernel(int num_cls, int64_t begin, int64_t end,
+                                                        const uint8_t* masks, const float* preds,
+                                                        const uint8_t* labels,
+                                                        unsigned long long* counts) {
+  const int64_t n = (end - begin) * num_cls;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned tp = 0, fp = 0, fn = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const int64_t i = begin + t / num_cls;
+    if (masks && masks[i] != 1) continue;
+    const int64_t idx = begin * num_cls + t;
+    const bool hot = preds[idx] > 0.5f;
+    const uint8_t y = labels[idx];
+    tp += (y == 1 && hot);
+    fp += (y == 0 && hot);
+    fn += (y == 1 && !hot);
+  }
+  __shared__ unsigned s[3];
+  if (threadIdx.x < 3) s[threadIdx.x] = 0;
+  __syncthreads();
+  tp = (unsigned)wave_sum_u32(tp);
+  fp = (unsigned)wave_sum_u32(fp);
+  fn = (unsigned)wave_sum_u32(fn);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s[0], tp);
+    atomicAdd(&s[1], fp);
+    atomicAdd(&s[2], fn);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
 // two-level deterministic masked reductions ------------------------------------------------
 // partial[b] = {sum, count} over a strip; final sum over b in order on the host side of the
 // C ABI (nblocks <= 1024 values).
@@ -344,6 +423,59 @@ extern "C" int gaib_d_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, in
   d_softmax_xent_kernel<<<stream_grid((end - begin) * num_cls, 256), 256, 0, ctx->stream>>>(
       num_cls, begin, end, d_masks, d_labels, d_out, d_diff);
   GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_sigmoid_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                                 const float* d_in, const uint8_t* d_masks, const uint8_t* d_labels,
+                                 float* d_loss, float* d_out) {
+  GAIB_CHECK(ctx && d_in && d_labels && d_loss && d_out, "gaib_sigmoid_xent: NULL argument");
+  GAIB_CHECK(num_cls > 0 && begin >= 0 && end >= begin, "gaib_sigmoid_xent: bad range");
+  if (end == begin) return GAIB_OK;
+  sigmoid_xent_kernel<<<(unsigned)cdiv64(end - begin, 4), 256, 0, ctx->stream>>>(
+      num_cls, begin, end, d_in, d_masks, d_labels, d_loss, d_out);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_d_sigmoid_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                                   const uint8_t* d_masks, const uint8_t* d_labels,
+                                   const float* d_out, float* d_diff) {
+  GAIB_CHECK(ctx && d_labels && d_out && d_diff, "gaib_d_sigmoid_xent: NULL argument");
+  GAIB_CHECK(num_cls > 0 && begin >= 0 && end >= begin, "gaib_d_sigmoid_xent: bad range");
+  if (end == begin) return GAIB_OK;
+  d_sigmoid_xent_kernel<<<stream_grid((end - begin) * num_cls, 256), 256, 0, ctx->stream>>>(
+      num_cls, begin, end, d_masks, d_labels, d_out, d_diff);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_masked_f1_micro(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                                    const uint8_t* d_masks, const float* d_preds,
+                                    const uint8_t* d_labels, float* h_result, int64_t* h_counts) {
+  GAIB_CHECK(ctx && d_preds && d_labels && h_result, "gaib_masked_f1_micro: NULL argument");
+  GAIB_CHECK(begin >= 0 && end >= begin && num_cls > 0, "gaib_masked_f1_micro: bad range");
+  *h_result = 0.f;
+  unsigned long long c[3] = {0, 0, 0};
+  if (end > begin) {
+    GAIB_TRY(gaib_ws_reserve(ctx, sizeof(c)));
+    GAIB_HIP(hipMemsetAsync(ctx->ws, 0, sizeof(c), ctx->stream));
+    unsigned grid = stream_grid((end - begin) * num_cls, 256);
+    f1_counts_kernel<<<grid, 256, 0, ctx->stream>>>(num_cls, begin, end, d_masks, d_preds, d_labels,
+                                                    (unsigned long long*)ctx->ws);
+    GAIB_LAUNCH_CHECK();
+    GAIB_HIP(hipMemcpyAsync(c, ctx->ws, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  const double tp = (double)c[0], fp = (double)c[1], fn = (double)c[2];
+  const double prec = tp + fp > 0 ? tp / (tp + fp) : 0.;
+  const double rec = tp + fn > 0 ? tp / (tp + fn) : 0.;
+  *h_result = (float)(rec + prec > 0. ? 2. * (rec * prec) / (rec + prec) : 0.);
+  if (h_counts) {
+    h_counts[0] = (int64_t)c[0];
+    h_counts[1] = (int64_t)c[1];
+    h_counts[2] = (int64_t)c[2];
+  }
   return GAIB_OK;
 }
 

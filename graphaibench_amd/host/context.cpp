@@ -41,8 +41,10 @@ void gpu_context::sync() { check(gaib_sync(get()), "gaib_sync"); }
 static bool overlap_enabled() {
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("GAIB_NO_OVERLAP");
-    on = (e && atoi(e) != 0) ? 0 : 1;
+    // opt-in: on MI355X the aggregation already saturates HBM and the wave slots, so running the
+    // weight-gradient GEMM next to it measured no gain; kept for narrower graphs
+    const char* e = getenv("GAIB_OVERLAP");
+    on = (e && atoi(e) != 0) ? 1 : 0;
   }
   return on == 1;
 }

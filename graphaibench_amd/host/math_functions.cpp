@@ -69,6 +69,21 @@ void d_softmax_cross_entropy_gpu(int len, int begin, int end, const mask_t* mask
   OpTimer t(OP_LOSS);
   GAIB_OR_DIE(gaib_d_softmax_xent(C(), len, begin, end, masks, labels, out_data, diff));
 }
+void sigmoid_cross_entropy_gpu(int len, int begin, int end, const float_t* in_data, const mask_t* masks,
+                               const label_t* labels, float_t* loss, float_t* out_data) {
+  GAIB_OR_DIE(gaib_sigmoid_xent(C(), len, begin, end, in_data, masks, labels, loss, out_data));
+}
+void d_sigmoid_cross_entropy_gpu(int len, int begin, int end, const mask_t* masks, const label_t* labels,
+                                 const float_t* out_data, float_t* diff) {
+  GAIB_OR_DIE(gaib_d_sigmoid_xent(C(), len, begin, end, masks, labels, out_data, diff));
+}
+// micro F1 over the masked range (math_functions.cu:1040-1044 -> masked_f1_score_gpu)
+float masked_accuracy_multi(int begin, int end, int, int num_classes, mask_t* masks, float* preds,
+                            label_t* ground_truth) {
+  float r = 0.f;
+  GAIB_OR_DIE(gaib_masked_f1_micro(C(), begin, end, num_classes, masks, preds, ground_truth, &r, NULL));
+  return r;
+}
 acc_t masked_avg_loss_gpu(int begin, int end, int, mask_t* masks, float_t* loss) {
   float r = 0.f;
   GAIB_OR_DIE(gaib_masked_avg_loss(C(), begin, end, masks, loss, &r));

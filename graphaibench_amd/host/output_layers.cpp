@@ -42,19 +42,15 @@ acc_t softmax_loss_layer::get_prediction_loss(size_t begin, size_t end, size_t c
   return masked_avg_loss_gpu(begin, end, count, masks, d_losses);
 }
 
-static void sigmoid_unsupported() {
-  fprintf(stderr, "sigmoid (multi-label) loss is not supported by the MI355X backend yet\n");
-  exit(EXIT_FAILURE);
+// multi-label head (sigmoid_loss_layer.cpp:4-55): labels are [num_samples x num_cls] 0/1 bytes
+void sigmoid_loss_layer::forward(size_t begin, size_t end, mask_t* masks) {
+  sigmoid_cross_entropy_gpu(num_cls, begin, end, feat_in, masks, labels, d_losses, feat_out);
 }
-void sigmoid_loss_layer::forward(size_t, size_t, mask_t*) { sigmoid_unsupported(); }
-void sigmoid_loss_layer::backward(size_t, size_t, mask_t*, float*) { sigmoid_unsupported(); }
-acc_t sigmoid_loss_layer::get_prediction_loss(size_t, size_t, size_t, mask_t*) {
-  sigmoid_unsupported();
-  return 0;
+void sigmoid_loss_layer::backward(size_t begin, size_t end, mask_t* masks, float* grad_out) {
+  d_sigmoid_cross_entropy_gpu(num_cls, begin, end, masks, labels, feat_out, grad_out);
 }
-float masked_accuracy_multi(int, int, int, int, mask_t*, float*, label_t*) {
-  sigmoid_unsupported();
-  return 0;
+acc_t sigmoid_loss_layer::get_prediction_loss(size_t begin, size_t end, size_t count, mask_t* masks) {
+  return masked_avg_loss_gpu(begin, end, count, masks, d_losses);
 }
 
 // ---- row_block ------------------------------------------------------------------------------------

@@ -67,17 +67,16 @@ struct Trainer {
   std::vector<gconv_t> layers;
   l2norm_layer* l2 = nullptr;
   dense_layer* dense = nullptr;
-  softmax_loss_layer* loss = nullptr;
+  loss_layer* loss = nullptr;  // softmax (single label) or sigmoid (multi label, argv[4])
+  bool is_sigmoid = false;
+  size_t label_width = 1;      // bytes of label per vertex: 1, or num_cls for multi-hot rows
 
   void parse(int argc, char** argv) {
     dataset = argv[1];
     num_epochs = atoi(argv[2]);
     num_threads = atoi(argv[3]);
     omp_set_num_threads(num_threads);
-    if (std::string(argv[4]) == "sigmoid") {
-      std::cerr << "sigmoid (multi-label) loss is not supported by the MI355X backend yet\n";
-      exit(1);
-    }
+    is_sigmoid = std::string(argv[4]) == "sigmoid";  // train.cpp:20
     if (argc >= 6) dim_hid = atoi(argv[5]);
     if (argc >= 7) score_drop = atof(argv[6]);
     if (argc >= 8) feat_drop = atof(argv[7]);
@@ -103,7 +102,8 @@ struct Trainer {
     reader.bin_read_graph(graph);
     num_samples = graph->size();
     dim_init = reader.bin_read_features(feats);
-    num_cls = reader.bin_read_vlabels(labels, true);
+    num_cls = reader.bin_read_vlabels(labels, !is_sigmoid);
+    label_width = is_sigmoid ? (size_t)num_cls : 1;
     if (ARCH != gnn_arch::SAGE) graph->add_selfloop();  // net.cpp:96
     graph->degree_counting();
     std::cout << "num_threads = " << num_threads << ", num_vertices = " << num_samples
@@ -123,8 +123,8 @@ struct Trainer {
     // transfer_data_to_device (net.cpp:206-227)
     float_malloc_device64((size_t)num_samples * dim_init, d_features);
     GAIB_OR_DIE(gaib_memcpy_h2d(gpu_context::get(), d_features, feats.data(), sizeof(float) * feats.size()));
-    uint8_malloc_device(num_samples, d_labels);
-    copy_uint8_device(num_samples, labels.data(), d_labels);
+    uint8_malloc_device(num_samples * label_width, d_labels);
+    copy_uint8_device(num_samples * label_width, labels.data(), d_labels);
     copy_masks_device(num_samples, mtrain.data(), d_masks_train);
     copy_masks_device(num_samples, mval.data(), d_masks_val);
     copy_masks_device(num_samples, mtest.data(), d_masks_test);
@@ -155,7 +155,7 @@ struct Trainer {
       for (auto& g : subgs) g = new Graph(true);
       subg_masks.resize((size_t)num_samples * num_subgraphs);
       float_malloc_device64((size_t)subg_size * dim_init, d_feats_subg);
-      uint8_malloc_device(subg_size, d_labels_subg);
+      uint8_malloc_device(subg_size * label_width, d_labels_subg);
     }
   }
 
@@ -186,16 +186,18 @@ struct Trainer {
     // features / labels of the kept vertices, in subgraph order
     const mask_t* mk = &subg_masks[(size_t)sg_id * num_samples];
     std::vector<float> f((size_t)subg_nv * dim_init);
-    std::vector<label_t> lab(subg_nv);
+    std::vector<label_t> lab((size_t)subg_nv * label_width);
     size_t k = 0;
     for (int v = 0; v < num_samples; v++)
       if (mk[v] == 1) {
         std::copy(&feats_host[(size_t)v * dim_init], &feats_host[(size_t)(v + 1) * dim_init], &f[k * dim_init]);
-        lab[k++] = labels_host[v];
+        std::copy(&labels_host[(size_t)v * label_width], &labels_host[(size_t)(v + 1) * label_width],
+                  &lab[k * label_width]);
+        k++;
       }
     assert((int)k == subg_nv);
     GAIB_OR_DIE(gaib_memcpy_h2d(gpu_context::get(), d_feats_subg, f.data(), sizeof(float) * f.size()));
-    copy_uint8_device(subg_nv, lab.data(), d_labels_subg);
+    copy_uint8_device(subg_nv * label_width, lab.data(), d_labels_subg);
     layers[0].set_feat_in(d_feats_subg);
     loss->set_labels_ptr(d_labels_subg);
   }
@@ -230,7 +232,8 @@ struct Trainer {
     if (use_l2norm) l2 = new l2norm_layer(nv, dim_hid);
     if (use_dense) dense = new dense_layer(nv, dim_hid, num_cls, lrate);
     layers[0].set_feat_in(d_features);
-    loss = new softmax_loss_layer(nv, num_cls, d_labels);
+    if (is_sigmoid) loss = new sigmoid_loss_layer(nv, num_cls, d_labels);
+    else loss = new softmax_loss_layer(nv, num_cls, d_labels);
   }
 
   void set_phase(net_phase p) {
@@ -249,17 +252,22 @@ struct Trainer {
     }
   }
 
+  // net.cpp:495-500: micro F1 on the sigmoid outputs, or argmax accuracy on the logits
+  acc_t accuracy(size_t begin, size_t end, size_t count, mask_t* masks, label_t* labels) {
+    if (is_sigmoid) return masked_accuracy_multi(begin, end, count, num_cls, masks, loss->get_feat_out(), labels);
+    return masked_accuracy_single(begin, end, count, num_cls, masks, loss->get_feat_in(), labels);
+  }
+
   acc_t forward_prop(acc_t& loss_value) {
     forward_layers();
     if (subg_size > 0) {  // every vertex of the subgraph is a training vertex (net.cpp:478-488)
       loss->forward(0, subg_nv, NULL);
       loss_value = loss->get_prediction_loss(0, subg_nv, subg_nv, NULL);
-      return masked_accuracy_single(0, subg_nv, subg_nv, num_cls, NULL, loss->get_feat_in(), d_labels_subg);
+      return accuracy(0, subg_nv, subg_nv, NULL, d_labels_subg);
     }
     loss->forward(train_begin, train_end, d_masks_train);
     loss_value = loss->get_prediction_loss(train_begin, train_end, train_count, d_masks_train);
-    return masked_accuracy_single(train_begin, train_end, train_count, num_cls, d_masks_train, loss->get_feat_in(),
-                                  d_labels);
+    return accuracy(train_begin, train_end, train_count, d_masks_train, d_labels);
   }
 
   void backward_prop() {
@@ -282,9 +290,11 @@ struct Trainer {
     set_phase(net_phase::TEST);
     if (subg_size > 0 || inductive) use_full_graph();
     forward_layers();
-    if (type == "test")
-      return masked_accuracy_single(test_begin, test_end, test_count, num_cls, d_masks_test, loss->get_feat_in(), d_labels);
-    return masked_accuracy_single(val_begin, val_end, val_count, num_cls, d_masks_val, loss->get_feat_in(), d_labels);
+    const bool test = type == "test";
+    const size_t b = test ? test_begin : val_begin, e = test ? test_end : val_end, c = test ? test_count : val_count;
+    mask_t* m = test ? d_masks_test : d_masks_val;
+    if (is_sigmoid) loss->forward(b, e, m);  // the F1 reads the sigmoid outputs (net.cpp:569-572)
+    return accuracy(b, e, c, m, d_labels);
   }
 
   void train() {

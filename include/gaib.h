@@ -212,6 +212,19 @@ int gaib_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
 int gaib_d_softmax_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
                         const uint8_t* d_masks, const uint8_t* d_labels, const float* d_out,
                         float* d_diff);
+/* multi-label head: sigmoid + cross entropy with [n x num_cls] 0/1 labels, its gradient, and the micro F1
+ * that masked_accuracy_multi returns (src/layers/sigmoid_loss_layer.cpp:4-33, sigmoid_loss_layer.cu:4-17,
+ * math_functions.cpp:517-521,553-559,580-621; math_functions.cu:583-637,944-1044).  Vertices of the range that
+ * the mask excludes get loss 0; h_counts (optional) receives tp, fp, fn. */
+int gaib_sigmoid_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                      const float* d_in, const uint8_t* d_masks, const uint8_t* d_labels,
+                      float* d_loss, float* d_out);
+int gaib_d_sigmoid_xent(gaib_ctx* ctx, int num_cls, int64_t begin, int64_t end,
+                        const uint8_t* d_masks, const uint8_t* d_labels,
+                        const float* d_out, float* d_diff);
+int gaib_masked_f1_micro(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                         const uint8_t* d_masks, const float* d_preds, const uint8_t* d_labels,
+                         float* h_result, int64_t* h_counts);
 int gaib_masked_avg_loss(gaib_ctx* ctx, int64_t begin, int64_t end, const uint8_t* d_masks,
                          const float* d_loss, float* h_result); /* syncs */
 int gaib_masked_accuracy_single(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,

@@ -11,7 +11,7 @@ class gpu_context {
   static gaib_ctx* get();                        // lazily created
   static void set(int device, void* hip_stream); // explicit (multi-GPU launchers, tests)
   static void sync();                            // CudaTest() equivalent
-  // side stream for independent work (gaib_side_begin/end/wait); GAIB_NO_OVERLAP=1 turns all three into no-ops
+  // side stream for independent work (gaib_side_begin/end/wait); no-ops unless GAIB_OVERLAP=1
   static void side_begin();
   static void side_end();
   static void side_wait();

@@ -4,7 +4,7 @@
 //   dense_layer      fully connected hid -> classes; backward() also applies its own Adam step
 //   loss_layer       logits / probabilities / per-vertex loss buffers + the virtual loss interface
 //   softmax_loss_layer   single-label: softmax + cross entropy, gradient (p - onehot) / (end - begin)
-//   sigmoid_loss_layer   multi-label: declared so drivers link; using it reports and exits
+//   sigmoid_loss_layer   multi-label: sigmoid + cross entropy on [n x num_cls] 0/1 labels
 // Class names and public methods are the ones the reference's drivers call (net.cpp:421-615;
 // reference declarations: include/gnn/loss_layer.h, include/layers/{l2norm,dense,softmax_loss,
 // sigmoid_loss}_layer.h).  The per-class headers of the same names just include this file.

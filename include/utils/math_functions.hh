@@ -28,6 +28,12 @@ void softmax_cross_entropy_gpu(int len, int begin, int end, const float_t* in_da
                                float_t* out_data);
 void d_softmax_cross_entropy_gpu(int len, int begin, int end, const mask_t* masks,
                                  const label_t* labels, const float_t* out_data, float_t* diff);
+// multi-label head (reference math_functions.hh:115-121)
+void sigmoid_cross_entropy_gpu(int len, int begin, int end, const float_t* in_data,
+                               const mask_t* masks, const label_t* labels, float_t* loss,
+                               float_t* out_data);
+void d_sigmoid_cross_entropy_gpu(int len, int begin, int end, const mask_t* masks,
+                                 const label_t* labels, const float_t* out_data, float_t* diff);
 acc_t masked_avg_loss_gpu(int begin, int end, int count, mask_t* masks, float_t* loss);
 float masked_accuracy_multi(int begin, int end, int count, int num_classes, mask_t* masks, float* preds,
                             label_t* ground_truth);

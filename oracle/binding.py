@@ -36,6 +36,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(str(LIB))
         _lib.orc_masked_avg_loss.restype = C.c_float
         _lib.orc_masked_accuracy_single.restype = C.c_float
+        _lib.orc_masked_f1_micro.restype = C.c_float
     return _lib
 
 
@@ -302,6 +303,39 @@ def softmax_xent_bwd(probs, labels, begin, end, masks=None):
     lib().orc_softmax_xent_bwd(C.c_int(probs.shape[1]), C.c_int64(begin), C.c_int64(end), _p(m), _p(labels),
                                _p(probs), _p(grad))
     return grad
+
+
+def sigmoid_xent_fwd(logits, labels, begin, end, masks=None):
+    """labels: [n x C] 0/1 bytes -> (sigmoid(logits), per-vertex loss)"""
+    logits = _f(logits)
+    labels = np.ascontiguousarray(labels, np.uint8)
+    assert labels.shape == logits.shape
+    probs = np.zeros_like(logits)
+    losses = np.zeros(logits.shape[0], np.float32)
+    m = np.ascontiguousarray(masks, np.uint8) if masks is not None else None
+    lib().orc_sigmoid_xent_fwd(C.c_int(logits.shape[1]), C.c_int64(begin), C.c_int64(end), _p(m), _p(labels),
+                               _p(logits), _p(probs), _p(losses))
+    return probs, losses
+
+
+def sigmoid_xent_bwd(probs, labels, begin, end, masks=None):
+    probs = _f(probs)
+    labels = np.ascontiguousarray(labels, np.uint8)
+    grad = np.zeros_like(probs)
+    m = np.ascontiguousarray(masks, np.uint8) if masks is not None else None
+    lib().orc_sigmoid_xent_bwd(C.c_int(probs.shape[1]), C.c_int64(begin), C.c_int64(end), _p(m), _p(labels),
+                               _p(probs), _p(grad))
+    return grad
+
+
+def masked_f1_micro(preds, labels, begin, end, masks=None, return_counts=False):
+    preds = _f(preds)
+    labels = np.ascontiguousarray(labels, np.uint8)
+    m = np.ascontiguousarray(masks, np.uint8) if masks is not None else None
+    counts = np.zeros(3, np.int64)
+    f1 = float(lib().orc_masked_f1_micro(C.c_int64(begin), C.c_int64(end), C.c_int(preds.shape[1]), _p(m),
+                                         _p(preds), _p(labels), _p(counts)))
+    return (f1, counts) if return_counts else f1
 
 
 def masked_avg_loss(losses, begin, end, masks=None) -> float:

@@ -621,6 +621,60 @@ void orc_softmax_xent_bwd(int num_cls, int64_t begin, int64_t end, const uint8_t
     }
   }
 }
+/* ------------------------------------------------------------------------- */
+/* sigmoid (multi-label) loss  src/layers/sigmoid_loss_layer.cpp:4-33         */
+/* labels are [n x num_cls] 0/1 bytes (reader.cpp:354-378)                    */
+/* ------------------------------------------------------------------------- */
+/* forward :4-17 with sigmoid math_functions.cpp:517-521 and
+ * sigmoid_cross_entropy :553-559 (the double-typed literals make the inner sums double) */
+void orc_sigmoid_xent_fwd(int num_cls, int64_t begin, int64_t end, const uint8_t* masks,
+                          const uint8_t* labels, const float* feat_in, float* feat_out,
+                          float* losses) {
+#pragma omp parallel for
+  for (int64_t i = begin; i < end; i++) {
+    if (masks == NULL || masks[i] == 1) {
+      const int64_t idx = (int64_t)num_cls * i;
+      const float* p = &feat_in[idx];
+      const uint8_t* y = &labels[idx];
+      for (int j = 0; j < num_cls; j++) feat_out[idx + j] = (float)(1. / (1. + expf(-p[j])));
+      float loss = 0.0f;
+      for (int j = 0; j < num_cls; j++)
+        loss -= p[j] * ((float)y[j] - (p[j] >= 0.)) -
+                logf((float)(1. + expf((float)(p[j] - 2. * p[j] * (p[j] >= 0.)))));
+      losses[i] = loss;
+    }
+  }
+}
+/* backward :19-33 : (sigmoid - label) / (end - begin), float division */
+void orc_sigmoid_xent_bwd(int num_cls, int64_t begin, int64_t end, const uint8_t* masks,
+                          const uint8_t* labels, const float* feat_out, float* grad_out) {
+#pragma omp parallel for
+  for (int64_t i = begin; i < end; i++) {
+    if (masks == NULL || masks[i] == 1) {
+      const int64_t idx = (int64_t)num_cls * i;
+      for (int j = 0; j < num_cls; j++)
+        grad_out[idx + j] = (feat_out[idx + j] - (float)labels[idx + j]) / (float)(uint64_t)(end - begin);
+    }
+  }
+}
+/* masked_f1_score math_functions.cpp:580-621 -> f1_micro (what masked_accuracy_multi returns);
+ * counts[0..2] receive the accumulated tp / fp / fn when not NULL */
+float orc_masked_f1_micro(int64_t begin, int64_t end, int num_classes, const uint8_t* masks,
+                          const float* pred, const uint8_t* truth, int64_t* counts) {
+  int64_t tp = 0, fp = 0, fn = 0;
+  for (int col = 0; col < num_classes; col++)
+    for (int64_t row = begin; row < end; row++)
+      if (masks == NULL || masks[row] == 1) {
+        const int64_t idx = row * num_classes + col;
+        if (truth[idx] == 1 && pred[idx] > 0.5) tp++;
+        else if (truth[idx] == 0 && pred[idx] > 0.5) fp++;
+        else if (truth[idx] == 1 && pred[idx] <= 0.5) fn++;
+      }
+  if (counts) { counts[0] = tp; counts[1] = fp; counts[2] = fn; }
+  const double prec = tp + fp > 0 ? (double)tp / (double)(tp + fp) : 0.;
+  const double rec = tp + fn > 0 ? (double)tp / (double)(tp + fn) : 0.;
+  return (float)(rec + prec > 0. ? 2. * (rec * prec) / (rec + prec) : 0.);
+}
 /* get_prediction_loss :39-55 (sequential here: the reference's omp reduction order is
  * unspecified) */
 float orc_masked_avg_loss(int64_t begin, int64_t end, const uint8_t* masks, const float* losses) {

@@ -51,7 +51,7 @@ class OracleModel:
             self.Wd = orc.init_glorot(H, C, 1)
             self.dense_opt = orc.Adam(lr)
 
-    def epoch(self, x, labels, begin, end, masks):
+    def epoch(self, x, labels, begin, end, masks, sigmoid=False):
         acts = [x]
         for l in self.layers:
             acts.append(l.forward(acts[-1]))
@@ -60,10 +60,15 @@ class OracleModel:
             logits = orc.matmul(z, self.Wd)
         else:
             logits = acts[-1]
-        probs, lv = orc.softmax_xent_fwd(logits, labels, begin, end, masks)
+        if sigmoid:  # labels: [n x C] multi-hot rows
+            probs, lv = orc.sigmoid_xent_fwd(logits, labels, begin, end, masks)
+            acc = orc.masked_f1_micro(probs, labels, begin, end, masks)
+            g = orc.sigmoid_xent_bwd(probs, labels, begin, end, masks)
+        else:
+            probs, lv = orc.softmax_xent_fwd(logits, labels, begin, end, masks)
+            acc = orc.masked_accuracy_single(logits, labels, begin, end, masks)
+            g = orc.softmax_xent_bwd(probs, labels, begin, end, masks)
         loss = orc.masked_avg_loss(lv, begin, end, masks)
-        acc = orc.masked_accuracy_single(logits, labels, begin, end, masks)
-        g = orc.softmax_xent_bwd(probs, labels, begin, end, masks)
         if self.arch == "gat":
             dWd = orc.matmul(z, g, True, False)
             gz = orc.matmul(g, self.Wd, False, True)
@@ -110,6 +115,33 @@ def test_driver_loss_curve_tracks_oracle(tmp_path, arch, layers):
         assert abs(gl - wl) < 2e-3, (got, want)
         assert abs(ga - wa) < 0.02, (got, want)
     assert want[-1][0] < want[0][0]  # it learns
+
+
+@pytest.mark.parametrize("arch", ["gcn", "sage"])
+def test_driver_sigmoid_loss_tracks_oracle(tmp_path, arch):
+    """argv[4] = sigmoid: multi-hot labels (reader), sigmoid loss layer, micro-F1 as the accuracy"""
+    root, x, labels, splits = make_dataset(tmp_path)
+    tb, te = splits[0], splits[1]
+    epochs, hid, lr = 6, 16, 0.01
+    exe = ROOT / "bin" / f"gpu_train_{arch}"
+    cmd = [str(exe), "cora", str(epochs), "2", "sigmoid", str(hid), "0", "0", str(lr), "2", "0", "4", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, DATASET_PATH=root), timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "multi-class (multi-hot) labels" in r.stdout
+    got = [(float(a), float(b)) for a, b in re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", r.stdout)]
+    assert len(got) == epochs and "val_acc" in r.stdout and "Test accuracy:" in r.stdout
+    rp = np.fromfile(GOLD / "cora" / "graph.vertex.bin", np.int64)
+    ci = np.fromfile(GOLD / "cora" / "graph.edge.bin", np.uint32)
+    masks = np.zeros(2708, np.uint8)
+    masks[tb:te] = 1
+    hot = np.zeros((2708, 7), np.uint8)
+    hot[np.arange(2708), labels] = 1
+    m = OracleModel(arch, rp, ci, x.shape[1], hid, 7, 2, lr)
+    want = [m.epoch(x, hot, tb, te, masks, sigmoid=True) for _ in range(epochs)]
+    for (gl, ga), (wl, wa) in zip(got, want):
+        assert abs(gl - wl) < 2e-3, (got, want)
+        assert abs(ga - wa) < 0.02, (got, want)
+    assert want[-1][0] < want[0][0]
 
 
 def test_driver_error_paths(tmp_path):

@@ -439,6 +439,38 @@ def test_softmax_xent_and_metrics(ctx, ncls):
     assert abs(ctx.masked_accuracy_single(ld, lab, begin, end, md) - acc_w) < 1e-6
 
 
+@pytest.mark.parametrize("ncls", [1, 41, 121])
+def test_sigmoid_xent_and_micro_f1(ctx, ncls):
+    """multi-label head: gaib_sigmoid_xent / gaib_d_sigmoid_xent / gaib_masked_f1_micro"""
+    n, begin, end = 3000, 140, 2140
+    logits = feat(n, ncls, 1) * 4
+    labels = (np.random.default_rng(2).random((n, ncls)) < 0.25).astype(np.uint8)
+    masks = np.zeros(n, np.uint8)
+    masks[begin:end:3] = 1
+    for mk in (masks, None):
+        probs_w, loss_w = orc.sigmoid_xent_fwd(logits, labels, begin, end, mk)
+        grad_w = orc.sigmoid_xent_bwd(probs_w, labels, begin, end, mk)
+        ld, lab = dev(logits), dev(labels)
+        md = dev(mk) if mk is not None else None
+        probs = torch.zeros(n, ncls, device="cuda")
+        loss = torch.full((n,), 7.0, device="cuda")
+        ctx.sigmoid_xent(ld, lab, loss, probs, begin, end, md)
+        assert rel_err(probs.cpu().numpy(), probs_w) < TOL
+        got_loss = loss.cpu().numpy()
+        assert rel_err(got_loss[begin:end], loss_w[begin:end]) < TOL  # masked-out rows of the range read 0
+        assert np.all(got_loss[:begin] == 7.0) and np.all(got_loss[end:] == 7.0)
+        grad = torch.zeros(n, ncls, device="cuda")
+        ctx.d_sigmoid_xent(probs, lab, grad, begin, end, md)
+        assert rel_err(grad.cpu().numpy(), grad_w) < TOL
+        f1_w, cnt_w = orc.masked_f1_micro(probs.cpu().numpy(), labels, begin, end, mk, return_counts=True)
+        f1, cnt = ctx.masked_f1_micro(probs, lab, begin, end, md)
+        assert cnt == tuple(int(c) for c in cnt_w)  # integer counts: exact
+        assert abs(f1 - f1_w) < 1e-6
+    f1, cnt = ctx.masked_f1_micro(torch.zeros(8, ncls, device="cuda"), torch.zeros(8, ncls, dtype=torch.uint8,
+                                                                                 device="cuda"), 2, 2)
+    assert f1 == 0.0 and cnt == (0, 0, 0)
+
+
 def test_l2norm(ctx):
     x = feat(500, 64, 1)
     x[3] = 0  # clamps at 1e-12

@@ -264,3 +264,35 @@ def test_citeseer_plumbing_cpu_path():
         opt.update("w0", l0.W_grad, l0.W)
         opt.update("w1", l1.W_grad, l1.W)
     assert losses[-1] < losses[0] - 0.05 and all(np.isfinite(losses))
+
+
+def test_sigmoid_loss_and_micro_f1_against_torch_and_sklearn():
+    """multi-label head (sigmoid_loss_layer.cpp, math_functions.cpp:517-621): the loss is the stable
+    BCE-with-logits, the gradient divides by (end-begin), masked_accuracy_multi is sklearn's micro F1."""
+    import torch
+    from sklearn.metrics import f1_score
+    rng = np.random.default_rng(11)
+    n, c, begin, end = 400, 37, 30, 330
+    logits = (rng.standard_normal((n, c)) * 4).astype(np.float32)
+    logits[5, :3] = [0.0, 60.0, -60.0]
+    labels = (rng.random((n, c)) < 0.3).astype(np.uint8)
+    masks = np.zeros(n, np.uint8)
+    masks[begin:end:2] = 1  # a strided mask inside the range
+    probs, losses = orc.sigmoid_xent_fwd(logits, labels, begin, end, masks)
+    sel = masks == 1
+    want_p = torch.sigmoid(torch.from_numpy(logits).double()).numpy()
+    want_l = torch.nn.functional.binary_cross_entropy_with_logits(
+        torch.from_numpy(logits).double(), torch.from_numpy(labels).double(), reduction="none").sum(1).numpy()
+    assert np.abs(probs[sel] - want_p[sel]).max() < 1e-6
+    assert np.abs(losses[sel] - want_l[sel]).max() < 1e-3 * max(1.0, np.abs(want_l).max() * 1e-2)
+    assert np.all(probs[~sel] == 0) and np.all(losses[~sel] == 0)  # rows outside the mask are not touched
+    g = orc.sigmoid_xent_bwd(probs, labels, begin, end, masks)
+    assert np.abs(g[sel] - (probs[sel] - labels[sel]) / np.float32(end - begin)).max() < 1e-7
+    assert np.all(g[~sel] == 0)
+    f1, (tp, fp, fn) = orc.masked_f1_micro(probs, labels, begin, end, masks, return_counts=True)
+    hot = (probs[sel] > 0.5).astype(np.uint8)
+    assert (tp, fp, fn) == (int((hot & labels[sel]).sum()), int((hot & (1 - labels[sel])).sum()),
+                            int(((1 - hot) & labels[sel]).sum()))
+    assert abs(f1 - f1_score(labels[sel], hot, average="micro")) < 1e-6
+    # nothing predicted and nothing true -> 0 (the reference's guards, not NaN)
+    assert orc.masked_f1_micro(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.uint8), 0, 4) == 0.0
