@@ -59,7 +59,7 @@ def build_hip(force: bool = False) -> Path:
     LIB.mkdir(exist_ok=True)
     out = LIB / "libgaib_hip.so"
     hipcc = _hipcc()
-    headers = [CSRC / "common.h", INCLUDE / "gaib.h"]
+    headers = [CSRC / "common.h", CSRC / "spmm_core.h", INCLUDE / "gaib.h"]
     objs = []
     for src in HIP_SOURCES:
         s = CSRC / src

@@ -53,6 +53,7 @@ SIGNATURES = {
     "gaib_spmm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_spmm_acc": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_spmm_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i]),
+    "gaib_spmm_gemm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i]),
     "gaib_spmm_mh": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i]),
     "gaib_gat_scores_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -196,6 +197,17 @@ class Context:
         flags = (1 if accumulate else 0) | (2 if relu else 0)
         _check(self.lib.gaib_spmm_mh(self.h, g.h, kind, _ptr(edge_w), heads, x.shape[1], _ptr(x), _ptr(out), flags),
                "gaib_spmm")
+        return out
+
+    def spmm_gemm(self, g: "Graph", kind: int, x, agg, W, out, transW: bool = False, relu: bool = False,
+                  agg_scratch: bool = False, edge_w=None):
+        """agg = A.x ; out = act(agg . op(W)) (gaib_spmm_gemm: fused on the matrix cores when the shape allows)"""
+        assert x.is_contiguous() and agg.is_contiguous() and W.is_contiguous() and out.is_contiguous()
+        len_in, len_out = x.shape[1], out.shape[1]
+        assert tuple(W.shape) == ((len_out, len_in) if transW else (len_in, len_out))
+        flags = (2 if relu else 0) | (4 if agg_scratch else 0)
+        _check(self.lib.gaib_spmm_gemm(self.h, g.h, kind, _ptr(edge_w), len_in, _ptr(x), _ptr(agg), _ptr(W),
+                                       1 if transW else 0, len_out, _ptr(out), flags), "gaib_spmm_gemm")
         return out
 
     def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2, heads: int = 1):

@@ -7,6 +7,7 @@
 // kernels that use it; only the feature rows are gathered.
 #include <algorithm>
 #include <functional>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -387,6 +388,15 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
     heavy_rows_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, thr,
                                                                    g->heavy_rows, cnt, nullptr);
     GAIB_LAUNCH_CHECK();
+    // the atomic append leaves the list in arrival order: sort it (ascending row id) so that it can
+    // be searched (fused aggregation) and the launch order is the same on every run
+    std::vector<uint32_t> rows((size_t)g->n_heavy);
+    GAIB_HIP(hipMemcpyAsync(rows.data(), g->heavy_rows, sizeof(uint32_t) * rows.size(),
+                            hipMemcpyDeviceToHost, ctx->stream));
+    GAIB_HIP(hipStreamSynchronize(ctx->stream));
+    std::sort(rows.begin(), rows.end());
+    GAIB_HIP(hipMemcpyAsync(g->heavy_rows, rows.data(), sizeof(uint32_t) * rows.size(),
+                            hipMemcpyHostToDevice, ctx->stream));
     GAIB_HIP(hipStreamSynchronize(ctx->stream));
   }
   GAIB_HIP(hipFree(cnt));

@@ -24,236 +24,9 @@
 //     meet in LDS and are added in wave order -> deterministic).
 //   * blockIdx -> row-block mapping is XCD-aware: consecutive row blocks land on the same
 //     XCD (blocks b and b+8 share one), so neighbouring rows share that XCD's 4 MB L2.
-#include "common.h"
+#include "spmm_core.h"
 
 namespace {
-
-struct SpmmArgs {
-  const int64_t* rowptr;
-  const uint32_t* col;
-  const float* rw;      // per-row weight    (WMODE 0)
-  const float* ew;      // per-edge weight   (WMODE 1, 2)
-  const uint32_t* rev;  // reverse edge ids  (WMODE 2: w = ew[rev[e]])
-  const float* in;
-  float* out;
-  int64_t ld;  // row stride of in/out (floats)
-  int ncols;   // columns handled by this launch (<= 64*VEC*CT), starting at in/out
-  int n_rows;
-  int heavy_thr;
-  const uint32_t* row_list;  // heavy kernel only
-  int nblocks;               // light kernels: logical number of row blocks
-  int per_xcd;               // ceil(nblocks/8) when swizzled, 0 otherwise
-  uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)
-  const uint32_t* col_flagged;  // GM 3: column ids with the top bit set on cold columns
-  int accumulate;            // out += instead of out = (second half of a split aggregation)
-  int relu;                  // clamp at 0 on store (activation fused)
-  int heads;                 // WMODE 3/4: edge weights are [ne][heads]; head of a column = col / dh
-  int dh;
-};
-
-template <int VEC> struct VecT;
-template <> struct VecT<1> { typedef float type; };
-template <> struct VecT<2> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct VecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
-
-template <int VEC>
-__device__ __forceinline__ typename VecT<VEC>::type vzero() {
-  typename VecT<VEC>::type z;
-  if constexpr (VEC == 1) z = 0.f;
-  else
-    for (int i = 0; i < VEC; ++i) z[i] = 0.f;
-  return z;
-}
-template <int VEC>
-__device__ __forceinline__ typename VecT<VEC>::type vrelu(typename VecT<VEC>::type v) {
-  if constexpr (VEC == 1) return v > 0.f ? v : 0.f;
-  else {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-    return v;
-  }
-}
-template <int VEC>
-__device__ __forceinline__ void vacc(typename VecT<VEC>::type& acc, float w,
-                                     const typename VecT<VEC>::type& x) {
-  // separate multiply and add: the reference does scale() then vadd_cpu()
-  // (math_functions.cpp:336-356, 266-283); this file is built with -ffp-contract=off.
-  if constexpr (VEC == 1) {
-    float t = w * x;
-    acc = acc + t;
-  } else {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float t = w * x[i];
-      acc[i] = acc[i] + t;
-    }
-  }
-}
-
-__device__ __forceinline__ int logical_block(const SpmmArgs& a) {
-  int b = blockIdx.x;
-  if (a.per_xcd > 0) b = (b & 7) * a.per_xcd + (b >> 3);
-  return b;
-}
-
-// WMODE: 0 per-row weight | 1 per-edge | 2 per-edge through the reverse permutation |
-//        3 per-(edge, head) | 4 per-(edge, head) through the reverse permutation
-template <int WMODE>
-__device__ __forceinline__ float load_edge_w(const SpmmArgs& a, int64_t e, int head = 0) {
-  if constexpr (WMODE == 1) return a.ew[e];
-  else if constexpr (WMODE == 2) return a.ew[a.rev[e]];
-  else if constexpr (WMODE == 3) return a.ew[e * a.heads + head];
-  else if constexpr (WMODE == 4) return a.ew[(int64_t)a.rev[e] * a.heads + head];
-  else return 0.f;
-}
-
-typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-
-// One feature-row gather.  BUF: `buffer_load_dwordxN v, voff, s[rsrc], soff offen` -- the row
-// base (col * row bytes) is a 32-bit SGPR offset against one descriptor for the whole table,
-// so a gather in flight costs only its VEC destination VGPRs (no 64-bit VGPR address pair).
-// Needs the table to be < 4 GB; larger tables use 64-bit global_load addresses.
-// GM (gather mode): 0 = 64-bit global_load; 1 = buffer_load, default cache policy; 2 = buffer_load nt
-// (streaming) for every gather; 3 = buffer_load, nt only for COLD columns (top bit of the column id
-// set by gaib_graph_ensure_hot_flags), so the few thousand hub rows keep their place in the 4 MB L2.
-template <int VEC, int GM>
-struct RowGather {
-  static constexpr bool BUF = GM != 0;
-  __amdgpu_buffer_rsrc_t rsrc;
-  const char* inb;
-  int64_t ldb;
-  __device__ __forceinline__ RowGather(const SpmmArgs& a) {
-    inb = reinterpret_cast<const char*>(a.in);
-    ldb = a.ld * 4;
-    if constexpr (BUF) rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-  }
-  __device__ __forceinline__ typename VecT<VEC>::type load(uint32_t cj, uint32_t voff) const {
-    typedef typename VecT<VEC>::type vec_t;
-    if constexpr (GM == 3) {
-      const uint32_t c = cj & 0x7fffffffu;
-      if (cj & 0x80000000u) return load_buf<2>(c, voff);  // wave-uniform branch (cj is scalar)
-      return load_buf<0>(c, voff);
-    } else if constexpr (GM == 2) {
-      return load_buf<2>(cj, voff);
-    } else if constexpr (GM == 1) {
-      return load_buf<0>(cj, voff);
-    } else {
-      const char* rowp = inb + (int64_t)cj * ldb;  // scalar base
-      return *reinterpret_cast<const vec_t*>(rowp + voff);
-    }
-  }
-  template <int AUX>
-  __device__ __forceinline__ typename VecT<VEC>::type load_buf(uint32_t cj, uint32_t voff) const {
-    typedef typename VecT<VEC>::type vec_t;
-    const int soff = (int)(cj * (uint32_t)ldb);
-    if constexpr (VEC == 1) {
-      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, AUX));
-    } else if constexpr (VEC == 2) {
-      u2_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, soff, AUX);
-      vec_t v;
-      v[0] = __uint_as_float(r[0]);
-      v[1] = __uint_as_float(r[1]);
-      return v;
-    } else {
-      u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, AUX);
-      vec_t v;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
-      return v;
-    }
-  }
-};
-
-// ---- the shared per-wave edge loop: accumulate edges [eb, ee) of one row -------------
-// chunk_stride: distance between this wave's 64-edge chunks (64 for a whole row, 64*W when
-// W waves share a row).
-// voff[ct] is the lane's BYTE offset inside a feature row; lanes whose columns fall outside
-// the row are pointed at offset 0, so every gather is unconditional (a predicated load makes
-// hipcc branch on EXEC and drain vmcnt after each one); what they accumulate is never stored.
-template <int VEC, int CT, int WMODE, int U, int BUF>
-__device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int64_t eb, int64_t ee,
-                                                int64_t chunk_stride, float roww,
-                                                const uint32_t (&voff)[CT],
-                                                typename VecT<VEC>::type (&acc)[CT]) {
-  typedef typename VecT<VEC>::type vec_t;
-  const RowGather<VEC, BUF> gather(a);
-  vec_t x[U][CT];  // gather destinations; the tail's piece p lives in x[p .. 2p-1]
-  constexpr bool MH = WMODE >= 3;  // multi-head: every lane fetches the weight of ITS head itself
-  int hd[CT];
-  float wv[MH ? U : 1][CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct) hd[ct] = MH ? (int)((voff[ct] >> 2) / (uint32_t)a.dh) : 0;
-  for (int64_t base = eb; base < ee; base += chunk_stride) {
-    const int64_t rem = ee - base;
-    const int n = rem < 64 ? (int)rem : 64;  // wave-uniform
-    uint32_t c = 0;
-    float w = 0.f;
-    if (lane < n) {
-      c = a.col[base + lane];
-      if constexpr (WMODE == 1 || WMODE == 2) w = load_edge_w<WMODE>(a, base + lane);
-    }
-    int j = 0;
-    // full batches: U independent row gathers in flight, straight-line code
-    for (; j + U <= n; j += U) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j + u);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          x[u][ct] = gather.load(cj, voff[ct]);
-          if constexpr (MH) wv[u][ct] = load_edge_w<WMODE>(a, base + j + u, hd[ct]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, j + u));
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          float wsel = wj;
-          if constexpr (MH) wsel = wv[u][ct];
-          vacc<VEC>(acc[ct], wsel, x[u][ct]);
-        }
-      }
-    }
-    // tail: r = n - j < U edges, done as power-of-two pieces U/2, U/4, .., 1 (CSR order kept):
-    // first every piece's gathers are issued, then every piece is accumulated.
-    const int r = n - j;
-    if (r > 0) {
-      int jj = j;
-#pragma unroll
-      for (int p = U / 2; p >= 1; p >>= 1) {
-        if (r & p) {
-#pragma unroll
-          for (int u = 0; u < p; ++u) {
-            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, jj + u);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) x[p + u][ct] = gather.load(cj, voff[ct]);
-          }
-          jj += p;
-        }
-      }
-      jj = j;
-#pragma unroll
-      for (int p = U / 2; p >= 1; p >>= 1) {
-        if (r & p) {
-#pragma unroll
-          for (int u = 0; u < p; ++u) {
-            const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, jj + u));
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              // (the tail is short: its per-head weights are fetched at the point of use)
-              float wh = wj;
-              if constexpr (MH) wh = load_edge_w<WMODE>(a, base + jj + u, hd[ct]);
-              vacc<VEC>(acc[ct], wh, x[p + u][ct]);
-            }
-          }
-          jj += p;
-        }
-      }
-    }
-  }
-}
 
 // ---- light rows, one wave per row ------------------------------------------------------
 template <int VEC, int CT, int WMODE, int U, int BUF>
@@ -315,11 +88,12 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a
   for (int ct = 0; ct < CT; ++ct)
     *reinterpret_cast<vec_t*>(&red[wave * W + (ct * 64 + lane) * VEC]) = acc[ct];
   __syncthreads();
+  float* orow = a.out + (a.compact ? (int64_t)blockIdx.x : (int64_t)row) * a.ld;
   for (int c = threadIdx.x; c < a.ncols; c += HEAVY_WAVES * 64) {
-    float s = a.accumulate ? a.out[(int64_t)row * a.ld + c] + red[c] : red[c];
+    float s = a.accumulate ? orow[c] + red[c] : red[c];
 #pragma unroll
     for (int w = 1; w < HEAVY_WAVES; ++w) s = s + red[w * W + c];
-    a.out[(int64_t)row * a.ld + c] = (a.relu && !(s > 0.f)) ? 0.f : s;
+    orow[c] = (a.relu && !(s > 0.f)) ? 0.f : s;
   }
 }
 
@@ -511,21 +285,166 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
   return GAIB_OK;
 }
 
+// ---- aggregation fused with the dense product ------------------------------------------
+//   agg[i,:] = sum_e w_e * in[col_e,:]          (the aggregation above, one wave per row)
+//   y[i,:]   = act(agg[i,:] . op(W))             on the matrix cores, inside the same wave
+// A wave owns FUSE_ROWS = 16 consecutive rows.  Each finished row is parked in the wave's LDS
+// tile [16][K+4]; after the 16th the tile is read back in MFMA operand order (lane l:
+// A[i = l&15][k = (l>>4)*K/4 + s] for step s) and multiplied with op(W) held k-contiguous as
+// wt[n][k] (read through L2, 64 KB), v_mfma_f32_16x16x4_f32, one 16x16 output tile at a time.
+// The dense product costs ~6 % of the wave's time and no extra pass over the [N x K] matrix:
+// the separate GEMM (read agg, write y) disappears, only the y store remains.
+// Heavy rows are aggregated first by spmm_heavy_kernel into a compact scratch and picked up here.
+struct FuseArgs {
+  const float* wt;            // [n_out][K]
+  float* y;                   // [n_rows][ldy]
+  int64_t ldy;
+  int n_out;                  // multiple of 16
+  int relu;
+  const float* heavy_agg;     // [n_heavy][K]
+  const uint32_t* heavy_rows; // ascending
+  int n_heavy;
+};
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int FUSE_ROWS = 16;
+
+template <int VEC, int WMODE, int U, int GM>
+__global__ __launch_bounds__(256) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
+  typedef typename VecT<VEC>::type vec_t;
+  constexpr int K = 64 * VEC;
+  constexpr int KQ = K / 4;
+  constexpr int LDT = K + 4;
+  extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lb = logical_block(a);
+  if (lb >= a.nblocks) return;
+  const int row0 = __builtin_amdgcn_readfirstlane((lb * 4 + wave) * FUSE_ROWS);
+  if (row0 >= a.n_rows) return;  // (no workgroup barrier below: waves are independent)
+  float* tile = fuse_lds + wave * (FUSE_ROWS * LDT);
+  // the 17 row boundaries of this wave's rows, lane r holds rowptr[row0 + r]
+  int rpi = row0 + (lane < FUSE_ROWS ? lane : FUSE_ROWS);
+  if (rpi > a.n_rows) rpi = a.n_rows;
+  const int64_t rp = a.rowptr[rpi];
+  const int rp_lo = (int)(uint32_t)(rp & 0xffffffffll), rp_hi = (int)(rp >> 32);
+  const uint32_t voff[1] = {(uint32_t)(lane * VEC * 4)};
+  for (int r = 0; r < FUSE_ROWS; ++r) {
+    const int row = row0 + r;
+    vec_t acc[1];
+    acc[0] = vzero<VEC>();
+    if (row < a.n_rows) {
+      const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, r) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane(rp_lo, r);
+      const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, r + 1) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane(rp_lo, r + 1);
+      if (e1 - e0 > (int64_t)a.heavy_thr) {
+        int lo = 0, hi = f.n_heavy - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (f.heavy_rows[mid] < (uint32_t)row) lo = mid + 1;
+          else hi = mid;
+        }
+        acc[0] = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * K + lane * VEC);
+      } else {
+        const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
+        wave_accumulate<VEC, 1, WMODE, U, GM>(a, lane, e0, e1, 64, roww, voff, acc);
+      }
+      if (a.out) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc[0];
+    }
+    *reinterpret_cast<vec_t*>(tile + r * LDT + lane * VEC) = acc[0];
+  }
+  // LDS operations of one wave complete in order; the fence keeps the compiler from moving the
+  // fragment reads above the row stores
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int i = lane & 15, kq = lane >> 4;
+  float af[KQ];
+  {
+    const float* trow = tile + i * LDT + kq * KQ;
+#pragma unroll
+    for (int s4 = 0; s4 < KQ / 4; ++s4) {
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(trow + 4 * s4);
+      af[4 * s4 + 0] = t[0];
+      af[4 * s4 + 1] = t[1];
+      af[4 * s4 + 2] = t[2];
+      af[4 * s4 + 3] = t[3];
+    }
+  }
+  const float* wbase = f.wt + (int64_t)i * K + kq * KQ;
+  for (int n0 = 0; n0 < f.n_out; n0 += 16) {
+    const float* wr = wbase + (int64_t)n0 * K;
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < KQ / 4; ++s4) {
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(wr + 4 * s4);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 0], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 1], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 2], b[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 3], b[3], c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
+      if (row < a.n_rows) {
+        float v = c[reg];
+        if (f.relu) v = v > 0.f ? v : 0.f;
+        f.y[(int64_t)row * f.ldy + n0 + i] = v;
+      }
+    }
+  }
+}
+
+__global__ void transpose_small_kernel(int rows, int cols, const float* in, float* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // out[c][r] = in[r][c]
+  if (t < rows * cols) {
+    const int c = t / rows, r = t % rows;
+    out[(int64_t)c * rows + r] = in[(int64_t)r * cols + c];
+  }
+}
+
+template <int VEC, int WMODE>
+int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, float* heavy_scratch) {
+  constexpr int U = 16;
+  constexpr int K = 64 * VEC;
+  const bool buf = a.in_bytes != 0 && ctx->spmm_addr_mode != 2;
+  if (g->n_heavy > 0) {
+    SpmmArgs h = a;
+    h.row_list = g->heavy_rows;
+    h.out = heavy_scratch;
+    h.ld = K;  // NB the gather stride is a.ld too: K == len on this path
+    h.compact = 1;
+    h.relu = 0;
+    h.accumulate = 0;
+    size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
+    ProfScope ps(ctx, "spmm_heavy");
+    if (buf) spmm_heavy_kernel<VEC, 1, WMODE, U, 1><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
+    else spmm_heavy_kernel<VEC, 1, WMODE, U, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
+    GAIB_LAUNCH_CHECK();
+  }
+  a.nblocks = (int)cdiv64(a.n_rows, 4 * FUSE_ROWS);
+  unsigned grid = (unsigned)a.nblocks;
+  if (ctx->spmm_xcd_swizzle && a.nblocks >= 64) {
+    a.per_xcd = (int)cdiv64(a.nblocks, 8);
+    grid = (unsigned)a.per_xcd * 8u;
+  }
+  const size_t lds = sizeof(float) * 4 * FUSE_ROWS * (K + 4);
+  if (grid > 0) {
+    ProfScope ps(ctx, "spmm_gemm_fused");
+    if (buf) spmm_gemm_kernel<VEC, WMODE, U, 1><<<dim3(grid), 256, lds, ctx->stream>>>(a, f);
+    else spmm_gemm_kernel<VEC, WMODE, U, 0><<<dim3(grid), 256, lds, ctx->stream>>>(a, f);
+    GAIB_LAUNCH_CHECK();
+  }
+  return GAIB_OK;
+}
+
 }  // namespace
 
-static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
-                     const float* d_in, float* d_out, int flags, int heads = 1) {
-  const int accumulate = (flags & GAIB_ACCUMULATE) ? 1 : 0;
-  GAIB_CHECK(ctx && g, "gaib_spmm: NULL ctx/graph");
-  GAIB_CHECK(len >= 0, "gaib_spmm: len < 0");
-  GAIB_CHECK(ctx->device == g->device, "gaib_spmm: graph lives on device %d, ctx on %d", g->device,
-             ctx->device);
-  if (len == 0 || g->nv == 0) return GAIB_OK;
-  GAIB_CHECK(d_in && d_out, "gaib_spmm: NULL feature pointer");
-  GAIB_CHECK(d_in != d_out, "gaib_spmm: in and out must not alias");
+// fills the launch arguments shared by every aggregation path; *wmode = kernel weight mode
+static int spmm_setup(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
+                      const float* d_in, float* d_out, int flags, int heads, SpmmArgs* pa, int* wmode) {
+  SpmmArgs& a = *pa;
   GAIB_HIP(hipSetDevice(ctx->device));
   GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
-  SpmmArgs a;
   a.rowptr = g->rowptr;
   a.col = g->colidx;
   a.rw = nullptr;
@@ -540,11 +459,12 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
   a.row_list = nullptr;
   a.nblocks = 0;
   a.per_xcd = 0;
-  a.accumulate = accumulate;
+  a.accumulate = (flags & GAIB_ACCUMULATE) ? 1 : 0;
   a.relu = (flags & GAIB_RELU) ? 1 : 0;
   a.heads = heads;
   a.dh = heads > 0 ? len / heads : len;
   a.col_flagged = nullptr;
+  a.compact = 0;
   if (ctx->spmm_gather_mode == 3 && g->nc == g->nv && !g->col_vdata) {
     GAIB_TRY(gaib_graph_ensure_hot_flags(ctx, g, len));
     a.col_flagged = g->colidx_flagged;
@@ -556,30 +476,54 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
     case GAIB_W_GCN:
       GAIB_TRY(gaib_graph_ensure_w_gcn(ctx, g));
       a.ew = g->w_gcn;
-      return dispatch_vec<1>(ctx, g, a, len);
+      *wmode = 1;
+      return GAIB_OK;
     case GAIB_W_MEAN:
       GAIB_TRY(gaib_graph_ensure_inv_deg(ctx, g));
       a.rw = g->inv_deg;
-      return dispatch_vec<0>(ctx, g, a, len);
+      *wmode = 0;
+      return GAIB_OK;
     case GAIB_W_MEAN_T:
       GAIB_TRY(gaib_graph_ensure_w_mean_t(ctx, g));
       a.ew = g->w_mean_t;
-      return dispatch_vec<1>(ctx, g, a, len);
+      *wmode = 1;
+      return GAIB_OK;
     case GAIB_W_EDGE:
       GAIB_CHECK(d_edge_w || g->ne == 0, "gaib_spmm: GAIB_W_EDGE needs d_edge_w");
       a.ew = d_edge_w;
-      if (heads > 1) return dispatch_vec<3>(ctx, g, a, len);
-      return dispatch_vec<1>(ctx, g, a, len);
+      *wmode = heads > 1 ? 3 : 1;
+      return GAIB_OK;
     case GAIB_W_EDGE_T:
       GAIB_CHECK(d_edge_w || g->ne == 0, "gaib_spmm: GAIB_W_EDGE_T needs d_edge_w");
       GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
       a.ew = d_edge_w;
       a.rev = g->rev;
-      if (heads > 1) return dispatch_vec<4>(ctx, g, a, len);
-      return dispatch_vec<2>(ctx, g, a, len);
+      *wmode = heads > 1 ? 4 : 2;
+      return GAIB_OK;
     default:
       gaib_set_error("gaib_spmm: unknown weight_kind %d", weight_kind);
       return GAIB_ERR_INVALID;
+  }
+}
+
+static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
+                     const float* d_in, float* d_out, int flags, int heads = 1) {
+  GAIB_CHECK(ctx && g, "gaib_spmm: NULL ctx/graph");
+  GAIB_CHECK(len >= 0, "gaib_spmm: len < 0");
+  GAIB_CHECK(ctx->device == g->device, "gaib_spmm: graph lives on device %d, ctx on %d", g->device,
+             ctx->device);
+  if (len == 0 || g->nv == 0) return GAIB_OK;
+  GAIB_CHECK(d_in && d_out, "gaib_spmm: NULL feature pointer");
+  GAIB_CHECK(d_in != d_out, "gaib_spmm: in and out must not alias");
+  SpmmArgs a;
+  int wmode = 0;
+  GAIB_TRY(spmm_setup(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags, heads, &a, &wmode));
+  switch (wmode) {
+    case 0: return dispatch_vec<0>(ctx, g, a, len);
+    case 1: return dispatch_vec<1>(ctx, g, a, len);
+    case 2: return dispatch_vec<2>(ctx, g, a, len);
+    case 3: return dispatch_vec<3>(ctx, g, a, len);
+    default: return dispatch_vec<4>(ctx, g, a, len);
   }
 }
 
@@ -596,6 +540,61 @@ extern "C" int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, cons
 extern "C" int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
                             int len, const float* d_in, float* d_out, int flags) {
   return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags);
+}
+
+// agg = A.in ; out = act(agg . op(W)).  Fused on the matrix cores when the shape allows, otherwise
+// gaib_spmm followed by gaib_sgemm (same results up to summation order).
+extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                              int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
+                              int len_out, float* d_out, int flags) {
+  GAIB_CHECK(ctx && g, "gaib_spmm_gemm: NULL ctx/graph");
+  GAIB_CHECK(len_in >= 0 && len_out >= 0, "gaib_spmm_gemm: negative length");
+  GAIB_CHECK(ctx->device == g->device, "gaib_spmm_gemm: graph lives on device %d, ctx on %d", g->device,
+             ctx->device);
+  GAIB_CHECK((flags & ~(GAIB_RELU | GAIB_AGG_SCRATCH)) == 0, "gaib_spmm_gemm: unsupported flags %d", flags);
+  if (g->nv == 0 || len_out == 0) return GAIB_OK;
+  GAIB_CHECK(d_in && d_agg && d_W && d_out, "gaib_spmm_gemm: NULL pointer");
+  GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out, "gaib_spmm_gemm: buffers must not alias");
+  const uintptr_t al = (uintptr_t)d_in | (uintptr_t)d_agg | (uintptr_t)d_W;
+  const bool fusable = ctx->spmm_fuse != 0 && (len_in == 64 || len_in == 128) && len_out % 16 == 0 &&
+                       len_out <= 1024 && (al & 15) == 0 && g->ne > 0 &&
+                       (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
+                        weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
+  if (!fusable) {
+    GAIB_TRY(spmm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, 0));
+    return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_agg, d_W, (flags & GAIB_RELU) ? GAIB_RELU : 0,
+                         d_out);
+  }
+  SpmmArgs a;
+  int wmode = 0;
+  GAIB_TRY(spmm_setup(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, 0, 1, &a, &wmode));
+  if (flags & GAIB_AGG_SCRATCH) a.out = nullptr;  // the caller does not read agg: skip its store
+  // scratch: op(W) k-contiguous + the heavy rows' aggregates
+  const size_t wt_bytes = sizeof(float) * (size_t)len_out * len_in;
+  const size_t hv_bytes = sizeof(float) * (size_t)g->n_heavy * len_in;
+  GAIB_TRY(gaib_ws_reserve(ctx, wt_bytes + hv_bytes + 256));
+  float* wt = (float*)ctx->ws;
+  float* hv = (float*)((char*)ctx->ws + ((wt_bytes + 255) & ~(size_t)255));
+  FuseArgs f;
+  if (transW) {
+    f.wt = d_W;  // W is [len_out x len_in]: already k-contiguous
+  } else {
+    const int n = len_in * len_out;
+    transpose_small_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(len_in, len_out, d_W, wt);
+    GAIB_LAUNCH_CHECK();
+    f.wt = wt;
+  }
+  f.y = d_out;
+  f.ldy = len_out;
+  f.n_out = len_out;
+  f.relu = (flags & GAIB_RELU) ? 1 : 0;
+  f.heavy_agg = hv;
+  f.heavy_rows = g->heavy_rows;
+  f.n_heavy = (int)g->n_heavy;
+  if (len_in == 64) {
+    return wmode == 0 ? launch_fused<1, 0>(ctx, g, a, f, hv) : launch_fused<1, 1>(ctx, g, a, f, hv);
+  }
+  return wmode == 0 ? launch_fused<2, 0>(ctx, g, a, f, hv) : launch_fused<2, 1>(ctx, g, a, f, hv);
 }
 
 extern "C" int gaib_spmm_mh(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,

@@ -1,0 +1,236 @@
+// spmm_core.h -- device code shared by the aggregation kernels (spmm.hip, spmm_gemm.hip):
+// launch arguments, the feature-row gather and the per-wave edge loop.
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct SpmmArgs {
+  const int64_t* rowptr;
+  const uint32_t* col;
+  const float* rw;      // per-row weight    (WMODE 0)
+  const float* ew;      // per-edge weight   (WMODE 1, 2)
+  const uint32_t* rev;  // reverse edge ids  (WMODE 2: w = ew[rev[e]])
+  const float* in;
+  float* out;
+  int64_t ld;  // row stride of in/out (floats)
+  int ncols;   // columns handled by this launch (<= 64*VEC*CT), starting at in/out
+  int n_rows;
+  int heavy_thr;
+  const uint32_t* row_list;  // heavy kernel only
+  int nblocks;               // light kernels: logical number of row blocks
+  int per_xcd;               // ceil(nblocks/8) when swizzled, 0 otherwise
+  uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)
+  const uint32_t* col_flagged;  // GM 3: column ids with the top bit set on cold columns
+  int accumulate;            // out += instead of out = (second half of a split aggregation)
+  int relu;                  // clamp at 0 on store (activation fused)
+  int heads;                 // WMODE 3/4: edge weights are [ne][heads]; head of a column = col / dh
+  int dh;
+  int compact;               // heavy kernel: row k of row_list is written to out row k (fused path's scratch)
+};
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type vzero() {
+  typename VecT<VEC>::type z;
+  if constexpr (VEC == 1) z = 0.f;
+  else
+    for (int i = 0; i < VEC; ++i) z[i] = 0.f;
+  return z;
+}
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type vrelu(typename VecT<VEC>::type v) {
+  if constexpr (VEC == 1) return v > 0.f ? v : 0.f;
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    return v;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void vacc(typename VecT<VEC>::type& acc, float w,
+                                     const typename VecT<VEC>::type& x) {
+  // separate multiply and add: the reference does scale() then vadd_cpu()
+  // (math_functions.cpp:336-356, 266-283); this file is built with -ffp-contract=off.
+  if constexpr (VEC == 1) {
+    float t = w * x;
+    acc = acc + t;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float t = w * x[i];
+      acc[i] = acc[i] + t;
+    }
+  }
+}
+
+__device__ __forceinline__ int logical_block(const SpmmArgs& a) {
+  int b = blockIdx.x;
+  if (a.per_xcd > 0) b = (b & 7) * a.per_xcd + (b >> 3);
+  return b;
+}
+
+// WMODE: 0 per-row weight | 1 per-edge | 2 per-edge through the reverse permutation |
+//        3 per-(edge, head) | 4 per-(edge, head) through the reverse permutation
+template <int WMODE>
+__device__ __forceinline__ float load_edge_w(const SpmmArgs& a, int64_t e, int head = 0) {
+  if constexpr (WMODE == 1) return a.ew[e];
+  else if constexpr (WMODE == 2) return a.ew[a.rev[e]];
+  else if constexpr (WMODE == 3) return a.ew[e * a.heads + head];
+  else if constexpr (WMODE == 4) return a.ew[(int64_t)a.rev[e] * a.heads + head];
+  else return 0.f;
+}
+
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+
+// One feature-row gather.  BUF: `buffer_load_dwordxN v, voff, s[rsrc], soff offen` -- the row
+// base (col * row bytes) is a 32-bit SGPR offset against one descriptor for the whole table,
+// so a gather in flight costs only its VEC destination VGPRs (no 64-bit VGPR address pair).
+// Needs the table to be < 4 GB; larger tables use 64-bit global_load addresses.
+// GM (gather mode): 0 = 64-bit global_load; 1 = buffer_load, default cache policy; 2 = buffer_load nt
+// (streaming) for every gather; 3 = buffer_load, nt only for COLD columns (top bit of the column id
+// set by gaib_graph_ensure_hot_flags), so the few thousand hub rows keep their place in the 4 MB L2.
+template <int VEC, int GM>
+struct RowGather {
+  static constexpr bool BUF = GM != 0;
+  __amdgpu_buffer_rsrc_t rsrc;
+  const char* inb;
+  int64_t ldb;
+  __device__ __forceinline__ RowGather(const SpmmArgs& a) {
+    inb = reinterpret_cast<const char*>(a.in);
+    ldb = a.ld * 4;
+    if constexpr (BUF) rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+  }
+  __device__ __forceinline__ typename VecT<VEC>::type load(uint32_t cj, uint32_t voff) const {
+    typedef typename VecT<VEC>::type vec_t;
+    if constexpr (GM == 3) {
+      const uint32_t c = cj & 0x7fffffffu;
+      if (cj & 0x80000000u) return load_buf<2>(c, voff);  // wave-uniform branch (cj is scalar)
+      return load_buf<0>(c, voff);
+    } else if constexpr (GM == 2) {
+      return load_buf<2>(cj, voff);
+    } else if constexpr (GM == 1) {
+      return load_buf<0>(cj, voff);
+    } else {
+      const char* rowp = inb + (int64_t)cj * ldb;  // scalar base
+      return *reinterpret_cast<const vec_t*>(rowp + voff);
+    }
+  }
+  template <int AUX>
+  __device__ __forceinline__ typename VecT<VEC>::type load_buf(uint32_t cj, uint32_t voff) const {
+    typedef typename VecT<VEC>::type vec_t;
+    const int soff = (int)(cj * (uint32_t)ldb);
+    if constexpr (VEC == 1) {
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, AUX));
+    } else if constexpr (VEC == 2) {
+      u2_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, soff, AUX);
+      vec_t v;
+      v[0] = __uint_as_float(r[0]);
+      v[1] = __uint_as_float(r[1]);
+      return v;
+    } else {
+      u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, AUX);
+      vec_t v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
+      return v;
+    }
+  }
+};
+
+// ---- the shared per-wave edge loop: accumulate edges [eb, ee) of one row -------------
+// chunk_stride: distance between this wave's 64-edge chunks (64 for a whole row, 64*W when
+// W waves share a row).
+// voff[ct] is the lane's BYTE offset inside a feature row; lanes whose columns fall outside
+// the row are pointed at offset 0, so every gather is unconditional (a predicated load makes
+// hipcc branch on EXEC and drain vmcnt after each one); what they accumulate is never stored.
+template <int VEC, int CT, int WMODE, int U, int BUF>
+__device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int64_t eb, int64_t ee,
+                                                int64_t chunk_stride, float roww,
+                                                const uint32_t (&voff)[CT],
+                                                typename VecT<VEC>::type (&acc)[CT]) {
+  typedef typename VecT<VEC>::type vec_t;
+  const RowGather<VEC, BUF> gather(a);
+  vec_t x[U][CT];  // gather destinations; the tail's piece p lives in x[p .. 2p-1]
+  constexpr bool MH = WMODE >= 3;  // multi-head: every lane fetches the weight of ITS head itself
+  int hd[CT];
+  float wv[MH ? U : 1][CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) hd[ct] = MH ? (int)((voff[ct] >> 2) / (uint32_t)a.dh) : 0;
+  for (int64_t base = eb; base < ee; base += chunk_stride) {
+    const int64_t rem = ee - base;
+    const int n = rem < 64 ? (int)rem : 64;  // wave-uniform
+    uint32_t c = 0;
+    float w = 0.f;
+    if (lane < n) {
+      c = a.col[base + lane];
+      if constexpr (WMODE == 1 || WMODE == 2) w = load_edge_w<WMODE>(a, base + lane);
+    }
+    int j = 0;
+    // full batches: U independent row gathers in flight, straight-line code
+    for (; j + U <= n; j += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j + u);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          x[u][ct] = gather.load(cj, voff[ct]);
+          if constexpr (MH) wv[u][ct] = load_edge_w<WMODE>(a, base + j + u, hd[ct]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, j + u));
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          float wsel = wj;
+          if constexpr (MH) wsel = wv[u][ct];
+          vacc<VEC>(acc[ct], wsel, x[u][ct]);
+        }
+      }
+    }
+    // tail: r = n - j < U edges, done as power-of-two pieces U/2, U/4, .., 1 (CSR order kept):
+    // first every piece's gathers are issued, then every piece is accumulated.
+    const int r = n - j;
+    if (r > 0) {
+      int jj = j;
+#pragma unroll
+      for (int p = U / 2; p >= 1; p >>= 1) {
+        if (r & p) {
+#pragma unroll
+          for (int u = 0; u < p; ++u) {
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, jj + u);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) x[p + u][ct] = gather.load(cj, voff[ct]);
+          }
+          jj += p;
+        }
+      }
+      jj = j;
+#pragma unroll
+      for (int p = U / 2; p >= 1; p >>= 1) {
+        if (r & p) {
+#pragma unroll
+          for (int u = 0; u < p; ++u) {
+            const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, jj + u));
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              // (the tail is short: its per-head weights are fetched at the point of use)
+              float wh = wj;
+              if constexpr (MH) wh = load_edge_w<WMODE>(a, base + jj + u, hd[ct]);
+              vacc<VEC>(acc[ct], wh, x[p + u][ct]);
+            }
+          }
+          jj += p;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace

@@ -141,6 +141,7 @@ int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_
  * the layers apply the activation right after the aggregation / GEMM, gcn_layer.cpp:27) */
 #define GAIB_ACCUMULATE 1
 #define GAIB_RELU 2
+#define GAIB_AGG_SCRATCH 4 /* gaib_spmm_gemm: d_agg is scratch, its contents after the call are unspecified */
 int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                  const float* d_in, float* d_out, int flags);
 /* multi-head attention weights: d_edge_w is [ne][heads]; column c uses head c / (len/heads).
@@ -185,6 +186,17 @@ int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const floa
 /* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):
  *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
 int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);
+
+/* ---- aggregation fused with the dense product: the `din <= dout` branch of the layers
+ * (gcn_layer.cpp:19-24, sage_layer.cpp:25-34): agg = A.in (gaib_spmm semantics, [nv x len_in]),
+ * out = act(agg . op(W)), op(W) = W [len_in x len_out] or, with transW, W^T for W [len_out x len_in]
+ * (the input-gradient product of backward).  For len_in in {64, 128} and len_out % 16 == 0 the product
+ * runs on the matrix cores inside the aggregating wave (no second pass over agg); other shapes run
+ * gaib_spmm + gaib_sgemm.  flags: GAIB_RELU, GAIB_AGG_SCRATCH.  d_agg must always be a valid
+ * [nv x len_in] buffer.  Option "spmm_fuse" = 0 forces the two-kernel path. */
+int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                   int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
+                   int len_out, float* d_out, int flags);
 
 /* ---- dense update: matmul -> sgemm_gpu -> cublasSgemm (math_functions.cu:321-343) --------
  * row-major C[M x N] = op(A)[M x K] . op(B)[K x N]  (+ C if accum).  fp32 MFMA. */

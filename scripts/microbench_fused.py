@@ -1,0 +1,46 @@
+"""A/B of gaib_spmm_gemm (aggregation fused with the dense product) against gaib_spmm + gaib_sgemm
+on the bench graph.  usage: python scripts/microbench_fused.py [scale]"""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from graphaibench_amd import capi, synth  # noqa: E402
+
+
+def timeit(fn, ctx, n=6):
+    fn()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    ctx.sync()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def main():
+    scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    ctx = capi.Context(0)
+    sg = synth.make("ogbn-products", seed=42, device="cuda", scale=scale)
+    g = ctx.graph(sg.rowptr, sg.colidx).add_selfloop()
+    n, D = g.nv, 128
+    x = torch.randn(n, D, device="cuda")
+    agg = torch.empty(n, D, device="cuda")
+    y = torch.empty(n, D, device="cuda")
+    W = torch.randn(D, D, device="cuda") * 0.1
+    print(f"nv={n} ne={g.ne}")
+    for fuse in (0, 1):
+        ctx.set_option("spmm_fuse", fuse)
+        for transW, relu, scratch in ((False, True, False), (True, False, True)):
+            t = timeit(lambda: ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y, transW=transW, relu=relu,
+                                             agg_scratch=scratch), ctx)
+            print(f"fuse={fuse} transW={transW} relu={relu} agg_scratch={scratch}: {t:.3f} ms")
+    ctx.set_option("spmm_fuse", 1)
+    t = timeit(lambda: ctx.spmm(g, capi.W_GCN, x, agg), ctx)
+    print(f"plain spmm: {t:.3f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -611,3 +611,50 @@ def test_side_section_overlaps_and_orders(ctx):
         ctx.side_begin()
     ctx.side_end()
     ctx.side_wait()
+
+
+@pytest.mark.parametrize("len_in,len_out,kind,transW,relu", [
+    (128, 128, "gcn", False, True),    # the headline layer's forward
+    (128, 128, "gcn", True, False),    # its input-gradient product
+    (64, 32, "mean", False, False),
+    (128, 48, "mean_t", True, True),
+    (64, 256, "edge", False, False),
+    (100, 40, "gcn", False, True),     # not fusable: two-kernel path
+    (128, 30, "mean", True, False),    # not fusable (len_out % 16)
+])
+def test_spmm_gemm_fused(ctx, len_in, len_out, kind, transW, relu):
+    """gaib_spmm_gemm == aggregate then matmul (+relu) of the oracle; heavy rows, ragged row count"""
+    rp, ci = random_graph(3001, 12, seed=len_in + len_out, power_law=True, hub_deg=1500)  # vertex 0 is heavy
+    g_o, g_d = make(ctx, rp, ci, selfloop=(kind == "gcn"))
+    n = g_o.nv
+    x = feat(n, len_in, 3)
+    W = (feat(len_out, len_in, 4) if transW else feat(len_in, len_out, 4)) * 0.2
+    ew = np.random.default_rng(5).random(g_o.ne).astype(np.float32)
+    if kind == "gcn":
+        agg_w, k = orc.gcn_aggregate(g_o, x), capi.W_GCN
+    elif kind == "mean":
+        agg_w, k = orc.sage_aggregate(g_o, x), capi.W_MEAN
+    elif kind == "mean_t":
+        agg_w, k = orc.sage_d_aggregate(g_o, x), capi.W_MEAN_T
+    else:
+        agg_w, k = orc.spmm_edge(g_o, ew, x), capi.W_EDGE
+    y_w = orc.matmul(agg_w, W, False, transW)
+    if relu:
+        y_w = np.maximum(y_w, 0)
+    for scratch in (False, True):
+        agg = torch.full((n, len_in), 3.0, device="cuda")
+        y = torch.full((n, len_out), -5.0, device="cuda")
+        ctx.spmm_gemm(g_d, k, dev(x), agg, dev(W), y, transW=transW, relu=relu, agg_scratch=scratch,
+                      edge_w=dev(ew) if kind == "edge" else None)
+        assert rel_err(y.cpu().numpy(), y_w) < TOL
+        if not scratch:
+            assert rel_err(agg.cpu().numpy(), agg_w) < TOL
+    # the fused and the two-kernel path agree
+    ctx.set_option("spmm_fuse", 0)
+    try:
+        y2 = torch.empty(n, len_out, device="cuda")
+        ctx.spmm_gemm(g_d, k, dev(x), agg, dev(W), y2, transW=transW, relu=relu,
+                      edge_w=dev(ew) if kind == "edge" else None)
+    finally:
+        ctx.set_option("spmm_fuse", 1)
+    assert rel_err(y2.cpu().numpy(), y.cpu().numpy()) < 1e-5
