@@ -24,6 +24,7 @@
 //     meet in LDS and are added in wave order -> deterministic).
 //   * blockIdx -> row-block mapping is XCD-aware: consecutive row blocks land on the same
 //     XCD (blocks b and b+8 share one), so neighbouring rows share that XCD's 4 MB L2.
+#include <algorithm>
 #include "spmm_core.h"
 
 namespace {
@@ -288,12 +289,14 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
 // ---- aggregation fused with the dense product ------------------------------------------
 //   agg[i,:] = sum_e w_e * in[col_e,:]          (the aggregation above, one wave per row)
 //   y[i,:]   = act(agg[i,:] . op(W))             on the matrix cores, inside the same wave
-// A wave owns FUSE_ROWS = 16 consecutive rows.  Each finished row is parked in the wave's LDS
-// tile [16][K+4]; after the 16th the tile is read back in MFMA operand order (lane l:
-// A[i = l&15][k = (l>>4)*K/4 + s] for step s) and multiplied with op(W) held k-contiguous as
-// wt[n][k] (read through L2, 64 KB), v_mfma_f32_16x16x4_f32, one 16x16 output tile at a time.
-// The dense product costs ~6 % of the wave's time and no extra pass over the [N x K] matrix:
-// the separate GEMM (read agg, write y) disappears, only the y store remains.
+// One persistent 1024-thread workgroup per CU.  op(W) is staged ONCE into LDS, k-contiguous
+// (wl[n][k]); after that the 16 waves never synchronise again.  A wave takes 16-row tiles off
+// a global counter; finished rows are parked eight at a time in the wave's LDS strip [8][K+4]
+// and read back in MFMA operand order (lane l: A[i = l&15][k = (l>>4)*K/4 + s] at step s), then
+// multiplied with op(W) from LDS: v_mfma_f32_16x16x4_f32, one 16x16 output tile at a time.
+// Why LDS and not L2 for op(W): the vector-memory path of a CU is in order, so a weight load
+// issued between gathers waits ~5 us behind them (measured: +1.5 ms per pass at products scale);
+// from LDS the dense product costs only the y store.
 // Heavy rows are aggregated first by spmm_heavy_kernel into a compact scratch and picked up here.
 struct FuseArgs {
   const float* wt;            // [n_out][K]
@@ -304,91 +307,108 @@ struct FuseArgs {
   const float* heavy_agg;     // [n_heavy][K]
   const uint32_t* heavy_rows; // ascending
   int n_heavy;
+  int* tile_counter;          // zeroed before the launch
+  int dbg;
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int FUSE_ROWS = 16;
+constexpr int FUSE_WAVES = 16;
 
 template <int VEC, int WMODE, int U, int GM>
-__global__ __launch_bounds__(256) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
+__global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int K = 64 * VEC;
   constexpr int KQ = K / 4;
   constexpr int LDT = K + 4;
+  constexpr int HALF = FUSE_ROWS / 2;
   extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int lb = logical_block(a);
-  if (lb >= a.nblocks) return;
-  const int row0 = __builtin_amdgcn_readfirstlane((lb * 4 + wave) * FUSE_ROWS);
-  if (row0 >= a.n_rows) return;  // (no workgroup barrier below: waves are independent)
-  float* tile = fuse_lds + wave * (FUSE_ROWS * LDT);
-  // the 17 row boundaries of this wave's rows, lane r holds rowptr[row0 + r]
-  int rpi = row0 + (lane < FUSE_ROWS ? lane : FUSE_ROWS);
-  if (rpi > a.n_rows) rpi = a.n_rows;
-  const int64_t rp = a.rowptr[rpi];
-  const int rp_lo = (int)(uint32_t)(rp & 0xffffffffll), rp_hi = (int)(rp >> 32);
-  const uint32_t voff[1] = {(uint32_t)(lane * VEC * 4)};
-  for (int r = 0; r < FUSE_ROWS; ++r) {
-    const int row = row0 + r;
-    vec_t acc[1];
-    acc[0] = vzero<VEC>();
-    if (row < a.n_rows) {
-      const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, r) << 32) |
-                         (uint32_t)__builtin_amdgcn_readlane(rp_lo, r);
-      const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, r + 1) << 32) |
-                         (uint32_t)__builtin_amdgcn_readlane(rp_lo, r + 1);
-      if (e1 - e0 > (int64_t)a.heavy_thr) {
-        int lo = 0, hi = f.n_heavy - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (f.heavy_rows[mid] < (uint32_t)row) lo = mid + 1;
-          else hi = mid;
-        }
-        acc[0] = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * K + lane * VEC);
-      } else {
-        const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
-        wave_accumulate<VEC, 1, WMODE, U, GM>(a, lane, e0, e1, 64, roww, voff, acc);
-      }
-      if (a.out) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc[0];
-    }
-    *reinterpret_cast<vec_t*>(tile + r * LDT + lane * VEC) = acc[0];
+  float* wl = fuse_lds;                                              // [n_out][LDT]
+  float* tile = fuse_lds + f.n_out * LDT + wave * (HALF * LDT);      // [HALF][LDT]
+  for (int t = threadIdx.x; t < f.n_out * (K / 4); t += FUSE_WAVES * 64) {
+    const int n = t / (K / 4), q = t % (K / 4);
+    *reinterpret_cast<f32x4_t*>(wl + n * LDT + 4 * q) = reinterpret_cast<const f32x4_t*>(f.wt)[t];
   }
-  // LDS operations of one wave complete in order; the fence keeps the compiler from moving the
-  // fragment reads above the row stores
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // the only workgroup barrier
   const int i = lane & 15, kq = lane >> 4;
-  float af[KQ];
-  {
-    const float* trow = tile + i * LDT + kq * KQ;
+  const uint32_t voff[1] = {(uint32_t)(lane * VEC * 4)};
+  const int ntiles = (a.n_rows + FUSE_ROWS - 1) / FUSE_ROWS;
+  for (;;) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(f.tile_counter, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= ntiles) break;
+    const int row0 = t * FUSE_ROWS;
+    // the 17 row boundaries of this tile, lane r holds rowptr[row0 + r]
+    int rpi = row0 + (lane < FUSE_ROWS ? lane : FUSE_ROWS);
+    if (rpi > a.n_rows) rpi = a.n_rows;
+    const int64_t rp = a.rowptr[rpi];
+    const int rp_lo = (int)(uint32_t)(rp & 0xffffffffll), rp_hi = (int)(rp >> 32);
+    float af[KQ];
 #pragma unroll
-    for (int s4 = 0; s4 < KQ / 4; ++s4) {
-      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(trow + 4 * s4);
-      af[4 * s4 + 0] = t[0];
-      af[4 * s4 + 1] = t[1];
-      af[4 * s4 + 2] = t[2];
-      af[4 * s4 + 3] = t[3];
+    for (int s = 0; s < KQ; ++s) af[s] = 0.f;
+    for (int h = 0; h < 2; ++h) {
+      for (int r = 0; r < HALF; ++r) {
+        const int rr = h * HALF + r;
+        const int row = row0 + rr;
+        vec_t acc[1];
+        acc[0] = vzero<VEC>();
+        if (row < a.n_rows) {
+          const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr);
+          const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr + 1) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr + 1);
+          if (e1 - e0 > (int64_t)a.heavy_thr) {
+            int lo = 0, hi = f.n_heavy - 1;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (f.heavy_rows[mid] < (uint32_t)row) lo = mid + 1;
+              else hi = mid;
+            }
+            acc[0] = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * K + lane * VEC);
+          } else {
+            const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
+            wave_accumulate<VEC, 1, WMODE, U, GM>(a, lane, e0, e1, 64, roww, voff, acc);
+          }
+          if (a.out) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc[0];
+        }
+        *reinterpret_cast<vec_t*>(tile + r * LDT + lane * VEC) = acc[0];
+      }
+      // LDS operations of one wave complete in order; the fences keep the compiler from moving
+      // the fragment reads above the row stores (and the next half's stores above the reads)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const bool mine = (i >> 3) == h;  // lanes whose A row sits in this half
+      const float* trow = tile + (i & 7) * LDT + kq * KQ;
+#pragma unroll
+      for (int s4 = 0; s4 < KQ / 4; ++s4) {
+        const f32x4_t tv = *reinterpret_cast<const f32x4_t*>(trow + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) af[4 * s4 + e] = mine ? tv[e] : af[4 * s4 + e];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-  }
-  const float* wbase = f.wt + (int64_t)i * K + kq * KQ;
-  for (int n0 = 0; n0 < f.n_out; n0 += 16) {
-    const float* wr = wbase + (int64_t)n0 * K;
-    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    const float* wbase = wl + i * LDT + kq * KQ;
+    for (int n0 = 0; n0 < f.n_out; n0 += 16) {
+      const float* wr = wbase + n0 * LDT;
+      f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s4 = 0; s4 < KQ / 4; ++s4) {
-      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(wr + 4 * s4);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 0], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 1], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 2], b[2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 3], b[3], c, 0, 0, 0);
-    }
+      for (int s4 = 0; s4 < KQ / 4; ++s4) {
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(wr + 4 * s4);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 3], b[3], c, 0, 0, 0);
+      }
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
-      if (row < a.n_rows) {
-        float v = c[reg];
-        if (f.relu) v = v > 0.f ? v : 0.f;
-        f.y[(int64_t)row * f.ldy + n0 + i] = v;
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
+        if (row < a.n_rows) {
+          float v = c[reg];
+          if (f.relu) v = v > 0.f ? v : 0.f;
+          f.y[(int64_t)row * f.ldy + n0 + i] = v;
+        }
       }
     }
   }
@@ -411,8 +431,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     SpmmArgs h = a;
     h.row_list = g->heavy_rows;
     h.out = heavy_scratch;
-    h.ld = K;  // NB the gather stride is a.ld too: K == len on this path
-    h.compact = 1;
+    h.compact = 1;  // (h.ld stays len == K: it is the gather stride too)
     h.relu = 0;
     h.accumulate = 0;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
@@ -421,19 +440,22 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     else spmm_heavy_kernel<VEC, 1, WMODE, U, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
   }
-  a.nblocks = (int)cdiv64(a.n_rows, 4 * FUSE_ROWS);
-  unsigned grid = (unsigned)a.nblocks;
-  if (ctx->spmm_xcd_swizzle && a.nblocks >= 64) {
-    a.per_xcd = (int)cdiv64(a.nblocks, 8);
-    grid = (unsigned)a.per_xcd * 8u;
+  const size_t lds = sizeof(float) * (size_t)(K + 4) * (f.n_out + FUSE_WAVES * FUSE_ROWS / 2);
+  const int64_t ntiles = cdiv64(a.n_rows, FUSE_ROWS);
+  const unsigned grid = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, FUSE_WAVES));
+  GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, sizeof(int), ctx->stream));
+  ProfScope ps(ctx, "spmm_gemm_fused");
+  // more than 64 KB of dynamic LDS has to be asked for
+  if (buf) {
+    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, U, 1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    spmm_gemm_kernel<VEC, WMODE, U, 1><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f);
+  } else {
+    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, U, 0>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    spmm_gemm_kernel<VEC, WMODE, U, 0><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f);
   }
-  const size_t lds = sizeof(float) * 4 * FUSE_ROWS * (K + 4);
-  if (grid > 0) {
-    ProfScope ps(ctx, "spmm_gemm_fused");
-    if (buf) spmm_gemm_kernel<VEC, WMODE, U, 1><<<dim3(grid), 256, lds, ctx->stream>>>(a, f);
-    else spmm_gemm_kernel<VEC, WMODE, U, 0><<<dim3(grid), 256, lds, ctx->stream>>>(a, f);
-    GAIB_LAUNCH_CHECK();
-  }
+  GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
 
@@ -556,8 +578,10 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   GAIB_CHECK(d_in && d_agg && d_W && d_out, "gaib_spmm_gemm: NULL pointer");
   GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out, "gaib_spmm_gemm: buffers must not alias");
   const uintptr_t al = (uintptr_t)d_in | (uintptr_t)d_agg | (uintptr_t)d_W;
+  // op(W) [len_out x (len_in+4)] + 16 strips [8 x (len_in+4)] must fit the CU's 160 KB of LDS
+  const size_t fuse_lds = sizeof(float) * (size_t)(len_in + 4) * ((size_t)len_out + FUSE_WAVES * FUSE_ROWS / 2);
   const bool fusable = ctx->spmm_fuse != 0 && (len_in == 64 || len_in == 128) && len_out % 16 == 0 &&
-                       len_out <= 1024 && (al & 15) == 0 && g->ne > 0 &&
+                       fuse_lds <= 160 * 1024 && (al & 15) == 0 && g->ne > 0 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
   if (!fusable) {
@@ -572,9 +596,10 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   // scratch: op(W) k-contiguous + the heavy rows' aggregates
   const size_t wt_bytes = sizeof(float) * (size_t)len_out * len_in;
   const size_t hv_bytes = sizeof(float) * (size_t)g->n_heavy * len_in;
-  GAIB_TRY(gaib_ws_reserve(ctx, wt_bytes + hv_bytes + 256));
+  GAIB_TRY(gaib_ws_reserve(ctx, wt_bytes + hv_bytes + 512));
   float* wt = (float*)ctx->ws;
   float* hv = (float*)((char*)ctx->ws + ((wt_bytes + 255) & ~(size_t)255));
+  int* counter = (int*)((char*)hv + ((hv_bytes + 255) & ~(size_t)255));
   FuseArgs f;
   if (transW) {
     f.wt = d_W;  // W is [len_out x len_in]: already k-contiguous
@@ -587,10 +612,12 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   f.y = d_out;
   f.ldy = len_out;
   f.n_out = len_out;
+  f.tile_counter = counter;
   f.relu = (flags & GAIB_RELU) ? 1 : 0;
   f.heavy_agg = hv;
   f.heavy_rows = g->heavy_rows;
   f.n_heavy = (int)g->n_heavy;
+  f.dbg = ctx->spmm_fuse;
   if (len_in == 64) {
     return wmode == 0 ? launch_fused<1, 0>(ctx, g, a, f, hv) : launch_fused<1, 1>(ctx, g, a, f, hv);
   }

@@ -27,7 +27,36 @@ static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* 
     GAIB_OR_DIE(gaib_spmm_ex(C(), g.halo_graph(), kind, NULL, len, halo, out, GAIB_ACCUMULATE | act));
 }
 
+void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float* in, float* agg, bool keep_agg,
+                                       const float* W, bool transW, int len_out, float* out, bool relu) {
+  OpTimer t(OP_SPARSEMM);
+  if (g.has_halo()) {
+    aggregate_rows(g, kind, len, in, agg);
+    if (relu) matmul_relu(g.size(), len_out, len, agg, W, out, false, transW);
+    else matmul(g.size(), len_out, len, agg, W, out, false, transW);
+    return;
+  }
+  const int flags = (relu ? GAIB_RELU : 0) | (keep_agg ? 0 : GAIB_AGG_SCRATCH);
+  GAIB_OR_DIE(gaib_spmm_gemm(C(), dev(g), kind, NULL, len, in, agg, W, transW ? 1 : 0, len_out, out, flags));
+}
+
 // ---- GCN ---------------------------------------------------------------------------------------
+void GCN_Aggregator::aggregate_matmul(int len, Graph& g, const float* in, float* agg, bool keep_agg,
+                                      const float* W, bool transW, int len_out, float* out, bool relu) {
+  aggregate_then_matmul(GAIB_W_GCN, len, g, in, agg, keep_agg, W, transW, len_out, out, relu);
+}
+void GCN_Aggregator::d_aggregate_matmul(int len, Graph& g, const float* grad_in, float* agg, bool keep_agg,
+                                        const float* W, bool transW, int len_out, float* out) {
+  aggregate_then_matmul(GAIB_W_GCN, len, g, grad_in, agg, keep_agg, W, transW, len_out, out, false);
+}
+void SAGE_Aggregator::aggregate_matmul(int len, Graph& g, const float* in, float* agg, bool keep_agg,
+                                       const float* W, bool transW, int len_out, float* out, bool relu) {
+  aggregate_then_matmul(GAIB_W_MEAN, len, g, in, agg, keep_agg, W, transW, len_out, out, relu);
+}
+void SAGE_Aggregator::d_aggregate_matmul(int len, Graph& g, const float* grad_in, float* agg, bool keep_agg,
+                                         const float* W, bool transW, int len_out, float* out) {
+  aggregate_then_matmul(GAIB_W_MEAN_T, len, g, grad_in, agg, keep_agg, W, transW, len_out, out, false);
+}
 void GCN_Aggregator::init(int l, int nv, int, float, float) {
   length = l;
   n = nv;

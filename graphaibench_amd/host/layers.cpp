@@ -95,10 +95,8 @@ void GCN_layer::forward(float* feat_out) {
     matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
     if (is_act) aggr.fuse_relu_once();
     aggr.aggregate(z, *graph, d_out_temp, feat_out);
-  } else {  // aggregate first; A.X is kept for the weight gradient
-    aggr.aggregate(y, *graph, in_data, d_in_temp1);
-    if (is_act) matmul_relu(x, z, y, d_in_temp1, d_W_neigh, feat_out);
-    else matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out);
+  } else {  // aggregate first; A.X is kept for the weight gradient.  One kernel: the product rides on the aggregation
+    aggr.aggregate_matmul(y, *graph, in_data, d_in_temp1, true, d_W_neigh, false, z, feat_out, is_act);
   }
 }
 
@@ -106,8 +104,8 @@ void GCN_layer::backward(float* feat_out, float* grad_out) {
   const size_t x = num_samples, y = dim_in, z = dim_out;
   if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);  // in place, mask = post-activation output
   if (y > z) {
-    aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
-    if (level_ > 0) matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);
+    if (level_ > 0) aggr.d_aggregate_matmul(z, *graph, grad_in, d_out_temp, true, d_W_neigh, true, y, grad_out);
+    else aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
     float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
@@ -117,8 +115,14 @@ void GCN_layer::backward(float* feat_out, float* grad_out) {
     matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
     if (level_ > 0) {
       gpu_context::side_end();
-      matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
-      aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+      if (y == z) {
+        // A.(g.W^T) == (A.g).W^T: at equal widths the aggregation goes first and carries the product
+        // (the reference order would cost a separate GEMM pass; same result up to summation order)
+        aggr.d_aggregate_matmul(z, *graph, grad_in, d_in_temp, false, d_W_neigh, true, y, grad_out);
+      } else {
+        matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
+        aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+      }
       gpu_context::side_wait();
     }
   }
@@ -141,43 +145,39 @@ void SAGE_layer::forward(float* feat_out) {
   if (y > z) {
     matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
     aggr.aggregate(z, *graph, d_out_temp, feat_out);
-    // + X.W_self, with the activation fused into this last product
-    if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
-    else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
-  } else {
-    // X.W_self goes first, on the side stream next to the aggregation; the neighbour product then
-    // adds onto it (a+b == b+a bit for bit) with the activation fused
-    gpu_context::side_begin();
-    matmul(x, z, y, in_data, d_W_self, feat_out);
-    gpu_context::side_end();
-    aggr.aggregate(y, *graph, in_data, d_in_temp1);
-    gpu_context::side_wait();
-    if (is_act) matmul_relu(x, z, y, d_in_temp1, d_W_neigh, feat_out, false, false, true);
-    else matmul(x, z, y, d_in_temp1, d_W_neigh, feat_out, false, false, true);
+  } else {  // mean aggregation with the neighbour product riding on it (one kernel)
+    aggr.aggregate_matmul(y, *graph, in_data, d_in_temp1, true, d_W_neigh, false, z, feat_out, false);
   }
+  // + X.W_self, with the activation fused into this last product
+  if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
+  else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
 }
 
 void SAGE_layer::backward(float* feat_out, float* grad_out) {
   const size_t x = num_samples, y = dim_in, z = dim_out;
   if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
   float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
-  // NB with feature dropout in_data == d_in_temp, which the else-branch below overwrites: the
-  // side section is only opened when the two do not alias
+  // the two weight gradients can run on the side stream next to the aggregation (GAIB_OVERLAP=1).
+  // NB with feature dropout in_data == d_in_temp, which the else-branch overwrites: no side section then
   const bool overlap = (y > z) || (level_ > 0 && in_data != d_in_temp);
   if (overlap) gpu_context::side_begin();
   matmul(y, z, x, in_data, grad_in, d_W_self_grad, true, false);
   if (y > z) {
     gpu_context::side_end();
-    aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
+    if (level_ > 0) aggr.d_aggregate_matmul(z, *graph, grad_in, d_out_temp, true, d_W_neigh, true, y, grad_out);
+    else aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
     gpu_context::side_wait();
-    if (level_ > 0) matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
     matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
     if (overlap) gpu_context::side_end();
     if (level_ > 0) {
-      matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
-      aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+      if (y == z) {  // (M^T g).W^T instead of M^T (g.W^T): the product rides on the aggregation
+        aggr.d_aggregate_matmul(z, *graph, grad_in, d_in_temp, false, d_W_neigh, true, y, grad_out);
+      } else {
+        matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
+        aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+      }
     }
     if (overlap) gpu_context::side_wait();
   }

@@ -16,6 +16,14 @@ class aggregator {
   void fuse_relu_once() { fuse_relu = true; }
 
  protected:
+  // extension shared by the GCN / SAGE operators: agg = Op.in followed by out = act(agg . op(W)) -- the
+  // layers' "aggregate first" branches -- as ONE kernel (gaib_spmm_gemm: the product runs on the matrix
+  // cores inside the aggregating wave).  W is [len x len_out], or [len_out x len] with transW.  keep_agg = false
+  // lets the kernel skip the store of agg (still needs the buffer).  On a partitioned graph (halo exchange)
+  // it runs as aggregation + matmul.
+  void aggregate_then_matmul(int kind, int len, Graph& g, const float* in, float* agg, bool keep_agg,
+                             const float* W, bool transW, int len_out, float* out, bool relu);
+
   int n;
   int length;  // feature vector length
   bool fuse_relu;
@@ -27,6 +35,11 @@ class GCN_Aggregator : public aggregator {
   void init(int length, int nv, int ne = 0, float lr = 0.01, float drop_rate = 0.);
   void aggregate(int len, Graph& g, const float* in, float* out);
   void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
+  // aggregate / d_aggregate fused with the following matmul (see aggregator::aggregate_then_matmul)
+  void aggregate_matmul(int len, Graph& g, const float* in, float* agg, bool keep_agg, const float* W,
+                        bool transW, int len_out, float* out, bool relu);
+  void d_aggregate_matmul(int len, Graph& g, const float* grad_in, float* agg, bool keep_agg, const float* W,
+                          bool transW, int len_out, float* out);
 };
 
 // forward: mean over neighbours (1/deg(i)); backward: its transpose (1/deg(col_e))
@@ -35,6 +48,10 @@ class SAGE_Aggregator : public aggregator {
   void init(int length, int nv, int ne = 0, float lr = 0.01, float drop_rate = 0.);
   void aggregate(int len, Graph& g, const float* in, float* out);
   void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
+  void aggregate_matmul(int len, Graph& g, const float* in, float* agg, bool keep_agg, const float* W,
+                        bool transW, int len_out, float* out, bool relu);
+  void d_aggregate_matmul(int len, Graph& g, const float* grad_in, float* agg, bool keep_agg, const float* W,
+                          bool transW, int len_out, float* out);
 };
 
 // single-head attention: p = softmax_row(leaky_relu_0.2(a_l.h_i + a_r.h_j)); out = P h.
