@@ -383,7 +383,8 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   g->max_degree = (int64_t)h[1];
   g->heavy_edges = (int64_t)h[2];
   if (g->n_heavy > 0) {
-    GAIB_HIP(hipMalloc(&g->heavy_rows, sizeof(uint32_t) * (size_t)g->n_heavy));
+    // [0, n): row ids ascending; [n, 2n): launch order = slots by descending degree
+    GAIB_HIP(hipMalloc(&g->heavy_rows, sizeof(uint32_t) * 2 * (size_t)g->n_heavy));
     GAIB_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
     heavy_rows_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, thr,
                                                                    g->heavy_rows, cnt, nullptr);
@@ -395,6 +396,17 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
                             hipMemcpyDeviceToHost, ctx->stream));
     GAIB_HIP(hipStreamSynchronize(ctx->stream));
     std::sort(rows.begin(), rows.end());
+    // longest rows first: the workgroup-per-row kernel then ends on its shortest rows
+    std::vector<int64_t> rp((size_t)g->nv + 1);
+    GAIB_HIP(hipMemcpyAsync(rp.data(), g->rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost,
+                            ctx->stream));
+    GAIB_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> order(rows.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      return rp[rows[x] + 1] - rp[rows[x]] > rp[rows[y] + 1] - rp[rows[y]];
+    });
+    rows.insert(rows.end(), order.begin(), order.end());
     GAIB_HIP(hipMemcpyAsync(g->heavy_rows, rows.data(), sizeof(uint32_t) * rows.size(),
                             hipMemcpyHostToDevice, ctx->stream));
     GAIB_HIP(hipStreamSynchronize(ctx->stream));

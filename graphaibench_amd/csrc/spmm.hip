@@ -71,7 +71,8 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a
   extern __shared__ __attribute__((aligned(16))) float red[];  // [HEAVY_WAVES][CT*64*VEC]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int row = (int)a.row_list[blockIdx.x];
+  const int slot = (int)a.row_order[blockIdx.x];
+  const int row = (int)a.row_list[slot];
   const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
   uint32_t voff[CT];
   vec_t acc[CT];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a
   for (int ct = 0; ct < CT; ++ct)
     *reinterpret_cast<vec_t*>(&red[wave * W + (ct * 64 + lane) * VEC]) = acc[ct];
   __syncthreads();
-  float* orow = a.out + (a.compact ? (int64_t)blockIdx.x : (int64_t)row) * a.ld;
+  float* orow = a.out + (a.compact ? (int64_t)slot : (int64_t)row) * a.ld;
   for (int c = threadIdx.x; c < a.ncols; c += HEAVY_WAVES * 64) {
     float s = a.accumulate ? orow[c] + red[c] : red[c];
 #pragma unroll
@@ -152,6 +153,7 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   if (g->n_heavy > 0) {
     SpmmArgs h = a;
     h.row_list = g->heavy_rows;
+    h.row_order = g->heavy_rows + g->n_heavy;
     size_t lds = sizeof(float) * HEAVY_WAVES * CT * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy");
     spmm_heavy_kernel<VEC, CT, WMODE, U, BUF><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
@@ -196,6 +198,7 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   if (g->n_heavy > 0) {
     SpmmArgs h = a;
     h.row_list = g->heavy_rows;
+    h.row_order = g->heavy_rows + g->n_heavy;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy");
     spmm_heavy_kernel<VEC, 1, WMODE, 8, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
@@ -430,6 +433,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   if (g->n_heavy > 0) {
     SpmmArgs h = a;
     h.row_list = g->heavy_rows;
+    h.row_order = g->heavy_rows + g->n_heavy;
     h.out = heavy_scratch;
     h.compact = 1;  // (h.ld stays len == K: it is the gather stride too)
     h.relu = 0;
@@ -479,6 +483,7 @@ static int spmm_setup(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float
   a.n_rows = (int)g->nv;
   a.heavy_thr = g->heavy_thr;
   a.row_list = nullptr;
+  a.row_order = nullptr;
   a.nblocks = 0;
   a.per_xcd = 0;
   a.accumulate = (flags & GAIB_ACCUMULATE) ? 1 : 0;

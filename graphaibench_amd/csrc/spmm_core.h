@@ -17,7 +17,8 @@ struct SpmmArgs {
   int ncols;   // columns handled by this launch (<= 64*VEC*CT), starting at in/out
   int n_rows;
   int heavy_thr;
-  const uint32_t* row_list;  // heavy kernel only
+  const uint32_t* row_list;  // heavy kernel only: row ids (ascending) ...
+  const uint32_t* row_order; // ... and the slot each workgroup takes (longest rows first)
   int nblocks;               // light kernels: logical number of row blocks
   int per_xcd;               // ceil(nblocks/8) when swizzled, 0 otherwise
   uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)

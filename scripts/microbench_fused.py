@@ -38,6 +38,11 @@ def main():
                                              agg_scratch=scratch), ctx)
             print(f"fuse={fuse} transW={transW} relu={relu} agg_scratch={scratch}: {t:.3f} ms")
     ctx.set_option("spmm_fuse", 1)
+    for thr in (256, 512, 1024, 2048, 4096):
+        ctx.set_option("spmm_heavy_threshold", thr)
+        t = timeit(lambda: ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y, relu=True), ctx)
+        print(f"heavy threshold {thr}: fused fwd {t:.3f} ms  {ctx.graph_stats(g)}")
+    ctx.set_option("spmm_heavy_threshold", 1024)
     t = timeit(lambda: ctx.spmm(g, capi.W_GCN, x, agg), ctx)
     print(f"plain spmm: {t:.3f} ms")
 
