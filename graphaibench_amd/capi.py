@@ -200,12 +200,12 @@ class Context:
         return out
 
     def spmm_gemm(self, g: "Graph", kind: int, x, agg, W, out, transW: bool = False, relu: bool = False,
-                  agg_scratch: bool = False, edge_w=None):
+                  agg_scratch: bool = False, edge_w=None, accumulate: bool = False):
         """agg = A.x ; out = act(agg . op(W)) (gaib_spmm_gemm: fused on the matrix cores when the shape allows)"""
         assert x.is_contiguous() and agg.is_contiguous() and W.is_contiguous() and out.is_contiguous()
-        len_in, len_out = x.shape[1], out.shape[1]
+        len_in, len_out = agg.shape[1], out.shape[1]
         assert tuple(W.shape) == ((len_out, len_in) if transW else (len_in, len_out))
-        flags = (2 if relu else 0) | (4 if agg_scratch else 0)
+        flags = (2 if relu else 0) | (4 if agg_scratch else 0) | (1 if accumulate else 0)
         _check(self.lib.gaib_spmm_gemm(self.h, g.h, kind, _ptr(edge_w), len_in, _ptr(x), _ptr(agg), _ptr(W),
                                        1 if transW else 0, len_out, _ptr(out), flags), "gaib_spmm_gemm")
         return out

@@ -311,6 +311,7 @@ struct FuseArgs {
   const uint32_t* heavy_rows; // ascending
   int n_heavy;
   int* tile_counter;          // zeroed before the launch
+  const float* agg_in;        // accumulate mode: partial sums to continue (same layout as the agg rows)
   int dbg;
 };
 
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         vec_t acc[1];
         acc[0] = vzero<VEC>();
         if (row < a.n_rows) {
+          if (f.agg_in) acc[0] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ld + lane * VEC);
           const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr) << 32) |
                              (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr);
           const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr + 1) << 32) |
@@ -370,7 +372,16 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
               if (f.heavy_rows[mid] < (uint32_t)row) lo = mid + 1;
               else hi = mid;
             }
-            acc[0] = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * K + lane * VEC);
+            const vec_t hv = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * K + lane * VEC);
+            if (f.agg_in) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                if constexpr (VEC == 1) acc[0] = acc[0] + hv;
+                else acc[0][e] = acc[0][e] + hv[e];
+              }
+            } else {
+              acc[0] = hv;
+            }
           } else {
             const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
             wave_accumulate<VEC, 1, WMODE, U, GM>(a, lane, e0, e1, 64, roww, voff, acc);
@@ -578,7 +589,8 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   GAIB_CHECK(len_in >= 0 && len_out >= 0, "gaib_spmm_gemm: negative length");
   GAIB_CHECK(ctx->device == g->device, "gaib_spmm_gemm: graph lives on device %d, ctx on %d", g->device,
              ctx->device);
-  GAIB_CHECK((flags & ~(GAIB_RELU | GAIB_AGG_SCRATCH)) == 0, "gaib_spmm_gemm: unsupported flags %d", flags);
+  GAIB_CHECK((flags & ~(GAIB_RELU | GAIB_AGG_SCRATCH | GAIB_ACCUMULATE)) == 0, "gaib_spmm_gemm: unsupported flags %d",
+             flags);
   if (g->nv == 0 || len_out == 0) return GAIB_OK;
   GAIB_CHECK(d_in && d_agg && d_W && d_out, "gaib_spmm_gemm: NULL pointer");
   GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out, "gaib_spmm_gemm: buffers must not alias");
@@ -586,17 +598,18 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   // op(W) [len_out x (len_in+4)] + 16 strips [8 x (len_in+4)] must fit the CU's 160 KB of LDS
   const size_t fuse_lds = sizeof(float) * (size_t)(len_in + 4) * ((size_t)len_out + FUSE_WAVES * FUSE_ROWS / 2);
   const bool fusable = ctx->spmm_fuse != 0 && (len_in == 64 || len_in == 128) && len_out % 16 == 0 &&
-                       fuse_lds <= 160 * 1024 && (al & 15) == 0 && g->ne > 0 &&
+                       fuse_lds <= 160 * 1024 && (al & 15) == 0 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
   if (!fusable) {
-    GAIB_TRY(spmm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, 0));
+    GAIB_TRY(spmm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, flags & GAIB_ACCUMULATE));
     return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_agg, d_W, (flags & GAIB_RELU) ? GAIB_RELU : 0,
                          d_out);
   }
   SpmmArgs a;
   int wmode = 0;
   GAIB_TRY(spmm_setup(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, 0, 1, &a, &wmode));
+  a.accumulate = 0;  // (the fused kernel takes the partial sums through f.agg_in)
   if (flags & GAIB_AGG_SCRATCH) a.out = nullptr;  // the caller does not read agg: skip its store
   // scratch: op(W) k-contiguous + the heavy rows' aggregates
   const size_t wt_bytes = sizeof(float) * (size_t)len_out * len_in;
@@ -618,6 +631,7 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   f.ldy = len_out;
   f.n_out = len_out;
   f.tile_counter = counter;
+  f.agg_in = (flags & GAIB_ACCUMULATE) ? d_agg : nullptr;
   f.relu = (flags & GAIB_RELU) ? 1 : 0;
   f.heavy_agg = hv;
   f.heavy_rows = g->heavy_rows;

@@ -30,13 +30,17 @@ static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* 
 void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float* in, float* agg, bool keep_agg,
                                        const float* W, bool transW, int len_out, float* out, bool relu) {
   OpTimer t(OP_SPARSEMM);
+  const int flags = (relu ? GAIB_RELU : 0) | (keep_agg ? 0 : GAIB_AGG_SCRATCH);
   if (g.has_halo()) {
-    aggregate_rows(g, kind, len, in, agg);
-    if (relu) matmul_relu(g.size(), len_out, len, agg, W, out, false, transW);
-    else matmul(g.size(), len_out, len, agg, W, out, false, transW);
+    // owned-column edges while the halo rows travel; the halo-column edges then continue the sums and
+    // carry the dense product
+    g.halo_begin(len, in);
+    GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, agg, 0));
+    const float* halo = g.halo_end(len);
+    GAIB_OR_DIE(gaib_spmm_gemm(C(), g.halo_graph(), kind, NULL, len, halo, agg, W, transW ? 1 : 0, len_out, out,
+                               flags | GAIB_ACCUMULATE));
     return;
   }
-  const int flags = (relu ? GAIB_RELU : 0) | (keep_agg ? 0 : GAIB_AGG_SCRATCH);
   GAIB_OR_DIE(gaib_spmm_gemm(C(), dev(g), kind, NULL, len, in, agg, W, transW ? 1 : 0, len_out, out, flags));
 }
 

@@ -192,7 +192,8 @@ int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float
  * out = act(agg . op(W)), op(W) = W [len_in x len_out] or, with transW, W^T for W [len_out x len_in]
  * (the input-gradient product of backward).  For len_in in {64, 128} and len_out % 16 == 0 the product
  * runs on the matrix cores inside the aggregating wave (no second pass over agg); other shapes run
- * gaib_spmm + gaib_sgemm.  flags: GAIB_RELU, GAIB_AGG_SCRATCH.  d_agg must always be a valid
+ * gaib_spmm + gaib_sgemm.  flags: GAIB_RELU, GAIB_AGG_SCRATCH, GAIB_ACCUMULATE (d_agg holds partial sums that
+ * this call continues -- the halo half of a partitioned aggregation).  d_agg must always be a valid
  * [nv x len_in] buffer.  Option "spmm_fuse" = 0 forces the two-kernel path. */
 int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
                    int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,

@@ -658,3 +658,44 @@ def test_spmm_gemm_fused(ctx, len_in, len_out, kind, transW, relu):
     finally:
         ctx.set_option("spmm_fuse", 1)
     assert rel_err(y2.cpu().numpy(), y.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("d,d_out", [(128, 128), (64, 48), (96, 32)])
+def test_spmm_gemm_accumulate_split_by_column(ctx, d, d_out):
+    """the multi-GPU own/halo split through the fused kernel: gaib_spmm on the low-column edges, then
+    gaib_spmm_gemm(GAIB_ACCUMULATE) on the high-column edges continues the sums and carries the product"""
+    rp, ci = random_graph(3000, 14, seed=3, power_law=True, hub_deg=2500)
+    g_o = orc.Graph(rp, ci)
+    n = g_o.nv
+    x = feat(n, d, 1)
+    W = feat(d, d_out, 6) * 0.2
+    ew = np.random.default_rng(2).random(g_o.ne).astype(np.float32)
+    agg_w = orc.spmm_edge(g_o, ew, x)
+    y_w = np.maximum(orc.matmul(agg_w, W), 0)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    lo_mask = ci < n // 2
+
+    def sub(mask):
+        cnt = np.bincount(rows[mask], minlength=n)
+        return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ci[mask], ew[mask]
+
+    rpa, cia, ewa = sub(lo_mask)
+    rpb, cib, ewb = sub(~lo_mask)
+    ga = ctx.graph(rpa, cia.view(np.int32))
+    gb = ctx.graph(rpb, cib.view(np.int32))
+    xd = dev(x)
+    agg = torch.empty(n, d, device="cuda")
+    y = torch.empty(n, d_out, device="cuda")
+    ctx.spmm(ga, capi.W_EDGE, xd, agg, edge_w=dev(ewa))
+    ctx.spmm_gemm(gb, capi.W_EDGE, xd, agg, dev(W), y, relu=True, edge_w=dev(ewb), accumulate=True)
+    assert rel_err(agg.cpu().numpy(), agg_w) < 1e-5
+    assert rel_err(y.cpu().numpy(), y_w) < TOL
+    if d in (64, 128):  # fused shapes: light rows continue the CSR-order sum bit for bit
+        light = (np.diff(rpa) <= 1024) & (np.diff(rpb) <= 1024)
+        assert np.array_equal(agg.cpu().numpy()[light].view(np.uint32), agg_w[light].view(np.uint32))
+    # an empty second half (a rank without halo edges) leaves the sums alone and still applies the product
+    ge = ctx.graph(np.zeros(n + 1, np.int64), np.zeros(0, np.int32))
+    ctx.spmm(g_o_dev := ctx.graph(rp, ci.view(np.int32)), capi.W_EDGE, xd, agg, edge_w=dev(ew))
+    y2 = torch.empty(n, d_out, device="cuda")
+    ctx.spmm_gemm(ge, capi.W_EDGE, xd, agg, dev(W), y2, relu=True, edge_w=dev(ew[:1]), accumulate=True)
+    assert rel_err(y2.cpu().numpy(), y_w) < TOL
