@@ -105,6 +105,15 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
                        f"{t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
 
 
+def emit(result: dict) -> None:
+    """the ONE JSON line, last on stdout: libraries that write to C stdio (RCCL prints its library path
+    there) sit in libc's buffer until exit and would otherwise land after it"""
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,9 +151,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log)
-        if rank == 0:
-            print(json.dumps(result), flush=True)
         dist.barrier()
+        if rank == 0:
+            emit(result)
         dist.destroy_process_group()
         return
 
@@ -253,7 +262,7 @@ def main():
         t1 = time.time()
         result["cpu_baseline"] = cpu_baseline(sg.rowptr, sg.colidx, sg.nv)
         log(f"[bench] cpu baseline took {time.time()-t1:.1f}s")
-    print(json.dumps(result), flush=True)
+    emit(result)
 
 
 if __name__ == "__main__":

@@ -318,6 +318,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     elapsed = time.perf_counter() - t_start
     ctx.prof_enable(False)
     n_light, ms_light = ctx.prof_get("spmm_light")
+    n_fused, ms_fused = ctx.prof_get("spmm_gemm_fused")
     ctx.prof_reset()
     # max time over ranks, total edges over ranks
     rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
@@ -327,15 +328,20 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     dist.all_reduce(e, op=dist.ReduceOp.SUM)
     elapsed = float(t[0])
     total_edges = float(e[0])
-    # dominant kernel = the light SpMM over the owned-column edges (the first launch of each aggregation)
+    # dominant kernel (rank 0's view) = the pass over the owned-column edges of each aggregation: with halo
+    # edges that is spmm_w64_kernel (the halo half then carries the dense product), without them the fused
+    # kernel does everything, as in the single-GPU bench
     st_own = ctx.graph_stats(dg.lgraph.device_graph())
     e_light = part.colidx_own.numel() - st_own["heavy_edges"]
-    alg_bytes = e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
-    if dg.g_halo is not None:  # launches alternate own / halo: average over both
-        st_h = ctx.graph_stats(dg.g_halo)
-        e_light_h = part.colidx_halo.numel() - st_h["heavy_edges"]
-        alg_bytes = (alg_bytes + e_light_h * (4 * D + 8) + 2 * (nv - st_h["n_heavy"]) * 4 * D + (nv + 1) * 8) / 2
-    avg_ms = ms_light / max(n_light, 1)
+    if part.colidx_halo.numel() > 0:
+        kernel_name = "spmm_w64_kernel<VEC=2,CT=1,edge-weights,U=16,buffer> over the owned-column edges (rank 0)"
+        alg_bytes = e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
+        n_dom, ms_dom = n_light, ms_light
+    else:
+        kernel_name = "spmm_gemm_kernel<VEC=2,edge-weights,U=16,buffer> (aggregation + MFMA dense product, rank 0)"
+        alg_bytes = e_light * (4 * D + 8) + int(1.5 * nv * 4 * D) + (nv + 1) * 8
+        n_dom, ms_dom = n_fused, ms_fused
+    avg_ms = ms_dom / max(n_dom, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {
         "metric": "GCN-layer fwd+bwd aggregated edges/sec",
@@ -359,8 +365,8 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
             "parallelism": f"vertex-range x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "spmm_w64_kernel<VEC=2,CT=1,edge-weights,U=16,buffer> (rank 0)",
+            "bound": "hbm", "kernel": kernel_name,
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-            "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_light,
+            "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_dom,
         },
     }

@@ -34,7 +34,12 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
   if (g.has_halo()) {
     // owned-column edges while the halo rows travel; the halo-column edges then continue the sums and
     // carry the dense product
-    g.halo_begin(len, in);
+    g.halo_begin(len, in);  // every rank joins every exchange, also one without halo edges
+    if (gaib_graph_ne(g.halo_graph()) == 0) {
+      GAIB_OR_DIE(gaib_spmm_gemm(C(), dev(g), kind, NULL, len, in, agg, W, transW ? 1 : 0, len_out, out, flags));
+      g.halo_end(len);
+      return;
+    }
     GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, agg, 0));
     const float* halo = g.halo_end(len);
     GAIB_OR_DIE(gaib_spmm_gemm(C(), g.halo_graph(), kind, NULL, len, halo, agg, W, transW ? 1 : 0, len_out, out,
