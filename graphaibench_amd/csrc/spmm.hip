@@ -322,22 +322,24 @@ constexpr int FUSE_WAVES = 16;
 template <int VEC, int WMODE, int U, int GM>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
-  constexpr int K = 64 * VEC;
+  constexpr int K = 64 * VEC;  // padded inner dimension; a.ncols (<= K) columns are real
   constexpr int KQ = K / 4;
   constexpr int LDT = K + 4;
   constexpr int HALF = FUSE_ROWS / 2;
   extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  float* wl = fuse_lds;                                              // [n_out][LDT]
-  float* tile = fuse_lds + f.n_out * LDT + wave * (HALF * LDT);      // [HALF][LDT]
-  for (int t = threadIdx.x; t < f.n_out * (K / 4); t += FUSE_WAVES * 64) {
-    const int n = t / (K / 4), q = t % (K / 4);
-    *reinterpret_cast<f32x4_t*>(wl + n * LDT + 4 * q) = reinterpret_cast<const f32x4_t*>(f.wt)[t];
+  const int n_pad = (f.n_out + 15) & ~15;
+  float* wl = fuse_lds;                                            // [n_pad][LDT], zero padded
+  float* tile = fuse_lds + n_pad * LDT + wave * (HALF * LDT);      // [HALF][LDT]
+  for (int t = threadIdx.x; t < n_pad * K; t += FUSE_WAVES * 64) {
+    const int n = t / K, k = t % K;
+    wl[n * LDT + k] = (n < f.n_out && k < a.ncols) ? f.wt[(int64_t)n * a.ncols + k] : 0.f;
   }
   __syncthreads();  // the only workgroup barrier
   const int i = lane & 15, kq = lane >> 4;
-  const uint32_t voff[1] = {(uint32_t)(lane * VEC * 4)};
+  const bool colok = lane * VEC < a.ncols;
+  const uint32_t voff[1] = {colok ? (uint32_t)(lane * VEC * 4) : 0u};
   const int ntiles = (a.n_rows + FUSE_ROWS - 1) / FUSE_ROWS;
   for (;;) {
     int t = 0;
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         vec_t acc[1];
         acc[0] = vzero<VEC>();
         if (row < a.n_rows) {
-          if (f.agg_in) acc[0] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ld + lane * VEC);
+          if (f.agg_in && colok)
+            acc[0] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ld + lane * VEC);
           const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr) << 32) |
                              (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr);
           const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr + 1) << 32) |
@@ -372,22 +375,22 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
               if (f.heavy_rows[mid] < (uint32_t)row) lo = mid + 1;
               else hi = mid;
             }
-            const vec_t hv = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * K + lane * VEC);
-            if (f.agg_in) {
+            if (colok) {
+              const vec_t hv = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * a.ld + lane * VEC);
+              if constexpr (VEC == 1) acc[0] = f.agg_in ? acc[0] + hv : hv;
+              else {
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) {
-                if constexpr (VEC == 1) acc[0] = acc[0] + hv;
-                else acc[0][e] = acc[0][e] + hv[e];
+                for (int e = 0; e < VEC; ++e) acc[0][e] = f.agg_in ? acc[0][e] + hv[e] : hv[e];
               }
-            } else {
-              acc[0] = hv;
             }
           } else {
             const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
             wave_accumulate<VEC, 1, WMODE, U, GM>(a, lane, e0, e1, 64, roww, voff, acc);
           }
-          if (a.out) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc[0];
+          if (a.out && colok) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc[0];
         }
+        // lanes beyond the real columns gathered column 0 (see wave_accumulate): they must enter the product as 0
+        if (!colok) acc[0] = vzero<VEC>();
         *reinterpret_cast<vec_t*>(tile + r * LDT + lane * VEC) = acc[0];
       }
       // LDS operations of one wave complete in order; the fences keep the compiler from moving
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     const float* wbase = wl + i * LDT + kq * KQ;
-    for (int n0 = 0; n0 < f.n_out; n0 += 16) {
+    for (int n0 = 0; n0 < n_pad; n0 += 16) {
       const float* wr = wbase + n0 * LDT;
       f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -415,13 +418,15 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 2], b[2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 3], b[3], c, 0, 0, 0);
       }
+      if (n0 + i < f.n_out) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
-        if (row < a.n_rows) {
-          float v = c[reg];
-          if (f.relu) v = v > 0.f ? v : 0.f;
-          f.y[(int64_t)row * f.ldy + n0 + i] = v;
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
+          if (row < a.n_rows) {
+            float v = c[reg];
+            if (f.relu) v = v > 0.f ? v : 0.f;
+            f.y[(int64_t)row * f.ldy + n0 + i] = v;
+          }
         }
       }
     }
@@ -455,7 +460,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     else spmm_heavy_kernel<VEC, 1, WMODE, U, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
   }
-  const size_t lds = sizeof(float) * (size_t)(K + 4) * (f.n_out + FUSE_WAVES * FUSE_ROWS / 2);
+  const size_t lds = sizeof(float) * (size_t)(K + 4) * (((f.n_out + 15) & ~15) + FUSE_WAVES * FUSE_ROWS / 2);
   const int64_t ntiles = cdiv64(a.n_rows, FUSE_ROWS);
   const unsigned grid = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, FUSE_WAVES));
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, sizeof(int), ctx->stream));
@@ -596,9 +601,12 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out, "gaib_spmm_gemm: buffers must not alias");
   const uintptr_t al = (uintptr_t)d_in | (uintptr_t)d_agg | (uintptr_t)d_W;
   // op(W) [len_out x (len_in+4)] + 16 strips [8 x (len_in+4)] must fit the CU's 160 KB of LDS
-  const size_t fuse_lds = sizeof(float) * (size_t)(len_in + 4) * ((size_t)len_out + FUSE_WAVES * FUSE_ROWS / 2);
-  const bool fusable = ctx->spmm_fuse != 0 && (len_in == 64 || len_in == 128) && len_out % 16 == 0 &&
-                       fuse_lds <= 160 * 1024 && (al & 15) == 0 && g->ne > 0 && g->nv >= 1 &&
+  // rows narrower than 33 floats are better served by the packed sub-wave kernel; 65..128 needs 8-byte lanes
+  const int kpad = len_in <= 64 ? 64 : 128;
+  const size_t fuse_lds = sizeof(float) * (size_t)(kpad + 4) * ((size_t)((len_out + 15) & ~15) + FUSE_WAVES * FUSE_ROWS / 2);
+  const bool lanes_ok = len_in <= 64 ? true : (len_in % 2 == 0 && (al & 7) == 0);
+  const bool fusable = ctx->spmm_fuse != 0 && len_in > 32 && len_in <= 128 && lanes_ok &&
+                       fuse_lds <= 160 * 1024 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
   if (!fusable) {
@@ -637,7 +645,7 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   f.heavy_rows = g->heavy_rows;
   f.n_heavy = (int)g->n_heavy;
   f.dbg = ctx->spmm_fuse;
-  if (len_in == 64) {
+  if (len_in <= 64) {
     return wmode == 0 ? launch_fused<1, 0>(ctx, g, a, f, hv) : launch_fused<1, 1>(ctx, g, a, f, hv);
   }
   return wmode == 0 ? launch_fused<2, 0>(ctx, g, a, f, hv) : launch_fused<2, 1>(ctx, g, a, f, hv);

@@ -13,6 +13,8 @@ python "$ROOT/scripts/make_synth_dataset.py" reddit "$DATA"
 export DATASET_PATH="$DATA/"
 echo "=== config 3: gpu_train_sage ogbn-products 10 32 softmax 256 0 0 0.01 3 0 50 0 (GAIB_SYNC_TIMERS=1)"
 GAIB_SYNC_TIMERS=1 "$ROOT/bin/gpu_train_sage" ogbn-products 10 32 softmax 256 0 0 0.01 3 0 50 0
+echo "=== config 3 at the BASELINE width: gpu_train_sage ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0"
+"$ROOT/bin/gpu_train_sage" ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0
 echo "=== GCN on the same graph: gpu_train_gcn ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0"
 "$ROOT/bin/gpu_train_gcn" ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0
 echo "=== config 4: GAIB_GAT_HEADS=8 gpu_train_gat reddit 10 32 softmax 64 0 0 0.01 2 0 50 0"

@@ -619,8 +619,13 @@ def test_side_section_overlaps_and_orders(ctx):
     (64, 32, "mean", False, False),
     (128, 48, "mean_t", True, True),
     (64, 256, "edge", False, False),
-    (100, 40, "gcn", False, True),     # not fusable: two-kernel path
-    (128, 30, "mean", True, False),    # not fusable (len_out % 16)
+    (100, 128, "gcn", False, True),    # products layer 0: K padded to 128
+    (47, 128, "gcn", True, False),     # products output layer backward: odd K, one float per lane
+    (128, 47, "mean", True, False),    # ragged output width
+    (60, 50, "mean_t", False, True),
+    (101, 40, "gcn", False, True),     # not fusable (odd K > 64): two-kernel path
+    (16, 7, "gcn", False, False),      # narrow rows stay on the packed sub-wave kernel + GEMM
+    (256, 64, "mean", False, True),    # K > 128: two-kernel path
 ])
 def test_spmm_gemm_fused(ctx, len_in, len_out, kind, transW, relu):
     """gaib_spmm_gemm == aggregate then matmul (+relu) of the oracle; heavy rows, ragged row count"""
