@@ -318,77 +318,190 @@ struct HeadVec {
   }
 };
 
-template <int H>
-__global__ __launch_bounds__(256) void edge_softmax_hv_kernel(int64_t nv, const int64_t* rowptr,
-                                                              const uint32_t* col, const float* sl,
-                                                              const float* sr, float eps, float* temp,
-                                                              float* scores, float* norm) {
-  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= nv) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-  if (e0 == e1) return;
-  HeadVec<H> ssrc, mx, den;
-  ssrc.load(sl + row * H);
+// Row-owner kernels.  BLK = false: one wave per row, 4 rows per 256-thread block, rows longer than
+// heavy_thr are left to the BLK = true launch: one 1024-thread workgroup per heavy row (longest
+// first), partial reductions meet in LDS.  A row's edges are strided over the owner's lanes.
+constexpr int ROW_BLK_WAVES = 16;
+
+template <bool BLK>
+struct RowOwner {
+  int64_t row, e0, e1;
+  int tid, nthreads, lane, wave;
+  bool valid;
+  __device__ __forceinline__ RowOwner(int64_t nv, const int64_t* rowptr, int heavy_thr,
+                                      const uint32_t* row_list, const uint32_t* row_order) {
+    lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    if constexpr (BLK) {
+      row = row_list[row_order[blockIdx.x]];
+      tid = threadIdx.x;
+      nthreads = ROW_BLK_WAVES * 64;
+      valid = true;
+    } else {
+      row = (int64_t)blockIdx.x * 4 + wave;
+      tid = lane;
+      nthreads = 64;
+      valid = row < nv;
+    }
+    e0 = e1 = 0;
+    if (valid) {
+      e0 = rowptr[row];
+      e1 = rowptr[row + 1];
+      if (!BLK && heavy_thr > 0 && e1 - e0 > (int64_t)heavy_thr) valid = false;
+    }
+  }
+};
+
+// sum over the row owner's threads; lds: [ROW_BLK_WAVES][H] floats (BLK only).  Fixed order.
+template <int H, bool BLK>
+__device__ __forceinline__ void owner_sum(HeadVec<H>& v, int wave, int lane, float* lds) {
 #pragma unroll
-  for (int h = 0; h < H; ++h) { mx.v[h] = -INFINITY; den.v[h] = 0.f; }
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
+  for (int h = 0; h < H; ++h) v.v[h] = wave_sum(v.v[h]);
+  if constexpr (BLK) {
+    __syncthreads();  // lds may still be read from a previous reduction
+    if (lane == 0) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) lds[wave * H + h] = v.v[h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float t = lds[h];
+      for (int w = 1; w < ROW_BLK_WAVES; ++w) t += lds[w * H + h];
+      v.v[h] = t;
+    }
+  }
+}
+
+// (m, d) = (running maximum, sum of exp(s - m)) per lane -> the row's (M, D) in every thread
+template <int H, bool BLK>
+__device__ __forceinline__ void owner_softmax_stats(HeadVec<H>& m, HeadVec<H>& d, int wave, int lane, float* lds) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float mw = wave_max(m.v[h]);
+    const float scaled = (m.v[h] == -INFINITY) ? 0.f : d.v[h] * expf(m.v[h] - mw);
+    d.v[h] = wave_sum(scaled);
+    m.v[h] = mw;
+  }
+  if constexpr (BLK) {
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        lds[(wave * H + h) * 2] = m.v[h];
+        lds[(wave * H + h) * 2 + 1] = d.v[h];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float M = -INFINITY;
+      for (int w = 0; w < ROW_BLK_WAVES; ++w) M = fmaxf(M, lds[(w * H + h) * 2]);
+      float D = 0.f;
+      for (int w = 0; w < ROW_BLK_WAVES; ++w) {
+        const float mw = lds[(w * H + h) * 2];
+        if (mw != -INFINITY) D += lds[(w * H + h) * 2 + 1] * expf(mw - M);
+      }
+      m.v[h] = M;
+      d.v[h] = D;
+    }
+  }
+}
+
+// temp = sl[i] + sr[col]; s = leaky_relu(temp); norm = softmax_row(s)   (gat_aggregator.cpp:64-77).
+// Rows that fit one edge per lane stay in registers; longer rows take two passes: an online
+// (max, sum) pass that writes temp, then norm = exp(s - M) / D from the re-read temp.  132 B per edge
+// at H = 8 (4 col + 32 gathered + 32 temp + 32 re-read + 32 norm); `scores` is optional (+32 B).
+template <int H, bool BLK>
+__global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v2_kernel(
+    int64_t nv, const int64_t* rowptr, const uint32_t* col, const float* sl, const float* sr, float eps,
+    float* temp, float* scores, float* norm, int heavy_thr, const uint32_t* row_list, const uint32_t* row_order) {
+  __shared__ float lds[BLK ? ROW_BLK_WAVES * H * 2 : 1];
+  const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
+  if (!o.valid || o.e0 == o.e1) return;
+  HeadVec<H> ssrc, m, d;
+  ssrc.load(sl + o.row * H);
+  if (!BLK && o.e1 - o.e0 <= 64) {
+    const int64_t e = o.e0 + o.lane;
+    const bool ok = e < o.e1;
+    HeadVec<H> t, s;
+    if (ok) t.load(sr + (int64_t)col[e] * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      t.v[h] = ssrc.v[h] + t.v[h];
+      s.v[h] = ok ? (t.v[h] > 0.0f ? t.v[h] : eps * t.v[h]) : -INFINITY;
+      const float mx = wave_max(s.v[h]);
+      const float ex = ok ? expf(s.v[h] - mx) : 0.f;
+      const float den = wave_sum(ex);
+      m.v[h] = ex / den;
+    }
+    if (ok) {
+      t.store(temp + e * H);
+      if (scores) s.store(scores + e * H);
+      m.store(norm + e * H);
+    }
+    return;
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) { m.v[h] = -INFINITY; d.v[h] = 0.f; }
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
     HeadVec<H> t, s;
     t.load(sr + (int64_t)col[e] * H);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       t.v[h] = ssrc.v[h] + t.v[h];
       s.v[h] = t.v[h] > 0.0f ? t.v[h] : eps * t.v[h];
-      mx.v[h] = fmaxf(mx.v[h], s.v[h]);
+      // online softmax statistics with one expf: ex = exp(-|s - m|)
+      const bool up = s.v[h] > m.v[h];
+      const float ex = expf(up ? m.v[h] - s.v[h] : s.v[h] - m.v[h]);
+      d.v[h] = up ? d.v[h] * ex + 1.0f : d.v[h] + ex;
+      m.v[h] = up ? s.v[h] : m.v[h];
     }
     t.store(temp + e * H);
-    s.store(scores + e * H);
+    if (scores) s.store(scores + e * H);
   }
-#pragma unroll
-  for (int h = 0; h < H; ++h) mx.v[h] = wave_max(mx.v[h]);
-  for (int64_t e = e0 + lane; e < e1; e += 64) {  // each lane re-reads only its own writes
-    HeadVec<H> s;
-    s.load(scores + e * H);
+  owner_softmax_stats<H, BLK>(m, d, o.wave, o.lane, lds);
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {  // each thread re-reads only its own writes
+    HeadVec<H> t;
+    t.load(temp + e * H);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      s.v[h] = expf(s.v[h] - mx.v[h]);
-      den.v[h] += s.v[h];
+      const float sv = t.v[h] > 0.0f ? t.v[h] : eps * t.v[h];
+      t.v[h] = expf(sv - m.v[h]) / d.v[h];
     }
-    s.store(norm + e * H);
-  }
-#pragma unroll
-  for (int h = 0; h < H; ++h) den.v[h] = wave_sum(den.v[h]);
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
-    HeadVec<H> p;
-    p.load(norm + e * H);
-#pragma unroll
-    for (int h = 0; h < H; ++h) p.v[h] = p.v[h] / den.v[h];
-    p.store(norm + e * H);
+    t.store(norm + e * H);
   }
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void softmax_bwd_hv_kernel(int64_t nv, const int64_t* rowptr,
-                                                             const float* p, const float* dp,
-                                                             const float* temp, float eps,
-                                                             float* scores, float* gbuf, float* rs) {
-  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= nv) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+// softmax backward (math_functions.cpp:496-514, closed form of the :497-504 branch) + leaky-relu'
+// (gat_aggregator.cpp:145): ds = p(1-p)dp - (dot - p dp) p with dot = sum_e p dp, g = ds * lrelu'(temp).
+// Writes g into gbuf, the row sum of g into rs, ds into scores when asked.  DOT = true: the row's dot comes
+// from the caller (rowdot[i,h] = <grad_i, forward output_i> on slice h -- the same sum regrouped by vertex),
+// which makes this ONE pass over the edge arrays.
+template <int H, bool BLK, bool DOT>
+__global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2_kernel(
+    int64_t nv, const int64_t* rowptr, const float* p, const float* dp, const float* temp, float eps,
+    const float* rowdot, float* scores, float* gbuf, float* rs, int heavy_thr, const uint32_t* row_list,
+    const uint32_t* row_order) {
+  __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
+  const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
+  if (!o.valid) return;
   HeadVec<H> dot, gs;
 #pragma unroll
   for (int h = 0; h < H; ++h) { dot.v[h] = 0.f; gs.v[h] = 0.f; }
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
-    HeadVec<H> a, b;
-    a.load(p + e * H);
-    b.load(dp + e * H);
+  if constexpr (DOT) {
+    dot.load(rowdot + o.row * H);
+  } else {
+    for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
+      HeadVec<H> a, b;
+      a.load(p + e * H);
+      b.load(dp + e * H);
 #pragma unroll
-    for (int h = 0; h < H; ++h) dot.v[h] += a.v[h] * b.v[h];
+      for (int h = 0; h < H; ++h) dot.v[h] += a.v[h] * b.v[h];
+    }
+    owner_sum<H, BLK>(dot, o.wave, o.lane, lds);
   }
-#pragma unroll
-  for (int h = 0; h < H; ++h) dot.v[h] = wave_sum(dot.v[h]);
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
     HeadVec<H> a, b, t, ds, ge;
     a.load(p + e * H);
     b.load(dp + e * H);
@@ -400,33 +513,49 @@ __global__ __launch_bounds__(256) void softmax_bwd_hv_kernel(int64_t nv, const i
       ge.v[h] = ds.v[h] * (t.v[h] > 0.0f ? 1.0f : eps);
       gs.v[h] += ge.v[h];
     }
-    ds.store(scores + e * H);
+    if (scores) ds.store(scores + e * H);
     ge.store(gbuf + e * H);
   }
-#pragma unroll
-  for (int h = 0; h < H; ++h) gs.v[h] = wave_sum(gs.v[h]);
-  if (lane == 0) gs.store(rs + row * H);
+  owner_sum<H, BLK>(gs, o.wave, o.lane, lds);
+  if (o.tid == 0) gs.store(rs + o.row * H);
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void colsum_hv_kernel(int64_t nv, const int64_t* rowptr,
-                                                        const uint32_t* rev, const float* gbuf, float* cs) {
-  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= nv) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+// cs[v] = sum_{e in row v} g[rev[e]]  == column sum of g (structurally symmetric graph)
+template <int H, bool BLK>
+__global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kernel(
+    int64_t nv, const int64_t* rowptr, const uint32_t* rev, const float* gbuf, float* cs, int heavy_thr,
+    const uint32_t* row_list, const uint32_t* row_order) {
+  __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
+  const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
+  if (!o.valid) return;
   HeadVec<H> s;
 #pragma unroll
   for (int h = 0; h < H; ++h) s.v[h] = 0.f;
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
     HeadVec<H> g;
     g.load(gbuf + (int64_t)rev[e] * H);
 #pragma unroll
     for (int h = 0; h < H; ++h) s.v[h] += g.v[h];
   }
-#pragma unroll
-  for (int h = 0; h < H; ++h) s.v[h] = wave_sum(s.v[h]);
-  if (lane == 0) s.store(cs + row * H);
+  owner_sum<H, BLK>(s, o.wave, o.lane, lds);
+  if (o.tid == 0) s.store(cs + o.row * H);
+}
+
+// rowdot[v,h] = <a[v, slice h], b[v, slice h]>.  One wave per row.
+__global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H, const float* a,
+                                                     const float* b, float* out) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const float* ar = a + row * (int64_t)len;
+  const float* br = b + row * (int64_t)len;
+  const int dh = len / H;
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int c = h * dh + lane; c < (h + 1) * dh; c += 64) s += ar[c] * br[c];
+    s = wave_sum(s);
+    if (lane == 0) out[row * H + h] = s;
+  }
 }
 
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
@@ -434,6 +563,46 @@ inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4
 int check_heads(const char* who, int len, int heads) {
   GAIB_CHECK(len > 0, "%s: len must be > 0", who);
   GAIB_CHECK(heads >= 1 && len % heads == 0, "%s: heads (%d) must divide len (%d)", who, heads, len);
+  return GAIB_OK;
+}
+
+template <int H>
+int launch_edge_softmax(gaib_ctx* ctx, gaib_graph* g, const float* sl, const float* sr, float eps, float* temp,
+                        float* scores, float* norm) {
+  GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
+  const uint32_t* rl = g->heavy_rows;
+  const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;
+  const int thr = g->n_heavy > 0 ? g->heavy_thr : 0;
+  if (g->n_heavy > 0) {  // long rows first: their tail hides under the light launch
+    edge_softmax_v2_kernel<H, true><<<(unsigned)g->n_heavy, ROW_BLK_WAVES * 64, 0, ctx->stream>>>(
+        g->nv, g->rowptr, g->colidx, sl, sr, eps, temp, scores, norm, thr, rl, ro);
+    GAIB_LAUNCH_CHECK();
+  }
+  edge_softmax_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
+      g->nv, g->rowptr, g->colidx, sl, sr, eps, temp, scores, norm, thr, rl, ro);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+template <int H>
+int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float* dp, const float* temp, float eps,
+                       const float* rowdot, float* scores, float* gbuf, float* rs, float* cs) {
+  GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
+  const uint32_t* rl = g->heavy_rows;
+  const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;
+  const int thr = g->n_heavy > 0 ? g->heavy_thr : 0;
+  const unsigned nh = (unsigned)g->n_heavy, blk = ROW_BLK_WAVES * 64;
+  if (rowdot) {
+    if (nh) softmax_bwd_v2_kernel<H, true, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
+    softmax_bwd_v2_kernel<H, false, true><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
+  } else {
+    if (nh) softmax_bwd_v2_kernel<H, true, false><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
+    softmax_bwd_v2_kernel<H, false, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
+  }
+  GAIB_LAUNCH_CHECK();
+  if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, thr, rl, ro);
+  colsum_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, thr, rl, ro);
+  GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
 
@@ -445,8 +614,7 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   GAIB_CHECK(ctx && g, "gaib_gat_scores: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_scores", len, heads));
   if (g->nv == 0) return GAIB_OK;
-  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_temp_scores && d_scores && d_norm_scores,
-             "gaib_gat_scores: NULL pointer");
+  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_temp_scores && d_norm_scores, "gaib_gat_scores: NULL pointer");
   GAIB_CHECK(g->nc == g->nv, "gaib_gat_scores: square graphs only");
   GAIB_HIP(hipSetDevice(ctx->device));
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)g->nv * heads));
@@ -461,17 +629,18 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   {
     ProfScope ps(ctx, "gat_edge_softmax");
     const bool al16 = (((uintptr_t)d_temp_scores | (uintptr_t)d_scores | (uintptr_t)d_norm_scores) & 15) == 0;
-#define GAIB_ESM(HH)                                                                        \
-  edge_softmax_hv_kernel<HH><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(                     \
-      g->nv, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores)
-    if (heads == 2) GAIB_ESM(2);
-    else if (heads == 4 && al16) GAIB_ESM(4);
-    else if (heads == 8 && al16) GAIB_ESM(8);
-    else if (heads == 16 && al16) GAIB_ESM(16);
-    else
+    int rc = GAIB_OK;
+    if (heads == 1) rc = launch_edge_softmax<1>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+    else if (heads == 2) rc = launch_edge_softmax<2>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+    else if (heads == 4 && al16) rc = launch_edge_softmax<4>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+    else if (heads == 8 && al16) rc = launch_edge_softmax<8>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+    else if (heads == 16 && al16) rc = launch_edge_softmax<16>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
+    else {
+      GAIB_CHECK(d_scores, "gaib_gat_scores: this head count needs d_scores");
       edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
           g->nv, heads, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
-#undef GAIB_ESM
+    }
+    if (rc != GAIB_OK) return rc;
   }
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
@@ -543,50 +712,60 @@ extern "C" int gaib_sddmm(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_
   return gaib_sddmm_mh(ctx, g, len, 1, d_grad, d_feat, d_out_e);
 }
 
-extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
+extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
                                              const float* d_feat, const float* d_norm_scores,
                                              const float* d_norm_scores_grad,
                                              const float* d_temp_scores, float epsilon,
                                              float* d_scores, float* d_alpha_lgrad,
-                                             float* d_alpha_rgrad) {
+                                             float* d_alpha_rgrad, const float* d_grad_rows,
+                                             const float* d_fwd_out_rows) {
   GAIB_CHECK(ctx && g, "gaib_gat_softmax_bwd_alpha: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_softmax_bwd_alpha", len, heads));
   GAIB_CHECK(d_alpha_lgrad && d_alpha_rgrad, "gaib_gat_softmax_bwd_alpha: NULL alpha grad");
   GAIB_HIP(hipSetDevice(ctx->device));
   if (g->nv == 0) return GAIB_OK;
-  GAIB_CHECK(d_feat && d_norm_scores && d_norm_scores_grad && d_temp_scores && d_scores,
+  GAIB_CHECK(d_feat && d_norm_scores && d_norm_scores_grad && d_temp_scores,
              "gaib_gat_softmax_bwd_alpha: NULL pointer");
+  GAIB_CHECK((d_grad_rows == nullptr) == (d_fwd_out_rows == nullptr),
+             "gaib_gat_softmax_bwd_alpha: d_grad_rows and d_fwd_out_rows go together");
   GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
   const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };  // keep every slab 16-byte aligned
   const size_t n_g = up4((size_t)g->ne * heads), n_v = up4((size_t)g->nv * heads);
-  const size_t ws_floats = n_g + 2 * n_v + (size_t)nblocks * 2 * len;
+  const size_t ws_floats = n_g + 3 * n_v + (size_t)nblocks * 2 * len;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * ws_floats));
   float* gbuf = (float*)ctx->ws;
   float* rs = gbuf + n_g;
   float* cs = rs + n_v;
-  float* partial = cs + n_v;
+  float* rowdot = cs + n_v;
+  float* partial = rowdot + n_v;
   ProfScope ps(ctx, "gat_softmax_bwd_alpha");
+  if (d_grad_rows) {
+    rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad_rows, d_fwd_out_rows, rowdot);
+    GAIB_LAUNCH_CHECK();
+  } else {
+    rowdot = nullptr;
+  }
   const bool al16 = (((uintptr_t)d_norm_scores | (uintptr_t)d_norm_scores_grad | (uintptr_t)d_temp_scores |
                       (uintptr_t)d_scores | (uintptr_t)gbuf | (uintptr_t)rs | (uintptr_t)cs) & 15) == 0;
-#define GAIB_SBW(HH)                                                                                         \
-  do {                                                                                                       \
-    softmax_bwd_hv_kernel<HH><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(                                      \
-        g->nv, g->rowptr, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, d_scores, gbuf, rs);    \
-    colsum_hv_kernel<HH><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs);       \
-  } while (0)
-  if (heads == 2) GAIB_SBW(2);
+  int rc = GAIB_OK;
+#define GAIB_SBW(HH) rc = launch_softmax_bwd<HH>(ctx, g, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, \
+                                                 rowdot, d_scores, gbuf, rs, cs)
+  if (heads == 1) GAIB_SBW(1);
+  else if (heads == 2) GAIB_SBW(2);
   else if (heads == 4 && al16) GAIB_SBW(4);
   else if (heads == 8 && al16) GAIB_SBW(8);
   else if (heads == 16 && al16) GAIB_SBW(16);
   else {
+    GAIB_CHECK(d_scores, "gaib_gat_softmax_bwd_alpha: this head count needs d_scores");
     softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_norm_scores,
                                                                 d_norm_scores_grad, d_temp_scores, epsilon,
                                                                 d_scores, gbuf, rs);
     colsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->rev, gbuf, cs);
   }
 #undef GAIB_SBW
+  if (rc != GAIB_OK) return rc;
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
                                                                          rows_per_block, partial);
@@ -595,6 +774,16 @@ extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int l
                                                                          d_alpha_lgrad, d_alpha_rgrad);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
+}
+
+extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
+                                             const float* d_feat, const float* d_norm_scores,
+                                             const float* d_norm_scores_grad,
+                                             const float* d_temp_scores, float epsilon,
+                                             float* d_scores, float* d_alpha_lgrad,
+                                             float* d_alpha_rgrad) {
+  return gaib_gat_softmax_bwd_alpha_ex(ctx, g, len, heads, d_feat, d_norm_scores, d_norm_scores_grad, d_temp_scores,
+                                       epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad, nullptr, nullptr);
 }
 
 extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_feat,

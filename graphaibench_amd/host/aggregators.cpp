@@ -99,8 +99,8 @@ void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* 
 // ---- GAT ---------------------------------------------------------------------------------------
 GAT_Aggregator::GAT_Aggregator()
     : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
-      d_alpha_rgrad(NULL), d_scores(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
-      d_norm_scores_grad(NULL), alpha_opt(NULL) {}
+      d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
+      d_norm_scores_grad(NULL), fwd_out(NULL), alpha_opt(NULL) {}
 
 void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   length = l;
@@ -121,7 +121,6 @@ void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   copy_float_device(l, ar.data(), d_alpha_r);
   GAIB_OR_DIE(gaib_fill_f32(C(), l, 0.f, d_alpha_lgrad));
   GAIB_OR_DIE(gaib_fill_f32(C(), l, 0.f, d_alpha_rgrad));
-  d_scores = gaib_host::dmalloc<float>(num_edges);
   d_temp_scores = gaib_host::dmalloc<float>(num_edges);
   d_norm_scores = gaib_host::dmalloc<float>(num_edges);
   d_norm_scores_grad = gaib_host::dmalloc<float>(num_edges);
@@ -136,7 +135,7 @@ void GAT_Aggregator::set_num_heads(int h) {
   }
   if (h == heads) return;
   heads = h;
-  float** arrays[] = {&d_scores, &d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
+  float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
   for (float** a : arrays) {
     float_free_device(*a);
     *a = gaib_host::dmalloc<float>(num_edges * heads);
@@ -146,7 +145,7 @@ void GAT_Aggregator::set_num_heads(int h) {
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
     num_edges = g.sizeEdges();
-    float** arrays[] = {&d_scores, &d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
+    float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
     for (float** a : arrays) {
       float_free_device(*a);
       *a = gaib_host::dmalloc<float>(num_edges * heads);
@@ -154,8 +153,9 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   }
   {
     OpTimer t(OP_SCORE);
+    // the leaky-relu output itself is not materialised (NULL): nothing downstream reads it
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), dev(g), len, heads, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,
-                                   d_scores, d_norm_scores));
+                                   NULL, d_norm_scores));
   }
   OpTimer t(OP_SPARSEMM);
   GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores, heads, len, in, out,
@@ -173,8 +173,13 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
   }
   {
     OpTimer t(OP_ATTN);
-    GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_mh(C(), dev(g), len, heads, feat_in, d_norm_scores, d_norm_scores_grad,
-                                              d_temp_scores, epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad));
+    // with the layer's forward output at hand the softmax backward is one pass over the edge arrays:
+    // sum_e p_e dp_e == <grad_i, out_i> (out_i = sum_e p_e h_col; where relu cut out_i the gradient is 0 too)
+    const float* fwd = fwd_out;
+    fwd_out = NULL;
+    GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_ex(C(), dev(g), len, heads, feat_in, d_norm_scores, d_norm_scores_grad,
+                                              d_temp_scores, epsilon, NULL, d_alpha_lgrad, d_alpha_rgrad,
+                                              fwd ? grad_in : NULL, fwd));
   }
   // transpose + aggregation fused: w_e = norm_scores[rev(e)]
   OpTimer t(OP_SPARSEMM);

@@ -209,6 +209,7 @@ void GAT_layer::backward(float* feat_out, float* grad_out) {
   if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
   float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
   // out_temp holds h on entry and the aggregated gradient on exit
+  aggr.use_forward_output_once(feat_out);
   aggr.d_aggregate(z, *graph, d_out_temp, grad_in, d_out_temp);
   if (level_ != 0) {
     matmul(x, y, z, d_out_temp, d_W_neigh, grad_out, false, true);

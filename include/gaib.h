@@ -153,7 +153,8 @@ int gaib_spmm_mh(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_e
  * gaib_gat_scores: GAT_Aggregator::aggregate's score pass (gat_aggregator.cpp:60-92;
  *   compute_attn_score_warp, graph_operations.h:250-337): per edge
  *   temp = a_l.h[i] + a_r.h[col_e]; scores = leaky_relu(temp, eps); norm = row softmax.
- *   All three d_* edge arrays [ne] are written. */
+ *   The d_* edge arrays [ne] are written; d_scores may be NULL for 1, 2, 4, 8 or 16 heads (it is
+ *   leaky_relu(temp) and nothing in backward reads it). */
 int gaib_gat_scores(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_h, const float* d_alpha_l,
                     const float* d_alpha_r, float epsilon, float* d_temp_scores, float* d_scores,
                     float* d_norm_scores);
@@ -183,6 +184,14 @@ int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const floa
                                const float* d_norm_scores, const float* d_norm_scores_grad,
                                const float* d_temp_scores, float epsilon, float* d_scores,
                                float* d_alpha_lgrad, float* d_alpha_rgrad);
+/* general form: H heads; d_scores (the softmax-input gradient ds) may be NULL when the caller does not read it;
+ * d_grad_rows / d_fwd_out_rows (both or neither, [nv x len]): the gradient and the forward output of the
+ * aggregation -- sum_e p_e dp_e is then taken per vertex as <grad_i, out_i> and the edge arrays are read once. */
+int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
+                                  const float* d_norm_scores, const float* d_norm_scores_grad,
+                                  const float* d_temp_scores, float epsilon, float* d_scores,
+                                  float* d_alpha_lgrad, float* d_alpha_rgrad, const float* d_grad_rows,
+                                  const float* d_fwd_out_rows);
 /* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):
  *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
 int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);

@@ -67,6 +67,9 @@ class GAT_Aggregator : public aggregator {
   // on the column slices of width length/h.  Call right after init().
   void set_num_heads(int h);
   int num_heads() const { return heads; }
+  // extension: the next d_aggregate() may read the layer's forward output rows `out` (post-activation is fine as
+  // long as grad_in went through the matching d_relu): it replaces the per-row sum_e p_e dp_e by <grad_i, out_i>
+  void use_forward_output_once(const float* out) { fwd_out = out; }
   // device state (tests / checkpoints)
   float* alpha_l_ptr() { return d_alpha_l; }
   float* alpha_r_ptr() { return d_alpha_r; }
@@ -74,7 +77,7 @@ class GAT_Aggregator : public aggregator {
   float* alpha_rgrad_ptr() { return d_alpha_rgrad; }
   float* norm_scores_ptr() { return d_norm_scores; }
   float* temp_scores_ptr() { return d_temp_scores; }
-  float* scores_ptr() { return d_scores; }
+  float* scores_ptr() { return NULL; }  // leaky_relu(temp_scores): not materialised by this backend
   float* norm_scores_grad_ptr() { return d_norm_scores_grad; }
 
  private:
@@ -83,6 +86,7 @@ class GAT_Aggregator : public aggregator {
   size_t num_edges;
   int heads;
   float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
-  float *d_scores, *d_temp_scores, *d_norm_scores, *d_norm_scores_grad;
+  float *d_temp_scores, *d_norm_scores, *d_norm_scores_grad;
+  const float* fwd_out;  // see use_forward_output_once
   optimizer* alpha_opt;
 };

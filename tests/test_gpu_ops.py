@@ -357,7 +357,7 @@ def test_dropout_mask_replay(ctx):
 
 
 # ---- a4/a5: GAT ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,hub", [(8, 0), (64, 0), (64, 900), (100, 0), (300, 0)])
+@pytest.mark.parametrize("d,hub", [(8, 0), (64, 0), (64, 900), (64, 1800), (100, 0), (300, 0)])
 def test_gat_forward_pieces(ctx, d, hub):
     rp, ci = random_graph(2000, 9, seed=d, power_law=True, hub_deg=hub)
     g_o, g_d = make(ctx, rp, ci, selfloop=True)
@@ -376,9 +376,15 @@ def test_gat_forward_pieces(ctx, d, hub):
     out = torch.empty(g_o.nv, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE, hd, out, edge_w=p)
     assert rel_err(out.cpu().numpy(), want_out) < TOL
+    # the leaky-relu output is optional
+    t2 = torch.empty_like(t)
+    p2 = torch.empty_like(t)
+    ctx.gat_scores(g_d, hd, dev(al), dev(ar), t2, None, p2)
+    assert torch.equal(t2, t) and torch.equal(p2, p)
 
 
-@pytest.mark.parametrize("d,hub", [(4, 0), (8, 0), (32, 0), (64, 0), (64, 900), (128, 0), (130, 0), (256, 0), (300, 0)])
+@pytest.mark.parametrize("d,hub", [(4, 0), (8, 0), (32, 0), (64, 0), (64, 900), (64, 1400), (128, 0), (130, 0), (256, 0),
+                                   (300, 0)])
 def test_gat_backward_pieces(ctx, d, hub):
     rp, ci = random_graph(1500, 8, seed=d + 1, power_law=True, hub_deg=hub)
     g_o, g_d = make(ctx, rp, ci, selfloop=True)
@@ -386,7 +392,7 @@ def test_gat_backward_pieces(ctx, d, hub):
     gin = feat(g_o.nv, d, 4)
     al = feat(1, d, 2).ravel() * 0.2
     ar = feat(1, d, 3).ravel() * 0.2
-    _, temp, _, norm = orc.gat_aggregate(g_o, h, al, ar)
+    out_w, temp, _, norm = orc.gat_aggregate(g_o, h, al, ar)
     want_go, want_ds, want_ng, want_lg, want_rg = orc.gat_d_aggregate(g_o, h, gin, norm, temp, fast=True)
     hd, gd = dev(h), dev(gin)
     ng = torch.empty(g_o.ne, device="cuda")
@@ -399,6 +405,17 @@ def test_gat_backward_pieces(ctx, d, hub):
     assert rel_err(sc.cpu().numpy(), want_ds) < TOL
     assert rel_err(lg.cpu().numpy(), want_lg) < TOL
     assert rel_err(rg.cpu().numpy(), want_rg) < TOL
+    # one-pass form: the row's sum_e p dp taken per vertex as <grad_i, out_i>; ds optional
+    for keep_ds in (True, False):
+        sc2 = torch.zeros(g_o.ne, device="cuda")
+        lg2 = torch.empty(d, device="cuda")
+        rg2 = torch.empty(d, device="cuda")
+        ctx.gat_softmax_bwd_alpha(g_d, hd, dev(norm), dev(want_ng), dev(temp), sc2 if keep_ds else None, lg2, rg2,
+                                  grad_rows=gd, fwd_out_rows=dev(out_w))
+        if keep_ds:
+            assert rel_err(sc2.cpu().numpy(), want_ds) < TOL
+        assert rel_err(lg2.cpu().numpy(), want_lg) < TOL
+        assert rel_err(rg2.cpu().numpy(), want_rg) < TOL
     # explicit transpose == oracle's symmetric_csr_transpose (a permutation: bit-exact)
     pt = torch.empty(g_o.ne, device="cuda")
     ctx.edge_transpose(g_d, dev(norm), pt)
@@ -538,7 +555,7 @@ def test_spmm_relu_store(ctx, d):
 
 
 # ---- multi-head GAT (BASELINE config 4: 8 heads; each head == the single-head oracle on its slice) ----
-@pytest.mark.parametrize("d,heads,hub", [(64, 8, 0), (64, 8, 900), (64, 4, 0), (128, 8, 0), (32, 8, 0), (256, 8, 0),
+@pytest.mark.parametrize("d,heads,hub", [(64, 8, 0), (64, 8, 900), (64, 8, 1700), (64, 2, 1700), (64, 4, 0), (128, 8, 0), (32, 8, 0), (256, 8, 0),
                                          (48, 3, 0), (24, 8, 0), (130, 2, 0)])
 def test_gat_multi_head(ctx, d, heads, hub):
     rp, ci = random_graph(1800, 9, seed=d + heads, power_law=True, hub_deg=hub)
