@@ -58,7 +58,7 @@ SIGNATURES = {
     "gaib_gat_scores_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
-    "gaib_gat_softmax_bwd_alpha_ex": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "gaib_gat_softmax_bwd_alpha_ex": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gaib_edge_transpose_mh": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -220,12 +220,12 @@ class Context:
                "gaib_sddmm")
 
     def gat_softmax_bwd_alpha(self, g, feat, norm, norm_grad, temp, scores, lgrad, rgrad, eps: float = 0.2,
-                              heads: int = 1, grad_rows=None, fwd_out_rows=None):
+                              heads: int = 1, grad_rows=None, fwd_out_rows=None, norm_t=None):
         """scores may be None; grad_rows + fwd_out_rows select the one-pass form (gaib_gat_softmax_bwd_alpha_ex)"""
         _check(self.lib.gaib_gat_softmax_bwd_alpha_ex(self.h, g.h, feat.shape[1], heads, _ptr(feat), _ptr(norm),
                                                       _ptr(norm_grad), _ptr(temp), eps, _ptr(scores),
                                                       _ptr(lgrad), _ptr(rgrad), _ptr(grad_rows),
-                                                      _ptr(fwd_out_rows)), "gaib_gat_softmax_bwd_alpha")
+                                                      _ptr(fwd_out_rows), _ptr(norm_t)), "gaib_gat_softmax_bwd_alpha")
 
     def edge_transpose(self, g, in_e, out_e, heads: int = 1):
         _check(self.lib.gaib_edge_transpose_mh(self.h, g.h, heads, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")

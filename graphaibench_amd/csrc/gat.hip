@@ -444,32 +444,61 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
   }
 #pragma unroll
   for (int h = 0; h < H; ++h) { m.v[h] = -INFINITY; d.v[h] = 0.f; }
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
-    HeadVec<H> t, s;
-    t.load(sr + (int64_t)col[e] * H);
+  // EU edges per thread per trip: all column ids, then all gathers, then the arithmetic -- the loop is
+  // latency-bound otherwise (one dependent col -> gather chain in flight per wave)
+  constexpr int EU = 4;
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
+    uint32_t c[EU];
+    HeadVec<H> t[EU];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      t.v[h] = ssrc.v[h] + t.v[h];
-      s.v[h] = t.v[h] > 0.0f ? t.v[h] : eps * t.v[h];
-      // online softmax statistics with one expf: ex = exp(-|s - m|)
-      const bool up = s.v[h] > m.v[h];
-      const float ex = expf(up ? m.v[h] - s.v[h] : s.v[h] - m.v[h]);
-      d.v[h] = up ? d.v[h] * ex + 1.0f : d.v[h] + ex;
-      m.v[h] = up ? s.v[h] : m.v[h];
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      c[u] = eu < o.e1 ? col[eu] : 0u;
     }
-    t.store(temp + e * H);
-    if (scores) s.store(scores + e * H);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) t[u].load(sr + (int64_t)c[u] * H);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      if (eu < o.e1) {
+        HeadVec<H> s;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          t[u].v[h] = ssrc.v[h] + t[u].v[h];
+          s.v[h] = t[u].v[h] > 0.0f ? t[u].v[h] : eps * t[u].v[h];
+          // online softmax statistics with one expf: ex = exp(-|s - m|)
+          const bool up = s.v[h] > m.v[h];
+          const float ex = __expf(up ? m.v[h] - s.v[h] : s.v[h] - m.v[h]);
+          d.v[h] = up ? d.v[h] * ex + 1.0f : d.v[h] + ex;
+          m.v[h] = up ? s.v[h] : m.v[h];
+        }
+        t[u].store(temp + eu * H);
+        if (scores) s.store(scores + eu * H);
+      }
+    }
   }
   owner_softmax_stats<H, BLK>(m, d, o.wave, o.lane, lds);
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {  // each thread re-reads only its own writes
-    HeadVec<H> t;
-    t.load(temp + e * H);
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const float sv = t.v[h] > 0.0f ? t.v[h] : eps * t.v[h];
-      t.v[h] = expf(sv - m.v[h]) / d.v[h];
+  for (int h = 0; h < H; ++h) d.v[h] = 1.0f / d.v[h];
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {  // each thread re-reads only its own writes
+    HeadVec<H> t[EU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      t[u].load(temp + (eu < o.e1 ? eu : o.e0) * H);
     }
-    t.store(norm + e * H);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      if (eu < o.e1) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float sv = t[u].v[h] > 0.0f ? t[u].v[h] : eps * t[u].v[h];
+          t[u].v[h] = __expf(sv - m.v[h]) * d.v[h];  // d holds 1/D here
+        }
+        t[u].store(norm + eu * H);
+      }
+    }
   }
 }
 
@@ -501,41 +530,75 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2
     }
     owner_sum<H, BLK>(dot, o.wave, o.lane, lds);
   }
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
-    HeadVec<H> a, b, t, ds, ge;
-    a.load(p + e * H);
-    b.load(dp + e * H);
-    t.load(temp + e * H);
+  constexpr int EU = H >= 8 ? 2 : 4;  // three streams per edge: keep the live registers in check
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
+    HeadVec<H> a[EU], b[EU], t[EU];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const float x = a.v[h] * (1.0f - a.v[h]) * b.v[h];
-      ds.v[h] = x - (dot.v[h] - a.v[h] * b.v[h]) * a.v[h];
-      ge.v[h] = ds.v[h] * (t.v[h] > 0.0f ? 1.0f : eps);
-      gs.v[h] += ge.v[h];
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t es = eu < o.e1 ? eu : o.e0;
+      a[u].load(p + es * H);
+      b[u].load(dp + es * H);
+      t[u].load(temp + es * H);
     }
-    if (scores) ds.store(scores + e * H);
-    ge.store(gbuf + e * H);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      if (eu < o.e1) {
+        HeadVec<H> ds, ge;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float x = a[u].v[h] * (1.0f - a[u].v[h]) * b[u].v[h];
+          ds.v[h] = x - (dot.v[h] - a[u].v[h] * b[u].v[h]) * a[u].v[h];
+          ge.v[h] = ds.v[h] * (t[u].v[h] > 0.0f ? 1.0f : eps);
+          gs.v[h] += ge.v[h];
+        }
+        if (scores) ds.store(scores + eu * H);
+        ge.store(gbuf + eu * H);
+      }
+    }
   }
   owner_sum<H, BLK>(gs, o.wave, o.lane, lds);
   if (o.tid == 0) gs.store(rs + o.row * H);
 }
 
-// cs[v] = sum_{e in row v} g[rev[e]]  == column sum of g (structurally symmetric graph)
+// cs[v] = sum_{e in row v} g[rev[e]]  == column sum of g (structurally symmetric graph); optionally also
+// pT[e] = p[rev[e]] (symmetric_csr_transpose of the attention, gat_aggregator.cpp:172-175)
 template <int H, bool BLK>
 __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kernel(
-    int64_t nv, const int64_t* rowptr, const uint32_t* rev, const float* gbuf, float* cs, int heavy_thr,
-    const uint32_t* row_list, const uint32_t* row_order) {
+    int64_t nv, const int64_t* rowptr, const uint32_t* rev, const float* gbuf, float* cs, const float* p,
+    float* pT, int heavy_thr, const uint32_t* row_list, const uint32_t* row_order) {
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
   const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
   if (!o.valid) return;
   HeadVec<H> s;
 #pragma unroll
   for (int h = 0; h < H; ++h) s.v[h] = 0.f;
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
-    HeadVec<H> g;
-    g.load(gbuf + (int64_t)rev[e] * H);
+  constexpr int EU = 4;
+  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
+    int64_t r[EU];
+    HeadVec<H> g[EU];
 #pragma unroll
-    for (int h = 0; h < H; ++h) s.v[h] += g.v[h];
+    for (int u = 0; u < EU; ++u) {
+      const int64_t eu = e + (int64_t)u * o.nthreads;
+      r[u] = eu < o.e1 ? (int64_t)rev[eu] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * H);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      if (r[u] >= 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) s.v[h] += g[u].v[h];
+      }
+    }
+    if (pT) {  // the transposed attention for the gradient aggregation, while rev[e] is at hand
+#pragma unroll
+      for (int u = 0; u < EU; ++u) g[u].load(p + (r[u] < 0 ? 0 : r[u]) * H);
+#pragma unroll
+      for (int u = 0; u < EU; ++u)
+        if (r[u] >= 0) g[u].store(pT + (e + (int64_t)u * o.nthreads) * H);
+    }
   }
   owner_sum<H, BLK>(s, o.wave, o.lane, lds);
   if (o.tid == 0) s.store(cs + o.row * H);
@@ -586,7 +649,7 @@ int launch_edge_softmax(gaib_ctx* ctx, gaib_graph* g, const float* sl, const flo
 
 template <int H>
 int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float* dp, const float* temp, float eps,
-                       const float* rowdot, float* scores, float* gbuf, float* rs, float* cs) {
+                       const float* rowdot, float* scores, float* gbuf, float* rs, float* cs, float* pT) {
   GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
   const uint32_t* rl = g->heavy_rows;
   const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;
@@ -600,8 +663,8 @@ int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float
     softmax_bwd_v2_kernel<H, false, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
   }
   GAIB_LAUNCH_CHECK();
-  if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, thr, rl, ro);
-  colsum_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, thr, rl, ro);
+  if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, p, pT, thr, rl, ro);
+  colsum_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, p, pT, thr, rl, ro);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -718,7 +781,7 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
                                              const float* d_temp_scores, float epsilon,
                                              float* d_scores, float* d_alpha_lgrad,
                                              float* d_alpha_rgrad, const float* d_grad_rows,
-                                             const float* d_fwd_out_rows) {
+                                             const float* d_fwd_out_rows, float* d_norm_scores_t) {
   GAIB_CHECK(ctx && g, "gaib_gat_softmax_bwd_alpha: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_softmax_bwd_alpha", len, heads));
   GAIB_CHECK(d_alpha_lgrad && d_alpha_rgrad, "gaib_gat_softmax_bwd_alpha: NULL alpha grad");
@@ -748,10 +811,11 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
     rowdot = nullptr;
   }
   const bool al16 = (((uintptr_t)d_norm_scores | (uintptr_t)d_norm_scores_grad | (uintptr_t)d_temp_scores |
-                      (uintptr_t)d_scores | (uintptr_t)gbuf | (uintptr_t)rs | (uintptr_t)cs) & 15) == 0;
+                      (uintptr_t)d_scores | (uintptr_t)gbuf | (uintptr_t)rs | (uintptr_t)cs |
+                      (uintptr_t)d_norm_scores_t) & 15) == 0;
   int rc = GAIB_OK;
 #define GAIB_SBW(HH) rc = launch_softmax_bwd<HH>(ctx, g, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, \
-                                                 rowdot, d_scores, gbuf, rs, cs)
+                                                 rowdot, d_scores, gbuf, rs, cs, d_norm_scores_t)
   if (heads == 1) GAIB_SBW(1);
   else if (heads == 2) GAIB_SBW(2);
   else if (heads == 4 && al16) GAIB_SBW(4);
@@ -763,6 +827,10 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
                                                                 d_norm_scores_grad, d_temp_scores, epsilon,
                                                                 d_scores, gbuf, rs);
     colsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->rev, gbuf, cs);
+    if (d_norm_scores_t) {
+      GAIB_LAUNCH_CHECK();
+      GAIB_TRY(gaib_edge_transpose_mh(ctx, g, heads, d_norm_scores, d_norm_scores_t));
+    }
   }
 #undef GAIB_SBW
   if (rc != GAIB_OK) return rc;
@@ -783,7 +851,7 @@ extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int l
                                              float* d_scores, float* d_alpha_lgrad,
                                              float* d_alpha_rgrad) {
   return gaib_gat_softmax_bwd_alpha_ex(ctx, g, len, heads, d_feat, d_norm_scores, d_norm_scores_grad, d_temp_scores,
-                                       epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad, nullptr, nullptr);
+                                       epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad, nullptr, nullptr, nullptr);
 }
 
 extern "C" int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_feat,

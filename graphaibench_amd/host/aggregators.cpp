@@ -100,7 +100,7 @@ void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* 
 GAT_Aggregator::GAT_Aggregator()
     : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
-      d_norm_scores_grad(NULL), fwd_out(NULL), alpha_opt(NULL) {}
+      d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), alpha_opt(NULL) {}
 
 void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   length = l;
@@ -124,6 +124,7 @@ void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   d_temp_scores = gaib_host::dmalloc<float>(num_edges);
   d_norm_scores = gaib_host::dmalloc<float>(num_edges);
   d_norm_scores_grad = gaib_host::dmalloc<float>(num_edges);
+  d_norm_scores_t = gaib_host::dmalloc<float>(num_edges);
   epsilon = 0.2f;
   alpha_opt = new adam(lr);
 }
@@ -135,7 +136,7 @@ void GAT_Aggregator::set_num_heads(int h) {
   }
   if (h == heads) return;
   heads = h;
-  float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
+  float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
   for (float** a : arrays) {
     float_free_device(*a);
     *a = gaib_host::dmalloc<float>(num_edges * heads);
@@ -145,7 +146,7 @@ void GAT_Aggregator::set_num_heads(int h) {
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
     num_edges = g.sizeEdges();
-    float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad};
+    float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
     for (float** a : arrays) {
       float_free_device(*a);
       *a = gaib_host::dmalloc<float>(num_edges * heads);
@@ -177,13 +178,14 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
     // sum_e p_e dp_e == <grad_i, out_i> (out_i = sum_e p_e h_col; where relu cut out_i the gradient is 0 too)
     const float* fwd = fwd_out;
     fwd_out = NULL;
+    // the pass that walks rev anyway also leaves the transposed attention p[rev(e)] in d_norm_scores_t, so the
+    // gradient aggregation reads its weights linearly
     GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_ex(C(), dev(g), len, heads, feat_in, d_norm_scores, d_norm_scores_grad,
                                               d_temp_scores, epsilon, NULL, d_alpha_lgrad, d_alpha_rgrad,
-                                              fwd ? grad_in : NULL, fwd));
+                                              fwd ? grad_in : NULL, fwd, d_norm_scores_t));
   }
-  // transpose + aggregation fused: w_e = norm_scores[rev(e)]
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE_T, d_norm_scores, heads, len, grad_in, grad_out, 0));
+  GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores_t, heads, len, grad_in, grad_out, 0));
 }
 
 void GAT_Aggregator::update_weights(optimizer*) {

@@ -186,12 +186,15 @@ int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const floa
                                float* d_alpha_lgrad, float* d_alpha_rgrad);
 /* general form: H heads; d_scores (the softmax-input gradient ds) may be NULL when the caller does not read it;
  * d_grad_rows / d_fwd_out_rows (both or neither, [nv x len]): the gradient and the forward output of the
- * aggregation -- sum_e p_e dp_e is then taken per vertex as <grad_i, out_i> and the edge arrays are read once. */
+ * aggregation -- sum_e p_e dp_e is then taken per vertex as <grad_i, out_i> and the edge arrays are read once;
+ * d_norm_scores_t (optional, [ne][heads]) receives the transposed attention p[rev(e)] (symmetric_csr_transpose,
+ * gat_aggregator.cpp:172-175), produced in the pass that already walks rev: the gradient aggregation can then read
+ * it linearly (GAIB_W_EDGE) instead of through the permutation (GAIB_W_EDGE_T). */
 int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
                                   const float* d_norm_scores, const float* d_norm_scores_grad,
                                   const float* d_temp_scores, float epsilon, float* d_scores,
                                   float* d_alpha_lgrad, float* d_alpha_rgrad, const float* d_grad_rows,
-                                  const float* d_fwd_out_rows);
+                                  const float* d_fwd_out_rows, float* d_norm_scores_t);
 /* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):
  *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
 int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);

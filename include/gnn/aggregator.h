@@ -86,7 +86,7 @@ class GAT_Aggregator : public aggregator {
   size_t num_edges;
   int heads;
   float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
-  float *d_temp_scores, *d_norm_scores, *d_norm_scores_grad;
+  float *d_temp_scores, *d_norm_scores, *d_norm_scores_grad, *d_norm_scores_t;
   const float* fwd_out;  // see use_forward_output_once
   optimizer* alpha_opt;
 };

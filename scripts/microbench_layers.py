@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from graphaibench_amd import layers as L, synth  # noqa: E402
 
-KEYS = ["spmm_light", "spmm_heavy", "spmm_sub", "sgemm", "relu", "d_relu", "gat_vertex_dots", "gat_edge_softmax",
+KEYS = ["spmm_gemm_fused", "spmm_light", "spmm_heavy", "spmm_sub", "sgemm", "relu", "d_relu", "gat_vertex_dots", "gat_edge_softmax",
         "gat_sddmm", "gat_softmax_bwd_alpha"]
 
 
@@ -69,8 +69,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--only", default="", help="substring of the layer names to run (e.g. 'GAT')")
     args = ap.parse_args()
     ctx = L.init(0)
+    if args.only:
+        _run = run_layer
+
+        def run_layer_filtered(c, kind, name, *a, **k):
+            if args.only in name:
+                _run(c, kind, name, *a, **k)
+        globals()["run_layer"] = run_layer_filtered
     run_layer(ctx, L.SAGE, "SAGE 128->128", "ogbn-products", 128, 128, False, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 128->128", "ogbn-products", 128, 128, True, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 100->128 (layer 0 shape, level 1)", "ogbn-products", 100, 128, True, args.steps, args.scale)

@@ -410,8 +410,10 @@ def test_gat_backward_pieces(ctx, d, hub):
         sc2 = torch.zeros(g_o.ne, device="cuda")
         lg2 = torch.empty(d, device="cuda")
         rg2 = torch.empty(d, device="cuda")
+        pt2 = torch.zeros(g_o.ne, device="cuda")
         ctx.gat_softmax_bwd_alpha(g_d, hd, dev(norm), dev(want_ng), dev(temp), sc2 if keep_ds else None, lg2, rg2,
-                                  grad_rows=gd, fwd_out_rows=dev(out_w))
+                                  grad_rows=gd, fwd_out_rows=dev(out_w), norm_t=pt2)
+        assert np.array_equal(pt2.cpu().numpy(), orc.symmetric_csr_transpose(g_o, norm))  # a permutation: exact
         if keep_ds:
             assert rel_err(sc2.cpu().numpy(), want_ds) < TOL
         assert rel_err(lg2.cpu().numpy(), want_lg) < TOL
