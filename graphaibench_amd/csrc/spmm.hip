@@ -312,7 +312,6 @@ struct FuseArgs {
   int n_heavy;
   int* tile_counter;          // zeroed before the launch
   const float* agg_in;        // accumulate mode: partial sums to continue (same layout as the agg rows)
-  int dbg;
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -644,7 +643,6 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   f.heavy_agg = hv;
   f.heavy_rows = g->heavy_rows;
   f.n_heavy = (int)g->n_heavy;
-  f.dbg = ctx->spmm_fuse;
   if (len_in <= 64) {
     return wmode == 0 ? launch_fused<1, 0>(ctx, g, a, f, hv) : launch_fused<1, 1>(ctx, g, a, f, hv);
   }
