@@ -250,16 +250,18 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
   int variant = ctx->spmm_variant;
   // variant: 0 auto | 1 force w64 with VEC=1 | 2 force w64 VEC=2 | 4 force w64 VEC=4 |
   //          32 force sub-wave G=32 path with the widest vector (two 128-wide rows per wave)
+  // Measured on the products-shaped graph (scripts/microbench.py, every width from 4 to 256): one row per wave
+  // with 16 gathers in flight beats the packed sub-wave kernel at EVERY width (D=64: 4.3 vs 5.6 ms, D=32: 2.4
+  // vs 3.8, D=4: 2.2 vs 3.2), and among the one-row kernels the narrowest lane vector that covers the row in
+  // at most two passes wins (D=64: 4 B lanes 4.3 ms, 16 B lanes 5.3; D=256: 8 B lanes 17.4, 16 B lanes 17.9).
+  // The sub-wave kernel stays reachable as variant 32.
   const int lanes_max = (len + vmax - 1) / vmax;
-  bool use_sub = lanes_max < 32;
+  bool use_sub = false;
   int vec = vmax;
-  if (!use_sub) {
-    // smallest vector that still fits the row in one 64-lane pass (more lanes busy per load)
-    if (len <= 64) vec = 1;
-    else if (len <= 128 && vmax >= 2) vec = 2;
-    else vec = vmax;
-    if (WMODE >= 3 && a0.dh % vec != 0) vec = vmax;
-  }
+  if (len <= 64) vec = 1;
+  else if (len <= 256 && vmax >= 2) vec = 2;
+  else if (len <= 128) vec = 1;
+  if (WMODE >= 3 && a0.dh % vec != 0) vec = 1;
   if (variant == 1) { use_sub = false; vec = 1; }
   if (variant == 2 && vmax >= 2) { use_sub = false; vec = 2; }
   if (variant == 4 && vmax >= 4) { use_sub = false; vec = 4; }
@@ -600,11 +602,11 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
   GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out, "gaib_spmm_gemm: buffers must not alias");
   const uintptr_t al = (uintptr_t)d_in | (uintptr_t)d_agg | (uintptr_t)d_W;
   // op(W) [len_out x (len_in+4)] + 16 strips [8 x (len_in+4)] must fit the CU's 160 KB of LDS
-  // rows narrower than 33 floats are better served by the packed sub-wave kernel; 65..128 needs 8-byte lanes
+  // 65..128 columns need 8-byte lanes
   const int kpad = len_in <= 64 ? 64 : 128;
   const size_t fuse_lds = sizeof(float) * (size_t)(kpad + 4) * ((size_t)((len_out + 15) & ~15) + FUSE_WAVES * FUSE_ROWS / 2);
   const bool lanes_ok = len_in <= 64 ? true : (len_in % 2 == 0 && (al & 7) == 0);
-  const bool fusable = ctx->spmm_fuse != 0 && len_in > 32 && len_in <= 128 && lanes_ok &&
+  const bool fusable = ctx->spmm_fuse != 0 && len_in >= 1 && len_in <= 128 && lanes_ok &&
                        fuse_lds <= 160 * 1024 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);

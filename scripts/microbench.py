@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--graph", default="ogbn-products")
+    ap.add_argument("--cache-modes", action="store_true", help="also sweep the gather cache policies")
     args = ap.parse_args()
     ctx = capi.Context(0)
     t0 = time.time()
@@ -68,20 +69,22 @@ def main():
         res.append(r)
 
     run("default")
-    run("gather_nt_all", spmm_gather_mode=2)
-    for hb in (64 << 20, 128 << 20, 192 << 20, 256 << 20, 384 << 20, 512 << 20, 768 << 20, 1024 << 20):
-        ctx.set_option("spmm_hot_bytes", hb)
-        run(f"gather_hotcold_{hb >> 20}MB", spmm_gather_mode=3)
-    ctx.set_option("spmm_hot_bytes", 3 << 20)
-    run("default_again")
+    if args.cache_modes:
+        run("gather_nt_all", spmm_gather_mode=2)
+        for hb in (64 << 20, 128 << 20, 192 << 20, 256 << 20, 384 << 20, 512 << 20, 768 << 20, 1024 << 20):
+            ctx.set_option("spmm_hot_bytes", hb)
+            run(f"gather_hotcold_{hb >> 20}MB", spmm_gather_mode=3)
+        ctx.set_option("spmm_hot_bytes", 3 << 20)
+        run("default_again")
     run("unroll8", spmm_unroll=8)
     run("global_addr", spmm_addr_mode=2)
     run("global_addr_unroll8", spmm_addr_mode=2, spmm_unroll=8)
     run("no_xcd_swizzle", spmm_xcd_swizzle=0)
-    if d == 128:
+    if d <= 128:
         run("vec4_sub32", spmm_variant=32)
-        run("vec4_w64", spmm_variant=4)
-        run("vec1_ct2", spmm_variant=1)
+    run("vec4_w64", spmm_variant=4)
+    run("vec2_w64", spmm_variant=2)
+    run("vec1_w64", spmm_variant=1)
     for thr in (256, 4096, 1 << 20):
         run(f"heavy_thr_{thr}", spmm_heavy_threshold=thr)
     # SAGE mean (row weight) for comparison

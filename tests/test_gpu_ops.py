@@ -643,7 +643,7 @@ def test_side_section_overlaps_and_orders(ctx):
     (128, 47, "mean", True, False),    # ragged output width
     (60, 50, "mean_t", False, True),
     (101, 40, "gcn", False, True),     # not fusable (odd K > 64): two-kernel path
-    (16, 7, "gcn", False, False),      # narrow rows stay on the packed sub-wave kernel + GEMM
+    (16, 7, "gcn", False, False),      # cora-sized widths
     (256, 64, "mean", False, True),    # K > 128: two-kernel path
 ])
 def test_spmm_gemm_fused(ctx, len_in, len_out, kind, transW, relu):
