@@ -510,8 +510,8 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
 template <int H, bool BLK, bool DOT>
 __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2_kernel(
     int64_t nv, const int64_t* rowptr, const float* p, const float* dp, const float* temp, float eps,
-    const float* rowdot, float* scores, float* gbuf, float* rs, int heavy_thr, const uint32_t* row_list,
-    const uint32_t* row_order) {
+    const float* rowdot, float* scores, float* gbuf, int pack, float* rs, int heavy_thr,
+    const uint32_t* row_list, const uint32_t* row_order) {
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
   const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
   if (!o.valid) return;
@@ -554,7 +554,12 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2
           gs.v[h] += ge.v[h];
         }
         if (scores) ds.store(scores + eu * H);
-        ge.store(gbuf + eu * H);
+        if (pack) {  // (g, p) side by side: the column-sum pass fetches both with one random access
+          ge.store(gbuf + eu * 2 * H);
+          a[u].store(gbuf + eu * 2 * H + H);
+        } else {
+          ge.store(gbuf + eu * H);
+        }
       }
     }
   }
@@ -563,10 +568,11 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2
 }
 
 // cs[v] = sum_{e in row v} g[rev[e]]  == column sum of g (structurally symmetric graph); optionally also
-// pT[e] = p[rev[e]] (symmetric_csr_transpose of the attention, gat_aggregator.cpp:172-175)
+// pT[e] = p[rev[e]] (symmetric_csr_transpose of the attention, gat_aggregator.cpp:172-175); gbuf then holds
+// (g, p) records written by softmax_bwd_v2_kernel
 template <int H, bool BLK>
 __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kernel(
-    int64_t nv, const int64_t* rowptr, const uint32_t* rev, const float* gbuf, float* cs, const float* p,
+    int64_t nv, const int64_t* rowptr, const uint32_t* rev, const float* gbuf, float* cs,
     float* pT, int heavy_thr, const uint32_t* row_list, const uint32_t* row_order) {
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
   const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kern
       r[u] = eu < o.e1 ? (int64_t)rev[eu] : -1;
     }
 #pragma unroll
-    for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * H);
+    for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * (pT ? 2 : 1) * H);
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       if (r[u] >= 0) {
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kern
     }
     if (pT) {  // the transposed attention for the gradient aggregation, while rev[e] is at hand
 #pragma unroll
-      for (int u = 0; u < EU; ++u) g[u].load(p + (r[u] < 0 ? 0 : r[u]) * H);
+      for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * 2 * H + H);  // same line as g
 #pragma unroll
       for (int u = 0; u < EU; ++u)
         if (r[u] >= 0) g[u].store(pT + (e + (int64_t)u * o.nthreads) * H);
@@ -656,15 +662,15 @@ int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float
   const int thr = g->n_heavy > 0 ? g->heavy_thr : 0;
   const unsigned nh = (unsigned)g->n_heavy, blk = ROW_BLK_WAVES * 64;
   if (rowdot) {
-    if (nh) softmax_bwd_v2_kernel<H, true, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
-    softmax_bwd_v2_kernel<H, false, true><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
+    if (nh) softmax_bwd_v2_kernel<H, true, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
+    softmax_bwd_v2_kernel<H, false, true><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
   } else {
-    if (nh) softmax_bwd_v2_kernel<H, true, false><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
-    softmax_bwd_v2_kernel<H, false, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, rs, thr, rl, ro);
+    if (nh) softmax_bwd_v2_kernel<H, true, false><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
+    softmax_bwd_v2_kernel<H, false, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
   }
   GAIB_LAUNCH_CHECK();
-  if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, p, pT, thr, rl, ro);
-  colsum_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, p, pT, thr, rl, ro);
+  if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
+  colsum_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -795,7 +801,7 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
   const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };  // keep every slab 16-byte aligned
-  const size_t n_g = up4((size_t)g->ne * heads), n_v = up4((size_t)g->nv * heads);
+  const size_t n_g = up4((size_t)g->ne * heads * (d_norm_scores_t ? 2 : 1)), n_v = up4((size_t)g->nv * heads);
   const size_t ws_floats = n_g + 3 * n_v + (size_t)nblocks * 2 * len;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * ws_floats));
   float* gbuf = (float*)ctx->ws;
