@@ -65,6 +65,7 @@ SIGNATURES = {
     "gaib_gat_softmax_bwd_alpha": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_edge_transpose": (_i, [_vp, _vp, _vp, _vp]),
     "gaib_sgemm": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
+    "gaib_sgemm_drelu": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _vp]),
     "gaib_sgemm_ex": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
     "gaib_relu": (_i, [_vp, _i64, _vp, _vp]),
     "gaib_d_relu": (_i, [_vp, _i64, _vp, _vp, _vp]),
@@ -231,6 +232,13 @@ class Context:
         _check(self.lib.gaib_edge_transpose_mh(self.h, g.h, heads, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")
 
     # ---- dense ----------------------------------------------------------------------------
+    def sgemm_drelu(self, A, G, mask, Cm, accum=False):
+        """G <- G * (mask > 0) in place; Cm (+)= A^T . G   (A [K x M], G / mask [K x N])"""
+        K, M = A.shape
+        assert G.shape == mask.shape and G.shape[0] == K and tuple(Cm.shape) == (M, G.shape[1])
+        _check(self.lib.gaib_sgemm_drelu(self.h, M, G.shape[1], K, _ptr(A), _ptr(G), _ptr(mask), 1 if accum else 0,
+                                         _ptr(Cm)), "gaib_sgemm_drelu")
+
     def sgemm(self, A, B, Cm, transA=False, transB=False, accum=False, relu=False):
         """row-major C[M x N] (=|+=) op(A) . op(B); shapes follow the reference's matmul()."""
         M, N = Cm.shape

@@ -39,6 +39,10 @@ struct GemmArgs {
   int relu;         // clamp at 0 in the epilogue (ignored when writing split-K partials)
   int64_t slab;     // M*N when writing partials (C + blockIdx.y*slab), else 0
   int tiles_n;
+  // BMASK kernels (weight gradient with d_relu folded in): op(B) = B where bmask > 0 else 0, and the masked
+  // B is written back through bwrite (by the workgroups of the first M tile only)
+  const float* bmask;
+  float* bwrite;
 };
 
 // Load a TR x TC tile (TC % 4 == 0) of a row-major matrix [R][Cc] (leading dim ld) starting at
@@ -69,6 +73,31 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t
   }
 }
 
+// the mirror of tile_load: registers -> the same TR x TC window of a row-major matrix
+template <int TR, int TC, bool VEC4>
+__device__ __forceinline__ void tile_store_global(float* __restrict__ dst, int64_t R, int64_t Cc, int64_t ld,
+                                                  int64_t r0, int64_t c0,
+                                                  const f4 (&regs)[TR * TC / 4 / THREADS]) {
+  constexpr int CPR = TC / 4;
+  constexpr int NCH = TR * TC / 4 / THREADS;
+#pragma unroll
+  for (int s = 0; s < NCH; ++s) {
+    const int q = threadIdx.x + s * THREADS;
+    const int r = q / CPR, cq = q % CPR;
+    const int64_t gr = r0 + r, gc = c0 + cq * 4;
+    if (gr < R) {
+      float* p = dst + gr * ld + gc;
+      if (VEC4 && gc + 3 < Cc) {
+        *reinterpret_cast<f4*>(p) = regs[s];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gc + e < Cc) p[e] = regs[s][e];
+      }
+    }
+  }
+}
+
 template <int TR, int TC>
 __device__ __forceinline__ void tile_store_lds(float* lds, const f4 (&regs)[TR * TC / 4 / THREADS]) {
   constexpr int CPR = TC / 4;
@@ -84,8 +113,10 @@ __device__ __forceinline__ void tile_store_lds(float* lds, const f4 (&regs)[TR *
 
 // WAVES_M x WAVES_N waves, each WM x WN tiles of 32x32.
 // A_KMAJOR: op(A) is stored [K][M] (transA);  B_KMAJOR: op(B) is stored [K][N] (no transB).
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC, int OCC>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC, int OCC,
+          bool BMASK = false>
 __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
+  static_assert(!BMASK || B_KMAJOR, "the B mask is implemented for row-major [K][N] B operands");
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int BM = WAVES_M * WM * 32;
   constexpr int BN = WAVES_N * WN * 32;
@@ -123,6 +154,15 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
     else tile_load<BM, BK, AVEC>(g.A, g.M, g.K, g.K, m0, k0, ra);
     if constexpr (B_KMAJOR) tile_load<BK, BN, BVEC>(g.B, g.K, g.N, g.N, k0, n0, rb);
     else tile_load<BN, BK, BVEC>(g.B, g.N, g.K, g.K, n0, k0, rb);
+    if constexpr (BMASK) {
+      f4 rm[B_ELEMS / 4 / THREADS];
+      tile_load<BK, BN, BVEC>(g.bmask, g.K, g.N, g.N, k0, n0, rm);
+#pragma unroll
+      for (int s = 0; s < B_ELEMS / 4 / THREADS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[s][e] = rm[s][e] > 0.f ? rb[s][e] : 0.f;  // d_relu (math_functions.cu:258-268)
+      if (g.bwrite && m0 == 0) tile_store_global<BK, BN, BVEC>(g.bwrite, g.K, g.N, g.N, k0, n0, rb);
+    }
   };
   auto store_tiles = [&]() {
     if constexpr (A_KMAJOR) tile_store_lds<BK, BM>(As, ra);
@@ -254,6 +294,19 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
 #define GAIB_GEMM_LAUNCH(AV, BV, OCC)                                                    \
   sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV, OCC><<<grid, THREADS, 0, ctx->stream>>>(g)
   const int occ = ctx->sgemm_variant == 2 ? 2 : ((ctx->sgemm_variant == 4 || ctx->sgemm_variant >= 10) ? 4 : 3);
+  if constexpr (AK && BKM) {
+    if (g.bmask) {  // (the entry point only takes this path with 16-B aligned operands)
+      sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 3, true><<<grid, THREADS, 0, ctx->stream>>>(g);
+      GAIB_LAUNCH_CHECK();
+      if (splits > 1) {
+        const int64_t n = g.M * g.N;
+        unsigned rg = (unsigned)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
+        splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, splits, (const float*)ctx->ws, accum, g.relu, Cout);
+        GAIB_LAUNCH_CHECK();
+      }
+      return GAIB_OK;
+    }
+  }
   if (avec && bvec) {
     if (occ == 4) GAIB_GEMM_LAUNCH(true, true, 4);
     else if (occ == 3) GAIB_GEMM_LAUNCH(true, true, 3);
@@ -325,6 +378,8 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   g.relu = (flags & GAIB_RELU) ? 1 : 0;
   g.slab = 0;
   g.tiles_n = 1;
+  g.bmask = nullptr;
+  g.bwrite = nullptr;
   // 16-B loads need an aligned base and a leading dimension that keeps rows aligned
   const int64_t lda = transA ? M : K;
   const int64_t ldb = transB ? K : N;
@@ -333,4 +388,37 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
   if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);
   return dispatch_shape<true, true>(ctx, g, avec, bvec);
+}
+
+// weight gradient with the layer's d_relu folded in (graph_conv_layer backward: d_relu_gpu on grad_in, then
+// matmul(transA) -- gcn_layer.cpp:33-52):  G <- G where mask > 0 else 0 (in place), C (=|+=) A^T . G.
+// A is [K x M], G and mask are [K x N].  One pass over G instead of d_relu's read-modify-write plus the GEMM's read.
+extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* d_A, float* d_G,
+                                const float* d_mask, int accum, float* d_C) {
+  GAIB_CHECK(ctx, "gaib_sgemm_drelu: ctx is NULL");
+  GAIB_CHECK(M >= 0 && N >= 0 && K >= 0, "gaib_sgemm_drelu: negative dimension");
+  GAIB_CHECK(K == 0 || N == 0 || (d_G && d_mask), "gaib_sgemm_drelu: G/mask is NULL");
+  const bool aligned = ((((uintptr_t)d_A | (uintptr_t)d_G | (uintptr_t)d_mask) & 15) == 0) && M % 4 == 0 && N % 4 == 0;
+  if (M == 0 || N == 0 || K == 0 || !aligned || N <= 64) {
+    // shapes the masked kernel is not built for: the two-step form
+    if (K > 0 && N > 0) GAIB_TRY(gaib_d_relu(ctx, K * N, d_G, d_mask, d_G));
+    return gaib_sgemm(ctx, 1, 0, M, N, K, d_A, d_G, accum, d_C);
+  }
+  GAIB_CHECK(d_C && d_A, "gaib_sgemm_drelu: A/C is NULL");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  GemmArgs g;
+  g.A = d_A;
+  g.B = d_G;
+  g.C = d_C;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.k_chunk = K;
+  g.accum = accum ? 1 : 0;
+  g.relu = 0;
+  g.slab = 0;
+  g.tiles_n = 1;
+  g.bmask = d_mask;
+  g.bwrite = d_G;
+  return launch<2, 2, 2, 2, true, true>(ctx, g, true, true);  // 128 x 128 split-K tile, as the plain weight gradient
 }

@@ -102,19 +102,18 @@ void GCN_layer::forward(float* feat_out) {
 
 void GCN_layer::backward(float* feat_out, float* grad_out) {
   const size_t x = num_samples, y = dim_in, z = dim_out;
-  if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);  // in place, mask = post-activation output
+  // d_relu (gcn_layer.cpp:35) runs in place on grad_in with the post-activation output as mask (Q9)
   if (y > z) {
+    if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
     if (level_ > 0) aggr.d_aggregate_matmul(z, *graph, grad_in, d_out_temp, true, d_W_neigh, true, y, grad_out);
     else aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
     float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
-    // the weight gradient (MFMA-bound) is independent of the input gradient (HBM-bound
-    // aggregation): it runs next to it on the side stream
-    if (level_ > 0) gpu_context::side_begin();
-    matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
+    // the weight gradient goes first and applies the d_relu while it streams grad_in (one pass instead of two)
+    if (is_act) matmul_drelu(y, z, x, d_in_temp1, grad_in, feat_out, d_W_neigh_grad);
+    else matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
     if (level_ > 0) {
-      gpu_context::side_end();
       if (y == z) {
         // A.(g.W^T) == (A.g).W^T: at equal widths the aggregation goes first and carries the product
         // (the reference order would cost a separate GEMM pass; same result up to summation order)
@@ -123,7 +122,6 @@ void GCN_layer::backward(float* feat_out, float* grad_out) {
         matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
         aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
       }
-      gpu_context::side_wait();
     }
   }
   if (level_ != 0 && feat_dropout_rate > 0.)
@@ -155,22 +153,16 @@ void SAGE_layer::forward(float* feat_out) {
 
 void SAGE_layer::backward(float* feat_out, float* grad_out) {
   const size_t x = num_samples, y = dim_in, z = dim_out;
-  if (is_act) d_relu_gpu(x * z, grad_in, feat_out, grad_in);
   float* in_data = feat_dropout_rate > 0. ? d_in_temp : feat_in;
-  // the two weight gradients can run on the side stream next to the aggregation (GAIB_OVERLAP=1).
-  // NB with feature dropout in_data == d_in_temp, which the else-branch overwrites: no side section then
-  const bool overlap = (y > z) || (level_ > 0 && in_data != d_in_temp);
-  if (overlap) gpu_context::side_begin();
-  matmul(y, z, x, in_data, grad_in, d_W_self_grad, true, false);
+  // the first product that streams grad_in applies the layer's d_relu on the way (in place, Q9)
+  if (is_act) matmul_drelu(y, z, x, in_data, grad_in, feat_out, d_W_self_grad);
+  else matmul(y, z, x, in_data, grad_in, d_W_self_grad, true, false);
   if (y > z) {
-    gpu_context::side_end();
     if (level_ > 0) aggr.d_aggregate_matmul(z, *graph, grad_in, d_out_temp, true, d_W_neigh, true, y, grad_out);
     else aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
-    gpu_context::side_wait();
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
     matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
-    if (overlap) gpu_context::side_end();
     if (level_ > 0) {
       if (y == z) {  // (M^T g).W^T instead of M^T (g.W^T): the product rides on the aggregation
         aggr.d_aggregate_matmul(z, *graph, grad_in, d_in_temp, false, d_W_neigh, true, y, grad_out);
@@ -179,7 +171,6 @@ void SAGE_layer::backward(float* feat_out, float* grad_out) {
         aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
       }
     }
-    if (overlap) gpu_context::side_wait();
   }
   if (level_ > 0) matmul(x, y, z, grad_in, d_W_self, grad_out, false, true, true);  // += g.W_self^T
   if (level_ != 0 && feat_dropout_rate > 0.)

@@ -30,6 +30,12 @@ void matmul_relu(const size_t x, const size_t y, const size_t z, const float_t* 
                             (accum ? GAIB_ACCUMULATE : 0) | GAIB_RELU, C_));
 }
 
+void matmul_drelu(const size_t x, const size_t y, const size_t z, const float_t* A, float_t* G, const float_t* mask,
+                  float* C_) {
+  OpTimer t(OP_DENSEMM);
+  GAIB_OR_DIE(gaib_sgemm_drelu(C(), (int64_t)x, (int64_t)y, (int64_t)z, A, G, mask, 0, C_));
+}
+
 void init_const_gpu(size_t n, float_t value, float_t* array) { GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)n, value, array)); }
 void copy_gpu(size_t len, const float_t* in, float_t* out) {
   GAIB_OR_DIE(gaib_memcpy_d2d(C(), out, in, sizeof(float) * (size_t)len));

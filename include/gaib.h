@@ -219,6 +219,12 @@ int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int6
 int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
                   const float* d_A, const float* d_B, int flags, float* d_C);
 
+/* weight gradient with the layer's d_relu folded in (d_relu_gpu on grad_in followed by matmul(transA),
+ * gcn_layer.cpp:33-52): d_G <- d_G where d_mask > 0 else 0 (IN PLACE, what d_relu_gpu leaves behind) and
+ * C[M x N] (=|+=) A^T . G for A [K x M], G / mask [K x N].  One pass over G instead of two. */
+int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* d_A, float* d_G,
+                     const float* d_mask, int accum, float* d_C);
+
 /* ---- elementwise: relu_gpu / d_relu_gpu (math_functions.cu:242-268), dropout mask replay
  * d_dropout_gpu (:134-146) ---- */
 int gaib_relu(gaib_ctx* ctx, int64_t n, const float* d_in, float* d_out);

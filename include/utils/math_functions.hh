@@ -15,6 +15,10 @@ void matmul(const size_t x, const size_t y, const size_t z, const float_t* A, co
 void matmul_relu(const size_t x, const size_t y, const size_t z, const float_t* A, const float_t* B,
                  float* C, bool transA = false, bool transB = false, bool accum = false);
 
+// extension: d_relu_gpu(G, mask) in place fused into the weight-gradient product C = A^T . G  (A [z x x], G / mask [z x y])
+void matmul_drelu(const size_t x, const size_t y, const size_t z, const float_t* A, float_t* G, const float_t* mask,
+                  float* C);
+
 void init_const_gpu(size_t n, float_t value, float_t* array);  // element counts are size_t: N*D exceeds int at scale
 void copy_gpu(size_t len, const float_t* in, float_t* out);
 void relu_gpu(const size_t n, const float_t* in, float_t* out);

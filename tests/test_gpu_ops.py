@@ -723,3 +723,23 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, d, d_out):
     y2 = torch.empty(n, d_out, device="cuda")
     ctx.spmm_gemm(ge, capi.W_EDGE, xd, agg, dev(W), y2, relu=True, edge_w=dev(ew[:1]), accumulate=True)
     assert rel_err(y2.cpu().numpy(), y_w) < TOL
+
+
+@pytest.mark.parametrize("m,n,k,accum", [(128, 128, 20011, False), (100, 128, 9000, True), (256, 192, 4097, False),
+                                         (128, 47, 3000, False), (16, 64, 500, True), (130, 130, 777, False)])
+def test_sgemm_drelu(ctx, m, n, k, accum):
+    """weight gradient with d_relu folded in: G masked in place (== d_relu_gpu), C (+)= A^T . G"""
+    rng = np.random.default_rng(m + n + k)
+    A = rng.standard_normal((k, m)).astype(np.float32)
+    G = rng.standard_normal((k, n)).astype(np.float32)
+    mask = rng.standard_normal((k, n)).astype(np.float32)
+    mask[rng.random((k, n)) < 0.1] = 0.0  # exact zeros are masked out too (data > 0)
+    C0 = rng.standard_normal((m, n)).astype(np.float32)
+    Gm = orc.d_relu(G, mask)
+    want = orc.matmul(A, Gm, True, False, C0 if accum else None)
+    Gd, Cd = dev(G.copy()), dev(C0.copy())
+    ctx.sgemm_drelu(dev(A), Gd, dev(mask), Cd, accum=accum)
+    assert np.array_equal(Gd.cpu().numpy().view(np.uint32), Gm.view(np.uint32))  # the in-place d_relu is exact
+    assert rel_err(Cd.cpu().numpy(), want) < TOL
+    ref64 = A.T.astype(np.float64) @ Gm.astype(np.float64) + (C0 if accum else 0)
+    assert rel_err(Cd.cpu().numpy(), ref64) < 2e-5
