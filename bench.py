@@ -252,7 +252,14 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_dom,
+            # SURVEY 8d extras: perfect-reuse lower bound of one aggregation (every feature row read once) and the
+            # PMC-measured bytes as a fraction of the peak over the same launch time
+            "b_min_bytes_per_launch": 2 * nv * 4 * D + 4 * ne,
+            "hbm_measured_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         },
+        # the aggregation kernels alone (both SpMM launches of the step incl. heavy rows; the dense products that
+        # ride on them are inside): aggregated edges per second of kernel time
+        "aggregation_only_edges_per_s": edges_per_step * args.steps / max((ms_fused + ms_light + ms_heavy) * 1e-3, 1e-9),
         "breakdown_ms_per_step": {
             "spmm_gemm_fused": ms_fused / args.steps, "spmm_light": ms_light / args.steps,
             "spmm_heavy": ms_heavy / args.steps, "sgemm": ms_gemm / args.steps,
