@@ -111,6 +111,45 @@ def test_sgemm_full_size_vs_torch(ctx, products):
     assert (dw - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
+def test_fused_aggregation_product_full_size(ctx, products):
+    """gaib_spmm_gemm at the bench size: the aggregate it stores is bit-identical to gaib_spmm's, the product
+    equals torch's on it (fp64 on sampled rows), forward and (A g) W^T forms, fused == two-kernel path,
+    and the weight gradient with d_relu folded in equals d_relu + matmul."""
+    nv, g1 = products["nv"], products["g1"]
+    torch.manual_seed(5)
+    x = torch.randn(nv, D, device="cuda")
+    W = torch.randn(D, D, device="cuda") * 0.1
+    agg_ref = torch.empty(nv, D, device="cuda")
+    ctx.spmm(g1, capi.W_GCN, x, agg_ref)
+    agg = torch.empty(nv, D, device="cuda")
+    y = torch.empty(nv, D, device="cuda")
+    ctx.spmm_gemm(g1, capi.W_GCN, x, agg, W, y, relu=True)
+    assert torch.equal(agg, agg_ref)
+    rows = torch.randint(0, nv, (4096,), device="cuda")
+    want = torch.relu(agg_ref[rows].double() @ W.double())
+    assert ((y[rows].double() - want).norm() / want.norm()).item() < 1e-5
+    yt = torch.empty(nv, D, device="cuda")
+    ctx.spmm_gemm(g1, capi.W_GCN, x, agg, W, yt, transW=True, agg_scratch=True)
+    want_t = agg_ref[rows].double() @ W.double().T
+    assert ((yt[rows].double() - want_t).norm() / want_t.norm()).item() < 1e-5
+    ctx.set_option("spmm_fuse", 0)
+    try:
+        y2 = torch.empty(nv, D, device="cuda")
+        ctx.spmm_gemm(g1, capi.W_GCN, x, agg, W, y2, relu=True)
+    finally:
+        ctx.set_option("spmm_fuse", 1)
+    assert ((y2 - y).norm() / y.norm()).item() < 1e-6
+    # weight gradient with the d_relu folded in
+    gr = torch.randn(nv, D, device="cuda")
+    gm = torch.where(y > 0, gr, torch.zeros_like(gr))
+    dW = torch.empty(D, D, device="cuda")
+    g_inout = gr.clone()
+    ctx.sgemm_drelu(agg_ref, g_inout, y, dW)
+    assert torch.equal(g_inout, gm)
+    want_dw = agg_ref.double().T @ gm.double()
+    assert ((dW.double() - want_dw).norm() / want_dw.norm()).item() < 1e-5
+
+
 def test_gat_properties_reddit_size(ctx):
     sg = synth.make("reddit", seed=7, device="cuda")
     g = ctx.graph(sg.rowptr, sg.colidx).add_selfloop()
