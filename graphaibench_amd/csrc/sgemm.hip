@@ -114,7 +114,7 @@ __device__ __forceinline__ void tile_store_lds(float* lds, const f4 (&regs)[TR *
 // WAVES_M x WAVES_N waves, each WM x WN tiles of 32x32.
 // A_KMAJOR: op(A) is stored [K][M] (transA);  B_KMAJOR: op(B) is stored [K][N] (no transB).
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC, int OCC,
-          bool BMASK = false>
+          bool BMASK = false, bool DB = false>
 __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
   static_assert(!BMASK || B_KMAJOR, "the B mask is implemented for row-major [K][N] B operands");
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
   constexpr int B_LD = B_KMAJOR ? BN + 4 : BK + 4;
   constexpr int A_LDS = A_KMAJOR ? BK * A_LD : BM * A_LD;
   constexpr int B_LDS = B_KMAJOR ? BK * B_LD : BN * B_LD;
-  __shared__ __attribute__((aligned(16))) float lds[A_LDS + B_LDS];
+  // DB: two LDS images, one barrier per K-step (the next tile's LDS stores and global loads are issued before
+  // the MFMAs of the current one); otherwise one image and two barriers
+  __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * (A_LDS + B_LDS)];
   float* As = lds;
   float* Bs = lds + A_LDS;
 
@@ -174,15 +176,7 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
   // note: rows of the K range beyond kend must read as zero -> clamp through the R/Cc bound
   // (g.K is the true extent; a split's kend <= g.K and k_chunk % BK == 0, so a tile never
   // straddles two splits).
-  if (kbeg < kend) {
-    load_tiles(kbeg);
-    store_tiles();
-  }
-  __syncthreads();
-
-  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) load_tiles(k0 + BK);
+  auto compute_tile = [&](const float* As_, const float* Bs_) {
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float af[WM][4], bf[WN][4];
@@ -191,9 +185,9 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
         const int m = (wm * WM + a) * 32 + li;
         if constexpr (A_KMAJOR) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) af[a][t] = As[(kk * 8 + 4 * lh + t) * A_LD + m];
+          for (int t = 0; t < 4; ++t) af[a][t] = As_[(kk * 8 + 4 * lh + t) * A_LD + m];
         } else {
-          const f4 v = *reinterpret_cast<const f4*>(&As[m * A_LD + kk * 8 + 4 * lh]);
+          const f4 v = *reinterpret_cast<const f4*>(&As_[m * A_LD + kk * 8 + 4 * lh]);
 #pragma unroll
           for (int t = 0; t < 4; ++t) af[a][t] = v[t];
         }
@@ -203,9 +197,9 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
         const int n = (wn * WN + b) * 32 + li;
         if constexpr (B_KMAJOR) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bf[b][t] = Bs[(kk * 8 + 4 * lh + t) * B_LD + n];
+          for (int t = 0; t < 4; ++t) bf[b][t] = Bs_[(kk * 8 + 4 * lh + t) * B_LD + n];
         } else {
-          const f4 v = *reinterpret_cast<const f4*>(&Bs[n * B_LD + kk * 8 + 4 * lh]);
+          const f4 v = *reinterpret_cast<const f4*>(&Bs_[n * B_LD + kk * 8 + 4 * lh]);
 #pragma unroll
           for (int t = 0; t < 4; ++t) bf[b][t] = v[t];
         }
@@ -218,10 +212,52 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
           for (int b = 0; b < WN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
     }
+  };
+
+  if constexpr (DB) {
+    auto store_to = [&](int buf) {
+      float* Ad = lds + buf * (A_LDS + B_LDS);
+      float* Bd = Ad + A_LDS;
+      if constexpr (A_KMAJOR) tile_store_lds<BK, BM>(Ad, ra);
+      else tile_store_lds<BM, BK>(Ad, ra);
+      if constexpr (B_KMAJOR) tile_store_lds<BK, BN>(Bd, rb);
+      else tile_store_lds<BN, BK>(Bd, rb);
+    };
+    if (kbeg < kend) {
+      load_tiles(kbeg);
+      store_to(0);
+      if (kbeg + BK < kend) load_tiles(kbeg + BK);
+    }
     __syncthreads();
-    if (more) {
-      store_tiles();
+    int cur = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+      if (k0 + BK < kend) {
+        store_to(cur ^ 1);  // registers hold tile k0 + BK; image cur^1 was last read before the previous barrier
+        if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK);
+      }
+      const float* Ac = lds + cur * (A_LDS + B_LDS);
+      compute_tile(Ac, Ac + A_LDS);
       __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // note: rows of the K range beyond kend must read as zero -> clamp through the R/Cc bound
+    // (g.K is the true extent; a split's kend <= g.K and k_chunk % BK == 0, so a tile never
+    // straddles two splits).
+    if (kbeg < kend) {
+      load_tiles(kbeg);
+      store_tiles();
+    }
+    __syncthreads();
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      if (more) load_tiles(k0 + BK);
+      compute_tile(As, Bs);
+      __syncthreads();
+      if (more) {
+        store_tiles();
+        __syncthreads();
+      }
     }
   }
 
@@ -307,7 +343,13 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
       return GAIB_OK;
     }
   }
-  if (avec && bvec) {
+  if (avec && bvec && ctx->sgemm_variant >= 20) {
+    // experimental: LDS double buffering (one barrier per K-step); 20 -> 2 workgroups/CU, 21 -> 3
+    if (ctx->sgemm_variant == 21)
+      sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 3, false, true><<<grid, THREADS, 0, ctx->stream>>>(g);
+    else
+      sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 2, false, true><<<grid, THREADS, 0, ctx->stream>>>(g);
+  } else if (avec && bvec) {
     if (occ == 4) GAIB_GEMM_LAUNCH(true, true, 4);
     else if (occ == 3) GAIB_GEMM_LAUNCH(true, true, 3);
     else GAIB_GEMM_LAUNCH(true, true, 2);

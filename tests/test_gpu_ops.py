@@ -743,3 +743,20 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
     assert rel_err(Cd.cpu().numpy(), want) < TOL
     ref64 = A.T.astype(np.float64) @ Gm.astype(np.float64) + (C0 if accum else 0)
     assert rel_err(Cd.cpu().numpy(), ref64) < 2e-5
+
+
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21])
+def test_sgemm_experimental_variants_agree(ctx, variant):
+    """the tiling / double-buffer knobs (gaib_set_option sgemm_variant) change the schedule, not the result"""
+    rng = np.random.default_rng(variant)
+    try:
+        for (x, y, z, tA, tB) in [(1000, 128, 128, 0, 0), (777, 128, 96, 0, 1), (128, 128, 30011, 1, 0), (200, 72, 264, 0, 0)]:
+            A = rng.standard_normal((z, x) if tA else (x, z)).astype(np.float32)
+            B = rng.standard_normal((y, z) if tB else (z, y)).astype(np.float32)
+            want = orc.matmul(A, B, bool(tA), bool(tB))
+            ctx.set_option("sgemm_variant", variant)
+            Cd = torch.empty(x, y, device="cuda")
+            ctx.sgemm(dev(A), dev(B), Cd, bool(tA), bool(tB))
+            assert rel_err(Cd.cpu().numpy(), want) < TOL
+    finally:
+        ctx.set_option("sgemm_variant", 0)
