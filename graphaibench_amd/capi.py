@@ -54,6 +54,7 @@ SIGNATURES = {
     "gaib_spmm_acc": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "gaib_spmm_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i]),
     "gaib_spmm_gemm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i]),
+    "gaib_spmm_gemm2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i]),
     "gaib_spmm_mh": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i]),
     "gaib_gat_scores_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -202,12 +203,18 @@ class Context:
         return out
 
     def spmm_gemm(self, g: "Graph", kind: int, x, agg, W, out, transW: bool = False, relu: bool = False,
-                  agg_scratch: bool = False, edge_w=None, accumulate: bool = False):
+                  agg_scratch: bool = False, edge_w=None, accumulate: bool = False, rows2=None, W2=None):
         """agg = A.x ; out = act(agg . op(W)) (gaib_spmm_gemm: fused on the matrix cores when the shape allows)"""
         assert x.is_contiguous() and agg.is_contiguous() and W.is_contiguous() and out.is_contiguous()
         len_in, len_out = agg.shape[1], out.shape[1]
         assert tuple(W.shape) == ((len_out, len_in) if transW else (len_in, len_out))
         flags = (2 if relu else 0) | (4 if agg_scratch else 0) | (1 if accumulate else 0)
+        if rows2 is not None:  # + rows2 . op(W2) in the same store (gaib_spmm_gemm2)
+            assert rows2.is_contiguous() and W2.is_contiguous() and W2.shape == W.shape and rows2.shape[1] == len_in
+            _check(self.lib.gaib_spmm_gemm2(self.h, g.h, kind, _ptr(edge_w), len_in, _ptr(x), _ptr(agg), _ptr(W),
+                                            1 if transW else 0, _ptr(rows2), _ptr(W2), len_out, _ptr(out), flags),
+                   "gaib_spmm_gemm2")
+            return out
         _check(self.lib.gaib_spmm_gemm(self.h, g.h, kind, _ptr(edge_w), len_in, _ptr(x), _ptr(agg), _ptr(W),
                                        1 if transW else 0, len_out, _ptr(out), flags), "gaib_spmm_gemm")
         return out

@@ -314,28 +314,36 @@ struct FuseArgs {
   int n_heavy;
   int* tile_counter;          // zeroed before the launch
   const float* agg_in;        // accumulate mode: partial sums to continue (same layout as the agg rows)
+  const float* wt2;           // DUAL: second weight matrix [n_out][K], k-contiguous
+  const float* rows2;         // DUAL: second row operand [n_rows][ncols]:  y += rows2[i,:] . op(W2)
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int FUSE_ROWS = 16;
 constexpr int FUSE_WAVES = 16;
 
-template <int VEC, int WMODE, int U, int GM>
+// STRIP = rows a wave parks in LDS at a time (8, or 2 when two weight matrices have to fit);
+// DUAL: y = act(agg . op(W) + rows2 . op(W2)) -- the self term of a SAGE layer (sage_layer.cpp:22,50) in the same pass
+template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int K = 64 * VEC;  // padded inner dimension; a.ncols (<= K) columns are real
   constexpr int KQ = K / 4;
   constexpr int LDT = K + 4;
-  constexpr int HALF = FUSE_ROWS / 2;
+  constexpr int HALF = STRIP;
+  constexpr int NPASS = FUSE_ROWS / STRIP;
   extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n_pad = (f.n_out + 15) & ~15;
   float* wl = fuse_lds;                                            // [n_pad][LDT], zero padded
-  float* tile = fuse_lds + n_pad * LDT + wave * (HALF * LDT);      // [HALF][LDT]
+  float* wl2 = fuse_lds + n_pad * LDT;                             // DUAL: the second matrix
+  float* tile = fuse_lds + (DUAL ? 2 : 1) * n_pad * LDT + wave * (HALF * LDT);  // [HALF][LDT]
   for (int t = threadIdx.x; t < n_pad * K; t += FUSE_WAVES * 64) {
     const int n = t / K, k = t % K;
-    wl[n * LDT + k] = (n < f.n_out && k < a.ncols) ? f.wt[(int64_t)n * a.ncols + k] : 0.f;
+    const bool in = n < f.n_out && k < a.ncols;
+    wl[n * LDT + k] = in ? f.wt[(int64_t)n * a.ncols + k] : 0.f;
+    if constexpr (DUAL) wl2[n * LDT + k] = in ? f.wt2[(int64_t)n * a.ncols + k] : 0.f;
   }
   __syncthreads();  // the only workgroup barrier
   const int i = lane & 15, kq = lane >> 4;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
     float af[KQ];
 #pragma unroll
     for (int s = 0; s < KQ; ++s) af[s] = 0.f;
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NPASS; ++h) {
       for (int r = 0; r < HALF; ++r) {
         const int rr = h * HALF + r;
         const int row = row0 + rr;
@@ -397,8 +405,8 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
       // LDS operations of one wave complete in order; the fences keep the compiler from moving
       // the fragment reads above the row stores (and the next half's stores above the reads)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const bool mine = (i >> 3) == h;  // lanes whose A row sits in this half
-      const float* trow = tile + (i & 7) * LDT + kq * KQ;
+      const bool mine = (i / HALF) == h;  // lanes whose A row sits in this strip
+      const float* trow = tile + (i % HALF) * LDT + kq * KQ;
 #pragma unroll
       for (int s4 = 0; s4 < KQ / 4; ++s4) {
         const f32x4_t tv = *reinterpret_cast<const f32x4_t*>(trow + 4 * s4);
@@ -406,6 +414,31 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         for (int e = 0; e < 4; ++e) af[4 * s4 + e] = mine ? tv[e] : af[4 * s4 + e];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // DUAL: the tile's own rows of the second operand, straight from memory in A-operand order
+    // (lane l: rows2[row0 + (l&15)][(l>>4)*K/4 + s]); rows and columns outside the matrix read as 0
+    float af2[DUAL ? KQ : 1];
+    if constexpr (DUAL) {
+      const int row = row0 + i;
+      const bool rok = row < a.n_rows;
+      const float* xr = f.rows2 + (int64_t)(rok ? row : 0) * a.ld + kq * KQ;
+      const bool v4 = (a.ld % 4 == 0) && (((uintptr_t)f.rows2 & 15) == 0);
+#pragma unroll
+      for (int s4 = 0; s4 < KQ / 4; ++s4) {
+        const int k = kq * KQ + 4 * s4;
+        f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+        if (rok) {
+          if (v4 && k + 3 < a.ncols) {
+            t = *reinterpret_cast<const f32x4_t*>(xr + 4 * s4);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + e < a.ncols) t[e] = xr[4 * s4 + e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) af2[4 * s4 + e] = t[e];
+      }
     }
     const float* wbase = wl + i * LDT + kq * KQ;
     for (int n0 = 0; n0 < n_pad; n0 += 16) {
@@ -418,6 +451,17 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 1], b[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 2], b[2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 3], b[3], c, 0, 0, 0);
+      }
+      if constexpr (DUAL) {
+        const float* wr2 = wr + n_pad * LDT;  // same position in wl2
+#pragma unroll
+        for (int s4 = 0; s4 < KQ / 4; ++s4) {
+          const f32x4_t b = *reinterpret_cast<const f32x4_t*>(wr2 + 4 * s4);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 0], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 1], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 2], b[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 3], b[3], c, 0, 0, 0);
+        }
       }
       if (n0 + i < f.n_out) {
 #pragma unroll
@@ -442,6 +486,17 @@ __global__ void transpose_small_kernel(int rows, int cols, const float* in, floa
   }
 }
 
+// LDS of one fused workgroup: one or two weight matrices [n_pad][K+4] + 16 row strips [strip][K+4]
+inline size_t fuse_lds_bytes(int kpad, int n_out, bool dual, int strip) {
+  const size_t n_pad = (size_t)((n_out + 15) & ~15);
+  return sizeof(float) * (size_t)(kpad + 4) * ((dual ? 2 : 1) * n_pad + (size_t)FUSE_WAVES * strip);
+}
+inline int fuse_strip_rows(int kpad, int n_out, bool dual) {
+  if (fuse_lds_bytes(kpad, n_out, dual, 8) <= 160 * 1024) return 8;
+  if (dual && fuse_lds_bytes(kpad, n_out, dual, 2) <= 160 * 1024) return 2;
+  return 0;
+}
+
 template <int VEC, int WMODE>
 int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, float* heavy_scratch) {
   constexpr int U = 16;
@@ -461,21 +516,30 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     else spmm_heavy_kernel<VEC, 1, WMODE, U, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
   }
-  const size_t lds = sizeof(float) * (size_t)(K + 4) * (((f.n_out + 15) & ~15) + FUSE_WAVES * FUSE_ROWS / 2);
+  const bool dual = f.wt2 != nullptr;
+  const int strip = fuse_strip_rows(K, f.n_out, dual);  // 8, 2 or 0 (does not fit: the caller checked)
+  const size_t lds = fuse_lds_bytes(K, f.n_out, dual, strip);
   const int64_t ntiles = cdiv64(a.n_rows, FUSE_ROWS);
   const unsigned grid = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, FUSE_WAVES));
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, sizeof(int), ctx->stream));
   ProfScope ps(ctx, "spmm_gemm_fused");
   // more than 64 KB of dynamic LDS has to be asked for
+#define GAIB_FUSED_LAUNCH(GM, STRIP, DUAL)                                                                    \
+  do {                                                                                                        \
+    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, U, GM, STRIP, DUAL>,               \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
+    spmm_gemm_kernel<VEC, WMODE, U, GM, STRIP, DUAL><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f); \
+  } while (0)
   if (buf) {
-    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, U, 1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    spmm_gemm_kernel<VEC, WMODE, U, 1><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f);
+    if (!dual) GAIB_FUSED_LAUNCH(1, 8, false);
+    else if (strip == 8) GAIB_FUSED_LAUNCH(1, 8, true);
+    else GAIB_FUSED_LAUNCH(1, 2, true);
   } else {
-    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, U, 0>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    spmm_gemm_kernel<VEC, WMODE, U, 0><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f);
+    if (!dual) GAIB_FUSED_LAUNCH(0, 8, false);
+    else if (strip == 8) GAIB_FUSED_LAUNCH(0, 8, true);
+    else GAIB_FUSED_LAUNCH(0, 2, true);
   }
+#undef GAIB_FUSED_LAUNCH
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -586,56 +650,67 @@ extern "C" int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const
   return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags);
 }
 
-// agg = A.in ; out = act(agg . op(W)).  Fused on the matrix cores when the shape allows, otherwise
-// gaib_spmm followed by gaib_sgemm (same results up to summation order).
-extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
-                              int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
-                              int len_out, float* d_out, int flags) {
+// agg = A.in ; out = act(agg . op(W) [+ rows2 . op(W2)]).  Fused on the matrix cores when the shape allows,
+// otherwise gaib_spmm followed by gaib_sgemm (same results up to summation order).
+static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len_in,
+                          const float* d_in, float* d_agg, const float* d_W, int transW, const float* d_rows2,
+                          const float* d_W2, int len_out, float* d_out, int flags) {
   GAIB_CHECK(ctx && g, "gaib_spmm_gemm: NULL ctx/graph");
   GAIB_CHECK(len_in >= 0 && len_out >= 0, "gaib_spmm_gemm: negative length");
   GAIB_CHECK(ctx->device == g->device, "gaib_spmm_gemm: graph lives on device %d, ctx on %d", g->device,
              ctx->device);
   GAIB_CHECK((flags & ~(GAIB_RELU | GAIB_AGG_SCRATCH | GAIB_ACCUMULATE)) == 0, "gaib_spmm_gemm: unsupported flags %d",
              flags);
+  GAIB_CHECK((d_rows2 == nullptr) == (d_W2 == nullptr), "gaib_spmm_gemm2: rows2 and W2 go together");
   if (g->nv == 0 || len_out == 0) return GAIB_OK;
   GAIB_CHECK(d_in && d_agg && d_W && d_out, "gaib_spmm_gemm: NULL pointer");
-  GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out, "gaib_spmm_gemm: buffers must not alias");
-  const uintptr_t al = (uintptr_t)d_in | (uintptr_t)d_agg | (uintptr_t)d_W;
-  // op(W) [len_out x (len_in+4)] + 16 strips [8 x (len_in+4)] must fit the CU's 160 KB of LDS
+  GAIB_CHECK(d_in != d_agg && d_agg != d_out && d_in != d_out && d_rows2 != d_out && d_rows2 != d_agg,
+             "gaib_spmm_gemm: buffers must not alias");
+  const bool dual = d_rows2 != nullptr;
+  const uintptr_t al = (uintptr_t)d_in | (uintptr_t)d_agg;
+  // the weight matrices [len_out x (len_in+4)] and 16 row strips must fit the CU's 160 KB of LDS;
   // 65..128 columns need 8-byte lanes
   const int kpad = len_in <= 64 ? 64 : 128;
-  const size_t fuse_lds = sizeof(float) * (size_t)(kpad + 4) * ((size_t)((len_out + 15) & ~15) + FUSE_WAVES * FUSE_ROWS / 2);
   const bool lanes_ok = len_in <= 64 ? true : (len_in % 2 == 0 && (al & 7) == 0);
   const bool fusable = ctx->spmm_fuse != 0 && len_in >= 1 && len_in <= 128 && lanes_ok &&
-                       fuse_lds <= 160 * 1024 && g->ne > 0 && g->nv >= 1 &&
+                       fuse_strip_rows(kpad, len_out, dual) != 0 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
   if (!fusable) {
+    const int act = (flags & GAIB_RELU) ? GAIB_RELU : 0;
     GAIB_TRY(spmm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, flags & GAIB_ACCUMULATE));
-    return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_agg, d_W, (flags & GAIB_RELU) ? GAIB_RELU : 0,
-                         d_out);
+    GAIB_TRY(gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_agg, d_W, dual ? 0 : act, d_out));
+    if (dual) return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_rows2, d_W2, GAIB_ACCUMULATE | act, d_out);
+    return GAIB_OK;
   }
   SpmmArgs a;
   int wmode = 0;
   GAIB_TRY(spmm_setup(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, 0, 1, &a, &wmode));
   a.accumulate = 0;  // (the fused kernel takes the partial sums through f.agg_in)
   if (flags & GAIB_AGG_SCRATCH) a.out = nullptr;  // the caller does not read agg: skip its store
-  // scratch: op(W) k-contiguous + the heavy rows' aggregates
-  const size_t wt_bytes = sizeof(float) * (size_t)len_out * len_in;
-  const size_t hv_bytes = sizeof(float) * (size_t)g->n_heavy * len_in;
-  GAIB_TRY(gaib_ws_reserve(ctx, wt_bytes + hv_bytes + 512));
+  // scratch: op(W) (and op(W2)) k-contiguous + the heavy rows' aggregates + the tile counter
+  const size_t wt_bytes = (sizeof(float) * (size_t)len_out * len_in + 255) & ~(size_t)255;
+  const size_t hv_bytes = (sizeof(float) * (size_t)g->n_heavy * len_in + 255) & ~(size_t)255;
+  GAIB_TRY(gaib_ws_reserve(ctx, 2 * wt_bytes + hv_bytes + 256));
   float* wt = (float*)ctx->ws;
-  float* hv = (float*)((char*)ctx->ws + ((wt_bytes + 255) & ~(size_t)255));
-  int* counter = (int*)((char*)hv + ((hv_bytes + 255) & ~(size_t)255));
+  float* wt2 = (float*)((char*)ctx->ws + wt_bytes);
+  float* hv = (float*)((char*)ctx->ws + 2 * wt_bytes);
+  int* counter = (int*)((char*)hv + hv_bytes);
   FuseArgs f;
-  if (transW) {
-    f.wt = d_W;  // W is [len_out x len_in]: already k-contiguous
-  } else {
+  f.wt = d_W;  // with transW, W is [len_out x len_in]: already k-contiguous
+  f.wt2 = d_W2;
+  if (!transW) {
     const int n = len_in * len_out;
     transpose_small_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(len_in, len_out, d_W, wt);
     GAIB_LAUNCH_CHECK();
     f.wt = wt;
+    if (dual) {
+      transpose_small_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(len_in, len_out, d_W2, wt2);
+      GAIB_LAUNCH_CHECK();
+      f.wt2 = wt2;
+    }
   }
+  f.rows2 = d_rows2;
   f.y = d_out;
   f.ldy = len_out;
   f.n_out = len_out;
@@ -649,6 +724,21 @@ extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, con
     return wmode == 0 ? launch_fused<1, 0>(ctx, g, a, f, hv) : launch_fused<1, 1>(ctx, g, a, f, hv);
   }
   return wmode == 0 ? launch_fused<2, 0>(ctx, g, a, f, hv) : launch_fused<2, 1>(ctx, g, a, f, hv);
+}
+
+extern "C" int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                              int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
+                              int len_out, float* d_out, int flags) {
+  return spmm_gemm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, d_W, transW, nullptr, nullptr, len_out,
+                        d_out, flags);
+}
+
+extern "C" int gaib_spmm_gemm2(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                               int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
+                               const float* d_rows2, const float* d_W2, int len_out, float* d_out, int flags) {
+  GAIB_CHECK(d_rows2 && d_W2, "gaib_spmm_gemm2: NULL second operand");
+  return spmm_gemm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, d_W, transW, d_rows2, d_W2, len_out,
+                        d_out, flags);
 }
 
 extern "C" int gaib_spmm_mh(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,

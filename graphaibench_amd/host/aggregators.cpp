@@ -28,25 +28,31 @@ static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* 
 }
 
 void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float* in, float* agg, bool keep_agg,
-                                       const float* W, bool transW, int len_out, float* out, bool relu) {
+                                       const float* W, bool transW, int len_out, float* out, bool relu,
+                                       const float* rows2, const float* W2) {
   OpTimer t(OP_SPARSEMM);
   const int flags = (relu ? GAIB_RELU : 0) | (keep_agg ? 0 : GAIB_AGG_SCRATCH);
+  auto fused = [&](gaib_graph* dg, const float* src, int fl) {
+    if (rows2)
+      GAIB_OR_DIE(gaib_spmm_gemm2(C(), dg, kind, NULL, len, src, agg, W, transW ? 1 : 0, rows2, W2, len_out, out, fl));
+    else
+      GAIB_OR_DIE(gaib_spmm_gemm(C(), dg, kind, NULL, len, src, agg, W, transW ? 1 : 0, len_out, out, fl));
+  };
   if (g.has_halo()) {
     // owned-column edges while the halo rows travel; the halo-column edges then continue the sums and
-    // carry the dense product
+    // carry the dense product(s)
     g.halo_begin(len, in);  // every rank joins every exchange, also one without halo edges
     if (gaib_graph_ne(g.halo_graph()) == 0) {
-      GAIB_OR_DIE(gaib_spmm_gemm(C(), dev(g), kind, NULL, len, in, agg, W, transW ? 1 : 0, len_out, out, flags));
+      fused(dev(g), in, flags);
       g.halo_end(len);
       return;
     }
     GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, agg, 0));
     const float* halo = g.halo_end(len);
-    GAIB_OR_DIE(gaib_spmm_gemm(C(), g.halo_graph(), kind, NULL, len, halo, agg, W, transW ? 1 : 0, len_out, out,
-                               flags | GAIB_ACCUMULATE));
+    fused(g.halo_graph(), halo, flags | GAIB_ACCUMULATE);
     return;
   }
-  GAIB_OR_DIE(gaib_spmm_gemm(C(), dev(g), kind, NULL, len, in, agg, W, transW ? 1 : 0, len_out, out, flags));
+  fused(dev(g), in, flags);
 }
 
 // ---- GCN ---------------------------------------------------------------------------------------
@@ -59,12 +65,15 @@ void GCN_Aggregator::d_aggregate_matmul(int len, Graph& g, const float* grad_in,
   aggregate_then_matmul(GAIB_W_GCN, len, g, grad_in, agg, keep_agg, W, transW, len_out, out, false);
 }
 void SAGE_Aggregator::aggregate_matmul(int len, Graph& g, const float* in, float* agg, bool keep_agg,
-                                       const float* W, bool transW, int len_out, float* out, bool relu) {
-  aggregate_then_matmul(GAIB_W_MEAN, len, g, in, agg, keep_agg, W, transW, len_out, out, relu);
+                                       const float* W, bool transW, int len_out, float* out, bool relu,
+                                       const float* rows_self, const float* W_self) {
+  aggregate_then_matmul(GAIB_W_MEAN, len, g, in, agg, keep_agg, W, transW, len_out, out, relu, rows_self, W_self);
 }
 void SAGE_Aggregator::d_aggregate_matmul(int len, Graph& g, const float* grad_in, float* agg, bool keep_agg,
-                                         const float* W, bool transW, int len_out, float* out) {
-  aggregate_then_matmul(GAIB_W_MEAN_T, len, g, grad_in, agg, keep_agg, W, transW, len_out, out, false);
+                                         const float* W, bool transW, int len_out, float* out,
+                                         const float* rows_self, const float* W_self) {
+  aggregate_then_matmul(GAIB_W_MEAN_T, len, g, grad_in, agg, keep_agg, W, transW, len_out, out, false, rows_self,
+                        W_self);
 }
 void GCN_Aggregator::init(int l, int nv, int, float, float) {
   length = l;

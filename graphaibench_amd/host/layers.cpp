@@ -143,12 +143,14 @@ void SAGE_layer::forward(float* feat_out) {
   if (y > z) {
     matmul(x, z, y, in_data, d_W_neigh, d_out_temp);
     aggr.aggregate(z, *graph, d_out_temp, feat_out);
-  } else {  // mean aggregation with the neighbour product riding on it (one kernel)
-    aggr.aggregate_matmul(y, *graph, in_data, d_in_temp1, true, d_W_neigh, false, z, feat_out, false);
+    // + X.W_self, with the activation fused into this last product
+    if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
+    else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
+  } else {
+    // one kernel: mean aggregation, then out = act(mean . W_neigh + X . W_self) on the matrix cores
+    aggr.aggregate_matmul(y, *graph, in_data, d_in_temp1, true, d_W_neigh, false, z, feat_out, is_act, in_data,
+                          d_W_self);
   }
-  // + X.W_self, with the activation fused into this last product
-  if (is_act) matmul_relu(x, z, y, in_data, d_W_self, feat_out, false, false, true);
-  else matmul(x, z, y, in_data, d_W_self, feat_out, false, false, true);
 }
 
 void SAGE_layer::backward(float* feat_out, float* grad_out) {
@@ -157,22 +159,25 @@ void SAGE_layer::backward(float* feat_out, float* grad_out) {
   // the first product that streams grad_in applies the layer's d_relu on the way (in place, Q9)
   if (is_act) matmul_drelu(y, z, x, in_data, grad_in, feat_out, d_W_self_grad);
   else matmul(y, z, x, in_data, grad_in, d_W_self_grad, true, false);
+  // grad_out = M^T-aggregated gradient . W_neigh^T + g . W_self^T: where the aggregation comes first, both
+  // products ride on it (sage_layer.cpp:44-50 runs them as two GEMMs after / before the aggregation)
   if (y > z) {
-    if (level_ > 0) aggr.d_aggregate_matmul(z, *graph, grad_in, d_out_temp, true, d_W_neigh, true, y, grad_out);
+    if (level_ > 0)
+      aggr.d_aggregate_matmul(z, *graph, grad_in, d_out_temp, true, d_W_neigh, true, y, grad_out, grad_in, d_W_self);
     else aggr.d_aggregate(z, *graph, NULL, grad_in, d_out_temp);
     matmul(y, z, x, in_data, d_out_temp, d_W_neigh_grad, true, false);
   } else {
     matmul(y, z, x, d_in_temp1, grad_in, d_W_neigh_grad, true, false);
     if (level_ > 0) {
-      if (y == z) {  // (M^T g).W^T instead of M^T (g.W^T): the product rides on the aggregation
-        aggr.d_aggregate_matmul(z, *graph, grad_in, d_in_temp, false, d_W_neigh, true, y, grad_out);
+      if (y == z) {  // (M^T g).W^T instead of M^T (g.W^T): the products ride on the aggregation
+        aggr.d_aggregate_matmul(z, *graph, grad_in, d_in_temp, false, d_W_neigh, true, y, grad_out, grad_in, d_W_self);
       } else {
         matmul(x, y, z, grad_in, d_W_neigh, d_in_temp, false, true);
         aggr.d_aggregate(y, *graph, NULL, d_in_temp, grad_out);
+        matmul(x, y, z, grad_in, d_W_self, grad_out, false, true, true);  // += g.W_self^T
       }
     }
   }
-  if (level_ > 0) matmul(x, y, z, grad_in, d_W_self, grad_out, false, true, true);  // += g.W_self^T
   if (level_ != 0 && feat_dropout_rate > 0.)
     d_dropout_gpu(x * y, feat_scale, grad_out, dropout_mask, grad_out);
 }

@@ -211,6 +211,12 @@ int gaib_spmm_gemm(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d
                    int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
                    int len_out, float* d_out, int flags);
 
+/* the same with a second, row-local product in the store: out = act(agg . op(W) + rows2 . op(W2)), rows2 [nv x len_in],
+ * W2 shaped like W -- the self term of a SAGE layer (sage_layer.cpp:22 forward, :50 backward) without its own pass. */
+int gaib_spmm_gemm2(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w,
+                    int len_in, const float* d_in, float* d_agg, const float* d_W, int transW,
+                    const float* d_rows2, const float* d_W2, int len_out, float* d_out, int flags);
+
 /* ---- dense update: matmul -> sgemm_gpu -> cublasSgemm (math_functions.cu:321-343) --------
  * row-major C[M x N] = op(A)[M x K] . op(B)[K x N]  (+ C if accum).  fp32 MFMA. */
 int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,

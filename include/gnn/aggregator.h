@@ -21,8 +21,10 @@ class aggregator {
   // cores inside the aggregating wave).  W is [len x len_out], or [len_out x len] with transW.  keep_agg = false
   // lets the kernel skip the store of agg (still needs the buffer).  On a partitioned graph (halo exchange)
   // it runs as aggregation + matmul.
+  // rows2 / W2 (both or neither): + rows2 . op(W2) in the same store (the self term of a SAGE layer)
   void aggregate_then_matmul(int kind, int len, Graph& g, const float* in, float* agg, bool keep_agg,
-                             const float* W, bool transW, int len_out, float* out, bool relu);
+                             const float* W, bool transW, int len_out, float* out, bool relu,
+                             const float* rows2 = NULL, const float* W2 = NULL);
 
   int n;
   int length;  // feature vector length
@@ -48,10 +50,13 @@ class SAGE_Aggregator : public aggregator {
   void init(int length, int nv, int ne = 0, float lr = 0.01, float drop_rate = 0.);
   void aggregate(int len, Graph& g, const float* in, float* out);
   void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
+  // out = act(mean(in) . op(W) + rows_self . op(W_self)): neighbour and self product of the layer in one kernel
   void aggregate_matmul(int len, Graph& g, const float* in, float* agg, bool keep_agg, const float* W,
-                        bool transW, int len_out, float* out, bool relu);
+                        bool transW, int len_out, float* out, bool relu, const float* rows_self = NULL,
+                        const float* W_self = NULL);
   void d_aggregate_matmul(int len, Graph& g, const float* grad_in, float* agg, bool keep_agg, const float* W,
-                          bool transW, int len_out, float* out);
+                          bool transW, int len_out, float* out, const float* rows_self = NULL,
+                          const float* W_self = NULL);
 };
 
 // single-head attention: p = softmax_row(leaky_relu_0.2(a_l.h_i + a_r.h_j)); out = P h.

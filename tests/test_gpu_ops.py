@@ -760,3 +760,59 @@ def test_sgemm_experimental_variants_agree(ctx, variant):
             assert rel_err(Cd.cpu().numpy(), want) < TOL
     finally:
         ctx.set_option("sgemm_variant", 0)
+
+
+@pytest.mark.parametrize("len_in,len_out,kind,transW,relu", [
+    (128, 128, "mean", False, True),     # SAGE hidden layer forward: two 128x128 matrices -> 2-row strips
+    (128, 128, "mean_t", True, False),   # its backward
+    (100, 128, "mean", False, True),     # products layer 0
+    (47, 128, "mean_t", True, False),    # output layer backward (odd K)
+    (128, 47, "mean", False, False),
+    (64, 200, "gcn", False, True),
+    (128, 160, "mean", False, True),     # two matrices do not fit LDS: three-kernel path
+    (256, 64, "mean", False, True),      # K > 128: three-kernel path
+])
+def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
+    """gaib_spmm_gemm2: out = act(agg . op(W) + rows2 . op(W2)) == oracle aggregate + two matmuls"""
+    rp, ci = random_graph(3001, 12, seed=len_in * 3 + len_out, power_law=True, hub_deg=1500)
+    g_o, g_d = make(ctx, rp, ci, selfloop=(kind == "gcn"))
+    n = g_o.nv
+    x = feat(n, len_in, 3)
+    shape = (len_out, len_in) if transW else (len_in, len_out)
+    W = feat(*shape, 4) * 0.2
+    W2 = feat(*shape, 5) * 0.2
+    agg_w, k = {"gcn": (orc.gcn_aggregate, capi.W_GCN), "mean": (orc.sage_aggregate, capi.W_MEAN),
+                "mean_t": (orc.sage_d_aggregate, capi.W_MEAN_T)}[kind]
+    agg_w = agg_w(g_o, x)
+    y_w = orc.matmul(agg_w, W, False, transW) + orc.matmul(x, W2, False, transW)
+    if relu:
+        y_w = np.maximum(y_w, 0)
+    xd = dev(x)
+    for scratch in (False, True):
+        agg = torch.full((n, len_in), 3.0, device="cuda")
+        y = torch.full((n, len_out), -5.0, device="cuda")
+        ctx.spmm_gemm(g_d, k, xd, agg, dev(W), y, transW=transW, relu=relu, agg_scratch=scratch, rows2=xd, W2=dev(W2))
+        assert rel_err(y.cpu().numpy(), y_w) < TOL
+        if not scratch:
+            assert rel_err(agg.cpu().numpy(), agg_w) < TOL
+    # the halo half of a partitioned aggregation carries both products as well
+    rows = np.repeat(np.arange(n), np.diff(g_o.rowptr))
+    cols = np.asarray(g_o.colidx)
+    lo = cols < n // 2
+
+    def sub(mask):
+        cnt = np.bincount(rows[mask], minlength=n)
+        return ctx.graph(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), cols[mask].view(np.int32))
+
+    ga, gb = sub(lo), sub(~lo)
+    deg = np.diff(g_o.rowptr)
+    vd = dev(np.asarray(g_o.vertex_data(), np.float32))
+    inv = dev(np.where(deg > 0, (1.0 / np.maximum(deg, 1).astype(np.float32)).astype(np.float64), 0.0).astype(np.float32))
+    for gg in (ga, gb):  # the halves carry the normalisers of the WHOLE graph, like a partition does
+        gg.set_vertex_norm(row_vdata=vd, col_vdata=vd, col_inv_deg=inv, row_inv_deg=inv)
+    agg = torch.empty(n, len_in, device="cuda")
+    y = torch.empty(n, len_out, device="cuda")
+    ctx.spmm(ga, k, xd, agg)
+    ctx.spmm_gemm(gb, k, xd, agg, dev(W), y, transW=transW, relu=relu, accumulate=True, rows2=xd, W2=dev(W2))
+    assert rel_err(agg.cpu().numpy(), agg_w) < TOL
+    assert rel_err(y.cpu().numpy(), y_w) < TOL
