@@ -322,7 +322,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int FUSE_ROWS = 16;
 constexpr int FUSE_WAVES = 16;
 
-// STRIP = rows a wave parks in LDS at a time (8, or 2 when two weight matrices have to fit);
+// STRIP = rows a wave parks in LDS at a time (8; 2 with two weight matrices);
 // DUAL: y = act(agg . op(W) + rows2 . op(W2)) -- the self term of a SAGE layer (sage_layer.cpp:22,50) in the same pass
 template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
@@ -415,35 +415,8 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // DUAL: the tile's own rows of the second operand, straight from memory in A-operand order
-    // (lane l: rows2[row0 + (l&15)][(l>>4)*K/4 + s]); rows and columns outside the matrix read as 0
-    float af2[DUAL ? KQ : 1];
-    if constexpr (DUAL) {
-      const int row = row0 + i;
-      const bool rok = row < a.n_rows;
-      const float* xr = f.rows2 + (int64_t)(rok ? row : 0) * a.ld + kq * KQ;
-      const bool v4 = (a.ld % 4 == 0) && (((uintptr_t)f.rows2 & 15) == 0);
-#pragma unroll
-      for (int s4 = 0; s4 < KQ / 4; ++s4) {
-        const int k = kq * KQ + 4 * s4;
-        f32x4_t t = {0.f, 0.f, 0.f, 0.f};
-        if (rok) {
-          if (v4 && k + 3 < a.ncols) {
-            t = *reinterpret_cast<const f32x4_t*>(xr + 4 * s4);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (k + e < a.ncols) t[e] = xr[4 * s4 + e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) af2[4 * s4 + e] = t[e];
-      }
-    }
     const float* wbase = wl + i * LDT + kq * KQ;
-    for (int n0 = 0; n0 < n_pad; n0 += 16) {
-      const float* wr = wbase + n0 * LDT;
-      f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    auto mfma_tile = [&](const float* wr, f32x4_t c) {
 #pragma unroll
       for (int s4 = 0; s4 < KQ / 4; ++s4) {
         const f32x4_t b = *reinterpret_cast<const f32x4_t*>(wr + 4 * s4);
@@ -452,17 +425,9 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 2], b[2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * s4 + 3], b[3], c, 0, 0, 0);
       }
-      if constexpr (DUAL) {
-        const float* wr2 = wr + n_pad * LDT;  // same position in wl2
-#pragma unroll
-        for (int s4 = 0; s4 < KQ / 4; ++s4) {
-          const f32x4_t b = *reinterpret_cast<const f32x4_t*>(wr2 + 4 * s4);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 0], b[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 1], b[1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 2], b[2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[4 * s4 + 3], b[3], c, 0, 0, 0);
-        }
-      }
+      return c;
+    };
+    auto store_tile = [&](int n0, const f32x4_t& c) {
       if (n0 + i < f.n_out) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -472,6 +437,56 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
             if (f.relu) v = v > 0.f ? v : 0.f;
             f.y[(int64_t)row * f.ldy + n0 + i] = v;
           }
+        }
+      }
+    };
+    if constexpr (!DUAL) {
+      for (int n0 = 0; n0 < n_pad; n0 += 16) {
+        const f32x4_t c = mfma_tile(wbase + n0 * LDT, f32x4_t{0.f, 0.f, 0.f, 0.f});
+        store_tile(n0, c);
+      }
+    } else {
+      // second product with the tile's own rows of rows2.  Nothing of it is live while the gathers run (64 more
+      // registers there made the compiler serialise them): the 16 rows are requested now, coalesced like gathered
+      // rows, the first product runs on the matrix cores while they travel, then they take the same trip through
+      // the LDS strip into operand order (reusing af) and the second chain continues the same accumulators.
+      constexpr int NT = 8;  // n_pad <= 128 on this path (checked by the launcher)
+      vec_t xs[FUSE_ROWS];
+#pragma unroll
+      for (int r = 0; r < FUSE_ROWS; ++r) {
+        const int row = row0 + r;
+        const int64_t rs = row < a.n_rows ? row : 0;
+        xs[r] = *reinterpret_cast<const vec_t*>(f.rows2 + rs * a.ld + (colok ? lane * VEC : 0));
+      }
+      f32x4_t c[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        c[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (nt * 16 < n_pad) c[nt] = mfma_tile(wbase + nt * 16 * LDT, c[nt]);
+      }
+#pragma unroll
+      for (int h = 0; h < NPASS; ++h) {
+#pragma unroll
+        for (int r = 0; r < HALF; ++r) {
+          const bool ok = colok && (row0 + h * HALF + r < a.n_rows);
+          *reinterpret_cast<vec_t*>(tile + r * LDT + lane * VEC) = ok ? xs[h * HALF + r] : vzero<VEC>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool mine = (i / HALF) == h;
+        const float* trow = tile + (i % HALF) * LDT + kq * KQ;
+#pragma unroll
+        for (int s4 = 0; s4 < KQ / 4; ++s4) {
+          const f32x4_t tv = *reinterpret_cast<const f32x4_t*>(trow + 4 * s4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) af[4 * s4 + e] = mine ? tv[e] : af[4 * s4 + e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt * 16 < n_pad) {
+          c[nt] = mfma_tile(wbase + n_pad * LDT + nt * 16 * LDT, c[nt]);  // same position in wl2
+          store_tile(nt * 16, c[nt]);
         }
       }
     }
@@ -492,9 +507,10 @@ inline size_t fuse_lds_bytes(int kpad, int n_out, bool dual, int strip) {
   return sizeof(float) * (size_t)(kpad + 4) * ((dual ? 2 : 1) * n_pad + (size_t)FUSE_WAVES * strip);
 }
 inline int fuse_strip_rows(int kpad, int n_out, bool dual) {
-  if (fuse_lds_bytes(kpad, n_out, dual, 8) <= 160 * 1024) return 8;
-  if (dual && fuse_lds_bytes(kpad, n_out, dual, 2) <= 160 * 1024) return 2;
-  return 0;
+  // two products: 2-row strips (measured: the strip height costs nothing) and at most eight 16-wide output tiles
+  // (their accumulators stay in registers between the two products)
+  if (dual) return (n_out <= 128 && fuse_lds_bytes(kpad, n_out, dual, 2) <= 160 * 1024) ? 2 : 0;
+  return fuse_lds_bytes(kpad, n_out, dual, 8) <= 160 * 1024 ? 8 : 0;
 }
 
 template <int VEC, int WMODE>
@@ -530,13 +546,12 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
     spmm_gemm_kernel<VEC, WMODE, U, GM, STRIP, DUAL><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f); \
   } while (0)
+  (void)strip;
   if (buf) {
     if (!dual) GAIB_FUSED_LAUNCH(1, 8, false);
-    else if (strip == 8) GAIB_FUSED_LAUNCH(1, 8, true);
     else GAIB_FUSED_LAUNCH(1, 2, true);
   } else {
     if (!dual) GAIB_FUSED_LAUNCH(0, 8, false);
-    else if (strip == 8) GAIB_FUSED_LAUNCH(0, 8, true);
     else GAIB_FUSED_LAUNCH(0, 2, true);
   }
 #undef GAIB_FUSED_LAUNCH

@@ -184,6 +184,9 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
           if constexpr (MH) wv[u][ct] = load_edge_w<WMODE>(a, base + j + u, hd[ct]);
         }
       }
+      // all U gathers are issued before the first one is consumed: without the fence the scheduler may interleave
+      // loads and uses to save registers (seen in the two-product fused kernel: vmcnt(1) after every load)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float wj = (WMODE == 0) ? roww : (MH ? 0.f : readlane_f(w, j + u));
@@ -212,6 +215,7 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
           jj += p;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       jj = j;
 #pragma unroll
       for (int p = U / 2; p >= 1; p >>= 1) {

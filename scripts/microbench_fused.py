@@ -38,7 +38,15 @@ def main():
                                              agg_scratch=scratch), ctx)
             print(f"fuse={fuse} transW={transW} relu={relu} agg_scratch={scratch}: {t:.3f} ms")
     ctx.set_option("spmm_fuse", 1)
-    for thr in (256, 512, 1024, 2048, 4096):
+    # second row-local product in the same store (SAGE self term): 128 outputs -> 2-row strips, 48 outputs -> 8-row strips
+    for n_out in (128, 48):
+        Wn = torch.randn(D, n_out, device="cuda") * 0.1
+        Ws = torch.randn(D, n_out, device="cuda") * 0.1
+        yo = torch.empty(n, n_out, device="cuda")
+        t1 = timeit(lambda: ctx.spmm_gemm(g, capi.W_GCN, x, agg, Wn, yo, relu=True), ctx)
+        t2 = timeit(lambda: ctx.spmm_gemm(g, capi.W_GCN, x, agg, Wn, yo, relu=True, rows2=x, W2=Ws), ctx)
+        print(f"n_out={n_out}: single product {t1:.3f} ms, with self term {t2:.3f} ms")
+    for thr in (1024,):
         ctx.set_option("spmm_heavy_threshold", thr)
         t = timeit(lambda: ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y, relu=True), ctx)
         print(f"heavy threshold {thr}: fused fwd {t:.3f} ms  {ctx.graph_stats(g)}")
