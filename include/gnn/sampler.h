@@ -1,12 +1,13 @@
-// include/gnn/sampler.h -- GraphSAINT-style frontier sampler (host side).
+// include/gnn/sampler.h -- GraphSAINT frontier sampler (host side).
 // Interface of the reference class (include/gnn/sampler.h:9-67; algorithm src/gnn/sampler.cpp:146-294,
 // after GraphSAINT's ipdps19 sample.cpp): keep a frontier of m training vertices; n - m times pick
-// a frontier slot with probability proportional to its (clipped) degree in the masked training
+// a frontier vertex with probability proportional to its (clipped) degree in the masked training
 // graph, replace it by a uniformly chosen neighbour and add that neighbour to the vertex set; the
 // subgraph is the one the FULL graph induces on the set, re-indexed in ascending vertex order.
-// Our implementation keeps the slot weights in a Fenwick tree (O(log m) per draw) instead of the
-// reference's "dashboard" arrays, and draws from std::mt19937: the distribution is the same, the
-// random stream (rand_r in the reference) is not, so sampled sets are not comparable draw by draw.
+// select_vertices consumes the same rand_r stream over the same "dashboard" layout as the reference, so
+// the same (graph, training set, n, seed) gives the SAME vertex set and subgraph, bit for bit
+// (tests/test_sampler_cpu.py against the reference's own sampler.cpp in oracle/_ref and against
+// tests/golden/sampler_*.npz).
 #pragma once
 #include <set>
 #include "lgraph.h"

@@ -488,3 +488,42 @@ def ref_lib():
         return None
     os.environ.setdefault("DATASET_PATH", "/tmp/")  # configs.h:5 reads it at load time
     return C.CDLL(str(REF_LIB))
+
+
+def ref_sample_subgraph(rowptr, colidx, train_masks, n: int, seed: int):
+    """the REAL reference's Sampler::select_vertices + generateSubgraph (oracle/_ref, sampler.cpp compiled
+    unmodified): -> (kept vertex ids ascending, subgraph rowptr uint32, subgraph colidx uint32) or None without _ref"""
+    lib_ = ref_lib()
+    if lib_ is None or not hasattr(lib_, "ref_sample_subgraph"):
+        return None
+    rp = np.ascontiguousarray(rowptr, np.uint32)
+    ci = np.ascontiguousarray(colidx, np.uint32)
+    m = np.ascontiguousarray(train_masks, np.uint8).copy()
+    nv, ne = len(rp) - 1, len(ci)
+    kept = np.zeros(max(n, 1), np.uint32)
+    sub_ne = C.c_uint32(0)
+    lib_.ref_sample_subgraph.restype = C.c_uint32
+    k = lib_.ref_sample_subgraph(C.c_uint32(nv), C.c_uint32(ne), _p(rp), _p(ci), _p(m), C.c_uint32(n), C.c_uint(seed),
+                                 _p(kept), C.byref(sub_ne), None, None)
+    srp = np.zeros(k + 1, np.uint32)
+    sci = np.zeros(max(sub_ne.value, 1), np.uint32)
+    lib_.ref_sample_subgraph(C.c_uint32(nv), C.c_uint32(ne), _p(rp), _p(ci), _p(m), C.c_uint32(n), C.c_uint(seed),
+                             _p(kept), C.byref(sub_ne), _p(srp), _p(sci))
+    return kept[:k].copy(), srp, sci[:sub_ne.value].copy()
+
+
+def ref_masked_graph(rowptr, colidx, masks):
+    """the REAL reference's LearningGraph::generate_masked_graph -> (rowptr, colidx) or None without _ref"""
+    lib_ = ref_lib()
+    if lib_ is None or not hasattr(lib_, "ref_masked_graph"):
+        return None
+    rp = np.ascontiguousarray(rowptr, np.uint32)
+    ci = np.ascontiguousarray(colidx, np.uint32)
+    m = np.ascontiguousarray(masks, np.uint8).copy()
+    nv, ne = len(rp) - 1, len(ci)
+    ne_out = C.c_uint32(0)
+    lib_.ref_masked_graph(C.c_uint32(nv), C.c_uint32(ne), _p(rp), _p(ci), _p(m), C.byref(ne_out), None, None)
+    rpo = np.zeros(nv + 1, np.uint32)
+    cio = np.zeros(max(ne_out.value, 1), np.uint32)
+    lib_.ref_masked_graph(C.c_uint32(nv), C.c_uint32(ne), _p(rp), _p(ci), _p(m), C.byref(ne_out), _p(rpo), _p(cio))
+    return rpo, cio[:ne_out.value].copy()

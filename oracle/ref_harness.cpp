@@ -11,6 +11,7 @@
 // below points them at the host arrays, which is what a CPU build would see.
 #include "lgraph.h"
 #include "reader.h"
+#include "sampler.h"
 #include <cstring>
 
 std::map<char, double> time_ops;  // extern in include/gnn/global.h:77
@@ -94,5 +95,50 @@ int ref_read_dataset(const char* name, uint32_t* nv, uint32_t* ne, uint32_t* rp,
   if (labels) memcpy(labels, lab.data(), lab.size());
   if (feats && flen) memcpy(feats, ft.data(), sizeof(float) * ft.size());
   return 0;
+}
+
+// LearningGraph::generate_masked_graph (include/gnn/lgraph.h:231-270): two-call protocol (NULL ci_out -> *ne_out)
+void ref_masked_graph(uint32_t nv, uint32_t ne, const uint32_t* rp, const uint32_t* ci, uint8_t* masks,
+                      uint32_t* ne_out, uint32_t* rp_out, uint32_t* ci_out) {
+  RefGraph g;
+  g.load(nv, ne, rp, ci);
+  LearningGraph* mg = g.generate_masked_graph(masks);
+  *ne_out = (uint32_t)mg->sizeEdges();
+  if (ci_out) {
+    for (uint32_t v = 0; v <= nv; v++) rp_out[v] = v == 0 ? 0 : (uint32_t)mg->edge_end_host(v - 1);
+    for (uint32_t e = 0; e < *ne_out; e++) ci_out[e] = mg->getEdgeDstHost(e);
+  }
+}
+
+// Sampler::select_vertices + Sampler::generateSubgraph (src/gnn/sampler.cpp:146-294, 128-144), driven the way
+// net.cpp:288-300 does: Sampler(full graph, training-masked graph, training masks, count).
+// kept[] receives the sorted vertex set (capacity n); the subgraph comes back through the two-call protocol:
+// first call (sub_ci == NULL) samples and returns sizes, second call copies.
+static RefGraph* s_sub = nullptr;
+uint32_t ref_sample_subgraph(uint32_t nv, uint32_t ne, const uint32_t* rp, const uint32_t* ci,
+                             uint8_t* train_masks, uint32_t n, unsigned seed, uint32_t* kept,
+                             uint32_t* sub_ne, uint32_t* sub_rp, uint32_t* sub_ci) {
+  if (sub_ci || sub_rp) {
+    uint32_t snv = (uint32_t)s_sub->size();
+    memcpy(sub_rp, s_sub->rp(), sizeof(uint32_t) * (snv + 1));
+    if (s_sub->sizeEdges()) memcpy(sub_ci, s_sub->ci(), sizeof(uint32_t) * s_sub->sizeEdges());
+    return snv;
+  }
+  RefGraph g;
+  g.load(nv, ne, rp, ci);
+  size_t count = 0;
+  for (uint32_t v = 0; v < nv; v++) count += train_masks[v] == 1;
+  LearningGraph* tg = g.generate_masked_graph(train_masks);
+  Sampler sampler(&g, tg, train_masks, count);
+  VertexSet st;
+  sampler.select_vertices(n, st, seed);
+  std::vector<mask_t> m(nv);
+  delete s_sub;
+  s_sub = new RefGraph();
+  sampler.generateSubgraph(st, m.data(), s_sub);
+  uint32_t k = 0;
+  for (auto v : st) kept[k++] = v;
+  *sub_ne = (uint32_t)s_sub->sizeEdges();
+  return (uint32_t)st.size();
 }
 }

@@ -5,6 +5,9 @@
         tiny datasets (inputs/tester, inputs/cora, inputs/citeseer) -- byte copies of data files.
   <name>/ref_*.npy    outputs of the REAL reference (oracle/_ref = lgraph.cpp + reader.cpp compiled
         unmodified): add_selfloop, compute_vertex_data, compute_edge_data, reader round trip.
+  sampler_*.npz       outputs of the REAL reference's Sampler::select_vertices + generateSubgraph and
+        LearningGraph::generate_masked_graph (src/gnn/sampler.cpp compiled unmodified into oracle/_ref) on seeded
+        graphs from tests/util.random_graph: kept vertex ids + the induced, re-indexed subgraph.
   glorot_*.npy        outputs of libstdc++'s std::default_random_engine +
         std::uniform_real_distribution<float>, the two std calls init_glorot makes
         (math_functions.cpp:11-18), produced by the 12-line program below.
@@ -39,6 +42,13 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < dx * dy; ++i) { float v = dist(rng); fwrite(&v, 4, 1, stdout); }
 }
 """
+
+# tag -> (vertices, average degree, graph seed, training prefix, subgraph size n, sampler seed); frontier = 3000
+SAMPLER_CASES = {
+    "walk_rebuild": (12000, 8, 21, 8000, 6000, 0),   # 3000 pops: the dashboard is rebuilt on the way
+    "short_walk": (9000, 6, 22, 5000, 3400, 5),
+    "no_walk": (6000, 6, 23, 6000, 2000, 2),          # n < frontier size: only the initial picks
+}
 
 GLOROT_CASES = [(16, 7, 1), (1433, 16, 1), (128, 128, 1), (128, 128, 2), (64, 1, 2), (64, 1, 3), (100, 47, 1)]
 
@@ -85,6 +95,19 @@ def main():
                                  C.byref(flen), None, 0)
             np.savez(d / "ref_reader.npz", rowptr=rrp, colidx=rci, labels=lab, num_cls=ncls.value,
                      feat_len=flen.value)
+    # sampler: same seeded graphs the tests rebuild (tests/util.random_graph)
+    sys.path.insert(0, str(ROOT / "tests"))
+    from oracle import binding as orc
+    from util import random_graph
+    for tag, (nvtx, deg, gseed, ntrain, n, seed) in SAMPLER_CASES.items():
+        rp, ci = random_graph(nvtx, deg, seed=gseed, power_law=True)
+        masks = np.zeros(nvtx, np.uint8)
+        masks[:ntrain] = 1
+        kept, srp, sci = orc.ref_sample_subgraph(rp, ci, masks, n, seed)
+        mrp, mci = orc.ref_masked_graph(rp, ci, masks)
+        np.savez_compressed(HERE / f"sampler_{tag}.npz", kept=kept, sub_rowptr=srp, sub_colidx=sci,
+                            masked_rowptr=mrp, masked_colidx_crc=np.uint32(__import__("zlib").crc32(mci.tobytes())),
+                            params=np.array([nvtx, deg, gseed, ntrain, n, seed]))
     with tempfile.TemporaryDirectory() as td:
         src = Path(td) / "g.cpp"
         src.write_text(GLOROT_CPP)

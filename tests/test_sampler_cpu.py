@@ -1,12 +1,46 @@
-"""CPU suite: the GraphSAINT-style frontier sampler of the host mirror (include/gnn/sampler.h,
-SURVEY 8f rank 4) -- host-only code, no GPU: sampled sets stay inside the training set, the
-subgraph is exactly the one the full graph induces on the set (re-indexed, rows sorted), sampling
-is seeded-deterministic and degree-biased."""
+"""CPU suite: the GraphSAINT frontier sampler of the host mirror (include/gnn/sampler.h)
+-- host-only code, no GPU.  Pinned against the REAL reference: the same seeds give the reference's vertex
+sets and subgraphs bit for bit (golden fixtures produced by the reference's own sampler.cpp, and a live
+comparison where oracle/_ref is built).  Plus the structural properties: sampled sets stay inside the
+training set, the subgraph is exactly the one the full graph induces on the set, degree bias."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from graphaibench_amd import layers as L
+from oracle import binding as orc
 from util import random_graph
+
+GOLD = Path(__file__).resolve().parent / "golden"
+REF_FRONTIER = 3000  # DEFAULT_SIZE_FRONTIER (include/gnn/global.h:31)
+
+
+@pytest.mark.parametrize("tag", ["walk_rebuild", "short_walk", "no_walk"])
+def test_sampler_matches_reference_golden(tag):
+    """fixtures = outputs of the reference's Sampler::select_vertices + generateSubgraph (make_golden.py)"""
+    g = np.load(GOLD / f"sampler_{tag}.npz")
+    nvtx, deg, gseed, ntrain, n, seed = (int(v) for v in g["params"])
+    rp, ci = random_graph(nvtx, deg, seed=gseed, power_law=True)
+    masks = np.zeros(nvtx, np.uint8)
+    masks[:ntrain] = 1
+    srp, sci, ids = L.sample_subgraph(rp, ci, masks, n, REF_FRONTIER, seed=seed)
+    assert np.array_equal(ids, g["kept"])
+    assert np.array_equal(srp, g["sub_rowptr"]) and np.array_equal(sci, g["sub_colidx"])
+
+
+@pytest.mark.skipif(orc.ref_lib() is None or not hasattr(orc.ref_lib(), "ref_sample_subgraph"),
+                    reason="oracle/_ref (the reference's own sampler.cpp) is only built where /root/reference exists")
+@pytest.mark.parametrize("nvtx,deg,ntrain,n,seed", [(20000, 10, 12000, 8000, 3), (9000, 6, 5000, 4000, 5),
+                                                    (15000, 30, 15000, 7000, 1), (5000, 4, 4000, 3100, 9),
+                                                    (4000, 5, 2500, 2500, 4)])
+def test_sampler_matches_live_reference(nvtx, deg, ntrain, n, seed):
+    rp, ci = random_graph(nvtx, deg, seed=100 + seed, power_law=True)
+    masks = np.zeros(nvtx, np.uint8)
+    masks[:ntrain] = 1
+    kept, rrp, rci = orc.ref_sample_subgraph(rp, ci, masks, n, seed)
+    srp, sci, ids = L.sample_subgraph(rp, ci, masks, n, REF_FRONTIER, seed=seed)
+    assert np.array_equal(ids, kept) and np.array_equal(srp, rrp) and np.array_equal(sci, rci)
 
 
 def _induced(rp, ci, ids):
