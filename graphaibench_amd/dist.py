@@ -100,13 +100,12 @@ class Partition:
         return int(self.colidx_own.numel() + self.colidx_halo.numel())
 
 
-def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_global: int, rank: int, world: int,
-                    group=None) -> Partition:
-    """rowptr_local/colidx_global: this rank's rows [lo,hi) of the global CSR (global column ids),
-    on the compute device.  Collective: every rank calls it."""
+def split_by_owner(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, lo: int, hi: int):
+    """the local (no communication) half of the partition: rows [lo, hi) of the global CSR -> an owned-column CSR
+    (column ids relative to lo), a halo-column CSR (column ids index `halo`), the sorted global ids of the halo
+    vertices and the rows' full degrees.  owned + halo == the vertex set of the reference's induced subgraph
+    (graph_partition.cc:150-166), pinned against it in tests/test_dist_cpu.py."""
     device = colidx_global.device
-    bounds = partition_bounds(n_global, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
     n_own = hi - lo
     assert rowptr_local.numel() == n_own + 1
     rowptr_local = rowptr_local.to(torch.int64)
@@ -124,7 +123,18 @@ def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_g
 
     rp_own, ci_own = csr_of(own, cols[own] - lo)
     rp_halo, ci_halo = csr_of(~own, torch.searchsorted(halo, cols[~own]))
-    del rows
+    return rp_own, ci_own, rp_halo, ci_halo, halo, deg
+
+
+def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_global: int, rank: int, world: int,
+                    group=None) -> Partition:
+    """rowptr_local/colidx_global: this rank's rows [lo,hi) of the global CSR (global column ids),
+    on the compute device.  Collective: every rank calls it."""
+    device = colidx_global.device
+    bounds = partition_bounds(n_global, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_own = hi - lo
+    rp_own, ci_own, rp_halo, ci_halo, halo, deg = split_by_owner(rowptr_local, colidx_global, lo, hi)
     # owner of each halo vertex -> how many rows we receive from each rank
     bt = torch.tensor(bounds, dtype=torch.int64, device=device)
     owner = torch.searchsorted(bt, halo, right=True) - 1

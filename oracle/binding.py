@@ -527,3 +527,29 @@ def ref_masked_graph(rowptr, colidx, masks):
     cio = np.zeros(max(ne_out.value, 1), np.uint32)
     lib_.ref_masked_graph(C.c_uint32(nv), C.c_uint32(ne), _p(rp), _p(ci), _p(m), C.byref(ne_out), _p(rpo), _p(cio))
     return rpo, cio[:ne_out.value].copy()
+
+
+REF_PART_LIB = HERE / "_ref" / "libref_partition.so"
+
+
+def ref_partition(rowptr, colidx, parts: int):
+    """the REAL reference's PartitionedGraph::edgecut_induced_partition1D (oracle/_ref/libref_partition.so:
+    graph_partition.cc + graph.cc + VertexSet.cc compiled unmodified).  -> list of dicts per subgraph
+    (begin, end, idx_map, rowptr, colidx) or None where _ref is not built."""
+    if not REF_PART_LIB.exists():
+        return None
+    lib_ = C.CDLL(str(REF_PART_LIB))
+    rp = np.ascontiguousarray(rowptr, np.int64)
+    ci = np.ascontiguousarray(colidx, np.uint32)
+    nv, ne = len(rp) - 1, len(ci)
+    n = lib_.refp_partition(C.c_uint32(nv), C.c_int64(ne), _p(rp), _p(ci), C.c_int(parts))
+    out = []
+    for i in range(n):
+        snv, sne, b, e = C.c_uint32(), C.c_int64(), C.c_uint32(), C.c_uint32()
+        lib_.refp_sizes(C.c_int(i), C.byref(snv), C.byref(sne), C.byref(b), C.byref(e))
+        idx = np.zeros(snv.value, np.uint32)
+        srp = np.zeros(snv.value + 1, np.int64)
+        sci = np.zeros(max(sne.value, 1), np.uint32)
+        lib_.refp_copy(C.c_int(i), _p(idx), _p(srp), _p(sci))
+        out.append(dict(begin=b.value, end=e.value, idx_map=idx, rowptr=srp, colidx=sci[:sne.value].copy()))
+    return out

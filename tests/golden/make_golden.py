@@ -8,6 +8,9 @@
   sampler_*.npz       outputs of the REAL reference's Sampler::select_vertices + generateSubgraph and
         LearningGraph::generate_masked_graph (src/gnn/sampler.cpp compiled unmodified into oracle/_ref) on seeded
         graphs from tests/util.random_graph: kept vertex ids + the induced, re-indexed subgraph.
+  partition_p*.npz    outputs of the REAL reference's PartitionedGraph::edgecut_induced_partition1D
+        (src/partitioner/graph_partition.cc + src/common/{graph,VertexSet}.cc compiled unmodified): owned range,
+        local -> global id map and local CSR of every subgraph.
   glorot_*.npy        outputs of libstdc++'s std::default_random_engine +
         std::uniform_real_distribution<float>, the two std calls init_glorot makes
         (math_functions.cpp:11-18), produced by the 12-line program below.
@@ -49,6 +52,9 @@ SAMPLER_CASES = {
     "short_walk": (9000, 6, 22, 5000, 3400, 5),
     "no_walk": (6000, 6, 23, 6000, 2000, 2),          # n < frontier size: only the initial picks
 }
+
+PARTITION_GRAPH = (1203, 7, 5)  # vertices (not a multiple of the part counts), average degree, seed
+PARTITION_CASES = (2, 3, 8)
 
 GLOROT_CASES = [(16, 7, 1), (1433, 16, 1), (128, 128, 1), (128, 128, 2), (64, 1, 2), (64, 1, 3), (100, 47, 1)]
 
@@ -108,6 +114,17 @@ def main():
         np.savez_compressed(HERE / f"sampler_{tag}.npz", kept=kept, sub_rowptr=srp, sub_colidx=sci,
                             masked_rowptr=mrp, masked_colidx_crc=np.uint32(__import__("zlib").crc32(mci.tobytes())),
                             params=np.array([nvtx, deg, gseed, ntrain, n, seed]))
+    # vertex-range partitioner: PartitionedGraph::edgecut_induced_partition1D on a seeded graph
+    for parts in PARTITION_CASES:
+        rp, ci = random_graph(*PARTITION_GRAPH[:2], seed=PARTITION_GRAPH[2], power_law=True)
+        ref_parts = orc.ref_partition(rp, ci, parts)
+        blob = {}
+        for i, r in enumerate(ref_parts):
+            blob[f"range{i}"] = np.array([r["begin"], r["end"]], np.int64)
+            blob[f"idx_map{i}"] = r["idx_map"]
+            blob[f"rowptr{i}"] = r["rowptr"]
+            blob[f"colidx{i}"] = r["colidx"]
+        np.savez_compressed(HERE / f"partition_p{parts}.npz", graph=np.array(PARTITION_GRAPH), **blob)
     with tempfile.TemporaryDirectory() as td:
         src = Path(td) / "g.cpp"
         src.write_text(GLOROT_CPP)
