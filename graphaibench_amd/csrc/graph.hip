@@ -368,6 +368,10 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   if (g->heavy_thr == thr) return GAIB_OK;
   unsigned long long* cnt = nullptr;
   GAIB_HIP(hipMalloc(&cnt, 3 * sizeof(unsigned long long)));
+  struct Release {  // (every early return below goes through GAIB_HIP / GAIB_LAUNCH_CHECK)
+    void* p;
+    ~Release() { (void)hipFree(p); }
+  } release{cnt};
   GAIB_HIP(hipMemsetAsync(cnt, 0, 3 * sizeof(unsigned long long), ctx->stream));
   heavy_rows_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, thr, nullptr,
                                                                  cnt, cnt + 1);
@@ -411,7 +415,6 @@ int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
                             hipMemcpyHostToDevice, ctx->stream));
     GAIB_HIP(hipStreamSynchronize(ctx->stream));
   }
-  GAIB_HIP(hipFree(cnt));
   g->heavy_thr = thr;
   return GAIB_OK;
 }
