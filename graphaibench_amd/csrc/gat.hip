@@ -446,7 +446,7 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
   for (int h = 0; h < H; ++h) { m.v[h] = -INFINITY; d.v[h] = 0.f; }
   // EU edges per thread per trip: all column ids, then all gathers, then the arithmetic -- the loop is
   // latency-bound otherwise (one dependent col -> gather chain in flight per wave)
-  constexpr int EU = 4;
+  constexpr int EU = H >= 8 ? 2 : 4;
   for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
     uint32_t c[EU];
     HeadVec<H> t[EU];
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kern
   HeadVec<H> s;
 #pragma unroll
   for (int h = 0; h < H; ++h) s.v[h] = 0.f;
-  constexpr int EU = 4;
+  constexpr int EU = H >= 8 ? 2 : 4;
   for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
     int64_t r[EU];
     HeadVec<H> g[EU];
