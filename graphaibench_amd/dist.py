@@ -330,11 +330,32 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     n_light, ms_light = ctx.prof_get("spmm_light")
     n_fused, ms_fused = ctx.prof_get("spmm_gemm_fused")
     ctx.prof_reset()
+    # diagnostics outside the timed region (collective: every rank runs them): one halo exchange of a [nv x D]
+    # matrix on its own (pack + all-to-all + wait) and the pack alone -- what the owned-edge SpMM has to hide
+    bytes_timed = dg.ex.bytes_sent
+    feat = layer.tensor(L.FEAT_IN, (nv, D))
+    reps = 3
+    dg.ex.exchange(feat, D)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dg.ex.exchange(feat, D)
+    torch.cuda.synchronize()
+    exch_ms = (time.perf_counter() - t0) / reps * 1e3
+    sendbuf, _ = dg.ex._bufs(D, torch.float32, feat.device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        if part.send_idx.numel():
+            dg.ex.gather_rows(part.send_idx, feat, D, sendbuf)
+    torch.cuda.synchronize()
+    pack_ms = (time.perf_counter() - t0) / reps * 1e3
     # max time over ranks, total edges over ranks
     rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    t = torch.tensor([elapsed, exch_ms, pack_ms], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    e = torch.tensor([float(part.ne), float(part.n_halo), float(dg.ex.bytes_sent)], dtype=torch.float64, device=rdev)
+    exch_ms, pack_ms = float(t[1]), float(t[2])
+    e = torch.tensor([float(part.ne), float(part.n_halo), float(bytes_timed)], dtype=torch.float64, device=rdev)
     dist.all_reduce(e, op=dist.ReduceOp.SUM)
     elapsed = float(t[0])
     total_edges = float(e[0])
@@ -372,6 +393,10 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
             "nv_per_gpu": nv, "ne_total_with_selfloops": int(total_edges), "D": D, "scale": args.scale,
             "cut_fraction": cut, "halo_rows_total": int(e[1]),
             "halo_bytes_per_step_total": float(e[2]) / args.steps,
+            # slowest rank, measured after the timed region: one exchange on its own (pack + all-to-all + wait), the
+            # pack alone, and the owned-edge aggregation kernels of one step that run while the two exchanges fly
+            "halo_exchange_standalone_ms": exch_ms, "halo_pack_ms": pack_ms,
+            "owned_edge_spmm_ms_per_step": ms_light / args.steps,
             "parallelism": f"vertex-range x{world}",
         },
         "roofline": {
