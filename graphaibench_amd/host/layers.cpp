@@ -8,9 +8,8 @@
 
 static inline gaib_ctx* C() { return gpu_context::get(); }
 
-template <typename Aggregator>
-graph_conv_layer<Aggregator>::graph_conv_layer(int id, int nv, int din, int dout, Graph* g, bool act,
-                                               bool concat, float lr, float feat_drop, float score_drop)
+gconv_state::gconv_state(int id, int nv, int din, int dout, Graph* g, bool act, bool concat, float lr,
+                         float feat_drop, float score_drop)
     : level_(id), num_samples(nv), dim_in(din), dim_out(dout), graph(g), is_act(act), is_bias(false),
       use_concat(concat), feat_dropout_rate(feat_drop), score_dropout_rate(score_drop),
       phase_(net_phase::TRAIN), capacity_((size_t)nv), dropout_calls(0), feat_in(NULL), grad_in(NULL),
@@ -54,8 +53,7 @@ graph_conv_layer<Aggregator>::graph_conv_layer(int id, int nv, int din, int dout
 
 // number of rows changes with subgraph sampling (training on subgraphs, evaluation on the full
 // graph); buffers grow when needed (reference GPU build: src/gnn/graph_conv_layer.cu:57-83)
-template <typename Aggregator>
-void graph_conv_layer<Aggregator>::update_dim_size(size_t x) {
+void gconv_state::update_dim_size(size_t x) {
   if (x > capacity_) {
     const size_t nin = x * dim_in, nout = x * dim_out;
     auto regrow = [&](float*& p, size_t n) {
