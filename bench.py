@@ -70,6 +70,8 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
     rng = np.random.default_rng(43)
     W = orc.init_glorot(D, D, 1)
 
+    libs = {"lib": orc.lib()}
+
     def run(R):
         g = orc.Graph.__new__(orc.Graph)
         g.rowptr, g.colidx, g.nv, g.ne, g.vd = g_full.rowptr[:R + 1], g_full.colidx, R, int(g_full.rowptr[R]), vd
@@ -82,7 +84,7 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
         import ctypes as C
         s = g._struct()
         out = np.empty((R, D), np.float32)
-        lib = orc.lib()
+        lib = libs["lib"]
         p = orc._p
         lib.orc_gcn_layer_forward(C.byref(s), C.c_int(D), C.c_int(D), C.c_int(1), p(x), p(W), p(layer.in_temp1[:R]),
                                   p(layer.out_temp[:R]), p(out))
@@ -100,9 +102,16 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
     R = nv if total_edges / rate <= budget_s else max(int(nv * budget_s * rate / total_edges), probe_R)
     R = min(R, nv)
     t, e = run(R)
-    return dict(value=e / t, unit="edges/s", cores=cores, kind="port",
-                sample=f"rows [0,{R}) of the same graph ({e // 2} edges incl. self loops), 1 layer fwd+bwd, "
-                       f"{t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
+    res = dict(value=e / t, unit="edges/s", cores=cores, kind="port",
+               sample=f"rows [0,{R}) of the same graph ({e // 2} edges incl. self loops), 1 layer fwd+bwd, "
+                      f"{t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
+    nat = orc.native_lib()  # second figure with -march=native built on this host, same sample
+    if nat is not None:
+        libs["lib"] = nat
+        run(min(probe_R, nv))
+        tn, en = run(R)
+        res["value_march_native"] = en / tn
+    return res
 
 
 def emit(result: dict) -> None:

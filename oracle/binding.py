@@ -29,15 +29,30 @@ def build(force: bool = False) -> None:
         subprocess.run(["make", "-C", str(HERE), "all"], check=True, capture_output=True)
 
 
+def _declare(l: C.CDLL) -> C.CDLL:
+    l.orc_masked_avg_loss.restype = C.c_float
+    l.orc_masked_accuracy_single.restype = C.c_float
+    l.orc_masked_f1_micro.restype = C.c_float
+    return l
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(str(LIB))
-        _lib.orc_masked_avg_loss.restype = C.c_float
-        _lib.orc_masked_accuracy_single.restype = C.c_float
-        _lib.orc_masked_f1_micro.restype = C.c_float
+        _lib = _declare(C.CDLL(str(LIB)))
     return _lib
+
+
+def native_lib():
+    """the same restatement built with -march=native ON THIS HOST (rebuilt every time: a copy that travelled from
+    another machine may use instructions this CPU lacks).  None if the build fails.  Only for bench.py's second
+    CPU-baseline figure (the reference Makefile has -march=native commented out)."""
+    try:
+        subprocess.run(["make", "-B", "-C", str(HERE), "libgnn_oracle_native.so"], check=True, capture_output=True)
+        return _declare(C.CDLL(str(HERE / "libgnn_oracle_native.so")))
+    except Exception:
+        return None
 
 
 def _f(a):
