@@ -18,13 +18,37 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from graphaibench_amd import synth  # noqa: E402
 
 
+def cora(root: Path, feat_len: int = 1433, seed: int = 0):
+    """the reference's own cora topology / labels / split (tests/golden/cora = byte copies of inputs/cora) with
+    seeded sparse-binary, row-normalised features like the real ones (the shipped dataset has none)"""
+    import shutil
+    gold = Path(__file__).resolve().parent.parent / "tests" / "golden" / "cora"
+    d = root / "cora"
+    d.mkdir(parents=True, exist_ok=True)
+    for f in ("graph.vertex.bin", "graph.edge.bin", "graph.vlabel.bin", "graph.meta.txt"):
+        shutil.copyfile(gold / f, d / f)
+    meta = (d / "graph.meta.txt").read_text().split()
+    meta[7] = str(feat_len)
+    (d / "graph.meta.txt").write_text("\n".join(meta) + "\n")
+    rng = np.random.default_rng(seed)
+    labels = np.fromfile(d / "graph.vlabel.bin", np.uint8).astype(int)
+    nv, ncls = len(labels), int(labels.max()) + 1
+    proto = rng.random((ncls, feat_len)) < 0.03          # class "vocabularies"
+    x = ((rng.random((nv, feat_len)) < 0.008) | (proto[labels] & (rng.random((nv, feat_len)) < 0.3))).astype(np.float32)
+    x /= np.maximum(x.sum(1, keepdims=True), 1.0)
+    x.tofile(d / "graph.feats.bin")
+    print(f"wrote {d}: nv={nv} F={feat_len} C={ncls}")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("name", choices=list(synth.SHAPES))
+    ap.add_argument("name", choices=list(synth.SHAPES) + ["cora"])
     ap.add_argument("root")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     args = ap.parse_args()
+    if args.name == "cora":
+        return cora(Path(args.root))
     nv0, nnz0, maxdeg, F, C = synth.SHAPES[args.name]
     sg = synth.make(args.name, seed=42, device=args.device, scale=args.scale)
     d = Path(args.root) / args.name
