@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, arch="gcn"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -28,11 +28,13 @@ def _worker(rank, world, port, q):
 
         ctx = L.init(0)
         rp, ci = random_graph(3000, 16, seed=13, power_law=True, hub_deg=1500)
-        g = orc.Graph(rp, ci).add_selfloop()
+        g = orc.Graph(rp, ci)
+        if arch == "gcn":
+            g = g.add_selfloop()  # (SAGE aggregates over A, net.cpp:96)
         n, D = g.nv, 128
         x = np.random.default_rng(5).standard_normal((n, D)).astype(np.float32)
         gin = np.random.default_rng(6).standard_normal((n, D)).astype(np.float32)
-        lo_ = orc.GCNLayer(1, g, D, D, True)
+        lo_ = (orc.GCNLayer if arch == "gcn" else orc.SAGELayer)(1, g, D, D, True)
         want = lo_.forward(x)
         want_go = lo_.backward(gin.copy())
         b = gd.partition_bounds(n, world)
@@ -42,7 +44,7 @@ def _worker(rank, world, port, q):
         ci_g = torch.from_numpy(g.colidx[e0:e1].astype(np.int64)).cuda()
         part = gd.build_partition(rp_l, ci_g, n, rank, world)
         dg = gd.DistLayerGraph(ctx, part)
-        layer = L.Layer(L.GCN, 1, hi - lo, D, D, dg.lgraph, True)
+        layer = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, hi - lo, D, D, dg.lgraph, True)
         layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
         out = torch.empty(hi - lo, D, device="cuda")
         layer.forward(out)
@@ -51,8 +53,12 @@ def _worker(rank, world, port, q):
         grad_out = torch.empty(hi - lo, D, device="cuda")
         layer.backward(out, grad_out)
         assert rel_err(grad_out.cpu().numpy(), want_go[lo:hi]) < 1e-4
-        gd.allreduce_layer_grads(ctx, layer, [L.W_NEIGH_GRAD], (D, D))
-        assert rel_err(layer.tensor(L.W_NEIGH_GRAD, (D, D)).cpu().numpy(), lo_.W_grad) < 1e-4
+        which = [L.W_NEIGH_GRAD] if arch == "gcn" else [L.W_NEIGH_GRAD, L.W_SELF_GRAD]
+        gd.allreduce_layer_grads(ctx, layer, which, (D, D))
+        want_wg = lo_.W_grad if arch == "gcn" else lo_.W_neigh_grad
+        assert rel_err(layer.tensor(L.W_NEIGH_GRAD, (D, D)).cpu().numpy(), want_wg) < 1e-4
+        if arch == "sage":  # the self term rode on the halo half of the aggregation (gaib_spmm_gemm2 + GAIB_ACCUMULATE)
+            assert rel_err(layer.tensor(L.W_SELF_GRAD, (D, D)).cpu().numpy(), lo_.W_self_grad) < 1e-4
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -62,11 +68,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_global_oracle():
+@pytest.mark.parametrize("arch", ["gcn", "sage"])
+def test_two_ranks_on_one_gpu_match_global_oracle(arch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 200)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + (os.getpid() % 200) + (0 if arch == "gcn" else 300)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, arch)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
