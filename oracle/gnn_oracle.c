@@ -14,7 +14,7 @@
  *   a1 (LearningGraph::add_selfloop / compute_vertex_data / compute_edge_data) and the
  *   binary reader are pinned bit-for-bit against oracle/_ref (the reference's own
  *   src/gnn/lgraph.cpp + include/gnn/lgraph.h + src/gnn/reader.cpp compiled unmodified,
- *   see oracle/Makefile and tests/test_oracle_vs_ref.py).
+ *   see oracle/Makefile and tests/test_oracle_golden.py).
  *   init_glorot is pinned against libstdc++'s std::default_random_engine /
  *   std::uniform_real_distribution<float> (the two std calls the reference makes).
  *   a2-a12 (aggregators, layers, matmul, adam, loss): ** parity unpinned **.  Those
