@@ -162,6 +162,7 @@ class HaloExchanger:
         self.bytes_sent = 0
         self._buf = {}
         self._pending = None
+        self._sync_fallback = False
 
     def _bufs(self, D, dtype, device):
         key = (D, dtype, str(device))
@@ -181,9 +182,14 @@ class HaloExchanger:
         self.bytes_sent += sendbuf.numel() * sendbuf.element_size()
         work = None
         if p.world > 1:
-            if sendbuf.is_cuda and dist.get_backend(p.group) != "gloo":
-                work = dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=list(p.recv_counts),
-                                              input_split_sizes=list(p.send_counts), group=p.group, async_op=True)
+            if sendbuf.is_cuda and dist.get_backend(p.group) != "gloo" and not self._sync_fallback:
+                try:
+                    work = dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=list(p.recv_counts),
+                                                  input_split_sizes=list(p.send_counts), group=p.group, async_op=True)
+                except (RuntimeError, NotImplementedError):
+                    # a backend without (async) all-to-all(v): pairwise exchange from here on (no overlap, still correct)
+                    self._sync_fallback = True
+                    _all_to_all_rows(recvbuf, sendbuf, p.recv_counts, p.send_counts, p.group)
             else:
                 _all_to_all_rows(recvbuf, sendbuf, p.recv_counts, p.send_counts, p.group)
         self._pending = (work, recvbuf)
