@@ -1,0 +1,78 @@
+"""Randomised sweep of gaib_spmm (every weight kind, multi-head weights, accumulate / relu flags, widths 1..300,
+tiny heavy thresholds) against an fp64 index_add formulation (development aid, GPU box).
+
+    python scripts/fuzz_spmm.py [n_cases] [seed]
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+from graphaibench_amd import capi  # noqa: E402
+from util import random_graph  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    ctx = capi.Context(0)
+    worst = 0.0
+    for case in range(n_cases):
+        nv = int(rng.choice([2, 5, 64, 65, 1000, int(rng.integers(2, 8000))]))
+        rp, ci = random_graph(nv, float(rng.choice([1, 6, 25])), seed=int(rng.integers(1 << 30)), power_law=bool(rng.integers(2)),
+                              hub_deg=int(rng.choice([0, min(nv - 1, 2000)])) if nv > 2100 else 0)
+        nv = len(rp) - 1
+        ctx.set_option("spmm_heavy_threshold", int(rng.choice([1024, 1024, 32, 1])))
+        kind = int(rng.choice([capi.W_GCN, capi.W_MEAN, capi.W_MEAN_T, capi.W_EDGE, capi.W_EDGE_T]))
+        heads = int(rng.choice([1, 1, 2, 4, 8])) if kind in (capi.W_EDGE, capi.W_EDGE_T) else 1
+        dh = int(rng.choice([1, 3, 4, 8, 16, 25, 32]))
+        D = heads * dh if heads > 1 else int(rng.choice([1, 2, 3, 7, 16, 31, 47, 64, 65, 100, 128, 129, 200, 256, 300]))
+        accumulate, relu = bool(rng.integers(2)), bool(rng.integers(2))
+        g = ctx.graph(rp, ci.view(np.int32))
+        if kind == capi.W_GCN:
+            g = g.add_selfloop()
+        ne = g.ne
+        rowptr, col = g.rowptr().long(), g.colidx().long()
+        deg = (rowptr[1:] - rowptr[:-1]).double()
+        rows = torch.repeat_interleave(torch.arange(nv, device="cuda"), rowptr[1:] - rowptr[:-1])
+        x = torch.randn(nv, D, device="cuda")
+        ew = torch.rand(max(ne, 1) * heads, device="cuda")
+        if kind == capi.W_GCN:
+            vd = torch.where(deg > 0, deg.sqrt().reciprocal(), torch.zeros_like(deg))
+            w = (vd[rows] * vd[col]).unsqueeze(1).expand(-1, D)
+        elif kind == capi.W_MEAN:
+            w = (1.0 / deg.clamp(min=1))[rows].unsqueeze(1).expand(-1, D)
+        elif kind == capi.W_MEAN_T:
+            w = (1.0 / deg.clamp(min=1))[col].unsqueeze(1).expand(-1, D)
+        else:
+            we = ew[:ne * heads].view(ne, heads).double()
+            if kind == capi.W_EDGE_T:  # weight of the reverse edge
+                key, rkey = rows * nv + col, col * nv + rows
+                order = torch.argsort(key)
+                we = we[order[torch.searchsorted(key[order], rkey)]]
+            w = we.repeat_interleave(D // heads, dim=1)
+        want = torch.zeros(nv, D, dtype=torch.float64, device="cuda").index_add_(0, rows, w * x.double()[col])
+        out0 = torch.randn(nv, D, device="cuda")
+        out = out0.clone()
+        if accumulate:
+            want = want + out0.double()
+        if relu:
+            want = torch.relu(want)
+        ctx.spmm(g, kind, x, out, edge_w=ew if kind in (capi.W_EDGE, capi.W_EDGE_T) else None, accumulate=accumulate,
+                 relu=relu, heads=heads)
+        ctx.sync()
+        err = (out.double() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        worst = max(worst, err)
+        if not err < 2e-5:
+            print(f"FAIL case {case}: nv={nv} ne={ne} kind={kind} heads={heads} D={D} acc={accumulate} relu={relu} err={err:.2e}")
+            sys.exit(1)
+        g.close()
+    ctx.set_option("spmm_heavy_threshold", 1024)
+    print(f"{n_cases} cases ok, worst relative error {worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()
