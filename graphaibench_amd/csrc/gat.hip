@@ -323,15 +323,30 @@ struct HeadVec {
 // first), partial reductions meet in LDS.  A row's edges are strided over the owner's lanes.
 constexpr int ROW_BLK_WAVES = 16;
 
-template <bool BLK>
+// How a row owner's threads cover the [edge][head] records: a thread handles HV = min(H, 4) heads of an edge
+// (one 16-byte access at H >= 4) and LPE = H / HV neighbouring threads share an edge, so a wave instruction
+// touches whole 128-byte lines (one lane per 32-byte record, as in the first version, touched every line twice
+// and left the waves stalled on memory-instruction issue: SQ_WAIT_INST_ANY 55-73 %).
+template <int H>
+struct HeadSplit {
+  static constexpr int HV = H >= 4 ? 4 : H;
+  static constexpr int LPE = H / HV;
+  static_assert(HV * LPE == H && (LPE & (LPE - 1)) == 0, "H must be 1, 2, 4, 8 or 16");
+};
+
+template <bool BLK, int LPE>
 struct RowOwner {
   int64_t row, e0, e1;
-  int tid, nthreads, lane, wave;
+  int tid, lane, wave;
+  int sub;       // which HV-wide slice of an edge's heads this thread handles
+  int etid;      // edge slot of this thread among the owner's threads
+  int ethreads;  // edges the owner's threads cover per trip
   bool valid;
   __device__ __forceinline__ RowOwner(int64_t nv, const int64_t* rowptr, int heavy_thr,
                                       const uint32_t* row_list, const uint32_t* row_order) {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
+    int nthreads;
     if constexpr (BLK) {
       row = row_list[row_order[blockIdx.x]];
       tid = threadIdx.x;
@@ -343,6 +358,9 @@ struct RowOwner {
       nthreads = 64;
       valid = row < nv;
     }
+    sub = tid % LPE;
+    etid = tid / LPE;
+    ethreads = nthreads / LPE;
     e0 = e1 = 0;
     if (valid) {
       e0 = rowptr[row];
@@ -352,55 +370,70 @@ struct RowOwner {
   }
 };
 
-// sum over the row owner's threads; lds: [ROW_BLK_WAVES][H] floats (BLK only).  Fixed order.
-template <int H, bool BLK>
-__device__ __forceinline__ void owner_sum(HeadVec<H>& v, int wave, int lane, float* lds) {
+// reductions over the lanes of a wave that handle the SAME head slice (lane % LPE equal)
+template <int LPE>
+__device__ __forceinline__ float slice_sum(float v) {
 #pragma unroll
-  for (int h = 0; h < H; ++h) v.v[h] = wave_sum(v.v[h]);
+  for (int o = 32; o >= LPE; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPE>
+__device__ __forceinline__ float slice_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= LPE; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// sum over the row owner's threads of one head slice; lds: [ROW_BLK_WAVES][LPE][HV] floats (BLK only).  Fixed order.
+template <int HV, int LPE, bool BLK>
+__device__ __forceinline__ void owner_sum(HeadVec<HV>& v, int wave, int lane, int sub, float* lds) {
+#pragma unroll
+  for (int h = 0; h < HV; ++h) v.v[h] = slice_sum<LPE>(v.v[h]);
   if constexpr (BLK) {
     __syncthreads();  // lds may still be read from a previous reduction
-    if (lane == 0) {
+    if (lane < LPE) {  // (lane == sub here)
 #pragma unroll
-      for (int h = 0; h < H; ++h) lds[wave * H + h] = v.v[h];
+      for (int h = 0; h < HV; ++h) lds[(wave * LPE + sub) * HV + h] = v.v[h];
     }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      float t = lds[h];
-      for (int w = 1; w < ROW_BLK_WAVES; ++w) t += lds[w * H + h];
+    for (int h = 0; h < HV; ++h) {
+      float t = lds[sub * HV + h];
+      for (int w = 1; w < ROW_BLK_WAVES; ++w) t += lds[(w * LPE + sub) * HV + h];
       v.v[h] = t;
     }
   }
 }
 
-// (m, d) = (running maximum, sum of exp(s - m)) per lane -> the row's (M, D) in every thread
-template <int H, bool BLK>
-__device__ __forceinline__ void owner_softmax_stats(HeadVec<H>& m, HeadVec<H>& d, int wave, int lane, float* lds) {
+// (m, d) = (running maximum, sum of exp(s - m)) per thread -> the row's (M, D) of the thread's head slice
+template <int HV, int LPE, bool BLK>
+__device__ __forceinline__ void owner_softmax_stats(HeadVec<HV>& m, HeadVec<HV>& d, int wave, int lane, int sub,
+                                                    float* lds) {
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    const float mw = wave_max(m.v[h]);
+  for (int h = 0; h < HV; ++h) {
+    const float mw = slice_max<LPE>(m.v[h]);
     const float scaled = (m.v[h] == -INFINITY) ? 0.f : d.v[h] * expf(m.v[h] - mw);
-    d.v[h] = wave_sum(scaled);
+    d.v[h] = slice_sum<LPE>(scaled);
     m.v[h] = mw;
   }
   if constexpr (BLK) {
     __syncthreads();
-    if (lane == 0) {
+    if (lane < LPE) {
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        lds[(wave * H + h) * 2] = m.v[h];
-        lds[(wave * H + h) * 2 + 1] = d.v[h];
+      for (int h = 0; h < HV; ++h) {
+        lds[((wave * LPE + sub) * HV + h) * 2] = m.v[h];
+        lds[((wave * LPE + sub) * HV + h) * 2 + 1] = d.v[h];
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
+    for (int h = 0; h < HV; ++h) {
       float M = -INFINITY;
-      for (int w = 0; w < ROW_BLK_WAVES; ++w) M = fmaxf(M, lds[(w * H + h) * 2]);
+      for (int w = 0; w < ROW_BLK_WAVES; ++w) M = fmaxf(M, lds[((w * LPE + sub) * HV + h) * 2]);
       float D = 0.f;
       for (int w = 0; w < ROW_BLK_WAVES; ++w) {
-        const float mw = lds[(w * H + h) * 2];
-        if (mw != -INFINITY) D += lds[(w * H + h) * 2 + 1] * expf(mw - M);
+        const float mw = lds[((w * LPE + sub) * HV + h) * 2];
+        if (mw != -INFINITY) D += lds[((w * LPE + sub) * HV + h) * 2 + 1] * expf(mw - M);
       }
       m.v[h] = M;
       d.v[h] = D;
@@ -409,61 +442,62 @@ __device__ __forceinline__ void owner_softmax_stats(HeadVec<H>& m, HeadVec<H>& d
 }
 
 // temp = sl[i] + sr[col]; s = leaky_relu(temp); norm = softmax_row(s)   (gat_aggregator.cpp:64-77).
-// Rows that fit one edge per lane stay in registers; longer rows take two passes: an online
+// Rows that fit one edge per thread group stay in registers; longer rows take two passes: an online
 // (max, sum) pass that writes temp, then norm = exp(s - M) / D from the re-read temp.  132 B per edge
 // at H = 8 (4 col + 32 gathered + 32 temp + 32 re-read + 32 norm); `scores` is optional (+32 B).
 template <int H, bool BLK>
 __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v2_kernel(
     int64_t nv, const int64_t* rowptr, const uint32_t* col, const float* sl, const float* sr, float eps,
     float* temp, float* scores, float* norm, int heavy_thr, const uint32_t* row_list, const uint32_t* row_order) {
+  constexpr int HV = HeadSplit<H>::HV, LPE = HeadSplit<H>::LPE;
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H * 2 : 1];
-  const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
+  const RowOwner<BLK, LPE> o(nv, rowptr, heavy_thr, row_list, row_order);
   if (!o.valid || o.e0 == o.e1) return;
-  HeadVec<H> ssrc, m, d;
-  ssrc.load(sl + o.row * H);
-  if (!BLK && o.e1 - o.e0 <= 64) {
-    const int64_t e = o.e0 + o.lane;
+  const int hb = o.sub * HV;  // first head of this thread's slice
+  HeadVec<HV> ssrc, m, d;
+  ssrc.load(sl + o.row * H + hb);
+  if (!BLK && o.e1 - o.e0 <= 64 / LPE) {
+    const int64_t e = o.e0 + o.etid;
     const bool ok = e < o.e1;
-    HeadVec<H> t, s;
-    if (ok) t.load(sr + (int64_t)col[e] * H);
+    HeadVec<HV> t, s;
+    t.load(sr + (int64_t)(ok ? col[e] : 0u) * H + hb);
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
+    for (int h = 0; h < HV; ++h) {
       t.v[h] = ssrc.v[h] + t.v[h];
       s.v[h] = ok ? (t.v[h] > 0.0f ? t.v[h] : eps * t.v[h]) : -INFINITY;
-      const float mx = wave_max(s.v[h]);
+      const float mx = slice_max<LPE>(s.v[h]);
       const float ex = ok ? expf(s.v[h] - mx) : 0.f;
-      const float den = wave_sum(ex);
+      const float den = slice_sum<LPE>(ex);
       m.v[h] = ex / den;
     }
     if (ok) {
-      t.store(temp + e * H);
-      if (scores) s.store(scores + e * H);
-      m.store(norm + e * H);
+      t.store(temp + e * H + hb);
+      if (scores) s.store(scores + e * H + hb);
+      m.store(norm + e * H + hb);
     }
     return;
   }
 #pragma unroll
-  for (int h = 0; h < H; ++h) { m.v[h] = -INFINITY; d.v[h] = 0.f; }
-  // EU edges per thread per trip: all column ids, then all gathers, then the arithmetic -- the loop is
-  // latency-bound otherwise (one dependent col -> gather chain in flight per wave)
-  constexpr int EU = H >= 8 ? 2 : 4;
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
+  for (int h = 0; h < HV; ++h) { m.v[h] = -INFINITY; d.v[h] = 0.f; }
+  // EU edges per thread per trip: all column ids, then all gathers, then the arithmetic
+  constexpr int EU = 4;
+  for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {
     uint32_t c[EU];
-    HeadVec<H> t[EU];
+    HeadVec<HV> t[EU];
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t eu = e + (int64_t)u * o.ethreads;
       c[u] = eu < o.e1 ? col[eu] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < EU; ++u) t[u].load(sr + (int64_t)c[u] * H);
+    for (int u = 0; u < EU; ++u) t[u].load(sr + (int64_t)c[u] * H + hb);
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t eu = e + (int64_t)u * o.ethreads;
       if (eu < o.e1) {
-        HeadVec<H> s;
+        HeadVec<HV> s;
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < HV; ++h) {
           t[u].v[h] = ssrc.v[h] + t[u].v[h];
           s.v[h] = t[u].v[h] > 0.0f ? t[u].v[h] : eps * t[u].v[h];
           // online softmax statistics with one expf: ex = exp(-|s - m|)
@@ -472,31 +506,31 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
           d.v[h] = up ? d.v[h] * ex + 1.0f : d.v[h] + ex;
           m.v[h] = up ? s.v[h] : m.v[h];
         }
-        t[u].store(temp + eu * H);
-        if (scores) s.store(scores + eu * H);
+        t[u].store(temp + eu * H + hb);
+        if (scores) s.store(scores + eu * H + hb);
       }
     }
   }
-  owner_softmax_stats<H, BLK>(m, d, o.wave, o.lane, lds);
+  owner_softmax_stats<HV, LPE, BLK>(m, d, o.wave, o.lane, o.sub, lds);
 #pragma unroll
-  for (int h = 0; h < H; ++h) d.v[h] = 1.0f / d.v[h];
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {  // each thread re-reads only its own writes
-    HeadVec<H> t[EU];
+  for (int h = 0; h < HV; ++h) d.v[h] = 1.0f / d.v[h];
+  for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {  // each thread re-reads only its own writes
+    HeadVec<HV> t[EU];
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
-      t[u].load(temp + (eu < o.e1 ? eu : o.e0) * H);
+      const int64_t eu = e + (int64_t)u * o.ethreads;
+      t[u].load(temp + (eu < o.e1 ? eu : o.e0) * H + hb);
     }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t eu = e + (int64_t)u * o.ethreads;
       if (eu < o.e1) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < HV; ++h) {
           const float sv = t[u].v[h] > 0.0f ? t[u].v[h] : eps * t[u].v[h];
           t[u].v[h] = __expf(sv - m.v[h]) * d.v[h];  // d holds 1/D here
         }
-        t[u].store(norm + eu * H);
+        t[u].store(norm + eu * H + hb);
       }
     }
   }
@@ -512,59 +546,61 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2
     int64_t nv, const int64_t* rowptr, const float* p, const float* dp, const float* temp, float eps,
     const float* rowdot, float* scores, float* gbuf, int pack, float* rs, int heavy_thr,
     const uint32_t* row_list, const uint32_t* row_order) {
+  constexpr int HV = HeadSplit<H>::HV, LPE = HeadSplit<H>::LPE;
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
-  const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
+  const RowOwner<BLK, LPE> o(nv, rowptr, heavy_thr, row_list, row_order);
   if (!o.valid) return;
-  HeadVec<H> dot, gs;
+  const int hb = o.sub * HV;
+  HeadVec<HV> dot, gs;
 #pragma unroll
-  for (int h = 0; h < H; ++h) { dot.v[h] = 0.f; gs.v[h] = 0.f; }
+  for (int h = 0; h < HV; ++h) { dot.v[h] = 0.f; gs.v[h] = 0.f; }
   if constexpr (DOT) {
-    dot.load(rowdot + o.row * H);
+    dot.load(rowdot + o.row * H + hb);
   } else {
-    for (int64_t e = o.e0 + o.tid; e < o.e1; e += o.nthreads) {
-      HeadVec<H> a, b;
-      a.load(p + e * H);
-      b.load(dp + e * H);
+    for (int64_t e = o.e0 + o.etid; e < o.e1; e += o.ethreads) {
+      HeadVec<HV> a, b;
+      a.load(p + e * H + hb);
+      b.load(dp + e * H + hb);
 #pragma unroll
-      for (int h = 0; h < H; ++h) dot.v[h] += a.v[h] * b.v[h];
+      for (int h = 0; h < HV; ++h) dot.v[h] += a.v[h] * b.v[h];
     }
-    owner_sum<H, BLK>(dot, o.wave, o.lane, lds);
+    owner_sum<HV, LPE, BLK>(dot, o.wave, o.lane, o.sub, lds);
   }
-  constexpr int EU = H >= 8 ? 2 : 4;  // three streams per edge: keep the live registers in check
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
-    HeadVec<H> a[EU], b[EU], t[EU];
+  constexpr int EU = 4;
+  for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {
+    HeadVec<HV> a[EU], b[EU], t[EU];
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t eu = e + (int64_t)u * o.ethreads;
       const int64_t es = eu < o.e1 ? eu : o.e0;
-      a[u].load(p + es * H);
-      b[u].load(dp + es * H);
-      t[u].load(temp + es * H);
+      a[u].load(p + es * H + hb);
+      b[u].load(dp + es * H + hb);
+      t[u].load(temp + es * H + hb);
     }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t eu = e + (int64_t)u * o.ethreads;
       if (eu < o.e1) {
-        HeadVec<H> ds, ge;
+        HeadVec<HV> ds, ge;
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < HV; ++h) {
           const float x = a[u].v[h] * (1.0f - a[u].v[h]) * b[u].v[h];
           ds.v[h] = x - (dot.v[h] - a[u].v[h] * b[u].v[h]) * a[u].v[h];
           ge.v[h] = ds.v[h] * (t[u].v[h] > 0.0f ? 1.0f : eps);
           gs.v[h] += ge.v[h];
         }
-        if (scores) ds.store(scores + eu * H);
+        if (scores) ds.store(scores + eu * H + hb);
         if (pack) {  // (g, p) side by side: the column-sum pass fetches both with one random access
-          ge.store(gbuf + eu * 2 * H);
-          a[u].store(gbuf + eu * 2 * H + H);
+          ge.store(gbuf + eu * 2 * H + hb);
+          a[u].store(gbuf + eu * 2 * H + H + hb);
         } else {
-          ge.store(gbuf + eu * H);
+          ge.store(gbuf + eu * H + hb);
         }
       }
     }
   }
-  owner_sum<H, BLK>(gs, o.wave, o.lane, lds);
-  if (o.tid == 0) gs.store(rs + o.row * H);
+  owner_sum<HV, LPE, BLK>(gs, o.wave, o.lane, o.sub, lds);
+  if (o.tid < LPE) gs.store(rs + o.row * H + hb);
 }
 
 // cs[v] = sum_{e in row v} g[rev[e]]  == column sum of g (structurally symmetric graph); optionally also
@@ -574,40 +610,43 @@ template <int H, bool BLK>
 __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kernel(
     int64_t nv, const int64_t* rowptr, const uint32_t* rev, const float* gbuf, float* cs,
     float* pT, int heavy_thr, const uint32_t* row_list, const uint32_t* row_order) {
+  constexpr int HV = HeadSplit<H>::HV, LPE = HeadSplit<H>::LPE;
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
-  const RowOwner<BLK> o(nv, rowptr, heavy_thr, row_list, row_order);
+  const RowOwner<BLK, LPE> o(nv, rowptr, heavy_thr, row_list, row_order);
   if (!o.valid) return;
-  HeadVec<H> s;
+  const int hb = o.sub * HV;
+  HeadVec<HV> s;
 #pragma unroll
-  for (int h = 0; h < H; ++h) s.v[h] = 0.f;
-  constexpr int EU = H >= 8 ? 2 : 4;
-  for (int64_t e = o.e0 + o.tid; e < o.e1; e += (int64_t)EU * o.nthreads) {
+  for (int h = 0; h < HV; ++h) s.v[h] = 0.f;
+  constexpr int EU = 4;
+  const int rec = (pT ? 2 : 1) * H;  // floats per edge record in gbuf
+  for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {
     int64_t r[EU];
-    HeadVec<H> g[EU];
+    HeadVec<HV> g[EU];
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.nthreads;
+      const int64_t eu = e + (int64_t)u * o.ethreads;
       r[u] = eu < o.e1 ? (int64_t)rev[eu] : -1;
     }
 #pragma unroll
-    for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * (pT ? 2 : 1) * H);
+    for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * rec + hb);
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       if (r[u] >= 0) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) s.v[h] += g[u].v[h];
+        for (int h = 0; h < HV; ++h) s.v[h] += g[u].v[h];
       }
     }
     if (pT) {  // the transposed attention for the gradient aggregation, while rev[e] is at hand
 #pragma unroll
-      for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * 2 * H + H);  // same line as g
+      for (int u = 0; u < EU; ++u) g[u].load(gbuf + (r[u] < 0 ? 0 : r[u]) * rec + H + hb);  // same line as g
 #pragma unroll
       for (int u = 0; u < EU; ++u)
-        if (r[u] >= 0) g[u].store(pT + (e + (int64_t)u * o.nthreads) * H);
+        if (r[u] >= 0) g[u].store(pT + (e + (int64_t)u * o.ethreads) * H + hb);
     }
   }
-  owner_sum<H, BLK>(s, o.wave, o.lane, lds);
-  if (o.tid == 0) s.store(cs + o.row * H);
+  owner_sum<HV, LPE, BLK>(s, o.wave, o.lane, o.sub, lds);
+  if (o.tid < LPE) s.store(cs + o.row * H + hb);
 }
 
 // rowdot[v,h] = <a[v, slice h], b[v, slice h]>.  One wave per row.
