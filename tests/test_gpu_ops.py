@@ -288,6 +288,10 @@ GEMM_SHAPES = [
     (5000, 128, 100, 0, 0, 1),   # accum (SAGE W_self)
     (5000, 100, 128, 0, 1, 1),
     (100, 128, 20011, 1, 0, 1),  # split-K + accum, ragged K
+    (128, 128, 40001, 1, 0, 0),  # long K, M, N <= 128: register-resident split-K kernel (odd K)
+    (100, 47, 33000, 1, 0, 1),   # ... ragged M / N, accumulate
+    (7, 16, 70000, 1, 0, 0),
+    (128, 96, 32768, 1, 0, 0),
     (1, 1, 1, 0, 0, 0),
     (33, 65, 129, 0, 0, 0),
     (257, 33, 31, 0, 1, 0),
@@ -726,6 +730,7 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, d, d_out):
 
 
 @pytest.mark.parametrize("m,n,k,accum", [(128, 128, 20011, False), (100, 128, 9000, True), (256, 192, 4097, False),
+                                         (128, 128, 50001, False), (100, 47, 40000, True), (16, 7, 33333, False),
                                          (128, 47, 3000, False), (16, 64, 500, True), (130, 130, 777, False)])
 def test_sgemm_drelu(ctx, m, n, k, accum):
     """weight gradient with d_relu folded in: G masked in place (== d_relu_gpu), C (+)= A^T . G"""
@@ -737,12 +742,17 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
     C0 = rng.standard_normal((m, n)).astype(np.float32)
     Gm = orc.d_relu(G, mask)
     want = orc.matmul(A, Gm, True, False, C0 if accum else None)
-    Gd, Cd = dev(G.copy()), dev(C0.copy())
-    ctx.sgemm_drelu(dev(A), Gd, dev(mask), Cd, accum=accum)
-    assert np.array_equal(Gd.cpu().numpy().view(np.uint32), Gm.view(np.uint32))  # the in-place d_relu is exact
-    assert rel_err(Cd.cpu().numpy(), want) < TOL
     ref64 = A.T.astype(np.float64) @ Gm.astype(np.float64) + (C0 if accum else 0)
-    assert rel_err(Cd.cpu().numpy(), ref64) < 2e-5
+    for variant in (0, 31):  # 31: the register-resident split-K kernel with the mask folded in (long K only)
+        ctx.set_option("sgemm_variant", variant)
+        try:
+            Gd, Cd = dev(G.copy()), dev(C0.copy())
+            ctx.sgemm_drelu(dev(A), Gd, dev(mask), Cd, accum=accum)
+        finally:
+            ctx.set_option("sgemm_variant", 0)
+        assert np.array_equal(Gd.cpu().numpy().view(np.uint32), Gm.view(np.uint32))  # the in-place d_relu is exact
+        assert rel_err(Cd.cpu().numpy(), want) < TOL
+        assert rel_err(Cd.cpu().numpy(), ref64) < 2e-5
 
 
 @pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21])
