@@ -308,10 +308,12 @@ __global__ void splitk_reduce_kernel(int64_t n, int splits, const float* partial
 // Partials go to a slab per wave and are summed in fixed order by splitk_reduce_kernel.
 // BMASK: B <- B where mask > 0 else 0 on the way (d_relu folded in), written back in place -- K ranges are
 // disjoint, so every element is written exactly once.
-constexpr int TN_PD = 8;  // pairs of rows per register set
+// pairs of rows per register set: 8 plain, 4 with the mask rows travelling along (register budget)
+template <bool BMASK> struct TnDepth { static constexpr int PD = BMASK ? 4 : 8; };
 
 template <bool BMASK>
 __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
+  constexpr int TN_PD = TnDepth<BMASK>::PD;
   const int lane = threadIdx.x & 63;
   const int i = lane & 31, h = lane >> 5;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
   const int mo = mok ? 4 * i : 0, no = nok ? 4 * i : 0;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f4 sa[2][TN_PD], sb[2][TN_PD];
+  f4 sm[BMASK ? 2 : 1][BMASK ? TN_PD : 1];  // BMASK: the mask rows travel with the set and are applied when it is consumed
 
   // load the TN_PD row pairs starting at row kp into register set `set`.  full: every row exists -> no selects on the
   // loaded values (a select makes the compiler wait for each load where it is issued).  Lanes beyond M / N read
@@ -341,10 +344,9 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
       f4 va = *reinterpret_cast<const f4*>(g.A + kr * g.M + mo);
       f4 vb = *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
       if constexpr (BMASK) {
-        const f4 mk = *reinterpret_cast<const f4*>(g.bmask + kr * g.N + no);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vb[e] = mk[e] > 0.f ? vb[e] : 0.f;  // d_relu (math_functions.cu:258-268)
-        if (kok && nok) *reinterpret_cast<f4*>(g.bwrite + kr * g.N + no) = vb;
+        f4 mk = *reinterpret_cast<const f4*>(g.bmask + kr * g.N + no);
+        if (!full) mk = kok ? mk : zero4;  // (a zero mask also keeps the row out of the write-back below)
+        sm[set][s] = mk;
       }
       if (!full) {  // rows past the end of this wave's range must not contribute
         va = kok ? va : zero4;
@@ -354,6 +356,21 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
       sb[set][s] = vb;
     }
     __builtin_amdgcn_sched_barrier(0);  // all loads of the set are issued before the MFMAs that follow
+  };
+  // BMASK: d_relu on the set that is about to be consumed (its loads landed a whole set ago), masked rows written back
+  auto apply_mask = [&](int set, int64_t kp, bool full) {
+    if constexpr (BMASK) {
+#pragma unroll
+      for (int s = 0; s < TN_PD; ++s) {
+        f4 vb = sb[set][s];
+        const f4 mk = sm[set][s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vb[e] = mk[e] > 0.f ? vb[e] : 0.f;  // d_relu (math_functions.cu:258-268)
+        sb[set][s] = vb;
+        const int64_t k = kp + 2 * s + h;
+        if (nok && (full || k < kend)) *reinterpret_cast<f4*>(g.bwrite + k * g.N + no) = vb;
+      }
+    }
   };
   auto compute = [&](int set) {
     __builtin_amdgcn_sched_barrier(0);
@@ -368,22 +385,34 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
   constexpr int64_t GROUP = 2 * TN_PD;  // rows per register set
   if (kbeg < kend) {
     int64_t kp = kbeg;
-    fetch(0, kp, kp + GROUP <= kend);
+    const bool f0 = kp + GROUP <= kend;
+    fetch(0, kp, f0);
+    bool full0 = f0;
     // steady state: two full groups per trip, no predicates on the loads
     while (kp + 3 * GROUP <= kend) {
       fetch(1, kp + GROUP, true);
+      apply_mask(0, kp, true);
       compute(0);
       fetch(0, kp + 2 * GROUP, true);
+      apply_mask(1, kp + GROUP, true);
       compute(1);
       kp += 2 * GROUP;
+      full0 = true;
     }
     // tail: set 0 holds the group at kp; at most two more (possibly partial) groups follow
-    if (kp + GROUP < kend) fetch(1, kp + GROUP, kp + 2 * GROUP <= kend);
+    const bool more1 = kp + GROUP < kend, more2 = kp + 2 * GROUP < kend;
+    const bool full1 = kp + 2 * GROUP <= kend;
+    if (more1) fetch(1, kp + GROUP, full1);
+    apply_mask(0, kp, full0 && kp + GROUP <= kend);
     compute(0);
-    if (kp + GROUP < kend) {
-      if (kp + 2 * GROUP < kend) fetch(0, kp + 2 * GROUP, false);
+    if (more1) {
+      if (more2) fetch(0, kp + 2 * GROUP, false);
+      apply_mask(1, kp + GROUP, full1);
       compute(1);
-      if (kp + 2 * GROUP < kend) compute(0);
+      if (more2) {
+        apply_mask(0, kp + 2 * GROUP, false);
+        compute(0);
+      }
     }
   }
   // partial slab of this wave.  C/D map of the 32x32 MFMA: col j = lane&31, row r_ = (r&3) + 8*(r>>2) + 4*(lane>>5);
@@ -407,7 +436,8 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
 // M, N <= 128 weight gradients with a long K: one wave per SIMD of the whole chip
 int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
   const int64_t waves = (int64_t)ctx->num_cus * 4;
-  int64_t chunk = cdiv64(cdiv64(g.K, waves), 2 * TN_PD) * (2 * TN_PD);  // whole register sets per wave
+  const int64_t group = 2 * (g.bmask ? TnDepth<true>::PD : TnDepth<false>::PD);
+  int64_t chunk = cdiv64(cdiv64(g.K, waves), group) * group;  // whole register sets per wave
   const int64_t active = cdiv64(g.K, chunk);            // waves that own rows
   const unsigned blocks = (unsigned)cdiv64(active, 4);
   float* Cout = g.C;
@@ -578,9 +608,9 @@ extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, 
   GAIB_CHECK(M >= 0 && N >= 0 && K >= 0, "gaib_sgemm_drelu: negative dimension");
   GAIB_CHECK(K == 0 || N == 0 || (d_G && d_mask), "gaib_sgemm_drelu: G/mask is NULL");
   const bool aligned = ((((uintptr_t)d_A | (uintptr_t)d_G | (uintptr_t)d_mask) & 15) == 0) && M % 4 == 0 && N % 4 == 0;
-  // the register-resident kernel loses with the mask folded in (1.39 vs 1.18 ms at 2.45 M x 128 x 128: mask loads, selects
-  // and write-back sit in its load stream); sgemm_variant 31 selects it for experiments
-  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant == 31;
+  // long K, M, N <= 128: the register-resident split-K kernel (mask rows travel with the operand sets and are applied
+  // when a set is consumed); sgemm_variant 30 keeps the LDS kernel
+  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant != 30;
   if (M == 0 || N == 0 || K == 0 || (!reg_path && (!aligned || N <= 64))) {
     // shapes the masked kernel is not built for: the two-step form
     if (K > 0 && N > 0) GAIB_TRY(gaib_d_relu(ctx, K * N, d_G, d_mask, d_G));
