@@ -492,7 +492,7 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
   // more resident blocks hide the staging / epilogue phases of one block under another's MFMAs.
 #define GAIB_GEMM_LAUNCH(AV, BV, OCC)                                                    \
   sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV, OCC><<<grid, THREADS, 0, ctx->stream>>>(g)
-  const int occ = ctx->sgemm_variant == 2 ? 2 : ((ctx->sgemm_variant == 4 || ctx->sgemm_variant >= 10) ? 4 : 3);
+  const int occ = ctx->sgemm_variant == 2 ? 2 : ((ctx->sgemm_variant == 4 || (ctx->sgemm_variant >= 10 && ctx->sgemm_variant < 20)) ? 4 : 3);
   if constexpr (AK && BKM) {
     if (g.bmask) {  // (the entry point only takes this path with 16-B aligned operands)
       sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 3, true><<<grid, THREADS, 0, ctx->stream>>>(g);
@@ -506,7 +506,7 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
       return GAIB_OK;
     }
   }
-  if (avec && bvec && ctx->sgemm_variant >= 20) {
+  if (avec && bvec && (ctx->sgemm_variant == 20 || ctx->sgemm_variant == 21)) {
     // experimental: LDS double buffering (one barrier per K-step); 20 -> 2 workgroups/CU, 21 -> 3
     if (ctx->sgemm_variant == 21)
       sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 3, false, true><<<grid, THREADS, 0, ctx->stream>>>(g);
@@ -608,9 +608,10 @@ extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, 
   GAIB_CHECK(M >= 0 && N >= 0 && K >= 0, "gaib_sgemm_drelu: negative dimension");
   GAIB_CHECK(K == 0 || N == 0 || (d_G && d_mask), "gaib_sgemm_drelu: G/mask is NULL");
   const bool aligned = ((((uintptr_t)d_A | (uintptr_t)d_G | (uintptr_t)d_mask) & 15) == 0) && M % 4 == 0 && N % 4 == 0;
-  // long K, M, N <= 128: the register-resident split-K kernel (mask rows travel with the operand sets and are applied
-  // when a set is consumed); sgemm_variant 30 keeps the LDS kernel
-  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant != 30;
+  // sgemm_variant 32: the register-resident split-K kernel (mask rows travel with the operand sets and are applied
+  // when a set is consumed).  Alone it beats the LDS kernel (1.03 vs 1.16 ms at the headline shape); inside the layer
+  // step, behind the aggregation kernel, it is the slower one (1.15 vs 1.10 ms), so the LDS kernel is the default.
+  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant == 32;
   if (M == 0 || N == 0 || K == 0 || (!reg_path && (!aligned || N <= 64))) {
     // shapes the masked kernel is not built for: the two-step form
     if (K > 0 && N > 0) GAIB_TRY(gaib_d_relu(ctx, K * N, d_G, d_mask, d_G));

@@ -743,7 +743,7 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
     Gm = orc.d_relu(G, mask)
     want = orc.matmul(A, Gm, True, False, C0 if accum else None)
     ref64 = A.T.astype(np.float64) @ Gm.astype(np.float64) + (C0 if accum else 0)
-    for variant in (0, 30):  # 30: the LDS-tiled kernel also where the register-resident split-K kernel would run (long K)
+    for variant in (0, 32):  # 32: the register-resident split-K kernel instead of the LDS-tiled one (long K)
         ctx.set_option("sgemm_variant", variant)
         try:
             Gd, Cd = dev(G.copy()), dev(C0.copy())
