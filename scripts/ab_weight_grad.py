@@ -1,3 +1,5 @@
+"""A/B of the weight-gradient kernels inside the layer step (sgemm_variant 0 / 30 / 31 / 32), GCN and SAGE 128->128
+on the products-shaped graph: wall time per step and the HIP-event time of the GEMM launches."""
 import sys, time, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,0 +1,152 @@
+"""GPU suite past the 32-bit limits the reference's index arithmetic has (`dst * len` and the edge
+offsets are uint32 there, include/gnn/lgraph.h; ogbn-papers100M's 3.2 G edges / 111 M x 128 features do not fit):
+
+  * N . D > 2^32 elements  (34 M vertices x 128 floats = 17.4 GB per matrix): aggregation, the fused aggregation +
+    dense product, the weight gradient (K = 34 M rows), relu / d_relu over > 2^32 elements
+  * E just under 2^32 edges (4.2 M vertices x 1024 neighbours, 17.2 GB of column ids -- edge ids stay uint32 like
+    the reference's index_t, so 2^32 - 1 is the documented per-GPU limit and gaib_graph_create refuses more):
+    aggregation through the one-row-per-wave kernel and through the heavy-row kernel, edge offsets past 2^31
+
+Inputs are integer valued and the weights powers of two where that makes every sum exact, so the sampled rows are
+compared bit for bit with a torch gather of the same rows.  288 GB of HBM is what makes these sizes one-GPU tests.
+"""
+import pytest
+import torch
+
+from graphaibench_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _need(gb):
+    free, _ = torch.cuda.mem_get_info()
+    if free < gb * (1 << 30):
+        pytest.skip(f"needs {gb} GB of free HBM, {free >> 30} GB available")
+
+
+def _int_rows(n, d, mod, chunk=1 << 22):
+    """x[r, c] = ((31 r + 17 c) mod `mod`) - mod // 2 as fp32, built in row chunks"""
+    x = torch.empty(n, d, device="cuda", dtype=torch.float32)
+    cols = torch.arange(d, device="cuda", dtype=torch.int64) * 17
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        r = torch.arange(r0, r1, device="cuda", dtype=torch.int64).unsqueeze(1) * 31
+        x[r0:r1] = (((r + cols) % mod) - mod // 2).to(torch.float32)
+    return x
+
+
+def _sample_rows(n, k, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    rows = torch.randint(0, n, (k,), generator=g, device="cuda", dtype=torch.int64)
+    edge = torch.tensor([0, 1, n // 2, n - 2, n - 1], device="cuda", dtype=torch.int64)  # both ends of every array
+    return torch.cat([rows, edge])
+
+
+def test_feature_offsets_beyond_2_32(ctx):
+    _need(120)
+    n, d = 34_000_001, 128
+    assert n * d > 1 << 32
+    # three neighbours per vertex: i, i + n/3, i + 2n/3 (mod n), sorted
+    i = torch.arange(n, device="cuda", dtype=torch.int64)
+    cols = torch.stack([i, (i + n // 3) % n, (i + 2 * (n // 3)) % n], 1).sort(1).values
+    rowptr = torch.arange(n + 1, device="cuda", dtype=torch.int64) * 3
+    g = ctx.graph(rowptr, cols.reshape(-1).to(torch.int32))
+    del i
+    x = _int_rows(n, d, 13)
+    out = torch.empty_like(x)
+    rows = _sample_rows(n, 50_000, 1)
+    inv = torch.tensor(1.0 / 3.0, dtype=torch.float64).to(torch.float32).cuda()  # 1.0 / float(deg), narrowed
+
+    def mean_rows(src):  # the operator's order: product then sum, edge by edge (sage_aggregator.cpp:7-30)
+        c = cols[rows]
+        acc = src[c[:, 0]] * inv
+        acc = acc + src[c[:, 1]] * inv
+        return acc + src[c[:, 2]] * inv
+
+    ctx.spmm(g, capi.W_MEAN, x, out)
+    ctx.sync()
+    assert torch.equal(out[rows], mean_rows(x))
+
+    # aggregation with the dense product riding on it: agg rows as above, out = relu(agg . W)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    W = torch.randn(d, d, device="cuda", generator=gen) / 8
+    agg = torch.empty_like(x)
+    ctx.spmm_gemm(g, capi.W_MEAN, x, agg, W, out, relu=True)
+    ctx.sync()
+    want_agg = mean_rows(x)
+    assert torch.equal(agg[rows], want_agg)
+    want = torch.relu(want_agg.double() @ W.double())
+    assert (out[rows].double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+    # weight gradient over K = 34 M rows (split-K over the whole range): dW = x^T . agg, against fp64 on row blocks
+    dW = torch.empty(d, d, device="cuda")
+    ctx.sgemm(x, agg, dW, transA=True)
+    ctx.sync()
+    ref = torch.zeros(d, d, device="cuda", dtype=torch.float64)
+    step = 1 << 21
+    for r0 in range(0, n, step):
+        ref += x[r0:r0 + step].double().T @ agg[r0:r0 + step].double()
+    scale = (x[:step].double().abs().T @ agg[:step].double().abs()).max().item() * (n / step)  # summand magnitude
+    assert (dW.double() - ref).abs().max().item() < 2e-5 * scale
+
+    # elementwise over > 2^32 elements: relu, then d_relu with the relu output as the mask
+    ctx.relu(x, out)
+    ctx.sync()
+    tail = slice(n - 1000, n)
+    assert torch.equal(out[rows], torch.relu(x[rows])) and torch.equal(out[tail], torch.relu(x[tail]))
+    ctx.d_relu(agg, out, agg)  # in place, like the layer's backward
+    ctx.sync()
+    assert torch.equal(agg[rows], torch.where(x[rows] > 0, want_agg, torch.zeros_like(want_agg)))
+    g.close()
+
+
+def test_edge_count_limit_is_reported(ctx):
+    import ctypes as C
+    h = C.c_void_p()
+    dummy = torch.zeros(8, device="cuda", dtype=torch.int64)
+    rc = ctx.lib.gaib_graph_create(ctx.h, 4, 1 << 32, C.c_void_p(dummy.data_ptr()), 64, C.c_void_p(dummy.data_ptr()), 1,
+                                   C.byref(h))
+    assert rc != 0 and b"2^32" in ctx.lib.gaib_last_error()
+
+
+def test_edge_offsets_up_to_2_32(ctx):
+    _need(80)
+    deg, stride = 1024, 4000
+    n = (1 << 22) - 64
+    ne = n * deg
+    assert (1 << 32) - (1 << 17) < ne < 1 << 32
+    span = n - deg * stride
+    assert span > 0
+    # row i: base_i + k * stride, k = 0..1023 (sorted, distinct, in range); every vertex has degree 1024
+    base = (torch.arange(n, device="cuda", dtype=torch.int64) * 7919) % span
+    ks = torch.arange(deg, device="cuda", dtype=torch.int64) * stride
+    colidx = torch.empty(ne, device="cuda", dtype=torch.int32)
+    chunk = 1 << 17
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        colidx[r0 * deg:r1 * deg] = (base[r0:r1].unsqueeze(1) + ks).reshape(-1).to(torch.int32)
+    rowptr = torch.arange(n + 1, device="cuda", dtype=torch.int64) * deg
+    g = ctx.graph(rowptr, colidx)
+    del colidx
+    assert g.ne == ne
+    d = 8
+    x = _int_rows(n, d, 7)
+    out = torch.empty_like(x)
+    rows = _sample_rows(n, 4096, 2)
+    cols = base[rows].unsqueeze(1) + ks                                   # [rows x 1024]
+    want = x[cols.reshape(-1)].reshape(rows.numel(), deg, d).sum(1) / deg  # integers / 2^10: exact in any order
+    try:
+        for threshold in (1024, 512):  # 1024: one row per wave; 512: every row through the heavy-row kernel
+            ctx.set_option("spmm_heavy_threshold", threshold)
+            g_stats = ctx.graph_stats(g)
+            assert g_stats["n_heavy"] == (0 if threshold == 1024 else n), g_stats
+            for kind in (capi.W_MEAN, capi.W_GCN):  # 1/deg(i) = 2^-10;  deg(i)^-1/2 . deg(j)^-1/2 = 2^-5 . 2^-5
+                out.fill_(-1.0)
+                ctx.spmm(g, kind, x, out)
+                ctx.sync()
+                assert torch.equal(out[rows], want), (threshold, kind)
+    finally:
+        ctx.set_option("spmm_heavy_threshold", 1024)
+    g.close()
