@@ -44,6 +44,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_xcd_swizzle = 1;
   c->spmm_unroll = 0;
   c->spmm_fuse = 1;
+  c->spmm_flat = -1;
   c->spmm_addr_mode = 0;
   c->spmm_gather_mode = 0;
   c->spmm_hot_bytes = 3 << 20;
@@ -222,6 +223,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_xcd_swizzle = (int)value;
   else if (!strcmp(key, "spmm_fuse"))
     ctx->spmm_fuse = (int)value;
+  else if (!strcmp(key, "spmm_flat"))
+    ctx->spmm_flat = (int)value;
   else if (!strcmp(key, "spmm_unroll"))
     ctx->spmm_unroll = (int)value;
   else if (!strcmp(key, "spmm_addr_mode"))

@@ -324,7 +324,12 @@ constexpr int FUSE_WAVES = 16;
 
 // STRIP = rows a wave parks in LDS at a time (8; 2 with two weight matrices);
 // DUAL: y = act(agg . op(W) + rows2 . op(W2)) -- the self term of a SAGE layer (sage_layer.cpp:22,50) in the same pass
-template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL>
+// FLAT: short rows (the halo-column half of a partitioned graph has 3-5 edges per row).  Row by row, a wave then has
+// one column-id load and a handful of gathers in flight and waits two memory latencies per row (measured 2.3 ms for
+// 12 M edges over 2.4 M rows, 1.3 ms of traffic).  Here the edges of a strip's rows are ONE stream: column ids and
+// weights are loaded 64 edges at a time, U gathers are in flight whatever rows they belong to, and the running sum
+// moves to the next row when the edge index passes a row boundary (wave-uniform control).  Same edge order, same sums.
+template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL, bool FLAT = false>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int K = 64 * VEC;  // padded inner dimension; a.ncols (<= K) columns are real
@@ -350,10 +355,27 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   const bool colok = lane * VEC < a.ncols;
   const uint32_t voff[1] = {colok ? (uint32_t)(lane * VEC * 4) : 0u};
   const int ntiles = (a.n_rows + FUSE_ROWS - 1) / FUSE_ROWS;
+  // FLAT: tiles are cheap (a few edges per row), and one atomic per tile on one address becomes the floor (153 k
+  // atomics = 0.4 ms at 2.4 M rows).  Guided chunks instead: a wave takes (tiles left) / (4 x waves) tiles at a time,
+  // at most 8, down to single tiles at the end.
+  int t_next = 0, t_left = 0;
+  const int nwaves4 = (int)gridDim.x * FUSE_WAVES * 4;
   for (;;) {
     int t = 0;
-    if (lane == 0) t = atomicAdd(f.tile_counter, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
+    if constexpr (FLAT) {
+      if (t_left == 0) {
+        int want = (ntiles - t_next) / nwaves4;  // t_next: where the counter stood at this wave's last visit
+        want = want < 1 ? 1 : (want > 8 ? 8 : want);
+        if (lane == 0) t = atomicAdd(f.tile_counter, want);
+        t_next = __builtin_amdgcn_readfirstlane(t);
+        t_left = want;
+      }
+      t = t_next++;
+      --t_left;
+    } else {
+      if (lane == 0) t = atomicAdd(f.tile_counter, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+    }
     if (t >= ntiles) break;
     const int row0 = t * FUSE_ROWS;
     // the 17 row boundaries of this tile, lane r holds rowptr[row0 + r]
@@ -364,8 +386,112 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
     float af[KQ];
 #pragma unroll
     for (int s = 0; s < KQ; ++s) af[s] = 0.f;
+    unsigned long long heavy_mask = 0;  // FLAT: bit r = row r of the tile is a heavy row
+    float rwv = 0.f;                    // FLAT, WMODE 0: lane r holds the row weight of row r
+    if constexpr (FLAT) {
+      const int nb = lane < 63 ? lane + 1 : 63;
+      const int64_t rp_next = ((int64_t)__shfl(rp_hi, nb) << 32) | (uint32_t)__shfl(rp_lo, nb);
+      heavy_mask = __ballot(lane < FUSE_ROWS && rp_next - rp > (int64_t)a.heavy_thr);
+      if constexpr (WMODE == 0) {
+        int rwi = row0 + (lane < FUSE_ROWS ? lane : 0);
+        if (rwi >= a.n_rows) rwi = a.n_rows - 1;
+        rwv = a.rw[rwi];
+      }
+    }
     for (int h = 0; h < NPASS; ++h) {
-      for (int r = 0; r < HALF; ++r) {
+      bool flat_done = false;
+      if constexpr (FLAT) {
+        if (((heavy_mask >> (h * HALF)) & ((1ull << HALF) - 1)) == 0) {
+          flat_done = true;
+          const int rbase = h * HALF;
+          auto rp_at = [&](int rr) -> int64_t {
+            return ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr);
+          };
+          const int64_t e_lo = rp_at(rbase), e_hi = rp_at(rbase + HALF);
+          const RowGather<VEC, GM> gather(a);
+          float* trow_w = tile + lane * VEC;  // this lane's columns of strip row 0
+          if (f.agg_in) {
+            // accumulate mode: the strip starts out as the partial sums of its rows (all requests first)
+            vec_t t[HALF];
+#pragma unroll
+            for (int r2 = 0; r2 < HALF; ++r2) {
+              int row = row0 + rbase + r2;
+              if (row >= a.n_rows) row = a.n_rows - 1;
+              t[r2] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ld + (colok ? lane * VEC : 0));
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < HALF; ++r2)
+              *reinterpret_cast<vec_t*>(trow_w + r2 * LDT) = colok ? t[r2] : vzero<VEC>();
+          }
+          int r = 0;
+          int64_t row_end = rp_at(rbase + 1);
+          vec_t acc = f.agg_in ? *reinterpret_cast<const vec_t*>(trow_w) : vzero<VEC>();
+          float roww = (WMODE == 0) ? readlane_f(rwv, rbase) : 0.f;
+          auto flush = [&]() {  // row r is complete: store it, park it, open row r + 1
+            const int row = row0 + rbase + r;
+            if (row < a.n_rows && a.out && colok)
+              *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc;
+            *reinterpret_cast<vec_t*>(trow_w + r * LDT) = colok ? acc : vzero<VEC>();
+            ++r;
+            if (r < HALF) {
+              row_end = rp_at(rbase + r + 1);
+              acc = f.agg_in ? *reinterpret_cast<const vec_t*>(trow_w + r * LDT) : vzero<VEC>();
+              if constexpr (WMODE == 0) roww = readlane_f(rwv, rbase + r);
+            }
+          };
+          for (int64_t base = e_lo; base < e_hi; base += 64) {
+            const int64_t rem = e_hi - base;
+            const int n = rem < 64 ? (int)rem : 64;
+            uint32_t c = 0;
+            float w = 0.f;
+            if (lane < n) {
+              c = a.col[base + lane];
+              if constexpr (WMODE == 1 || WMODE == 2) w = load_edge_w<WMODE>(a, base + lane);
+            }
+            vec_t x[U];
+            int j = 0;
+            for (; j + U <= n; j += U) {
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+                x[u] = gather.load((uint32_t)__builtin_amdgcn_readlane((int)c, j + u), voff[0]);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                while (base + j + u == row_end) flush();
+                vacc<VEC>(acc, (WMODE == 0) ? roww : readlane_f(w, j + u), x[u]);
+              }
+            }
+            const int rest = n - j;
+            if (rest > 0) {  // power-of-two pieces, all requests first (as in wave_accumulate)
+              int jj = j;
+#pragma unroll
+              for (int p = U / 2; p >= 1; p >>= 1) {
+                if (rest & p) {
+#pragma unroll
+                  for (int u = 0; u < p; ++u)
+                    x[p + u] = gather.load((uint32_t)__builtin_amdgcn_readlane((int)c, jj + u), voff[0]);
+                  jj += p;
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              jj = j;
+#pragma unroll
+              for (int p = U / 2; p >= 1; p >>= 1) {
+                if (rest & p) {
+#pragma unroll
+                  for (int u = 0; u < p; ++u) {
+                    while (base + jj + u == row_end) flush();
+                    vacc<VEC>(acc, (WMODE == 0) ? roww : readlane_f(w, jj + u), x[p + u]);
+                  }
+                  jj += p;
+                }
+              }
+            }
+          }
+          while (r < HALF) flush();  // the row in progress and the empty rows behind the last edge
+        }
+      }
+      for (int r = 0; r < HALF && !flat_done; ++r) {
         const int rr = h * HALF + r;
         const int row = row0 + rr;
         vec_t acc[1];
@@ -540,19 +666,28 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, sizeof(int), ctx->stream));
   ProfScope ps(ctx, "spmm_gemm_fused");
   // more than 64 KB of dynamic LDS has to be asked for
-#define GAIB_FUSED_LAUNCH(GM, STRIP, DUAL)                                                                    \
-  do {                                                                                                        \
-    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, U, GM, STRIP, DUAL>,               \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
-    spmm_gemm_kernel<VEC, WMODE, U, GM, STRIP, DUAL><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f); \
+  // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
+  // spill and are reloaded inside the MFMA loop)
+#define GAIB_FUSED_LAUNCH(GM, STRIP, DUAL, FLAT)                                                                \
+  do {                                                                                                          \
+    constexpr int UU = FLAT ? 8 : U;                                                                            \
+    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT>,          \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>( \
+        a, f);                                                                                                  \
   } while (0)
   (void)strip;
+  // short rows (fewer than 12 edges per row on average: halo-column halves, citation graphs): the edge-stream form
+  // (scripts/ab_flat.py: -34 % at 3 edges per row, -20 % at 5, even at 12, +2 % at 30)
+  const bool flat = !dual && (ctx->spmm_flat == 1 || (ctx->spmm_flat < 0 && g->ne < 12 * (int64_t)a.n_rows));
   if (buf) {
-    if (!dual) GAIB_FUSED_LAUNCH(1, 8, false);
-    else GAIB_FUSED_LAUNCH(1, 2, true);
+    if (dual) GAIB_FUSED_LAUNCH(1, 2, true, false);
+    else if (flat) GAIB_FUSED_LAUNCH(1, 8, false, true);
+    else GAIB_FUSED_LAUNCH(1, 8, false, false);
   } else {
-    if (!dual) GAIB_FUSED_LAUNCH(0, 8, false);
-    else GAIB_FUSED_LAUNCH(0, 2, true);
+    if (dual) GAIB_FUSED_LAUNCH(0, 2, true, false);
+    else if (flat) GAIB_FUSED_LAUNCH(0, 8, false, true);
+    else GAIB_FUSED_LAUNCH(0, 8, false, false);
   }
 #undef GAIB_FUSED_LAUNCH
   GAIB_LAUNCH_CHECK();

@@ -7,11 +7,11 @@ static inline gaib_ctx* C() { return gpu_context::get(); }
 
 // ---- loss_layer -----------------------------------------------------------------------------------
 loss_layer::loss_layer() : num_samples(0), num_cls(1), capacity_(0), phase_(net_phase::TRAIN), feat_in(NULL),
-                           feat_out(NULL), labels(NULL), d_losses(NULL) {}
+                           feat_out(NULL), d_losses(NULL), labels(NULL) {}
 loss_layer::loss_layer(int nv, int ncls) : loss_layer(nv, ncls, NULL) {}
 loss_layer::loss_layer(int nv, int ncls, label_t* ptr)
     : num_samples(nv), num_cls(ncls), capacity_(0), phase_(net_phase::TRAIN), feat_in(NULL), feat_out(NULL),
-      labels(ptr), d_losses(NULL) {
+      d_losses(NULL), labels(ptr) {
   allocate(nv);
 }
 void loss_layer::allocate(int nv) {

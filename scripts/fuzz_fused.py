@@ -29,6 +29,8 @@ def main():
         nv = len(rp) - 1
         thr = int(rng.choice([1024, 1024, 8, 1]))  # tiny thresholds make (almost) every row heavy
         ctx.set_option("spmm_heavy_threshold", thr)
+        flat = int(rng.choice([-1, 0, 1]))  # fused kernel: row by row / one edge stream per strip / by average degree
+        ctx.set_option("spmm_flat", flat)
         len_in = int(rng.choice([1, 7, 16, 33, 47, 64, 66, 100, 128]))
         len_out = int(rng.choice([1, 7, 16, 47, 64, 100, 128, 130, 200]))
         kind = int(rng.choice([capi.W_MEAN, capi.W_MEAN_T, capi.W_EDGE, capi.W_GCN]))
@@ -61,12 +63,40 @@ def main():
         err = (y.double() - want).abs().max().item() / scale
         worst = max(worst, err)
         ok = err < 2e-5 and (scratch or torch.equal(agg, agg_ref) or ne == 0)
+        if ok and kind != capi.W_GCN and not dual and ne > 0:
+            # accumulate mode: the edges split by column (a partition's own / halo halves), second half fused
+            rows_of = np.repeat(np.arange(nv), np.diff(rp))
+            cut = int(rng.integers(0, nv + 1))
+            halves = []
+            for mask in (ci < cut, ci >= cut):
+                cnt = np.bincount(rows_of[mask], minlength=nv)
+                gh = ctx.graph(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ci[mask].view(np.int32))
+                deg_all = np.diff(rp)
+                inv = torch.from_numpy(np.where(deg_all > 0, 1.0 / np.maximum(deg_all, 1), 0.0).astype(np.float32)).cuda()
+                gh.set_vertex_norm(row_vdata=inv, col_vdata=inv, col_inv_deg=inv, row_inv_deg=inv)
+                ewh = ew[torch.from_numpy(np.nonzero(mask)[0]).cuda()] if ew is not None and mask.any() else ew
+                halves.append((gh, ewh))
+            agg2 = torch.full((nv, len_in), 5.0, device="cuda")
+            y2 = torch.full((nv, len_out), -3.0, device="cuda")
+            ctx.spmm(halves[0][0], kind, x, agg2, edge_w=halves[0][1])
+            ctx.spmm_gemm(halves[1][0], kind, x, agg2, W, y2, transW=transW, relu=relu, edge_w=halves[1][1], accumulate=True)
+            ctx.sync()
+            err2 = (y2.double() - want).abs().max().item() / scale
+            erra = (agg2.double() - agg_ref.double()).abs().max().item() / max(agg_ref.abs().max().item(), 1e-6)
+            worst = max(worst, err2)
+            if not (err2 < 2e-5 and erra < 1e-5):
+                print(f"FAIL (accumulate) case {case}: nv={nv} ne={ne} thr={thr} flat={flat} len_in={len_in} len_out={len_out} "
+                      f"kind={kind} cut={cut} err={err2:.2e} agg_err={erra:.2e}")
+                sys.exit(1)
+            for gh, _ in halves:
+                gh.close()
         if not ok:
-            print(f"FAIL case {case}: nv={nv} ne={ne} thr={thr} len_in={len_in} len_out={len_out} kind={kind} transW={transW} "
+            print(f"FAIL case {case}: flat={flat} nv={nv} ne={ne} thr={thr} len_in={len_in} len_out={len_out} kind={kind} transW={transW} "
                   f"relu={relu} dual={dual} scratch={scratch} err={err:.2e} agg_equal={torch.equal(agg, agg_ref)}")
             sys.exit(1)
         g.close()
     ctx.set_option("spmm_heavy_threshold", 1024)
+    ctx.set_option("spmm_flat", -1)
     print(f"{n_cases} cases ok, worst relative error {worst:.2e}")
 
 

@@ -523,12 +523,20 @@ def test_adam_steps(ctx):
     assert rel_err(Wd.cpu().numpy(), W) < 1e-5
 
 
-def test_gather_rows(ctx):
-    x = feat(1000, 100, 1)
-    idx = np.random.default_rng(1).integers(0, 1000, 333)
-    out = torch.empty(333, 100, device="cuda")
-    ctx.gather_rows(dev(idx.astype(np.int64)), dev(x), out)
-    assert np.array_equal(out.cpu().numpy(), x[idx])
+@pytest.mark.parametrize("n,d,k", [(1000, 100, 333), (1000, 128, 1), (1000, 128, 15), (1000, 128, 16), (5000, 128, 4099),
+                                   (300, 12, 77), (300, 260, 131), (1000, 99, 333), (50, 4, 1000), (64, 128, 0)])
+def test_gather_rows(ctx, n, d, k):
+    """rows of every width class: 16-B path with power-of-two / other row lengths, row counts around the 16-row
+    pieces a wave copies, the 4-B path (d % 4 != 0), repeated and out-of-order ids, nothing to do"""
+    x = feat(n, d, 1)
+    idx = np.random.default_rng(k).integers(0, n, k)
+    if k > 2:
+        idx[0], idx[-1] = n - 1, 0
+    out = torch.full((max(k, 1) + 1, d), -7.0, device="cuda")
+    ctx.gather_rows(dev(idx.astype(np.int64)), dev(x), out[:k])
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:k], x[idx])
+    assert np.all(got[k:] == -7.0)  # nothing written past the last row
 
 
 # ---- fused activation ---------------------------------------------------------------------------------
@@ -636,6 +644,15 @@ def test_side_section_overlaps_and_orders(ctx):
     ctx.side_wait()
 
 
+@pytest.fixture
+def flat_option(ctx):
+    """forces the fused kernel's row-by-row (0) / edge-stream (1) form for one test, then back to automatic"""
+    def set_flat(v):
+        ctx.set_option("spmm_flat", v)
+    yield set_flat
+    ctx.set_option("spmm_flat", -1)
+
+
 @pytest.mark.parametrize("len_in,len_out,kind,transW,relu", [
     (128, 128, "gcn", False, True),    # the headline layer's forward
     (128, 128, "gcn", True, False),    # its input-gradient product
@@ -650,8 +667,11 @@ def test_side_section_overlaps_and_orders(ctx):
     (16, 7, "gcn", False, False),      # cora-sized widths
     (256, 64, "mean", False, True),    # K > 128: two-kernel path
 ])
-def test_spmm_gemm_fused(ctx, len_in, len_out, kind, transW, relu):
-    """gaib_spmm_gemm == aggregate then matmul (+relu) of the oracle; heavy rows, ragged row count"""
+@pytest.mark.parametrize("flat", [0, 1])
+def test_spmm_gemm_fused(ctx, flat_option, len_in, len_out, kind, transW, relu, flat):
+    """gaib_spmm_gemm == aggregate then matmul (+relu) of the oracle; heavy rows, ragged row count; row by row
+    (flat 0) and as one edge stream per strip of rows (flat 1, what short-row graphs get by default)"""
+    flat_option(flat)
     rp, ci = random_graph(3001, 12, seed=len_in + len_out, power_law=True, hub_deg=1500)  # vertex 0 is heavy
     g_o, g_d = make(ctx, rp, ci, selfloop=(kind == "gcn"))
     n = g_o.nv
@@ -688,10 +708,12 @@ def test_spmm_gemm_fused(ctx, len_in, len_out, kind, transW, relu):
     assert rel_err(y2.cpu().numpy(), y.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("flat", [0, 1])
 @pytest.mark.parametrize("d,d_out", [(128, 128), (64, 48), (96, 32)])
-def test_spmm_gemm_accumulate_split_by_column(ctx, d, d_out):
+def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     """the multi-GPU own/halo split through the fused kernel: gaib_spmm on the low-column edges, then
     gaib_spmm_gemm(GAIB_ACCUMULATE) on the high-column edges continues the sums and carries the product"""
+    flat_option(flat)
     rp, ci = random_graph(3000, 14, seed=3, power_law=True, hub_deg=2500)
     g_o = orc.Graph(rp, ci)
     n = g_o.nv
