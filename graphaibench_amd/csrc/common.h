@@ -45,6 +45,9 @@ struct gaib_ctx {
   // growable scratch (split-K partials, per-vertex scores, ...); never shrinks
   void* ws;
   size_t ws_bytes;
+  // padded copy of an aggregation's input table (spmm.hip: rows re-strided to whole 64-B pieces); never shrinks
+  void* pad;
+  size_t pad_bytes;
   // side stream (gaib_stream_fork/join) with its own scratch
   hipStream_t main_stream, side_stream;
   hipEvent_t ev_fork, ev_join;
@@ -55,6 +58,7 @@ struct gaib_ctx {
   int spmm_heavy_threshold;  // rows with more edges go to the workgroup-per-row kernel
   int spmm_variant;          // 0 = auto, see spmm.hip
   int spmm_xcd_swizzle;      // 1 = consecutive row blocks share an XCD
+  int spmm_pad;              // 1 = re-stride odd-width input tables where that saves >10 % of the gathered lines, 0 = never
   int spmm_fuse;             // 1 = gaib_spmm_gemm may fuse the dense product into the aggregation
   int spmm_flat;             // fused kernel, edge-stream form for short rows: -1 = by average degree, 0 = never, 1 = always
   int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8
@@ -88,6 +92,7 @@ struct ProfScope {
 };
 
 int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes);
+int gaib_pad_reserve(gaib_ctx* ctx, size_t bytes);
 
 struct gaib_graph {
   int device;

@@ -33,6 +33,8 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->num_cus = prop.multiProcessorCount;
   c->ws = nullptr;
   c->ws_bytes = 0;
+  c->pad = nullptr;
+  c->pad_bytes = 0;
   c->main_stream = c->stream;
   c->side_stream = nullptr;
   c->ev_fork = c->ev_join = nullptr;
@@ -44,6 +46,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_xcd_swizzle = 1;
   c->spmm_unroll = 0;
   c->spmm_fuse = 1;
+  c->spmm_pad = 1;
   c->spmm_flat = -1;
   c->spmm_addr_mode = 0;
   c->spmm_gather_mode = 0;
@@ -59,6 +62,7 @@ extern "C" int gaib_ctx_destroy(gaib_ctx* ctx) {
   if (!ctx) return GAIB_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->pad) (void)hipFree(ctx->pad);
   if (ctx->ws_side) (void)hipFree(ctx->ws_side);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -132,6 +136,21 @@ int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes) {
     return GAIB_ERR_NOMEM;
   }
   ctx->ws_bytes = want;
+  return GAIB_OK;
+}
+
+int gaib_pad_reserve(gaib_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pad_bytes) return GAIB_OK;
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));  // the old buffer may still be read by enqueued kernels
+  if (ctx->pad) GAIB_HIP(hipFree(ctx->pad));
+  ctx->pad = nullptr;
+  ctx->pad_bytes = 0;
+  hipError_t e = hipMalloc(&ctx->pad, bytes);
+  if (e != hipSuccess) {
+    gaib_set_error("padded-table hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return GAIB_ERR_NOMEM;
+  }
+  ctx->pad_bytes = bytes;
   return GAIB_OK;
 }
 
@@ -223,6 +242,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_xcd_swizzle = (int)value;
   else if (!strcmp(key, "spmm_fuse"))
     ctx->spmm_fuse = (int)value;
+  else if (!strcmp(key, "spmm_pad"))
+    ctx->spmm_pad = (int)value;
   else if (!strcmp(key, "spmm_flat"))
     ctx->spmm_flat = (int)value;
   else if (!strcmp(key, "spmm_unroll"))

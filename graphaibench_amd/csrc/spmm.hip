@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void spmm_w64_kernel(SpmmArgs a) {
     acc[ct] = vzero<VEC>();
   }
   const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
-  float* o = a.out + (int64_t)row * a.ld + lane * VEC;
+  float* o = a.out + (int64_t)row * a.ldo + lane * VEC;
   if (a.accumulate) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void spmm_heavy_kernel(SpmmArgs a
   for (int ct = 0; ct < CT; ++ct)
     *reinterpret_cast<vec_t*>(&red[wave * W + (ct * 64 + lane) * VEC]) = acc[ct];
   __syncthreads();
-  float* orow = a.out + (a.compact ? (int64_t)slot : (int64_t)row) * a.ld;
+  float* orow = a.out + (a.compact ? (int64_t)slot : (int64_t)row) * a.ldo;
   for (int c = threadIdx.x; c < a.ncols; c += HEAVY_WAVES * 64) {
     float s = a.accumulate ? orow[c] + red[c] : red[c];
 #pragma unroll
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
   }
   const bool colok = sl * VEC < a.ncols;
   vec_t acc = vzero<VEC>();
-  if (a.accumulate && active && colok) acc = *reinterpret_cast<const vec_t*>(a.out + row * a.ld + sl * VEC);
+  if (a.accumulate && active && colok) acc = *reinterpret_cast<const vec_t*>(a.out + row * a.ldo + sl * VEC);
   const float roww = (WMODE == 0 && active) ? a.rw[row] : 0.f;
   const int head = (WMODE >= 3 && colok) ? (sl * VEC) / a.dh : 0;
   const float* inl = a.in + sl * VEC;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void spmm_sub_kernel(SpmmArgs a) {
     for (int u = 0; u < U; ++u)
       if (e + u < e1) vacc<VEC>(acc, wj[u], x[u]);
   }
-  if (active && colok) *reinterpret_cast<vec_t*>(a.out + row * a.ld + sl * VEC) = a.relu ? vrelu<VEC>(acc) : acc;
+  if (active && colok) *reinterpret_cast<vec_t*>(a.out + row * a.ldo + sl * VEC) = a.relu ? vrelu<VEC>(acc) : acc;
 }
 
 // ---- dispatch --------------------------------------------------------------------------
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
             for (int r2 = 0; r2 < HALF; ++r2) {
               int row = row0 + rbase + r2;
               if (row >= a.n_rows) row = a.n_rows - 1;
-              t[r2] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ld + (colok ? lane * VEC : 0));
+              t[r2] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ldo + (colok ? lane * VEC : 0));
             }
 #pragma unroll
             for (int r2 = 0; r2 < HALF; ++r2)
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
           auto flush = [&]() {  // row r is complete: store it, park it, open row r + 1
             const int row = row0 + rbase + r;
             if (row < a.n_rows && a.out && colok)
-              *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc;
+              *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ldo + lane * VEC) = acc;
             *reinterpret_cast<vec_t*>(trow_w + r * LDT) = colok ? acc : vzero<VEC>();
             ++r;
             if (r < HALF) {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         acc[0] = vzero<VEC>();
         if (row < a.n_rows) {
           if (f.agg_in && colok)
-            acc[0] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ld + lane * VEC);
+            acc[0] = *reinterpret_cast<const vec_t*>(f.agg_in + (int64_t)row * a.ldo + lane * VEC);
           const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr) << 32) |
                              (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr);
           const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr + 1) << 32) |
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
               else hi = mid;
             }
             if (colok) {
-              const vec_t hv = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * a.ld + lane * VEC);
+              const vec_t hv = *reinterpret_cast<const vec_t*>(f.heavy_agg + (int64_t)lo * a.ldo + lane * VEC);
               if constexpr (VEC == 1) acc[0] = f.agg_in ? acc[0] + hv : hv;
               else {
 #pragma unroll
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
             const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
             wave_accumulate<VEC, 1, WMODE, U, GM>(a, lane, e0, e1, 64, roww, voff, acc);
           }
-          if (a.out && colok) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ld + lane * VEC) = acc[0];
+          if (a.out && colok) *reinterpret_cast<vec_t*>(a.out + (int64_t)row * a.ldo + lane * VEC) = acc[0];
         }
         // lanes beyond the real columns gathered column 0 (see wave_accumulate): they must enter the product as 0
         if (!colok) acc[0] = vzero<VEC>();
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
       for (int r = 0; r < FUSE_ROWS; ++r) {
         const int row = row0 + r;
         const int64_t rs = row < a.n_rows ? row : 0;
-        xs[r] = *reinterpret_cast<const vec_t*>(f.rows2 + rs * a.ld + (colok ? lane * VEC : 0));
+        xs[r] = *reinterpret_cast<const vec_t*>(f.rows2 + rs * a.ldo + (colok ? lane * VEC : 0));
       }
       f32x4_t c[NT];
 #pragma unroll
@@ -649,7 +649,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     h.row_list = g->heavy_rows;
     h.row_order = g->heavy_rows + g->n_heavy;
     h.out = heavy_scratch;
-    h.compact = 1;  // (h.ld stays len == K: it is the gather stride too)
+    h.compact = 1;  // (row k of the scratch has the stride of the output rows, h.ldo)
     h.relu = 0;
     h.accumulate = 0;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
@@ -694,6 +694,27 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   return GAIB_OK;
 }
 
+// out[r][0..lp) = in[r][0..len) followed by zeros; lp % 4 == 0, out 16-B aligned.  One float4 of `out` per thread.
+__global__ __launch_bounds__(256) void pad_rows_kernel(int64_t n4, int len, int lp4, const float* in, f32x4_t* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / lp4;
+    const int c = (int)(i - r * lp4) * 4;
+    const float* src = in + r * len + c;
+    f32x4_t v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = c + k < len ? src[k] : 0.f;
+    out[i] = v;
+  }
+}
+
+// 128-B lines a gathered row of `bytes` bytes touches on average when rows are `bytes` apart (any 4-B alignment) ...
+inline double lines_packed(int bytes) { return 1.0 + (bytes - 4) / 128.0; }
+// ... and when rows start on 64-B boundaries `stride` bytes apart (stride % 64 == 0)
+inline double lines_strided(int bytes, int stride) {
+  const int at0 = (bytes + 127) / 128, at64 = (bytes + 64 + 127) / 128;
+  return stride % 128 == 0 ? at0 : 0.5 * (at0 + at64);
+}
+
 }  // namespace
 
 // fills the launch arguments shared by every aggregation path; *wmode = kernel weight mode
@@ -727,8 +748,28 @@ static int spmm_setup(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float
     GAIB_TRY(gaib_graph_ensure_hot_flags(ctx, g, len));
     a.col_flagged = g->colidx_flagged;
   }
-  // feature table = nc rows of len floats; the 32-bit buffer path needs it below 4 GB
-  const int64_t table_bytes = g->nc * (int64_t)len * 4;
+  a.ldo = len;
+  // Rows whose byte length is not a multiple of 64 straddle more 128-B lines than they fill (a 188-B row of the
+  // 47-class output layer touches 2.44 lines on average, 2 when rows start on 64-B boundaries), and the gather time
+  // follows the lines touched: products, D = 47: 5.28 ms, D = 48: 4.04 ms.  Where re-striding saves more than 10 %
+  // of the lines, the input table is copied once into rows of whole 64-B pieces (0.9 GB of streaming traffic against
+  // 40 GB of gathers at products / 47) and gathered from there; output rows keep the caller's stride.
+  {
+    const int bytes = len * 4, stride = (bytes + 63) & ~63;
+    if (ctx->spmm_pad && len > 16 && stride != bytes && g->ne > 4 * g->nc &&
+        lines_strided(bytes, stride) < 0.9 * lines_packed(bytes)) {
+      const int lp = stride / 4;
+      GAIB_TRY(gaib_pad_reserve(ctx, (size_t)g->nc * (size_t)stride));
+      const int64_t n4 = g->nc * (int64_t)(lp / 4);
+      const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n4, 256), (int64_t)ctx->num_cus * 16);
+      pad_rows_kernel<<<grid, 256, 0, ctx->stream>>>(n4, len, lp / 4, d_in, reinterpret_cast<f32x4_t*>(ctx->pad));
+      GAIB_LAUNCH_CHECK();
+      a.in = reinterpret_cast<const float*>(ctx->pad);
+      a.ld = lp;
+    }
+  }
+  // feature table = nc rows of a.ld floats; the 32-bit buffer path needs it below 4 GB
+  const int64_t table_bytes = g->nc * a.ld * 4;
   a.in_bytes = table_bytes < ((int64_t)1 << 32) ? (uint32_t)table_bytes : 0u;
   switch (weight_kind) {
     case GAIB_W_GCN:

@@ -13,7 +13,8 @@ struct SpmmArgs {
   const uint32_t* rev;  // reverse edge ids  (WMODE 2: w = ew[rev[e]])
   const float* in;
   float* out;
-  int64_t ld;  // row stride of in/out (floats)
+  int64_t ld;   // row stride of the gathered table `in` (floats)
+  int64_t ldo;  // row stride of out, of the partial sums continued in accumulate mode and of the fused path's row operands
   int ncols;   // columns handled by this launch (<= 64*VEC*CT), starting at in/out
   int n_rows;
   int heavy_thr;

@@ -121,6 +121,48 @@ def test_spmm_kinds(ctx, kind, d):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("d", [17, 20, 41, 44, 47, 60, 61])
+def test_spmm_restrided_input_table(ctx, d):
+    """input tables whose rows straddle 128-B lines (row bytes not a multiple of 64) are gathered from a copy with
+    the rows on 64-B boundaries (spmm_pad, on by default where it saves lines): the same bits as the direct gather --
+    light and hub rows, per-head weights, accumulate mode, and the fused aggregation + product"""
+    rp, ci = random_graph(3001, 12, seed=d, power_law=True, hub_deg=1500)
+    g_o, g_d = make(ctx, rp, ci)
+    n, ne = g_o.nv, g_o.ne
+    x = dev(feat(n, d, 2))
+    ew = torch.rand(ne, device="cuda")
+    heads = 4 if d % 4 == 0 else 1
+    ewh = torch.rand(ne, heads, device="cuda")
+    W = torch.randn(d, 24, device="cuda") * 0.2
+
+    def run():
+        res = []
+        for kind, w in ((capi.W_MEAN, None), (capi.W_GCN, None), (capi.W_EDGE, ew), (capi.W_EDGE_T, ew)):
+            out = torch.full((n, d), 9.0, device="cuda")
+            ctx.spmm(g_d, kind, x, out, edge_w=w)
+            res.append(out)
+            ctx.spmm(g_d, kind, x, out2 := out.clone(), edge_w=w, accumulate=True, relu=True)
+            res.append(out2)
+        out = torch.empty(n, d, device="cuda")
+        ctx.spmm(g_d, capi.W_EDGE, x, out, edge_w=ewh, heads=heads)
+        res.append(out)
+        agg, y = torch.empty(n, d, device="cuda"), torch.empty(n, 24, device="cuda")
+        ctx.spmm_gemm(g_d, capi.W_MEAN, x, agg, W, y, relu=True)
+        res += [agg, y]
+        ctx.sync()
+        return res
+
+    ctx.set_option("spmm_pad", 0)
+    try:
+        direct = run()
+    finally:
+        ctx.set_option("spmm_pad", 1)
+    padded = run()
+    for a, b in zip(direct, padded):
+        assert torch.equal(a, b)
+    assert rel_err(padded[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy())) < TOL
+
+
 @pytest.mark.parametrize("d", [16, 100, 128, 512])
 def test_spmm_heavy_rows(ctx, d):
     """hub rows above the heavy threshold take the workgroup-per-row kernel (fixed-order LDS reduce)"""
