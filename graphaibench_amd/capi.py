@@ -60,6 +60,7 @@ SIGNATURES = {
     "gaib_sddmm_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_ex": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gaib_gat_softmax_bwd_alpha_re": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gaib_edge_transpose_mh": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -228,8 +229,15 @@ class Context:
                "gaib_sddmm")
 
     def gat_softmax_bwd_alpha(self, g, feat, norm, norm_grad, temp, scores, lgrad, rgrad, eps: float = 0.2,
-                              heads: int = 1, grad_rows=None, fwd_out_rows=None, norm_t=None):
-        """scores may be None; grad_rows + fwd_out_rows select the one-pass form (gaib_gat_softmax_bwd_alpha_ex)"""
+                              heads: int = 1, grad_rows=None, fwd_out_rows=None, norm_t=None, alpha=None):
+        """scores may be None; grad_rows + fwd_out_rows select the one-pass form (gaib_gat_softmax_bwd_alpha_ex);
+        temp=None with alpha=(alpha_l, alpha_r): the form without the temp array (gaib_gat_softmax_bwd_alpha_re)"""
+        if temp is None:
+            _check(self.lib.gaib_gat_softmax_bwd_alpha_re(self.h, g.h, feat.shape[1], heads, _ptr(feat), _ptr(alpha[0]),
+                                                          _ptr(alpha[1]), _ptr(norm), _ptr(norm_grad), eps, _ptr(scores),
+                                                          _ptr(lgrad), _ptr(rgrad), _ptr(grad_rows),
+                                                          _ptr(fwd_out_rows), _ptr(norm_t)), "gaib_gat_softmax_bwd_alpha_re")
+            return
         _check(self.lib.gaib_gat_softmax_bwd_alpha_ex(self.h, g.h, feat.shape[1], heads, _ptr(feat), _ptr(norm),
                                                       _ptr(norm_grad), _ptr(temp), eps, _ptr(scores),
                                                       _ptr(lgrad), _ptr(rgrad), _ptr(grad_rows),

@@ -353,7 +353,7 @@ struct RowOwner {
       nthreads = ROW_BLK_WAVES * 64;
       valid = true;
     } else {
-      row = (int64_t)blockIdx.x * 4 + wave;
+      row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
       tid = lane;
       nthreads = 64;
       valid = row < nv;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
       m.v[h] = ex / den;
     }
     if (ok) {
-      t.store(temp + e * H + hb);
+      if (temp) t.store(temp + e * H + hb);
       if (scores) s.store(scores + e * H + hb);
       m.store(norm + e * H + hb);
     }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
           d.v[h] = up ? d.v[h] * ex + 1.0f : d.v[h] + ex;
           m.v[h] = up ? s.v[h] : m.v[h];
         }
-        t[u].store(temp + eu * H + hb);
+        if (temp) t[u].store(temp + eu * H + hb);
         if (scores) s.store(scores + eu * H + hb);
       }
     }
@@ -514,12 +514,30 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
   owner_softmax_stats<HV, LPE, BLK>(m, d, o.wave, o.lane, o.sub, lds);
 #pragma unroll
   for (int h = 0; h < HV; ++h) d.v[h] = 1.0f / d.v[h];
-  for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {  // each thread re-reads only its own writes
+  for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {
     HeadVec<HV> t[EU];
+    if (temp) {  // each thread re-reads only its own writes
 #pragma unroll
-    for (int u = 0; u < EU; ++u) {
-      const int64_t eu = e + (int64_t)u * o.ethreads;
-      t[u].load(temp + (eu < o.e1 ? eu : o.e0) * H + hb);
+      for (int u = 0; u < EU; ++u) {
+        const int64_t eu = e + (int64_t)u * o.ethreads;
+        t[u].load(temp + (eu < o.e1 ? eu : o.e0) * H + hb);
+      }
+    } else {
+      // no temp array asked for: the pre-activation score is formed again from the per-vertex dots (4 + 4H bytes
+      // per edge out of the caches instead of 4H written and 4H read back through HBM); same sum, same bits
+      uint32_t c[EU];
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int64_t eu = e + (int64_t)u * o.ethreads;
+        c[u] = col[eu < o.e1 ? eu : o.e0];
+      }
+#pragma unroll
+      for (int u = 0; u < EU; ++u) t[u].load(sr + (int64_t)c[u] * H + hb);
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+#pragma unroll
+        for (int h = 0; h < HV; ++h) t[u].v[h] = ssrc.v[h] + t[u].v[h];
+      }
     }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
@@ -541,11 +559,12 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void edge_softmax_v
 // Writes g into gbuf, the row sum of g into rs, ds into scores when asked.  DOT = true: the row's dot comes
 // from the caller (rowdot[i,h] = <grad_i, forward output_i> on slice h -- the same sum regrouped by vertex),
 // which makes this ONE pass over the edge arrays.
-template <int H, bool BLK, bool DOT>
+// RE = true: no temp array; the sign of the pre-activation score comes from sl[i] + sr[col] formed again.
+template <int H, bool BLK, bool DOT, bool RE>
 __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2_kernel(
     int64_t nv, const int64_t* rowptr, const float* p, const float* dp, const float* temp, float eps,
     const float* rowdot, float* scores, float* gbuf, int pack, float* rs, int heavy_thr,
-    const uint32_t* row_list, const uint32_t* row_order) {
+    const uint32_t* row_list, const uint32_t* row_order, const uint32_t* col, const float* sl, const float* sr) {
   constexpr int HV = HeadSplit<H>::HV, LPE = HeadSplit<H>::LPE;
   __shared__ float lds[BLK ? ROW_BLK_WAVES * H : 1];
   const RowOwner<BLK, LPE> o(nv, rowptr, heavy_thr, row_list, row_order);
@@ -567,15 +586,34 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void softmax_bwd_v2
     owner_sum<HV, LPE, BLK>(dot, o.wave, o.lane, o.sub, lds);
   }
   constexpr int EU = 4;
+  HeadVec<HV> ssrc;
+  if constexpr (RE) ssrc.load(sl + o.row * H + hb);
   for (int64_t e = o.e0 + o.etid; e < o.e1; e += (int64_t)EU * o.ethreads) {
     HeadVec<HV> a[EU], b[EU], t[EU];
+    if constexpr (RE) {
+      uint32_t c[EU];
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int64_t eu = e + (int64_t)u * o.ethreads;
+        c[u] = col[eu < o.e1 ? eu : o.e0];
+      }
+#pragma unroll
+      for (int u = 0; u < EU; ++u) t[u].load(sr + (int64_t)c[u] * H + hb);
+    }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int64_t eu = e + (int64_t)u * o.ethreads;
       const int64_t es = eu < o.e1 ? eu : o.e0;
       a[u].load(p + es * H + hb);
       b[u].load(dp + es * H + hb);
-      t[u].load(temp + es * H + hb);
+      if constexpr (!RE) t[u].load(temp + es * H + hb);
+    }
+    if constexpr (RE) {
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+#pragma unroll
+        for (int h = 0; h < HV; ++h) t[u].v[h] = ssrc.v[h] + t[u].v[h];
+      }
     }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
@@ -667,6 +705,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H,
 }
 
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
+// the row-owner kernels: gat_row_waves (1, 2 or 4) one-wave rows per workgroup
+inline unsigned rowgrid_w(const gaib_ctx* ctx, int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, ctx->gat_row_waves); }
 
 int check_heads(const char* who, int len, int heads) {
   GAIB_CHECK(len > 0, "%s: len must be > 0", who);
@@ -686,7 +726,7 @@ int launch_edge_softmax(gaib_ctx* ctx, gaib_graph* g, const float* sl, const flo
         g->nv, g->rowptr, g->colidx, sl, sr, eps, temp, scores, norm, thr, rl, ro);
     GAIB_LAUNCH_CHECK();
   }
-  edge_softmax_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
+  edge_softmax_v2_kernel<H, false><<<rowgrid_w(ctx, g->nv), ctx->gat_row_waves * 64, 0, ctx->stream>>>(
       g->nv, g->rowptr, g->colidx, sl, sr, eps, temp, scores, norm, thr, rl, ro);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
@@ -694,22 +734,33 @@ int launch_edge_softmax(gaib_ctx* ctx, gaib_graph* g, const float* sl, const flo
 
 template <int H>
 int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float* dp, const float* temp, float eps,
-                       const float* rowdot, float* scores, float* gbuf, float* rs, float* cs, float* pT) {
+                       const float* rowdot, float* scores, float* gbuf, float* rs, float* cs, float* pT,
+                       const float* sl, const float* sr) {
   GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
   const uint32_t* rl = g->heavy_rows;
   const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;
   const int thr = g->n_heavy > 0 ? g->heavy_thr : 0;
   const unsigned nh = (unsigned)g->n_heavy, blk = ROW_BLK_WAVES * 64;
+  const unsigned lg = rowgrid_w(ctx, g->nv), lb = (unsigned)ctx->gat_row_waves * 64;
+#define GAIB_SBW_LAUNCH(DOT, RE)                                                                                   \
+  do {                                                                                                             \
+    if (nh)                                                                                                        \
+      softmax_bwd_v2_kernel<H, true, DOT, RE><<<nh, blk, 0, ctx->stream>>>(                                        \
+          g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro, g->colidx, sl, sr); \
+    softmax_bwd_v2_kernel<H, false, DOT, RE><<<lg, lb, 0, ctx->stream>>>(                                          \
+        g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro, g->colidx, sl, sr);   \
+  } while (0)
   if (rowdot) {
-    if (nh) softmax_bwd_v2_kernel<H, true, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
-    softmax_bwd_v2_kernel<H, false, true><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
+    if (temp) GAIB_SBW_LAUNCH(true, false);
+    else GAIB_SBW_LAUNCH(true, true);
   } else {
-    if (nh) softmax_bwd_v2_kernel<H, true, false><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
-    softmax_bwd_v2_kernel<H, false, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, p, dp, temp, eps, rowdot, scores, gbuf, pT ? 1 : 0, rs, thr, rl, ro);
+    if (temp) GAIB_SBW_LAUNCH(false, false);
+    else GAIB_SBW_LAUNCH(false, true);
   }
+#undef GAIB_SBW_LAUNCH
   GAIB_LAUNCH_CHECK();
   if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
-  colsum_v2_kernel<H, false><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
+  colsum_v2_kernel<H, false><<<lg, lb, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -722,7 +773,7 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   GAIB_CHECK(ctx && g, "gaib_gat_scores: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_scores", len, heads));
   if (g->nv == 0) return GAIB_OK;
-  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_temp_scores && d_norm_scores, "gaib_gat_scores: NULL pointer");
+  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_norm_scores, "gaib_gat_scores: NULL pointer");
   GAIB_CHECK(g->nc == g->nv, "gaib_gat_scores: square graphs only");
   GAIB_HIP(hipSetDevice(ctx->device));
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)g->nv * heads));
@@ -744,7 +795,7 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
     else if (heads == 8 && al16) rc = launch_edge_softmax<8>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
     else if (heads == 16 && al16) rc = launch_edge_softmax<16>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
     else {
-      GAIB_CHECK(d_scores, "gaib_gat_scores: this head count needs d_scores");
+      GAIB_CHECK(d_scores && d_temp_scores, "gaib_gat_scores: this head count needs d_temp_scores and d_scores");
       edge_softmax_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(
           g->nv, heads, g->rowptr, g->colidx, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
     }
@@ -820,19 +871,18 @@ extern "C" int gaib_sddmm(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_
   return gaib_sddmm_mh(ctx, g, len, 1, d_grad, d_feat, d_out_e);
 }
 
-extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
-                                             const float* d_feat, const float* d_norm_scores,
-                                             const float* d_norm_scores_grad,
-                                             const float* d_temp_scores, float epsilon,
-                                             float* d_scores, float* d_alpha_lgrad,
-                                             float* d_alpha_rgrad, const float* d_grad_rows,
-                                             const float* d_fwd_out_rows, float* d_norm_scores_t) {
+// d_temp_scores == NULL: the sign of the pre-activation score is formed again from d_feat and (d_alpha_l, d_alpha_r)
+static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
+                                  const float* d_norm_scores, const float* d_norm_scores_grad,
+                                  const float* d_temp_scores, const float* d_alpha_l, const float* d_alpha_r,
+                                  float epsilon, float* d_scores, float* d_alpha_lgrad, float* d_alpha_rgrad,
+                                  const float* d_grad_rows, const float* d_fwd_out_rows, float* d_norm_scores_t) {
   GAIB_CHECK(ctx && g, "gaib_gat_softmax_bwd_alpha: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_softmax_bwd_alpha", len, heads));
   GAIB_CHECK(d_alpha_lgrad && d_alpha_rgrad, "gaib_gat_softmax_bwd_alpha: NULL alpha grad");
   GAIB_HIP(hipSetDevice(ctx->device));
   if (g->nv == 0) return GAIB_OK;
-  GAIB_CHECK(d_feat && d_norm_scores && d_norm_scores_grad && d_temp_scores,
+  GAIB_CHECK(d_feat && d_norm_scores && d_norm_scores_grad && (d_temp_scores || (d_alpha_l && d_alpha_r)),
              "gaib_gat_softmax_bwd_alpha: NULL pointer");
   GAIB_CHECK((d_grad_rows == nullptr) == (d_fwd_out_rows == nullptr),
              "gaib_gat_softmax_bwd_alpha: d_grad_rows and d_fwd_out_rows go together");
@@ -841,14 +891,20 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };  // keep every slab 16-byte aligned
   const size_t n_g = up4((size_t)g->ne * heads * (d_norm_scores_t ? 2 : 1)), n_v = up4((size_t)g->nv * heads);
-  const size_t ws_floats = n_g + 3 * n_v + (size_t)nblocks * 2 * len;
+  const size_t ws_floats = n_g + 5 * n_v + (size_t)nblocks * 2 * len;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * ws_floats));
   float* gbuf = (float*)ctx->ws;
   float* rs = gbuf + n_g;
   float* cs = rs + n_v;
   float* rowdot = cs + n_v;
-  float* partial = rowdot + n_v;
+  float* sl = rowdot + n_v;
+  float* sr = sl + n_v;
+  float* partial = sr + n_v;
   ProfScope ps(ctx, "gat_softmax_bwd_alpha");
+  if (!d_temp_scores) {
+    vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_feat, d_alpha_l, d_alpha_r, sl, sr);
+    GAIB_LAUNCH_CHECK();
+  }
   if (d_grad_rows) {
     rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad_rows, d_fwd_out_rows, rowdot);
     GAIB_LAUNCH_CHECK();
@@ -860,14 +916,14 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
                       (uintptr_t)d_norm_scores_t) & 15) == 0;
   int rc = GAIB_OK;
 #define GAIB_SBW(HH) rc = launch_softmax_bwd<HH>(ctx, g, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, \
-                                                 rowdot, d_scores, gbuf, rs, cs, d_norm_scores_t)
+                                                 rowdot, d_scores, gbuf, rs, cs, d_norm_scores_t, sl, sr)
   if (heads == 1) GAIB_SBW(1);
   else if (heads == 2) GAIB_SBW(2);
   else if (heads == 4 && al16) GAIB_SBW(4);
   else if (heads == 8 && al16) GAIB_SBW(8);
   else if (heads == 16 && al16) GAIB_SBW(16);
   else {
-    GAIB_CHECK(d_scores, "gaib_gat_softmax_bwd_alpha: this head count needs d_scores");
+    GAIB_CHECK(d_scores && d_temp_scores, "gaib_gat_softmax_bwd_alpha: this head count needs d_temp_scores and d_scores");
     softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_norm_scores,
                                                                 d_norm_scores_grad, d_temp_scores, epsilon,
                                                                 d_scores, gbuf, rs);
@@ -887,6 +943,33 @@ extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int l
                                                                          d_alpha_lgrad, d_alpha_rgrad);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
+}
+
+extern "C" int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
+                                             const float* d_feat, const float* d_norm_scores,
+                                             const float* d_norm_scores_grad,
+                                             const float* d_temp_scores, float epsilon,
+                                             float* d_scores, float* d_alpha_lgrad,
+                                             float* d_alpha_rgrad, const float* d_grad_rows,
+                                             const float* d_fwd_out_rows, float* d_norm_scores_t) {
+  GAIB_CHECK(d_temp_scores, "gaib_gat_softmax_bwd_alpha: NULL pointer");
+  return softmax_bwd_alpha_impl(ctx, g, len, heads, d_feat, d_norm_scores, d_norm_scores_grad, d_temp_scores, nullptr,
+                                nullptr, epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad, d_grad_rows, d_fwd_out_rows,
+                                d_norm_scores_t);
+}
+
+extern "C" int gaib_gat_softmax_bwd_alpha_re(gaib_ctx* ctx, gaib_graph* g, int len, int heads,
+                                             const float* d_feat, const float* d_alpha_l, const float* d_alpha_r,
+                                             const float* d_norm_scores, const float* d_norm_scores_grad,
+                                             float epsilon, float* d_scores, float* d_alpha_lgrad,
+                                             float* d_alpha_rgrad, const float* d_grad_rows,
+                                             const float* d_fwd_out_rows, float* d_norm_scores_t) {
+  GAIB_CHECK(d_alpha_l && d_alpha_r, "gaib_gat_softmax_bwd_alpha_re: NULL alpha");
+  GAIB_CHECK(heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16,
+             "gaib_gat_softmax_bwd_alpha_re: heads must be 1, 2, 4, 8 or 16");
+  return softmax_bwd_alpha_impl(ctx, g, len, heads, d_feat, d_norm_scores, d_norm_scores_grad, nullptr, d_alpha_l,
+                                d_alpha_r, epsilon, d_scores, d_alpha_lgrad, d_alpha_rgrad, d_grad_rows, d_fwd_out_rows,
+                                d_norm_scores_t);
 }
 
 extern "C" int gaib_gat_softmax_bwd_alpha_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads,

@@ -145,25 +145,33 @@ void GAT_Aggregator::set_num_heads(int h) {
   }
   if (h == heads) return;
   heads = h;
-  float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
+  float** arrays[] = {&d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
   for (float** a : arrays) {
     float_free_device(*a);
     *a = gaib_host::dmalloc<float>(num_edges * heads);
   }
+  // the temp_scores array only where the kernels do not form the pre-activation score again (see needs_temp)
+  if (d_temp_scores) float_free_device(d_temp_scores);
+  d_temp_scores = needs_temp() ? gaib_host::dmalloc<float>(num_edges * heads) : NULL;
 }
 
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
     num_edges = g.sizeEdges();
-    float** arrays[] = {&d_temp_scores, &d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
+    float** arrays[] = {&d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
     for (float** a : arrays) {
       float_free_device(*a);
       *a = gaib_host::dmalloc<float>(num_edges * heads);
+    }
+    if (d_temp_scores) {
+      float_free_device(d_temp_scores);
+      d_temp_scores = gaib_host::dmalloc<float>(num_edges * heads);
     }
   }
   {
     OpTimer t(OP_SCORE);
     // the leaky-relu output itself is not materialised (NULL): nothing downstream reads it
+    // nor is the pre-activation score where backward can form its sign again (d_temp_scores stays NULL then)
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), dev(g), len, heads, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,
                                    NULL, d_norm_scores));
   }
@@ -189,9 +197,14 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
     fwd_out = NULL;
     // the pass that walks rev anyway also leaves the transposed attention p[rev(e)] in d_norm_scores_t, so the
     // gradient aggregation reads its weights linearly
-    GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_ex(C(), dev(g), len, heads, feat_in, d_norm_scores, d_norm_scores_grad,
-                                              d_temp_scores, epsilon, NULL, d_alpha_lgrad, d_alpha_rgrad,
-                                              fwd ? grad_in : NULL, fwd, d_norm_scores_t));
+    if (d_temp_scores)
+      GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_ex(C(), dev(g), len, heads, feat_in, d_norm_scores, d_norm_scores_grad,
+                                                d_temp_scores, epsilon, NULL, d_alpha_lgrad, d_alpha_rgrad,
+                                                fwd ? grad_in : NULL, fwd, d_norm_scores_t));
+    else
+      GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_re(C(), dev(g), len, heads, feat_in, d_alpha_l, d_alpha_r, d_norm_scores,
+                                                d_norm_scores_grad, epsilon, NULL, d_alpha_lgrad, d_alpha_rgrad,
+                                                fwd ? grad_in : NULL, fwd, d_norm_scores_t));
   }
   OpTimer t(OP_SPARSEMM);
   GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores_t, heads, len, grad_in, grad_out, 0));

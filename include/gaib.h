@@ -154,7 +154,8 @@ int gaib_spmm_mh(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_e
  *   compute_attn_score_warp, graph_operations.h:250-337): per edge
  *   temp = a_l.h[i] + a_r.h[col_e]; scores = leaky_relu(temp, eps); norm = row softmax.
  *   The d_* edge arrays [ne] are written; d_scores may be NULL for 1, 2, 4, 8 or 16 heads (it is
- *   leaky_relu(temp) and nothing in backward reads it). */
+ *   leaky_relu(temp) and nothing in backward reads it), and so may d_temp_scores: backward reads only
+ *   its sign, which gaib_gat_softmax_bwd_alpha_re forms again from the per-vertex dots. */
 int gaib_gat_scores(gaib_ctx* ctx, gaib_graph* g, int len, const float* d_h, const float* d_alpha_l,
                     const float* d_alpha_r, float epsilon, float* d_temp_scores, float* d_scores,
                     float* d_norm_scores);
@@ -193,6 +194,14 @@ int gaib_gat_softmax_bwd_alpha(gaib_ctx* ctx, gaib_graph* g, int len, const floa
 int gaib_gat_softmax_bwd_alpha_ex(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
                                   const float* d_norm_scores, const float* d_norm_scores_grad,
                                   const float* d_temp_scores, float epsilon, float* d_scores,
+                                  float* d_alpha_lgrad, float* d_alpha_rgrad, const float* d_grad_rows,
+                                  const float* d_fwd_out_rows, float* d_norm_scores_t);
+/* the same without the temp_scores array (1, 2, 4, 8 or 16 heads): leaky-relu' needs only the sign of
+ * temp = a_l.h[i] + a_r.h[col_e], formed again from d_feat and the alpha vectors (4 + 4*heads bytes per edge out of the
+ * caches instead of 4*heads written in forward and read here through HBM).  Same results bit for bit. */
+int gaib_gat_softmax_bwd_alpha_re(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
+                                  const float* d_alpha_l, const float* d_alpha_r, const float* d_norm_scores,
+                                  const float* d_norm_scores_grad, float epsilon, float* d_scores,
                                   float* d_alpha_lgrad, float* d_alpha_rgrad, const float* d_grad_rows,
                                   const float* d_fwd_out_rows, float* d_norm_scores_t);
 /* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):

@@ -70,13 +70,17 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--only", default="", help="substring of the layer names to run (e.g. 'GAT')")
+    ap.add_argument("--opt", action="append", default=[], help="context option key=value (gaib_set_option), repeatable")
     args = ap.parse_args()
     ctx = L.init(0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     if args.only:
         _run = run_layer
 
         def run_layer_filtered(c, kind, name, *a, **k):
-            if args.only in name:
+            if args.only.replace("_", " ") in name:
                 _run(c, kind, name, *a, **k)
         globals()["run_layer"] = run_layer_filtered
     run_layer(ctx, L.SAGE, "SAGE 128->128", "ogbn-products", 128, 128, False, args.steps, args.scale)

@@ -7,10 +7,10 @@ OUT=$ROOT/gpurun_out/prof_r01b
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 $ARGS > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 $ARGS > "$OUT/write.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/mfma" -- python3 $ARGS > "$OUT/mfma.log" 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/stats.log" 2>&1
+timeout 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 $ARGS > "$OUT/fetch.log" 2>&1
+timeout 420 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 $ARGS > "$OUT/write.log" 2>&1
+timeout 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/mfma" -- python3 $ARGS > "$OUT/mfma.log" 2>&1
 cd "$ROOT"
 python3 scripts/summarize_rocprof.py stats "$OUT/stats" "$OUT/bench_kernel_stats.csv"
 python3 scripts/summarize_rocprof.py pmc "$OUT/bench_pmc_summary.json" fetch="$OUT/fetch" write="$OUT/write" mfma="$OUT/mfma"

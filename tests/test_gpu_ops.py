@@ -427,6 +427,10 @@ def test_gat_forward_pieces(ctx, d, hub):
     p2 = torch.empty_like(t)
     ctx.gat_scores(g_d, hd, dev(al), dev(ar), t2, None, p2)
     assert torch.equal(t2, t) and torch.equal(p2, p)
+    # ... and so is the pre-activation score (long rows then form it twice instead of writing and re-reading it)
+    p3 = torch.empty_like(t)
+    ctx.gat_scores(g_d, hd, dev(al), dev(ar), None, None, p3)
+    assert torch.equal(p3, p)
 
 
 @pytest.mark.parametrize("d,hub", [(4, 0), (8, 0), (32, 0), (64, 0), (64, 900), (64, 1400), (128, 0), (130, 0), (256, 0),
@@ -464,6 +468,20 @@ def test_gat_backward_pieces(ctx, d, hub):
             assert rel_err(sc2.cpu().numpy(), want_ds) < TOL
         assert rel_err(lg2.cpu().numpy(), want_lg) < TOL
         assert rel_err(rg2.cpu().numpy(), want_rg) < TOL
+    # the form without the temp array (the sign of a_l.h[i] + a_r.h[col] formed again): same bits as with the temp
+    # array the forward kernel wrote
+    t_gpu = torch.empty(g_o.ne, device="cuda")
+    ctx.gat_scores(g_d, hd, dev(al), dev(ar), t_gpu, None, torch.empty(g_o.ne, device="cuda"))
+    res = []
+    for temp_arg in (t_gpu, None):
+        sc3, lg3, rg3, pt3 = (torch.zeros(g_o.ne, device="cuda"), torch.empty(d, device="cuda"),
+                              torch.empty(d, device="cuda"), torch.zeros(g_o.ne, device="cuda"))
+        ctx.gat_softmax_bwd_alpha(g_d, hd, dev(norm), dev(want_ng), temp_arg, sc3, lg3, rg3, grad_rows=gd,
+                                  fwd_out_rows=dev(out_w), norm_t=pt3, alpha=(dev(al), dev(ar)))
+        res.append((sc3, lg3, rg3, pt3))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert rel_err(res[1][1].cpu().numpy(), want_lg) < TOL and rel_err(res[1][2].cpu().numpy(), want_rg) < TOL
     # explicit transpose == oracle's symmetric_csr_transpose (a permutation: bit-exact)
     pt = torch.empty(g_o.ne, device="cuda")
     ctx.edge_transpose(g_d, dev(norm), pt)
@@ -644,6 +662,23 @@ def test_gat_multi_head(ctx, d, heads, hub):
     assert rel_err(sc.cpu().numpy(), want_ds) < TOL
     assert rel_err(lg.cpu().numpy(), want_lg) < TOL
     assert rel_err(rg.cpu().numpy(), want_rg) < TOL
+    # without the temp array: forward gives the same attention, backward the same gradients as with the GPU's own temp
+    if heads in (1, 2, 4, 8, 16):
+        p3 = torch.empty_like(p)
+        ctx.gat_scores(g_d, hd, dev(al), dev(ar), None, None, p3, heads=heads)
+        assert torch.equal(p3, p)
+        res = []
+        for temp_arg in (t, None):
+            sc3, lg3, rg3 = torch.zeros(ne, heads, device="cuda"), torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+            ctx.gat_softmax_bwd_alpha(g_d, hd, p, ng, temp_arg, sc3, lg3, rg3, heads=heads, alpha=(dev(al), dev(ar)))
+            res.append((sc3, lg3, rg3))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    else:
+        with pytest.raises(capi.GaibError):
+            ctx.gat_scores(g_d, hd, dev(al), dev(ar), None, s, p, heads=heads)
+        with pytest.raises(capi.GaibError):
+            ctx.gat_softmax_bwd_alpha(g_d, hd, p, ng, None, sc, lg, rg, heads=heads, alpha=(dev(al), dev(ar)))
     go = torch.empty(n, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE_T, gd, go, edge_w=dev(want_n), heads=heads)
     assert rel_err(go.cpu().numpy(), want_go) < TOL
