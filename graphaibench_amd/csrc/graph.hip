@@ -474,6 +474,25 @@ int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g) {
       cbase[c] = (uint32_t)e;
       ++c;
     }
+  if (ctx->gat_chunk_sort && nch > 1) {
+    // Chunks are independent (each writes its own 64 edge values), so their order is free: sorted by the column
+    // block of their first edge, the chunks in flight at any time gather feature rows from one window of columns
+    // instead of from all over the table (rows are sorted by column, so a chunk covers a compact column interval).
+    std::vector<uint32_t> colh((size_t)g->ne);
+    GAIB_HIP(hipMemcpy(colh.data(), g->colidx, sizeof(uint32_t) * (size_t)g->ne, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> order((size_t)nch);
+    for (int64_t i = 0; i < nch; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+      return (colh[cbase[a]] >> 10) < (colh[cbase[b]] >> 10);
+    });
+    std::vector<uint32_t> crow2((size_t)nch), cbase2((size_t)nch);
+    for (int64_t i = 0; i < nch; ++i) {
+      crow2[i] = crow[order[i]];
+      cbase2[i] = cbase[order[i]];
+    }
+    crow.swap(crow2);
+    cbase.swap(cbase2);
+  }
   GAIB_HIP(hipMalloc(&g->chunk_row, sizeof(uint32_t) * crow.size()));
   GAIB_HIP(hipMalloc(&g->chunk_ebase, sizeof(uint32_t) * cbase.size()));
   GAIB_HIP(hipMemcpy(g->chunk_row, crow.data(), sizeof(uint32_t) * crow.size(), hipMemcpyHostToDevice));
