@@ -58,6 +58,7 @@ struct gaib_ctx {
   int spmm_heavy_threshold;  // rows with more edges go to the workgroup-per-row kernel
   int spmm_variant;          // 0 = auto, see spmm.hip
   int spmm_xcd_swizzle;      // 1 = consecutive row blocks share an XCD
+  int spmm_chunked;          // dense graphs: aggregation by ordered 64-edge chunks + per-row reduction: -1 auto, 0 never, 1 always
   int spmm_pad;              // 1 = re-stride odd-width input tables where that saves >10 % of the gathered lines, 0 = never
   int spmm_fuse;             // 1 = gaib_spmm_gemm may fuse the dense product into the aggregation
   int spmm_flat;             // fused kernel, edge-stream form for short rows: -1 = by average degree, 0 = never, 1 = always
@@ -114,6 +115,7 @@ struct gaib_graph {
   // 64-edge chunks of the edge list (edge-parallel kernels: SDDMM), built lazily on the host
   uint32_t* chunk_row;    // [n_chunks] row of each chunk
   uint32_t* chunk_ebase;  // [n_chunks] first edge of each chunk
+  uint32_t* chunk_start;  // [nv + 1] number of chunks in the rows before row v (chunk k of a row, in row order)
   int64_t n_chunks;
   uint32_t* colidx_flagged;  // gather mode 3: colidx with bit 31 set on cold (low-degree) columns
   int64_t hot_threshold;     // degree threshold the flags were built with (-1 = none)

@@ -243,7 +243,7 @@ extern "C" int gaib_graph_destroy(gaib_graph* g) {
   (void)hipSetDevice(g->device);
   void* ptrs[] = {g->rowptr, g->colidx,   g->vdata, g->edata,      g->inv_deg,  g->col_vdata,
                   g->col_inv_deg, g->w_gcn, g->w_mean_t, g->rev,   g->heavy_rows,
-                  g->chunk_row, g->chunk_ebase, g->colidx_flagged};
+                  g->chunk_row, g->chunk_ebase, g->chunk_start, g->colidx_flagged};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -493,12 +493,23 @@ int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g) {
     crow.swap(crow2);
     cbase.swap(cbase2);
   }
+  {
+    std::vector<uint32_t> cstart((size_t)g->nv + 1);
+    uint32_t run = 0;
+    for (int64_t v = 0; v < g->nv; ++v) {
+      cstart[v] = run;
+      run += (uint32_t)((rp[v + 1] - rp[v] + 63) / 64);
+    }
+    cstart[g->nv] = run;
+    GAIB_HIP(hipMalloc(&g->chunk_start, sizeof(uint32_t) * cstart.size()));
+    GAIB_HIP(hipMemcpy(g->chunk_start, cstart.data(), sizeof(uint32_t) * cstart.size(), hipMemcpyHostToDevice));
+  }
   GAIB_HIP(hipMalloc(&g->chunk_row, sizeof(uint32_t) * crow.size()));
   GAIB_HIP(hipMalloc(&g->chunk_ebase, sizeof(uint32_t) * cbase.size()));
   GAIB_HIP(hipMemcpy(g->chunk_row, crow.data(), sizeof(uint32_t) * crow.size(), hipMemcpyHostToDevice));
   GAIB_HIP(hipMemcpy(g->chunk_ebase, cbase.data(), sizeof(uint32_t) * cbase.size(), hipMemcpyHostToDevice));
   g->n_chunks = nch;
-  g->dev_bytes += 2 * sizeof(uint32_t) * nch;
+  g->dev_bytes += 2 * sizeof(uint32_t) * nch + sizeof(uint32_t) * (g->nv + 1);
   return GAIB_OK;
 }
 

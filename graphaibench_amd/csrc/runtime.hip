@@ -47,6 +47,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_unroll = 0;
   c->spmm_fuse = 1;
   c->spmm_pad = 1;
+  c->spmm_chunked = -1;
   c->spmm_flat = -1;
   c->spmm_addr_mode = 0;
   c->spmm_gather_mode = 0;
@@ -244,6 +245,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_xcd_swizzle = (int)value;
   else if (!strcmp(key, "spmm_fuse"))
     ctx->spmm_fuse = (int)value;
+  else if (!strcmp(key, "spmm_chunked"))
+    ctx->spmm_chunked = (int)value;
   else if (!strcmp(key, "spmm_pad"))
     ctx->spmm_pad = (int)value;
   else if (!strcmp(key, "spmm_flat"))

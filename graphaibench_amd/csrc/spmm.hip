@@ -694,6 +694,130 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   return GAIB_OK;
 }
 
+// ---- dense graphs: aggregation by ordered 64-edge chunks -------------------------------------------------------------
+// Where rows have hundreds of edges and the feature table sits in the Infinity Cache but not in the 4 MB L2 (reddit:
+// 490 edges per row over 60 MB), the row-per-wave kernels gather from all over the table at any moment.  The chunk
+// list of the graph (SDDMM's, ordered by column block) turns that into a sweep: a wave sums the 64 edges of one chunk
+// -- G lanes x 16 B per edge, 64/G edges per instruction -- into a partial row, a second kernel adds a row's partials in
+// row order.  Fixed order, so deterministic, but not the CSR-order sum of the one-row kernels (the oracle's order).
+// (Per-head weights are fetched per lane inside the loop; parking the chunk's [64][heads] block in LDS first was
+// measured slower: 9.0 vs 5.4 ms for the two aggregations of the 8-head layer.)
+template <int G, int WMODE>
+__global__ __launch_bounds__(256) void spmm_chunk_kernel(int64_t n_chunks, const uint32_t* chunk_row,
+                                                         const uint32_t* chunk_ebase, const uint32_t* chunk_start,
+                                                         SpmmArgs a, float* partial) {
+  constexpr int U = G < 8 ? G : 8;
+  constexpr bool MH = WMODE >= 3;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rb = a.rowptr[row];
+  const int64_t rem = a.rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const uint32_t cl = a.col[eb + (lane < n ? lane : 0)];
+  float wl = 0.f;  // weight of edge `lane` of the chunk (0 past the end)
+  if (lane < n) {
+    if constexpr (WMODE == 0) wl = a.rw[row];
+    else if constexpr (WMODE == 1 || WMODE == 2) wl = load_edge_w<WMODE>(a, eb + lane);
+  }
+  const bool colok = sl * 4 < a.ncols;
+  const int coff = colok ? sl * 4 : 0;
+  const int head = MH ? coff / a.dh : 0;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < G; j += U) {
+    f32x4_t x[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ei = gbase + j + u;  // edge of the chunk this group handles now
+      const uint32_t cj = (uint32_t)__shfl((int)cl, ei, 64);
+      x[u] = *reinterpret_cast<const f32x4_t*>(a.in + (int64_t)cj * a.ld + coff);
+      if constexpr (MH) w[u] = ei < n ? load_edge_w<WMODE>(a, eb + ei, head) : 0.f;
+      else w[u] = __shfl(wl, ei, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t = w[u] * x[u][k];
+        acc[k] = acc[k] + t;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+  }
+  const int64_t slot = (int64_t)chunk_start[row] + (eb - rb) / 64;
+  if (gbase == 0 && colok) *reinterpret_cast<f32x4_t*>(partial + slot * a.ncols + coff) = acc;
+}
+
+// out[row] (+)= sum of the row's chunk partials, in row order.  One wave per row, 16 B per lane (ncols <= 256).
+__global__ __launch_bounds__(256) void spmm_chunk_reduce_kernel(SpmmArgs a, const uint32_t* chunk_start,
+                                                                const float* partial) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.n_rows) return;
+  const int lane = threadIdx.x & 63;
+  if (lane * 4 >= a.ncols) return;
+  const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
+  float* o = a.out + row * a.ldo + lane * 4;
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  if (a.accumulate) s = *reinterpret_cast<const f32x4_t*>(o);
+  const float* p = partial + lane * 4;
+  int64_t k = c0;
+  for (; k + 4 <= c1; k += 4) {
+    f32x4_t t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4_t*>(p + (k + u) * a.ncols);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += t[u][q];
+  }
+  for (; k < c1; ++k) {
+    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p + k * a.ncols);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] += t[q];
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = s[q] > 0.f ? s[q] : 0.f;
+  }
+  *reinterpret_cast<f32x4_t*>(o) = s;
+}
+
+template <int WMODE>
+int launch_chunked(gaib_ctx* ctx, gaib_graph* g, const SpmmArgs& a) {
+  GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)g->n_chunks * a.ncols + 256));
+  float* partial = (float*)ctx->ws;
+  const unsigned grid = (unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4);
+  const int lanes = (a.ncols + 3) / 4;
+  {
+    ProfScope ps(ctx, "spmm_chunk");
+#define GAIB_CHUNK(GG) \
+  spmm_chunk_kernel<GG, WMODE><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, a, partial)
+    if (lanes <= 1) GAIB_CHUNK(1);
+    else if (lanes <= 2) GAIB_CHUNK(2);
+    else if (lanes <= 4) GAIB_CHUNK(4);
+    else if (lanes <= 8) GAIB_CHUNK(8);
+    else if (lanes <= 16) GAIB_CHUNK(16);
+    else if (lanes <= 32) GAIB_CHUNK(32);
+    else GAIB_CHUNK(64);
+#undef GAIB_CHUNK
+    GAIB_LAUNCH_CHECK();
+  }
+  ProfScope ps(ctx, "spmm_chunk_reduce");
+  spmm_chunk_reduce_kernel<<<(unsigned)cdiv64(a.n_rows, 4), 256, 0, ctx->stream>>>(a, g->chunk_start, partial);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
 // out[r][0..lp) = in[r][0..len) followed by zeros; lp % 4 == 0, out 16-B aligned.  One float4 of `out` per thread.
 __global__ __launch_bounds__(256) void pad_rows_kernel(int64_t n4, int len, int lp4, const float* in, f32x4_t* out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -817,6 +941,19 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
   SpmmArgs a;
   int wmode = 0;
   GAIB_TRY(spmm_setup(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags, heads, &a, &wmode));
+  // dense graphs over a table that fits the Infinity Cache: ordered chunks (see spmm_chunk_kernel)
+  const bool chunk_shape = len % 4 == 0 && len <= 256 && a.ld % 4 == 0 && a.ldo % 4 == 0 && g->ne > 0 &&
+                           ((((uintptr_t)a.in | (uintptr_t)a.out) & 15) == 0) && (wmode < 3 || a.dh % 4 == 0);
+  const bool chunk_auto = g->ne >= 128 * g->nv && g->nc * a.ld * 4 <= ((int64_t)512 << 20);
+  if (chunk_shape && (ctx->spmm_chunked == 1 || (ctx->spmm_chunked < 0 && chunk_auto))) {
+    switch (wmode) {
+      case 0: return launch_chunked<0>(ctx, g, a);
+      case 1: return launch_chunked<1>(ctx, g, a);
+      case 2: return launch_chunked<2>(ctx, g, a);
+      case 3: return launch_chunked<3>(ctx, g, a);
+      default: return launch_chunked<4>(ctx, g, a);
+    }
+  }
   switch (wmode) {
     case 0: return dispatch_vec<0>(ctx, g, a, len);
     case 1: return dispatch_vec<1>(ctx, g, a, len);

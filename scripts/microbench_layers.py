@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from graphaibench_amd import layers as L, synth  # noqa: E402
 
-KEYS = ["spmm_gemm_fused", "spmm_light", "spmm_heavy", "spmm_sub", "sgemm", "relu", "d_relu", "gat_vertex_dots", "gat_edge_softmax",
+KEYS = ["spmm_gemm_fused", "spmm_light", "spmm_heavy", "spmm_sub", "spmm_chunk", "spmm_chunk_reduce", "sgemm", "relu", "d_relu", "gat_vertex_dots", "gat_edge_softmax",
         "gat_sddmm", "gat_softmax_bwd_alpha"]
 
 

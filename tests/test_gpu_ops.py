@@ -163,6 +163,49 @@ def test_spmm_restrided_input_table(ctx, d):
     assert rel_err(padded[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy())) < TOL
 
 
+@pytest.mark.parametrize("d", [4, 16, 44, 64, 100, 128, 256])
+def test_spmm_chunked_dense_graph_path(ctx, d):
+    """spmm_chunked: partial rows per ordered 64-edge chunk + per-row reduction (what dense graphs get by default)
+    against the one-row-per-wave kernels and the oracle: every weight kind, per-head weights, hub and empty rows,
+    accumulate + relu"""
+    rp, ci = random_graph(1500, 70, seed=d, power_law=True, hub_deg=1300)
+    rp = np.concatenate([rp, [rp[-1]] * 3])  # three empty rows at the end (square graph: columns stay valid)
+    g_o, g_d = make(ctx, rp, ci)
+    n, ne = g_o.nv, g_o.ne
+    x = dev(feat(n, d, 2))
+    ew = torch.rand(ne, device="cuda")
+    heads = 4 if d % 16 == 0 else 1
+    ewh = torch.rand(ne, heads, device="cuda")
+
+    def run():
+        res = []
+        for kind, w in ((capi.W_MEAN, None), (capi.W_MEAN_T, None), (capi.W_GCN, None), (capi.W_EDGE, ew), (capi.W_EDGE_T, ew)):
+            out = torch.full((n, d), 9.0, device="cuda")
+            ctx.spmm(g_d, kind, x, out, edge_w=w)
+            res.append(out)
+            ctx.spmm(g_d, kind, x, out2 := out.clone(), edge_w=w, accumulate=True, relu=True)
+            res.append(out2)
+        for kind in (capi.W_EDGE, capi.W_EDGE_T):
+            out = torch.empty(n, d, device="cuda")
+            ctx.spmm(g_d, kind, x, out, edge_w=ewh, heads=heads)
+            res.append(out)
+        ctx.sync()
+        return res
+
+    ctx.set_option("spmm_chunked", 0)
+    rows = run()
+    ctx.set_option("spmm_chunked", 1)
+    try:
+        chunks = run()
+        chunks_again = run()
+    finally:
+        ctx.set_option("spmm_chunked", -1)
+    for a, b, c in zip(rows, chunks, chunks_again):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+        assert torch.equal(b, c)  # fixed summation order: run-to-run identical
+    assert rel_err(chunks[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy())) < TOL
+
+
 @pytest.mark.parametrize("d", [16, 100, 128, 512])
 def test_spmm_heavy_rows(ctx, d):
     """hub rows above the heavy threshold take the workgroup-per-row kernel (fixed-order LDS reduce)"""
