@@ -1000,7 +1000,11 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   // 65..128 columns need 8-byte lanes
   const int kpad = len_in <= 64 ? 64 : 128;
   const bool lanes_ok = len_in <= 64 ? true : (len_in % 2 == 0 && (al & 7) == 0);
-  const bool fusable = ctx->spmm_fuse != 0 && len_in >= 1 && len_in <= 128 && lanes_ok &&
+  // dense graphs over a cache-sized table aggregate faster by ordered chunks (spmm_chunk_kernel) than row by row
+  // inside the fused kernel: two kernels there
+  const bool dense = ctx->spmm_chunked != 0 && len_in % 4 == 0 && g->ne >= 128 * g->nv &&
+                     g->nc * (int64_t)len_in * 4 <= ((int64_t)512 << 20) && (al & 15) == 0;
+  const bool fusable = ctx->spmm_fuse != 0 && !dense && len_in >= 1 && len_in <= 128 && lanes_ok &&
                        fuse_strip_rows(kpad, len_out, dual) != 0 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);

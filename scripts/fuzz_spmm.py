@@ -26,6 +26,8 @@ def main():
                               hub_deg=int(rng.choice([0, min(nv - 1, 2000)])) if nv > 2100 else 0)
         nv = len(rp) - 1
         ctx.set_option("spmm_heavy_threshold", int(rng.choice([1024, 1024, 32, 1])))
+        ctx.set_option("spmm_chunked", int(rng.choice([-1, 0, 1])))  # ordered-chunk path where the shape allows
+        ctx.set_option("spmm_pad", int(rng.choice([0, 1])))
         kind = int(rng.choice([capi.W_GCN, capi.W_MEAN, capi.W_MEAN_T, capi.W_EDGE, capi.W_EDGE_T]))
         heads = int(rng.choice([1, 1, 2, 4, 8])) if kind in (capi.W_EDGE, capi.W_EDGE_T) else 1
         dh = int(rng.choice([1, 3, 4, 8, 16, 25, 32]))
@@ -71,6 +73,8 @@ def main():
             sys.exit(1)
         g.close()
     ctx.set_option("spmm_heavy_threshold", 1024)
+    ctx.set_option("spmm_chunked", -1)
+    ctx.set_option("spmm_pad", 1)
     print(f"{n_cases} cases ok, worst relative error {worst:.2e}")
 
 
