@@ -700,14 +700,17 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
 // list of the graph (SDDMM's, ordered by column block) turns that into a sweep: a wave sums the 64 edges of one chunk
 // -- G lanes x 16 B per edge, 64/G edges per instruction -- into a partial row, a second kernel adds a row's partials in
 // row order.  Fixed order, so deterministic, but not the CSR-order sum of the one-row kernels (the oracle's order).
-// (Per-head weights are fetched per lane inside the loop; parking the chunk's [64][heads] block in LDS first was
-// measured slower: 9.0 vs 5.4 ms for the two aggregations of the 8-head layer.)
-template <int G, int WMODE>
+// HT > 0 (WMODE 3, heads == HT in {4, 8, 16}): the chunk's [64][HT] weight block is read once, one edge per lane
+// (HT/4 16-byte loads), parked in the wave's LDS slice with a row stride of HT + 1 floats and picked up per (edge, head)
+// from there: 2 + 2 wave instructions per chunk instead of one 4-byte global load per lane and edge.
+template <int G, int WMODE, int HT = 0>
 __global__ __launch_bounds__(256) void spmm_chunk_kernel(int64_t n_chunks, const uint32_t* chunk_row,
                                                          const uint32_t* chunk_ebase, const uint32_t* chunk_start,
                                                          SpmmArgs a, float* partial) {
   constexpr int U = G < 8 ? G : 8;
   constexpr bool MH = WMODE >= 3;
+  constexpr int WS = HT + 1;  // LDS row stride (floats)
+  __shared__ float wlds[HT > 0 ? 4 * 64 * WS : 1];
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
   const int lane = threadIdx.x & 63;
@@ -726,6 +729,18 @@ __global__ __launch_bounds__(256) void spmm_chunk_kernel(int64_t n_chunks, const
   const bool colok = sl * 4 < a.ncols;
   const int coff = colok ? sl * 4 : 0;
   const int head = MH ? coff / a.dh : 0;
+  float* wd = wlds + (HT > 0 ? (threadIdx.x >> 6) * 64 * WS : 0);
+  if constexpr (HT > 0) {
+    f32x4_t wv[HT / 4];
+    const float* src = a.ew + (eb + (lane < n ? lane : 0)) * HT;
+#pragma unroll
+    for (int q = 0; q < HT / 4; ++q) wv[q] = reinterpret_cast<const f32x4_t*>(src)[q];
+#pragma unroll
+    for (int q = 0; q < HT / 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wd[lane * WS + 4 * q + k] = lane < n ? wv[q][k] : 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wave complete in order
+  }
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < G; j += U) {
@@ -736,7 +751,8 @@ __global__ __launch_bounds__(256) void spmm_chunk_kernel(int64_t n_chunks, const
       const int ei = gbase + j + u;  // edge of the chunk this group handles now
       const uint32_t cj = (uint32_t)__shfl((int)cl, ei, 64);
       x[u] = *reinterpret_cast<const f32x4_t*>(a.in + (int64_t)cj * a.ld + coff);
-      if constexpr (MH) w[u] = ei < n ? load_edge_w<WMODE>(a, eb + ei, head) : 0.f;
+      if constexpr (HT > 0) w[u] = wd[ei * WS + head];
+      else if constexpr (MH) w[u] = ei < n ? load_edge_w<WMODE>(a, eb + ei, head) : 0.f;
       else w[u] = __shfl(wl, ei, 64);
     }
 #pragma unroll
@@ -802,7 +818,15 @@ int launch_chunked(gaib_ctx* ctx, gaib_graph* g, const SpmmArgs& a) {
     ProfScope ps(ctx, "spmm_chunk");
 #define GAIB_CHUNK(GG) \
   spmm_chunk_kernel<GG, WMODE><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, a, partial)
-    if (lanes <= 1) GAIB_CHUNK(1);
+#define GAIB_CHUNK_H(GG, HH) \
+  spmm_chunk_kernel<GG, 3, HH><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, a, partial)
+    const bool w16 = WMODE == 3 && (((uintptr_t)a.ew) & 15) == 0;
+    if (w16 && lanes > 8 && lanes <= 16 && a.heads == 8) GAIB_CHUNK_H(16, 8);
+    else if (w16 && lanes > 8 && lanes <= 16 && a.heads == 4) GAIB_CHUNK_H(16, 4);
+    else if (w16 && lanes > 8 && lanes <= 16 && a.heads == 16) GAIB_CHUNK_H(16, 16);
+    else if (w16 && lanes > 16 && lanes <= 32 && a.heads == 8) GAIB_CHUNK_H(32, 8);
+    else if (w16 && lanes > 32 && a.heads == 8) GAIB_CHUNK_H(64, 8);
+    else if (lanes <= 1) GAIB_CHUNK(1);
     else if (lanes <= 2) GAIB_CHUNK(2);
     else if (lanes <= 4) GAIB_CHUNK(4);
     else if (lanes <= 8) GAIB_CHUNK(8);
@@ -810,6 +834,7 @@ int launch_chunked(gaib_ctx* ctx, gaib_graph* g, const SpmmArgs& a) {
     else if (lanes <= 32) GAIB_CHUNK(32);
     else GAIB_CHUNK(64);
 #undef GAIB_CHUNK
+#undef GAIB_CHUNK_H
     GAIB_LAUNCH_CHECK();
   }
   ProfScope ps(ctx, "spmm_chunk_reduce");

@@ -174,8 +174,8 @@ def test_spmm_chunked_dense_graph_path(ctx, d):
     n, ne = g_o.nv, g_o.ne
     x = dev(feat(n, d, 2))
     ew = torch.rand(ne, device="cuda")
-    heads = 4 if d % 16 == 0 else 1
-    ewh = torch.rand(ne, heads, device="cuda")
+    head_counts = [h for h in (4, 8, 16) if d % (4 * h) == 0] or [1]  # (a head's columns are whole 16-B lane slices)
+    ewh = {h: torch.rand(ne, h, device="cuda") for h in head_counts}
 
     def run():
         res = []
@@ -185,10 +185,11 @@ def test_spmm_chunked_dense_graph_path(ctx, d):
             res.append(out)
             ctx.spmm(g_d, kind, x, out2 := out.clone(), edge_w=w, accumulate=True, relu=True)
             res.append(out2)
-        for kind in (capi.W_EDGE, capi.W_EDGE_T):
-            out = torch.empty(n, d, device="cuda")
-            ctx.spmm(g_d, kind, x, out, edge_w=ewh, heads=heads)
-            res.append(out)
+        for heads in head_counts:  # 4 / 8 / 16 heads at 16-lane rows: weights staged through LDS
+            for kind in (capi.W_EDGE, capi.W_EDGE_T):
+                out = torch.empty(n, d, device="cuda")
+                ctx.spmm(g_d, kind, x, out, edge_w=ewh[heads], heads=heads)
+                res.append(out)
         ctx.sync()
         return res
 
