@@ -905,7 +905,8 @@ static int spmm_setup(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float
   // 40 GB of gathers at products / 47) and gathered from there; output rows keep the caller's stride.
   {
     const int bytes = len * 4, stride = (bytes + 63) & ~63;
-    if (ctx->spmm_pad && len > 16 && stride != bytes && g->ne > 4 * g->nc &&
+    // (not inside a side-stream section: the copy buffer belongs to the main stream's calls)
+    if (ctx->spmm_pad && !ctx->forked && len > 16 && stride != bytes && g->ne > 4 * g->nc &&
         lines_strided(bytes, stride) < 0.9 * lines_packed(bytes)) {
       const int lp = stride / 4;
       GAIB_TRY(gaib_pad_reserve(ctx, (size_t)g->nc * (size_t)stride));
