@@ -553,6 +553,106 @@ extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
   return gaib_sgemm_ex(ctx, transA, transB, M, N, K, d_A, d_B, accum ? GAIB_ACCUMULATE : 0, d_C);
 }
 
+// ---- streaming products C[M x N] = A[M x K] . op(B), M in the millions, K <= 256 ----------------------------------------
+// The LDS-tiled kernel re-stages the same small B for every 64-row tile (9.8 GB of L2 -> LDS traffic for 2.45 M x 256 x
+// 256 against 2.5 GB of A) and synchronises every 32 columns of K; every tiling of it lands at 103-106 TF/s.  Here a
+// persistent workgroup keeps a 128-column slab of op(B) in LDS, k-major [K][128 + 4], for its whole life, and every wave
+// streams its own 32-row tiles of A straight from global memory into MFMA operand registers: lane (i, h) reads the 16
+// bytes A[row i][k0 + 4h .. k0 + 4h + 3] and pairs them, step by step, with B rows k0 + 4h + s from LDS (the two lane
+// halves of v_mfma_f32_32x32x2_f32 may carry any two k's as long as both operands agree).  One float4 load feeds 16
+// MFMAs; no barrier after the slab is staged.  Chosen for K > 128 (at K = 128 a tile is too short: 1.00 vs 0.90 ms).
+constexpr int NNP_WAVES = 8;
+constexpr int NNP_LDB = 128 + 4;
+template <int NT, bool BT>  // NT = 32-column MFMA tiles per wave (N slab = 32 * NT <= 128); BT: B is [N][K] (op = transpose)
+__global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float nnp_lds[];  // [K][NNP_LDB]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t n0 = (int64_t)blockIdx.y * (32 * NT);
+  const int K = (int)g.K;
+  // stage the slab: Bs[k][n] = op(B)[k][n0 + n], zero past N
+  for (int t = threadIdx.x; t < K * 32 * NT; t += NNP_WAVES * 64) {
+    int k, n;
+    if constexpr (BT) { n = t / K; k = t - n * K; }  // coalesced along k of B[n][:]
+    else { k = t / (32 * NT); n = t - k * (32 * NT); }
+    const int64_t nn = n0 + n;
+    float v = 0.f;
+    if (nn < g.N) v = BT ? g.B[nn * g.K + k] : g.B[(int64_t)k * g.N + nn];
+    nnp_lds[k * NNP_LDB + n] = v;
+  }
+  __syncthreads();
+  const int64_t ntiles = (g.M + 31) / 32;
+  const float* bcol = nnp_lds + li;
+  for (int64_t t = (int64_t)blockIdx.x * NNP_WAVES + wave; t < ntiles; t += (int64_t)gridDim.x * NNP_WAVES) {
+    const int64_t m0 = t * 32;
+    int64_t row = m0 + li;
+    if (row >= g.M) row = g.M - 1;  // clamped: loaded, never stored
+    const float* arow = g.A + row * g.K + 4 * lh;
+    f16v acc[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    // two operand sets: the load of step k0 + 8 is in flight while step k0 runs on the matrix cores.  (Measured at
+    // 2.45 M x 256 x 256: this form 2.82 ms; 16 waves + two steps ahead 2.97 ms; 32-wide K blocks with whole-line
+    // loads 2.94 ms; the LDS-tiled kernel 3.0-3.1 ms in every tiling; rocBLAS 2.63 ms.)
+    f4 a_cur = *reinterpret_cast<const f4*>(arow);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      f4 a_nxt = a_cur;
+      if (k0 + 8 < K) a_nxt = *reinterpret_cast<const f4*>(arow + k0 + 8);
+      const float* bk = bcol + (k0 + 4 * lh) * NNP_LDB;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bk[s * NNP_LDB + 32 * b], acc[b], 0, 0, 0);
+      }
+      a_cur = a_nxt;
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int64_t nn = n0 + 32 * b + li;
+      if (nn < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (mm < g.M) {
+            float* p = g.C + mm * g.N + nn;
+            float v = g.accum ? (*p + acc[b][r]) : acc[b][r];
+            if (g.relu && !(v > 0.f)) v = 0.f;
+            *p = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool BT>
+int launch_stream(gaib_ctx* ctx, const GemmArgs& g) {
+  const int nt = g.N > 96 ? 4 : (g.N > 64 ? 3 : (g.N > 32 ? 2 : 1));
+  const unsigned slabs = (unsigned)cdiv64(g.N, 32 * nt);
+  const size_t lds = sizeof(float) * (size_t)g.K * NNP_LDB;
+  const int64_t ntiles = cdiv64(g.M, 32);
+  unsigned gx = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus / slabs > 0 ? ctx->num_cus / slabs : 1, cdiv64(ntiles, NNP_WAVES));
+  if (slabs == 1) gx = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, NNP_WAVES));
+  ProfScope ps(ctx, "sgemm");
+#define GAIB_STREAM(NTT)                                                                                        \
+  do {                                                                                                          \
+    GAIB_HIP(hipFuncSetAttribute((const void*)sgemm_stream_kernel<NTT, BT>,                                     \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+    sgemm_stream_kernel<NTT, BT><<<dim3(gx, slabs), NNP_WAVES * 64, lds, ctx->stream>>>(g);                     \
+  } while (0)
+  if (nt == 4) GAIB_STREAM(4);
+  else if (nt == 3) GAIB_STREAM(3);
+  else if (nt == 2) GAIB_STREAM(2);
+  else GAIB_STREAM(1);
+#undef GAIB_STREAM
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
 extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K,
                              const float* d_A, const float* d_B, int flags, float* d_C) {
   const int accum = (flags & GAIB_ACCUMULATE) ? 1 : 0;
@@ -594,6 +694,11 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   if (transA && !transB && M <= 128 && N <= 128 && M % 4 == 0 && N % 4 == 0 && avec && bvec && K >= 32768 &&
       ctx->sgemm_variant != 30)
     return launch_tn_reg(ctx, g);
+  // streaming products (rows in the millions, K <= 256): persistent workgroups with the op(B) slab in LDS
+  // (sgemm_variant 40 keeps the LDS-tiled kernel, 41 forces this one wherever the shape allows)
+  const bool stream_shape = !transA && K % 8 == 0 && K <= 256 && avec;
+  if (stream_shape && ctx->sgemm_variant != 40 && (ctx->sgemm_variant == 41 || (M >= 65536 && K > 128 && ctx->sgemm_variant == 0)))
+    return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
   if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);
   return dispatch_shape<true, true>(ctx, g, avec, bvec);

@@ -898,6 +898,38 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
         assert rel_err(Cd.cpu().numpy(), ref64) < 2e-5
 
 
+@pytest.mark.parametrize("x,y,z,tB,accum,relu", [
+    (1000, 128, 128, 0, 0, 0), (777, 128, 96, 1, 0, 1), (200, 72, 264, 0, 0, 0), (5001, 256, 256, 0, 1, 1), (4099, 256, 256, 1, 0, 0),
+    (31, 47, 128, 0, 0, 0), (33, 47, 128, 1, 1, 0), (3000, 100, 256, 0, 0, 1), (3000, 200, 104, 1, 0, 0), (2049, 16, 16, 0, 0, 0),
+    (70001, 64, 64, 0, 0, 0), (70001, 48, 200, 1, 0, 1), (1, 128, 8, 0, 0, 0)])
+def test_sgemm_streaming_kernel(ctx, x, y, z, tB, accum, relu):
+    """the persistent streaming kernel (what NN / NT products with >= 65 536 rows and 128 < K <= 256 get; forced here with
+    sgemm_variant 41 at every slab / tile-count / tail shape): same product as the LDS-tiled kernel and the oracle"""
+    rng = np.random.default_rng(x + y + z)
+    A = rng.standard_normal((x, z)).astype(np.float32)
+    B = rng.standard_normal((y, z) if tB else (z, y)).astype(np.float32)
+    C0 = rng.standard_normal((x, y)).astype(np.float32)
+    want = orc.matmul(A, B, False, bool(tB), C0 if accum else None)
+    if relu:
+        want = np.maximum(want, 0)
+    res = []
+    try:
+        for variant in ((41, 40) if z % 8 == 0 and z <= 256 else (40,)):
+            ctx.set_option("sgemm_variant", variant)
+            Cd = dev(C0.copy())
+            ctx.sgemm(dev(A), dev(B), Cd, False, bool(tB), bool(accum), relu=bool(relu))
+            res.append(Cd.cpu().numpy())
+    finally:
+        ctx.set_option("sgemm_variant", 0)
+    for got in res:
+        assert rel_err(got, want) < 2e-5
+    # default dispatch at the row count where the streaming kernel takes over
+    if x >= 65536:
+        Cd = dev(C0.copy())
+        ctx.sgemm(dev(A), dev(B), Cd, False, bool(tB), bool(accum), relu=bool(relu))
+        assert np.array_equal(Cd.cpu().numpy(), res[0])
+
+
 @pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21])
 def test_sgemm_experimental_variants_agree(ctx, variant):
     """the tiling / double-buffer knobs (gaib_set_option sgemm_variant) change the schedule, not the result"""
