@@ -560,7 +560,7 @@ extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
 // streams its own 32-row tiles of A straight from global memory into MFMA operand registers: lane (i, h) reads the 16
 // bytes A[row i][k0 + 4h .. k0 + 4h + 3] and pairs them, step by step, with B rows k0 + 4h + s from LDS (the two lane
 // halves of v_mfma_f32_32x32x2_f32 may carry any two k's as long as both operands agree).  One float4 load feeds 16
-// MFMAs; no barrier after the slab is staged.  Chosen for K > 128 (at K = 128 a tile is too short: 1.00 vs 0.90 ms).
+// MFMAs; no barrier after the slab is staged.  An option (sgemm_variant 41), see gaib_sgemm_ex.
 constexpr int NNP_WAVES = 8;
 constexpr int NNP_LDB = 128 + 4;
 template <int NT, bool BT>  // NT = 32-column MFMA tiles per wave (N slab = 32 * NT <= 128); BT: B is [N][K] (op = transpose)
@@ -694,10 +694,11 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   if (transA && !transB && M <= 128 && N <= 128 && M % 4 == 0 && N % 4 == 0 && avec && bvec && K >= 32768 &&
       ctx->sgemm_variant != 30)
     return launch_tn_reg(ctx, g);
-  // streaming products (rows in the millions, K <= 256): persistent workgroups with the op(B) slab in LDS
-  // (sgemm_variant 40 keeps the LDS-tiled kernel, 41 forces this one wherever the shape allows)
+  // streaming products (rows in the millions, K <= 256): persistent workgroups with the op(B) slab in LDS.  Behind
+  // sgemm_variant 41 only: timed alone it beats the LDS-tiled kernel at K = 256 (2.84 vs 3.00 ms), inside the SAGE
+  // 256 -> 256 layer step it loses (four launches 1.3 ms slower in total, alternating A/B in one process).
   const bool stream_shape = !transA && K % 8 == 0 && K <= 256 && avec;
-  if (stream_shape && ctx->sgemm_variant != 40 && (ctx->sgemm_variant == 41 || (M >= 65536 && K > 128 && ctx->sgemm_variant == 0)))
+  if (stream_shape && ctx->sgemm_variant == 41)
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
   if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);

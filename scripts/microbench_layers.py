@@ -84,6 +84,7 @@ def main():
                 _run(c, kind, name, *a, **k)
         globals()["run_layer"] = run_layer_filtered
     run_layer(ctx, L.SAGE, "SAGE 128->128", "ogbn-products", 128, 128, False, args.steps, args.scale)
+    run_layer(ctx, L.SAGE, "SAGE 256->256 (hidden 256 of scripts/run-sage-products.sh)", "ogbn-products", 256, 256, False, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 128->128", "ogbn-products", 128, 128, True, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 100->128 (layer 0 shape, level 1)", "ogbn-products", 100, 128, True, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 128->47", "ogbn-products", 128, 47, True, args.steps, args.scale)
