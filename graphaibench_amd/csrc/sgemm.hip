@@ -271,14 +271,32 @@ __global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
     for (int b = 0; b < WN; ++b) {
       const int64_t nn = n0 + (wn * WN + b) * 32 + li;
       if (nn < g.N) {
+        const int64_t mt = m0 + (wm * WM + a) * 32;
+        if (mt + 32 <= g.M) {
+          // whole tile: the 16 old values of the C += form are requested together (one dependent load per element,
+          // behind a bounds branch each, cost the accumulating products of the SAGE layers ~0.5 ms per launch)
+          float* pc = C + (mt + 4 * lh) * g.N + nn;
+          float cv[16];
+          if (accum) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t mm = m0 + (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (mm < g.M) {
-            float* p = C + mm * g.N + nn;
-            float v = accum ? (*p + acc[a][b][r]) : acc[a][b][r];
+            for (int r = 0; r < 16; ++r) cv[r] = pc[((r & 3) + 8 * (r >> 2)) * g.N];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = accum ? (cv[r] + acc[a][b][r]) : acc[a][b][r];
             if (relu && !(v > 0.f)) v = 0.f;
-            *p = v;
+            pc[((r & 3) + 8 * (r >> 2)) * g.N] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t mm = mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mm < g.M) {
+              float* p = C + mm * g.N + nn;
+              float v = accum ? (*p + acc[a][b][r]) : acc[a][b][r];
+              if (relu && !(v > 0.f)) v = 0.f;
+              *p = v;
+            }
           }
         }
       }
@@ -560,7 +578,7 @@ extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
 // streams its own 32-row tiles of A straight from global memory into MFMA operand registers: lane (i, h) reads the 16
 // bytes A[row i][k0 + 4h .. k0 + 4h + 3] and pairs them, step by step, with B rows k0 + 4h + s from LDS (the two lane
 // halves of v_mfma_f32_32x32x2_f32 may carry any two k's as long as both operands agree).  One float4 load feeds 16
-// MFMAs; no barrier after the slab is staged.  An option (sgemm_variant 41), see gaib_sgemm_ex.
+// MFMAs; no barrier after the slab is staged.
 constexpr int NNP_WAVES = 8;
 constexpr int NNP_LDB = 128 + 4;
 template <int NT, bool BT>  // NT = 32-column MFMA tiles per wave (N slab = 32 * NT <= 128); BT: B is [N][K] (op = transpose)
@@ -610,18 +628,35 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
       a_cur = a_nxt;
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool full_rows = m0 + 32 <= g.M;
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       const int64_t nn = n0 + 32 * b + li;
       if (nn < g.N) {
+        float* pc = g.C + (m0 + 4 * lh) * g.N + nn;
+        if (full_rows) {
+          // whole tile: the 16 old values (C += form) are requested together, not one dependent load per element
+          float cv[16];
+          if (g.accum) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (mm < g.M) {
-            float* p = g.C + mm * g.N + nn;
-            float v = g.accum ? (*p + acc[b][r]) : acc[b][r];
+            for (int r = 0; r < 16; ++r) cv[r] = pc[((r & 3) + 8 * (r >> 2)) * g.N];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = g.accum ? (cv[r] + acc[b][r]) : acc[b][r];
             if (g.relu && !(v > 0.f)) v = 0.f;
-            *p = v;
+            pc[((r & 3) + 8 * (r >> 2)) * g.N] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mm < g.M) {
+              float* p = g.C + mm * g.N + nn;
+              float v = g.accum ? (*p + acc[b][r]) : acc[b][r];
+              if (g.relu && !(v > 0.f)) v = 0.f;
+              *p = v;
+            }
           }
         }
       }
@@ -694,11 +729,12 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   if (transA && !transB && M <= 128 && N <= 128 && M % 4 == 0 && N % 4 == 0 && avec && bvec && K >= 32768 &&
       ctx->sgemm_variant != 30)
     return launch_tn_reg(ctx, g);
-  // streaming products (rows in the millions, K <= 256): persistent workgroups with the op(B) slab in LDS.  Behind
-  // sgemm_variant 41 only: timed alone it beats the LDS-tiled kernel at K = 256 (2.84 vs 3.00 ms), inside the SAGE
-  // 256 -> 256 layer step it loses (four launches 1.3 ms slower in total, alternating A/B in one process).
+  // streaming products (rows in the millions, 128 < K <= 256): persistent workgroups with the op(B) slab in LDS
+  // (sgemm_variant 40 keeps the LDS-tiled kernel, 41 forces this one wherever the shape allows).  Inside the SAGE
+  // 256 -> 256 layer step: 17.9 vs 19.5 ms for the six GEMMs (scripts/ab_gemm_in_layer.py); at K = 128 a tile is too
+  // short for this form (1.00 vs 0.90 ms).
   const bool stream_shape = !transA && K % 8 == 0 && K <= 256 && avec;
-  if (stream_shape && ctx->sgemm_variant == 41)
+  if (stream_shape && ctx->sgemm_variant != 40 && (ctx->sgemm_variant == 41 || (ctx->sgemm_variant == 0 && M >= 65536 && K > 128)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
   if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);
