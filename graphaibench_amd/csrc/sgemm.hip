@@ -43,6 +43,7 @@ struct GemmArgs {
   // B is written back through bwrite (by the workgroups of the first M tile only)
   const float* bmask;
   float* bwrite;
+  int interleave;  // register-resident TN kernel: waves take register sets round robin (a compact moving window over K)
 };
 
 // Load a TR x TC tile (TC % 4 == 0) of a row-major matrix [R][Cc] (leading dim ld) starting at
@@ -335,8 +336,24 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 31, h = lane >> 5;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t kbeg = wid * g.k_chunk;  // k_chunk is a multiple of 2 * TN_PD
-  const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
+  constexpr int64_t GRP = 2 * TN_PD;  // rows per register set
+  // Two ways to deal K out.  Contiguous: wave w owns rows [w * k_chunk, (w + 1) * k_chunk).  Interleaved: set q of
+  // 2 * TN_PD rows goes to wave q mod W, so at any time the W waves sweep one compact window of the operands (W sets =
+  // a few MB) instead of W places spread over 1.25 GB each.  Below, k and kp are positions inside the wave's own
+  // sequence of rows; phys() turns the start of a set into its row in the matrices.
+  const int64_t W = (int64_t)gridDim.x * 4;
+  int64_t kbeg, kend;
+  if (g.interleave) {
+    const int64_t total = (g.K + GRP - 1) / GRP;
+    const int64_t mine = wid < total ? (total - wid + W - 1) / W : 0;
+    kbeg = 0;
+    kend = mine * GRP;
+    if (mine > 0 && wid == (total - 1) % W) kend = (mine - 1) * GRP + (g.K - (total - 1) * GRP);  // the short last set
+  } else {
+    kbeg = wid * g.k_chunk;  // k_chunk is a multiple of 2 * TN_PD
+    kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
+  }
+  auto phys = [&](int64_t kp) -> int64_t { return g.interleave ? ((kp / GRP) * W + wid) * GRP : kp; };
   f16v acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
     for (int s = 0; s < TN_PD; ++s) {
       const int64_t k = kp + 2 * s + h;
       const bool kok = full || k < kend;
-      const int64_t kr = kok ? k : kbeg;
+      const int64_t kr = kok ? phys(kp) + 2 * s + h : 0;
       f4 va = *reinterpret_cast<const f4*>(g.A + kr * g.M + mo);
       f4 vb = *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
       if constexpr (BMASK) {
@@ -386,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) vb[e] = mk[e] > 0.f ? vb[e] : 0.f;  // d_relu (math_functions.cu:258-268)
         sb[set][s] = vb;
         const int64_t k = kp + 2 * s + h;
-        if (nok && (full || k < kend)) *reinterpret_cast<f4*>(g.bwrite + k * g.N + no) = vb;
+        if (nok && (full || k < kend)) *reinterpret_cast<f4*>(g.bwrite + (phys(kp) + 2 * s + h) * g.N + no) = vb;
       }
     }
   };
@@ -456,7 +473,10 @@ int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
   const int64_t waves = (int64_t)ctx->num_cus * 4;
   const int64_t group = 2 * (g.bmask ? TnDepth<true>::PD : TnDepth<false>::PD);
   int64_t chunk = cdiv64(cdiv64(g.K, waves), group) * group;  // whole register sets per wave
-  const int64_t active = cdiv64(g.K, chunk);            // waves that own rows
+  int64_t active = cdiv64(g.K, chunk);            // waves that own rows
+  // sgemm_variant 33: contiguous K ranges per wave; default: sets dealt round robin
+  g.interleave = ctx->sgemm_variant == 33 ? 0 : 1;
+  if (g.interleave) active = std::min<int64_t>(waves, cdiv64(g.K, group));
   const unsigned blocks = (unsigned)cdiv64(active, 4);
   float* Cout = g.C;
   const int accum = g.accum;
@@ -720,6 +740,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   g.tiles_n = 1;
   g.bmask = nullptr;
   g.bwrite = nullptr;
+  g.interleave = 0;
   // 16-B loads need an aligned base and a leading dimension that keeps rows aligned
   const int64_t lda = transA ? M : K;
   const int64_t ldb = transB ? K : N;
@@ -750,10 +771,11 @@ extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, 
   GAIB_CHECK(M >= 0 && N >= 0 && K >= 0, "gaib_sgemm_drelu: negative dimension");
   GAIB_CHECK(K == 0 || N == 0 || (d_G && d_mask), "gaib_sgemm_drelu: G/mask is NULL");
   const bool aligned = ((((uintptr_t)d_A | (uintptr_t)d_G | (uintptr_t)d_mask) & 15) == 0) && M % 4 == 0 && N % 4 == 0;
-  // sgemm_variant 32: the register-resident split-K kernel (mask rows travel with the operand sets and are applied
-  // when a set is consumed).  Alone it beats the LDS kernel (1.03 vs 1.16 ms at the headline shape); inside the layer
-  // step, behind the aggregation kernel, it is the slower one (1.15 vs 1.10 ms), so the LDS kernel is the default.
-  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant == 32;
+  // long K, M, N <= 128: the register-resident split-K kernel (mask rows travel with the operand sets and are applied
+  // when a set is consumed); sgemm_variant 30 / 31 keep the LDS kernel.  With K dealt out in contiguous per-wave ranges
+  // this kernel won alone (1.03 vs 1.16 ms) and lost inside the layer step (1.15 vs 1.10); with the register sets dealt
+  // round robin (one compact window over K for all waves) it wins there too: 0.97 vs 1.03 ms (scripts/ab_weight_grad.py).
+  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant != 30 && ctx->sgemm_variant != 31;
   if (M == 0 || N == 0 || K == 0 || (!reg_path && (!aligned || N <= 64))) {
     // shapes the masked kernel is not built for: the two-step form
     if (K > 0 && N > 0) GAIB_TRY(gaib_d_relu(ctx, K * N, d_G, d_mask, d_G));
@@ -775,6 +797,7 @@ extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, 
   g.tiles_n = 1;
   g.bmask = d_mask;
   g.bwrite = d_G;
+  g.interleave = 0;
   if (reg_path) return launch_tn_reg(ctx, g);
   return launch<2, 2, 2, 2, true, true>(ctx, g, true, true);  // 128 x 128 split-K tile, as the plain weight gradient
 }

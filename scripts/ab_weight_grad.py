@@ -1,4 +1,4 @@
-"""A/B of the weight-gradient kernels inside the layer step (sgemm_variant 0 / 30 / 31 / 32), GCN and SAGE 128->128
+"""A/B of the weight-gradient kernels inside the layer step (sgemm_variant 0 = register-resident kernels with interleaved sets, 33 = contiguous K ranges, 30 = LDS kernels, 31 = LDS kernel for the masked form only), GCN and SAGE 128->128
 on the products-shaped graph: wall time per step and the HIP-event time of the GEMM launches."""
 import sys, time, torch
 from pathlib import Path
@@ -16,7 +16,7 @@ for kind, nm in ((L.GCN, "gcn"), (L.SAGE, "sage")):
     def step():
         layer.forward(fo); layer.backward(fo, go)
     for rnd in range(2):
-        for variant in (0, 30, 32):
+        for variant in (0, 33, 30, 31):
             ctx.set_option("sgemm_variant", variant)
             for _ in range(2): step()
             torch.cuda.synchronize(); ctx.prof_reset(); ctx.prof_enable(True); t0 = time.perf_counter()

@@ -886,7 +886,7 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
     Gm = orc.d_relu(G, mask)
     want = orc.matmul(A, Gm, True, False, C0 if accum else None)
     ref64 = A.T.astype(np.float64) @ Gm.astype(np.float64) + (C0 if accum else 0)
-    for variant in (0, 32):  # 32: the register-resident split-K kernel instead of the LDS-tiled one (long K)
+    for variant in (0, 30):  # 30: the LDS-tiled kernel also where the register-resident split-K kernel would run (long K)
         ctx.set_option("sgemm_variant", variant)
         try:
             Gd, Cd = dev(G.copy()), dev(C0.copy())
@@ -924,12 +924,13 @@ def test_sgemm_streaming_kernel(ctx, x, y, z, tB, accum, relu):
         assert rel_err(got, want) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21])
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21, 30, 33])
 def test_sgemm_experimental_variants_agree(ctx, variant):
     """the tiling / double-buffer knobs (gaib_set_option sgemm_variant) change the schedule, not the result"""
     rng = np.random.default_rng(variant)
     try:
-        for (x, y, z, tA, tB) in [(1000, 128, 128, 0, 0), (777, 128, 96, 0, 1), (128, 128, 30011, 1, 0), (200, 72, 264, 0, 0)]:
+        for (x, y, z, tA, tB) in [(1000, 128, 128, 0, 0), (777, 128, 96, 0, 1), (128, 128, 30011, 1, 0), (200, 72, 264, 0, 0),
+                                  (128, 128, 40003, 1, 0), (100, 48, 33001, 1, 0)]:  # (long K: the register-resident kernel; 33 = contiguous K ranges)
             A = rng.standard_normal((z, x) if tA else (x, z)).astype(np.float32)
             B = rng.standard_normal((y, z) if tB else (z, y)).astype(np.float32)
             want = orc.matmul(A, B, bool(tA), bool(tB))
