@@ -68,6 +68,7 @@ struct gaib_ctx {
   int spmm_hot_bytes;        // L2 budget for the hot rows of gather mode 3
   int sgemm_variant;         // 0 = auto
   int gat_fast;              // reserved
+  int gat_chunk_colsum;      // GAT backward column sums by ordered chunks: -1 = dense graphs, 0 never, 1 always
   int gat_chunk_sort;        // 1 = SDDMM edge chunks ordered by column block (set before the graph's first SDDMM)
   int gat_row_waves;         // rows (= waves) per workgroup in the GAT row-owner kernels: 1, 2 or 4
   // in-stream kernel timing (gaib_prof_*)

@@ -706,6 +706,69 @@ __global__ __launch_bounds__(BLK ? ROW_BLK_WAVES * 64 : 256) void colsum_v2_kern
   if (o.tid < LPE) s.store(cs + o.row * H + hb);
 }
 
+// The same column sums over the graph's ordered 64-edge chunk list (gaib_graph_ensure_chunks): a wave takes one chunk,
+// fetches the (g, p) records of its reverse edges, writes the chunk's piece of pT and one partial sum per head; a second
+// kernel adds a row's partials in row order.  Row by row, the 8192 rows in flight each sweep the whole 7 GB record array
+// (the reverse edge of (v -> c) sits in row c's segment); chunk by chunk in column order, everything in flight points
+// into the segments of one window of rows.
+template <int H>
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(int64_t n_chunks, const uint32_t* chunk_row,
+                                                           const uint32_t* chunk_ebase, const uint32_t* chunk_start,
+                                                           const int64_t* rowptr, const uint32_t* rev, const float* gbuf,
+                                                           float* partial, float* pT) {
+  constexpr int HV = HeadSplit<H>::HV, LPE = HeadSplit<H>::LPE;
+  constexpr int EPP = 64 / LPE;  // edges per pass; a 64-edge chunk takes LPE passes
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPE, etid = lane / LPE, hb = sub * HV;
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rem = rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const int rec = (pT ? 2 : 1) * H;
+  int64_t r[LPE];
+  HeadVec<HV> g[LPE], s;
+#pragma unroll
+  for (int h = 0; h < HV; ++h) s.v[h] = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < LPE; ++ps) {
+    const int ei = ps * EPP + etid;
+    r[ps] = ei < n ? (int64_t)rev[eb + ei] : -1;
+  }
+#pragma unroll
+  for (int ps = 0; ps < LPE; ++ps) g[ps].load(gbuf + (r[ps] < 0 ? 0 : r[ps]) * rec + hb);
+#pragma unroll
+  for (int ps = 0; ps < LPE; ++ps) {
+    if (r[ps] >= 0) {
+#pragma unroll
+      for (int h = 0; h < HV; ++h) s.v[h] += g[ps].v[h];
+    }
+  }
+  if (pT) {
+#pragma unroll
+    for (int ps = 0; ps < LPE; ++ps) g[ps].load(gbuf + (r[ps] < 0 ? 0 : r[ps]) * rec + H + hb);  // same line as g
+#pragma unroll
+    for (int ps = 0; ps < LPE; ++ps)
+      if (r[ps] >= 0) g[ps].store(pT + (eb + ps * EPP + etid) * H + hb);
+  }
+#pragma unroll
+  for (int h = 0; h < HV; ++h) s.v[h] = slice_sum<LPE>(s.v[h]);
+  const int64_t slot = (int64_t)chunk_start[row] + (eb - rowptr[row]) / 64;
+  if (lane < LPE) s.store(partial + slot * H + hb);
+}
+
+// cs[v, h] = sum of row v's chunk partials, in row order
+__global__ void colsum_reduce_kernel(int64_t nv, int H, const uint32_t* chunk_start, const float* partial, float* cs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nv * H) return;
+  const int64_t v = t / H;
+  const int h = (int)(t - v * H);
+  float s = 0.f;
+  for (int64_t k = chunk_start[v]; k < chunk_start[v + 1]; ++k) s += partial[k * H + h];
+  cs[t] = s;
+}
+
 // rowdot[v,h] = <a[v, slice h], b[v, slice h]>.  One wave per row.
 __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H, const float* a,
                                                      const float* b, float* out) {
@@ -764,7 +827,7 @@ int launch_edge_softmax(gaib_ctx* ctx, gaib_graph* g, const float* sl, const flo
 template <int H>
 int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float* dp, const float* temp, float eps,
                        const float* rowdot, float* scores, float* gbuf, float* rs, float* cs, float* pT,
-                       const float* sl, const float* sr) {
+                       const float* sl, const float* sr, float* colsum_partial) {
   GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
   const uint32_t* rl = g->heavy_rows;
   const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;
@@ -788,6 +851,15 @@ int launch_softmax_bwd(gaib_ctx* ctx, gaib_graph* g, const float* p, const float
   }
 #undef GAIB_SBW_LAUNCH
   GAIB_LAUNCH_CHECK();
+  if (colsum_partial) {  // dense graphs: chunk by chunk in column order (the caller reserved the partials)
+    colsum_chunk_kernel<H><<<(unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4), 256, 0, ctx->stream>>>(
+        g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->rev, gbuf, colsum_partial, pT);
+    GAIB_LAUNCH_CHECK();
+    colsum_reduce_kernel<<<(unsigned)cdiv64(g->nv * H, 256), 256, 0, ctx->stream>>>(g->nv, H, g->chunk_start,
+                                                                                  colsum_partial, cs);
+    GAIB_LAUNCH_CHECK();
+    return GAIB_OK;
+  }
   if (nh) colsum_v2_kernel<H, true><<<nh, blk, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
   colsum_v2_kernel<H, false><<<lg, lb, 0, ctx->stream>>>(g->nv, g->rowptr, g->rev, gbuf, cs, pT, thr, rl, ro);
   GAIB_LAUNCH_CHECK();
@@ -920,7 +992,15 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };  // keep every slab 16-byte aligned
   const size_t n_g = up4((size_t)g->ne * heads * (d_norm_scores_t ? 2 : 1)), n_v = up4((size_t)g->nv * heads);
-  const size_t ws_floats = n_g + 5 * n_v + (size_t)nblocks * 2 * len;
+  // dense graphs, 1-2 heads: the column sums go chunk by chunk (reddit shape: 2.86 -> 2.67 ms single-head; at 8 heads
+  // the 64-byte records gain nothing, 7.10 vs 7.11 ms).  gat_chunk_colsum: -1 = that rule, 0 never, 1 always.
+  const bool v2_heads = heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16;
+  const bool chunk_cs = v2_heads && g->ne > 0 &&
+                        (ctx->gat_chunk_colsum == 1 ||
+                         (ctx->gat_chunk_colsum < 0 && heads <= 2 && g->ne >= 128 * g->nv));
+  if (chunk_cs) GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+  const size_t n_p = chunk_cs ? up4((size_t)g->n_chunks * heads) : 0;
+  const size_t ws_floats = n_g + 5 * n_v + n_p + (size_t)nblocks * 2 * len;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * ws_floats));
   float* gbuf = (float*)ctx->ws;
   float* rs = gbuf + n_g;
@@ -928,7 +1008,8 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   float* rowdot = cs + n_v;
   float* sl = rowdot + n_v;
   float* sr = sl + n_v;
-  float* partial = sr + n_v;
+  float* cs_partial = sr + n_v;
+  float* partial = cs_partial + n_p;
   ProfScope ps(ctx, "gat_softmax_bwd_alpha");
   if (!d_temp_scores) {
     vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_feat, d_alpha_l, d_alpha_r, sl, sr);
@@ -945,7 +1026,8 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
                       (uintptr_t)d_norm_scores_t) & 15) == 0;
   int rc = GAIB_OK;
 #define GAIB_SBW(HH) rc = launch_softmax_bwd<HH>(ctx, g, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, \
-                                                 rowdot, d_scores, gbuf, rs, cs, d_norm_scores_t, sl, sr)
+                                                 rowdot, d_scores, gbuf, rs, cs, d_norm_scores_t, sl, sr, \
+                                                 chunk_cs ? cs_partial : nullptr)
   if (heads == 1) GAIB_SBW(1);
   else if (heads == 2) GAIB_SBW(2);
   else if (heads == 4 && al16) GAIB_SBW(4);

@@ -56,6 +56,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_fast = 1;
   c->gat_row_waves = 4;
   c->gat_chunk_sort = 1;
+  c->gat_chunk_colsum = -1;
   c->prof_on = 0;
   *out = c;
   return GAIB_OK;
@@ -263,6 +264,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->sgemm_variant = (int)value;
   else if (!strcmp(key, "gat_fast"))
     ctx->gat_fast = (int)value;
+  else if (!strcmp(key, "gat_chunk_colsum"))
+    ctx->gat_chunk_colsum = (int)value;
   else if (!strcmp(key, "gat_chunk_sort"))
     ctx->gat_chunk_sort = (int)value;
   else if (!strcmp(key, "gat_row_waves")) {

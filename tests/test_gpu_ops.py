@@ -672,6 +672,38 @@ def test_spmm_relu_store(ctx, d):
     assert rel_err(got, want) < 1e-5
 
 
+@pytest.mark.parametrize("d,heads,hub", [(64, 1, 0), (64, 2, 1500), (64, 4, 0), (64, 8, 1500), (128, 16, 0)])
+def test_gat_column_sums_by_chunks(ctx, d, heads, hub):
+    """gat_chunk_colsum (what dense graphs get): the backward's column sums and the transposed attention produced
+    chunk by chunk in column order instead of row by row -- same transposed attention bit for bit, alpha gradients
+    equal up to summation order, run-to-run identical"""
+    rp, ci = random_graph(1200, 40, seed=d + heads, power_law=True, hub_deg=hub)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    n, ne = g_o.nv, g_o.ne
+    h = dev(feat(n, d, 1))
+    gin = dev(feat(n, d, 4))
+    al, ar = dev(feat(1, d, 2).ravel() * 0.2), dev(feat(1, d, 3).ravel() * 0.2)
+    t, p = torch.empty(ne, heads, device="cuda"), torch.empty(ne, heads, device="cuda")
+    ctx.gat_scores(g_d, h, al, ar, t, None, p, heads=heads)
+    out = torch.empty(n, d, device="cuda")
+    ctx.spmm(g_d, capi.W_EDGE, h, out, edge_w=p, heads=heads)
+    dp = torch.empty(ne, heads, device="cuda")
+    ctx.sddmm(g_d, gin, h, dp, heads=heads)
+    res = []
+    try:
+        for opt in (0, 1, 1):
+            ctx.set_option("gat_chunk_colsum", opt)
+            lg, rg, pt = torch.empty(d, device="cuda"), torch.empty(d, device="cuda"), torch.zeros(ne, heads, device="cuda")
+            ctx.gat_softmax_bwd_alpha(g_d, h, p, dp, t, None, lg, rg, heads=heads, grad_rows=gin, fwd_out_rows=out, norm_t=pt)
+            res.append((lg, rg, pt))
+    finally:
+        ctx.set_option("gat_chunk_colsum", -1)
+    rows, chunks, again = res
+    assert torch.equal(rows[2], chunks[2]) and torch.equal(rows[0], chunks[0])  # pT a permutation; alpha_l uses row sums
+    assert rel_err(chunks[1].cpu().numpy(), rows[1].cpu().numpy()) < 1e-5
+    assert all(torch.equal(a, b) for a, b in zip(chunks, again))
+
+
 # ---- multi-head GAT (BASELINE config 4: 8 heads; each head == the single-head oracle on its slice) ----
 @pytest.mark.parametrize("d,heads,hub", [(64, 8, 0), (64, 8, 900), (64, 8, 1700), (64, 2, 1700), (64, 4, 0), (128, 8, 0), (32, 8, 0), (256, 8, 0),
                                          (48, 3, 0), (24, 8, 0), (130, 2, 0)])
