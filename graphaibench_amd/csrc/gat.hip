@@ -992,12 +992,13 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };  // keep every slab 16-byte aligned
   const size_t n_g = up4((size_t)g->ne * heads * (d_norm_scores_t ? 2 : 1)), n_v = up4((size_t)g->nv * heads);
-  // dense graphs, 1-2 heads: the column sums go chunk by chunk (reddit shape: 2.86 -> 2.67 ms single-head; at 8 heads
+  // graphs with a quarter of their edges in heavy rows, 1-2 heads: the column sums go chunk by chunk (reddit shape: 2.86 -> 2.67 ms single-head; at 8 heads
   // the 64-byte records gain nothing, 7.10 vs 7.11 ms).  gat_chunk_colsum: -1 = that rule, 0 never, 1 always.
+  GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
   const bool v2_heads = heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16;
   const bool chunk_cs = v2_heads && g->ne > 0 &&
                         (ctx->gat_chunk_colsum == 1 ||
-                         (ctx->gat_chunk_colsum < 0 && heads <= 2 && g->ne >= 128 * g->nv));
+                         (ctx->gat_chunk_colsum < 0 && heads <= 2 && g->n_heavy > 0 && 4 * g->heavy_edges >= g->ne));
   if (chunk_cs) GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
   const size_t n_p = chunk_cs ? up4((size_t)g->n_chunks * heads) : 0;
   const size_t ws_floats = n_g + 5 * n_v + n_p + (size_t)nblocks * 2 * len;

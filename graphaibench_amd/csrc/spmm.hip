@@ -955,6 +955,16 @@ static int spmm_setup(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float
   }
 }
 
+// Where the ordered-chunk aggregation pays (scripts/ab_chunked.py, microbench_layers.py): a chunk of 64 edges of a row
+// with d edges spans 64/d of the columns, so it is L2-sized only on long rows -- on the reddit shape the rows above the
+// heavy threshold hold half of the edges and the two aggregations of a layer drop from 6.65 to 4.1 ms, on uniform random
+// graphs of the same density nothing is gained (-12 % at 256 edges per row, +5-8 % at 32-128).  Rule: a table that can
+// live in the Infinity Cache and at least a quarter of the edges in heavy rows.
+static bool chunk_rule(gaib_ctx* ctx, gaib_graph* g, int64_t ld) {
+  if (gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold) != GAIB_OK) return false;
+  return g->nc * ld * 4 <= ((int64_t)512 << 20) && 4 * g->heavy_edges >= g->ne && g->ne > 0;
+}
+
 static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                      const float* d_in, float* d_out, int flags, int heads = 1) {
   GAIB_CHECK(ctx && g, "gaib_spmm: NULL ctx/graph");
@@ -970,7 +980,7 @@ static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float*
   // dense graphs over a table that fits the Infinity Cache: ordered chunks (see spmm_chunk_kernel)
   const bool chunk_shape = len % 4 == 0 && len <= 256 && a.ld % 4 == 0 && a.ldo % 4 == 0 && g->ne > 0 &&
                            ((((uintptr_t)a.in | (uintptr_t)a.out) & 15) == 0) && (wmode < 3 || a.dh % 4 == 0);
-  const bool chunk_auto = g->ne >= 128 * g->nv && g->nc * a.ld * 4 <= ((int64_t)512 << 20);
+  const bool chunk_auto = ctx->spmm_chunked < 0 && chunk_rule(ctx, g, a.ld);
   if (chunk_shape && (ctx->spmm_chunked == 1 || (ctx->spmm_chunked < 0 && chunk_auto))) {
     switch (wmode) {
       case 0: return launch_chunked<0>(ctx, g, a);
@@ -1028,8 +1038,8 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   const bool lanes_ok = len_in <= 64 ? true : (len_in % 2 == 0 && (al & 7) == 0);
   // dense graphs over a cache-sized table aggregate faster by ordered chunks (spmm_chunk_kernel) than row by row
   // inside the fused kernel: two kernels there
-  const bool dense = ctx->spmm_chunked != 0 && len_in % 4 == 0 && g->ne >= 128 * g->nv &&
-                     g->nc * (int64_t)len_in * 4 <= ((int64_t)512 << 20) && (al & 15) == 0;
+  const bool dense = ctx->spmm_chunked != 0 && len_in % 4 == 0 && (al & 15) == 0 &&
+                     (ctx->spmm_chunked == 1 || chunk_rule(ctx, g, len_in));
   const bool fusable = ctx->spmm_fuse != 0 && !dense && len_in >= 1 && len_in <= 128 && lanes_ok &&
                        fuse_strip_rows(kpad, len_out, dual) != 0 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
