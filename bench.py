@@ -11,9 +11,12 @@ inputs resident in HBM when the timed region starts.
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One JSON line on rank 0.  `roofline` prices the dominant kernel (the one-wave-per-row SpMM,
-spmm_w64_kernel) by ALGORITHMIC bytes per launch / mean launch time measured with HIP events in
-the timed region; `cpu_baseline` times the oracle's restatement of the OpenMP path on the host.
+One JSON line on rank 0.  `roofline` prices the dominant kernel (spmm_gemm_kernel: the one-wave-per-row
+aggregation with the dense product riding on it) by ALGORITHMIC bytes per launch / mean launch time measured
+with HIP events in the timed region, next to the stream-copy rate measured in the same run; `cpu_baseline` times
+the oracle's restatement of the OpenMP path on the host on the SAME graph and inputs, and `parity` compares the
+GPU layer's forward output, input gradient and weight gradient with that run element by element (exit code 3
+above 1e-4); `sustained_ms_per_step` is the same step kept up for >= 5 s after the timed region.
 """
 from __future__ import annotations
 
@@ -21,6 +24,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -55,9 +59,24 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
-    """The oracle (port of the reference's OpenMP GCN layer, oracle/gnn_oracle.c) timed on the host
-    cores on a bounded row-prefix sample of the SAME graph: rows [0, R) forward + backward."""
+def host_inputs(nv: int):
+    """the layer's inputs, generated ONCE on the host (seed 43) and fed to BOTH legs: the GPU layer and
+    the CPU oracle see the same X and the same incoming gradient, so their outputs are comparable element-wise."""
+    import numpy as np
+
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((nv, D), dtype=np.float32)
+    gin = rng.standard_normal((nv, D), dtype=np.float32)
+    return x, gin
+
+
+def cpu_baseline(sg_rowptr, sg_colidx, nv, x, gin, budget_s=30.0, want_outputs=True):
+    """The oracle (port of the reference's OpenMP GCN layer, oracle/gnn_oracle.c) on the host cores, on the SAME
+    graph and the SAME inputs as the GPU leg.  Returns (cpu_baseline record, outputs of the full-graph run or None).
+    The full graph is run whenever parity is wanted; its time is the baseline when it fits the budget, otherwise a
+    bounded row-prefix sample [0, R) is timed."""
+    import ctypes as C
+
     import numpy as np
     from oracle import binding as orc
 
@@ -67,51 +86,86 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, budget_s=15.0):
     ci = sg_colidx.cpu().numpy().view(np.uint32)
     g_full = orc.Graph(rp, ci).add_selfloop()  # net.cpp:96
     vd = g_full.vertex_data()
-    rng = np.random.default_rng(43)
     W = orc.init_glorot(D, D, 1)
-
     libs = {"lib": orc.lib()}
+    p = orc._p
+    # scratch of the layer (graph_conv_layer.cpp:10-36), allocated once outside the timed region like the ctor does
+    in_temp = np.zeros((nv, D), np.float32)
+    in_temp1 = np.zeros((nv, D), np.float32)
+    out_temp = np.zeros((nv, D), np.float32)
 
-    def run(R):
+    def run(R, keep=False):
         g = orc.Graph.__new__(orc.Graph)
         g.rowptr, g.colidx, g.nv, g.ne, g.vd = g_full.rowptr[:R + 1], g_full.colidx, R, int(g_full.rowptr[R]), vd
-        layer = orc.GCNLayer(1, g, D, D, True, W=W)
-        # feature tables keep ALL rows: the aggregation gathers any column
-        x = rng.standard_normal((nv, D), dtype=np.float32)
-        layer.in_temp = np.zeros((nv, D), np.float32)
-        gin = rng.standard_normal((R, D), dtype=np.float32)
-        t0 = time.perf_counter()
-        import ctypes as C
         s = g._struct()
         out = np.empty((R, D), np.float32)
-        lib = libs["lib"]
-        p = orc._p
-        lib.orc_gcn_layer_forward(C.byref(s), C.c_int(D), C.c_int(D), C.c_int(1), p(x), p(W), p(layer.in_temp1[:R]),
-                                  p(layer.out_temp[:R]), p(out))
         grad_out = np.zeros((R, D), np.float32)
+        W_grad = np.zeros((D, D), np.float32)
+        g_in = gin[:R].copy()  # backward applies d_relu to it in place (Q9)
+        lib = libs["lib"]
+        t0 = time.perf_counter()
+        # feature tables keep ALL rows: the aggregation gathers any column
+        lib.orc_gcn_layer_forward(C.byref(s), C.c_int(D), C.c_int(D), C.c_int(1), p(x), p(W), p(in_temp1[:R]),
+                                  p(out_temp[:R]), p(out))
         lib.orc_gcn_layer_backward(C.byref(s), C.c_int(1), C.c_int(D), C.c_int(D), C.c_int(1), p(x), p(W), p(out),
-                                   p(gin), p(layer.in_temp), p(layer.in_temp1[:R]), p(layer.out_temp[:R]),
-                                   p(grad_out), p(layer.W_grad))
-        return time.perf_counter() - t0, 2 * g.ne
+                                   p(g_in), p(in_temp), p(in_temp1[:R]), p(out_temp[:R]), p(grad_out), p(W_grad))
+        t = time.perf_counter() - t0
+        return t, 2 * g.ne, (dict(forward=out, grad_out=grad_out, W_grad=W_grad, agg_x=in_temp1[:R].copy(),
+                                  masked_grad=g_in) if keep else None)
 
     probe_R = max(nv // 64, 1024)
     run(min(probe_R, nv))  # thread spin-up: the first pass is ~2x slower
-    t_probe, e_probe = run(min(probe_R, nv))
+    t_probe, e_probe, _ = run(min(probe_R, nv))
     rate = e_probe / max(t_probe, 1e-9)
     total_edges = 2 * g_full.ne
-    R = nv if total_edges / rate <= budget_s else max(int(nv * budget_s * rate / total_edges), probe_R)
-    R = min(R, nv)
-    t, e = run(R)
+    fits = total_edges / rate <= budget_s
+    outputs = None
+    if want_outputs or fits:
+        t, e, outputs = run(nv, keep=want_outputs)
+        R = nv
+    if not fits:
+        R = min(max(int(nv * budget_s * rate / total_edges), probe_R), nv)
+        t, e, _ = run(R)
     res = dict(value=e / t, unit="edges/s", cores=cores, kind="port",
-               sample=f"rows [0,{R}) of the same graph ({e // 2} edges incl. self loops), 1 layer fwd+bwd, "
-                      f"{t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
+               sample=f"rows [0,{R}) of the same graph ({e // 2} edges incl. self loops), 1 layer fwd+bwd on the GPU "
+                      f"leg's inputs, {t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
     nat = orc.native_lib()  # second figure with -march=native built on this host, same sample
     if nat is not None:
         libs["lib"] = nat
         run(min(probe_R, nv))
-        tn, en = run(R)
+        tn, en, _ = run(R)
         res["value_march_native"] = en / tn
-    return res
+    return res, outputs
+
+
+def parity_record(torch, got: dict, want: dict, tol=1e-4, floor=1e-6):
+    """element-wise parity of the GPU layer against the oracle's full-graph run on the same inputs.
+    Per tensor: `elem` = max_i |a_i-b_i| / (|b_i| + (floor/tol) max|b|)  (<= tol  <=>  |a-b| <= tol|b| + floor max|b|
+    everywhere) and `inf` = max|a-b| / max|b|.  Computed on the device in fp64, chunked."""
+    rec = {"tol": tol, "floor_frac_of_max": floor}
+    ok = True
+    for k in ("forward", "grad_out", "W_grad"):
+        a = got[k].reshape(-1)
+        b = torch.from_numpy(want[k]).cuda().reshape(-1)
+        scale = max(b.abs().max().item(), 1e-30)
+        elem = inf = 0.0
+        step = 1 << 26
+        for i in range(0, a.numel(), step):
+            d = (a[i:i + step].double() - b[i:i + step].double()).abs()
+            inf = max(inf, d.max().item() / scale)
+            elem = max(elem, (d / (b[i:i + step].double().abs() + (floor / tol) * scale)).max().item())
+        rec[k] = {"elem": elem, "inf": inf}
+        ok = ok and elem <= tol and inf <= tol
+        del b
+    # the weight gradient is a sum over 2.4 M vertices in fp32 on both sides; where the truth lies: fp64 on the device
+    ax = torch.from_numpy(want["agg_x"]).cuda().double()
+    mg = torch.from_numpy(want["masked_grad"]).cuda().double()
+    w64 = ax.t() @ mg
+    sc = w64.abs().max().item()
+    rec["W_grad_vs_fp64_inf"] = {"gpu": ((got["W_grad"].double() - w64).abs().max().item() / sc),
+                                 "oracle": ((torch.from_numpy(want["W_grad"]).cuda().double() - w64).abs().max().item() / sc)}
+    rec["ok"] = bool(ok)
+    return rec
 
 
 def emit(result: dict) -> None:
@@ -130,6 +184,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the element-wise comparison with the oracle's run")
+    ap.add_argument("--sustain-s", type=float, default=5.0,
+                    help="after the timed steps, run the same step for this many seconds (0 = skip)")
     ap.add_argument("--cut-fraction", type=float, default=None,
                     help="N>1: fraction of each partition's edges that cross partitions")
     args = ap.parse_args()
@@ -179,11 +236,18 @@ def main():
     log(f"[bench] products-shaped graph: nv={nv} ne={ne} (incl. self loops) max_deg={stats['max_degree']} "
         f"heavy rows={stats['n_heavy']} holding {stats['heavy_edges']} edges; gen+upload {time.time()-t0:.1f}s")
     lg = L.LGraph.adopt(g1)
-    gview = lg.device_graph()
-    torch.manual_seed(43)
+    want_parity = not (args.no_cpu_baseline or args.no_parity)
     layer = L.Layer(L.GCN, 1, nv, D, D, lg, act=True, lr=0.01)
-    layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda"))
-    layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda"))
+    if want_parity:
+        x_h, gin_h = host_inputs(nv)  # one set of inputs for both legs (element-wise parity below)
+        x_d, gin_d = torch.from_numpy(x_h).cuda(), torch.from_numpy(gin_h).cuda()
+    else:
+        torch.manual_seed(43)
+        x_h = gin_h = None
+        x_d, gin_d = torch.randn(nv, D, device="cuda"), torch.randn(nv, D, device="cuda")
+    layer.write(L.FEAT_IN, x_d)
+    layer.write(L.GRAD_IN, gin_d)
+    del x_d, gin_d
     feat_out = torch.empty(nv, D, device="cuda")
     grad_out = torch.empty(nv, D, device="cuda")
 
@@ -208,6 +272,28 @@ def main():
     n_gemm, ms_gemm = ctx.prof_get("sgemm")
     n_fused, ms_fused = ctx.prof_get("spmm_gemm_fused")
     ctx.prof_reset()
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # sustained leg (not the reported value): the same step for >= --sustain-s seconds, to show the timed figure
+    # survives seconds of load (clocks / power); the clocks are sampled mid-run by a child process
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(int(args.sustain_s * 1e3 / ms_per_step) + 1, args.steps)
+        clocks = {}
+        th = threading.Thread(target=_sample_clocks, args=(clocks, min(2.0, args.sustain_s / 2)), daemon=True)
+        th.start()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        t_sus = time.perf_counter() - t1
+        th.join(timeout=20)
+        sustained = {"steps": n_sus, "seconds": t_sus, "ms_per_step": t_sus / n_sus * 1e3,
+                     "vs_timed": (t_sus / n_sus * 1e3) / ms_per_step, "clocks_mid_run": clocks or None}
+
+    # the chip's achievable streaming rate, measured in this run: 1 GiB float4 copy, read + written bytes
+    peak_measured = ctx.probe_stream_copy(1 << 30, 20) if args.scale >= 0.05 else None
 
     edges_per_step = 2 * ne
     value = edges_per_step * args.steps / elapsed
@@ -230,13 +316,19 @@ def main():
         n_dom, ms_dom = n_light, ms_light
     avg_ms = ms_dom / max(n_dom, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    # `traffic`: PMC counters need their own rocprofv3 passes (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE
+    # separately, gfx950 half-count correction), so the per-launch figure comes from the committed summary of the
+    # same command at the commit named inside it -- not measurable inside this process
+    traffic = traffic_src = None
     tf = ROOT / "profiles" / "hbm_traffic.json"
     if tf.exists() and args.scale == 1.0:
         try:
-            traffic = json.loads(tf.read_text()).get(traffic_key)
+            tj = json.loads(tf.read_text())
+            traffic = tj.get(traffic_key)
+            traffic_src = f"profiles/hbm_traffic.json (rocprofv3 --pmc passes at commit {tj.get('commit', '?')})"
         except Exception:
             traffic = None
+    b_min = 2 * nv * 4 * D + 4 * ne
     result = {
         "metric": "GCN-layer fwd+bwd aggregated edges/sec",
         "value": value,
@@ -244,7 +336,7 @@ def main():
         "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -258,13 +350,21 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel_name,
+            # achieved = ALGORITHMIC bytes / launch time: every gathered row counted as if it came from HBM.  Part of
+            # the gathers hit the 256 MB Infinity Cache, so this can exceed what HBM alone delivers (see
+            # peak_measured / frac_of_measured): it is a work rate in bytes, not a physical HBM rate.
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
+            "peak_measured": peak_measured,  # stream copy in this run, read + written bytes per second
+            "frac_of_measured": (achieved / peak_measured) if peak_measured else None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_dom,
-            # SURVEY 8d extras: perfect-reuse lower bound of one aggregation (every feature row read once) and the
-            # PMC-measured bytes as a fraction of the peak over the same launch time
-            "b_min_bytes_per_launch": 2 * nv * 4 * D + 4 * ne,
-            "hbm_measured_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            # perfect-reuse lower bound of one aggregation (every feature row read once) and how far the
+            # measured L2->fabric traffic is above it (no reuse of gathered rows in a 4 MB L2 on a random vertex order)
+            "b_min_bytes_per_launch": b_min,
+            "traffic_over_b_min": (traffic / b_min) if traffic else None,
+            # FETCH_SIZE x2 + WRITE_SIZE per launch time over the spec peak: L2 -> fabric bytes, Infinity-Cache hits
+            # INCLUDED (MI355X_MICROARCH.md), i.e. an upper bound on the HBM share, not an HBM measurement
+            "fabric_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         },
         # the aggregation kernels alone (both SpMM launches of the step incl. heavy rows; the dense products that
         # ride on them are inside): aggregated edges per second of kernel time
@@ -274,11 +374,43 @@ def main():
             "spmm_heavy": ms_heavy / args.steps, "sgemm": ms_gemm / args.steps,
         },
     }
+    if sustained:
+        result["sustained_ms_per_step"] = sustained["ms_per_step"]
+        result["sustained"] = sustained
+    rc = 0
     if not args.no_cpu_baseline:
         t1 = time.time()
-        result["cpu_baseline"] = cpu_baseline(sg.rowptr, sg.colidx, sg.nv)
+        xs = (x_h, gin_h) if want_parity else host_inputs(nv)
+        result["cpu_baseline"], want = cpu_baseline(sg.rowptr, sg.colidx, nv, *xs, want_outputs=want_parity)
         log(f"[bench] cpu baseline took {time.time()-t1:.1f}s")
+        if want_parity:
+            got = {"forward": feat_out, "grad_out": grad_out, "W_grad": layer.tensor(L.W_NEIGH_GRAD, (D, D))}
+            result["parity"] = parity_record(torch, got, want)
+            log(f"[bench] parity vs the oracle's full-graph run: {result['parity']}")
+            if not result["parity"]["ok"]:
+                log("[bench] PARITY FAILED (> 1e-4)")
+                rc = 3
     emit(result)
+    if rc:
+        sys.exit(rc)
+
+
+def _sample_clocks(out: dict, delay_s: float) -> None:
+    """rocm-smi in a CHILD process (never an exec of this one) a moment into the sustained leg"""
+    import subprocess
+
+    time.sleep(delay_s)
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--json"], capture_output=True,
+                           text=True, timeout=15)
+        j = json.loads(r.stdout)
+        card = next(iter(j.values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl or "mclk" in kl or "power" in kl:
+                out[k] = v
+    except Exception as e:  # measurement garnish only
+        out["error"] = str(e)[:80]
 
 
 if __name__ == "__main__":

@@ -89,11 +89,20 @@ SIGNATURES = {
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "gaib_probe_stream_copy": (_i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
+    "gaib_probe_peer_copy": (_i, [_i, _i, C.c_size_t, _i, _i, C.POINTER(C.c_double)]),
 }
 
 
 class GaibError(RuntimeError):
     pass
+
+
+def probe_peer_copy(src_dev: int, dst_dev: int, nbytes: int = 1 << 28, iters: int = 10, bidir: bool = False) -> float:
+    """GB/s per direction of hipMemcpyPeerAsync between two visible devices (the xGMI link probe)"""
+    v = C.c_double(0.0)
+    _check(load().gaib_probe_peer_copy(src_dev, dst_dev, nbytes, iters, int(bidir), C.byref(v)), "gaib_probe_peer_copy")
+    return v.value
 
 
 _lib = None
@@ -184,6 +193,12 @@ class Context:
         n, ms = _i64(), C.c_double()
         _check(self.lib.gaib_prof_get(self.h, key.encode(), C.byref(n), C.byref(ms)), "gaib_prof_get")
         return n.value, ms.value
+
+    def probe_stream_copy(self, nbytes: int = 1 << 30, iters: int = 20) -> float:
+        """GB/s (read + written bytes) of a 16-B-per-lane copy kernel on this context's stream"""
+        v = C.c_double(0.0)
+        _check(load().gaib_probe_stream_copy(self.h, nbytes, iters, C.byref(v)), "gaib_probe_stream_copy")
+        return v.value
 
     def graph_stats(self, g: "Graph"):
         a, b, c = _i64(), _i64(), _i64()

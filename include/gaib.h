@@ -304,6 +304,18 @@ int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_to
 int gaib_graph_stats(gaib_ctx* ctx, gaib_graph* g, int64_t* h_n_heavy, int64_t* h_heavy_edges,
                      int64_t* h_max_degree);
 
+/* ---- bandwidth probes (measurement only) -------------------------------------------------------
+ * gaib_probe_stream_copy: a 16-B-per-lane copy kernel of `bytes` bytes (rounded down to 16), `iters` launches
+ *   on the context's stream between one HIP event pair; *h_gbs = (bytes read + bytes written) * iters / time.
+ *   This is the chip's achievable streaming rate that bench.py reports next to the 8 TB/s spec figure
+ *   (SURVEY.md 8d "confirm with a stream-copy kernel").
+ * gaib_probe_peer_copy: hipMemcpyPeerAsync of `bytes` from device src_dev to device dst_dev, `iters` copies
+ *   (and as many in the opposite direction at the same time on a second stream when bidir != 0);
+ *   *h_gbs = bytes moved per direction * iters / time.  The xGMI link probe
+ *   (template: /root/reference/src/test/test_nvlink.cu:37-77).  Needs two visible devices. */
+int gaib_probe_stream_copy(gaib_ctx* ctx, size_t bytes, int iters, double* h_gbs);
+int gaib_probe_peer_copy(int src_dev, int dst_dev, size_t bytes, int iters, int bidir, double* h_gbs);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ---- */
 int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value);
 

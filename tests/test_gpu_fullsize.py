@@ -1,6 +1,12 @@
 """GPU suite at BASELINE.json's FULL sizes (ogbn-products-shaped graph: 2.45 M vertices, 126 M
-edges, D = 128; reddit-shaped graph for GAT), where the oracle would take minutes: size-independent
-properties of the operators instead of element-wise comparison.
+edges, D = 128; reddit-shaped graph for GAT).
+
+Element-wise against the oracle at full size (the oracle's OpenMP loops take seconds per layer on the host cores):
+  * SAGE_layer 128 -> 128 forward + backward on the products shape (BASELINE config 3)
+  * GAT_layer 64 -> 64 with 8 heads forward + backward on the reddit shape (config 4; oracle head by head)
+  * GCN_layer 128 -> 128 is compared the same way inside bench.py (`parity`), on the bench graph
+
+and size-independent properties of the operators:
 
   * eigenvector of the normalised adjacency:  A_hat (D^1/2 1) = D^1/2 1   (with self loops)
   * mean aggregation of a constant is that constant; transpose-mean preserves column sums
@@ -13,7 +19,9 @@ import numpy as np
 import pytest
 import torch
 
-from graphaibench_amd import capi, synth
+from graphaibench_amd import capi, layers as L, synth
+from oracle import binding as orc
+from util import assert_close_dev
 
 pytestmark = pytest.mark.gpu
 D = 128
@@ -191,3 +199,88 @@ def test_gat_properties_reddit_size(ctx):
     out = torch.empty_like(const)
     ctx.spmm(g, capi.W_EDGE, const, out, edge_w=p, heads=H)
     assert (out - const).abs().max().item() < 1e-4
+
+
+# ---- element-wise against the oracle at full size ---------------------------------------------------------------
+def _host_feat(n, d, seed):
+    return np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32)
+
+
+def test_sage_layer_products_vs_oracle(products):
+    """SAGE_layer 128 -> 128 (hidden layer of BASELINE config 3) forward + backward on the products-shaped graph,
+    every output tensor element-wise against the oracle's layer (sage_layer.cpp:5-53) on the same inputs."""
+    lctx = L.init(0)
+    nv = products["nv"]
+    rp = products["rowptr"].cpu().numpy()
+    ci = products["colidx"].cpu().numpy().view(np.uint32)
+    orc.set_threads(len(__import__("os").sched_getaffinity(0)))
+    g_o = orc.Graph(rp, ci)
+    lg = L.LGraph.adopt(lctx.graph(products["rowptr"], products["colidx"]))  # its own copy: adopt takes ownership
+    x, gin = _host_feat(nv, D, 43), _host_feat(nv, D, 44)
+    lo = orc.SAGELayer(1, g_o, D, D, True)
+    ld = L.Layer(L.SAGE, 1, nv, D, D, lg, True)
+    ld.write(L.FEAT_IN, torch.from_numpy(x).cuda())
+    out = torch.empty(nv, D, device="cuda")
+    ld.forward(out)
+    assert_close_dev(out, lo.forward(x), "forward")
+    ld.write(L.GRAD_IN, torch.from_numpy(gin).cuda())
+    grad_out = torch.zeros(nv, D, device="cuda")
+    ld.backward(out, grad_out)
+    want_go = lo.backward(gin)  # gin is masked in place (Q9)
+    assert_close_dev(grad_out, want_go, "grad_out")
+    assert_close_dev(ld.tensor(L.GRAD_IN, (nv, D)), gin, "masked grad_in")
+    assert_close_dev(ld.tensor(L.W_NEIGH_GRAD, (D, D)), lo.W_neigh_grad, "W_neigh_grad")
+    assert_close_dev(ld.tensor(L.W_SELF_GRAD, (D, D)), lo.W_self_grad, "W_self_grad")
+
+
+def test_gat_layer_8_heads_reddit_vs_oracle():
+    """GAT_layer 64 -> 64 with 8 heads (BASELINE config 4: hidden 64 = 8 x 8) forward + backward on the reddit-shaped
+    graph (112 M edges) against 8 single-head oracles on the column slices (gat_aggregator.cpp:57-200, the
+    `fast` d_softmax branch = the reference's AVX-512 form; the O(deg^2) fallback is the same function)."""
+    L.init(0)
+    sg = synth.make("reddit", seed=7, device="cuda")
+    rp = sg.rowptr.cpu().numpy()
+    ci = sg.colidx.cpu().numpy().view(np.uint32)
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
+    orc.set_threads(len(__import__("os").sched_getaffinity(0)))
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    del sg
+    n, ne, d, H = g_o.nv, g_o.ne, 64, 8
+    dh = d // H
+    x, gin = _host_feat(n, d, 3), _host_feat(n, d, 4)
+    ld = L.Layer(L.GAT, 1, n, d, d, g_d, True)
+    ld.set_heads(H)
+    W = orc.init_glorot(d, d, 1)
+    al, ar = orc.init_glorot(d, 1, 2).ravel(), orc.init_glorot(d, 1, 3).ravel()
+    ld.write(L.FEAT_IN, torch.from_numpy(x).cuda())
+    out = torch.empty(n, d, device="cuda")
+    ld.forward(out)
+    norm_d = ld.tensor(L.NORM_SCORES, (ne, H))
+    hfeat = orc.matmul(x, W)
+    agg = np.empty((n, d), np.float32)
+    temps, norms = [], []
+    for k in range(H):  # head by head: one head's edge arrays (0.45 GB each) at a time on the host
+        sl = slice(k * dh, (k + 1) * dh)
+        o, t, _, p = orc.gat_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(al[sl]),
+                                       np.ascontiguousarray(ar[sl]))
+        agg[:, sl] = o
+        assert_close_dev(norm_d[:, k].contiguous(), p, f"attention of head {k}")
+        temps.append(t)
+        norms.append(p)
+    want = orc.relu(agg)
+    assert_close_dev(out, want, "forward")
+    ld.write(L.GRAD_IN, torch.from_numpy(gin).cuda())
+    grad_out = torch.zeros(n, d, device="cuda")
+    ld.backward(out, grad_out)
+    g_act = orc.d_relu(gin, want)
+    T = np.empty((n, d), np.float32)
+    lg_w, rg_w = np.empty(d, np.float32), np.empty(d, np.float32)
+    for k in range(H):
+        sl = slice(k * dh, (k + 1) * dh)
+        go, _, _, l_, r_ = orc.gat_d_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(g_act[:, sl]),
+                                               norms[k], temps[k], fast=True)
+        T[:, sl], lg_w[sl], rg_w[sl] = go, l_, r_
+    assert_close_dev(grad_out, orc.matmul(T, W, False, True), "grad_out")
+    assert_close_dev(ld.tensor(L.W_NEIGH_GRAD, (d, d)), orc.matmul(x, T, True, False), "W_grad")
+    assert_close_dev(ld.tensor(L.ALPHA_LGRAD, (d,)), lg_w, "alpha_l grad")
+    assert_close_dev(ld.tensor(L.ALPHA_RGRAD, (d,)), rg_w, "alpha_r grad")

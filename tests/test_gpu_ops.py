@@ -14,7 +14,7 @@ import torch
 
 from graphaibench_amd import capi
 from oracle import binding as orc
-from util import random_graph, rel_err
+from util import assert_close, random_graph, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4  # BASELINE.json north_star: "outputs within 1e-4 rel-err of the OpenMP path"
@@ -94,7 +94,7 @@ def test_spmm_gcn_bit_exact_light_rows(ctx, d):
     deg = np.diff(g_o.rowptr)
     light = deg <= 1024
     assert np.array_equal(got[light].view(np.uint32), want[light].view(np.uint32)), "CSR-order rows must be bit-exact"
-    assert rel_err(got, want) < TOL
+    assert_close(got, want)
 
 
 @pytest.mark.parametrize("kind", ["mean", "mean_t", "edge", "edge_t"])
@@ -160,7 +160,7 @@ def test_spmm_restrided_input_table(ctx, d):
     padded = run()
     for a, b in zip(direct, padded):
         assert torch.equal(a, b)
-    assert rel_err(padded[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy())) < TOL
+    assert_close(padded[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy()))
 
 
 @pytest.mark.parametrize("d", [4, 16, 44, 64, 100, 128, 256])
@@ -204,7 +204,7 @@ def test_spmm_chunked_dense_graph_path(ctx, d):
     for a, b, c in zip(rows, chunks, chunks_again):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
         assert torch.equal(b, c)  # fixed summation order: run-to-run identical
-    assert rel_err(chunks[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy())) < TOL
+    assert_close(chunks[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy()))
 
 
 @pytest.mark.parametrize("d", [16, 100, 128, 512])
@@ -396,7 +396,7 @@ def test_sgemm(ctx, x, y, z, tA, tB, accum):
     ctx.sgemm(dev(A), dev(B), Cd, bool(tA), bool(tB), bool(accum))
     got = Cd.cpu().numpy()
     ref64 = (A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64) + (C0 if accum else 0)
-    assert rel_err(got, want) < TOL
+    assert_close(got, want)
     assert rel_err(got, ref64) < 2e-5  # fp32 MFMA is an exact-fp32 fma chain
 
 
@@ -460,12 +460,12 @@ def test_gat_forward_pieces(ctx, d, hub):
     p = torch.empty_like(t)
     hd = dev(h)
     ctx.gat_scores(g_d, hd, dev(al), dev(ar), t, s, p)
-    assert rel_err(t.cpu().numpy(), want_t) < TOL
-    assert rel_err(s.cpu().numpy(), want_s) < TOL
-    assert rel_err(p.cpu().numpy(), want_n) < TOL
+    assert_close(t.cpu().numpy(), want_t)
+    assert_close(s.cpu().numpy(), want_s)
+    assert_close(p.cpu().numpy(), want_n)
     out = torch.empty(g_o.nv, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE, hd, out, edge_w=p)
-    assert rel_err(out.cpu().numpy(), want_out) < TOL
+    assert_close(out.cpu().numpy(), want_out)
     # the leaky-relu output is optional
     t2 = torch.empty_like(t)
     p2 = torch.empty_like(t)
@@ -491,14 +491,14 @@ def test_gat_backward_pieces(ctx, d, hub):
     hd, gd = dev(h), dev(gin)
     ng = torch.empty(g_o.ne, device="cuda")
     ctx.sddmm(g_d, gd, hd, ng)
-    assert rel_err(ng.cpu().numpy(), want_ng) < TOL
+    assert_close(ng.cpu().numpy(), want_ng)
     sc = torch.empty(g_o.ne, device="cuda")
     lg = torch.empty(d, device="cuda")
     rg = torch.empty(d, device="cuda")
     ctx.gat_softmax_bwd_alpha(g_d, hd, dev(norm), dev(want_ng), dev(temp), sc, lg, rg)
-    assert rel_err(sc.cpu().numpy(), want_ds) < TOL
-    assert rel_err(lg.cpu().numpy(), want_lg) < TOL
-    assert rel_err(rg.cpu().numpy(), want_rg) < TOL
+    assert_close(sc.cpu().numpy(), want_ds)
+    assert_close(lg.cpu().numpy(), want_lg)
+    assert_close(rg.cpu().numpy(), want_rg)
     # one-pass form: the row's sum_e p dp taken per vertex as <grad_i, out_i>; ds optional
     for keep_ds in (True, False):
         sc2 = torch.zeros(g_o.ne, device="cuda")
@@ -509,9 +509,9 @@ def test_gat_backward_pieces(ctx, d, hub):
                                   grad_rows=gd, fwd_out_rows=dev(out_w), norm_t=pt2)
         assert np.array_equal(pt2.cpu().numpy(), orc.symmetric_csr_transpose(g_o, norm))  # a permutation: exact
         if keep_ds:
-            assert rel_err(sc2.cpu().numpy(), want_ds) < TOL
-        assert rel_err(lg2.cpu().numpy(), want_lg) < TOL
-        assert rel_err(rg2.cpu().numpy(), want_rg) < TOL
+            assert_close(sc2.cpu().numpy(), want_ds)
+        assert_close(lg2.cpu().numpy(), want_lg)
+        assert_close(rg2.cpu().numpy(), want_rg)
     # the form without the temp array (the sign of a_l.h[i] + a_r.h[col] formed again): same bits as with the temp
     # array the forward kernel wrote
     t_gpu = torch.empty(g_o.ne, device="cuda")
@@ -525,14 +525,14 @@ def test_gat_backward_pieces(ctx, d, hub):
         res.append((sc3, lg3, rg3, pt3))
     for a, b in zip(*res):
         assert torch.equal(a, b)
-    assert rel_err(res[1][1].cpu().numpy(), want_lg) < TOL and rel_err(res[1][2].cpu().numpy(), want_rg) < TOL
+    assert_close(res[1][1].cpu().numpy(), want_lg) < TOL and rel_err(res[1][2].cpu().numpy(), want_rg)
     # explicit transpose == oracle's symmetric_csr_transpose (a permutation: bit-exact)
     pt = torch.empty(g_o.ne, device="cuda")
     ctx.edge_transpose(g_d, dev(norm), pt)
     assert np.array_equal(pt.cpu().numpy(), orc.symmetric_csr_transpose(g_o, norm))
     out = torch.empty(g_o.nv, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE_T, gd, out, edge_w=dev(norm))
-    assert rel_err(out.cpu().numpy(), want_go) < TOL
+    assert_close(out.cpu().numpy(), want_go)
 
 
 def test_edge_transpose_rejects_asymmetric(ctx):
@@ -556,11 +556,11 @@ def test_softmax_xent_and_metrics(ctx, ncls):
     probs = torch.zeros(n, ncls, device="cuda")
     loss = torch.zeros(n, device="cuda")
     ctx.softmax_xent(ld, lab, loss, probs, begin, end, md)
-    assert rel_err(probs.cpu().numpy(), probs_w) < TOL
-    assert rel_err(loss.cpu().numpy(), loss_w) < TOL
+    assert_close(probs.cpu().numpy(), probs_w)
+    assert_close(loss.cpu().numpy(), loss_w)
     grad = torch.zeros(n, ncls, device="cuda")
     ctx.d_softmax_xent(probs, lab, grad, begin, end, md)
-    assert rel_err(grad.cpu().numpy(), grad_w) < TOL
+    assert_close(grad.cpu().numpy(), grad_w)
     assert abs(ctx.masked_avg_loss(loss, begin, end, md) - orc.masked_avg_loss(loss_w, begin, end, masks)) < 1e-4
     acc_w = orc.masked_accuracy_single(logits, labels, begin, end, masks)
     assert abs(ctx.masked_accuracy_single(ld, lab, begin, end, md) - acc_w) < 1e-6
@@ -582,13 +582,13 @@ def test_sigmoid_xent_and_micro_f1(ctx, ncls):
         probs = torch.zeros(n, ncls, device="cuda")
         loss = torch.full((n,), 7.0, device="cuda")
         ctx.sigmoid_xent(ld, lab, loss, probs, begin, end, md)
-        assert rel_err(probs.cpu().numpy(), probs_w) < TOL
+        assert_close(probs.cpu().numpy(), probs_w)
         got_loss = loss.cpu().numpy()
-        assert rel_err(got_loss[begin:end], loss_w[begin:end]) < TOL  # masked-out rows of the range read 0
+        assert_close(got_loss[begin:end], loss_w[begin:end])  # masked-out rows of the range read 0
         assert np.all(got_loss[:begin] == 7.0) and np.all(got_loss[end:] == 7.0)
         grad = torch.zeros(n, ncls, device="cuda")
         ctx.d_sigmoid_xent(probs, lab, grad, begin, end, md)
-        assert rel_err(grad.cpu().numpy(), grad_w) < TOL
+        assert_close(grad.cpu().numpy(), grad_w)
         f1_w, cnt_w = orc.masked_f1_micro(probs.cpu().numpy(), labels, begin, end, mk, return_counts=True)
         f1, cnt = ctx.masked_f1_micro(probs, lab, begin, end, md)
         assert cnt == tuple(int(c) for c in cnt_w)  # integer counts: exact
@@ -604,10 +604,10 @@ def test_l2norm(ctx):
     g = feat(500, 64, 2)
     out = torch.empty(500, 64, device="cuda")
     ctx.l2norm(dev(x), out)
-    assert rel_err(out.cpu().numpy(), orc.l2norm(x)) < TOL
+    assert_close(out.cpu().numpy(), orc.l2norm(x))
     ctx.d_l2norm(dev(x), dev(g), out)
     keep = np.arange(500) != 3  # the clamped row amplifies by 1e18: compare the rest
-    assert rel_err(out.cpu().numpy()[keep], orc.d_l2norm(x, g)[keep]) < TOL
+    assert_close(out.cpu().numpy()[keep], orc.d_l2norm(x, g)[keep])
 
 
 def test_adam_steps(ctx):
@@ -721,23 +721,23 @@ def test_gat_multi_head(ctx, d, heads, hub):
     s = torch.empty_like(t)
     p = torch.empty_like(t)
     ctx.gat_scores(g_d, hd, dev(al), dev(ar), t, s, p, heads=heads)
-    assert rel_err(t.cpu().numpy(), want_t) < TOL
-    assert rel_err(p.cpu().numpy(), want_n) < TOL
+    assert_close(t.cpu().numpy(), want_t)
+    assert_close(p.cpu().numpy(), want_n)
     out = torch.empty(n, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE, hd, out, edge_w=p, heads=heads)
-    assert rel_err(out.cpu().numpy(), want_out) < TOL
+    assert_close(out.cpu().numpy(), want_out)
     # backward pieces
     want_go, want_ds, want_ng, want_lg, want_rg = orc.gat_d_aggregate_mh(g_o, h, gin, want_n, want_t, heads)
     ng = torch.empty(ne, heads, device="cuda")
     ctx.sddmm(g_d, gd, hd, ng, heads=heads)
-    assert rel_err(ng.cpu().numpy(), want_ng) < TOL
+    assert_close(ng.cpu().numpy(), want_ng)
     sc = torch.empty(ne, heads, device="cuda")
     lg = torch.empty(d, device="cuda")
     rg = torch.empty(d, device="cuda")
     ctx.gat_softmax_bwd_alpha(g_d, hd, dev(want_n), dev(want_ng), dev(want_t), sc, lg, rg, heads=heads)
-    assert rel_err(sc.cpu().numpy(), want_ds) < TOL
-    assert rel_err(lg.cpu().numpy(), want_lg) < TOL
-    assert rel_err(rg.cpu().numpy(), want_rg) < TOL
+    assert_close(sc.cpu().numpy(), want_ds)
+    assert_close(lg.cpu().numpy(), want_lg)
+    assert_close(rg.cpu().numpy(), want_rg)
     # without the temp array: forward gives the same attention, backward the same gradients as with the GPU's own temp
     if heads in (1, 2, 4, 8, 16):
         p3 = torch.empty_like(p)
@@ -757,7 +757,7 @@ def test_gat_multi_head(ctx, d, heads, hub):
             ctx.gat_softmax_bwd_alpha(g_d, hd, p, ng, None, sc, lg, rg, heads=heads, alpha=(dev(al), dev(ar)))
     go = torch.empty(n, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE_T, gd, go, edge_w=dev(want_n), heads=heads)
-    assert rel_err(go.cpu().numpy(), want_go) < TOL
+    assert_close(go.cpu().numpy(), want_go)
     pt = torch.empty(ne, heads, device="cuda")
     ctx.edge_transpose(g_d, dev(want_n), pt, heads=heads)
     want_pt = np.stack([orc.symmetric_csr_transpose(g_o, np.ascontiguousarray(want_n[:, k])) for k in range(heads)], 1)
@@ -847,9 +847,9 @@ def test_spmm_gemm_fused(ctx, flat_option, len_in, len_out, kind, transW, relu, 
         y = torch.full((n, len_out), -5.0, device="cuda")
         ctx.spmm_gemm(g_d, k, dev(x), agg, dev(W), y, transW=transW, relu=relu, agg_scratch=scratch,
                       edge_w=dev(ew) if kind == "edge" else None)
-        assert rel_err(y.cpu().numpy(), y_w) < TOL
+        assert_close(y.cpu().numpy(), y_w)
         if not scratch:
-            assert rel_err(agg.cpu().numpy(), agg_w) < TOL
+            assert_close(agg.cpu().numpy(), agg_w)
     # the fused and the two-kernel path agree
     ctx.set_option("spmm_fuse", 0)
     try:
@@ -892,7 +892,7 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     ctx.spmm(ga, capi.W_EDGE, xd, agg, edge_w=dev(ewa))
     ctx.spmm_gemm(gb, capi.W_EDGE, xd, agg, dev(W), y, relu=True, edge_w=dev(ewb), accumulate=True)
     assert rel_err(agg.cpu().numpy(), agg_w) < 1e-5
-    assert rel_err(y.cpu().numpy(), y_w) < TOL
+    assert_close(y.cpu().numpy(), y_w)
     if d in (64, 128):  # fused shapes: light rows continue the CSR-order sum bit for bit
         light = (np.diff(rpa) <= 1024) & (np.diff(rpb) <= 1024)
         assert np.array_equal(agg.cpu().numpy()[light].view(np.uint32), agg_w[light].view(np.uint32))
@@ -901,7 +901,7 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     ctx.spmm(g_o_dev := ctx.graph(rp, ci.view(np.int32)), capi.W_EDGE, xd, agg, edge_w=dev(ew))
     y2 = torch.empty(n, d_out, device="cuda")
     ctx.spmm_gemm(ge, capi.W_EDGE, xd, agg, dev(W), y2, relu=True, edge_w=dev(ew[:1]), accumulate=True)
-    assert rel_err(y2.cpu().numpy(), y_w) < TOL
+    assert_close(y2.cpu().numpy(), y_w)
 
 
 @pytest.mark.parametrize("m,n,k,accum", [(128, 128, 20011, False), (100, 128, 9000, True), (256, 192, 4097, False),
@@ -926,7 +926,7 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
         finally:
             ctx.set_option("sgemm_variant", 0)
         assert np.array_equal(Gd.cpu().numpy().view(np.uint32), Gm.view(np.uint32))  # the in-place d_relu is exact
-        assert rel_err(Cd.cpu().numpy(), want) < TOL
+        assert_close(Cd.cpu().numpy(), want)
         assert rel_err(Cd.cpu().numpy(), ref64) < 2e-5
 
 
@@ -969,7 +969,7 @@ def test_sgemm_experimental_variants_agree(ctx, variant):
             ctx.set_option("sgemm_variant", variant)
             Cd = torch.empty(x, y, device="cuda")
             ctx.sgemm(dev(A), dev(B), Cd, bool(tA), bool(tB))
-            assert rel_err(Cd.cpu().numpy(), want) < TOL
+            assert_close(Cd.cpu().numpy(), want)
     finally:
         ctx.set_option("sgemm_variant", 0)
 
@@ -1004,9 +1004,9 @@ def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
         agg = torch.full((n, len_in), 3.0, device="cuda")
         y = torch.full((n, len_out), -5.0, device="cuda")
         ctx.spmm_gemm(g_d, k, xd, agg, dev(W), y, transW=transW, relu=relu, agg_scratch=scratch, rows2=xd, W2=dev(W2))
-        assert rel_err(y.cpu().numpy(), y_w) < TOL
+        assert_close(y.cpu().numpy(), y_w)
         if not scratch:
-            assert rel_err(agg.cpu().numpy(), agg_w) < TOL
+            assert_close(agg.cpu().numpy(), agg_w)
     # the halo half of a partitioned aggregation carries both products as well
     rows = np.repeat(np.arange(n), np.diff(g_o.rowptr))
     cols = np.asarray(g_o.colidx)
@@ -1026,5 +1026,5 @@ def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
     y = torch.empty(n, len_out, device="cuda")
     ctx.spmm(ga, k, xd, agg)
     ctx.spmm_gemm(gb, k, xd, agg, dev(W), y, transW=transW, relu=relu, accumulate=True, rows2=xd, W2=dev(W2))
-    assert rel_err(agg.cpu().numpy(), agg_w) < TOL
-    assert rel_err(y.cpu().numpy(), y_w) < TOL
+    assert_close(agg.cpu().numpy(), agg_w)
+    assert_close(y.cpu().numpy(), y_w)

@@ -56,6 +56,57 @@ def rel_err(a, b) -> float:
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
 
 
+ELEM_RTOL = 1e-4   # north star: "outputs within 1e-4 rel-err of the OpenMP path"
+ELEM_FLOOR = 1e-6  # absolute floor as a fraction of max|b|: entries far below the tensor's scale are sums that cancel
+
+
+def elem_err(a, b, floor: float = ELEM_FLOOR, rtol: float = ELEM_RTOL) -> float:
+    """element-wise relative error with an absolute floor:  max_i |a_i - b_i| / (|b_i| + (floor/rtol) * max|b|).
+    elem_err(a, b) <= rtol  <=>  |a_i - b_i| <= rtol * |b_i| + floor * max|b|  for every element -- unlike rel_err
+    (one norm for the whole tensor) an O(1) relative error on a small entry shows up here."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    scale = max(float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + (floor / rtol) * scale)))
+
+
+def assert_close(a, b, what: str = "", rtol: float = ELEM_RTOL, floor: float = ELEM_FLOOR) -> None:
+    """both metrics: norm-wise rel_err and the element-wise check with the floor"""
+    r, e = rel_err(a, b), elem_err(a, b, floor, rtol)
+    assert r <= rtol and e <= rtol, f"{what}: norm-wise {r:.3e}, element-wise {e:.3e} (rtol {rtol}, floor {floor})"
+
+
+def dev_errs(a_dev, b, floor: float = ELEM_FLOOR, rtol: float = ELEM_RTOL):
+    """(rel_err, elem_err) of a device tensor against a numpy array (or device tensor), computed on the device in fp64
+    chunk by chunk -- for the full-size comparisons (hundreds of millions of elements)"""
+    import torch
+
+    a = a_dev.reshape(-1)
+    b = (torch.from_numpy(np.ascontiguousarray(b)) if isinstance(b, np.ndarray) else b).reshape(-1)
+    assert a.numel() == b.numel(), (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0, 0.0
+    step = 1 << 26
+    scale = 0.0
+    for i in range(0, b.numel(), step):
+        scale = max(scale, b[i:i + step].abs().max().item())
+    scale = max(scale, 1e-30)
+    inf = elem = 0.0
+    for i in range(0, a.numel(), step):
+        bb = b[i:i + step].to(a.device).double()
+        d = (a[i:i + step].double() - bb).abs()
+        inf = max(inf, d.max().item() / scale)
+        elem = max(elem, (d / (bb.abs() + (floor / rtol) * scale)).max().item())
+    return inf, elem
+
+
+def assert_close_dev(a_dev, b, what: str = "", rtol: float = ELEM_RTOL, floor: float = ELEM_FLOOR) -> None:
+    r, e = dev_errs(a_dev, b, floor, rtol)
+    assert r <= rtol and e <= rtol, f"{what}: norm-wise {r:.3e}, element-wise {e:.3e} (rtol {rtol}, floor {floor})"
+
+
 def dense_adj(rowptr, colidx, w=None):
     n = len(rowptr) - 1
     A = np.zeros((n, n), np.float64)
