@@ -37,10 +37,16 @@ def _declare(l: C.CDLL) -> C.CDLL:
 
 
 def lib() -> C.CDLL:
+    """GNN_ORACLE_LIB=<path> loads another build of the same restatement (the sanitizer builds of
+    `make -C oracle san`, tests/test_sanitizers.py)"""
     global _lib
     if _lib is None:
-        build()
-        _lib = _declare(C.CDLL(str(LIB)))
+        alt = os.environ.get("GNN_ORACLE_LIB")
+        if alt:
+            _lib = _declare(C.CDLL(alt))
+        else:
+            build()
+            _lib = _declare(C.CDLL(str(LIB)))
     return _lib
 
 

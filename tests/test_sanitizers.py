@@ -1,0 +1,65 @@
+"""CPU sanitizer runs ("race detection / sanitizers"): the oracle's OpenMP restatement under
+AddressSanitizer + UBSan (gcc) and under ThreadSanitizer (clang + libomp + Archer), and the host-only C++ of the
+product (dataset reader, GraphSAINT sampler, vertex-range partition builder) under ASan + UBSan.  GPU code cannot be
+sanitized on this pool (no GPU ASan / xnack), so this is the CPU half only."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE = ROOT / "oracle"
+LLVM = Path(os.environ.get("LLVM", "/opt/rocm/lib/llvm"))
+BAD = ("ERROR: AddressSanitizer", "WARNING: ThreadSanitizer", "runtime error:", "ERROR: LeakSanitizer")
+
+
+def _run(env_extra, args, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=timeout)
+    return r.returncode, r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def san_libs():
+    r = subprocess.run(["make", "-C", str(ORACLE), "san"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.fail("make -C oracle san failed:\n" + r.stdout + r.stderr)
+    return ORACLE / "_san"
+
+
+def test_oracle_asan_ubsan(san_libs):
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    assert Path(asan_rt).exists(), asan_rt
+    rc, out = _run({"LD_PRELOAD": asan_rt, "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1",
+                    "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1",
+                    "GNN_ORACLE_LIB": str(san_libs / "libgnn_oracle_asan.so")},
+                   [sys.executable, str(ROOT / "tests" / "san_workload.py")])
+    assert rc == 0 and "san_workload done" in out and not any(b in out for b in BAD), out[-4000:]
+
+
+def test_oracle_asan_catches_a_planted_overrun(san_libs):
+    """the harness really runs the instrumented library: a column id past the feature table must be reported"""
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from oracle import binding as orc; "
+            "g = orc.Graph(np.array([0, 1], np.int64), np.array([40], np.uint32)); "
+            "orc.sage_aggregate(g, np.ones((1, 4), np.float32))" % str(ROOT))
+    rc, out = _run({"LD_PRELOAD": asan_rt, "ASAN_OPTIONS": "detect_leaks=0",
+                    "GNN_ORACLE_LIB": str(san_libs / "libgnn_oracle_asan.so")}, [sys.executable, "-c", code])
+    assert rc != 0 and "AddressSanitizer" in out, out[-2000:]
+
+
+def test_oracle_tsan_openmp(san_libs):
+    rts = glob.glob(str(LLVM / "lib" / "clang" / "*" / "lib" / "linux" / "libclang_rt.tsan-x86_64.so"))
+    archer = LLVM / "lib" / "libarcher.so"
+    if not rts or not archer.exists():
+        pytest.skip("LLVM ThreadSanitizer runtime / Archer not in this image")
+    rc, out = _run({"LD_PRELOAD": rts[0], "OMP_TOOL_LIBRARIES": str(archer),
+                    "TSAN_OPTIONS": "report_signal_unsafe=0 ignore_noninstrumented_modules=1 exitcode=66",
+                    "GNN_ORACLE_LIB": str(san_libs / "libgnn_oracle_tsan.so")},
+                   [sys.executable, str(ROOT / "tests" / "san_workload.py")])
+    assert rc == 0 and "san_workload done" in out and not any(b in out for b in BAD), out[-6000:]
