@@ -138,33 +138,74 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, x, gin, budget_s=30.0, want_outputs=T
     return res, outputs
 
 
-def parity_record(torch, got: dict, want: dict, tol=1e-4, floor=1e-6):
-    """element-wise parity of the GPU layer against the oracle's full-graph run on the same inputs.
+def _errs(torch, a, b, tol, floor):
+    """(elem, inf) of device tensor a against device tensor b, fp64, chunked"""
+    a, b = a.reshape(-1), b.reshape(-1)
+    scale = max(b.abs().max().item(), 1e-30)
+    elem = inf = 0.0
+    step = 1 << 26
+    for i in range(0, a.numel(), step):
+        bb = b[i:i + step].double()
+        d = (a[i:i + step].double() - bb).abs()
+        inf = max(inf, d.max().item() / scale)
+        elem = max(elem, (d / (bb.abs() + (floor / tol) * scale)).max().item())
+    return {"elem": elem, "inf": inf}
+
+
+def parity_record(torch, L, layer, feat_out, grad_out, gin_h, want: dict, tol=1e-4, floor=1e-6):
+    """Element-wise parity of the GPU layer against the oracle's full-graph run on the same inputs.
+
     Per tensor: `elem` = max_i |a_i-b_i| / (|b_i| + (floor/tol) max|b|)  (<= tol  <=>  |a-b| <= tol|b| + floor max|b|
-    everywhere) and `inf` = max|a-b| / max|b|.  Computed on the device in fp64, chunked."""
+    for every element) and `inf` = max|a-b| / max|b|, on the device in fp64.
+
+    forward is compared as is.  backward depends on the relu mask (d_relu masks with the layer's OUTPUT > 0, Q9): an
+    output within rounding of zero can land on either side in two correct fp32 evaluations, and one flipped mask bit
+    moves a whole gradient row by O(1).  So backward is compared twice: `*_own_mask` with the mask the GPU's own forward
+    produced (the raw end-to-end figure; a handful of flips among 3e8 elements dominate it) and `grad_out` / `W_grad`
+    with the GPU backward re-run on the ORACLE's forward output as feat_out (identical masks: arithmetic error only).
+    `relu_mask_flips` counts the differing mask bits and gives the largest |output| among them -- they must all sit
+    within rounding of zero for the run to pass."""
+    D_ = want["W_grad"].shape[0]
+    nv = want["forward"].shape[0]
     rec = {"tol": tol, "floor_frac_of_max": floor}
-    ok = True
-    for k in ("forward", "grad_out", "W_grad"):
-        a = got[k].reshape(-1)
-        b = torch.from_numpy(want[k]).cuda().reshape(-1)
-        scale = max(b.abs().max().item(), 1e-30)
-        elem = inf = 0.0
-        step = 1 << 26
-        for i in range(0, a.numel(), step):
-            d = (a[i:i + step].double() - b[i:i + step].double()).abs()
-            inf = max(inf, d.max().item() / scale)
-            elem = max(elem, (d / (b[i:i + step].double().abs() + (floor / tol) * scale)).max().item())
-        rec[k] = {"elem": elem, "inf": inf}
-        ok = ok and elem <= tol and inf <= tol
-        del b
+    fwd_o = torch.from_numpy(want["forward"]).cuda()
+    rec["forward"] = _errs(torch, feat_out, fwd_o, tol, floor)
+    flips = (feat_out > 0) != (fwd_o > 0)
+    n_flips = int(flips.sum().item())
+    scale = fwd_o.abs().max().item()
+    worst = max(feat_out[flips].abs().max().item(), fwd_o[flips].abs().max().item()) / scale if n_flips else 0.0
+    rec["relu_mask_flips"] = {"count": n_flips, "of": int(fwd_o.numel()), "max_abs_output_over_scale": worst}
+    del flips
+    go_o = torch.from_numpy(want["grad_out"]).cuda()
+    wg_o = torch.from_numpy(want["W_grad"]).cuda()
+    rec["grad_out_own_mask"] = _errs(torch, grad_out, go_o, tol, floor)
+    rec["W_grad_own_mask"] = _errs(torch, layer.tensor(L.W_NEIGH_GRAD, (D_, D_)), wg_o, tol, floor)
+    # the same backward kernels on the oracle's mask
+    layer.write(L.GRAD_IN, torch.from_numpy(gin_h).cuda())
+    layer.backward(fwd_o, grad_out)
+    torch.cuda.synchronize()
+    rec["grad_out"] = _errs(torch, grad_out, go_o, tol, floor)
+    w_gpu = layer.tensor(L.W_NEIGH_GRAD, (D_, D_))
+    rec["W_grad"] = _errs(torch, w_gpu, wg_o, tol, floor)
+    del go_o, fwd_o
     # the weight gradient is a sum over 2.4 M vertices in fp32 on both sides; where the truth lies: fp64 on the device
     ax = torch.from_numpy(want["agg_x"]).cuda().double()
     mg = torch.from_numpy(want["masked_grad"]).cuda().double()
     w64 = ax.t() @ mg
     sc = w64.abs().max().item()
-    rec["W_grad_vs_fp64_inf"] = {"gpu": ((got["W_grad"].double() - w64).abs().max().item() / sc),
-                                 "oracle": ((torch.from_numpy(want["W_grad"]).cuda().double() - w64).abs().max().item() / sc)}
-    rec["ok"] = bool(ok)
+    gpu64 = (w_gpu.double() - w64).abs().max().item() / sc
+    orc64 = (wg_o.double() - w64).abs().max().item() / sc
+    rec["W_grad_vs_fp64_inf"] = {"gpu": gpu64, "oracle": orc64}
+    # W_grad is a sum over the 2.4 M vertices, in fp32 on both sides: the oracle's own result sits `orc64` * max|b| away
+    # from fp64, so no evaluation can match it element-wise below that.  Its floor is therefore twice the ORACLE's own
+    # distance from fp64 (never the GPU's: a wrong GPU result must not widen its own tolerance), at least the default.
+    w_floor = max(floor, 2.0 * orc64)
+    rec["W_grad"]["elem_floor"] = w_floor
+    rec["W_grad"]["elem_at_floor"] = _errs(torch, w_gpu, wg_o, tol, w_floor)["elem"]
+    rec["ok"] = bool(rec["forward"]["elem"] <= tol and rec["forward"]["inf"] <= tol
+                     and rec["grad_out"]["elem"] <= tol and rec["grad_out"]["inf"] <= tol
+                     and rec["W_grad"]["inf"] <= tol and rec["W_grad"]["elem_at_floor"] <= tol
+                     and gpu64 <= 2e-5 and worst <= 1e-5)
     return rec
 
 
@@ -384,8 +425,7 @@ def main():
         result["cpu_baseline"], want = cpu_baseline(sg.rowptr, sg.colidx, nv, *xs, want_outputs=want_parity)
         log(f"[bench] cpu baseline took {time.time()-t1:.1f}s")
         if want_parity:
-            got = {"forward": feat_out, "grad_out": grad_out, "W_grad": layer.tensor(L.W_NEIGH_GRAD, (D, D))}
-            result["parity"] = parity_record(torch, got, want)
+            result["parity"] = parity_record(torch, L, layer, feat_out, grad_out, gin_h, want)
             log(f"[bench] parity vs the oracle's full-graph run: {result['parity']}")
             if not result["parity"]["ok"]:
                 log("[bench] PARITY FAILED (> 1e-4)")

@@ -1,0 +1,620 @@
+// comm.hip -- the collectives of the partitioned path behind include/gaib.h:
+// communicator, halo-row exchange (one all-to-all(v) of feature rows per aggregation), all-reduce of the
+// weight gradients.  The reference has no multi-GPU GNN; its multi-GPU host pattern is one host thread per
+// device + peer copies (src/triangle/multigpu_induced.cu:31-84) over the vertex-range partition of
+// src/partitioner/graph_partition.cc:128-178.  Here: one PROCESS per GPU and two transports behind one interface:
+//
+//   GAIB_COMM_RCCL  ncclSend/ncclRecv groups + ncclAllReduce on a communication stream next to the compute
+//                   stream (RCCL is dlopen'ed: the library has no link-time dependency on it, and inside a
+//                   torch process the already loaded librccl.so.1 is the one that gets used).  Stream-ordered:
+//                   the host never waits.
+//   GAIB_COMM_IPC   peer-to-peer PULL: every rank publishes the hipIpc handle of its packed send buffer in a
+//                   POSIX shared-memory segment; after a host barrier each rank copies the rows it needs straight
+//                   out of its peers' send buffers (device-to-device; over xGMI between GPUs of one node).  Works
+//                   for several ranks on ONE GPU as well (tests), needs no RCCL.  Host-synchronous at the two
+//                   hand-over points of an exchange (after the pack, after the pull); the owned-edge aggregation
+//                   enqueued in between still overlaps the copies.
+//
+// Failure behaviour: every wait on a peer has a deadline (GAIB_COMM_TIMEOUT_S, default 120 s) and a shared error
+// flag; a rank that fails or times out raises the flag, every other rank returns GAIB_ERR_COMM from its next wait
+// instead of spinning forever.  The C++ mirror turns that into the reference's print-and-exit.
+#include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include <atomic>
+#include <new>
+#include <rccl/rccl.h>
+#include "common.h"
+
+#define GAIB_COMM_MAX_RANKS 16
+#define GAIB_COMM_MAX_HALOS 8
+#define GAIB_COMM_REDUCE_FLOATS (64 * 1024)  // per-rank all-reduce staging slot in the shm segment (256 KB)
+
+namespace {
+
+struct RcclApi {
+  void* dl = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+  if (g_rccl.dl) return GAIB_OK;
+  const char* cands[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* c : cands)
+    if ((h = dlopen(c, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) {
+    gaib_set_error("gaib_comm: cannot dlopen librccl.so.1 (%s)", dlerror());
+    return GAIB_ERR_UNSUPPORTED;
+  }
+#define GAIB_SYM(field, name)                                        \
+  g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);             \
+  if (!g_rccl.field) {                                               \
+    gaib_set_error("gaib_comm: librccl lacks %s", name);             \
+    dlclose(h);                                                      \
+    return GAIB_ERR_UNSUPPORTED;                                     \
+  }
+  GAIB_SYM(GetUniqueId, "ncclGetUniqueId")
+  GAIB_SYM(CommInitRank, "ncclCommInitRank")
+  GAIB_SYM(CommDestroy, "ncclCommDestroy")
+  GAIB_SYM(GetErrorString, "ncclGetErrorString")
+  GAIB_SYM(AllReduce, "ncclAllReduce")
+  GAIB_SYM(Send, "ncclSend")
+  GAIB_SYM(Recv, "ncclRecv")
+  GAIB_SYM(GroupStart, "ncclGroupStart")
+  GAIB_SYM(GroupEnd, "ncclGroupEnd")
+#undef GAIB_SYM
+  g_rccl.dl = h;
+  return GAIB_OK;
+}
+
+#define GAIB_NCCL(call)                                                                                   \
+  do {                                                                                                    \
+    ncclResult_t r_ = (call);                                                                             \
+    if (r_ != ncclSuccess) {                                                                              \
+      gaib_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_));           \
+      return GAIB_ERR_COMM;                                                                               \
+    }                                                                                                     \
+  } while (0)
+
+// ---- shared-memory segment of the IPC transport --------------------------------------------------------------
+struct ShmSlot {  // one rank's published send buffer of one halo plan
+  uint64_t gen;   // bumped whenever the buffer was (re)allocated: peers re-open the handle
+  uint64_t capacity_bytes;
+  int32_t device;
+  int32_t pad;
+  hipIpcMemHandle_t handle;
+  int64_t send_off[GAIB_COMM_MAX_RANKS + 1];  // row offsets of the per-destination groups inside the buffer
+};
+struct ShmSeg {
+  std::atomic<uint32_t> magic;
+  uint32_t nranks;
+  std::atomic<uint32_t> bar_count;
+  std::atomic<uint32_t> bar_sense;
+  std::atomic<uint32_t> error;
+  uint32_t pad[3];
+  ShmSlot slot[GAIB_COMM_MAX_HALOS][GAIB_COMM_MAX_RANKS];
+  float reduce[GAIB_COMM_MAX_RANKS][GAIB_COMM_REDUCE_FLOATS];
+};
+const uint32_t kMagic = 0x47414942u;  // "GAIB"
+
+double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+double timeout_s() {
+  const char* e = getenv("GAIB_COMM_TIMEOUT_S");
+  double v = e ? atof(e) : 120.0;
+  return v > 0 ? v : 120.0;
+}
+
+}  // namespace
+
+struct gaib_comm {
+  gaib_ctx* ctx;
+  int rank, nranks, transport;
+  hipStream_t cstream;  // communication stream
+  hipEvent_t ev_ready, ev_done;
+  ncclComm_t nccl;
+  // IPC transport
+  ShmSeg* seg;
+  char shm_name[80];
+  uint32_t sense;
+  int n_halos;
+  float* h_stage;  // pinned staging for the IPC all-reduce
+};
+
+struct gaib_halo {
+  gaib_comm* c;
+  int id;  // slot row in the shm segment
+  int64_t send_counts[GAIB_COMM_MAX_RANKS], recv_counts[GAIB_COMM_MAX_RANKS];
+  int64_t send_off[GAIB_COMM_MAX_RANKS + 1], recv_off[GAIB_COMM_MAX_RANKS + 1];
+  int64_t* d_send_idx;
+  float* sendbuf;
+  size_t send_cap;
+  float* table;
+  size_t table_cap;
+  int pending_len;
+  struct Peer {
+    uint64_t gen;
+    void* base;
+  } peer[GAIB_COMM_MAX_RANKS];
+  int64_t bytes_sent;
+};
+
+namespace {
+
+// central sense-reversing barrier in the segment, with deadline and error flag
+int shm_barrier(gaib_comm* c, const char* what) {
+  ShmSeg* s = c->seg;
+  if (c->nranks == 1) return GAIB_OK;
+  const uint32_t my = (c->sense ^= 1u);
+  if (s->bar_count.fetch_add(1) + 1 == (uint32_t)c->nranks) {
+    s->bar_count.store(0);
+    s->bar_sense.store(my);
+    return GAIB_OK;
+  }
+  const double deadline = now_s() + timeout_s();
+  unsigned spins = 0;
+  while (s->bar_sense.load() != my) {
+    if (s->error.load()) {
+      gaib_set_error("gaib_comm(rank %d): a peer reported a failure while this rank waited in %s", c->rank, what);
+      return GAIB_ERR_COMM;
+    }
+    if ((++spins & 1023u) == 0) {
+      if (now_s() > deadline) {
+        s->error.store(1);
+        gaib_set_error("gaib_comm(rank %d): timed out after %.0f s waiting for the other ranks in %s", c->rank,
+                       timeout_s(), what);
+        return GAIB_ERR_COMM;
+      }
+      usleep(50);
+    }
+  }
+  return GAIB_OK;
+}
+
+int fail(gaib_comm* c, int rc) {  // tell the peers, keep the message
+  if (c && c->seg) c->seg->error.store(1);
+  return rc;
+}
+
+int reserve(float** p, size_t* cap, size_t bytes, hipStream_t s) {
+  if (bytes <= *cap && *p) return 0;
+  if (*p) {
+    GAIB_HIP(hipStreamSynchronize(s));
+    GAIB_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+  }
+  size_t want = bytes < 256 ? 256 : bytes;
+  hipError_t e = hipMalloc((void**)p, want);
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_halo: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    return GAIB_ERR_NOMEM;
+  }
+  *cap = want;
+  return 1;  // (re)allocated
+}
+
+}  // namespace
+
+extern "C" int gaib_comm_unique_id(int transport, void* h_id) {
+  GAIB_CHECK(h_id, "gaib_comm_unique_id: h_id is NULL");
+  memset(h_id, 0, GAIB_COMM_ID_BYTES);
+  if (transport == GAIB_COMM_RCCL) {
+    GAIB_TRY(rccl_load());
+    ncclUniqueId id;
+    GAIB_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == GAIB_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(h_id, &id, sizeof(id));
+    return GAIB_OK;
+  }
+  GAIB_CHECK(transport == GAIB_COMM_IPC, "gaib_comm_unique_id: unknown transport %d", transport);
+  int fd = open("/dev/urandom", O_RDONLY);
+  GAIB_CHECK(fd >= 0, "gaib_comm_unique_id: /dev/urandom: %s", strerror(errno));
+  ssize_t n = read(fd, h_id, 16);
+  close(fd);
+  GAIB_CHECK(n == 16, "gaib_comm_unique_id: short read from /dev/urandom");
+  return GAIB_OK;
+}
+
+extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h_id, int transport, gaib_comm** out) {
+  GAIB_CHECK(ctx && h_id && out, "gaib_comm_init: NULL argument");
+  GAIB_CHECK(nranks >= 1 && nranks <= GAIB_COMM_MAX_RANKS && rank >= 0 && rank < nranks,
+             "gaib_comm_init: rank %d of %d (at most %d ranks)", rank, nranks, GAIB_COMM_MAX_RANKS);
+  GAIB_CHECK(transport == GAIB_COMM_RCCL || transport == GAIB_COMM_IPC, "gaib_comm_init: unknown transport %d", transport);
+  GAIB_HIP(hipSetDevice(ctx->device));
+  gaib_comm* c = new (std::nothrow) gaib_comm();
+  GAIB_CHECK(c, "gaib_comm_init: out of memory");
+  memset((void*)c, 0, sizeof(*c));
+  c->ctx = ctx;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->transport = transport;
+  hipError_t e = hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_comm_init: %s", hipGetErrorString(e));
+    delete c;
+    return GAIB_ERR_HIP;
+  }
+  if (transport == GAIB_COMM_RCCL) {
+    int rc = rccl_load();
+    if (rc != GAIB_OK) {
+      delete c;
+      return rc;
+    }
+    ncclUniqueId id;
+    memcpy(&id, h_id, sizeof(id));
+    // one GPU per rank: RCCL itself refuses two ranks on one device ("duplicate GPU")
+    ncclResult_t r = g_rccl.CommInitRank(&c->nccl, nranks, id, rank);
+    if (r != ncclSuccess) {
+      gaib_set_error("gaib_comm_init: ncclCommInitRank(rank %d of %d, device %d) -> %s", rank, nranks, ctx->device,
+                     g_rccl.GetErrorString(r));
+      delete c;
+      return GAIB_ERR_COMM;
+    }
+    *out = c;
+    return GAIB_OK;
+  }
+  // ---- IPC: map (rank 0: create) the segment named after the id ----
+  const unsigned char* b = (const unsigned char*)h_id;
+  snprintf(c->shm_name, sizeof(c->shm_name), "/gaib_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", b[0], b[1], b[2],
+           b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11]);
+  int fd = -1;
+  const double deadline = now_s() + timeout_s();
+  if (rank == 0) {
+    shm_unlink(c->shm_name);
+    fd = shm_open(c->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd >= 0 && ftruncate(fd, sizeof(ShmSeg)) != 0) {
+      close(fd);
+      fd = -1;
+    }
+  } else {
+    while ((fd = shm_open(c->shm_name, O_RDWR, 0600)) < 0 && now_s() < deadline) usleep(1000);
+    struct stat st;
+    while (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size < sizeof(ShmSeg) && now_s() < deadline) usleep(1000);
+  }
+  if (fd < 0) {
+    gaib_set_error("gaib_comm_init(rank %d): shm_open(%s): %s", rank, c->shm_name, strerror(errno));
+    delete c;
+    return GAIB_ERR_COMM;
+  }
+  void* m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) {
+    gaib_set_error("gaib_comm_init(rank %d): mmap(%s): %s", rank, c->shm_name, strerror(errno));
+    delete c;
+    return GAIB_ERR_COMM;
+  }
+  c->seg = (ShmSeg*)m;
+  if (rank == 0) {
+    c->seg->nranks = (uint32_t)nranks;
+    c->seg->bar_count.store(0);
+    c->seg->bar_sense.store(0);
+    c->seg->error.store(0);
+    c->seg->magic.store(kMagic);
+  } else {
+    while (c->seg->magic.load() != kMagic && now_s() < deadline) usleep(1000);
+    if (c->seg->magic.load() != kMagic || c->seg->nranks != (uint32_t)nranks) {
+      gaib_set_error("gaib_comm_init(rank %d): segment %s not initialised by rank 0 for %d ranks", rank, c->shm_name, nranks);
+      munmap(m, sizeof(ShmSeg));
+      delete c;
+      return GAIB_ERR_COMM;
+    }
+  }
+  e = hipHostMalloc((void**)&c->h_stage, sizeof(float) * GAIB_COMM_REDUCE_FLOATS, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_comm_init: hipHostMalloc: %s", hipGetErrorString(e));
+    munmap(m, sizeof(ShmSeg));
+    delete c;
+    return GAIB_ERR_HIP;
+  }
+  int rc = shm_barrier(c, "gaib_comm_init");
+  if (rc != GAIB_OK) return fail(c, rc);
+  if (rank == 0) shm_unlink(c->shm_name);  // everybody has it mapped: the name can go (nothing left behind on a crash)
+  *out = c;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_comm_rank(const gaib_comm* c) { return c ? c->rank : -1; }
+extern "C" int gaib_comm_size(const gaib_comm* c) { return c ? c->nranks : 0; }
+
+extern "C" int gaib_comm_destroy(gaib_comm* c) {
+  if (!c) return GAIB_OK;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->cstream);
+  if (c->transport == GAIB_COMM_RCCL && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->seg) munmap(c->seg, sizeof(ShmSeg));
+  (void)hipEventDestroy(c->ev_ready);
+  (void)hipEventDestroy(c->ev_done);
+  (void)hipStreamDestroy(c->cstream);
+  delete c;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_comm_barrier(gaib_comm* c) {
+  GAIB_CHECK(c, "gaib_comm_barrier: comm is NULL");
+  GAIB_HIP(hipStreamSynchronize(c->ctx->stream));
+  if (c->transport == GAIB_COMM_IPC) return shm_barrier(c, "gaib_comm_barrier");
+  float* d = nullptr;  // a 1-element all-reduce is RCCL's barrier
+  GAIB_TRY(gaib_ws_reserve(c->ctx, 256));
+  d = (float*)c->ctx->ws;
+  GAIB_NCCL(g_rccl.AllReduce(d, d, 1, ncclFloat32, ncclSum, c->nccl, c->ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(c->ctx->stream));
+  return GAIB_OK;
+}
+
+// weight gradients: in-place sum over ranks, identical bits on every rank (IPC: slots added in rank order)
+extern "C" int gaib_allreduce_f32(gaib_comm* c, float* d_buf, int64_t n) {
+  GAIB_CHECK(c && (d_buf || n == 0), "gaib_allreduce_f32: NULL argument");
+  GAIB_CHECK(n >= 0, "gaib_allreduce_f32: n < 0");
+  if (n == 0 || c->nranks == 1) return GAIB_OK;
+  GAIB_HIP(hipSetDevice(c->ctx->device));
+  hipStream_t s = c->ctx->stream;
+  if (c->transport == GAIB_COMM_RCCL) {
+    // the communicator is driven from ONE stream (the communication stream); the compute stream hands over and
+    // takes back through events, the host does not wait
+    GAIB_HIP(hipEventRecord(c->ev_ready, s));
+    GAIB_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+    GAIB_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, c->nccl, c->cstream));
+    GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
+    GAIB_HIP(hipStreamWaitEvent(s, c->ev_done, 0));
+    return GAIB_OK;
+  }
+  ShmSeg* seg = c->seg;
+  for (int64_t off = 0; off < n; off += GAIB_COMM_REDUCE_FLOATS) {
+    const int64_t cnt = n - off < GAIB_COMM_REDUCE_FLOATS ? n - off : GAIB_COMM_REDUCE_FLOATS;
+    hipError_t e = hipMemcpyAsync(c->h_stage, d_buf + off, sizeof(float) * cnt, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_allreduce_f32: %s", hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+    memcpy(seg->reduce[c->rank], c->h_stage, sizeof(float) * cnt);
+    int rc = shm_barrier(c, "gaib_allreduce_f32 (publish)");
+    if (rc != GAIB_OK) return rc;
+    for (int64_t i = 0; i < cnt; i++) {
+      float acc = seg->reduce[0][i];
+      for (int r = 1; r < c->nranks; r++) acc += seg->reduce[r][i];
+      c->h_stage[i] = acc;
+    }
+    rc = shm_barrier(c, "gaib_allreduce_f32 (consume)");  // nobody overwrites a slot that is still being read
+    if (rc != GAIB_OK) return rc;
+    e = hipMemcpyAsync(d_buf + off, c->h_stage, sizeof(float) * cnt, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_allreduce_f32: %s", hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+  }
+  return GAIB_OK;
+}
+
+// scalars that live on the host (loss, accuracy counts): sum over ranks
+extern "C" int gaib_allreduce_host_f64(gaib_comm* c, double* h_buf, int n) {
+  GAIB_CHECK(c && h_buf && n >= 0 && n <= 1024, "gaib_allreduce_host_f64: bad argument (n <= 1024)");
+  if (n == 0 || c->nranks == 1) return GAIB_OK;
+  if (c->transport == GAIB_COMM_IPC) {
+    double* slot = (double*)c->seg->reduce[c->rank];
+    memcpy(slot, h_buf, sizeof(double) * n);
+    int rc = shm_barrier(c, "gaib_allreduce_host_f64 (publish)");
+    if (rc != GAIB_OK) return rc;
+    for (int i = 0; i < n; i++) {
+      double acc = 0.0;
+      for (int r = 0; r < c->nranks; r++) acc += ((const double*)c->seg->reduce[r])[i];
+      h_buf[i] = acc;
+    }
+    return shm_barrier(c, "gaib_allreduce_host_f64 (consume)");
+  }
+  // RCCL: through a small device buffer as 2 floats per double would lose bits; use ncclFloat64
+  GAIB_HIP(hipSetDevice(c->ctx->device));
+  GAIB_TRY(gaib_ws_reserve(c->ctx, sizeof(double) * 1024));
+  double* d = (double*)c->ctx->ws;
+  hipStream_t s = c->ctx->stream;
+  GAIB_HIP(hipMemcpyAsync(d, h_buf, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  GAIB_HIP(hipEventRecord(c->ev_ready, s));
+  GAIB_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  GAIB_NCCL(g_rccl.AllReduce(d, d, (size_t)n, ncclFloat64, ncclSum, c->nccl, c->cstream));
+  GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
+  GAIB_HIP(hipStreamWaitEvent(s, c->ev_done, 0));
+  GAIB_HIP(hipMemcpyAsync(h_buf, d, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  GAIB_HIP(hipStreamSynchronize(s));
+  return GAIB_OK;
+}
+
+// ---- halo plan --------------------------------------------------------------------------------------------------
+extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, const int64_t* send_idx, int idx_on_device,
+                                const int64_t* h_recv_counts, gaib_halo** out) {
+  GAIB_CHECK(c && h_send_counts && h_recv_counts && out, "gaib_halo_create: NULL argument");
+  GAIB_CHECK(c->n_halos < GAIB_COMM_MAX_HALOS, "gaib_halo_create: at most %d halo plans per communicator", GAIB_COMM_MAX_HALOS);
+  GAIB_HIP(hipSetDevice(c->ctx->device));
+  gaib_halo* h = new (std::nothrow) gaib_halo();
+  GAIB_CHECK(h, "gaib_halo_create: out of memory");
+  memset((void*)h, 0, sizeof(*h));
+  h->c = c;
+  h->id = c->n_halos++;
+  h->send_off[0] = h->recv_off[0] = 0;
+  for (int r = 0; r < c->nranks; r++) {
+    if (h_send_counts[r] < 0 || h_recv_counts[r] < 0 || (r == c->rank && (h_send_counts[r] || h_recv_counts[r]))) {
+      gaib_set_error("gaib_halo_create: counts must be >= 0 and 0 for the rank itself (rank %d, peer %d)", c->rank, r);
+      delete h;
+      return GAIB_ERR_INVALID;
+    }
+    h->send_counts[r] = h_send_counts[r];
+    h->recv_counts[r] = h_recv_counts[r];
+    h->send_off[r + 1] = h->send_off[r] + h_send_counts[r];
+    h->recv_off[r + 1] = h->recv_off[r] + h_recv_counts[r];
+  }
+  const int64_t n_send = h->send_off[c->nranks];
+  GAIB_CHECK(n_send == 0 || send_idx, "gaib_halo_create: send_idx is NULL");
+  if (n_send) {
+    hipError_t e = hipMalloc((void**)&h->d_send_idx, sizeof(int64_t) * n_send);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(h->d_send_idx, send_idx, sizeof(int64_t) * n_send,
+                         idx_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_halo_create: %s", hipGetErrorString(e));
+      if (h->d_send_idx) (void)hipFree(h->d_send_idx);
+      delete h;
+      return GAIB_ERR_HIP;
+    }
+  }
+  *out = h;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_halo_destroy(gaib_halo* h) {
+  if (!h) return GAIB_OK;
+  gaib_comm* c = h->c;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->cstream);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->transport == GAIB_COMM_IPC) {
+    for (int r = 0; r < c->nranks; r++)
+      if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
+    // nobody may still be pulling from the send buffer that is about to be freed
+    if (c->seg && !c->seg->error.load()) (void)shm_barrier(c, "gaib_halo_destroy");
+  }
+  if (h->d_send_idx) (void)hipFree(h->d_send_idx);
+  if (h->sendbuf) (void)hipFree(h->sendbuf);
+  if (h->table) (void)hipFree(h->table);
+  delete h;
+  return GAIB_OK;
+}
+
+extern "C" int64_t gaib_halo_rows(const gaib_halo* h) { return h ? h->recv_off[h->c->nranks] : 0; }
+extern "C" int64_t gaib_halo_send_rows(const gaib_halo* h) { return h ? h->send_off[h->c->nranks] : 0; }
+extern "C" int64_t gaib_halo_bytes_sent(const gaib_halo* h) { return h ? h->bytes_sent : 0; }
+
+// 1. pack the owned rows the peers asked for (compute stream), 2. start moving them.  Every rank calls it for every
+// exchange (also one that neither sends nor receives).  Returns at once on RCCL; on IPC after the peers' packs are
+// done and this rank's pulls are enqueued.
+extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_rows) {
+  GAIB_CHECK(h && len >= 1, "gaib_halo_exchange_begin: bad argument");
+  GAIB_CHECK(h->pending_len == 0, "gaib_halo_exchange_begin: the previous exchange was not ended");
+  gaib_comm* c = h->c;
+  gaib_ctx* ctx = c->ctx;
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
+  GAIB_CHECK(n_send == 0 || d_rows, "gaib_halo_exchange_begin: d_rows is NULL");
+  const size_t row_bytes = sizeof(float) * (size_t)len;
+  int ra = reserve(&h->sendbuf, &h->send_cap, row_bytes * (size_t)n_send, ctx->stream);
+  if (ra < 0) return fail(c, ra);
+  int rb = reserve(&h->table, &h->table_cap, row_bytes * (size_t)n_recv, ctx->stream);
+  if (rb < 0) return fail(c, rb);
+  if (n_send) {
+    int rc = gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
+    if (rc != GAIB_OK) return fail(c, rc);
+  }
+  h->bytes_sent += (int64_t)row_bytes * n_send;
+  h->pending_len = len;
+  GAIB_HIP(hipEventRecord(c->ev_ready, ctx->stream));
+  if (c->transport == GAIB_COMM_RCCL) {
+    GAIB_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+    if (c->nranks > 1) {
+      GAIB_NCCL(g_rccl.GroupStart());
+      for (int r = 0; r < c->nranks; r++) {
+        if (h->send_counts[r])
+          GAIB_NCCL(g_rccl.Send(h->sendbuf + h->send_off[r] * len, (size_t)(h->send_counts[r] * len), ncclFloat32, r,
+                                c->nccl, c->cstream));
+        if (h->recv_counts[r])
+          GAIB_NCCL(g_rccl.Recv(h->table + h->recv_off[r] * len, (size_t)(h->recv_counts[r] * len), ncclFloat32, r,
+                                c->nccl, c->cstream));
+      }
+      GAIB_NCCL(g_rccl.GroupEnd());
+    }
+    GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
+    return GAIB_OK;
+  }
+  // ---- IPC pull ----
+  ShmSlot* mine = &c->seg->slot[h->id][c->rank];
+  if (ra == 1 || mine->gen == 0) {
+    hipError_t e = hipIpcGetMemHandle(&mine->handle, h->sendbuf);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_halo_exchange_begin: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+    mine->capacity_bytes = h->send_cap;
+    mine->device = ctx->device;
+    for (int r = 0; r <= c->nranks; r++) mine->send_off[r] = h->send_off[r];
+    mine->gen++;
+  }
+  hipError_t e = hipEventSynchronize(c->ev_ready);  // the pack is done: peers may read the buffer
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_halo_exchange_begin: %s", hipGetErrorString(e));
+    return fail(c, GAIB_ERR_HIP);
+  }
+  int rc = shm_barrier(c, "gaib_halo_exchange_begin (all packed)");
+  if (rc != GAIB_OK) return rc;
+  for (int r = 0; r < c->nranks; r++) {
+    if (!h->recv_counts[r]) continue;
+    const ShmSlot* ps = &c->seg->slot[h->id][r];
+    if (h->peer[r].gen != ps->gen) {
+      if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
+      h->peer[r].base = nullptr;
+      e = hipIpcOpenMemHandle(&h->peer[r].base, ps->handle, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        gaib_set_error("gaib_halo_exchange_begin(rank %d): hipIpcOpenMemHandle(rank %d's send buffer): %s", c->rank, r,
+                       hipGetErrorString(e));
+        return fail(c, GAIB_ERR_HIP);
+      }
+      h->peer[r].gen = ps->gen;
+    }
+    if (ps->send_off[c->rank + 1] - ps->send_off[c->rank] != h->recv_counts[r]) {
+      gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d sends %lld rows, this rank expects %lld", c->rank, r,
+                     (long long)(ps->send_off[c->rank + 1] - ps->send_off[c->rank]), (long long)h->recv_counts[r]);
+      return fail(c, GAIB_ERR_INVALID);
+    }
+    const float* src = (const float*)h->peer[r].base + ps->send_off[c->rank] * len;
+    e = hipMemcpyAsync(h->table + h->recv_off[r] * len, src, row_bytes * (size_t)h->recv_counts[r], hipMemcpyDeviceToDevice,
+                       c->cstream);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_halo_exchange_begin(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+  }
+  GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
+  return GAIB_OK;
+}
+
+// the compute stream continues after the rows have arrived; *d_table = [rows x len], grouped by owner rank in the
+// order of the recv counts
+extern "C" int gaib_halo_exchange_end(gaib_halo* h, const float** d_table) {
+  GAIB_CHECK(h && d_table, "gaib_halo_exchange_end: NULL argument");
+  GAIB_CHECK(h->pending_len > 0, "gaib_halo_exchange_end: no exchange in flight");
+  gaib_comm* c = h->c;
+  GAIB_HIP(hipSetDevice(c->ctx->device));
+  h->pending_len = 0;
+  if (c->transport == GAIB_COMM_IPC) {
+    hipError_t e = hipEventSynchronize(c->ev_done);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_halo_exchange_end: %s", hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+    int rc = shm_barrier(c, "gaib_halo_exchange_end (all pulled)");  // send buffers may be overwritten from here on
+    if (rc != GAIB_OK) return rc;
+  }
+  GAIB_HIP(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
+  *d_table = h->table;
+  return GAIB_OK;
+}

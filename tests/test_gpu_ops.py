@@ -14,7 +14,7 @@ import torch
 
 from graphaibench_amd import capi
 from oracle import binding as orc
-from util import assert_close, random_graph, rel_err
+from util import LONG_SUM_FLOOR, assert_close, random_graph, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4  # BASELINE.json north_star: "outputs within 1e-4 rel-err of the OpenMP path"
@@ -465,7 +465,8 @@ def test_gat_forward_pieces(ctx, d, hub):
     assert_close(p.cpu().numpy(), want_n)
     out = torch.empty(g_o.nv, d, device="cuda")
     ctx.spmm(g_d, capi.W_EDGE, hd, out, edge_w=p)
-    assert_close(out.cpu().numpy(), want_out)
+    # attention-weighted sums of O(1) rows with weights that carry expf's last-bit differences: cancelling entries
+    assert_close(out.cpu().numpy(), want_out, floor=LONG_SUM_FLOOR if d >= 128 or hub else 1e-6)
     # the leaky-relu output is optional
     t2 = torch.empty_like(t)
     p2 = torch.empty_like(t)
@@ -509,7 +510,9 @@ def test_gat_backward_pieces(ctx, d, hub):
                                   grad_rows=gd, fwd_out_rows=dev(out_w), norm_t=pt2)
         assert np.array_equal(pt2.cpu().numpy(), orc.symmetric_csr_transpose(g_o, norm))  # a permutation: exact
         if keep_ds:
-            assert_close(sc2.cpu().numpy(), want_ds)
+            # ds = p (dp - sum_e p dp) with the row sum taken as the D-term product <grad_i, out_i>: a difference of two
+            # O(sqrt(D)) numbers that nearly cancel on some edges
+            assert_close(sc2.cpu().numpy(), want_ds, floor=LONG_SUM_FLOOR if d >= 128 else 1e-6)
         assert_close(lg2.cpu().numpy(), want_lg)
         assert_close(rg2.cpu().numpy(), want_rg)
     # the form without the temp array (the sign of a_l.h[i] + a_r.h[col] formed again): same bits as with the temp
@@ -525,7 +528,8 @@ def test_gat_backward_pieces(ctx, d, hub):
         res.append((sc3, lg3, rg3, pt3))
     for a, b in zip(*res):
         assert torch.equal(a, b)
-    assert_close(res[1][1].cpu().numpy(), want_lg) < TOL and rel_err(res[1][2].cpu().numpy(), want_rg)
+    assert_close(res[1][1].cpu().numpy(), want_lg)
+    assert_close(res[1][2].cpu().numpy(), want_rg)
     # explicit transpose == oracle's symmetric_csr_transpose (a permutation: bit-exact)
     pt = torch.empty(g_o.ne, device="cuda")
     ctx.edge_transpose(g_d, dev(norm), pt)
@@ -892,7 +896,7 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     ctx.spmm(ga, capi.W_EDGE, xd, agg, edge_w=dev(ewa))
     ctx.spmm_gemm(gb, capi.W_EDGE, xd, agg, dev(W), y, relu=True, edge_w=dev(ewb), accumulate=True)
     assert rel_err(agg.cpu().numpy(), agg_w) < 1e-5
-    assert_close(y.cpu().numpy(), y_w)
+    assert_close(y.cpu().numpy(), y_w, floor=LONG_SUM_FLOOR)  # the hub row: 2500 terms, split in two halves
     if d in (64, 128):  # fused shapes: light rows continue the CSR-order sum bit for bit
         light = (np.diff(rpa) <= 1024) & (np.diff(rpb) <= 1024)
         assert np.array_equal(agg.cpu().numpy()[light].view(np.uint32), agg_w[light].view(np.uint32))
