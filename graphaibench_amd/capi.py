@@ -36,6 +36,7 @@ SIGNATURES = {
     "gaib_memcpy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "gaib_memcpy_d2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "gaib_fill_f32": (_i, [_vp, _i64, _f, _vp]),
+    "gaib_scale_f32": (_i, [_vp, _i64, _f, _vp]),
     "gaib_graph_create": (_i, [_vp, _i64, _i64, _vp, _i, _vp, _i, _pp]),
     "gaib_graph_create_rect": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _vp, _i, _pp]),
     "gaib_graph_destroy": (_i, [_vp]),
@@ -89,6 +90,21 @@ SIGNATURES = {
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "gaib_comm_unique_id": (_i, [_i, _vp]),
+    "gaib_comm_init": (_i, [_vp, _i, _i, _vp, _i, _pp]),
+    "gaib_comm_destroy": (_i, [_vp]),
+    "gaib_comm_rank": (_i, [_vp]),
+    "gaib_comm_size": (_i, [_vp]),
+    "gaib_comm_barrier": (_i, [_vp]),
+    "gaib_allreduce_f32": (_i, [_vp, _vp, _i64]),
+    "gaib_allreduce_host_f64": (_i, [_vp, C.POINTER(C.c_double), _i]),
+    "gaib_halo_create": (_i, [_vp, C.POINTER(_i64), _vp, _i, C.POINTER(_i64), _pp]),
+    "gaib_halo_destroy": (_i, [_vp]),
+    "gaib_halo_rows": (_i64, [_vp]),
+    "gaib_halo_send_rows": (_i64, [_vp]),
+    "gaib_halo_bytes_sent": (_i64, [_vp]),
+    "gaib_halo_exchange_begin": (_i, [_vp, _i, _vp]),
+    "gaib_halo_exchange_end": (_i, [_vp, _pp]),
     "gaib_probe_stream_copy": (_i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
     "gaib_probe_peer_copy": (_i, [_i, _i, C.c_size_t, _i, _i, C.POINTER(C.c_double)]),
 }
@@ -96,6 +112,87 @@ SIGNATURES = {
 
 class GaibError(RuntimeError):
     pass
+
+
+COMM_RCCL, COMM_IPC = 0, 1
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id(transport: int = COMM_RCCL) -> bytes:
+    """called by ONE rank; the bytes travel to the others by whatever the launcher has (a file, torch's store ...)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().gaib_comm_unique_id(transport, buf), "gaib_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """gaib_comm: the collectives of the partitioned path behind the C ABI (RCCL, or peer-to-peer pull over hipIpc)"""
+
+    def __init__(self, ctx: "Context", rank: int, nranks: int, unique_id: bytes, transport: int = COMM_RCCL):
+        self.lib = load()
+        self.ctx, self.rank, self.nranks, self.transport = ctx, rank, nranks, transport
+        h = C.c_void_p()
+        _check(self.lib.gaib_comm_init(ctx.h, rank, nranks, C.c_char_p(unique_id), transport, C.byref(h)), "gaib_comm_init")
+        self.h = h
+
+    def barrier(self):
+        _check(self.lib.gaib_comm_barrier(self.h), "gaib_comm_barrier")
+
+    def allreduce(self, t):
+        """in-place sum of a float32 device tensor"""
+        _check(self.lib.gaib_allreduce_f32(self.h, t.data_ptr(), t.numel()), "gaib_allreduce_f32")
+
+    def allreduce_host(self, values):
+        arr = (C.c_double * len(values))(*values)
+        _check(self.lib.gaib_allreduce_host_f64(self.h, arr, len(values)), "gaib_allreduce_host_f64")
+        return list(arr)
+
+    def halo(self, send_counts, send_idx, recv_counts) -> "Halo":
+        return Halo(self, send_counts, send_idx, recv_counts)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gaib_comm_destroy(self.h)
+            self.h = None
+
+
+class Halo:
+    """gaib_halo: one exchange plan (which rows go to / come from which rank)"""
+
+    def __init__(self, comm: Comm, send_counts, send_idx, recv_counts):
+        self.comm, self.lib = comm, comm.lib
+        n = comm.nranks
+        sc = (C.c_int64 * n)(*[int(v) for v in send_counts])
+        rc = (C.c_int64 * n)(*[int(v) for v in recv_counts])
+        on_dev = int(hasattr(send_idx, "is_cuda") and send_idx.is_cuda)
+        if hasattr(send_idx, "data_ptr"):
+            ptr = send_idx.data_ptr() if send_idx.numel() else None
+            self._keep = send_idx
+        else:
+            import numpy as np
+            self._keep = np.ascontiguousarray(send_idx, dtype=np.int64)
+            ptr = self._keep.ctypes.data if len(self._keep) else None
+        h = C.c_void_p()
+        _check(self.lib.gaib_halo_create(comm.h, sc, ptr, on_dev, rc, C.byref(h)), "gaib_halo_create")
+        self.h = h
+        self.rows = int(self.lib.gaib_halo_rows(h))
+
+    def begin(self, rows, length: int):
+        _check(self.lib.gaib_halo_exchange_begin(self.h, length, _ptr(rows)), "gaib_halo_exchange_begin")
+
+    def end(self) -> int:
+        p = C.c_void_p()
+        _check(self.lib.gaib_halo_exchange_end(self.h, C.byref(p)), "gaib_halo_exchange_end")
+        return p.value or 0
+
+    @property
+    def bytes_sent(self) -> int:
+        return int(self.lib.gaib_halo_bytes_sent(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gaib_halo_destroy(self.h)
+            self.h = None
 
 
 def probe_peer_copy(src_dev: int, dst_dev: int, nbytes: int = 1 << 28, iters: int = 10, bidir: bool = False) -> float:

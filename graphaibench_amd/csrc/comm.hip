@@ -367,7 +367,7 @@ extern "C" int gaib_comm_barrier(gaib_comm* c) {
 extern "C" int gaib_allreduce_f32(gaib_comm* c, float* d_buf, int64_t n) {
   GAIB_CHECK(c && (d_buf || n == 0), "gaib_allreduce_f32: NULL argument");
   GAIB_CHECK(n >= 0, "gaib_allreduce_f32: n < 0");
-  if (n == 0 || c->nranks == 1) return GAIB_OK;
+  if (n == 0 || (c->nranks == 1 && c->transport == GAIB_COMM_IPC)) return GAIB_OK;  // RCCL runs also with one rank
   GAIB_HIP(hipSetDevice(c->ctx->device));
   hipStream_t s = c->ctx->stream;
   if (c->transport == GAIB_COMM_RCCL) {

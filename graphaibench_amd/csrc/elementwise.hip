@@ -23,6 +23,11 @@ __global__ void fill_kernel(int64_t n, float v, float* x) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = v;
 }
 
+__global__ void scale_kernel(int64_t n, float a, float* x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = a * x[i];
+}
+
 // relu_cpu / relu_kernel: max(x, 0)    (math_functions.cpp:442-451; .cu:242)
 __global__ void relu_kernel(int64_t n, const float* in, float* out, int vec_ok) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -386,6 +391,14 @@ extern "C" int gaib_fill_f32(gaib_ctx* ctx, int64_t n, float value, float* d_x) 
   GAIB_CHECK(ctx && (d_x || n == 0), "gaib_fill_f32: NULL argument");
   if (n <= 0) return GAIB_OK;
   fill_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, value, d_x);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_scale_f32(gaib_ctx* ctx, int64_t n, float alpha, float* d_x) {
+  GAIB_CHECK(ctx && (d_x || n == 0), "gaib_scale_f32: NULL argument");
+  if (n <= 0) return GAIB_OK;
+  scale_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, alpha, d_x);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }

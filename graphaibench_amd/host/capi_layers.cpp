@@ -1,5 +1,6 @@
 // capi_layers.cpp -- opaque-handle C API over the host C++ classes (include/gaib_layers.h).
 #include "gaib_layers.h"
+#include "partition.h"
 #include "graph_conv_layer.h"
 #include "host_util.h"
 #include "sampler.h"
@@ -164,6 +165,40 @@ uint32_t gaibl_sample_subgraph(uint32_t nv, uint32_t ne, const uint32_t* rowptr,
   return snv;
 }
 void gaibl_free_host(void* p) { free(p); }
+
+// ---- vertex-range partition (include/gnn/partition.h) ----
+void* gaibl_partition_build(uint32_t nv, const uint32_t* rowptr, const uint32_t* colidx, int rank, int world) {
+  return new VertexRangePartition(build_vertex_range_partition((int64_t)nv, rowptr, colidx, rank, world));
+}
+int64_t gaibl_partition_array(void* part, int which, const void** data) {
+  VertexRangePartition* P = static_cast<VertexRangePartition*>(part);
+#define ARR(v) { *data = (v).data(); return (int64_t)(v).size(); }
+  switch (which) {
+    case 0: ARR(P->rowptr_own)
+    case 1: ARR(P->colidx_own)
+    case 2: ARR(P->rowptr_halo)
+    case 3: ARR(P->colidx_halo)
+    case 4: ARR(P->degree)
+    case 5: ARR(P->halo_gids)
+    case 6: ARR(P->halo_degree)
+    case 7: ARR(P->recv_counts)
+    case 8: ARR(P->send_counts)
+    case 9: ARR(P->send_idx)
+    default: *data = nullptr; return -1;
+  }
+#undef ARR
+}
+void gaibl_partition_range(void* part, int64_t* lo, int64_t* hi) {
+  VertexRangePartition* P = static_cast<VertexRangePartition*>(part);
+  *lo = P->lo;
+  *hi = P->hi;
+}
+void gaibl_partition_free(void* part) { delete static_cast<VertexRangePartition*>(part); }
+void* gaibl_partition_make_graph(void* part, void* comm) {
+  return make_partitioned_graph(*static_cast<VertexRangePartition*>(part), static_cast<gaib_comm*>(comm));
+}
+void gaibl_set_comm(void* comm) { gpu_context::set_comm(static_cast<gaib_comm*>(comm)); }
+void* gaibl_graph_halo_plan(void* graph) { return static_cast<Graph*>(graph)->halo_plan(); }
 
 void* gaibl_adam_create(float lr) { return static_cast<optimizer*>(new adam(lr)); }
 void gaibl_adam_free(void* opt) { delete static_cast<optimizer*>(opt); }

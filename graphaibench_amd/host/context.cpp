@@ -8,6 +8,10 @@ std::map<char, double> time_ops;  // declared extern in include/gnn/global.h (re
 
 static gaib_ctx* g_ctx = nullptr;
 static bool g_sync_timers = false;
+static gaib_comm* g_comm = nullptr;
+
+void gpu_context::set_comm(gaib_comm* comm) { g_comm = comm; }
+gaib_comm* gpu_context::comm() { return g_comm; }
 
 void gpu_context::check(int status, const char* what) {
   if (status == GAIB_OK) return;

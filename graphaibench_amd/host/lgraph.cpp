@@ -12,6 +12,17 @@ LearningGraph* LearningGraph::adopt_device(gaib_graph* g) {
   return lg;
 }
 
+void LearningGraph::halo_begin(int len, const float* d_in) {
+  if (halo_plan_) GAIB_OR_DIE(gaib_halo_exchange_begin(halo_plan_, len, d_in));
+  else halo_begin_(halo_user_, len, d_in);
+}
+const float* LearningGraph::halo_end(int len) {
+  if (!halo_plan_) return halo_end_(halo_user_, len);
+  const float* table = NULL;
+  GAIB_OR_DIE(gaib_halo_exchange_end(halo_plan_, &table));
+  return table;
+}
+
 void LearningGraph::allocateFrom(index_t nv, index_t ne) {
   num_vertices_ = nv;
   num_edges_ = ne;

@@ -15,6 +15,8 @@ void adam::update_gpu(const size_t n, const float_t* dW, float_t* W) {
     it = dev_state.emplace(W, s).first;
   }
   assert(it->second.n == n);
+  // vertex-range partitions: the gradient of a replicated weight is the sum of the ranks' partial gradients
+  if (gaib_comm* cm = gpu_context::comm()) GAIB_OR_DIE(gaib_allreduce_f32(cm, const_cast<float_t*>(dW), (int64_t)n));
   GAIB_OR_DIE(gaib_adam_step(c, (int64_t)n, dW, W, it->second.m, it->second.v, alpha, b1, b2, b1_t, b2_t, eps));
   b1_t *= b1;  // once per call: a shared optimizer advances per layer (Q6)
   b2_t *= b2;

@@ -1,0 +1,144 @@
+// partition.cpp -- vertex-range partition builder of the multi-rank trainer (include/gnn/partition.h).
+#include <algorithm>
+#include <math.h>
+#include "partition.h"
+#include "host_util.h"
+
+std::vector<int64_t> vertex_range_bounds(int64_t n, int world) {
+  const int64_t per = (n + world - 1) / world;
+  std::vector<int64_t> b(world + 1);
+  for (int p = 0; p <= world; p++) b[p] = std::min<int64_t>((int64_t)p * per, n);
+  return b;
+}
+
+VertexRangePartition build_vertex_range_partition(int64_t n, const index_t* rowptr, const index_t* colidx, int rank,
+                                                  int world) {
+  VertexRangePartition P;
+  P.rank = rank;
+  P.world = world;
+  P.n_global = n;
+  const std::vector<int64_t> bounds = vertex_range_bounds(n, world);
+  P.lo = bounds[rank];
+  P.hi = bounds[rank + 1];
+  const int64_t n_own = P.hi - P.lo;
+  // ---- halo set: columns of the owned rows outside [lo, hi), ascending ----
+  std::vector<uint8_t> mark((size_t)n, 0);
+  for (int64_t v = P.lo; v < P.hi; v++)
+    for (index_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+      const index_t c = colidx[e];
+      if ((int64_t)c < P.lo || (int64_t)c >= P.hi) mark[c] = 1;
+    }
+  std::vector<int64_t> halo_slot((size_t)n, -1);  // global id -> position in halo_gids
+  for (int64_t v = 0; v < n; v++)
+    if (mark[v]) {
+      halo_slot[v] = (int64_t)P.halo_gids.size();
+      P.halo_gids.push_back(v);
+      P.halo_degree.push_back((int64_t)rowptr[v + 1] - (int64_t)rowptr[v]);
+    }
+  P.recv_counts.assign(world, 0);
+  for (int q = 0, k = 0; q < world; q++) {
+    while (k < (int)P.halo_gids.size() && P.halo_gids[k] < bounds[q + 1]) {
+      P.recv_counts[q]++;
+      k++;
+    }
+  }
+  // ---- the rows' edges split by column owner; the order of the edges inside a row is kept ----
+  P.rowptr_own.assign(n_own + 1, 0);
+  P.rowptr_halo.assign(n_own + 1, 0);
+  P.degree.resize(n_own);
+  for (int64_t i = 0; i < n_own; i++) {
+    const int64_t v = P.lo + i;
+    int64_t a = 0, b = 0;
+    for (index_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+      const index_t c = colidx[e];
+      ((int64_t)c >= P.lo && (int64_t)c < P.hi) ? a++ : b++;
+    }
+    P.rowptr_own[i + 1] = P.rowptr_own[i] + a;
+    P.rowptr_halo[i + 1] = P.rowptr_halo[i] + b;
+    P.degree[i] = a + b;
+  }
+  P.colidx_own.resize(std::max<int64_t>(P.rowptr_own[n_own], 1));
+  P.colidx_halo.resize(std::max<int64_t>(P.rowptr_halo[n_own], 1));
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t i = 0; i < n_own; i++) {
+    const int64_t v = P.lo + i;
+    int64_t a = P.rowptr_own[i], b = P.rowptr_halo[i];
+    for (index_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+      const index_t c = colidx[e];
+      if ((int64_t)c >= P.lo && (int64_t)c < P.hi) P.colidx_own[a++] = (index_t)(c - P.lo);
+      else P.colidx_halo[b++] = (index_t)halo_slot[c];
+    }
+  }
+  P.colidx_own.resize(P.rowptr_own[n_own]);
+  P.colidx_halo.resize(P.rowptr_halo[n_own]);
+  // ---- what every peer q will ask of this rank: the columns inside [lo, hi) that q's rows touch, ascending
+  //      (== the segment of q's halo_gids that this rank owns) ----
+  P.send_counts.assign(world, 0);
+  std::vector<uint8_t> want((size_t)std::max<int64_t>(n_own, 1));
+  for (int q = 0; q < world; q++) {
+    if (q == rank) continue;
+    std::fill(want.begin(), want.end(), 0);
+    for (int64_t v = bounds[q]; v < bounds[q + 1]; v++)
+      for (index_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+        const index_t c = colidx[e];
+        if ((int64_t)c >= P.lo && (int64_t)c < P.hi) want[c - P.lo] = 1;
+      }
+    for (int64_t i = 0; i < n_own; i++)
+      if (want[i]) {
+        P.send_idx.push_back(i);
+        P.send_counts[q]++;
+      }
+  }
+  return P;
+}
+
+// deg^-1/2 (0 for isolated vertices) and (float)(1.0 / float(deg)) with the roundings of compute_vertex_data
+// (src/gnn/lgraph.cpp:22-34) and sage_aggregator.cpp:18,44 -- the same expressions as csrc/graph.hip
+static void normalisers(const std::vector<int64_t>& deg, std::vector<float>& vd, std::vector<float>& inv) {
+  vd.resize(std::max<size_t>(deg.size(), 1));
+  inv.resize(std::max<size_t>(deg.size(), 1));
+  for (size_t i = 0; i < deg.size(); i++) {
+    const float t = sqrtf((float)deg[i]);
+    vd[i] = (t == 0.0f) ? 0.0f : (float)(1.0 / (double)t);
+    inv[i] = (float)(1.0 / (double)(float)deg[i]);
+  }
+}
+
+static float* upload(const std::vector<float>& h) {
+  float* d = gaib_host::dmalloc<float>(h.size());
+  GAIB_OR_DIE(gaib_memcpy_h2d(gpu_context::get(), d, h.data(), sizeof(float) * h.size()));
+  return d;
+}
+
+LearningGraph* make_partitioned_graph(const VertexRangePartition& P, gaib_comm* comm) {
+  gaib_ctx* ctx = gpu_context::get();
+  const int64_t n_own = P.n_own(), n_halo = P.n_halo();
+  std::vector<float> vd, inv, vd_h, inv_h;
+  normalisers(P.degree, vd, inv);
+  normalisers(P.halo_degree, vd_h, inv_h);
+  float *d_vd = upload(vd), *d_inv = upload(inv), *d_vd_h = upload(vd_h), *d_inv_h = upload(inv_h);
+  gaib_graph* g_own = nullptr;
+  const index_t dummy = 0;
+  GAIB_OR_DIE(gaib_graph_create(ctx, n_own, (int64_t)P.colidx_own.size(), P.rowptr_own.data(), 64,
+                                P.colidx_own.empty() ? &dummy : P.colidx_own.data(), 0, &g_own));
+  GAIB_OR_DIE(gaib_graph_set_vertex_norm(ctx, g_own, d_vd, d_inv, d_vd, d_inv));
+  LearningGraph* lg = LearningGraph::adopt_device(g_own);
+  if (P.world > 1) {
+    if (!comm) {
+      fprintf(stderr, "make_partitioned_graph: world %d needs a communicator\n", P.world);
+      exit(EXIT_FAILURE);
+    }
+    // every rank takes part in every exchange, also one without halo rows of its own
+    gaib_graph* g_halo = nullptr;
+    GAIB_OR_DIE(gaib_graph_create_rect(ctx, n_own, std::max<int64_t>(n_halo, 1), (int64_t)P.colidx_halo.size(),
+                                       P.rowptr_halo.data(), 64, P.colidx_halo.empty() ? &dummy : P.colidx_halo.data(), 0,
+                                       &g_halo));
+    GAIB_OR_DIE(gaib_graph_set_vertex_norm(ctx, g_halo, d_vd, d_inv, d_vd_h, d_inv_h));
+    gaib_halo* plan = nullptr;
+    GAIB_OR_DIE(gaib_halo_create(comm, P.send_counts.data(), P.send_idx.data(), 0, P.recv_counts.data(), &plan));
+    lg->set_halo_plan(g_halo, plan);
+  }
+  float* tmp[] = {d_vd, d_inv, d_vd_h, d_inv_h};  // set_vertex_norm copied them
+  for (float* p : tmp) GAIB_OR_DIE(gaib_free(ctx, p));
+  return lg;
+}

@@ -11,7 +11,20 @@
 // [l2norm -> dense for GAT] -> softmax loss; masks are the contiguous ranges of graph.meta.txt;
 // GCN/GAT share one Adam instance across layers, GraphSAGE layers own theirs (quirk Q6).
 // Architecture is a compile-time choice like in the reference: -DUSE_SAGE / -DUSE_GAT.
+//
+// One process per GPU (no reference counterpart): launched N times with RANK / WORLD_SIZE / LOCAL_RANK
+// (torchrun's variables; GAIB_RANK / GAIB_WORLD override), GCN and GraphSAGE train on a vertex-range partition:
+// every rank reads the (global) dataset, keeps the rows [lo, hi) of its range (include/gnn/partition.h), exchanges
+// halo feature rows before every aggregation and sums the weight gradients before every optimizer step, all behind
+// the C ABI (gaib_comm_* / gaib_halo_* / gaib_allreduce_f32; transport GAIB_COMM=rccl|ipc).  The run's ncclUniqueId
+// travels from rank 0 to the others through the file GAIB_COMM_ID_FILE (default /dev/shm/gaib_id_<MASTER_PORT>).
+// Loss / accuracy are all-reduced; rank 0 prints the reference's log lines.  Any rank that fails exits non-zero and
+// the others follow (deadline in every wait).
 #include <omp.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include "partition.h"
 #include "cutils.h"
 #include "dense_layer.h"
 #include "graph_conv_layer.h"
@@ -70,6 +83,73 @@ struct Trainer {
   loss_layer* loss = nullptr;  // softmax (single label) or sigmoid (multi label, argv[4])
   bool is_sigmoid = false;
   size_t label_width = 1;      // bytes of label per vertex: 1, or num_cls for multi-hot rows
+  // one process per GPU
+  int rank = 0, world = 1;
+  gaib_comm* comm = nullptr;
+  VertexRangePartition part;
+  size_t g_train_begin = 0, g_train_end = 0, g_val_begin = 0, g_val_end = 0, g_test_begin = 0, g_test_end = 0;  // global
+  bool root() const { return rank == 0; }
+
+  static int env_int(const char* a, const char* b, int dflt) {
+    const char* v = getenv(a);
+    if (!v && b) v = getenv(b);
+    return v ? atoi(v) : dflt;
+  }
+
+  // rank 0 draws the communicator id and hands it to the other ranks through a file (one node)
+  void init_comm() {
+    rank = env_int("GAIB_RANK", "RANK", 0);
+    world = env_int("GAIB_WORLD", "WORLD_SIZE", 1);
+    if (world <= 1) return;
+    if (ARCH == gnn_arch::GAT) {
+      std::cerr << "GAT on a vertex-range partition is not in this trainer (see graphaibench_amd/dist.py)\n";
+      exit(EXIT_FAILURE);
+    }
+    const char* tr = getenv("GAIB_COMM");
+    const int transport = (tr && std::string(tr) == "ipc") ? GAIB_COMM_IPC : GAIB_COMM_RCCL;
+    std::string path = getenv("GAIB_COMM_ID_FILE") ? getenv("GAIB_COMM_ID_FILE")
+                                                  : std::string("/dev/shm/gaib_id_") +
+                                                        (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "default");
+    unsigned char id[GAIB_COMM_ID_BYTES];
+    if (rank == 0) {
+      GAIB_OR_DIE(gaib_comm_unique_id(transport, id));
+      const std::string tmp = path + ".tmp";
+      FILE* f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) {
+        std::cerr << "cannot write " << tmp << "\n";
+        exit(EXIT_FAILURE);
+      }
+      fclose(f);
+      rename(tmp.c_str(), path.c_str());
+    } else {
+      const double deadline = omp_get_wtime() + 120.0;
+      size_t got = 0;
+      while (omp_get_wtime() < deadline) {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (f) {
+          got = fread(id, 1, sizeof(id), f);
+          fclose(f);
+          if (got == sizeof(id)) break;
+        }
+        usleep(2000);
+      }
+      if (got != sizeof(id)) {
+        std::cerr << "rank " << rank << ": no communicator id at " << path << " after 120 s\n";
+        exit(EXIT_FAILURE);
+      }
+    }
+    GAIB_OR_DIE(gaib_comm_init(gpu_context::get(), rank, world, id, transport, &comm));
+    if (rank == 0) unlink(path.c_str());  // gaib_comm_init is collective: everybody has read it
+    gpu_context::set_comm(comm);
+  }
+
+  // intersect a global mask range with this rank's rows, in local row ids
+  void local_range(size_t gb, size_t ge, size_t& b, size_t& e) const {
+    const size_t lo = (size_t)part.lo, hi = (size_t)part.hi;
+    const size_t x = std::max(gb, lo), y = std::min(ge, hi);
+    b = x < y ? x - lo : 0;
+    e = x < y ? y - lo : 0;
+  }
 
   void parse(int argc, char** argv) {
     dataset = argv[1];
@@ -92,6 +172,11 @@ struct Trainer {
     // l2norm + dense head for sampling and GAT (net.cpp:69-71)
     if (subg_size > 0 || ARCH == gnn_arch::GAT) use_l2norm = use_dense = true;
     if (subg_size > 0) inductive = 1;  // net.cpp:160
+    init_comm();
+    if (world > 1 && (subg_size > 0 || inductive)) {
+      std::cerr << "subgraph sampling / inductive training run on one GPU only\n";
+      exit(EXIT_FAILURE);
+    }
   }
 
   void load() {
@@ -106,7 +191,7 @@ struct Trainer {
     label_width = is_sigmoid ? (size_t)num_cls : 1;
     if (ARCH != gnn_arch::SAGE) graph->add_selfloop();  // net.cpp:96
     graph->degree_counting();
-    std::cout << "num_threads = " << num_threads << ", num_vertices = " << num_samples
+    if (root()) std::cout << "num_threads = " << num_threads << ", num_vertices = " << num_samples
               << ", num_edges = " << graph->sizeEdges() << ", num_layers = " << num_layers
               << ", \nnum_epochs = " << num_epochs << ", input_length = " << dim_init
               << ", hidden_length = " << dim_hid << ", num_classes = " << num_cls
@@ -120,6 +205,35 @@ struct Trainer {
       std::cerr << "dataset has no features (feat_len = 0 in graph.meta.txt)\n";
       exit(1);
     }
+    g_train_begin = train_begin, g_train_end = train_end;
+    g_val_begin = val_begin, g_val_end = val_end;
+    g_test_begin = test_begin, g_test_end = test_end;
+    if (world > 1) {
+      // this rank's share: rows [lo, hi) of the global CSR, features / labels / masks of the same rows
+      part = build_vertex_range_partition(num_samples, graph->row_start_host_ptr(), graph->edge_dst_host_ptr(), rank, world);
+      Graph* global = graph;
+      graph = make_partitioned_graph(part, comm);
+      global->dealloc();
+      delete global;
+      const size_t lo = (size_t)part.lo, n_own = (size_t)part.n_own();
+      feats.erase(feats.begin(), feats.begin() + lo * dim_init);
+      feats.resize(n_own * dim_init);
+      labels.erase(labels.begin(), labels.begin() + lo * label_width);
+      labels.resize(n_own * label_width);
+      auto cut = [&](std::vector<mask_t>& m) {
+        m.erase(m.begin(), m.begin() + lo);
+        m.resize(n_own);
+      };
+      cut(mtrain), cut(mval), cut(mtest);
+      local_range(g_train_begin, g_train_end, train_begin, train_end);
+      local_range(g_val_begin, g_val_end, val_begin, val_end);
+      local_range(g_test_begin, g_test_end, test_begin, test_end);
+      printf("rank %d of %d: rows [%lld, %lld), %zu owned-column + %zu halo-column edges, %lld halo rows in, %zu rows out "
+             "per exchange\n", rank, world, (long long)part.lo, (long long)part.hi, part.colidx_own.size(),
+             part.colidx_halo.size(), (long long)part.n_halo(), part.send_idx.size());
+      fflush(stdout);
+      num_samples = (int)n_own;
+    }
     // transfer_data_to_device (net.cpp:206-227)
     float_malloc_device64((size_t)num_samples * dim_init, d_features);
     GAIB_OR_DIE(gaib_memcpy_h2d(gpu_context::get(), d_features, feats.data(), sizeof(float) * feats.size()));
@@ -128,9 +242,11 @@ struct Trainer {
     copy_masks_device(num_samples, mtrain.data(), d_masks_train);
     copy_masks_device(num_samples, mval.data(), d_masks_val);
     copy_masks_device(num_samples, mtest.data(), d_masks_test);
-    graph->alloc_on_device();
-    graph->copy_to_gpu();
-    graph->compute_vertex_data();
+    if (world == 1) {
+      graph->alloc_on_device();
+      graph->copy_to_gpu();
+      graph->compute_vertex_data();
+    }
     training_graph = graph;
     if (inductive) {
       training_graph = graph->generate_masked_graph(mtrain.data());
@@ -216,7 +332,7 @@ struct Trainer {
   }
 
   void construct() {
-    std::cout << "constructing neural network...\n";
+    if (root()) std::cout << "constructing neural network...\n";
     const int nv = subg_size > 0 ? subg_size : num_samples;  // buffers grow on demand (update_dim_size)
     for (int l = 0; l < num_layers - 1; l++)
       layers.push_back(gconv_t(l, nv, l == 0 ? dim_init : dim_hid, dim_hid, training_graph, true, lrate, feat_drop,
@@ -266,8 +382,36 @@ struct Trainer {
       return accuracy(0, subg_nv, subg_nv, NULL, d_labels_subg);
     }
     loss->forward(train_begin, train_end, d_masks_train);
+    if (world > 1) return reduced_metrics(train_begin, train_end, g_train_end - g_train_begin, d_masks_train, &loss_value);
     loss_value = loss->get_prediction_loss(train_begin, train_end, train_count, d_masks_train);
     return accuracy(train_begin, train_end, train_count, d_masks_train, d_labels);
+  }
+
+  // partitioned run: this rank's part [b, e) of a global mask range of `global_len` vertices (masks are the contiguous
+  // ranges of graph.meta.txt, Q5, so every vertex of the range counts).  Loss sum and hit / tp-fp-fn counts are summed
+  // over the ranks; returns the accuracy (micro F1 for the sigmoid head), *loss_value = mean loss.
+  acc_t reduced_metrics(size_t b, size_t e, size_t global_len, mask_t* masks, acc_t* loss_value) {
+    gaib_ctx* c = gpu_context::get();
+    double v[5] = {0, 0, 0, 0, 0};  // loss sum, hits, tp, fp, fn
+    const double n_local = (double)(e - b);
+    if (loss_value && e > b) v[0] = (double)loss->get_prediction_loss(b, e, e - b, masks) * n_local;
+    if (e > b) {
+      if (is_sigmoid) {
+        float f1 = 0.f;
+        int64_t cnt[3] = {0, 0, 0};
+        GAIB_OR_DIE(gaib_masked_f1_micro(c, (int64_t)b, (int64_t)e, num_cls, masks, loss->get_feat_out(), d_labels, &f1, cnt));
+        v[2] = (double)cnt[0], v[3] = (double)cnt[1], v[4] = (double)cnt[2];
+      } else {
+        v[1] = (double)masked_accuracy_single(b, e, e - b, num_cls, masks, loss->get_feat_in(), d_labels) * n_local;
+      }
+    }
+    GAIB_OR_DIE(gaib_allreduce_host_f64(comm, v, 5));
+    if (loss_value) *loss_value = (acc_t)(v[0] / (double)global_len);
+    if (is_sigmoid) {  // f1_micro of the summed counts (math_functions.cpp:580-621)
+      const double prec = v[2] + v[3] > 0 ? v[2] / (v[2] + v[3]) : 0., rec = v[2] + v[4] > 0 ? v[2] / (v[2] + v[4]) : 0.;
+      return (acc_t)(prec + rec > 0 ? 2. * prec * rec / (prec + rec) : 0.);
+    }
+    return (acc_t)(v[1] / (double)global_len);
   }
 
   void backward_prop() {
@@ -275,15 +419,25 @@ struct Trainer {
     mask_t* tm = subg_size > 0 ? NULL : d_masks_train;
     if (use_dense) {
       loss->backward(tb, te, tm, dense->get_grad_in());
+      rescale_loss_grad(dense->get_grad_in(), tb, te);
       dense->backward(l2->get_grad_in());
       l2->backward(layers[num_layers - 1].get_grad_in());
       layers[num_layers - 1].backward(l2->get_feat_in(), layers[num_layers - 2].get_grad_in());
     } else {
       loss->backward(tb, te, tm, layers[num_layers - 1].get_grad_in());
+      rescale_loss_grad(layers[num_layers - 1].get_grad_in(), tb, te);
       layers[num_layers - 1].backward(loss->get_feat_in(), layers[num_layers - 2].get_grad_in());
     }
     for (int l = num_layers - 2; l > 0; l--) layers[l].backward(layers[l + 1].get_feat_in(), layers[l - 1].get_grad_in());
     layers[0].backward(layers[1].get_feat_in(), NULL);
+  }
+
+  // the loss gradient is divided by (end - begin) of the range it was called on (softmax_loss_layer.cpp:31, Q8): a
+  // rank's local share of the range -> the global range
+  void rescale_loss_grad(float* grad, size_t b, size_t e) {
+    if (world == 1 || e <= b) return;
+    const float a = (float)((double)(e - b) / (double)(g_train_end - g_train_begin));
+    GAIB_OR_DIE(gaib_scale_f32(gpu_context::get(), (int64_t)num_samples * num_cls, a, grad));
   }
 
   acc_t evaluate(const std::string& type) {
@@ -294,6 +448,7 @@ struct Trainer {
     const size_t b = test ? test_begin : val_begin, e = test ? test_end : val_end, c = test ? test_count : val_count;
     mask_t* m = test ? d_masks_test : d_masks_val;
     if (is_sigmoid) loss->forward(b, e, m);  // the F1 reads the sigmoid outputs (net.cpp:569-572)
+    if (world > 1) return reduced_metrics(b, e, test ? g_test_end - g_test_begin : g_val_end - g_val_begin, m, NULL);
     return accuracy(b, e, c, m, d_labels);
   }
 
@@ -361,6 +516,7 @@ int main(int argc, char* argv[]) {
   std::cout << "Using " << ARCH_NAME << "\n";
   Trainer t;
   t.parse(argc, argv);
+  if (!t.root()) std::cout.setstate(std::ios_base::failbit);  // rank 0 prints the log lines
   t.load();
   t.construct();
   double t1 = omp_get_wtime();
@@ -372,5 +528,10 @@ int main(int argc, char* argv[]) {
   double tt2 = omp_get_wtime();
   std::cout << "Test accuracy: " << test_acc << "  test time: " << tt2 - tt1 << " seconds\n";
   if (getenv("GAIB_SYNC_TIMERS") && atoi(getenv("GAIB_SYNC_TIMERS"))) print_timers();
+  if (t.comm) {
+    GAIB_OR_DIE(gaib_comm_barrier(t.comm));
+    if (t.graph->halo_plan()) gaib_halo_destroy(t.graph->halo_plan());
+    gaib_comm_destroy(t.comm);
+  }
   return 0;
 }

@@ -38,6 +38,13 @@ SIGNATURES = {
     "gaibl_sample_subgraph": (C.c_uint32, [C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint,
                                            C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "gaibl_free_host": (None, [_vp]),
+    "gaibl_partition_build": (_vp, [C.c_uint32, _vp, _vp, _i, _i]),
+    "gaibl_partition_array": (C.c_int64, [_vp, _i, C.POINTER(_vp)]),
+    "gaibl_partition_range": (None, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gaibl_partition_free": (None, [_vp]),
+    "gaibl_partition_make_graph": (_vp, [_vp, _vp]),
+    "gaibl_set_comm": (None, [_vp]),
+    "gaibl_graph_halo_plan": (_vp, [_vp]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
     "gaibl_time_op": (C.c_double, [C.c_char]),
@@ -179,6 +186,54 @@ class Layer:
         c = capi.load()
         capi._check(c.gaib_memcpy_d2d(self.lib.gaibl_ctx(), p, src.data_ptr(), src.numel() * 4), "gaib_memcpy_d2d")
         sync()
+
+
+class HostPartition:
+    """VertexRangePartition (include/gnn/partition.h): one rank's share of a vertex-range partitioned graph, built by
+    the host C++ from the GLOBAL CSR without communication.  Arrays come back as numpy copies."""
+
+    _NAMES = ("rowptr_own", "colidx_own", "rowptr_halo", "colidx_halo", "degree", "halo_gids", "halo_degree",
+              "recv_counts", "send_counts", "send_idx")
+
+    def __init__(self, rowptr, colidx, rank: int, world: int):
+        import numpy as np
+
+        rp = np.ascontiguousarray(rowptr, dtype=np.uint32)
+        ci = np.ascontiguousarray(colidx, dtype=np.uint32)
+        self.lib = load()
+        self.rank, self.world = rank, world
+        self.h = self.lib.gaibl_partition_build(len(rp) - 1, rp.ctypes.data, ci.ctypes.data if len(ci) else None, rank,
+                                                world)
+        lo, hi = C.c_int64(), C.c_int64()
+        self.lib.gaibl_partition_range(self.h, C.byref(lo), C.byref(hi))
+        self.lo, self.hi = lo.value, hi.value
+        for which, name in enumerate(self._NAMES):
+            ptr = _vp()
+            n = self.lib.gaibl_partition_array(self.h, which, C.byref(ptr))
+            dt = np.uint32 if name.startswith("colidx") else np.int64
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32 if dt == np.uint32 else C.c_int64)),
+                                        (n,)).copy() if n > 0 else np.zeros(0, dt)
+            setattr(self, name, arr.astype(dt, copy=False))
+
+    def make_graph(self, comm=None) -> "LGraph":
+        """upload + halo plan on `comm` (capi.Comm, None for world 1) -> LearningGraph"""
+        return LGraph(self.lib.gaibl_partition_make_graph(self.h, comm.h if comm is not None else None))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gaibl_partition_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def set_comm(comm) -> None:
+    """gpu_context::set_comm: every optimizer step of the C++ layers first sums its gradient over the ranks"""
+    load().gaibl_set_comm(comm.h if comm is not None else None)
 
 
 def adam(lr: float):

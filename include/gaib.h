@@ -34,7 +34,8 @@ typedef enum {
   GAIB_ERR_HIP = -2,     /* a HIP runtime call failed */
   GAIB_ERR_NOMEM = -3,
   GAIB_ERR_ASYMMETRIC = -4, /* edge_transpose: reverse edge missing (math_functions.cpp:70 assert) */
-  GAIB_ERR_UNSUPPORTED = -5
+  GAIB_ERR_UNSUPPORTED = -5,
+  GAIB_ERR_COMM = -6 /* a collective failed, a peer reported a failure or did not arrive in time */
 } gaib_status;
 
 typedef struct gaib_ctx gaib_ctx;     /* device + stream + workspace              */
@@ -72,6 +73,9 @@ int gaib_memcpy_h2d(gaib_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
 int gaib_memcpy_d2h(gaib_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* syncs */
 int gaib_memcpy_d2d(gaib_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int gaib_fill_f32(gaib_ctx* ctx, int64_t n, float value, float* d_x);
+/* x <- alpha * x  (scale, math_functions.cpp:336-356 / scal_gpu; the partitioned trainer rescales the loss gradient
+ * from 1/(local range) to 1/(global range), softmax_loss_layer.cpp:31) */
+int gaib_scale_f32(gaib_ctx* ctx, int64_t n, float alpha, float* d_x);
 
 /* ---- graph: LearningGraph's device half (include/gnn/lgraph.h:20-277) ------------------
  * gaib_graph_create  = alloc_on_device + copy_to_gpu (src/gnn/lgraph.cu:51-92).
@@ -291,6 +295,54 @@ int gaib_adam_step(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, floa
  * pack rows for the halo exchange: d_out[k,:] = d_in[d_idx[k],:] */
 int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_idx, int len,
                      const float* d_in, float* d_out);
+
+/* ---- collectives of the vertex-range partitioned path ("halo_exchange(handle,D,buf)",
+ * "allreduce(buf,n)"; 8e) -------------------------------------------------------------------------------------
+ * One process per GPU.  The reference has no multi-GPU GNN; the partition scheme is its
+ * PartitionedGraph::edgecut_induced_partition1D (src/partitioner/graph_partition.cc:128-178), the host pattern it uses
+ * for multi-GPU work is one host thread per device with peer copies (src/triangle/multigpu_induced.cu:31-84).
+ *
+ * Transports:
+ *   GAIB_COMM_RCCL  RCCL (ncclSend/ncclRecv groups, ncclAllReduce) on a communication stream; ONE GPU PER RANK
+ *                   (RCCL refuses two ranks on one device: gaib_comm_init then fails on every rank); stream-ordered.
+ *   GAIB_COMM_IPC   peer-to-peer pull through hipIpc handles published in POSIX shared memory (one node; xGMI
+ *                   between GPUs, plain device copies when ranks share a GPU -- tests); host-synchronous hand-overs.
+ * gaib_comm_unique_id is called by ONE rank; the caller carries the GAIB_COMM_ID_BYTES to the other ranks (a file,
+ * MPI, torch.distributed's store ...).  gaib_comm_init is collective.  Every collective below must be called by
+ * every rank in the same order.  A rank that fails or does not arrive within GAIB_COMM_TIMEOUT_S (default 120 s)
+ * makes the waiting ranks return GAIB_ERR_COMM instead of hanging. */
+typedef struct gaib_comm gaib_comm;
+typedef struct gaib_halo gaib_halo;
+#define GAIB_COMM_ID_BYTES 128
+#define GAIB_COMM_RCCL 0
+#define GAIB_COMM_IPC 1
+int gaib_comm_unique_id(int transport, void* h_id);
+int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h_id, int transport, gaib_comm** out);
+int gaib_comm_destroy(gaib_comm* comm);
+int gaib_comm_rank(const gaib_comm* comm);
+int gaib_comm_size(const gaib_comm* comm);
+int gaib_comm_barrier(gaib_comm* comm); /* syncs the compute stream first */
+/* in-place sum over ranks on the context's stream: the weight / alpha gradients of a layer (<= 256 KB each);
+ * every rank ends with the same bits */
+int gaib_allreduce_f32(gaib_comm* comm, float* d_buf, int64_t n);
+/* host scalars (masked loss sums, accuracy counts): in-place sum over ranks, n <= 1024; syncs */
+int gaib_allreduce_host_f64(gaib_comm* comm, double* h_buf, int n);
+/* A halo plan: which of this rank's rows go to which peer and how many rows arrive from each peer.
+ *   h_send_counts[r] rows go to rank r: their local row ids are send_idx[sum(h_send_counts[:r]) ...] (host or device
+ *   array, copied); h_recv_counts[r] rows arrive from rank r; both 0 for the rank itself.  The table an exchange fills
+ *   is [sum(h_recv_counts) x len], grouped by source rank in rank order -- the order of the halo column ids of
+ *   gaib_graph_create_rect's column space after the owned rows.  Collective; plans are numbered in creation order. */
+int gaib_halo_create(gaib_comm* comm, const int64_t* h_send_counts, const int64_t* send_idx, int idx_on_device,
+                     const int64_t* h_recv_counts, gaib_halo** out);
+int gaib_halo_destroy(gaib_halo* halo);
+int64_t gaib_halo_rows(const gaib_halo* halo);      /* rows of the halo table */
+int64_t gaib_halo_send_rows(const gaib_halo* halo); /* rows this rank packs per exchange */
+int64_t gaib_halo_bytes_sent(const gaib_halo* halo);
+/* one exchange = begin (pack the requested rows of d_rows [n_own x len] on the compute stream, start moving them)
+ * ... independent work on the compute stream (the owned-column edges of the aggregation) ... end (the compute stream
+ * continues only after the halo rows have arrived; *d_table stays valid until the next begin on this plan). */
+int gaib_halo_exchange_begin(gaib_halo* halo, int len, const float* d_rows);
+int gaib_halo_exchange_end(gaib_halo* halo, const float** d_table);
 
 /* ---- in-stream kernel timing (measurement only) -----------------------------------------------
  * When enabled, the aggregation entry points bracket each kernel launch with a HIP event pair

@@ -43,6 +43,20 @@ typedef const float* (*gaibl_halo_end_fn)(void* user, int len);
 void gaibl_graph_set_halo(void* graph, void* halo_graph, gaibl_halo_begin_fn begin, gaibl_halo_end_fn end,
                           void* user);
 
+/* vertex-range partition built on the host (include/gnn/partition.h): every rank derives its share from the global
+ * CSR.  gaibl_partition_array: which = 0 rowptr_own (int64) 1 colidx_own (uint32) 2 rowptr_halo (int64) 3 colidx_halo
+ * (uint32) 4 degree 5 halo_gids 6 halo_degree 7 recv_counts 8 send_counts 9 send_idx (all int64); returns the element
+ * count, *data points into the partition object.  gaibl_partition_make_graph uploads it and creates the halo plan on
+ * `comm` (a gaib_comm*, NULL for world 1) -> LearningGraph*.  gaibl_set_comm: gpu_context::set_comm (every optimizer
+ * step all-reduces its gradient first). */
+void* gaibl_partition_build(uint32_t nv, const uint32_t* rowptr, const uint32_t* colidx, int rank, int world);
+int64_t gaibl_partition_array(void* part, int which, const void** data);
+void gaibl_partition_range(void* part, int64_t* lo, int64_t* hi);
+void gaibl_partition_free(void* part);
+void* gaibl_partition_make_graph(void* part, void* comm);
+void gaibl_set_comm(void* comm);
+void* gaibl_graph_halo_plan(void* graph); /* gaib_halo* or NULL */
+
 void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
                          float feat_drop, float score_drop);
 void gaibl_layer_forward(void* layer, float* d_feat_out);

@@ -17,5 +17,11 @@ class gpu_context {
   static void side_end();
   static void side_wait();
   static void check(int status, const char* what); // non-zero -> print + exit (cutils.h:18-28)
+  // one-process-per-GPU training: the communicator of this rank (NULL = single GPU).  While it is set, every
+  // optimizer step first sums its gradient buffer over the ranks (gaib_allreduce_f32: weights and Adam state stay
+  // replicated and bit-identical on all ranks), and LearningGraphs built by make_partitioned_graph exchange halo rows
+  // on it.  The context borrows it.
+  static void set_comm(gaib_comm* comm);
+  static gaib_comm* comm();
 };
 #define GAIB_OR_DIE(call) gpu_context::check((call), #call)

@@ -29,13 +29,14 @@ class LearningGraph {
   void (*halo_begin_)(void* user, int len, const float* d_in);
   const float* (*halo_end_)(void* user, int len);
   void* halo_user_;
+  gaib_halo* halo_plan_;  // the exchange behind the C ABI (gaib_halo_exchange_begin/end); set_halo_plan
 
  public:
   typedef size_t iterator;
   LearningGraph(bool use_gpu)
       : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
         colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_dev_(NULL),
-        halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL) {}
+        halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL) {}
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -82,10 +83,17 @@ class LearningGraph {
     halo_end_ = end;
     halo_user_ = user;
   }
+  // the same with the exchange running behind the C ABI (gaib_comm / gaib_halo: RCCL or peer-to-peer pull);
+  // the callback form above stays for launchers that bring their own transport (torch.distributed in dist.py)
+  void set_halo_plan(gaib_graph* halo_graph, gaib_halo* plan) {
+    halo_dev_ = halo_graph;
+    halo_plan_ = plan;
+  }
+  gaib_halo* halo_plan() { return halo_plan_; }
   bool has_halo() const { return halo_dev_ != NULL; }
   gaib_graph* halo_graph() { return halo_dev_; }
-  void halo_begin(int len, const float* d_in) { halo_begin_(halo_user_, len, d_in); }
-  const float* halo_end(int len) { return halo_end_(halo_user_, len); }
+  void halo_begin(int len, const float* d_in);
+  const float* halo_end(int len);
   // device pointers, as the reference's ENABLE_GPU accessors return them.  Row pointers are
   // int64 in HBM (the reference's uint32 offsets overflow past 2^32 edges*features).
   const int64_t* row_start_ptr() const { return gaib_graph_rowptr(dev_); }

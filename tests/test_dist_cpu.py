@@ -178,3 +178,39 @@ def test_partition_matches_live_reference(nv, parts):
     ref_parts = [dict(range=np.array([r["begin"], r["end"]]), idx_map=r["idx_map"], rowptr=r["rowptr"],
                       colidx=r["colidx"]) for r in ref]
     _check_against_reference_parts(rp, ci, parts, ref_parts)
+
+
+# ---- the host C++ partition builder of the multi-rank trainer (include/gnn/partition.h) --------------------------
+@pytest.mark.parametrize("nv,world", [(1000, 2), (777, 3), (4096, 8), (50, 8)])
+def test_cpp_partition_equals_dist_py(nv, world):
+    """build_vertex_range_partition (host C++, no communication: every rank derives its share from the global CSR)
+    == dist.py's split (pinned against the reference partitioner above), and the ranks' send / receive lists mirror
+    each other."""
+    from graphaibench_amd import dist as gd, layers as L
+    from util import random_graph
+
+    rp, ci = random_graph(nv, 7, seed=nv + world, power_law=True)
+    bounds = gd.partition_bounds(nv, world)
+    parts = [L.HostPartition(rp, ci, r, world) for r in range(world)]
+    for r, P in enumerate(parts):
+        lo, hi = bounds[r], bounds[r + 1]
+        assert (P.lo, P.hi) == (lo, hi)
+        rpl = torch.from_numpy((rp[lo:hi + 1] - rp[lo]).astype(np.int64))
+        cg = torch.from_numpy(ci[rp[lo]:rp[hi]].astype(np.int64))
+        rp_own, ci_own, rp_halo, ci_halo, halo, deg = gd.split_by_owner(rpl, cg, lo, hi)
+        assert np.array_equal(P.rowptr_own, rp_own.numpy()) and np.array_equal(P.rowptr_halo, rp_halo.numpy())
+        assert np.array_equal(P.colidx_own, ci_own.numpy().view(np.uint32))
+        assert np.array_equal(P.colidx_halo, ci_halo.numpy().view(np.uint32))
+        assert np.array_equal(P.halo_gids, halo.numpy()) and np.array_equal(P.degree, deg.numpy())
+        assert np.array_equal(P.halo_degree, np.diff(rp)[P.halo_gids])
+        owner = np.searchsorted(np.asarray(bounds), P.halo_gids, side="right") - 1
+        assert np.array_equal(P.recv_counts, np.bincount(owner, minlength=world))
+        assert P.recv_counts[r] == 0 and P.send_counts[r] == 0
+    for p in range(world):
+        off = np.concatenate([[0], np.cumsum(parts[p].send_counts)])
+        for q in range(world):
+            assert parts[p].send_counts[q] == parts[q].recv_counts[p]
+            # what p packs for q is exactly the segment of q's halo list that p owns, in q's order
+            mine = parts[p].send_idx[off[q]:off[q + 1]] + parts[p].lo
+            theirs = parts[q].halo_gids[(parts[q].halo_gids >= parts[p].lo) & (parts[q].halo_gids < parts[p].hi)]
+            assert np.array_equal(mine, theirs)

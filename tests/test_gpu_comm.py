@@ -1,0 +1,158 @@
+"""GPU suite: the collectives behind the C ABI (include/gaib.h: gaib_comm_* / gaib_halo_* / gaib_allreduce_*) and the
+host C++ partition builder + layers on top of them (SURVEY.md 8b "halo_exchange / allreduce", 8e).
+
+One GPU is all this box has, so:
+  * the IPC transport (peer-to-peer pull through hipIpc handles) runs for real with 2 and 3 PROCESSES sharing cuda:0:
+    partition -> LearningGraph with a halo plan -> C++ GCN / SAGE layer forward + backward + optimizer step, against the
+    oracle's GLOBAL result;
+  * the RCCL transport runs with one rank (init, all-reduce, an exchange without peers): RCCL refuses two ranks on
+    one device, which the two-rank case asserts as a clean error on both ranks;
+  * a rank whose peer never arrives returns GAIB_ERR_COMM within the deadline instead of hanging.
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _id_via_file(path, rank, transport, capi):
+    """rank 0 draws the id, the others read it (what the C++ trainer does with GAIB_COMM_ID_FILE)"""
+    if rank == 0:
+        uid = capi.comm_unique_id(transport)
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        if os.path.exists(path) and os.path.getsize(path) == 128:
+            return open(path, "rb").read()
+        time.sleep(0.005)
+    raise RuntimeError("no communicator id")
+
+
+def _worker(rank, world, idfile, q, arch, transport_name):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    try:
+        from graphaibench_amd import capi, layers as L
+        from oracle import binding as orc
+        from util import LONG_SUM_FLOOR, assert_close, random_graph
+
+        transport = capi.COMM_IPC if transport_name == "ipc" else capi.COMM_RCCL
+        ctx = L.init(0)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
+        # raw collectives first
+        t = torch.full((70000,), float(rank + 1), device="cuda")  # > one 64 K staging chunk
+        comm.allreduce(t)
+        assert torch.all(t == world * (world + 1) / 2)
+        assert comm.allreduce_host([1.0, float(rank)]) == [float(world), world * (world - 1) / 2]
+        L.set_comm(comm)
+
+        rp, ci = random_graph(3000, 16, seed=13, power_law=True, hub_deg=1500)
+        g = orc.Graph(rp, ci)
+        if arch == "gcn":
+            g = g.add_selfloop()  # (SAGE aggregates over A, net.cpp:96)
+        n, D = g.nv, 128
+        x = np.random.default_rng(5).standard_normal((n, D)).astype(np.float32)
+        gin = np.random.default_rng(6).standard_normal((n, D)).astype(np.float32)
+        lo_ = (orc.GCNLayer if arch == "gcn" else orc.SAGELayer)(1, g, D, D, True)
+        want = lo_.forward(x)
+        want_go = lo_.backward(gin.copy())
+        part = L.HostPartition(g.rowptr, g.colidx, rank, world)
+        lo, hi = part.lo, part.hi
+        lg = part.make_graph(comm)
+        layer = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, hi - lo, D, D, lg, True)
+        W0 = layer.tensor(L.W_NEIGH, (D, D)).clone()
+        layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+        out = torch.empty(hi - lo, D, device="cuda")
+        layer.forward(out)
+        assert_close(out.cpu().numpy(), want[lo:hi], "forward", floor=LONG_SUM_FLOOR)
+        out.copy_(torch.from_numpy(want[lo:hi]).cuda())  # identical relu masks (see bench.py parity_record)
+        layer.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
+        grad_out = torch.empty(hi - lo, D, device="cuda")
+        layer.backward(out, grad_out)
+        assert_close(grad_out.cpu().numpy(), want_go[lo:hi], "grad_out", floor=LONG_SUM_FLOOR)
+        # the optimizer step sums the gradient over the ranks first (gpu_context::set_comm) and then updates:
+        # afterwards the gradient buffer holds the GLOBAL gradient and every rank the same new weights
+        opt = L.adam(0.01)
+        layer.update_weight(opt)
+        want_wg = lo_.W_grad if arch == "gcn" else lo_.W_neigh_grad
+        assert_close(layer.tensor(L.W_NEIGH_GRAD, (D, D)).cpu().numpy(), want_wg, "W_grad", floor=LONG_SUM_FLOOR)
+        if arch == "sage":
+            assert_close(layer.tensor(L.W_SELF_GRAD, (D, D)).cpu().numpy(), lo_.W_self_grad, "W_self_grad",
+                         floor=LONG_SUM_FLOOR)
+        o_opt = orc.Adam(0.01)
+        W_want = W0.cpu().numpy().copy()
+        o_opt.update("w", want_wg, W_want)
+        W_new = layer.tensor(L.W_NEIGH, (D, D))
+        assert_close(W_new.cpu().numpy(), W_want, "W after Adam")
+        # bit-identical replicas: compare a checksum of the new weights across ranks
+        s = W_new.double().sum().item()
+        tot = comm.allreduce_host([s])[0]
+        assert abs(tot - world * s) <= 1e-9 * abs(tot), (tot, s)
+        comm.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def _spawn(world, target, args, timeout=600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world) + args[:1] + (q,) + args[1:]) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+@pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 2), ("gcn", 3)])
+def test_ipc_ranks_on_one_gpu_match_global_oracle(tmp_path, arch, world):
+    res = _spawn(world, _worker, (str(tmp_path / "id"), arch, "ipc"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_rccl_one_rank(tmp_path):
+    """the RCCL transport end to end with the one GPU this box has"""
+    res = _spawn(1, _worker, (str(tmp_path / "id"), "gcn", "rccl"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+def _lonely(rank, world, idfile, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "4"
+    try:
+        from graphaibench_amd import capi, layers as L
+
+        ctx = L.init(0)
+        t0 = time.time()
+        try:
+            capi.Comm(ctx, 0, 2, capi.comm_unique_id(capi.COMM_IPC), capi.COMM_IPC)  # rank 1 never shows up
+        except capi.GaibError as e:
+            q.put((rank, "ok" if "timed out" in str(e) and time.time() - t0 < 30 else f"FAIL: {e}"))
+            return
+        q.put((rank, "FAIL: init returned without a peer"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def test_missing_peer_is_an_error_not_a_hang(tmp_path):
+    res = _spawn(1, _lonely, (str(tmp_path / "id"),), timeout=120)
+    assert res[0][1] == "ok", res

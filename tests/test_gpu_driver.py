@@ -175,3 +175,43 @@ def test_driver_subgraph_sampling_and_inductive(tmp_path, arch):
         assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
         acc = float(re.search(r"Test accuracy: ([0-9.]+)", r.stdout).group(1))
         assert acc > 0.3, r.stdout[-1500:]  # 7 classes; the synthetic features carry the label
+
+
+@pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 3)])
+def test_driver_multi_rank_matches_single_rank(tmp_path, arch, world):
+    """bin/gpu_train_* as N processes (one per rank; here all on cuda:0 over the IPC transport): vertex-range
+    partition, halo exchange before every aggregation, gradient all-reduce before every optimizer step -- all behind
+    the C ABI.  The loss curve of rank 0 equals the single-process run's; every rank exits 0."""
+    root, x, labels, splits = make_dataset(tmp_path)
+    epochs = 6
+    exe = ROOT / "bin" / f"gpu_train_{arch}"
+    cmd = [str(exe), "cora", str(epochs), "2", "softmax", "16", "0", "0", "0.01", "2", "0", "4", "0"]
+    base = dict(os.environ, DATASET_PATH=root)
+    single = subprocess.run(cmd, capture_output=True, text=True, env=base, timeout=600)
+    assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-2000:]
+    want = re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", single.stdout)
+    want_test = float(re.search(r"Test accuracy: ([0-9.]+)", single.stdout).group(1))
+    procs = []
+    for r in range(world):
+        env = dict(base, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", GAIB_DEVICE="0", GAIB_COMM="ipc",
+                   GAIB_COMM_ID_FILE=str(tmp_path / "comm_id"), GAIB_COMM_TIMEOUT_S="60")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(o[0][-1500:], o[1][-1500:]) for o in outs]
+    got = re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", outs[0][0])
+    assert len(got) == epochs and "val_acc" in outs[0][0], outs[0][0]
+    for (gl, ga), (wl, wa) in zip(got, want):
+        assert abs(float(gl) - float(wl)) <= 2e-3 and abs(float(ga) - float(wa)) <= 0.01, (got, want)
+    assert abs(float(re.search(r"Test accuracy: ([0-9.]+)", outs[0][0]).group(1)) - want_test) <= 0.01
+    assert all(f"rank {r} of {world}: rows [" in outs[r][0] for r in range(world))
+    assert "train_loss" not in outs[1][0]  # rank 0 prints the log lines
+
+
+def test_driver_rank_failure_exits_nonzero(tmp_path):
+    """a rank whose peer never starts gives up after the deadline and exits non-zero (no hang)"""
+    root, *_ = make_dataset(tmp_path)
+    exe = ROOT / "bin" / "gpu_train_gcn"
+    env = dict(os.environ, DATASET_PATH=root, RANK="0", WORLD_SIZE="2", GAIB_DEVICE="0", GAIB_COMM="ipc",
+               GAIB_COMM_ID_FILE=str(tmp_path / "comm_id"), GAIB_COMM_TIMEOUT_S="3")
+    r = subprocess.run([str(exe), "cora", "2", "1", "softmax"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "timed out" in r.stderr, r.stderr[-1500:]
