@@ -229,7 +229,11 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=5.0,
                     help="after the timed steps, run the same step for this many seconds (0 = skip)")
     ap.add_argument("--cut-fraction", type=float, default=None,
-                    help="N>1: fraction of each partition's edges that cross partitions")
+                    help="N>1, weak scaling: fraction of each partition's edges that cross partitions (default: 0.1 as "
+                         "`value` and (N-1)/N as config.random_order, both in one run)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = one products-shaped vertex range per GPU; strong = the single-GPU bench graph "
+                         "partitioned N ways")
     args = ap.parse_args()
 
     import torch
@@ -252,11 +256,14 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("GAIB_DIST_BACKEND", "nccl")  # "gloo": several ranks on ONE GPU (tests)
+        # data path: gaib_comm behind the C ABI (GAIB_DIST_BACKEND = rccl (default) | ipc), or torch.distributed itself
+        # (nccl | gloo).  torch.distributed is the control plane either way (the communicator id, barriers, the max-over-
+        # ranks timing): gloo over 127.0.0.1 unless the data path is torch's nccl
+        backend = os.environ.get("GAIB_DIST_BACKEND", "rccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log)
         dist.barrier()
         if rank == 0:

@@ -28,20 +28,42 @@ def partition_bounds(n: int, world: int):
     return [min(p * per, n) for p in range(world + 1)]
 
 
+_A2A_OK = {}  # (backend, device type) -> every rank's all_to_all_single works (decided once, by all ranks together)
+
+
+def _a2a_supported(sample: torch.Tensor, group=None) -> bool:
+    """Does the backend have all_to_all_single for this kind of tensor?  Probed ONCE per (backend, device type) with a
+    one-element exchange, and the answer is the MINIMUM over ranks, so every rank takes the same path afterwards --
+    never a per-call, per-rank exception handler (ranks would end up in different collectives and hang)."""
+    key = (dist.get_backend(group), sample.device.type)
+    if key not in _A2A_OK:
+        world = dist.get_world_size(group)
+        ok = 1
+        try:
+            a = torch.zeros(world, dtype=torch.float32, device=sample.device)
+            b = torch.empty_like(a)
+            dist.all_to_all_single(b, a, group=group)
+        except (RuntimeError, NotImplementedError):
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=sample.device if key[0] == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        _A2A_OK[key] = bool(int(flag.item()))
+    return _A2A_OK[key]
+
+
 def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_counts, in_counts, group=None):
-    """all-to-all of row blocks; falls back to pairwise send/recv where the backend lacks it.
+    """all-to-all of row blocks; pairwise exchange where the backend lacks it (sends and receives posted together with
+    batch_isend_irecv: on a one-stream NCCL communicator a send queued ahead of the matching receive would deadlock).
     Device tensors over a gloo group (2 processes sharing one GPU in the tests) go through host."""
     if out.is_cuda and dist.get_backend(group) == "gloo":
         o_h = torch.empty(out.shape, dtype=out.dtype)
         _all_to_all_rows(o_h, inp.cpu(), out_counts, in_counts, group)
         out.copy_(o_h)
         return
-    try:
+    if _a2a_supported(out, group):
         dist.all_to_all_single(out, inp, output_split_sizes=list(out_counts), input_split_sizes=list(in_counts),
                                group=group)
         return
-    except (RuntimeError, NotImplementedError):
-        pass
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     oo = [0]
     for c in out_counts:
@@ -50,20 +72,21 @@ def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_counts, in_counts
     for c in in_counts:
         io.append(io[-1] + c)
     out[oo[rank]:oo[rank + 1]] = inp[io[rank]:io[rank + 1]]
-    reqs = []
+    ops, bufs = [], []
     for q in range(world):
         if q == rank:
             continue
         if in_counts[q]:
-            reqs.append(dist.isend(inp[io[q]:io[q + 1]].contiguous(), q, group=group))
-    for q in range(world):
-        if q == rank or not out_counts[q]:
-            continue
-        buf = torch.empty_like(out[oo[q]:oo[q + 1]])
-        dist.recv(buf, q, group=group)
+            ops.append(dist.P2POp(dist.isend, inp[io[q]:io[q + 1]].contiguous(), q, group))
+        if out_counts[q]:
+            buf = torch.empty_like(out[oo[q]:oo[q + 1]])
+            bufs.append((q, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, q, group))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    for q, buf in bufs:
         out[oo[q]:oo[q + 1]] = buf
-    for r in reqs:
-        r.wait()
 
 
 @dataclass
@@ -162,7 +185,6 @@ class HaloExchanger:
         self.bytes_sent = 0
         self._buf = {}
         self._pending = None
-        self._sync_fallback = False
 
     def _bufs(self, D, dtype, device):
         key = (D, dtype, str(device))
@@ -182,14 +204,11 @@ class HaloExchanger:
         self.bytes_sent += sendbuf.numel() * sendbuf.element_size()
         work = None
         if p.world > 1:
-            if sendbuf.is_cuda and dist.get_backend(p.group) != "gloo" and not self._sync_fallback:
-                try:
-                    work = dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=list(p.recv_counts),
-                                                  input_split_sizes=list(p.send_counts), group=p.group, async_op=True)
-                except (RuntimeError, NotImplementedError):
-                    # a backend without (async) all-to-all(v): pairwise exchange from here on (no overlap, still correct)
-                    self._sync_fallback = True
-                    _all_to_all_rows(recvbuf, sendbuf, p.recv_counts, p.send_counts, p.group)
+            # asynchronous all-to-all(v) on RCCL's stream where every rank has it (probed once, MIN over ranks);
+            # otherwise the synchronous pairwise exchange: no overlap, still correct, the same path on every rank
+            if sendbuf.is_cuda and dist.get_backend(p.group) != "gloo" and _a2a_supported(sendbuf, p.group):
+                work = dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=list(p.recv_counts),
+                                              input_split_sizes=list(p.send_counts), group=p.group, async_op=True)
             else:
                 _all_to_all_rows(recvbuf, sendbuf, p.recv_counts, p.send_counts, p.group)
         self._pending = (work, recvbuf)
@@ -204,6 +223,47 @@ class HaloExchanger:
     def exchange(self, src, D: int, dtype=torch.float32, device=None) -> torch.Tensor:
         self.start(src, D, dtype, device)
         return self.finish()
+
+
+class AbiHaloExchanger:
+    """the same exchange behind the C ABI (gaib_halo_*: RCCL send/recv groups, or peer-to-peer pull over hipIpc) --
+    torch.distributed is not on the data path.  Same interface as HaloExchanger; with it the C++ aggregators call
+    gaib_halo_exchange_begin/end themselves (LearningGraph::set_halo_plan), no Python in the loop."""
+
+    def __init__(self, ctx, comm, part: Partition):
+        self.ctx, self.comm, self.p = ctx, comm, part
+        self.halo = comm.halo(part.send_counts, part.send_idx, part.recv_counts)
+        assert self.halo.rows == part.n_halo
+        self._base = 0
+
+    @property
+    def bytes_sent(self) -> int:
+        return self.halo.bytes_sent - self._base
+
+    @bytes_sent.setter
+    def bytes_sent(self, v):
+        self._base = self.halo.bytes_sent - int(v)
+
+    def exchange(self, src, D: int, dtype=torch.float32, device=None) -> torch.Tensor:
+        """[n_halo x D] copy of the exchanged rows (set-up time use: normalisers, diagnostics)"""
+        assert dtype == torch.float32
+        self.halo.begin(src, D)
+        ptr = self.halo.end()
+        out = torch.empty(max(self.p.n_halo, 1), D, dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        if self.p.n_halo:
+            from . import capi
+            capi._check(self.ctx.lib.gaib_memcpy_d2d(self.ctx.h, out.data_ptr(), ptr, self.p.n_halo * D * 4),
+                        "gaib_memcpy_d2d")
+            self.ctx.sync()
+        return out[:self.p.n_halo]
+
+    def pack_only(self, src, D: int):
+        """diagnostics: the pack kernel alone"""
+        from . import capi
+        if self.p.send_idx.numel():
+            tmp = torch.empty(self.p.send_idx.numel(), D, dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+            capi._check(self.ctx.lib.gaib_gather_rows(self.ctx.h, self.p.send_idx.numel(), self.p.send_idx.data_ptr(), D,
+                                                      src.data_ptr(), tmp.data_ptr()), "gaib_gather_rows")
 
 
 def global_normalisers(part: Partition, ex: HaloExchanger):
@@ -229,10 +289,11 @@ class DistLayerGraph:
     owned-column edges meanwhile, then adds the halo-column edges.  The C++ layer code is the
     single-GPU one."""
 
-    def __init__(self, ctx, part: Partition):
+    def __init__(self, ctx, part: Partition, comm=None):
+        """comm: a capi.Comm -> the exchange runs behind the C ABI; None -> torch.distributed (HaloExchanger)"""
         from . import capi, layers as L
 
-        self.ctx, self.part = ctx, part
+        self.ctx, self.part, self.comm = ctx, part, comm
         self._capi = capi
         dev = f"cuda:{ctx.device}"
 
@@ -241,7 +302,7 @@ class DistLayerGraph:
             capi._check(ctx.lib.gaib_gather_rows(ctx.h, idx.numel(), idx.data_ptr(), D, ptr, out.data_ptr()),
                         "gaib_gather_rows")
 
-        self.ex = HaloExchanger(part, gather_rows=gather)
+        self.ex = AbiHaloExchanger(ctx, comm, part) if comm is not None else HaloExchanger(part, gather_rows=gather)
         vd, inv, vd_h, inv_h = global_normalisers(part, self.ex)
         g_own = ctx.graph(part.rowptr_own, part.colidx_own)
         g_own.set_vertex_norm(vd, vd, inv, row_inv_deg=inv)
@@ -253,7 +314,10 @@ class DistLayerGraph:
             pad = lambda t: t if part.n_halo > 0 else torch.zeros(1, dtype=torch.float32, device=dev)
             self.g_halo = ctx.graph(part.rowptr_halo, part.colidx_halo, ncols=nh)
             self.g_halo.set_vertex_norm(vd, pad(vd_h), pad(inv_h), row_inv_deg=inv)
-            self.lgraph.set_halo(self.g_halo, self._begin, self._end)
+            if comm is not None:
+                self.lgraph.set_halo_plan(self.g_halo, self.ex.halo)
+            else:
+                self.lgraph.set_halo(self.g_halo, self._begin, self._end)
         self._dev = dev
 
     def _begin(self, length: int, d_in: int) -> None:
@@ -271,11 +335,15 @@ class DistLayerGraph:
         return st
 
 
-def allreduce_layer_grads(ctx, layer, which_list, shape, group=None):
+def allreduce_layer_grads(ctx, layer, which_list, shape, group=None, comm=None):
     """sum the weight gradients of one layer over ranks (one fused all-reduce)."""
     from . import capi
 
     n = shape[0] * shape[1]
+    if comm is not None:  # behind the C ABI, in place on the layer's own gradient buffers
+        for w in which_list:
+            capi._check(ctx.lib.gaib_allreduce_f32(comm.h, layer.ptr(w), n), "gaib_allreduce_f32")
+        return
     buf = torch.empty(len(which_list) * n, dtype=torch.float32, device=f"cuda:{ctx.device}")
     for i, w in enumerate(which_list):
         capi._check(ctx.lib.gaib_memcpy_d2d(ctx.h, buf[i * n:].data_ptr(), layer.ptr(w), n * 4), "gaib_memcpy_d2d")
@@ -289,22 +357,57 @@ def allreduce_layer_grads(ctx, layer, which_list, shape, group=None):
         capi._check(ctx.lib.gaib_memcpy_d2d(ctx.h, layer.ptr(w), buf[i * n:].data_ptr(), n * 4), "gaib_memcpy_d2d")
 
 
-def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
-    """bench.py's N > 1 leg: weak scaling, every rank owns a products-shaped vertex range of one
-    global Chung-Lu graph (synth.block_rows); GCN hidden layer D -> D forward + backward per step,
-    halo exchange before each of the 2 SpMM, one all-reduce of dW per step."""
-    from . import layers as L, synth
+def make_comm(ctx, rank: int, world: int, log):
+    """The data-path communicator of bench.py's N > 1 leg, behind the C ABI.  GAIB_DIST_BACKEND:
+         rccl (default)  gaib_comm over RCCL -- one GPU per rank
+         ipc             gaib_comm over hipIpc peer-to-peer pull (also several ranks on one GPU: tests)
+         nccl | gloo     no gaib_comm: torch.distributed moves the halo rows (the round-1 path)
+    torch.distributed (the launcher's process group) only carries the 128-byte id, barriers and the timing reductions.
+    The choice is made ONCE here, by all ranks together: if any rank fails to create its communicator, every rank
+    falls back to torch.distributed (an all-reduce(MIN) of the success flag) -- never per call."""
+    import os
 
-    cut = 0.1 if args.cut_fraction is None else args.cut_fraction
+    from . import capi
+
+    backend = os.environ.get("GAIB_DIST_BACKEND", "rccl")
+    if backend in ("nccl", "gloo"):
+        return None, f"torch.distributed/{dist.get_backend()}"
+    transport = capi.COMM_IPC if backend == "ipc" else capi.COMM_RCCL
+    ok, comm, err = 1, None, ""
+    try:
+        uid = [capi.comm_unique_id(transport) if rank == 0 else None]
+    except capi.GaibError as e:
+        uid, ok, err = [None], 0, str(e)
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0] is None:
+        ok = 0
+    if ok:
+        try:
+            comm = capi.Comm(ctx, rank, world, uid[0], transport)
+        except capi.GaibError as e:
+            ok, err = 0, str(e)
+    flag = torch.tensor([ok], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        log(f"[bench r{rank}] gaib_comm({backend}) unavailable on some rank ({err or 'peer'}): torch.distributed carries the halo")
+        if comm is not None:
+            comm.close()
+        return None, f"torch.distributed/{dist.get_backend()} (gaib_comm {backend} failed at set-up)"
+    return comm, f"gaib_comm/{'ipc' if transport == capi.COMM_IPC else 'rccl'}"
+
+
+def _bench_case(ctx, comm, args, rank, world, D, log, rows, label):
+    """one timed case: partition `rows`, build the layer, warm up, time args.steps steps"""
+    from . import layers as L
+
     t0 = time.time()
-    rows = synth.block_rows("ogbn-products", rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
-                            selfloops=True)  # GCN aggregates over A + I (net.cpp:96)
     part = build_partition(rows.rowptr, rows.colidx_global, rows.n_global, rank, world)
-    dg = DistLayerGraph(ctx, part)
+    dg = DistLayerGraph(ctx, part, comm)
     torch.cuda.synchronize()
-    log(f"[bench r{rank}] rows [{part.lo},{part.hi}) ne={part.ne} (own-column {part.colidx_own.numel()}) "
-        f"halo rows={part.n_halo} "
-        f"send rows={part.send_idx.numel()} setup {time.time()-t0:.1f}s")
+    log(f"[bench r{rank}] {label}: rows [{part.lo},{part.hi}) ne={part.ne} (own-column {part.colidx_own.numel()}) "
+        f"halo rows={part.n_halo} send rows={part.send_idx.numel()} setup {time.time()-t0:.1f}s")
     nv = part.n_own
     torch.manual_seed(43 + rank)
     layer = L.Layer(L.GCN, 1, nv, D, D, dg.lgraph, act=True, lr=0.01)
@@ -316,7 +419,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     def step():
         layer.forward(feat_out)
         layer.backward(feat_out, grad_out)
-        allreduce_layer_grads(ctx, layer, [L.W_NEIGH_GRAD], (D, D))
+        allreduce_layer_grads(ctx, layer, [L.W_NEIGH_GRAD], (D, D), comm=comm)
 
     for _ in range(args.warmup):
         step()
@@ -349,22 +452,21 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
         dg.ex.exchange(feat, D)
     torch.cuda.synchronize()
     exch_ms = (time.perf_counter() - t0) / reps * 1e3
-    sendbuf, _ = dg.ex._bufs(D, torch.float32, feat.device)
     t0 = time.perf_counter()
     for _ in range(reps):
-        if part.send_idx.numel():
+        if isinstance(dg.ex, AbiHaloExchanger):
+            dg.ex.pack_only(feat, D)
+        elif part.send_idx.numel():
+            sendbuf, _ = dg.ex._bufs(D, torch.float32, feat.device)
             dg.ex.gather_rows(part.send_idx, feat, D, sendbuf)
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t0) / reps * 1e3
     # max time over ranks, total edges over ranks
-    rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([elapsed, exch_ms, pack_ms], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    exch_ms, pack_ms = float(t[1]), float(t[2])
     e = torch.tensor([float(part.ne), float(part.n_halo), float(bytes_timed)], dtype=torch.float64, device=rdev)
     dist.all_reduce(e, op=dist.ReduceOp.SUM)
-    elapsed = float(t[0])
-    total_edges = float(e[0])
     # dominant kernel (rank 0's view) = the pass over the owned-column edges of each aggregation: with halo
     # edges that is spmm_w64_kernel (the halo half then carries the dense product), without them the fused
     # kernel does everything, as in the single-GPU bench
@@ -379,35 +481,114 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
         alg_bytes = e_light * (4 * D + 8) + int(1.5 * nv * 4 * D) + (nv + 1) * 8
         n_dom, ms_dom = n_fused, ms_fused
     avg_ms = ms_dom / max(n_dom, 1)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    res = dict(elapsed=float(t[0]), exch_ms=float(t[1]), pack_ms=float(t[2]), total_edges=float(e[0]),
+               halo_rows_total=int(e[1]), halo_bytes_per_step_total=float(e[2]) / args.steps, nv=nv,
+               owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
+               avg_ms=avg_ms, launches=n_dom,
+               value=2 * float(e[0]) * args.steps / float(t[0]), ms_per_step=float(t[0]) / args.steps * 1e3)
+    del layer, feat_out, grad_out, dg
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
+    """bench.py's N > 1 leg.  GCN hidden layer D -> D forward + backward per step, halo exchange before each of the 2
+    SpMM, one all-reduce of dW per step.
+
+    --scaling weak (default): every rank owns a products-shaped vertex range of one global block Chung-Lu graph
+    (synth.block_rows).  The share of a range's edges that cross ranges stands for the partitioner's quality, so BOTH
+    ends are measured in one invocation: `value` at --cut-fraction (default 0.1, a locality-preserving order) and
+    `config.random_order` at (N-1)/N (a random vertex order: the adversarial end).
+    --scaling strong: the SAME 2.45 M-vertex products-shaped graph of the single-GPU bench, partitioned N ways by
+    vertex range (its vertex order is random, so the cut is (N-1)/N)."""
+    import os
+
+    from . import capi, synth
+
+    comm, transport = make_comm(ctx, rank, world, log)
+    # the xGMI link, measured (rank 0 while the others wait): replaces the 153 GB/s spec constant in the record
+    link = None
+    if rank == 0 and torch.cuda.device_count() >= 2:
+        try:
+            link = {"unidirectional_gbs": capi.probe_peer_copy(0, 1, 1 << 28, 10, False),
+                    "bidirectional_gbs_per_direction": capi.probe_peer_copy(0, 1, 1 << 28, 10, True), "bytes": 1 << 28,
+                    "pair": [0, 1]}
+        except capi.GaibError as e:
+            link = {"error": str(e)[:200]}
+    dist.barrier()
+    strong = getattr(args, "scaling", "weak") == "strong"
+    cut = 0.1 if args.cut_fraction is None else args.cut_fraction
+    extra = None
+    if strong:
+        sg = synth.make("ogbn-products", seed=42, device="cuda", scale=args.scale)
+        g0 = ctx.graph(sg.rowptr, sg.colidx)
+        g1 = g0.add_selfloop()  # GCN aggregates over A + I (net.cpp:96)
+        g0.close()
+        rp_all, ci_all = g1.rowptr(), g1.colidx().to(torch.int64)
+        n_global = g1.nv
+        g1.close()
+        b = partition_bounds(n_global, world)
+        lo, hi = b[rank], b[rank + 1]
+        e0, e1 = int(rp_all[lo]), int(rp_all[hi])
+        rows = synth.BlockRows((rp_all[lo:hi + 1] - e0).contiguous(), ci_all[e0:e1].contiguous(), n_global, hi - lo)
+        del rp_all, ci_all, sg
+        torch.cuda.empty_cache()
+        main = _bench_case(ctx, comm, args, rank, world, D, log, rows, "strong scaling, products graph")
+        workload = (f"the single-GPU bench's ogbn-products-shaped graph (seed 42, random vertex order) partitioned into "
+                    f"{world} vertex ranges, GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
+        cut_main = (world - 1) / world
+    else:
+        rows = synth.block_rows("ogbn-products", rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
+                                selfloops=True)  # GCN aggregates over A + I (net.cpp:96)
+        main = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}")
+        del rows
+        torch.cuda.empty_cache()
+        cut_main = cut
+        workload = ("block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
+                    "GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
+        if os.environ.get("GAIB_BENCH_RANDOM_ORDER", "1") != "0" and args.cut_fraction is None:
+            rcut = (world - 1) / world
+            rows = synth.block_rows("ogbn-products", rank, world, seed=42, cut_fraction=rcut, device="cuda",
+                                    scale=args.scale, selfloops=True)
+            r = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"random order, cut {rcut:.3f}")
+            extra = {"cut_fraction": rcut, "value": r["value"], "ms_per_step": r["ms_per_step"],
+                     "halo_rows_total": r["halo_rows_total"], "halo_bytes_per_step_total": r["halo_bytes_per_step_total"],
+                     "halo_exchange_standalone_ms": r["exch_ms"], "halo_pack_ms": r["pack_ms"],
+                     "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"]}
+    achieved = main["alg_bytes"] / (main["avg_ms"] * 1e-3) / 1e9 if main["avg_ms"] > 0 else 0.0
+    if comm is not None:
+        comm.barrier()
     return {
         "metric": "GCN-layer fwd+bwd aggregated edges/sec",
-        "value": 2 * total_edges * args.steps / elapsed,
+        "value": main["value"],
         "unit": "edges/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": main["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
-                        "GCN hidden layer 128->128 fwd+bwd, halo all-to-all before each SpMM + dW all-reduce",
-            "nv_per_gpu": nv, "ne_total_with_selfloops": int(total_edges), "D": D, "scale": args.scale,
-            "cut_fraction": cut, "halo_rows_total": int(e[1]),
-            "halo_bytes_per_step_total": float(e[2]) / args.steps,
+            "workload": workload,
+            "nv_per_gpu": main["nv"], "ne_total_with_selfloops": int(main["total_edges"]), "D": D, "scale": args.scale,
+            "cut_fraction": cut_main, "halo_rows_total": main["halo_rows_total"],
+            "halo_bytes_per_step_total": main["halo_bytes_per_step_total"],
             # slowest rank, measured after the timed region: one exchange on its own (pack + all-to-all + wait), the
             # pack alone, and the owned-edge aggregation kernels of one step that run while the two exchanges fly
-            "halo_exchange_standalone_ms": exch_ms, "halo_pack_ms": pack_ms,
-            "owned_edge_spmm_ms_per_step": ms_light / args.steps,
+            "halo_exchange_standalone_ms": main["exch_ms"], "halo_pack_ms": main["pack_ms"],
+            "owned_edge_spmm_ms_per_step": main["owned_edge_spmm_ms_per_step"],
             "parallelism": f"vertex-range x{world}",
+            "transport": transport, "rccl_ranks": world if transport.startswith("gaib_comm/rccl") else 0,
+            # the other end of the partition-quality axis, same invocation (weak scaling only)
+            "random_order": extra,
+            "xgmi_link_probe": link,
         },
         "roofline": {
-            "bound": "hbm", "kernel": kernel_name,
+            "bound": "hbm", "kernel": main["kernel_name"],
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-            "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_dom,
+            "alg_bytes_per_launch": main["alg_bytes"], "avg_launch_ms": main["avg_ms"], "launches": main["launches"],
         },
     }

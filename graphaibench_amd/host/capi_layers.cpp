@@ -198,6 +198,9 @@ void* gaibl_partition_make_graph(void* part, void* comm) {
   return make_partitioned_graph(*static_cast<VertexRangePartition*>(part), static_cast<gaib_comm*>(comm));
 }
 void gaibl_set_comm(void* comm) { gpu_context::set_comm(static_cast<gaib_comm*>(comm)); }
+void gaibl_graph_set_halo_plan(void* graph, void* halo_graph, void* plan) {
+  static_cast<Graph*>(graph)->set_halo_plan(static_cast<gaib_graph*>(halo_graph), static_cast<gaib_halo*>(plan));
+}
 void* gaibl_graph_halo_plan(void* graph) { return static_cast<Graph*>(graph)->halo_plan(); }
 
 void* gaibl_adam_create(float lr) { return static_cast<optimizer*>(new adam(lr)); }

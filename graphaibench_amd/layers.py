@@ -45,6 +45,7 @@ SIGNATURES = {
     "gaibl_partition_make_graph": (_vp, [_vp, _vp]),
     "gaibl_set_comm": (None, [_vp]),
     "gaibl_graph_halo_plan": (_vp, [_vp]),
+    "gaibl_graph_set_halo_plan": (None, [_vp, _vp, _vp]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
     "gaibl_time_op": (C.c_double, [C.c_char]),
@@ -135,6 +136,11 @@ class LGraph:
         self._halo_graph = halo_graph  # keep alive
         load().gaibl_graph_set_halo(self.h, halo_graph.h, C.cast(self._cb[0], C.c_void_p),
                                     C.cast(self._cb[1], C.c_void_p), None)
+
+    def set_halo_plan(self, halo_graph: capi.Graph, plan: "capi.Halo"):
+        """the exchange runs behind the C ABI (gaib_halo_exchange_begin/end inside the C++ aggregators)"""
+        self._halo_graph, self._halo_plan = halo_graph, plan  # keep alive
+        load().gaibl_graph_set_halo_plan(self.h, halo_graph.h, plan.h)
 
 
 class Layer:

@@ -56,6 +56,8 @@ void gaibl_partition_free(void* part);
 void* gaibl_partition_make_graph(void* part, void* comm);
 void gaibl_set_comm(void* comm);
 void* gaibl_graph_halo_plan(void* graph); /* gaib_halo* or NULL */
+/* LearningGraph::set_halo_plan: the halo-column gaib_graph + the gaib_halo plan every aggregation runs */
+void gaibl_graph_set_halo_plan(void* graph, void* halo_graph, void* plan);
 
 void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
                          float feat_drop, float score_drop);

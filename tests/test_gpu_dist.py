@@ -82,23 +82,35 @@ def test_two_ranks_on_one_gpu_match_global_oracle(arch):
     assert all(r[1] == "ok" for r in res), res
 
 
-def test_bench_multi_rank_path_on_one_gpu(tmp_path):
-    """bench.py's N>1 leg end to end (block graph generator with cut edges, partition, split
-    aggregation, dW all-reduce, JSON line) with 2 ranks sharing cuda:0 over gloo at 2 % scale."""
+@pytest.mark.parametrize("backend,scaling", [("gloo", "weak"), ("ipc", "weak"), ("ipc", "strong")])
+def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
+    """bench.py's N>1 leg end to end (graph generator with cut edges, partition, split aggregation, dW all-reduce,
+    JSON line) with 2 ranks sharing cuda:0 at 2 % scale: over torch.distributed/gloo (host-staged), and over the
+    C ABI's gaib_comm (hipIpc peer-to-peer pull) in both scaling modes.  Every field the record promises is there."""
     import json
     import subprocess
 
-    port = 29900 + (os.getpid() % 90)
+    port = 29900 + (os.getpid() % 90) + {"gloo": 0, "ipc": 100}[backend] + (200 if scaling == "strong" else 0)
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), GAIB_DIST_BACKEND="gloo")
+                   MASTER_PORT=str(port), GAIB_DIST_BACKEND=backend, GAIB_COMM_TIMEOUT_S="120")
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
-                                       "1", "--scale", "0.02", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+                                       "1", "--scale", "0.02", "--no-cpu-baseline", "--scaling", scaling], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     line = [l for l in outs[0][0].splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["halo_rows_total"] > 0
-    assert res["scaling"] == "weak" and res["roofline"]["achieved"] > 0
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and res["value"] > 0 and cfg["halo_rows_total"] > 0
+    assert res["scaling"] == scaling and res["roofline"]["achieved"] > 0
+    assert cfg["transport"].startswith("gaib_comm/ipc" if backend == "ipc" else "torch.distributed/gloo")
+    assert cfg["rccl_ranks"] == 0 and "xgmi_link_probe" in cfg  # one GPU here: no RCCL ranks, no link to probe
+    assert cfg["halo_exchange_standalone_ms"] > 0 and cfg["halo_bytes_per_step_total"] > 0
+    if scaling == "weak":
+        # both ends of the partition-quality axis in one invocation
+        assert cfg["cut_fraction"] == 0.1 and cfg["random_order"]["cut_fraction"] == 0.5
+        assert cfg["random_order"]["value"] > 0 and cfg["random_order"]["halo_rows_total"] > cfg["halo_rows_total"]
+    else:
+        assert cfg["cut_fraction"] == 0.5 and cfg["random_order"] is None
