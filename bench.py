@@ -231,6 +231,9 @@ def main():
     ap.add_argument("--cut-fraction", type=float, default=None,
                     help="N>1, weak scaling: fraction of each partition's edges that cross partitions (default: 0.1 as "
                          "`value` and (N-1)/N as config.random_order, both in one run)")
+    ap.add_argument("--workload", choices=["gcn-products", "gat-reddit"], default="gcn-products",
+                    help="gcn-products: BASELINE's headline (default).  gat-reddit: BASELINE config 4, one 8-head GAT layer "
+                         "64 -> 64 forward + backward on the reddit-shaped graph (same JSON schema)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = one products-shaped vertex range per GPU; strong = the single-GPU bench graph "
                          "partitioned N ways")
@@ -269,6 +272,12 @@ def main():
         if rank == 0:
             emit(result)
         dist.destroy_process_group()
+        return
+
+    if args.workload == "gat-reddit":
+        rc = bench_gat_reddit(args, torch, ctx, L, synth)
+        if rc:
+            sys.exit(rc)
         return
 
     # ---------------- single GPU -----------------------------------------------------------------
@@ -440,6 +449,148 @@ def main():
     emit(result)
     if rc:
         sys.exit(rc)
+
+
+def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
+    """BASELINE config 4 ("reddit GAT 2-layer 8-head", SDDMM + edge-softmax kernel path): the hidden GAT layer 64 -> 64
+    with 8 heads (8 x 8 columns), forward + backward per step, on the reddit-shaped graph with self loops (net.cpp:96).
+    `value` = aggregated edges per second (2 attention-weighted aggregations per step).  The table (60 MB) lives in the
+    Infinity Cache, so the roofline record prices the dominant kernel against the 8 TB/s HBM peak AND the guide's
+    cache-resident gather rate.  cpu_baseline: the oracle's GAT layer for the first `heads_sampled` heads (a head is an
+    independent single-head layer over all edges; gat_aggregator.cpp:57-200), same inputs; parity on those heads."""
+    import numpy as np
+
+    Dg, H = 64, 8
+    t0 = time.time()
+    sg = synth.make("reddit", seed=7, device="cuda", scale=args.scale)
+    g0 = ctx.graph(sg.rowptr, sg.colidx)
+    g1 = g0.add_selfloop()
+    g0.close()
+    ctx.sync()
+    nv, ne = g1.nv, g1.ne
+    log(f"[bench] reddit-shaped graph: nv={nv} ne={ne} (incl. self loops); gen+upload {time.time()-t0:.1f}s")
+    lg = L.LGraph.adopt(g1)
+    rng = np.random.default_rng(43)
+    x_h = rng.standard_normal((nv, Dg), dtype=np.float32)
+    gin_h = rng.standard_normal((nv, Dg), dtype=np.float32)
+    layer = L.Layer(L.GAT, 1, nv, Dg, Dg, lg, act=True, lr=0.01)
+    layer.set_heads(H)
+    layer.write(L.FEAT_IN, torch.from_numpy(x_h).cuda())
+    gin_d = torch.from_numpy(gin_h).cuda()
+    layer.write(L.GRAD_IN, gin_d)
+    feat_out = torch.empty(nv, Dg, device="cuda")
+    grad_out = torch.empty(nv, Dg, device="cuda")
+
+    def step():
+        layer.forward(feat_out)
+        layer.backward(feat_out, grad_out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    ctx.prof_enable(False)
+    keys = ["gat_vertex_dots", "gat_edge_softmax", "gat_sddmm", "gat_softmax_bwd_alpha", "spmm_chunk", "spmm_chunk_reduce",
+            "spmm_light", "spmm_heavy", "spmm_gemm_fused", "sgemm", "relu", "d_relu"]
+    prof = {}
+    for k in keys:
+        n, ms = ctx.prof_get(k)
+        if n:
+            prof[k] = (n, ms)
+    ctx.prof_reset()
+    ms_per_step = elapsed / args.steps * 1e3
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(int(args.sustain_s * 1e3 / ms_per_step) + 1, args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        sustained = (time.perf_counter() - t1) / n_sus * 1e3
+    peak_measured = ctx.probe_stream_copy(1 << 30, 20) if args.scale >= 0.05 else None
+    # ALGORITHMIC bytes per launch of the per-edge kernels (DESIGN.md 3.3): records are 4*H bytes per edge and array
+    alg = {
+        "gat_edge_softmax": ne * (4 + 4 * H + 4 * H) + nv * 8 * H,             # col + gathered dot + attention written
+        "gat_sddmm": ne * (4 + 4 * Dg + 4 * H) + nv * 4 * Dg,                    # col + gathered row + dp written
+        "gat_softmax_bwd_alpha": ne * (4 + 4 + 3 * 4 * H) + nv * (2 * 4 * Dg),  # col, rev, p, dp read, p^T written
+        "spmm_chunk": ne * (4 + 4 * Dg + 4 * H) + (ne // 64) * 4 * Dg,          # col + gathered row + weights, partial rows
+    }
+    dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
+    roof = None
+    if dom:
+        n_dom, ms_dom = prof[dom]
+        avg_ms = ms_dom / n_dom
+        ach = alg[dom] / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "peak_measured": peak_measured,
+                "frac_of_measured": ach / peak_measured if peak_measured else None,
+                # MI355X_MICROARCH.md: a 38 MB table gathered uniformly out of the Infinity Cache: 8.6 TB/s
+                "peak_cache_resident_gather": 8600.0, "traffic": None,
+                "alg_bytes_per_launch": alg[dom], "avg_launch_ms": avg_ms, "launches": n_dom}
+    result = {
+        "metric": "GAT-layer fwd+bwd aggregated edges/sec", "value": 2 * ne * args.steps / elapsed, "unit": "edges/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "reddit-shaped Chung-Lu graph (seed 7), GAT hidden layer 64->64 with 8 heads fwd+bwd "
+                               "(X.W, per-vertex dots, edge softmax, 2 attention SpMM, SDDMM, softmax backward + alpha "
+                               "gradients + transpose, 2 weight-side GEMMs)",
+                   "nv": nv, "ne_with_selfloops": ne, "D": Dg, "heads": H, "scale": args.scale, "parallelism": "1 GPU"},
+        "roofline": roof,
+        "breakdown_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+    }
+    if sustained:
+        result["sustained_ms_per_step"] = sustained
+    rc = 0
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+
+        cores = usable_cores()
+        orc.set_threads(cores)
+        hs = 2  # heads sampled
+        dh = Dg // H
+        g_o = orc.Graph(sg.rowptr.cpu().numpy(), sg.colidx.cpu().numpy().view(np.uint32)).add_selfloop()
+        W = orc.init_glorot(Dg, Dg, 1)
+        al, ar = orc.init_glorot(Dg, 1, 2).ravel(), orc.init_glorot(Dg, 1, 3).ravel()
+        hfeat = orc.matmul(x_h, W)
+        t1 = time.perf_counter()
+        outs, temps, norms = [], [], []
+        for k in range(hs):
+            sl = slice(k * dh, (k + 1) * dh)
+            o, t, _, p_ = orc.gat_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(al[sl]),
+                                            np.ascontiguousarray(ar[sl]))
+            outs.append(np.maximum(o, 0))
+            temps.append(t)
+            norms.append(p_)
+        for k in range(hs):
+            sl = slice(k * dh, (k + 1) * dh)
+            g_act = np.where(outs[k] > 0, gin_h[:, sl], 0).astype(np.float32)
+            orc.gat_d_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), g_act, norms[k], temps[k], fast=True)
+        t_cpu = time.perf_counter() - t1
+        result["cpu_baseline"] = dict(value=2 * ne / (t_cpu * H / hs), unit="edges/s", cores=cores, kind="port",
+                                      sample=f"attention heads 0..{hs - 1} of {H} over the whole graph ({ne} edges incl. self "
+                                             f"loops), score + softmax + aggregation forward and backward (`fast` d_softmax), "
+                                             f"{t_cpu:.2f} s; value scaled by {H}/{hs} heads")
+        layer.write(L.GRAD_IN, gin_d)
+        layer.forward(feat_out)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(np.concatenate(outs, 1)).cuda()
+        rec = _errs(torch, feat_out[:, :hs * dh].contiguous(), want, 1e-4, 1e-5)
+        result["parity"] = {"tol": 1e-4, "floor_frac_of_max": 1e-5, "forward_heads_sampled": rec,
+                            "ok": bool(rec["elem"] <= 1e-4 and rec["inf"] <= 1e-4),
+                            "note": "rows of up to 21 k edges: long-sum floor (tests/util.py LONG_SUM_FLOOR); the full layer "
+                                    "incl. backward is compared element-wise in tests/test_gpu_fullsize.py"}
+        if not result["parity"]["ok"]:
+            rc = 3
+    emit(result)
+    return rc
 
 
 def _sample_clocks(out: dict, delay_s: float) -> None:

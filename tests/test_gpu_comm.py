@@ -96,7 +96,12 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         W_want = W0.cpu().numpy().copy()
         o_opt.update("w", want_wg, W_want)
         W_new = layer.tensor(L.W_NEIGH, (D, D))
-        assert_close(W_new.cpu().numpy(), W_want, "W after Adam")
+        # the first Adam step is lr * g / sqrt(g^2 + 1e-8): +-lr wherever |g| >> 1e-4, and ill-conditioned in g where a
+        # gradient entry is within rounding of zero -- compare where the step is well defined, bound the rest by lr
+        sure = np.abs(want_wg) > 1e-4 * np.abs(want_wg).max()
+        assert sure.mean() > 0.99
+        assert_close(W_new.cpu().numpy()[sure], W_want[sure], "W after Adam")
+        assert np.abs(W_new.cpu().numpy() - W_want).max() <= 2.1 * 0.01
         # bit-identical replicas: compare a checksum of the new weights across ranks
         s = W_new.double().sum().item()
         tot = comm.allreduce_host([s])[0]

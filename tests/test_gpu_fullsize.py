@@ -302,5 +302,35 @@ def test_gat_layer_8_heads_reddit_vs_oracle():
     # 113 M-term alpha gradients: long sums in another order than the oracle's
     assert_close_dev(grad_out, orc.matmul(T, W, False, True), "grad_out", floor=LONG_SUM_FLOOR)
     assert_close_dev(ld.tensor(L.W_NEIGH_GRAD, (d, d)), orc.matmul(x, T, True, False), "W_grad", floor=LONG_SUM_FLOOR)
-    assert_close_dev(ld.tensor(L.ALPHA_LGRAD, (d,)), lg_w, "alpha_l grad", floor=LONG_SUM_FLOOR)
-    assert_close_dev(ld.tensor(L.ALPHA_RGRAD, (d,)), rg_w, "alpha_r grad", floor=LONG_SUM_FLOOR)
+    # The alpha gradients sum g_e = ds_e * leaky_relu'(temp_e) over 9e8 (edge, head) pairs, and leaky_relu' jumps from
+    # 0.2 to 1 at temp = 0: a pre-activation score within rounding of zero takes either slope in two correct fp32
+    # evaluations (the layer forms it as sl[i] + sr[col] from per-vertex dots, the reference per edge), and every such
+    # flip moves the sums by 0.8 ds_e h.  So: (1) the layer's alpha gradients agree to 1e-3 norm-wise, (2) the flips are
+    # counted and all sit within rounding of zero, (3) with the ORACLE's temp / attention arrays fed to the same GPU
+    # kernels (no flips possible) the alpha gradients agree to the usual 1e-4.
+    from util import dev_errs
+    for which, want_a, name in ((L.ALPHA_LGRAD, lg_w, "alpha_l grad"), (L.ALPHA_RGRAD, rg_w, "alpha_r grad")):
+        r, _ = dev_errs(ld.tensor(which, (d,)), want_a)
+        assert r <= 1e-3, (name, r)
+    lctx = L.init(0)
+    gd = g_d.device_graph()
+    hf_d = torch.from_numpy(hfeat).cuda()
+    al_d, ar_d = torch.from_numpy(al).cuda(), torch.from_numpy(ar).cuda()
+    t_gpu = torch.empty(ne, H, device="cuda")
+    p_gpu = torch.empty(ne, H, device="cuda")
+    lctx.gat_scores(gd, hf_d, al_d, ar_d, t_gpu, None, p_gpu, heads=H)
+    t_o = torch.from_numpy(np.stack(temps, 1)).cuda()
+    flips = (t_gpu > 0) != (t_o > 0)
+    n_flips = int(flips.sum().item())
+    if n_flips:
+        worst = max(t_gpu[flips].abs().max().item(), t_o[flips].abs().max().item()) / t_o.abs().max().item()
+        assert n_flips < 1e-5 * t_o.numel() and worst < 1e-5, (n_flips, worst)
+    del flips, t_gpu, p_gpu
+    p_o = torch.from_numpy(np.stack(norms, 1)).cuda()
+    g_act_d = torch.from_numpy(g_act).cuda()
+    dp = torch.empty(ne, H, device="cuda")
+    lctx.sddmm(gd, g_act_d, hf_d, dp, heads=H)
+    lg_d, rg_d = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+    lctx.gat_softmax_bwd_alpha(gd, hf_d, p_o, dp, t_o, None, lg_d, rg_d, heads=H)
+    assert_close_dev(lg_d, lg_w, "alpha_l grad on the oracle's temp", floor=LONG_SUM_FLOOR)
+    assert_close_dev(rg_d, rg_w, "alpha_r grad on the oracle's temp", floor=LONG_SUM_FLOOR)
