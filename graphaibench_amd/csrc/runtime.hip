@@ -57,6 +57,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_row_waves = 4;
   c->gat_chunk_sort = 1;
   c->gat_chunk_colsum = -1;
+  c->graph_rev_search = 0;
   c->prof_on = 0;
   *out = c;
   return GAIB_OK;
@@ -268,6 +269,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->gat_chunk_colsum = (int)value;
   else if (!strcmp(key, "gat_chunk_sort"))
     ctx->gat_chunk_sort = (int)value;
+  else if (!strcmp(key, "graph_rev_search"))
+    ctx->graph_rev_search = (int)value;
   else if (!strcmp(key, "gat_row_waves")) {
     GAIB_CHECK(value == 1 || value == 2 || value == 4, "gat_row_waves must be 1, 2 or 4");
     ctx->gat_row_waves = (int)value;

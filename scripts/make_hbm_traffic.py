@@ -1,0 +1,45 @@
+"""profiles/hbm_traffic.json from the PMC summaries of scripts/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes).
+
+    python scripts/make_hbm_traffic.py gpurun_out/prof_r02 <commit the profile was taken at>
+
+Counters are in KB (1024 B).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
+coalesced read -- re-calibrated for THIS access pattern (64 lanes x 8 B gathers of 512-B rows) with
+scripts/calibrate_fetch.py on a permutation graph whose byte count is known.  FETCH_SIZE counts L2 -> fabric requests:
+Infinity-Cache hits are INCLUDED, so the figures are an upper bound on the HBM share."""
+import json
+import sys
+from pathlib import Path
+
+src, commit = Path(sys.argv[1]), sys.argv[2]
+pmc = json.loads((src / "gcn_pmc_summary.json").read_text())
+cal = json.loads((src / "calib_pmc.json").read_text())
+NV, D = 2_449_029, 128
+known_read, known_write = NV * 4 * D + NV * 16, NV * 4 * D
+
+
+def find(d, counter, frag):
+    for k, v in d[counter].items():
+        if frag in k:
+            return v["mean"]
+    raise SystemExit(f"{frag} not in {counter}")
+
+
+cf, cw = find(cal, "FETCH_SIZE", "spmm_w64_kernel"), find(cal, "WRITE_SIZE", "spmm_w64_kernel")
+ratio = cf * 1024 / known_read
+out = {
+    "workload": "bench.py N=1: products-shaped graph nv=2449029 ne=125915443 D=128, GCN layer fwd+bwd",
+    "commit": commit,
+    "method": __doc__.split("Counters are", 1)[1].strip().replace("\n", " "),
+    "calibration": {"known_read_bytes": known_read, "FETCH_SIZE_KB": cf, "ratio_counter_to_known": ratio,
+                    "known_write_bytes": known_write, "WRITE_SIZE_KB": cw, "write_ratio": cw * 1024 / known_write},
+    "fetch_correction": 2.0,
+}
+for name, frag in (("spmm_gemm_kernel", "spmm_gemm_kernel"), ("spmm_heavy_kernel", "spmm_heavy_kernel"),
+                   ("sgemm_tn_reg_kernel_masked", "sgemm_tn_reg_kernel<true>")):
+    f, w = find(pmc, "FETCH_SIZE", frag), find(pmc, "WRITE_SIZE", frag)
+    out[name] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w}
+    out[f"{name}_bytes_per_launch"] = f * 1024 * 2.0 + w * 1024
+out["note"] = ("FETCH_SIZE counts L2 -> fabric requests; Infinity-Cache hits are included (MI355X_MICROARCH.md), so "
+               "these are upper bounds on the HBM bytes.")
+Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}, indent=1), "calibration ratio", ratio)

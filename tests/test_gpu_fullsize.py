@@ -332,5 +332,7 @@ def test_gat_layer_8_heads_reddit_vs_oracle():
     lctx.sddmm(gd, g_act_d, hf_d, dp, heads=H)
     lg_d, rg_d = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
     lctx.gat_softmax_bwd_alpha(gd, hf_d, p_o, dp, t_o, None, lg_d, rg_d, heads=H)
-    assert_close_dev(lg_d, lg_w, "alpha_l grad on the oracle's temp", floor=LONG_SUM_FLOOR)
-    assert_close_dev(rg_d, rg_w, "alpha_r grad on the oracle's temp", floor=LONG_SUM_FLOOR)
+    # 64 numbers, each a sum over 1.1e8 (edge, head) terms in fp32 on both sides (the oracle: sequential per-thread
+    # partials): element-wise only down to 1e-4 of the largest entry, i.e. the norm-wise bound, measured 5e-5
+    assert_close_dev(lg_d, lg_w, "alpha_l grad on the oracle's temp", floor=1e-4)
+    assert_close_dev(rg_d, rg_w, "alpha_r grad on the oracle's temp", floor=1e-4)
