@@ -757,9 +757,12 @@ __global__ __launch_bounds__(256) void spmm_chunk_kernel(int64_t n_chunks, const
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      // lanes past the end of a short chunk gathered the row of the chunk's FIRST edge: select the product, do not rely
+      // on a zero weight (0 * Inf = NaN would enter the partial sum; the row kernels never touch non-existent edges)
+      const bool live = gbase + j + u < n;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float t = w[u] * x[u][k];
+        const float t = live ? w[u] * x[u][k] : 0.f;
         acc[k] = acc[k] + t;
       }
     }

@@ -320,7 +320,18 @@ class DistLayerGraph:
                 self.lgraph.set_halo(self.g_halo, self._begin, self._end)
         self._dev = dev
 
+    def _check_stream(self) -> None:
+        """torch.distributed path only: the pack kernel and the halo SpMM run on the context's stream, the collective
+        syncs against torch's CURRENT stream -- they must be the same stream (L.init binds the context to the stream
+        that was current then), or the halo table / send buffer would be touched while still in flight."""
+        want = getattr(self.ctx, "stream_ptr", None)
+        if want is not None:
+            cur = torch.cuda.current_stream().cuda_stream
+            assert cur == want, (f"forward/backward called under torch stream {cur:#x}, the gaib context is bound to "
+                                 f"{want:#x}: call L.init(device, stream) / gaib_ctx_set_stream with the stream you use")
+
     def _begin(self, length: int, d_in: int) -> None:
+        self._check_stream()
         self.ex.start(d_in, length, torch.float32, self._dev)
 
     def _end(self, length: int) -> int:

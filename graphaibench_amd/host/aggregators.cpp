@@ -116,6 +116,15 @@ void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   n = nv;
   attn_drop = drop_rate;
   assert(attn_drop >= 0. && attn_drop < 1.);
+  if (attn_drop > 0.f) {
+    // not silent: the rate is accepted for API parity but no attention weight is dropped -- the behaviour of the
+    // reference's OpenMP path, whose dropout call is commented out (gat_aggregator.cpp:78-79); its CUDA path masks the
+    // forward weights only (graph_operations.h:326-331, the backward mask is commented out at :419-422)
+    static bool told = false;
+    if (!told) fprintf(stderr, "GAT_Aggregator: score_drop = %g is NOT applied (as in the reference's OpenMP path, "
+                               "gat_aggregator.cpp:78-79); attention weights are used undropped\n", attn_drop);
+    told = true;
+  }
   num_edges = (size_t)ne;
   // alpha_l / alpha_r: Glorot over (l, 1) with seeds 2 and 3, as the reference's CPU path
   // (gat_aggregator.cpp:11-12)

@@ -109,14 +109,14 @@ void symmetric_csr_transpose(LearningGraph& g, const float* A_nonzeros, float* B
 void float_malloc_device64(size_t n, float_t*& ptr) { ptr = gaib_host::dmalloc<float>(n); }
 void float_malloc_device(int n, float_t*& ptr) { ptr = gaib_host::dmalloc<float>((size_t)n); }
 void float_free_device(float_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }
-void copy_float_device(int n, float* h_ptr, float* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, sizeof(float) * (size_t)n)); }
+void copy_float_device(size_t n, float* h_ptr, float* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, sizeof(float) * (size_t)n)); }
 void copy_float_host(int n, const float* d_ptr, float* h_ptr) { GAIB_OR_DIE(gaib_memcpy_d2h(C(), h_ptr, d_ptr, sizeof(float) * (size_t)n)); }
-void uint_malloc_device(int n, uint32_t*& ptr) { ptr = gaib_host::dmalloc<uint32_t>((size_t)n); }
+void uint_malloc_device(size_t n, uint32_t*& ptr) { ptr = gaib_host::dmalloc<uint32_t>((size_t)n); }
 void uint_free_device(uint32_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }
-void copy_uint_device(int n, uint32_t* h_ptr, uint32_t* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, sizeof(uint32_t) * (size_t)n)); }
-void uint8_malloc_device(int n, uint8_t*& ptr) { ptr = gaib_host::dmalloc<uint8_t>((size_t)n); }
+void copy_uint_device(size_t n, uint32_t* h_ptr, uint32_t* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, sizeof(uint32_t) * (size_t)n)); }
+void uint8_malloc_device(size_t n, uint8_t*& ptr) { ptr = gaib_host::dmalloc<uint8_t>((size_t)n); }
 void uint8_free_device(uint8_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }
-void copy_uint8_device(int n, uint8_t* h_ptr, uint8_t* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, (size_t)n)); }
+void copy_uint8_device(size_t n, uint8_t* h_ptr, uint8_t* d_ptr) { GAIB_OR_DIE(gaib_memcpy_h2d(C(), d_ptr, h_ptr, (size_t)n)); }
 void copy_masks_device(int n, mask_t* h_masks, mask_t*& d_masks) {
   uint8_malloc_device(n, d_masks);
   copy_uint8_device(n, h_masks, d_masks);

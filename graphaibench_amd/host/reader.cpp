@@ -41,12 +41,16 @@ void Reader::bin_read_graph(LearningGraph* g) {
       feat_len >> num_vertex_classes >> num_edge_classes;
   meta >> train_begin >> train_end >> train_count >> val_begin >> val_end >> val_count >> test_begin >>
       test_end >> test_count;
-  // the same sanity checks the reference asserts (reader.cpp:433-437)
-  if (vid_size != 4 || eid_size != 8 || vlabel_size != 1 || !(max_degree > 0 && (index_t)max_degree < num_vertices_)) {
+  // the element sizes the reference asserts (reader.cpp:433-436) decide how the files are parsed: refuse others
+  if (vid_size != 4 || eid_size != 8 || vlabel_size != 1) {
     std::cerr << "graph.meta.txt: unsupported sizes (vid " << vid_size << ", eid " << eid_size << ", vlabel "
-              << vlabel_size << ") or max_degree " << max_degree << "\n";
+              << vlabel_size << "; need 4 / 8 / 1)\n";
     exit(1);
   }
+  // max_degree is only an assert in the reference (reader.cpp:437, compiled out with NDEBUG) and is recomputed by
+  // degree_counting() anyway: a dataset the reference binaries accept is not rejected here
+  if (!(max_degree > 0 && (index_t)max_degree < num_vertices_))
+    std::cerr << "graph.meta.txt: max_degree " << max_degree << " is outside (0, num_vertices): ignored, recomputed\n";
   g->allocateFrom(num_vertices_, num_edges_);
   std::vector<int64_t> rows((size_t)num_vertices_ + 1);
   read_exact<int64_t>(inputfile_path + "graph.vertex.bin", rows.data(), rows.size());

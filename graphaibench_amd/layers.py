@@ -85,6 +85,7 @@ def init(device: int = 0, stream: int | None = None) -> capi.Context:
     ctx.lib = capi.load()
     ctx.device = device
     ctx.h = C.c_void_p(lib.gaibl_ctx())
+    ctx.stream_ptr = int(stream or 0)  # the HIP stream every gaib call of this process is enqueued on
     ctx.close = lambda: None  # owned by the C++ side
     return ctx
 

@@ -50,14 +50,14 @@ void symmetric_csr_transpose(LearningGraph& g, const float* A_nonzeros, float* B
 // memory helpers (math_functions.hh:161-173)
 void float_malloc_device(int n, float_t*& ptr);
 void float_free_device(float_t*& ptr);
-void copy_float_device(int n, float* h_ptr, float* d_ptr);
+void copy_float_device(size_t n, float* h_ptr, float* d_ptr);
 void copy_float_host(int n, const float* d_ptr, float* h_ptr);
-void uint_malloc_device(int n, uint32_t*& ptr);
+void uint_malloc_device(size_t n, uint32_t*& ptr);
 void uint_free_device(uint32_t*& ptr);
-void copy_uint_device(int n, uint32_t* h_ptr, uint32_t* d_ptr);
-void uint8_malloc_device(int n, uint8_t*& ptr);
+void copy_uint_device(size_t n, uint32_t* h_ptr, uint32_t* d_ptr);
+void uint8_malloc_device(size_t n, uint8_t*& ptr);
 void uint8_free_device(uint8_t*& ptr);
-void copy_uint8_device(int n, uint8_t* h_ptr, uint8_t* d_ptr);
+void copy_uint8_device(size_t n, uint8_t* h_ptr, uint8_t* d_ptr);
 void copy_masks_device(int n, mask_t* h_masks, mask_t*& d_masks);
 // 64-bit element counts (N*D of the large graphs exceeds int)
 void float_malloc_device64(size_t n, float_t*& ptr);

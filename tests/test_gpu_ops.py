@@ -207,6 +207,36 @@ def test_spmm_chunked_dense_graph_path(ctx, d):
     assert_close(chunks[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy()))
 
 
+def test_spmm_chunked_short_chunk_does_not_touch_missing_edges(ctx):
+    """a 70-edge row = one full 64-edge chunk + a 6-edge chunk whose idle lanes point at the chunk's first column.
+    With an Inf in that column's feature row the sum must come out +Inf (the real edge carries it), not NaN
+    (0 * Inf from a non-existent edge): the same NaN/Inf pattern as the row kernels, finite rows unchanged."""
+    n, d = 200, 64
+    cols = np.arange(1, 71, dtype=np.uint32)  # row 0 -> 1..70 (not symmetric: aggregation only)
+    rp = np.zeros(n + 1, np.int64)
+    rp[1:] = 70
+    other = np.arange(100, 110, dtype=np.uint32)  # rows 1..: a short row each, to keep the graph non-trivial
+    rp[2:] = 70 + 10 * np.arange(1, n)
+    ci = np.concatenate([cols] + [other] * (n - 1))
+    g_d = ctx.graph(rp, ci.view(np.int32))
+    x = torch.from_numpy(feat(n, d, 3)).cuda()
+    x[65] = float("inf")  # first column of row 0's second (6-edge) chunk
+    outs = {}
+    for mode in (0, 1):
+        ctx.set_option("spmm_chunked", mode)
+        try:
+            out = torch.empty(n, d, device="cuda")
+            ctx.spmm(g_d, capi.W_MEAN, x, out)
+            ctx.sync()
+            outs[mode] = out
+        finally:
+            ctx.set_option("spmm_chunked", -1)
+    for out in outs.values():
+        assert torch.isinf(out[0]).all() and (out[0] > 0).all() and not torch.isnan(out).any()
+        assert torch.isfinite(out[1:]).all()
+    assert torch.allclose(outs[0][1:], outs[1][1:], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("d", [16, 100, 128, 512])
 def test_spmm_heavy_rows(ctx, d):
     """hub rows above the heavy threshold take the workgroup-per-row kernel (fixed-order LDS reduce)"""
