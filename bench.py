@@ -252,6 +252,10 @@ def main():
     from graphaibench_amd import capi, layers as L, synth
 
     ctx = L.init(local_rank)
+    for kv in filter(None, os.environ.get("GAIB_OPTS", "").split(",")):  # development knobs: GAIB_OPTS="key=value,..."
+        k, v = kv.split("=")
+        ctx.set_option(k.strip(), int(v))
+        log(f"[bench] option {k.strip()} = {int(v)}")
 
     if world > 1 or os.environ.get("GAIB_FORCE_DIST") == "1":  # the env knob runs the N>1 code on one GPU
         import torch.distributed as dist
@@ -497,7 +501,7 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     ctx.prof_enable(False)
-    keys = ["gat_vertex_dots", "gat_edge_softmax", "gat_sddmm", "gat_softmax_bwd_alpha", "spmm_chunk", "spmm_chunk_reduce",
+    keys = ["gat_vertex_dots", "gat_edge_softmax", "gat_bwd_fused", "gat_sddmm", "gat_softmax_bwd_alpha", "spmm_chunk", "spmm_chunk_reduce",
             "spmm_light", "spmm_heavy", "spmm_gemm_fused", "sgemm", "relu", "d_relu"]
     prof = {}
     for k in keys:
@@ -522,6 +526,9 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         "gat_sddmm": ne * (4 + 4 * Dg + 4 * H) + nv * 4 * Dg,                    # col + gathered row + dp written
         "gat_softmax_bwd_alpha": ne * (4 + 4 + 3 * 4 * H) + nv * (2 * 4 * Dg),  # col, rev, p, dp read, p^T written
         "spmm_chunk": ne * (4 + 4 * Dg + 4 * H) + (ne // 64) * 4 * Dg,          # col + gathered row + weights, partial rows
+        # the fused edge side of backward: col, rev, p_e, p_rev and TWO gathered rows per edge (h_c, grad_c), the per-vertex
+        # H-vectors of the column vertex (rowdot, sl, sr), partial rows per chunk; nothing per edge is written
+        "gat_bwd_fused": ne * (4 + 4 + 2 * 4 * H + 2 * 4 * Dg + 3 * 4 * H) + (ne // 64) * (4 * Dg + 8 * H) * 2,
     }
     dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
     roof = None

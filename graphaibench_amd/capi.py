@@ -62,6 +62,7 @@ SIGNATURES = {
     "gaib_gat_softmax_bwd_alpha_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_ex": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_re": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gaib_gat_backward_fused": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_edge_transpose_mh": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -354,6 +355,17 @@ class Context:
                                                       _ptr(norm_grad), _ptr(temp), eps, _ptr(scores),
                                                       _ptr(lgrad), _ptr(rgrad), _ptr(grad_rows),
                                                       _ptr(fwd_out_rows), _ptr(norm_t)), "gaib_gat_softmax_bwd_alpha")
+
+    def gat_backward_fused(self, g, feat, grad, fwd_out, alpha_l, alpha_r, norm, grad_out, lgrad, rgrad, eps: float = 0.2,
+                           heads: int = 1) -> bool:
+        """False when the fused path does not apply (GAIB_ERR_UNSUPPORTED, nothing touched)"""
+        rc = self.lib.gaib_gat_backward_fused(self.h, g.h, feat.shape[1], heads, _ptr(feat), _ptr(grad), _ptr(fwd_out),
+                                              _ptr(alpha_l), _ptr(alpha_r), _ptr(norm), eps, _ptr(grad_out), _ptr(lgrad),
+                                              _ptr(rgrad))
+        if rc == -5:
+            return False
+        _check(rc, "gaib_gat_backward_fused")
+        return True
 
     def edge_transpose(self, g, in_e, out_e, heads: int = 1):
         _check(self.lib.gaib_edge_transpose_mh(self.h, g.h, heads, _ptr(in_e), _ptr(out_e)), "gaib_edge_transpose")

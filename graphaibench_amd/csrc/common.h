@@ -71,6 +71,8 @@ struct gaib_ctx {
   int gat_chunk_colsum;      // GAT backward column sums by ordered chunks: -1 = dense graphs, 0 never, 1 always
   int gat_chunk_sort;        // 1 = SDDMM edge chunks ordered by column block (set before the graph's first SDDMM)
   int gat_row_waves;         // rows (= waves) per workgroup in the GAT row-owner kernels: 1, 2 or 4
+  int gat_fused_bwd;         // the one-pass edge side of GAT backward: -1 = dense graphs (aggregation's rule), 0 never, 1 whenever the shape fits
+  int gat_fused_unroll;      // gathers in flight per lane and table in the fused backward sweep: 8 (default) or 4
   int graph_rev_search;      // 1 = reverse-edge permutation by per-edge binary search (the reference's way) instead of the sort
   // in-stream kernel timing (gaib_prof_*)
   int prof_on;

@@ -796,6 +796,194 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H,
   }
 }
 
+// ---- the whole edge side of GAT backward in ONE pass over the ordered 64-edge chunk list ---------------------------
+// GAT_Aggregator::d_aggregate (gat_aggregator.cpp:99-200) is four sweeps over the edges: SDDMM dp_e = <grad_i, h_c>;
+// softmax backward + leaky-relu' -> g_e, with the row sums rs and the column sums cs of g for the alpha gradients;
+// the transpose pT_e = p[rev e]; the aggregation out_i = sum_e pT_e grad_c.  Staged (the kernels above) they move
+// ~340 B per edge through HBM at 8 heads (dp written and read twice, (g, p) records written and re-read through rev,
+// pT written and read).  Everything a row needs about its edge e = (i -> c) and the reverse edge (c -> i) follows from
+// per-vertex quantities and ONE attention value each:
+//   dp_e  = <grad_i, h_c>        g_e  = f(p_e,  dp_e,  rowdot_i, sl_i + sr_c)     -> rs_i += g_e
+//   dp_r  = <grad_c, h_i>        g_r  = f(p_r,  dp_r,  rowdot_c, sl_c + sr_i)     -> cs_i += g_r   (p_r = p[rev e])
+//   out_i += p_r * grad_c
+// with rowdot_v = <grad_v, forward output_v> = sum_e p_e dp_e of row v (the one-pass form of softmax_bwd_v2_kernel) and
+// f(p, dp, dot, t) = (p (1 - p) dp - (dot - p dp) p) * (t > 0 ? 1 : eps).  So one sweep gathers the rows h_c and grad_c
+// (the two gathers SDDMM and the aggregation did separately), reads p_e (linear) and p_r (one random 4H-byte access),
+// and writes nothing per edge: ~4 + 4 + 4H + 4H bytes per edge through HBM next to the two cache-resident row gathers.
+// Chunk by chunk in column-block order like sddmm_chunk_kernel / spmm_chunk_kernel (rows in flight gather from one
+// window of the tables); per chunk a partial output row and partial rs / cs, added per row in chunk order by
+// gat_fused_reduce_kernel: deterministic, no atomics.
+//
+// Lanes: group k = lane / G owns edges k*G .. k*G+G-1 of the chunk, lane sl = lane % G owns 4 columns (head = sl / LH,
+// LH = G / H lanes per head).  Per-(edge, head) scalars live one EDGE per lane (H-vectors in registers) and meet the
+// column layout through the wave's LDS slice: p_r goes in before the gather phase (it is the aggregation weight),
+// dp_e / dp_r come out of it.
+template <int G, int H, int U>
+__global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
+    int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
+    const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
+    const float* p, const float* rowdot, const float* sl_v, const float* sr_v, float eps, float* out_partial,
+    float* rc_partial) {
+  constexpr int LH = G / H;  // lanes per head
+  constexpr int WS = H + 1;  // LDS row stride (floats): conflict-free for the three access patterns below
+  __shared__ float lds[4 * 3 * 64 * WS];
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  float* w_pr = lds + (threadIdx.x >> 6) * (3 * 64 * WS);
+  float* w_dpe = w_pr + 64 * WS;
+  float* w_dpr = w_dpe + 64 * WS;
+  const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rb = rowptr[row];
+  const int64_t rem = rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const bool live_l = lane < n;
+  const int64_t el = eb + (live_l ? lane : 0);
+  const uint32_t cl = col[el];
+  const uint32_t rl = rev[el];
+  // one edge per lane: the attention of the reverse edge goes into LDS now (it is the aggregation weight); the other
+  // H-vectors of the edge and of its column vertex are fetched after the gather phase, when the 64 gather registers
+  // are free again (all of them live across it cost 178 VGPRs = 2 waves per SIMD)
+  {
+    HeadVec<H> pr0;
+    pr0.load(p + (int64_t)rl * H);
+#pragma unroll
+    for (int h = 0; h < H; ++h) w_pr[lane * WS + h] = live_l ? pr0.v[h] : 0.f;
+  }
+  const int coff = sl * 4;  // len == 4 * G
+  const int head = sl / LH;
+  const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)len + coff);
+  const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wave complete in order
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < G; j += U) {
+    f4 xg[U], xh[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t cj = (uint32_t)__shfl((int)cl, gbase + j + u, 64);
+      xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
+      xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ei = gbase + j + u;
+      float dpe = gi[0] * xh[u][0] + gi[1] * xh[u][1] + gi[2] * xh[u][2] + gi[3] * xh[u][3];
+      float dpr = xg[u][0] * hi[0] + xg[u][1] * hi[1] + xg[u][2] * hi[2] + xg[u][3] * hi[3];
+#pragma unroll
+      for (int o = LH / 2; o > 0; o >>= 1) {
+        dpe += __shfl_xor(dpe, o, 64);
+        dpr += __shfl_xor(dpr, o, 64);
+      }
+      if ((sl & (LH - 1)) == 0) {
+        w_dpe[ei * WS + head] = dpe;
+        w_dpr[ei * WS + head] = dpr;
+      }
+      const float w = w_pr[ei * WS + head];  // 0 past the end of the chunk ...
+      const bool live = ei < n;              // ... and the product is selected, never 0 * Inf
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t = live ? w * xg[u][k] : 0.f;
+        acc[k] = acc[k] + t;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+  }
+  const int64_t slot = (int64_t)chunk_start[row] + (eb - rb) / 64;
+  if (gbase == 0) *reinterpret_cast<f4*>(out_partial + slot * len + coff) = acc;
+  // ---- per-(edge, head) gradients, one edge per lane ----
+  __builtin_amdgcn_sched_barrier(0);  // keep these loads below the gather phase (register pressure, see above)
+  HeadVec<H> pe, pr, rdc, slc, src;
+  pe.load(p + el * H);
+  rdc.load(rowdot + (int64_t)cl * H);
+  slc.load(sl_v + (int64_t)cl * H);
+  src.load(sr_v + (int64_t)cl * H);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int h = 0; h < H; ++h) pr.v[h] = w_pr[lane * WS + h];
+  HeadVec<H> rdi, sli, sri;  // the row's own per-head values (wave-uniform addresses)
+  rdi.load(rowdot + row * H);
+  sli.load(sl_v + row * H);
+  sri.load(sr_v + row * H);
+  float ge[H], gr[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float dpe = w_dpe[lane * WS + h], dpr = w_dpr[lane * WS + h];
+    const float a = pe.v[h], b = pr.v[h];
+    const float dse = a * (1.0f - a) * dpe - (rdi.v[h] - a * dpe) * a;
+    const float dsr = b * (1.0f - b) * dpr - (rdc.v[h] - b * dpr) * b;
+    ge[h] = live_l ? dse * ((sli.v[h] + src.v[h]) > 0.0f ? 1.0f : eps) : 0.f;
+    gr[h] = live_l ? dsr * ((slc.v[h] + sri.v[h]) > 0.0f ? 1.0f : eps) : 0.f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read its dp values: the slices are reused
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    w_dpe[lane * WS + h] = ge[h];
+    w_dpr[lane * WS + h] = gr[h];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // sum over the chunk's 64 edges per head: lane (part, h) adds 64 / (64 / H) ... edges, then the parts meet by shuffle
+  constexpr int PARTS = 64 / H, EPP = 64 / PARTS;  // EPP == H edges per part
+  const int hh = lane & (H - 1), part = lane / H;
+  float s_e = 0.f, s_r = 0.f;
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) {
+    s_e += w_dpe[(part * EPP + k) * WS + hh];
+    s_r += w_dpr[(part * EPP + k) * WS + hh];
+  }
+#pragma unroll
+  for (int o = H; o < 64; o <<= 1) {
+    s_e += __shfl_xor(s_e, o, 64);
+    s_r += __shfl_xor(s_r, o, 64);
+  }
+  if (lane < H) {
+    rc_partial[slot * 2 * H + lane] = s_e;      // partial row sum of g   (-> alpha_l gradient)
+    rc_partial[slot * 2 * H + H + lane] = s_r;  // partial column sum of g (-> alpha_r gradient)
+  }
+}
+
+// out[row] = sum of the row's chunk partials in chunk order; rs / cs [row][H] the same for the g sums
+__global__ __launch_bounds__(256) void gat_fused_reduce_kernel(int64_t nv, int len, int H, const uint32_t* chunk_start,
+                                                               const float* out_partial, const float* rc_partial,
+                                                               float* out, float* rs, float* cs) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
+  if (lane * 4 < len) {
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* pp = out_partial + lane * 4;
+    int64_t k = c0;
+    for (; k + 4 <= c1; k += 4) {
+      f4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f4*>(pp + (k + u) * len);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += t[u][q];
+    }
+    for (; k < c1; ++k) {
+      const f4 t = *reinterpret_cast<const f4*>(pp + k * len);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += t[q];
+    }
+    *reinterpret_cast<f4*>(out + row * (int64_t)len + lane * 4) = s;
+  }
+  if (lane < 2 * H) {  // lanes 0..H-1: rs, H..2H-1: cs
+    float s = 0.f;
+    for (int64_t k = c0; k < c1; ++k) s += rc_partial[k * 2 * H + lane];
+    if (lane < H) rs[row * H + lane] = s;
+    else cs[row * H + lane - H] = s;
+  }
+}
+
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
 // the row-owner kernels: gat_row_waves (1, 2 or 4) one-wave rows per workgroup
 inline unsigned rowgrid_w(const gaib_ctx* ctx, int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, ctx->gat_row_waves); }
@@ -1047,6 +1235,87 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   }
 #undef GAIB_SBW
   if (rc != GAIB_OK) return rc;
+  GAIB_LAUNCH_CHECK();
+  alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
+                                                                         rows_per_block, partial);
+  GAIB_LAUNCH_CHECK();
+  alpha_final_kernel<<<(unsigned)cdiv64(2 * (int64_t)len, 4), 256, 0, ctx->stream>>>(nblocks, len, partial, d_alpha_lgrad,
+                                                                                    d_alpha_rgrad);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+// The fused edge side of backward (gat_bwd_fused_chunk_kernel).  Shapes: len == 64 (16 lanes x 4 columns per edge) and
+// 1, 2, 4, 8 or 16 heads; otherwise, or where the auto rule says the ordered-chunk sweep does not pay (option
+// gat_fused_bwd: -1 = graphs with >= 1/4 of their edges in heavy rows and a feature table of <= 512 MB -- the
+// dense-graph rule of the aggregation; 0 = never; 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and
+// nothing was touched: the caller runs the staged entry points.
+extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
+                                       const float* d_grad, const float* d_fwd_out, const float* d_alpha_l,
+                                       const float* d_alpha_r, const float* d_norm_scores, float epsilon,
+                                       float* d_grad_out, float* d_alpha_lgrad, float* d_alpha_rgrad) {
+  GAIB_CHECK(ctx && g, "gaib_gat_backward_fused: NULL ctx/graph");
+  GAIB_TRY(check_heads("gaib_gat_backward_fused", len, heads));
+  GAIB_CHECK(d_feat && d_grad && d_fwd_out && d_alpha_l && d_alpha_r && d_norm_scores && d_grad_out && d_alpha_lgrad &&
+                 d_alpha_rgrad, "gaib_gat_backward_fused: NULL pointer");
+  GAIB_CHECK(d_grad_out != d_feat && d_grad_out != d_grad, "gaib_gat_backward_fused: d_grad_out must not alias an input");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const bool shape_ok = len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) &&
+                        g->nc == g->nv && g->ne > 0 &&
+                        ((((uintptr_t)d_feat | (uintptr_t)d_grad | (uintptr_t)d_norm_scores | (uintptr_t)d_grad_out) & 15) == 0);
+  bool use = shape_ok && ctx->gat_fused_bwd != 0;
+  if (use && ctx->gat_fused_bwd < 0) {
+    GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
+    use = g->n_heavy > 0 && 4 * g->heavy_edges >= g->ne && (int64_t)g->nv * len * 4 <= ((int64_t)512 << 20);
+  }
+  if (!use) {
+    gaib_set_error("gaib_gat_backward_fused: not applicable to this shape / graph (len %d, heads %d)", len, heads);
+    return GAIB_ERR_UNSUPPORTED;
+  }
+  GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
+  GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+  const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
+  const int64_t rows_per_block = cdiv64(g->nv, nblocks);
+  auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+  const size_t n_v = up4((size_t)g->nv * heads);
+  const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (5 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
+  float* sl = (float*)ctx->ws;
+  float* sr = sl + n_v;
+  float* rowdot = sr + n_v;
+  float* rs = rowdot + n_v;
+  float* cs = rs + n_v;
+  float* out_partial = cs + n_v;
+  float* rc_partial = out_partial + n_op;
+  float* partial = rc_partial + n_rc;
+  ProfScope ps(ctx, "gat_bwd_fused");
+  vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_feat, d_alpha_l, d_alpha_r, sl, sr);
+  rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
+  GAIB_LAUNCH_CHECK();
+  const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+  // gathers in flight per lane and table: 8 (142 VGPRs, 3 waves per SIMD) or 4 (option gat_fused_unroll)
+#define GAIB_FB_U(HH, UU)                                                                                                 \
+  gat_bwd_fused_chunk_kernel<16, HH, UU><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,        \
+                                                                        g->chunk_start, g->rowptr, g->colidx, g->rev, len, \
+                                                                        d_feat, d_grad, d_norm_scores, rowdot, sl, sr,     \
+                                                                        epsilon, out_partial, rc_partial)
+#define GAIB_FB(HH)                      \
+  do {                                   \
+    if (ctx->gat_fused_unroll == 4) GAIB_FB_U(HH, 4); \
+    else GAIB_FB_U(HH, 8);               \
+  } while (0)
+  switch (heads) {
+    case 1: GAIB_FB(1); break;
+    case 2: GAIB_FB(2); break;
+    case 4: GAIB_FB(4); break;
+    case 8: GAIB_FB(8); break;
+    default: GAIB_FB(16); break;
+  }
+#undef GAIB_FB
+#undef GAIB_FB_U
+  GAIB_LAUNCH_CHECK();
+  gat_fused_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial,
+                                                                   rc_partial, d_grad_out, rs, cs);
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
                                                                          rows_per_block, partial);

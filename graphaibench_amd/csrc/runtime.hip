@@ -58,6 +58,8 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_chunk_sort = 1;
   c->gat_chunk_colsum = -1;
   c->graph_rev_search = 0;
+  c->gat_fused_bwd = -1;
+  c->gat_fused_unroll = 8;
   c->prof_on = 0;
   *out = c;
   return GAIB_OK;
@@ -269,6 +271,10 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->gat_chunk_colsum = (int)value;
   else if (!strcmp(key, "gat_chunk_sort"))
     ctx->gat_chunk_sort = (int)value;
+  else if (!strcmp(key, "gat_fused_unroll"))
+    ctx->gat_fused_unroll = (int)value;
+  else if (!strcmp(key, "gat_fused_bwd"))
+    ctx->gat_fused_bwd = (int)value;
   else if (!strcmp(key, "graph_rev_search"))
     ctx->graph_rev_search = (int)value;
   else if (!strcmp(key, "gat_row_waves")) {

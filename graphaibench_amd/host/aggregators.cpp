@@ -109,7 +109,7 @@ void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* 
 GAT_Aggregator::GAT_Aggregator()
     : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
-      d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), alpha_opt(NULL) {}
+      d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), d_tbuf(NULL), tbuf_floats(0), alpha_opt(NULL) {}
 
 void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   length = l;
@@ -194,6 +194,25 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
 // feat_in is last read by the alpha-gradient step, grad_out is first written by the final SpMM.
 void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in,
                                  float* grad_out) {
+  if (fwd_out) {
+    // one sweep over the edges instead of four (gaib_gat_backward_fused): needs the layer's forward output and an
+    // output that does not alias feat_in (GAT_layer::backward passes out_temp for both) -> a scratch of its own
+    OpTimer t(OP_ATTN);
+    const size_t need = (size_t)g.size() * len;
+    if (need > tbuf_floats) {
+      if (d_tbuf) float_free_device(d_tbuf);
+      float_malloc_device64(need, d_tbuf);
+      tbuf_floats = need;
+    }
+    const int rc = gaib_gat_backward_fused(C(), dev(g), len, heads, feat_in, grad_in, fwd_out, d_alpha_l, d_alpha_r,
+                                           d_norm_scores, epsilon, d_tbuf, d_alpha_lgrad, d_alpha_rgrad);
+    if (rc == GAIB_OK) {
+      fwd_out = NULL;
+      GAIB_OR_DIE(gaib_memcpy_d2d(C(), grad_out, d_tbuf, sizeof(float) * need));
+      return;
+    }
+    if (rc != GAIB_ERR_UNSUPPORTED) GAIB_OR_DIE(rc);  // a real failure; UNSUPPORTED = this shape / graph takes the staged path
+  }
   {
     OpTimer t(OP_SCORE);
     GAIB_OR_DIE(gaib_sddmm_mh(C(), dev(g), len, heads, grad_in, feat_in, d_norm_scores_grad));

@@ -208,6 +208,16 @@ int gaib_gat_softmax_bwd_alpha_re(gaib_ctx* ctx, gaib_graph* g, int len, int hea
                                   const float* d_norm_scores_grad, float epsilon, float* d_scores,
                                   float* d_alpha_lgrad, float* d_alpha_rgrad, const float* d_grad_rows,
                                   const float* d_fwd_out_rows, float* d_norm_scores_t);
+/* The whole edge side of GAT_Aggregator::d_aggregate (gat_aggregator.cpp:99-200: SDDMM, softmax backward + leaky-relu',
+ * alpha gradients, transpose, gradient aggregation) in ONE sweep over the edges.  d_fwd_out is the aggregation's forward
+ * output (sum_e p_e dp_e of a row == <grad_i, out_i>); d_grad_out [nv x len] must not alias an input.  Nothing per edge is
+ * written: the per-edge arrays dp / ds / p^T of the staged entry points do not exist on this path.  Applies to len == 64
+ * with 1, 2, 4, 8 or 16 heads on dense graphs (option "gat_fused_bwd": -1 auto, 0 never, 1 whenever the shape fits);
+ * otherwise returns GAIB_ERR_UNSUPPORTED without touching anything and the caller uses the staged entry points. */
+int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat, const float* d_grad,
+                            const float* d_fwd_out, const float* d_alpha_l, const float* d_alpha_r,
+                            const float* d_norm_scores, float epsilon, float* d_grad_out, float* d_alpha_lgrad,
+                            float* d_alpha_rgrad);
 /* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):
  *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
 int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);

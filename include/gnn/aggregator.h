@@ -96,5 +96,7 @@ class GAT_Aggregator : public aggregator {
   float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
   float *d_temp_scores, *d_norm_scores, *d_norm_scores_grad, *d_norm_scores_t;
   const float* fwd_out;  // see use_forward_output_once
+  float* d_tbuf;         // output of the fused backward sweep (the layer aliases feat_in and grad_out)
+  size_t tbuf_floats;
   optimizer* alpha_opt;
 };

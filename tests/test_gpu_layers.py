@@ -103,8 +103,17 @@ def test_sage_layer_powerlaw(din, dout, level):
         assert_close(grad_out.cpu().numpy(), want_go)
 
 
+@pytest.fixture(params=[-1, 1], ids=["staged-bwd", "fused-bwd"])
+def gat_bwd_mode(request, _ctx):
+    """GAT backward through the staged kernels (what these small graphs get by the auto rule) and through the one-sweep
+    kernel (gaib_gat_backward_fused, what dense graphs get at 64 columns)"""
+    _ctx.set_option("gat_fused_bwd", request.param)
+    yield request.param
+    _ctx.set_option("gat_fused_bwd", -1)
+
+
 @pytest.mark.parametrize("din,dout,level", [(100, 64, 0), (64, 64, 1), (64, 8, 1)])
-def test_gat_layer(din, dout, level):
+def test_gat_layer(gat_bwd_mode, din, dout, level):
     rp, ci = random_graph(4096, 24, seed=9, power_law=True, hub_deg=1500)
     g_o = orc.Graph(rp, ci).add_selfloop()
     g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
@@ -194,7 +203,7 @@ def test_gcn_training_steps_track_oracle():
     assert rel_err(d1.tensor(L.W_NEIGH, (H, Cn)).cpu().numpy(), o1.W) < 1e-3
 
 
-def test_gat_layer_8_heads():
+def test_gat_layer_8_heads(gat_bwd_mode):
     """GAT_layer with 8 attention heads (GAT_Aggregator::set_num_heads): forward/backward equal 8
     single-head oracles on the 8-column slices (BASELINE config 4 shape: hidden 64 = 8 x 8)."""
     rp, ci = random_graph(4096, 24, seed=19, power_law=True, hub_deg=1500)

@@ -207,6 +207,58 @@ def test_spmm_chunked_dense_graph_path(ctx, d):
     assert_close(chunks[0].cpu().numpy(), orc.sage_aggregate(g_o, x.cpu().numpy()))
 
 
+@pytest.mark.parametrize("heads,hub,unroll", [(1, 0, 8), (2, 0, 8), (4, 900, 8), (8, 0, 8), (8, 1400, 8), (8, 1400, 4), (16, 0, 8)])
+def test_gat_backward_fused(ctx, heads, hub, unroll):
+    """gaib_gat_backward_fused: SDDMM + softmax backward + alpha gradients + transpose + gradient aggregation in one
+    sweep over the ordered chunk list == the oracle's d_aggregate (gat_aggregator.cpp:99-200) head by head, and == the
+    staged entry points; deterministic; refuses shapes it does not cover without touching anything."""
+    d = 64
+    rp, ci = random_graph(1500, 8, seed=heads + 1, power_law=True, hub_deg=hub)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    h = feat(g_o.nv, d, 1)
+    gin = feat(g_o.nv, d, 4)
+    al = feat(1, d, 2).ravel() * 0.2
+    ar = feat(1, d, 3).ravel() * 0.2
+    out_w, temp, _, norm = orc.gat_aggregate_mh(g_o, h, al, ar, heads)
+    want_go, _, _, want_lg, want_rg = orc.gat_d_aggregate_mh(g_o, h, gin, norm, temp, heads)
+    hd, gd, pd = dev(h), dev(gin), dev(np.ascontiguousarray(norm))
+    ctx.set_option("gat_fused_bwd", 1)
+    ctx.set_option("gat_fused_unroll", unroll)
+    try:
+        res = []
+        for _ in range(2):
+            go = torch.full((g_o.nv, d), 7.0, device="cuda")
+            lg, rg = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+            assert ctx.gat_backward_fused(g_d, hd, gd, dev(out_w), dev(al), dev(ar), pd, go, lg, rg, heads=heads)
+            res.append((go, lg, rg))
+        # a shape outside its cover is refused, the output untouched
+        go48 = torch.full((g_o.nv, 48), 7.0, device="cuda")
+        assert not ctx.gat_backward_fused(g_d, dev(feat(g_o.nv, 48, 1)), dev(feat(g_o.nv, 48, 2)), dev(feat(g_o.nv, 48, 3)),
+                                          dev(feat(1, 48, 2).ravel()), dev(feat(1, 48, 3).ravel()), pd, go48,
+                                          torch.empty(48, device="cuda"), torch.empty(48, device="cuda"), heads=heads)
+        assert torch.all(go48 == 7.0)
+    finally:
+        ctx.set_option("gat_fused_bwd", -1)
+        ctx.set_option("gat_fused_unroll", 8)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)  # fixed summation order
+    go, lg, rg = res[0]
+    fl = LONG_SUM_FLOOR if hub else 1e-6
+    assert_close(go.cpu().numpy(), want_go, "grad_out", floor=fl)
+    assert_close(lg.cpu().numpy(), want_lg, "alpha_l grad", floor=LONG_SUM_FLOOR)  # differences of O(sqrt(D)) dots, summed
+    assert_close(rg.cpu().numpy(), want_rg, "alpha_r grad", floor=LONG_SUM_FLOOR)
+    # == the staged path on the same inputs
+    dp = torch.empty(g_o.ne, heads, device="cuda")
+    ctx.sddmm(g_d, gd, hd, dp, heads=heads)
+    lg2, rg2, pt = torch.empty(d, device="cuda"), torch.empty(d, device="cuda"), torch.empty(g_o.ne, heads, device="cuda")
+    ctx.gat_softmax_bwd_alpha(g_d, hd, pd, dp, dev(np.ascontiguousarray(temp)), None, lg2, rg2, heads=heads, grad_rows=gd,
+                              fwd_out_rows=dev(out_w), norm_t=pt)
+    go2 = torch.empty(g_o.nv, d, device="cuda")
+    ctx.spmm(g_d, capi.W_EDGE, gd, go2, edge_w=pt, heads=heads)
+    assert rel_err(go.cpu().numpy(), go2.cpu().numpy()) < 1e-5
+    assert rel_err(lg.cpu().numpy(), lg2.cpu().numpy()) < 1e-4 and rel_err(rg.cpu().numpy(), rg2.cpu().numpy()) < 1e-4
+
+
 def test_spmm_chunked_short_chunk_does_not_touch_missing_edges(ctx):
     """a 70-edge row = one full 64-edge chunk + a 6-edge chunk whose idle lanes point at the chunk's first column.
     With an Inf in that column's feature row the sum must come out +Inf (the real edge carries it), not NaN
