@@ -815,61 +815,57 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H,
 // gat_fused_reduce_kernel: deterministic, no atomics.
 //
 // Lanes: group k = lane / G owns edges k*G .. k*G+G-1 of the chunk, lane sl = lane % G owns 4 columns (head = sl / LH,
-// LH = G / H lanes per head).  Per-(edge, head) scalars live one EDGE per lane (H-vectors in registers) and meet the
-// column layout through the wave's LDS slice: p_r goes in before the gather phase (it is the aggregation weight),
-// dp_e / dp_r come out of it.
+// LH = G / H lanes per head).  EVERYTHING is fetched in that layout, U edges per group in flight: the two rows (16 B per
+// lane), the column vertex's per-head record vrec[c][head] = (rowdot, sl, sr, -) (16 B: the three per-vertex scalars in
+// one access, 4H floats = one 128-B line per vertex at 8 heads) and the two attention values p_e, p_r (4 B each), so the
+// only dependent step is col / rev -> gathers, as in spmm_chunk_kernel.  A first version kept the per-(edge, head)
+// scalars one EDGE per lane (H-vectors) and met the column layout through LDS: 64 different lines per wave instruction
+// for each of five H-vector fetches, a dependent post-phase and 178 -> 142 VGPRs made it 10.5 ms at the reddit shape
+// against 12.3 ms for the staged kernels.
 template <int G, int H, int U>
 __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
-    const float* p, const float* rowdot, const float* sl_v, const float* sr_v, float eps, float* out_partial,
-    float* rc_partial) {
+    const float* p, const f4* vrec, float eps, float* out_partial, float* rc_partial) {
   constexpr int LH = G / H;  // lanes per head
-  constexpr int WS = H + 1;  // LDS row stride (floats): conflict-free for the three access patterns below
-  __shared__ float lds[4 * 3 * 64 * WS];
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
   const int lane = threadIdx.x & 63;
-  float* w_pr = lds + (threadIdx.x >> 6) * (3 * 64 * WS);
-  float* w_dpe = w_pr + 64 * WS;
-  float* w_dpr = w_dpe + 64 * WS;
   const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
   const int64_t row = chunk_row[c];
   const int64_t eb = chunk_ebase[c];
   const int64_t rb = rowptr[row];
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
-  const bool live_l = lane < n;
-  const int64_t el = eb + (live_l ? lane : 0);
+  const int64_t el = eb + (lane < n ? lane : 0);
   const uint32_t cl = col[el];
   const uint32_t rl = rev[el];
-  // one edge per lane: the attention of the reverse edge goes into LDS now (it is the aggregation weight); the other
-  // H-vectors of the edge and of its column vertex are fetched after the gather phase, when the 64 gather registers
-  // are free again (all of them live across it cost 178 VGPRs = 2 waves per SIMD)
-  {
-    HeadVec<H> pr0;
-    pr0.load(p + (int64_t)rl * H);
-#pragma unroll
-    for (int h = 0; h < H; ++h) w_pr[lane * WS + h] = live_l ? pr0.v[h] : 0.f;
-  }
   const int coff = sl * 4;  // len == 4 * G
   const int head = sl / LH;
   const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)len + coff);
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wave complete in order
+  const f4 vi = vrec[row * H + head];  // (rowdot_i, sl_i, sr_i) of this lane's head
   f4 acc = {0.f, 0.f, 0.f, 0.f};
+  float s_e = 0.f, s_r = 0.f;
 #pragma unroll
   for (int j = 0; j < G; j += U) {
-    f4 xg[U], xh[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t cj = (uint32_t)__shfl((int)cl, gbase + j + u, 64);
-      xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
-      xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
-    }
+    f4 xg[U], xh[U], vr[U];
+    float pe[U], pr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ei = gbase + j + u;
+      const uint32_t cj = (uint32_t)__shfl((int)cl, ei, 64);
+      const uint32_t rj = (uint32_t)__shfl((int)rl, ei, 64);
+      xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
+      xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
+      vr[u] = vrec[(int64_t)cj * H + head];
+      pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
+      pr[u] = p[(int64_t)rj * H + head];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first one is consumed
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = gbase + j + u < n;
       float dpe = gi[0] * xh[u][0] + gi[1] * xh[u][1] + gi[2] * xh[u][2] + gi[3] * xh[u][3];
       float dpr = xg[u][0] * hi[0] + xg[u][1] * hi[1] + xg[u][2] * hi[2] + xg[u][3] * hi[3];
 #pragma unroll
@@ -877,16 +873,19 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
         dpe += __shfl_xor(dpe, o, 64);
         dpr += __shfl_xor(dpr, o, 64);
       }
-      if ((sl & (LH - 1)) == 0) {
-        w_dpe[ei * WS + head] = dpe;
-        w_dpr[ei * WS + head] = dpr;
-      }
-      const float w = w_pr[ei * WS + head];  // 0 past the end of the chunk ...
-      const bool live = ei < n;              // ... and the product is selected, never 0 * Inf
+      const float a = pe[u], b = pr[u];
+      const float dse = a * (1.0f - a) * dpe - (vi[0] - a * dpe) * a;
+      const float dsr = b * (1.0f - b) * dpr - (vr[u][0] - b * dpr) * b;
+      const float ge = dse * ((vi[1] + vr[u][2]) > 0.0f ? 1.0f : eps);  // leaky-relu' at sl_i + sr_c
+      const float gr = dsr * ((vr[u][1] + vi[2]) > 0.0f ? 1.0f : eps);  //              at sl_c + sr_i
+      if (live) {  // (lanes past the end of a short chunk looked at the chunk's first edge: nothing of it is added)
+        s_e += ge;
+        s_r += gr;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float t = live ? w * xg[u][k] : 0.f;
-        acc[k] = acc[k] + t;
+        for (int k = 0; k < 4; ++k) {
+          const float t = b * xg[u][k];
+          acc[k] = acc[k] + t;
+        }
       }
     }
   }
@@ -894,58 +893,23 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   for (int o = G; o < 64; o <<= 1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
-  }
-  const int64_t slot = (int64_t)chunk_start[row] + (eb - rb) / 64;
-  if (gbase == 0) *reinterpret_cast<f4*>(out_partial + slot * len + coff) = acc;
-  // ---- per-(edge, head) gradients, one edge per lane ----
-  __builtin_amdgcn_sched_barrier(0);  // keep these loads below the gather phase (register pressure, see above)
-  HeadVec<H> pe, pr, rdc, slc, src;
-  pe.load(p + el * H);
-  rdc.load(rowdot + (int64_t)cl * H);
-  slc.load(sl_v + (int64_t)cl * H);
-  src.load(sr_v + (int64_t)cl * H);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int h = 0; h < H; ++h) pr.v[h] = w_pr[lane * WS + h];
-  HeadVec<H> rdi, sli, sri;  // the row's own per-head values (wave-uniform addresses)
-  rdi.load(rowdot + row * H);
-  sli.load(sl_v + row * H);
-  sri.load(sr_v + row * H);
-  float ge[H], gr[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    const float dpe = w_dpe[lane * WS + h], dpr = w_dpr[lane * WS + h];
-    const float a = pe.v[h], b = pr.v[h];
-    const float dse = a * (1.0f - a) * dpe - (rdi.v[h] - a * dpe) * a;
-    const float dsr = b * (1.0f - b) * dpr - (rdc.v[h] - b * dpr) * b;
-    ge[h] = live_l ? dse * ((sli.v[h] + src.v[h]) > 0.0f ? 1.0f : eps) : 0.f;
-    gr[h] = live_l ? dsr * ((slc.v[h] + sri.v[h]) > 0.0f ? 1.0f : eps) : 0.f;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read its dp values: the slices are reused
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    w_dpe[lane * WS + h] = ge[h];
-    w_dpr[lane * WS + h] = gr[h];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // sum over the chunk's 64 edges per head: lane (part, h) adds 64 / (64 / H) ... edges, then the parts meet by shuffle
-  constexpr int PARTS = 64 / H, EPP = 64 / PARTS;  // EPP == H edges per part
-  const int hh = lane & (H - 1), part = lane / H;
-  float s_e = 0.f, s_r = 0.f;
-#pragma unroll
-  for (int k = 0; k < EPP; ++k) {
-    s_e += w_dpe[(part * EPP + k) * WS + hh];
-    s_r += w_dpr[(part * EPP + k) * WS + hh];
-  }
-#pragma unroll
-  for (int o = H; o < 64; o <<= 1) {
     s_e += __shfl_xor(s_e, o, 64);
     s_r += __shfl_xor(s_r, o, 64);
   }
-  if (lane < H) {
-    rc_partial[slot * 2 * H + lane] = s_e;      // partial row sum of g   (-> alpha_l gradient)
-    rc_partial[slot * 2 * H + H + lane] = s_r;  // partial column sum of g (-> alpha_r gradient)
+  const int64_t slot = (int64_t)chunk_start[row] + (eb - rb) / 64;
+  if (gbase == 0) {
+    *reinterpret_cast<f4*>(out_partial + slot * len + coff) = acc;
+    if ((sl & (LH - 1)) == 0) {
+      rc_partial[slot * 2 * H + head] = s_e;      // partial row sum of g    (-> alpha_l gradient)
+      rc_partial[slot * 2 * H + H + head] = s_r;  // partial column sum of g (-> alpha_r gradient)
+    }
   }
+}
+
+// vrec[v][h] = (rowdot, sl, sr, 0): the three per-(vertex, head) scalars of the fused sweep in one 16-B record
+__global__ void vrec_pack_kernel(int64_t n, const float* rowdot, const float* sl, const float* sr, f4* vrec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vrec[i] = f4{rowdot[i], sl[i], sr[i], 0.f};
 }
 
 // out[row] = sum of the row's chunk partials in chunk order; rs / cs [row][H] the same for the g sums
@@ -1279,26 +1243,29 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
   const size_t n_v = up4((size_t)g->nv * heads);
   const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (5 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (9 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
   float* sl = (float*)ctx->ws;
   float* sr = sl + n_v;
   float* rowdot = sr + n_v;
   float* rs = rowdot + n_v;
   float* cs = rs + n_v;
-  float* out_partial = cs + n_v;
+  f4* vrec = reinterpret_cast<f4*>(cs + n_v);  // [nv * heads] records of 4 floats
+  float* out_partial = cs + n_v + 4 * n_v;
   float* rc_partial = out_partial + n_op;
   float* partial = rc_partial + n_rc;
   ProfScope ps(ctx, "gat_bwd_fused");
   vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_feat, d_alpha_l, d_alpha_r, sl, sr);
   rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
+  vrec_pack_kernel<<<(unsigned)cdiv64((int64_t)g->nv * heads, 256), 256, 0, ctx->stream>>>((int64_t)g->nv * heads, rowdot, sl,
+                                                                                           sr, vrec);
   GAIB_LAUNCH_CHECK();
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
-  // gathers in flight per lane and table: 8 (142 VGPRs, 3 waves per SIMD) or 4 (option gat_fused_unroll)
+  // edges in flight per group: 8 or 4 (option gat_fused_unroll)
 #define GAIB_FB_U(HH, UU)                                                                                                 \
   gat_bwd_fused_chunk_kernel<16, HH, UU><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,        \
                                                                         g->chunk_start, g->rowptr, g->colidx, g->rev, len, \
-                                                                        d_feat, d_grad, d_norm_scores, rowdot, sl, sr,     \
-                                                                        epsilon, out_partial, rc_partial)
+                                                                        d_feat, d_grad, d_norm_scores, vrec, epsilon,      \
+                                                                        out_partial, rc_partial)
 #define GAIB_FB(HH)                      \
   do {                                   \
     if (ctx->gat_fused_unroll == 4) GAIB_FB_U(HH, 4); \
