@@ -62,6 +62,10 @@ SIGNATURES = {
     "gaib_gat_softmax_bwd_alpha_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_ex": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_re": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gaib_gat_softmax_bwd_rows": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp]),
+    "gaib_edge_gather_perm": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "gaib_edge_rowsum": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "gaib_gat_alpha_grads": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gaib_gat_backward_fused": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_edge_transpose_mh": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -106,6 +110,7 @@ SIGNATURES = {
     "gaib_halo_bytes_sent": (_i64, [_vp]),
     "gaib_halo_exchange_begin": (_i, [_vp, _i, _vp]),
     "gaib_halo_exchange_end": (_i, [_vp, _pp]),
+    "gaib_halo_reduce": (_i, [_vp, _i, _vp, _vp]),
     "gaib_probe_stream_copy": (_i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
     "gaib_probe_peer_copy": (_i, [_i, _i, C.c_size_t, _i, _i, C.POINTER(C.c_double)]),
 }
@@ -185,6 +190,10 @@ class Halo:
         p = C.c_void_p()
         _check(self.lib.gaib_halo_exchange_end(self.h, C.byref(p)), "gaib_halo_exchange_end")
         return p.value or 0
+
+    def reduce(self, halo_rows, rows, length: int):
+        """rows[send_idx[k]] += what the peers hold for this rank's vertices (the reverse exchange)"""
+        _check(self.lib.gaib_halo_reduce(self.h, length, _ptr(halo_rows), _ptr(rows)), "gaib_halo_reduce")
 
     @property
     def bytes_sent(self) -> int:

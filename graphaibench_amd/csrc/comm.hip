@@ -99,6 +99,10 @@ struct ShmSlot {  // one rank's published send buffer of one halo plan
   int32_t pad;
   hipIpcMemHandle_t handle;
   int64_t send_off[GAIB_COMM_MAX_RANKS + 1];  // row offsets of the per-destination groups inside the buffer
+  // the reverse direction (gaib_halo_reduce): the rank's halo table, grouped by OWNER rank
+  uint64_t gen_t;
+  hipIpcMemHandle_t handle_t;
+  int64_t recv_off[GAIB_COMM_MAX_RANKS + 1];
 };
 struct ShmSeg {
   std::atomic<uint32_t> magic;
@@ -153,6 +157,8 @@ struct gaib_halo {
   struct Peer {
     uint64_t gen;
     void* base;
+    uint64_t gen_t;  // the peer's halo table (reverse direction)
+    void* base_t;
   } peer[GAIB_COMM_MAX_RANKS];
   int64_t bytes_sent;
 };
@@ -490,8 +496,10 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   (void)hipStreamSynchronize(c->cstream);
   (void)hipStreamSynchronize(c->ctx->stream);
   if (c->transport == GAIB_COMM_IPC) {
-    for (int r = 0; r < c->nranks; r++)
+    for (int r = 0; r < c->nranks; r++) {
       if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
+      if (h->peer[r].base_t) (void)hipIpcCloseMemHandle(h->peer[r].base_t);
+    }
     // nobody may still be pulling from the send buffer that is about to be freed
     if (c->seg && !c->seg->error.load()) (void)shm_barrier(c, "gaib_halo_destroy");
   }
@@ -616,5 +624,114 @@ extern "C" int gaib_halo_exchange_end(gaib_halo* h, const float** d_table) {
   }
   GAIB_HIP(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
   *d_table = h->table;
+  return GAIB_OK;
+}
+
+// d_rows[idx[k], :] += buf[k, :]; the row ids of one peer's segment are distinct (ascending), one wave per row
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int64_t n, const int64_t* idx, int len, const float* buf,
+                                                               float* rows) {
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const int lane = threadIdx.x & 63;
+  float* dst = rows + idx[k] * (int64_t)len;
+  const float* src = buf + k * (int64_t)len;
+  for (int c = lane; c < len; c += 64) dst[c] += src[c];
+}
+
+// The reverse of an exchange: every rank holds partial rows for its HALO vertices (d_halo_rows, the table's layout:
+// grouped by owner rank) and returns them to their owners, which add what arrives to their own rows:
+//   d_rows[send_idx[k], :] += arrived[k, :]        peer by peer in rank order (deterministic, no atomics).
+// The transposed aggregation of GAT backward on a partition (out_c += p_(i->c) grad_i for rows i of another rank).
+// Collective; stream-ordered on RCCL, host-synchronous on IPC.
+extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows, float* d_rows) {
+  GAIB_CHECK(h && len >= 1, "gaib_halo_reduce: bad argument");
+  GAIB_CHECK(h->pending_len == 0, "gaib_halo_reduce: an exchange is in flight on this plan");
+  gaib_comm* c = h->c;
+  gaib_ctx* ctx = c->ctx;
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
+  GAIB_CHECK((n_recv == 0 || d_halo_rows) && (n_send == 0 || d_rows), "gaib_halo_reduce: NULL rows");
+  const size_t row_bytes = sizeof(float) * (size_t)len;
+  int ra = reserve(&h->sendbuf, &h->send_cap, row_bytes * (size_t)n_send, ctx->stream);  // arrivals land here
+  if (ra < 0) return fail(c, ra);
+  if (c->transport == GAIB_COMM_RCCL) {
+    GAIB_HIP(hipEventRecord(c->ev_ready, ctx->stream));
+    GAIB_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+    if (c->nranks > 1) {
+      GAIB_NCCL(g_rccl.GroupStart());
+      for (int r = 0; r < c->nranks; r++) {
+        if (h->recv_counts[r])
+          GAIB_NCCL(g_rccl.Send(d_halo_rows + h->recv_off[r] * len, (size_t)(h->recv_counts[r] * len), ncclFloat32, r, c->nccl,
+                                c->cstream));
+        if (h->send_counts[r])
+          GAIB_NCCL(g_rccl.Recv(h->sendbuf + h->send_off[r] * len, (size_t)(h->send_counts[r] * len), ncclFloat32, r, c->nccl,
+                                c->cstream));
+      }
+      GAIB_NCCL(g_rccl.GroupEnd());
+    }
+    GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
+    GAIB_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+  } else {
+    // IPC: stage the partial rows in this plan's own table allocation (a whole allocation can be exported), publish it,
+    // and let the owners pull their segments
+    int rb = reserve(&h->table, &h->table_cap, row_bytes * (size_t)n_recv, ctx->stream);
+    if (rb < 0) return fail(c, rb);
+    hipError_t e = hipSuccess;
+    if (n_recv && d_halo_rows != h->table)
+      e = hipMemcpyAsync(h->table, d_halo_rows, row_bytes * (size_t)n_recv, hipMemcpyDeviceToDevice, ctx->stream);
+    ShmSlot* mine = &c->seg->slot[h->id][c->rank];
+    if (e == hipSuccess && (rb == 1 || mine->gen_t == 0)) {
+      e = hipIpcGetMemHandle(&mine->handle_t, h->table);
+      for (int r = 0; r <= c->nranks; r++) mine->recv_off[r] = h->recv_off[r];
+      mine->gen_t++;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_halo_reduce: %s", hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+    int rc = shm_barrier(c, "gaib_halo_reduce (all staged)");
+    if (rc != GAIB_OK) return rc;
+    for (int r = 0; r < c->nranks; r++) {
+      if (!h->send_counts[r]) continue;  // rank r holds partial rows for send_counts[r] of this rank's vertices
+      const ShmSlot* ps = &c->seg->slot[h->id][r];
+      if (h->peer[r].gen_t != ps->gen_t) {
+        if (h->peer[r].base_t) (void)hipIpcCloseMemHandle(h->peer[r].base_t);
+        h->peer[r].base_t = nullptr;
+        e = hipIpcOpenMemHandle(&h->peer[r].base_t, ps->handle_t, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+          gaib_set_error("gaib_halo_reduce(rank %d): hipIpcOpenMemHandle(rank %d's halo table): %s", c->rank, r,
+                         hipGetErrorString(e));
+          return fail(c, GAIB_ERR_HIP);
+        }
+        h->peer[r].gen_t = ps->gen_t;
+      }
+      if (ps->recv_off[c->rank + 1] - ps->recv_off[c->rank] != h->send_counts[r]) {
+        gaib_set_error("gaib_halo_reduce(rank %d): rank %d returns %lld rows, this rank expects %lld", c->rank, r,
+                       (long long)(ps->recv_off[c->rank + 1] - ps->recv_off[c->rank]), (long long)h->send_counts[r]);
+        return fail(c, GAIB_ERR_INVALID);
+      }
+      const float* src = (const float*)h->peer[r].base_t + ps->recv_off[c->rank] * len;
+      e = hipMemcpyAsync(h->sendbuf + h->send_off[r] * len, src, row_bytes * (size_t)h->send_counts[r],
+                         hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) {
+        gaib_set_error("gaib_halo_reduce(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
+        return fail(c, GAIB_ERR_HIP);
+      }
+    }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_halo_reduce: %s", hipGetErrorString(e));
+      return fail(c, GAIB_ERR_HIP);
+    }
+    rc = shm_barrier(c, "gaib_halo_reduce (all pulled)");  // the tables may be overwritten from here on
+    if (rc != GAIB_OK) return rc;
+  }
+  for (int r = 0; r < c->nranks; r++) {
+    if (!h->send_counts[r]) continue;
+    scatter_add_rows_kernel<<<(unsigned)cdiv64(h->send_counts[r], 4), 256, 0, ctx->stream>>>(
+        h->send_counts[r], h->d_send_idx + h->send_off[r], len, h->sendbuf + h->send_off[r] * len, d_rows);
+  }
+  GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }

@@ -816,9 +816,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H,
 //
 // Lanes: group k = lane / G owns edges k*G .. k*G+G-1 of the chunk, lane sl = lane % G owns 4 columns (head = sl / LH,
 // LH = G / H lanes per head).  EVERYTHING is fetched in that layout, U edges per group in flight: the two rows (16 B per
-// lane), the column vertex's per-head record vrec[c][head] = (rowdot, sl, sr, -) (16 B: the three per-vertex scalars in
-// one access, 4H floats = one 128-B line per vertex at 8 heads) and the two attention values p_e, p_r (4 B each), so the
-// only dependent step is col / rev -> gathers, as in spmm_chunk_kernel.  A first version kept the per-(edge, head)
+// lane), rowdot of the column vertex and the two attention values p_e, p_r (4 B each), so the only dependent step is
+// col / rev -> gathers, as in spmm_chunk_kernel.  A first version kept the per-(edge, head)
 // scalars one EDGE per lane (H-vectors) and met the column layout through LDS: 64 different lines per wave instruction
 // for each of five H-vector fetches, a dependent post-phase and 178 -> 142 VGPRs made it 10.5 ms at the reddit shape
 // against 12.3 ms for the staged kernels.
@@ -826,7 +825,8 @@ template <int G, int H, int U>
 __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
-    const float* p, const f4* vrec, float eps, float* out_partial, float* rc_partial) {
+    const float* p, const float* rowdot, const float* alpha_l, const float* alpha_r, float eps, float* out_partial,
+    float* rc_partial) {
   constexpr int LH = G / H;  // lanes per head
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
@@ -844,13 +844,25 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   const int head = sl / LH;
   const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)len + coff);
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
-  const f4 vi = vrec[row * H + head];  // (rowdot_i, sl_i, sr_i) of this lane's head
+  // the per-vertex dots a_l.h_v, a_r.h_v are formed again from the gathered rows (4 FMAs + the head's shuffle each)
+  // instead of being gathered: only rowdot, which needs the vertex's forward output, comes from a table -- [nv][H]
+  // floats, small enough for the L2, where a (rowdot, sl, sr) record per (vertex, head) cost a 128-B line per edge
+  const f4 al4 = *reinterpret_cast<const f4*>(alpha_l + coff);
+  const f4 ar4 = *reinterpret_cast<const f4*>(alpha_r + coff);
+  float sl_i = al4[0] * hi[0] + al4[1] * hi[1] + al4[2] * hi[2] + al4[3] * hi[3];
+  float sr_i = ar4[0] * hi[0] + ar4[1] * hi[1] + ar4[2] * hi[2] + ar4[3] * hi[3];
+#pragma unroll
+  for (int o = LH / 2; o > 0; o >>= 1) {
+    sl_i += __shfl_xor(sl_i, o, 64);
+    sr_i += __shfl_xor(sr_i, o, 64);
+  }
+  const float rd_i = rowdot[row * H + head];
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   float s_e = 0.f, s_r = 0.f;
 #pragma unroll
   for (int j = 0; j < G; j += U) {
-    f4 xg[U], xh[U], vr[U];
-    float pe[U], pr[U];
+    f4 xg[U], xh[U];
+    float pe[U], pr[U], rd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ei = gbase + j + u;
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
       const uint32_t rj = (uint32_t)__shfl((int)rl, ei, 64);
       xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
-      vr[u] = vrec[(int64_t)cj * H + head];
+      rd[u] = rowdot[(int64_t)cj * H + head];
       pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
       pr[u] = p[(int64_t)rj * H + head];
     }
@@ -868,16 +880,20 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
       const bool live = gbase + j + u < n;
       float dpe = gi[0] * xh[u][0] + gi[1] * xh[u][1] + gi[2] * xh[u][2] + gi[3] * xh[u][3];
       float dpr = xg[u][0] * hi[0] + xg[u][1] * hi[1] + xg[u][2] * hi[2] + xg[u][3] * hi[3];
+      float sl_c = al4[0] * xh[u][0] + al4[1] * xh[u][1] + al4[2] * xh[u][2] + al4[3] * xh[u][3];
+      float sr_c = ar4[0] * xh[u][0] + ar4[1] * xh[u][1] + ar4[2] * xh[u][2] + ar4[3] * xh[u][3];
 #pragma unroll
       for (int o = LH / 2; o > 0; o >>= 1) {
         dpe += __shfl_xor(dpe, o, 64);
         dpr += __shfl_xor(dpr, o, 64);
+        sl_c += __shfl_xor(sl_c, o, 64);
+        sr_c += __shfl_xor(sr_c, o, 64);
       }
       const float a = pe[u], b = pr[u];
-      const float dse = a * (1.0f - a) * dpe - (vi[0] - a * dpe) * a;
-      const float dsr = b * (1.0f - b) * dpr - (vr[u][0] - b * dpr) * b;
-      const float ge = dse * ((vi[1] + vr[u][2]) > 0.0f ? 1.0f : eps);  // leaky-relu' at sl_i + sr_c
-      const float gr = dsr * ((vr[u][1] + vi[2]) > 0.0f ? 1.0f : eps);  //              at sl_c + sr_i
+      const float dse = a * (1.0f - a) * dpe - (rd_i - a * dpe) * a;
+      const float dsr = b * (1.0f - b) * dpr - (rd[u] - b * dpr) * b;
+      const float ge = dse * ((sl_i + sr_c) > 0.0f ? 1.0f : eps);  // leaky-relu' at the score of (i -> c)
+      const float gr = dsr * ((sl_c + sr_i) > 0.0f ? 1.0f : eps);  //              at the score of (c -> i)
       if (live) {  // (lanes past the end of a short chunk looked at the chunk's first edge: nothing of it is added)
         s_e += ge;
         s_r += gr;
@@ -904,12 +920,6 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
       rc_partial[slot * 2 * H + H + head] = s_r;  // partial column sum of g (-> alpha_r gradient)
     }
   }
-}
-
-// vrec[v][h] = (rowdot, sl, sr, 0): the three per-(vertex, head) scalars of the fused sweep in one 16-B record
-__global__ void vrec_pack_kernel(int64_t n, const float* rowdot, const float* sl, const float* sr, f4* vrec) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) vrec[i] = f4{rowdot[i], sl[i], sr[i], 0.f};
 }
 
 // out[row] = sum of the row's chunk partials in chunk order; rs / cs [row][H] the same for the g sums
@@ -1027,15 +1037,16 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   GAIB_TRY(check_heads("gaib_gat_scores", len, heads));
   if (g->nv == 0) return GAIB_OK;
   GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_norm_scores, "gaib_gat_scores: NULL pointer");
-  GAIB_CHECK(g->nc == g->nv, "gaib_gat_scores: square graphs only");
+  // rectangular graphs (a rank's rows over [owned | halo] columns): d_h is the COLUMN table [nc x len] whose first nv
+  // rows are the rows' own vectors; the per-vertex dots are taken over all nc rows
+  const int64_t nt = g->nc > g->nv ? g->nc : g->nv;
   GAIB_HIP(hipSetDevice(ctx->device));
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)g->nv * heads));
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * (size_t)nt * heads));
   float* sl = (float*)ctx->ws;
-  float* sr = sl + g->nv * heads;
+  float* sr = sl + nt * heads;
   {
     ProfScope ps(ctx, "gat_vertex_dots");
-    vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_h, d_alpha_l,
-                                                                d_alpha_r, sl, sr);
+    vertex_dots_kernel<<<rowgrid(nt), 256, 0, ctx->stream>>>(nt, len, heads, d_h, d_alpha_l, d_alpha_r, sl, sr);
   }
   GAIB_LAUNCH_CHECK();
   {
@@ -1243,33 +1254,27 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
   const size_t n_v = up4((size_t)g->nv * heads);
   const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (9 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
-  float* sl = (float*)ctx->ws;
-  float* sr = sl + n_v;
-  float* rowdot = sr + n_v;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (3 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
+  float* rowdot = (float*)ctx->ws;
   float* rs = rowdot + n_v;
   float* cs = rs + n_v;
-  f4* vrec = reinterpret_cast<f4*>(cs + n_v);  // [nv * heads] records of 4 floats
-  float* out_partial = cs + n_v + 4 * n_v;
+  float* out_partial = cs + n_v;
   float* rc_partial = out_partial + n_op;
   float* partial = rc_partial + n_rc;
   ProfScope ps(ctx, "gat_bwd_fused");
-  vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_feat, d_alpha_l, d_alpha_r, sl, sr);
   rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
-  vrec_pack_kernel<<<(unsigned)cdiv64((int64_t)g->nv * heads, 256), 256, 0, ctx->stream>>>((int64_t)g->nv * heads, rowdot, sl,
-                                                                                           sr, vrec);
   GAIB_LAUNCH_CHECK();
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
   // edges in flight per group: 8 or 4 (option gat_fused_unroll)
 #define GAIB_FB_U(HH, UU)                                                                                                 \
   gat_bwd_fused_chunk_kernel<16, HH, UU><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,        \
                                                                         g->chunk_start, g->rowptr, g->colidx, g->rev, len, \
-                                                                        d_feat, d_grad, d_norm_scores, vrec, epsilon,      \
-                                                                        out_partial, rc_partial)
+                                                                        d_feat, d_grad, d_norm_scores, rowdot, d_alpha_l,  \
+                                                                        d_alpha_r, epsilon, out_partial, rc_partial)
 #define GAIB_FB(HH)                      \
   do {                                   \
-    if (ctx->gat_fused_unroll == 4) GAIB_FB_U(HH, 4); \
-    else GAIB_FB_U(HH, 8);               \
+    if (ctx->gat_fused_unroll == 8) GAIB_FB_U(HH, 8); \
+    else GAIB_FB_U(HH, 4);               \
   } while (0)
   switch (heads) {
     case 1: GAIB_FB(1); break;
@@ -1285,6 +1290,111 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
                                                                    rc_partial, d_grad_out, rs, cs);
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
+                                                                         rows_per_block, partial);
+  GAIB_LAUNCH_CHECK();
+  alpha_final_kernel<<<(unsigned)cdiv64(2 * (int64_t)len, 4), 256, 0, ctx->stream>>>(nblocks, len, partial, d_alpha_lgrad,
+                                                                                    d_alpha_rgrad);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+// ---- the pieces of GAT backward that work on RECTANGULAR graphs (a rank's share of a partition) ------
+// On a partition the reverse edge of (i -> c) lives on the rank that owns c, so the reverse-edge permutation of the
+// square path is replaced by the rank's TRANSPOSED local structure (rows = owned + halo vertices, columns = owned rows,
+// built by the host with the edge permutation CSC position -> CSR edge id):
+//   gaib_gat_softmax_bwd_rows  per-row softmax backward + leaky-relu': g_e and the row sums rs (no column side)
+//   gaib_edge_gather_perm      out_e[k] = in_e[perm[k]]   (g and p in transposed order)
+//   gaib_edge_rowsum           out[v] = sum over row v of an edge array   (column sums of g = row sums over the transpose)
+//   gaib_gat_alpha_grads       alpha_l' = sum_v rs[v] x[v], alpha_r' = sum_v cs[v] x[v]   (fixed two-level reduction)
+// and the transposed aggregation is gaib_spmm_mh on the transposed graph followed by gaib_halo_reduce.
+extern "C" int gaib_gat_softmax_bwd_rows(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_norm_scores,
+                                         const float* d_norm_scores_grad, const float* d_temp_scores, float epsilon,
+                                         float* d_g_out, float* d_rs_out) {
+  GAIB_CHECK(ctx && g && d_norm_scores && d_norm_scores_grad && d_temp_scores && d_g_out && d_rs_out,
+             "gaib_gat_softmax_bwd_rows: NULL argument");
+  GAIB_CHECK(heads >= 1, "gaib_gat_softmax_bwd_rows: heads must be >= 1");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (g->nv == 0) return GAIB_OK;
+  const bool al16 = (((uintptr_t)d_norm_scores | (uintptr_t)d_norm_scores_grad | (uintptr_t)d_temp_scores |
+                      (uintptr_t)d_g_out | (uintptr_t)d_rs_out) & 15) == 0;
+  ProfScope ps(ctx, "gat_softmax_bwd_alpha");
+  GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
+  const uint32_t* rl = g->heavy_rows;
+  const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;
+  const int thr = g->n_heavy > 0 ? g->heavy_thr : 0;
+  const unsigned nh = (unsigned)g->n_heavy, blk = ROW_BLK_WAVES * 64;
+  const unsigned lg = rowgrid_w(ctx, g->nv), lb = (unsigned)ctx->gat_row_waves * 64;
+#define GAIB_ROWS(HH)                                                                                                    \
+  do {                                                                                                                   \
+    if (nh)                                                                                                              \
+      softmax_bwd_v2_kernel<HH, true, false, false><<<nh, blk, 0, ctx->stream>>>(                                        \
+          g->nv, g->rowptr, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, nullptr, nullptr, d_g_out, 0,      \
+          d_rs_out, thr, rl, ro, g->colidx, nullptr, nullptr);                                                           \
+    softmax_bwd_v2_kernel<HH, false, false, false><<<lg, lb, 0, ctx->stream>>>(                                          \
+        g->nv, g->rowptr, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon, nullptr, nullptr, d_g_out, 0,        \
+        d_rs_out, thr, rl, ro, g->colidx, nullptr, nullptr);                                                             \
+  } while (0)
+  if (heads == 1) GAIB_ROWS(1);
+  else if (heads == 2) GAIB_ROWS(2);
+  else if (heads == 4 && al16) GAIB_ROWS(4);
+  else if (heads == 8 && al16) GAIB_ROWS(8);
+  else if (heads == 16 && al16) GAIB_ROWS(16);
+  else {
+    // generic head counts: the kernel also writes ds; park it in the workspace
+    GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)g->ne * heads));
+    softmax_bwd_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_norm_scores, d_norm_scores_grad,
+                                                                d_temp_scores, epsilon, (float*)ctx->ws, d_g_out, d_rs_out);
+  }
+#undef GAIB_ROWS
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_edge_gather_perm(gaib_ctx* ctx, int64_t ne, int heads, const uint32_t* d_perm, const float* d_in_e,
+                                     float* d_out_e) {
+  GAIB_CHECK(ctx && heads >= 1 && ne >= 0, "gaib_edge_gather_perm: bad argument");
+  if (ne == 0) return GAIB_OK;
+  GAIB_CHECK(d_perm && d_in_e && d_out_e && d_in_e != d_out_e, "gaib_edge_gather_perm: NULL or aliased pointer");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  edge_gather_kernel<<<(unsigned)cdiv64(ne * heads, 256), 256, 0, ctx->stream>>>(ne, heads, d_perm, d_in_e, d_out_e);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+__global__ __launch_bounds__(256) void edge_rowsum_kernel(int64_t nv, int H, const int64_t* rowptr, const float* in_e,
+                                                          float* out) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) s += in_e[e * H + h];
+    s = wave_sum(s);
+    if (lane == 0) out[row * H + h] = s;
+  }
+}
+
+extern "C" int gaib_edge_rowsum(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_in_e, float* d_out_rows) {
+  GAIB_CHECK(ctx && g && heads >= 1 && d_out_rows && (d_in_e || g->ne == 0), "gaib_edge_rowsum: bad argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (g->nv == 0) return GAIB_OK;
+  edge_rowsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_in_e, d_out_rows);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_gat_alpha_grads(gaib_ctx* ctx, int64_t nv, int len, int heads, const float* d_x, const float* d_rs,
+                                    const float* d_cs, float* d_alpha_lgrad, float* d_alpha_rgrad) {
+  GAIB_CHECK(ctx && d_x && d_rs && d_cs && d_alpha_lgrad && d_alpha_rgrad && nv >= 1,
+             "gaib_gat_alpha_grads: bad argument");
+  GAIB_TRY(check_heads("gaib_gat_alpha_grads", len, heads));
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const int nblocks = (int)(nv < 2048 ? cdiv64(nv, 8) : 1024);
+  const int64_t rows_per_block = cdiv64(nv, nblocks);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)nblocks * 2 * len));
+  float* partial = (float*)ctx->ws;
+  alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(nv, len, heads, d_x, d_rs, d_cs,
                                                                          rows_per_block, partial);
   GAIB_LAUNCH_CHECK();
   alpha_final_kernel<<<(unsigned)cdiv64(2 * (int64_t)len, 4), 256, 0, ctx->stream>>>(nblocks, len, partial, d_alpha_lgrad,

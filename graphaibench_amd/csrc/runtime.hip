@@ -59,7 +59,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_chunk_colsum = -1;
   c->graph_rev_search = 0;
   c->gat_fused_bwd = -1;
-  c->gat_fused_unroll = 8;
+  c->gat_fused_unroll = 4;
   c->prof_on = 0;
   *out = c;
   return GAIB_OK;

@@ -109,7 +109,8 @@ void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* 
 GAT_Aggregator::GAT_Aggregator()
     : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
-      d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), d_tbuf(NULL), tbuf_floats(0), alpha_opt(NULL) {}
+      d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), d_tbuf(NULL), tbuf_floats(0), d_ptab(NULL), d_pout(NULL),
+      d_prs(NULL), d_pcs(NULL), ptab_floats(0), pvec_floats(0), alpha_opt(NULL) {}
 
 void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   length = l;
@@ -164,7 +165,89 @@ void GAT_Aggregator::set_num_heads(int h) {
   d_temp_scores = needs_temp() ? gaib_host::dmalloc<float>(num_edges * heads) : NULL;
 }
 
+// ---- GAT on a vertex-range partition ("h halo rows for the scores, g halo rows for the transposed
+// aggregation") ----
+// forward: the halo rows of h arrive while the owned rows are copied into one column table [owned | halo]; scores,
+// edge softmax and aggregation then run unchanged on the rank's rectangular graph over that column space.
+// backward: the reverse edge of (i -> c) belongs to the rank that owns c, so instead of the reverse-edge permutation the
+// rank's TRANSPOSED local structure is used: column sums of g (alpha_r gradient) are row sums over the transpose, and
+// the gradient aggregation out_c = sum_i p_(i->c) grad_i is an SpMM over the transpose whose halo rows -- partial sums
+// for vertices of other ranks -- travel back to their owners and are added there (gaib_halo_reduce).
+void GAT_Aggregator::ensure_partition_buffers(Graph& g, int len) {
+  const size_t nc = g.size() + g.gat_n_halo();
+  if (nc * len > ptab_floats) {
+    if (d_ptab) float_free_device(d_ptab);
+    if (d_pout) float_free_device(d_pout);
+    float_malloc_device64(nc * len, d_ptab);
+    float_malloc_device64(nc * len, d_pout);
+    ptab_floats = nc * len;
+  }
+  if (nc * heads > pvec_floats) {
+    if (d_prs) float_free_device(d_prs);
+    if (d_pcs) float_free_device(d_pcs);
+    float_malloc_device64(nc * heads, d_prs);
+    float_malloc_device64(nc * heads, d_pcs);
+    GAIB_OR_DIE(gaib_fill_f32(C(), (int64_t)(nc * heads), 0.f, d_prs));  // rows of halo vertices stay 0
+    pvec_floats = nc * heads;
+  }
+  if (!d_temp_scores) d_temp_scores = gaib_host::dmalloc<float>(num_edges * heads);  // the row-side backward reads it
+}
+
+void GAT_Aggregator::aggregate_partition(int len, Graph& g, const float* in, float* out) {
+  const size_t n_own = g.size(), n_halo = g.gat_n_halo();
+  ensure_partition_buffers(g, len);
+  {
+    OpTimer t(OP_SCORE);
+    g.halo_begin(len, in);
+    GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_ptab, in, sizeof(float) * n_own * len));
+    const float* halo = g.halo_end(len);
+    if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_ptab + n_own * len, halo, sizeof(float) * n_halo * len));
+    GAIB_OR_DIE(gaib_gat_scores_mh(C(), g.gat_full_graph(), len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon,
+                                   d_temp_scores, NULL, d_norm_scores));
+  }
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm_mh(C(), g.gat_full_graph(), GAIB_W_EDGE, d_norm_scores, heads, len, d_ptab, out,
+                           fuse_relu ? GAIB_RELU : 0));
+  fuse_relu = false;
+}
+
+void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_in, float* grad_out) {
+  const size_t n_own = g.size(), n_halo = g.gat_n_halo(), nc = n_own + n_halo;
+  const int64_t ne = (int64_t)g.sizeEdges();
+  gaib_graph *full = g.gat_full_graph(), *gt = g.gat_transposed_graph();
+  fwd_out = NULL;
+  ensure_partition_buffers(g, len);
+  {
+    OpTimer t(OP_SCORE);
+    GAIB_OR_DIE(gaib_sddmm_mh(C(), full, len, heads, grad_in, d_ptab, d_norm_scores_grad));
+  }
+  {
+    OpTimer t(OP_ATTN);
+    GAIB_OR_DIE(gaib_gat_softmax_bwd_rows(C(), full, heads, d_norm_scores, d_norm_scores_grad, d_temp_scores, epsilon,
+                                          d_norm_scores_t /* g_e */, d_prs));
+    GAIB_OR_DIE(gaib_edge_gather_perm(C(), ne, heads, g.gat_tperm(), d_norm_scores_t, d_norm_scores_grad));
+    GAIB_OR_DIE(gaib_edge_rowsum(C(), gt, heads, d_norm_scores_grad, d_pcs));
+    GAIB_OR_DIE(gaib_gat_alpha_grads(C(), (int64_t)nc, len, heads, d_ptab, d_prs, d_pcs, d_alpha_lgrad, d_alpha_rgrad));
+  }
+  {
+    OpTimer t(OP_TRANSPOSE);
+    GAIB_OR_DIE(gaib_edge_gather_perm(C(), ne, heads, g.gat_tperm(), d_norm_scores, d_norm_scores_grad));
+  }
+  OpTimer t(OP_SPARSEMM);
+  GAIB_OR_DIE(gaib_spmm_mh(C(), gt, GAIB_W_EDGE, d_norm_scores_grad, heads, len, grad_in, d_pout, 0));
+  GAIB_OR_DIE(gaib_memcpy_d2d(C(), grad_out, d_pout, sizeof(float) * n_own * len));
+  GAIB_OR_DIE(gaib_halo_reduce(g.halo_plan(), len, d_pout + n_own * len, grad_out));
+}
+
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
+  if (g.gat_full_graph()) {
+    aggregate_partition(len, g, in, out);
+    return;
+  }
+  if (g.has_halo()) {
+    fprintf(stderr, "GAT_Aggregator: this partitioned graph was built without build_gat_structures()\n");
+    exit(EXIT_FAILURE);
+  }
   if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
     num_edges = g.sizeEdges();
     float** arrays[] = {&d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
@@ -194,6 +277,10 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
 // feat_in is last read by the alpha-gradient step, grad_out is first written by the final SpMM.
 void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in,
                                  float* grad_out) {
+  if (g.gat_full_graph()) {
+    d_aggregate_partition(len, g, grad_in, grad_out);
+    return;
+  }
   if (fwd_out) {
     // one sweep over the edges instead of four (gaib_gat_backward_fused): needs the layer's forward output and an
     // output that does not alias feat_in (GAT_layer::backward passes out_temp for both) -> a scratch of its own

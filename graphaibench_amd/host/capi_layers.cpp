@@ -170,6 +170,9 @@ void gaibl_free_host(void* p) { free(p); }
 void* gaibl_partition_build(uint32_t nv, const uint32_t* rowptr, const uint32_t* colidx, int rank, int world) {
   return new VertexRangePartition(build_vertex_range_partition((int64_t)nv, rowptr, colidx, rank, world));
 }
+void gaibl_partition_build_gat(void* part, const uint32_t* rowptr, const uint32_t* colidx) {
+  build_gat_structures(*static_cast<VertexRangePartition*>(part), rowptr, colidx);
+}
 int64_t gaibl_partition_array(void* part, int which, const void** data) {
   VertexRangePartition* P = static_cast<VertexRangePartition*>(part);
 #define ARR(v) { *data = (v).data(); return (int64_t)(v).size(); }
@@ -184,6 +187,11 @@ int64_t gaibl_partition_array(void* part, int which, const void** data) {
     case 7: ARR(P->recv_counts)
     case 8: ARR(P->send_counts)
     case 9: ARR(P->send_idx)
+    case 10: ARR(P->rowptr_full)
+    case 11: ARR(P->colidx_full)
+    case 12: ARR(P->rowptr_t)
+    case 13: ARR(P->colidx_t)
+    case 14: ARR(P->tperm)
     default: *data = nullptr; return -1;
   }
 #undef ARR

@@ -92,6 +92,41 @@ VertexRangePartition build_vertex_range_partition(int64_t n, const index_t* rowp
   return P;
 }
 
+void build_gat_structures(VertexRangePartition& P, const index_t* rowptr, const index_t* colidx) {
+  const int64_t n_own = P.n_own(), n_halo = P.n_halo(), nc = n_own + n_halo;
+  // global id -> local column id: owned vertices first, then the halo vertices in ascending global order
+  auto local_of = [&](index_t c) -> index_t {
+    if ((int64_t)c >= P.lo && (int64_t)c < P.hi) return (index_t)(c - P.lo);
+    const auto it = std::lower_bound(P.halo_gids.begin(), P.halo_gids.end(), (int64_t)c);
+    return (index_t)(n_own + (it - P.halo_gids.begin()));
+  };
+  P.rowptr_full.assign(n_own + 1, 0);
+  for (int64_t i = 0; i < n_own; i++) P.rowptr_full[i + 1] = P.rowptr_full[i] + P.degree[i];
+  const int64_t ne = P.rowptr_full[n_own];
+  P.colidx_full.resize(std::max<int64_t>(ne, 1));
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t i = 0; i < n_own; i++) {
+    int64_t k = P.rowptr_full[i];
+    for (index_t e = rowptr[P.lo + i]; e < rowptr[P.lo + i + 1]; e++) P.colidx_full[k++] = local_of(colidx[e]);
+  }
+  P.colidx_full.resize(ne);
+  // transpose by counting sort on the local column id; stable, so the rows of a column come out ascending
+  P.rowptr_t.assign(nc + 1, 0);
+  for (int64_t e = 0; e < ne; e++) P.rowptr_t[P.colidx_full[e] + 1]++;
+  for (int64_t v = 0; v < nc; v++) P.rowptr_t[v + 1] += P.rowptr_t[v];
+  P.colidx_t.resize(std::max<int64_t>(ne, 1));
+  P.tperm.resize(std::max<int64_t>(ne, 1));
+  std::vector<int64_t> cur(P.rowptr_t.begin(), P.rowptr_t.end() - 1);
+  for (int64_t i = 0; i < n_own; i++)
+    for (int64_t e = P.rowptr_full[i]; e < P.rowptr_full[i + 1]; e++) {
+      const int64_t k = cur[P.colidx_full[e]]++;
+      P.colidx_t[k] = (index_t)i;
+      P.tperm[k] = (index_t)e;
+    }
+  P.colidx_t.resize(ne);
+  P.tperm.resize(ne);
+}
+
 // deg^-1/2 (0 for isolated vertices) and (float)(1.0 / float(deg)) with the roundings of compute_vertex_data
 // (src/gnn/lgraph.cpp:22-34) and sage_aggregator.cpp:18,44 -- the same expressions as csrc/graph.hip
 static void normalisers(const std::vector<int64_t>& deg, std::vector<float>& vd, std::vector<float>& inv) {
@@ -137,6 +172,18 @@ LearningGraph* make_partitioned_graph(const VertexRangePartition& P, gaib_comm* 
     gaib_halo* plan = nullptr;
     GAIB_OR_DIE(gaib_halo_create(comm, P.send_counts.data(), P.send_idx.data(), 0, P.recv_counts.data(), &plan));
     lg->set_halo_plan(g_halo, plan);
+  }
+  if (!P.rowptr_full.empty()) {
+    // GAT: one rectangular graph over [owned | halo] columns + its transpose + the edge permutation between them
+    const int64_t nc = n_own + n_halo, ne = (int64_t)P.colidx_full.size();
+    gaib_graph *g_full = nullptr, *g_t = nullptr;
+    GAIB_OR_DIE(gaib_graph_create_rect(ctx, n_own, nc, ne, P.rowptr_full.data(), 64,
+                                       P.colidx_full.empty() ? &dummy : P.colidx_full.data(), 0, &g_full));
+    GAIB_OR_DIE(gaib_graph_create_rect(ctx, nc, std::max<int64_t>(n_own, 1), ne, P.rowptr_t.data(), 64,
+                                       P.colidx_t.empty() ? &dummy : P.colidx_t.data(), 0, &g_t));
+    index_t* d_tperm = gaib_host::dmalloc<index_t>((size_t)ne);
+    if (ne) GAIB_OR_DIE(gaib_memcpy_h2d(ctx, d_tperm, P.tperm.data(), sizeof(index_t) * (size_t)ne));
+    lg->set_gat_partition(g_full, g_t, d_tperm, n_halo, ne);
   }
   float* tmp[] = {d_vd, d_inv, d_vd_h, d_inv_h};  // set_vertex_norm copied them
   for (float* p : tmp) GAIB_OR_DIE(gaib_free(ctx, p));

@@ -13,7 +13,7 @@
 // Architecture is a compile-time choice like in the reference: -DUSE_SAGE / -DUSE_GAT.
 //
 // One process per GPU (no reference counterpart): launched N times with RANK / WORLD_SIZE / LOCAL_RANK
-// (torchrun's variables; GAIB_RANK / GAIB_WORLD override), GCN and GraphSAGE train on a vertex-range partition:
+// (torchrun's variables; GAIB_RANK / GAIB_WORLD override), GCN, GraphSAGE and GAT train on a vertex-range partition:
 // every rank reads the (global) dataset, keeps the rows [lo, hi) of its range (include/gnn/partition.h), exchanges
 // halo feature rows before every aggregation and sums the weight gradients before every optimizer step, all behind
 // the C ABI (gaib_comm_* / gaib_halo_* / gaib_allreduce_f32; transport GAIB_COMM=rccl|ipc).  The run's ncclUniqueId
@@ -101,10 +101,6 @@ struct Trainer {
     rank = env_int("GAIB_RANK", "RANK", 0);
     world = env_int("GAIB_WORLD", "WORLD_SIZE", 1);
     if (world <= 1) return;
-    if (ARCH == gnn_arch::GAT) {
-      std::cerr << "GAT on a vertex-range partition is not in this trainer (see graphaibench_amd/dist.py)\n";
-      exit(EXIT_FAILURE);
-    }
     const char* tr = getenv("GAIB_COMM");
     const int transport = (tr && std::string(tr) == "ipc") ? GAIB_COMM_IPC : GAIB_COMM_RCCL;
     std::string path = getenv("GAIB_COMM_ID_FILE") ? getenv("GAIB_COMM_ID_FILE")
@@ -211,6 +207,8 @@ struct Trainer {
     if (world > 1) {
       // this rank's share: rows [lo, hi) of the global CSR, features / labels / masks of the same rows
       part = build_vertex_range_partition(num_samples, graph->row_start_host_ptr(), graph->edge_dst_host_ptr(), rank, world);
+      if (ARCH == gnn_arch::GAT)  // the [owned | halo] column space and its transpose (include/gnn/partition.h)
+        build_gat_structures(part, graph->row_start_host_ptr(), graph->edge_dst_host_ptr());
       Graph* global = graph;
       graph = make_partitioned_graph(part, comm);
       global->dealloc();

@@ -39,6 +39,7 @@ SIGNATURES = {
                                            C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "gaibl_free_host": (None, [_vp]),
     "gaibl_partition_build": (_vp, [C.c_uint32, _vp, _vp, _i, _i]),
+    "gaibl_partition_build_gat": (None, [_vp, _vp, _vp]),
     "gaibl_partition_array": (C.c_int64, [_vp, _i, C.POINTER(_vp)]),
     "gaibl_partition_range": (None, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gaibl_partition_free": (None, [_vp]),
@@ -202,7 +203,9 @@ class HostPartition:
     _NAMES = ("rowptr_own", "colidx_own", "rowptr_halo", "colidx_halo", "degree", "halo_gids", "halo_degree",
               "recv_counts", "send_counts", "send_idx")
 
-    def __init__(self, rowptr, colidx, rank: int, world: int):
+    _GAT_NAMES = ("rowptr_full", "colidx_full", "rowptr_t", "colidx_t", "tperm")
+
+    def __init__(self, rowptr, colidx, rank: int, world: int, gat: bool = False):
         import numpy as np
 
         rp = np.ascontiguousarray(rowptr, dtype=np.uint32)
@@ -211,13 +214,15 @@ class HostPartition:
         self.rank, self.world = rank, world
         self.h = self.lib.gaibl_partition_build(len(rp) - 1, rp.ctypes.data, ci.ctypes.data if len(ci) else None, rank,
                                                 world)
+        if gat:  # the [owned | halo] column space + its transpose (GAT layers need them)
+            self.lib.gaibl_partition_build_gat(self.h, rp.ctypes.data, ci.ctypes.data if len(ci) else None)
         lo, hi = C.c_int64(), C.c_int64()
         self.lib.gaibl_partition_range(self.h, C.byref(lo), C.byref(hi))
         self.lo, self.hi = lo.value, hi.value
-        for which, name in enumerate(self._NAMES):
+        for which, name in enumerate(self._NAMES + (self._GAT_NAMES if gat else ())):
             ptr = _vp()
             n = self.lib.gaibl_partition_array(self.h, which, C.byref(ptr))
-            dt = np.uint32 if name.startswith("colidx") else np.int64
+            dt = np.uint32 if name.startswith("colidx") or name == "tperm" else np.int64
             arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32 if dt == np.uint32 else C.c_int64)),
                                         (n,)).copy() if n > 0 else np.zeros(0, dt)
             setattr(self, name, arr.astype(dt, copy=False))

@@ -218,6 +218,25 @@ int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, co
                             const float* d_fwd_out, const float* d_alpha_l, const float* d_alpha_r,
                             const float* d_norm_scores, float epsilon, float* d_grad_out, float* d_alpha_lgrad,
                             float* d_alpha_rgrad);
+/* GAT backward on a RECTANGULAR graph (a rank's rows over [owned | halo] columns), where the reverse
+ * edge of (i -> c) lives on another rank and the reverse-edge permutation is replaced by the rank's transposed local
+ * structure (rows = owned + halo vertices, columns = owned rows; include/gnn/partition.h).  gaib_gat_scores_mh and
+ * gaib_sddmm_mh take rectangular graphs as they are (d_h / d_feat = the [nc x len] column table).
+ *   gaib_gat_softmax_bwd_rows: the row side of gat_aggregator.cpp:121-167 -- g_e = d(softmax) * leaky-relu' into
+ *     d_g_out [ne][heads], its row sums into d_rs_out [nv][heads];
+ *   gaib_edge_gather_perm: d_out_e[k] = d_in_e[perm[k]] for [ne][heads] edge arrays (g and p in transposed order);
+ *   gaib_edge_rowsum: d_out_rows[v] = sum of an edge array over row v (column sums of g = row sums over the transpose);
+ *   gaib_gat_alpha_grads: alpha_l' = sum_v rs[v] x[v], alpha_r' = sum_v cs[v] x[v] over nv rows (graph_operations.h:
+ *     396-467 regrouped by vertex; fixed two-level reduction, no atomics).
+ * The transposed aggregation is gaib_spmm_mh on the transposed graph followed by gaib_halo_reduce. */
+int gaib_gat_softmax_bwd_rows(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_norm_scores,
+                              const float* d_norm_scores_grad, const float* d_temp_scores, float epsilon,
+                              float* d_g_out, float* d_rs_out);
+int gaib_edge_gather_perm(gaib_ctx* ctx, int64_t ne, int heads, const uint32_t* d_perm, const float* d_in_e,
+                          float* d_out_e);
+int gaib_edge_rowsum(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_in_e, float* d_out_rows);
+int gaib_gat_alpha_grads(gaib_ctx* ctx, int64_t nv, int len, int heads, const float* d_x, const float* d_rs,
+                         const float* d_cs, float* d_alpha_lgrad, float* d_alpha_rgrad);
 /* symmetric_csr_transpose (math_functions.cpp:46-74; csr2csc math_functions.cu:345-358):
  *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
 int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);
@@ -353,6 +372,12 @@ int64_t gaib_halo_bytes_sent(const gaib_halo* halo);
  * continues only after the halo rows have arrived; *d_table stays valid until the next begin on this plan). */
 int gaib_halo_exchange_begin(gaib_halo* halo, int len, const float* d_rows);
 int gaib_halo_exchange_end(gaib_halo* halo, const float** d_table);
+
+/* the reverse of an exchange: d_halo_rows [halo rows x len] (the table's layout) holds this rank's partial sums for its
+ * HALO vertices; they travel back to the owners, which add them to their own rows: d_rows[send_idx[k], :] += arrived[k, :],
+ * peer by peer in rank order (deterministic).  The transposed aggregation of GAT backward on a partition: the term
+ * p_(i->c) * grad_i of a row i that another rank owns.  Collective; not while an exchange of the same plan is in flight. */
+int gaib_halo_reduce(gaib_halo* halo, int len, const float* d_halo_rows, float* d_rows);
 
 /* ---- in-stream kernel timing (measurement only) -----------------------------------------------
  * When enabled, the aggregation entry points bracket each kernel launch with a HIP event pair

@@ -50,6 +50,9 @@ void gaibl_graph_set_halo(void* graph, void* halo_graph, gaibl_halo_begin_fn beg
  * `comm` (a gaib_comm*, NULL for world 1) -> LearningGraph*.  gaibl_set_comm: gpu_context::set_comm (every optimizer
  * step all-reduces its gradient first). */
 void* gaibl_partition_build(uint32_t nv, const uint32_t* rowptr, const uint32_t* colidx, int rank, int world);
+/* GAT: adds the [owned | halo] column space and its transpose (which = 10 rowptr_full 11 colidx_full 12 rowptr_t
+ * 13 colidx_t 14 tperm); gaibl_partition_make_graph then builds a graph GAT layers can run on */
+void gaibl_partition_build_gat(void* part, const uint32_t* rowptr, const uint32_t* colidx);
 int64_t gaibl_partition_array(void* part, int which, const void** data);
 void gaibl_partition_range(void* part, int64_t* lo, int64_t* hi);
 void gaibl_partition_free(void* part);

@@ -98,5 +98,12 @@ class GAT_Aggregator : public aggregator {
   const float* fwd_out;  // see use_forward_output_once
   float* d_tbuf;         // output of the fused backward sweep (the layer aliases feat_in and grad_out)
   size_t tbuf_floats;
+  // vertex-range partitions: the [owned | halo] column table, the transposed aggregation's output, padded row sums and
+  // the column sums of g
+  float *d_ptab, *d_pout, *d_prs, *d_pcs;
+  size_t ptab_floats, pvec_floats;
+  void ensure_partition_buffers(Graph& g, int len);
+  void aggregate_partition(int len, Graph& g, const float* in, float* out);
+  void d_aggregate_partition(int len, Graph& g, const float* grad_in, float* grad_out);
   optimizer* alpha_opt;
 };

@@ -30,13 +30,20 @@ class LearningGraph {
   const float* (*halo_end_)(void* user, int len);
   void* halo_user_;
   gaib_halo* halo_plan_;  // the exchange behind the C ABI (gaib_halo_exchange_begin/end); set_halo_plan
+  // GAT on a partition (include/gnn/partition.h build_gat_structures): the rows over one [owned | halo] column space,
+  // the transposed structure and the edge permutation between them
+  gaib_graph* gat_full_;
+  gaib_graph* gat_t_;
+  index_t* gat_tperm_;
+  index_t gat_n_halo_;
 
  public:
   typedef size_t iterator;
   LearningGraph(bool use_gpu)
       : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
         colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_dev_(NULL),
-        halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL) {}
+        halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL), gat_full_(NULL), gat_t_(NULL),
+        gat_tperm_(NULL), gat_n_halo_(0) {}
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -90,6 +97,19 @@ class LearningGraph {
     halo_plan_ = plan;
   }
   gaib_halo* halo_plan() { return halo_plan_; }
+  // ne_full = all edges of the owned rows (owned- and halo-column): what sizeEdges() reports from here on, so that
+  // per-edge buffers of the aggregators are sized for the combined graph
+  void set_gat_partition(gaib_graph* full, gaib_graph* transposed, index_t* d_tperm, size_t n_halo, size_t ne_full) {
+    gat_full_ = full;
+    gat_t_ = transposed;
+    gat_tperm_ = d_tperm;
+    gat_n_halo_ = (index_t)n_halo;
+    num_edges_ = (index_t)ne_full;
+  }
+  gaib_graph* gat_full_graph() { return gat_full_; }
+  gaib_graph* gat_transposed_graph() { return gat_t_; }
+  const index_t* gat_tperm() { return gat_tperm_; }
+  size_t gat_n_halo() { return gat_n_halo_; }
   bool has_halo() const { return halo_dev_ != NULL; }
   gaib_graph* halo_graph() { return halo_dev_; }
   void halo_begin(int len, const float* d_in);

@@ -24,6 +24,14 @@ struct VertexRangePartition {
   std::vector<int64_t> recv_counts;            // [world] halo rows owned by rank q
   std::vector<int64_t> send_counts;            // [world] rows rank q needs from this rank ...
   std::vector<int64_t> send_idx;               // ... and their local row ids, grouped by destination, ascending
+  // GAT on a partition (build_gat_structures): the rows over ONE column space [owned | halo] (local id of a halo
+  // vertex = n_own + its position in halo_gids), edges in the global CSR order of the row, and the transposed structure
+  // (rows = the n_own + n_halo local column ids, columns = owned rows) with the edge permutation CSC position -> edge id
+  std::vector<int64_t> rowptr_full;   // [n_own + 1]
+  std::vector<index_t> colidx_full;   // ids in [0, n_own + n_halo)
+  std::vector<int64_t> rowptr_t;      // [n_own + n_halo + 1]
+  std::vector<index_t> colidx_t;      // owned row ids
+  std::vector<index_t> tperm;         // tperm[k] = edge id (in rowptr_full / colidx_full order) of transposed entry k
   int64_t n_own() const { return hi - lo; }
   int64_t n_halo() const { return (int64_t)halo_gids.size(); }
 };
@@ -36,7 +44,12 @@ std::vector<int64_t> vertex_range_bounds(int64_t n, int world);
 VertexRangePartition build_vertex_range_partition(int64_t n_global, const index_t* rowptr, const index_t* colidx,
                                                   int rank, int world);
 
+// fills rowptr_full / colidx_full / rowptr_t / colidx_t / tperm (needs the global CSR again)
+void build_gat_structures(VertexRangePartition& part, const index_t* rowptr, const index_t* colidx);
+
 // The rank's LearningGraph: owned-column CSR + halo-column CSR in HBM with the GLOBAL normalisers (a halo vertex's
 // local degree is truncated), and the halo plan on `comm` that every aggregation of the layers will run.
 // comm may be NULL for world == 1.  The returned graph borrows comm.
 LearningGraph* make_partitioned_graph(const VertexRangePartition& part, gaib_comm* comm);
+// If build_gat_structures was run on `part`, the graph also carries the combined and the transposed graph GAT needs
+// (LearningGraph::set_gat_partition).

@@ -214,3 +214,28 @@ def test_cpp_partition_equals_dist_py(nv, world):
             mine = parts[p].send_idx[off[q]:off[q + 1]] + parts[p].lo
             theirs = parts[q].halo_gids[(parts[q].halo_gids >= parts[p].lo) & (parts[q].halo_gids < parts[p].hi)]
             assert np.array_equal(mine, theirs)
+
+
+@pytest.mark.parametrize("nv,world", [(500, 3), (1200, 2)])
+def test_cpp_partition_gat_structures(nv, world):
+    """build_gat_structures: the rows over ONE [owned | halo] column space keep the global CSR's edge order, and the
+    transposed structure + tperm is exactly its transpose (what replaces the reverse-edge permutation on a partition)"""
+    from graphaibench_amd import layers as L
+    from util import random_graph
+
+    rp, ci = random_graph(nv, 6, seed=nv, power_law=True)
+    for r in range(world):
+        P = L.HostPartition(rp, ci, r, world, gat=True)
+        n_own = P.hi - P.lo
+        nc = n_own + len(P.halo_gids)
+        glob = np.concatenate([np.arange(P.lo, P.hi), P.halo_gids])
+        assert np.array_equal(np.diff(P.rowptr_full), P.degree)
+        assert np.array_equal(glob[P.colidx_full], ci[rp[P.lo]:rp[P.hi]])  # same edges, same order, local ids
+        rows = np.repeat(np.arange(n_own), np.diff(P.rowptr_full))
+        assert len(P.rowptr_t) == nc + 1 and P.rowptr_t[-1] == len(P.colidx_full)
+        assert sorted(P.tperm.tolist()) == list(range(len(P.colidx_full)))  # a permutation of the edges
+        tv = np.repeat(np.arange(nc), np.diff(P.rowptr_t))
+        assert np.array_equal(P.colidx_full[P.tperm], tv) and np.array_equal(rows[P.tperm], P.colidx_t)
+        for v in range(nc):  # rows of a column ascending (stable counting sort)
+            seg = P.colidx_t[P.rowptr_t[v]:P.rowptr_t[v + 1]]
+            assert np.all(np.diff(seg.astype(np.int64)) > 0)

@@ -114,6 +114,64 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
+def _gat_worker(rank, world, idfile, q, heads):
+    """GAT_layer 64 -> 64 on a vertex-range partition (h halo rows for the scores, partial gradient rows returned to
+    their owners, alpha gradients all-reduced) against the GLOBAL oracle: head by head for heads > 1"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    try:
+        from graphaibench_amd import capi, layers as L
+        from oracle import binding as orc
+        from util import LONG_SUM_FLOOR, assert_close, random_graph
+
+        ctx = L.init(0)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, capi.COMM_IPC, capi), capi.COMM_IPC)
+        L.set_comm(comm)
+        rp, ci = random_graph(2500, 14, seed=21, power_law=True, hub_deg=1300)
+        g = orc.Graph(rp, ci).add_selfloop()
+        n, din, d = g.nv, 48, 64
+        x = np.random.default_rng(5).standard_normal((n, din)).astype(np.float32)
+        gin = np.random.default_rng(6).standard_normal((n, d)).astype(np.float32)
+        W = orc.init_glorot(din, d, 1)
+        al, ar = orc.init_glorot(d, 1, 2).ravel(), orc.init_glorot(d, 1, 3).ravel()
+        hfeat = orc.matmul(x, W)
+        agg, temp, _, norm = orc.gat_aggregate_mh(g, hfeat, al, ar, heads)
+        want = orc.relu(agg)
+        g_act = orc.d_relu(gin, want)
+        T, _, _, lg_w, rg_w = orc.gat_d_aggregate_mh(g, hfeat, g_act, norm, temp, heads)
+        want_go = orc.matmul(T, W, False, True)
+        want_wg = orc.matmul(x, T, True, False)
+
+        part = L.HostPartition(g.rowptr, g.colidx, rank, world, gat=True)
+        lo, hi = part.lo, part.hi
+        lg = part.make_graph(comm)
+        layer = L.Layer(L.GAT, 1, hi - lo, din, d, lg, True)
+        if heads > 1:
+            layer.set_heads(heads)
+        layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+        out = torch.empty(hi - lo, d, device="cuda")
+        layer.forward(out)
+        assert_close(out.cpu().numpy(), want[lo:hi], "forward", floor=LONG_SUM_FLOOR)
+        out.copy_(torch.from_numpy(want[lo:hi]).cuda())  # identical relu masks
+        layer.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
+        grad_out = torch.empty(hi - lo, din, device="cuda")
+        layer.backward(out, grad_out)
+        assert_close(grad_out.cpu().numpy(), want_go[lo:hi], "grad_out", floor=LONG_SUM_FLOOR)
+        # weight and alpha gradients are partial sums until the optimizer step all-reduces them
+        for which, shape, want_g, name in ((L.W_NEIGH_GRAD, (din, d), want_wg, "W_grad"), (L.ALPHA_LGRAD, (d,), lg_w, "alpha_l"),
+                                           (L.ALPHA_RGRAD, (d,), rg_w, "alpha_r")):
+            t = layer.tensor(which, shape).reshape(-1).contiguous()
+            comm.allreduce(t)
+            assert_close(t.cpu().numpy().reshape(shape), want_g, name, floor=LONG_SUM_FLOOR)
+        comm.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
 def _spawn(world, target, args, timeout=600):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -129,6 +187,12 @@ def _spawn(world, target, args, timeout=600):
 @pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 2), ("gcn", 3)])
 def test_ipc_ranks_on_one_gpu_match_global_oracle(tmp_path, arch, world):
     res = _spawn(world, _worker, (str(tmp_path / "id"), arch, "ipc"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("heads,world", [(1, 2), (8, 2), (8, 3)])
+def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world):
+    res = _spawn(world, _gat_worker, (str(tmp_path / "id"), heads))
     assert all(r[1] == "ok" for r in res), res
 
 
