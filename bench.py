@@ -526,9 +526,9 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         "gat_sddmm": ne * (4 + 4 * Dg + 4 * H) + nv * 4 * Dg,                    # col + gathered row + dp written
         "gat_softmax_bwd_alpha": ne * (4 + 4 + 3 * 4 * H) + nv * (2 * 4 * Dg),  # col, rev, p, dp read, p^T written
         "spmm_chunk": ne * (4 + 4 * Dg + 4 * H) + (ne // 64) * 4 * Dg,          # col + gathered row + weights, partial rows
-        # the fused edge side of backward: col, rev, p_e, p_rev and TWO gathered rows per edge (h_c, grad_c), the per-vertex
-        # H-vectors of the column vertex (rowdot, sl, sr), partial rows per chunk; nothing per edge is written
-        "gat_bwd_fused": ne * (4 + 4 + 2 * 4 * H + 2 * 4 * Dg + 3 * 4 * H) + (ne // 64) * (4 * Dg + 8 * H) * 2,
+        # the fused edge side of backward: col, rev, p_e, p_rev, rowdot of the column vertex and TWO gathered rows per edge
+        # (h_c, grad_c); partial rows per chunk written and read once; nothing per edge is written
+        "gat_bwd_fused": ne * (4 + 4 + 2 * 4 * H + 2 * 4 * Dg + 4 * H) + (ne // 64) * (4 * Dg + 8 * H) * 2,
     }
     dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
     roof = None

@@ -316,6 +316,8 @@ struct FuseArgs {
   const float* agg_in;        // accumulate mode: partial sums to continue (same layout as the agg rows)
   const float* wt2;           // DUAL: second weight matrix [n_out][K], k-contiguous
   const float* rows2;         // DUAL: second row operand [n_rows][ncols]:  y += rows2[i,:] . op(W2)
+  int ldw;                    // row stride of wt / wt2 in floats (== ncols unless the launch handles a K-slab of a wider matrix)
+  int y_accum;                // y += instead of y = (the second K-slab of a 129..256-wide aggregation; not with DUAL)
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   for (int t = threadIdx.x; t < n_pad * K; t += FUSE_WAVES * 64) {
     const int n = t / K, k = t % K;
     const bool in = n < f.n_out && k < a.ncols;
-    wl[n * LDT + k] = in ? f.wt[(int64_t)n * a.ncols + k] : 0.f;
-    if constexpr (DUAL) wl2[n * LDT + k] = in ? f.wt2[(int64_t)n * a.ncols + k] : 0.f;
+    wl[n * LDT + k] = in ? f.wt[(int64_t)n * f.ldw + k] : 0.f;
+    if constexpr (DUAL) wl2[n * LDT + k] = in ? f.wt2[(int64_t)n * f.ldw + k] : 0.f;
   }
   __syncthreads();  // the only workgroup barrier
   const int i = lane & 15, kq = lane >> 4;
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
           const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
           if (row < a.n_rows) {
             float v = c[reg];
+            if (f.y_accum) v += f.y[(int64_t)row * f.ldy + n0 + i];
             if (f.relu) v = v > 0.f ? v : 0.f;
             f.y[(int64_t)row * f.ldy + n0 + i] = v;
           }
@@ -636,7 +639,9 @@ inline int fuse_strip_rows(int kpad, int n_out, bool dual) {
   // two products: 2-row strips (measured: the strip height costs nothing) and at most eight 16-wide output tiles
   // (their accumulators stay in registers between the two products)
   if (dual) return (n_out <= 128 && fuse_lds_bytes(kpad, n_out, dual, 2) <= 160 * 1024) ? 2 : 0;
-  return fuse_lds_bytes(kpad, n_out, dual, 8) <= 160 * 1024 ? 8 : 0;
+  if (fuse_lds_bytes(kpad, n_out, dual, 8) <= 160 * 1024) return 8;
+  // wide outputs (a 128-column slab of op(W) for 256 outputs is 135 KB): 2-row strips
+  return fuse_lds_bytes(kpad, n_out, dual, 2) <= 160 * 1024 ? 2 : 0;
 }
 
 template <int VEC, int WMODE>
@@ -676,16 +681,18 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>( \
         a, f);                                                                                                  \
   } while (0)
-  (void)strip;
   // short rows (fewer than 12 edges per row on average: halo-column halves, citation graphs): the edge-stream form
   // (scripts/ab_flat.py: -34 % at 3 edges per row, -20 % at 5, even at 12, +2 % at 30)
-  const bool flat = !dual && (ctx->spmm_flat == 1 || (ctx->spmm_flat < 0 && g->ne < 12 * (int64_t)a.n_rows));
+  const bool flat = !dual && strip == 8 &&
+                    (ctx->spmm_flat == 1 || (ctx->spmm_flat < 0 && g->ne < 12 * (int64_t)a.n_rows));
   if (buf) {
     if (dual) GAIB_FUSED_LAUNCH(1, 2, true, false);
+    else if (strip == 2) GAIB_FUSED_LAUNCH(1, 2, false, false);
     else if (flat) GAIB_FUSED_LAUNCH(1, 8, false, true);
     else GAIB_FUSED_LAUNCH(1, 8, false, false);
   } else {
     if (dual) GAIB_FUSED_LAUNCH(0, 2, true, false);
+    else if (strip == 2) GAIB_FUSED_LAUNCH(0, 2, false, false);
     else if (flat) GAIB_FUSED_LAUNCH(0, 8, false, true);
     else GAIB_FUSED_LAUNCH(0, 8, false, false);
   }
@@ -1047,6 +1054,62 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
                        fuse_strip_rows(kpad, len_out, dual) != 0 && g->ne > 0 && g->nv >= 1 &&
                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
+  // 129..256 columns (the hidden width 256 of scripts/run-sage-products.sh): op(W) does not fit LDS next to the strips,
+  // so the aggregation runs as two 128-column K-slabs through the same kernel, each with its [len_out x 128] slab of
+  // op(W) in LDS: slab 0 writes y = agg[:, :128] . op(W)[:128, :], slab 1 adds agg[:, 128:] . op(W)[128:, :] (and applies
+  // the activation).  The gathered bytes are the same as one 1-KB row gather per edge; colidx / weights are streamed
+  // twice and y is read-modify-written once -- against a separate pass over agg and a 2 x 2.45 M x 256 x 256 GEMM.
+  // A second product (SAGE's self term) follows as an accumulating GEMM.
+  const bool kslab = ctx->spmm_fuse != 0 && !dense && len_in > 128 && len_in <= 256 && len_in % 2 == 0 && (al & 7) == 0 &&
+                     len_out >= 1 && fuse_strip_rows(128, len_out, false) != 0 && g->ne > 0 &&
+                     (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN || weight_kind == GAIB_W_MEAN_T ||
+                      weight_kind == GAIB_W_EDGE);
+  if (kslab) {
+    SpmmArgs a0;
+    int wmode = 0;
+    GAIB_TRY(spmm_setup(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, 0, 1, &a0, &wmode));
+    const size_t wt_bytes = (sizeof(float) * (size_t)len_out * len_in + 255) & ~(size_t)255;
+    const size_t hv_bytes = (sizeof(float) * (size_t)g->n_heavy * len_in + 255) & ~(size_t)255;
+    GAIB_TRY(gaib_ws_reserve(ctx, wt_bytes + hv_bytes + 256));
+    float* wt = (float*)ctx->ws;
+    float* hv = (float*)((char*)ctx->ws + wt_bytes);
+    int* counter = (int*)((char*)hv + hv_bytes);
+    const float* wk = d_W;  // [len_out][len_in], k-contiguous
+    if (!transW) {
+      const int n = len_in * len_out;
+      transpose_small_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(len_in, len_out, d_W, wt);
+      GAIB_LAUNCH_CHECK();
+      wk = wt;
+    }
+    for (int k0 = 0; k0 < len_in; k0 += 128) {
+      SpmmArgs a = a0;
+      a.in = a0.in + k0;
+      a.ncols = len_in - k0 < 128 ? len_in - k0 : 128;
+      a.accumulate = 0;
+      a.out = (flags & GAIB_AGG_SCRATCH) ? nullptr : d_agg + k0;
+      if (a.in_bytes) a.in_bytes -= (uint32_t)(k0 * 4);
+      FuseArgs f;
+      f.wt = wk + k0;
+      f.wt2 = nullptr;
+      f.rows2 = nullptr;
+      f.ldw = len_in;
+      f.y = d_out;
+      f.ldy = len_out;
+      f.n_out = len_out;
+      f.tile_counter = counter;
+      f.agg_in = (flags & GAIB_ACCUMULATE) ? d_agg + k0 : nullptr;
+      f.y_accum = k0 > 0;
+      f.relu = ((flags & GAIB_RELU) && !dual && k0 + 128 >= len_in) ? 1 : 0;
+      f.heavy_agg = hv + k0;
+      f.heavy_rows = g->heavy_rows;
+      f.n_heavy = (int)g->n_heavy;
+      GAIB_TRY(wmode == 0 ? (launch_fused<2, 0>(ctx, g, a, f, hv + k0)) : (launch_fused<2, 1>(ctx, g, a, f, hv + k0)));
+    }
+    if (dual)
+      return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_rows2, d_W2,
+                           GAIB_ACCUMULATE | ((flags & GAIB_RELU) ? GAIB_RELU : 0), d_out);
+    return GAIB_OK;
+  }
   if (!fusable) {
     const int act = (flags & GAIB_RELU) ? GAIB_RELU : 0;
     GAIB_TRY(spmm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, flags & GAIB_ACCUMULATE));
@@ -1082,6 +1145,8 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
     }
   }
   f.rows2 = d_rows2;
+  f.ldw = len_in;
+  f.y_accum = 0;
   f.y = d_out;
   f.ldy = len_out;
   f.n_out = len_out;
