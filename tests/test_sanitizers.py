@@ -63,3 +63,26 @@ def test_oracle_tsan_openmp(san_libs):
                     "GNN_ORACLE_LIB": str(san_libs / "libgnn_oracle_tsan.so")},
                    [sys.executable, str(ROOT / "tests" / "san_workload.py")])
     assert rc == 0 and "san_workload done" in out and not any(b in out for b in BAD), out[-6000:]
+
+
+def test_host_cpp_asan_ubsan(tmp_path):
+    """the host-only C++ of the product under ASan + UBSan (tests/host_san_main.cpp): binary reader, LearningGraph host
+    methods, GraphSAINT sampler, vertex-range partition builder with the GAT structures.  The GPU libraries are linked to
+    resolve symbols only; nothing touches a device."""
+    lib = ROOT / "graphaibench_amd" / "lib"
+    if not (lib / "libgaib_hip.so").exists():
+        pytest.skip("libgaib_hip.so not built")
+    exe = tmp_path / "host_san"
+    inc = [f"-I{ROOT / 'include'}"] + [f"-I{ROOT / 'include' / d}" for d in ("gnn", "layers", "utils")]
+    srcs = [str(ROOT / "tests" / "host_san_main.cpp")] + [str(ROOT / "graphaibench_amd" / "host" / f"{n}.cpp")
+                                                          for n in ("reader", "sampler", "partition", "lgraph", "context")]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", *inc, *srcs, f"-L{lib}", "-lgaib_hip",
+                        f"-Wl,-rpath,{lib}", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    data = tmp_path / "data"
+    (data / "cora").mkdir(parents=True)
+    rc, out = _run({"DATASET_PATH": str(data) + "/", "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1",
+                    "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1", "OMP_NUM_THREADS": "4"},
+                   [str(exe), str(data) + "/"])
+    assert rc == 0 and "host_san_main done" in out and not any(b in out for b in BAD), out[-4000:]
