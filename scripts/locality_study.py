@@ -115,23 +115,37 @@ def order_from_graph(rowptr, cols, how):
     return new_of_old, time.time() - t0
 
 
+KERNEL = "w64"
+_W = None
+
+
 def run(ctx, name, rowptr, cols, x, extra=None):
+    """KERNEL w64: gaib_spmm (spmm_w64_kernel: rows assigned to waves statically, in order).  fused: gaib_spmm_gemm
+    (spmm_gemm_kernel: 16-row tiles taken off a counter in order -- what bench.py's layer runs); `out` is the aggregate."""
+    global _W
     g = ctx.graph(rowptr, cols)
     out = torch.empty_like(x)
-    ctx.spmm(g, capi.W_GCN, x, out)  # builds the per-edge weights, warms up
+    if KERNEL == "fused":
+        if _W is None:
+            _W = torch.randn(D, D, device="cuda") * 0.1
+        y = torch.empty_like(x)
+        call = lambda: ctx.spmm_gemm(g, capi.W_GCN, x, out, _W, y)
+    else:
+        call = lambda: ctx.spmm(g, capi.W_GCN, x, out)
+    call()  # builds the per-edge weights, warms up
     ctx.sync()
     ctx.prof_reset()
     ctx.prof_enable(True)
     for _ in range(REPS):
-        ctx.spmm(g, capi.W_GCN, x, out)
+        call()
     ctx.prof_enable(False)
-    nl, ml = ctx.prof_get("spmm_light")
+    nl, ml = ctx.prof_get("spmm_gemm_fused" if KERNEL == "fused" else "spmm_light")
     nh, mh = ctx.prof_get("spmm_heavy")
     ctx.prof_reset()
     nv, ne = g.nv, g.ne
     ms = (ml + mh) / REPS
     alg = ne * (4 * D + 8) + nv * 4 * D + (nv + 1) * 8
-    rec = dict(order=name, nv=nv, ne=ne, D=D, spmm_ms=ms, alg_GBs=alg / ms / 1e6, b_min_bytes=2 * nv * 4 * D + 4 * ne,
+    rec = dict(order=name, kernel=KERNEL, nv=nv, ne=ne, D=D, spmm_ms=ms, alg_GBs=alg / ms / 1e6, b_min_bytes=2 * nv * 4 * D + 4 * ne,
                launches_per_order=REPS + 1)
     rec.update(extra or {})
     print(json.dumps(rec), flush=True)
@@ -142,7 +156,8 @@ def run(ctx, name, rowptr, cols, x, extra=None):
 def parse(d):
     """per-order FETCH_SIZE of the spmm_w64 dispatches (KB, x2 half-count correction) from a rocprofv3 --pmc run"""
     f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "spmm_w64_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    rows = [r for r in csv.DictReader(open(f)) if ("spmm_w64_kernel" in r["Kernel_Name"] or "spmm_gemm_kernel" in r["Kernel_Name"])
+            and r["Counter_Name"] == "FETCH_SIZE"]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     per = REPS + 1
     names = ["natural", "permuted", "reordered"]
@@ -159,8 +174,11 @@ def main():
     ap.add_argument("--block", type=int, default=16384)
     ap.add_argument("--cut", type=float, default=0.1)
     ap.add_argument("--order", choices=["rcm", "degree"], default="rcm")
+    ap.add_argument("--kernel", choices=["w64", "fused"], default="w64")
     ap.add_argument("--parse", default=None)
     args = ap.parse_args()
+    global KERNEL
+    KERNEL = args.kernel
     if args.parse:
         return parse(args.parse)
     ctx = capi.Context(0)
