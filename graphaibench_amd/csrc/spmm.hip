@@ -164,6 +164,10 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   unsigned grid = (unsigned)a.nblocks;
   if (ctx->spmm_xcd_swizzle && a.nblocks >= 64) {
     a.per_xcd = (int)cdiv64(a.nblocks, 8);
+    if (ctx->spmm_xcd_swizzle == 2 && a.nblocks >= 8 * 64) {  // chunks of 64 row blocks (256 rows) round robin
+      a.xcd_chunk = 64;
+      a.per_xcd = (int)(cdiv64(a.per_xcd, 64) * 64);
+    }
     grid = (unsigned)a.per_xcd * 8u;
   }
   if (grid > 0) {
@@ -360,25 +364,53 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   // FLAT: tiles are cheap (a few edges per row), and one atomic per tile on one address becomes the floor (153 k
   // atomics = 0.4 ms at 2.4 M rows).  Guided chunks instead: a wave takes (tiles left) / (4 x waves) tiles at a time,
   // at most 8, down to single tiles at the end.
-  int t_next = 0, t_left = 0;
-  const int nwaves4 = (int)gridDim.x * FUSE_WAVES * 4;
+  // Tiles come off EIGHT counters, one per XCD (workgroups are dealt to the XCDs round robin: XCD = blockIdx & 7).
+  // XCD x owns the contiguous tile range [x * per, (x + 1) * per): consecutive rows of a graph with locality in its
+  // numbering meet in ONE L2 instead of being spread over all eight (scripts/locality_study.py, natural order: one
+  // global counter 6.7 ms / 42 GB of fabric traffic, the static per-XCD ranges of spmm_w64_kernel 5.0 ms / 25 GB).
+  // An XCD that runs dry takes tiles from the next one's range (a numbering with its long rows at one end stays
+  // balanced); a counter may overshoot its range, which only costs the overshooting wave one more atomic.
+  const int per = (ntiles + 7) / 8;
+  int own = (int)(blockIdx.x & 7);  // the range this wave is drawing from
+  int tried = 0;
+  int t_next = own * per, t_left = 0, t_hi = 0;  // t_next: where this range's counter stood at the wave's last visit
+  const int nwaves4 = ((int)gridDim.x * FUSE_WAVES * 4) / 8 > 0 ? ((int)gridDim.x * FUSE_WAVES * 4) / 8 : 1;
   for (;;) {
     int t = 0;
+    bool got = false;
     if constexpr (FLAT) {
-      if (t_left == 0) {
-        int want = (ntiles - t_next) / nwaves4;  // t_next: where the counter stood at this wave's last visit
-        want = want < 1 ? 1 : (want > 8 ? 8 : want);
-        if (lane == 0) t = atomicAdd(f.tile_counter, want);
-        t_next = __builtin_amdgcn_readfirstlane(t);
-        t_left = want;
+      if (t_left > 0) {
+        t = t_next++;
+        --t_left;
+        got = t < t_hi;
+        if (!got) t_left = 0;
       }
-      t = t_next++;
-      --t_left;
-    } else {
-      if (lane == 0) t = atomicAdd(f.tile_counter, 1);
-      t = __builtin_amdgcn_readfirstlane(t);
     }
-    if (t >= ntiles) break;
+    while (!got && tried < 8) {
+      const int lo = own * per, hi = (lo + per < ntiles) ? lo + per : ntiles;
+      int want = 1;
+      if constexpr (FLAT) {
+        want = (hi - t_next > 0 ? hi - t_next : 0) / nwaves4;  // guided chunks: (tiles left in the range) / (4 x waves)
+        want = want < 1 ? 1 : (want > 8 ? 8 : want);
+      }
+      int k = 0;
+      if (lane == 0) k = atomicAdd(f.tile_counter + own, want);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (lo + k < hi) {
+        t = lo + k;
+        got = true;
+        if constexpr (FLAT) {
+          t_next = t + 1;
+          t_left = want - 1;
+          t_hi = hi;
+        }
+      } else {  // this range is exhausted: move on to the next XCD's
+        own = (own + 1) & 7;
+        ++tried;
+        if constexpr (FLAT) t_next = own * per;
+      }
+    }
+    if (!got) break;
     const int row0 = t * FUSE_ROWS;
     // the 17 row boundaries of this tile, lane r holds rowptr[row0 + r]
     int rpi = row0 + (lane < FUSE_ROWS ? lane : FUSE_ROWS);
@@ -668,7 +700,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   const size_t lds = fuse_lds_bytes(K, f.n_out, dual, strip);
   const int64_t ntiles = cdiv64(a.n_rows, FUSE_ROWS);
   const unsigned grid = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, FUSE_WAVES));
-  GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, sizeof(int), ctx->stream));
+  GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, 8 * sizeof(int), ctx->stream));  // one counter per XCD
   ProfScope ps(ctx, "spmm_gemm_fused");
   // more than 64 KB of dynamic LDS has to be asked for
   // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
@@ -897,6 +929,7 @@ static int spmm_setup(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float
   a.row_order = nullptr;
   a.nblocks = 0;
   a.per_xcd = 0;
+  a.xcd_chunk = 0;
   a.accumulate = (flags & GAIB_ACCUMULATE) ? 1 : 0;
   a.relu = (flags & GAIB_RELU) ? 1 : 0;
   a.heads = heads;

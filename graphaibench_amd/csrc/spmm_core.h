@@ -22,6 +22,8 @@ struct SpmmArgs {
   const uint32_t* row_order; // ... and the slot each workgroup takes (longest rows first)
   int nblocks;               // light kernels: logical number of row blocks
   int per_xcd;               // ceil(nblocks/8) when swizzled, 0 otherwise
+  int xcd_chunk;             // > 0: an XCD takes chunks of this many consecutive row blocks in round robin over the XCDs
+                             // (0: one contiguous range of row blocks per XCD)
   uint32_t in_bytes;         // BUF kernels: size of the feature table (< 4 GB)
   const uint32_t* col_flagged;  // GM 3: column ids with the top bit set on cold columns
   int accumulate;            // out += instead of out = (second half of a split aggregation)
@@ -70,9 +72,19 @@ __device__ __forceinline__ void vacc(typename VecT<VEC>::type& acc, float w,
   }
 }
 
+// blockIdx -> row block.  Workgroups are dealt to the 8 XCDs round robin (XCD = blockIdx & 7), each XCD has its own L2.
+//   per_xcd > 0, xcd_chunk == 0: XCD x owns the contiguous range [x * per_xcd, (x + 1) * per_xcd) of row blocks --
+//     consecutive row blocks share an L2, but a graph whose long rows sit together (a degree-sorted numbering) loads
+//     one XCD with most of the edges (scripts/locality_study.py --order degree: 2.5x slower);
+//   xcd_chunk = C: XCD x takes the chunks x, x + 8, x + 16, ... of C consecutive row blocks -- still C consecutive
+//     row blocks per L2 at a time, and the edges spread over the XCDs at C-block granularity.
 __device__ __forceinline__ int logical_block(const SpmmArgs& a) {
   int b = blockIdx.x;
-  if (a.per_xcd > 0) b = (b & 7) * a.per_xcd + (b >> 3);
+  if (a.per_xcd > 0) {
+    const int x = b & 7, k = b >> 3;
+    if (a.xcd_chunk > 0) b = ((k / a.xcd_chunk) * 8 + x) * a.xcd_chunk + (k % a.xcd_chunk);
+    else b = x * a.per_xcd + k;
+  }
   return b;
 }
 

@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--cut", type=float, default=0.1)
     ap.add_argument("--order", choices=["rcm", "degree"], default="rcm")
     ap.add_argument("--kernel", choices=["w64", "fused"], default="w64")
+    ap.add_argument("--opt", action="append", default=[], help="context option key=value (gaib_set_option), repeatable")
     ap.add_argument("--parse", default=None)
     args = ap.parse_args()
     global KERNEL
@@ -182,6 +183,9 @@ def main():
     if args.parse:
         return parse(args.parse)
     ctx = capi.Context(0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     nv0, nnz0, max_deg, _, _ = synth.SHAPES["ogbn-products"]
     nv, nnz = int(nv0 * args.scale), int(nnz0 * args.scale)
     a, b = planted_graph(nv, nnz, min(max_deg, nv // 4), args.block, args.cut, seed=42)
