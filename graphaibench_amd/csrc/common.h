@@ -57,7 +57,7 @@ struct gaib_ctx {
   // tuning knobs
   int spmm_heavy_threshold;  // rows with more edges go to the workgroup-per-row kernel
   int spmm_variant;          // 0 = auto, see spmm.hip
-  int spmm_xcd_swizzle;      // 1 = consecutive row blocks share an XCD
+  int spmm_xcd_swizzle;      // row blocks -> XCDs: 2 (default) = chunks of 256 rows round robin, 1 = one contiguous range per XCD, 0 = none
   int spmm_chunked;          // dense graphs: aggregation by ordered 64-edge chunks + per-row reduction: -1 auto, 0 never, 1 always
   int spmm_pad;              // 1 = re-stride odd-width input tables where that saves >10 % of the gathered lines, 0 = never
   int spmm_fuse;             // 1 = gaib_spmm_gemm may fuse the dense product into the aggregation

@@ -43,7 +43,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->forked = 0;
   c->spmm_heavy_threshold = 1024;
   c->spmm_variant = 0;
-  c->spmm_xcd_swizzle = 1;
+  c->spmm_xcd_swizzle = 2;
   c->spmm_unroll = 0;
   c->spmm_fuse = 1;
   c->spmm_pad = 1;

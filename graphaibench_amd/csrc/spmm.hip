@@ -365,52 +365,42 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   // atomics = 0.4 ms at 2.4 M rows).  Guided chunks instead: a wave takes (tiles left) / (4 x waves) tiles at a time,
   // at most 8, down to single tiles at the end.
   // Tiles come off EIGHT counters, one per XCD (workgroups are dealt to the XCDs round robin: XCD = blockIdx & 7).
-  // XCD x owns the contiguous tile range [x * per, (x + 1) * per): consecutive rows of a graph with locality in its
-  // numbering meet in ONE L2 instead of being spread over all eight (scripts/locality_study.py, natural order: one
-  // global counter 6.7 ms / 42 GB of fabric traffic, the static per-XCD ranges of spmm_w64_kernel 5.0 ms / 25 GB).
-  // An XCD that runs dry takes tiles from the next one's range (a numbering with its long rows at one end stays
-  // balanced); a counter may overshoot its range, which only costs the overshooting wave one more atomic.
-  const int per = (ntiles + 7) / 8;
-  int own = (int)(blockIdx.x & 7);  // the range this wave is drawing from
-  int tried = 0;
-  int t_next = own * per, t_left = 0, t_hi = 0;  // t_next: where this range's counter stood at the wave's last visit
+  // XCD x owns the chunks x, x + 8, x + 16, ... of TCH = 16 consecutive tiles (256 rows): consecutive rows of a graph
+  // with locality in its numbering meet in ONE L2 instead of being spread over all eight, and all XCDs advance through
+  // the rows at the same pace, so a numbering with its long rows at one end stays balanced.  Measured
+  // (scripts/locality_study.py, products-sized graph with planted locality, natural order): one global counter 6.7 ms /
+  // 42 GB of fabric traffic; one contiguous range per XCD 5.8 ms but +0.4 ms per bench step on the random order (the
+  // ranges finish at different times); the static per-XCD ranges of spmm_w64_kernel 5.0 ms / 25 GB.  An XCD whose chunks
+  // are used up draws from the next XCD's counter.
+  constexpr int TCH = 16;
+  int own = (int)(blockIdx.x & 7);  // the XCD whose counter this wave is drawing from
+  int tried = 0, k_next = 0, k_left = 0;
   const int nwaves4 = ((int)gridDim.x * FUSE_WAVES * 4) / 8 > 0 ? ((int)gridDim.x * FUSE_WAVES * 4) / 8 : 1;
+  const int per_xcd_tiles = (ntiles + 7) / 8;  // about what one XCD's chunks hold
   for (;;) {
-    int t = 0;
-    bool got = false;
-    if constexpr (FLAT) {
-      if (t_left > 0) {
-        t = t_next++;
-        --t_left;
-        got = t < t_hi;
-        if (!got) t_left = 0;
-      }
-    }
-    while (!got && tried < 8) {
-      const int lo = own * per, hi = (lo + per < ntiles) ? lo + per : ntiles;
+    if (k_left == 0) {
+      if (tried >= 8) break;
       int want = 1;
-      if constexpr (FLAT) {
-        want = (hi - t_next > 0 ? hi - t_next : 0) / nwaves4;  // guided chunks: (tiles left in the range) / (4 x waves)
+      if constexpr (FLAT) {  // guided: (tiles this XCD has left) / (4 x its waves), at most 8, single tiles at the end
+        want = (per_xcd_tiles - k_next > 0 ? per_xcd_tiles - k_next : 0) / nwaves4;
         want = want < 1 ? 1 : (want > 8 ? 8 : want);
       }
-      int k = 0;
-      if (lane == 0) k = atomicAdd(f.tile_counter + own, want);
-      k = __builtin_amdgcn_readfirstlane(k);
-      if (lo + k < hi) {
-        t = lo + k;
-        got = true;
-        if constexpr (FLAT) {
-          t_next = t + 1;
-          t_left = want - 1;
-          t_hi = hi;
-        }
-      } else {  // this range is exhausted: move on to the next XCD's
+      int k0 = 0;
+      if (lane == 0) k0 = atomicAdd(f.tile_counter + own, want);
+      k0 = __builtin_amdgcn_readfirstlane(k0);
+      if (((k0 / TCH) * 8 + own) * TCH >= ntiles) {  // this XCD's chunks are used up: on to the next one's
         own = (own + 1) & 7;
         ++tried;
-        if constexpr (FLAT) t_next = own * per;
+        k_next = 0;
+        continue;
       }
+      k_next = k0;
+      k_left = want;
     }
-    if (!got) break;
+    const int kk = k_next++;
+    --k_left;
+    const int t = ((kk / TCH) * 8 + own) * TCH + (kk % TCH);
+    if (t >= ntiles) continue;  // the ragged end of the last chunk
     const int row0 = t * FUSE_ROWS;
     // the 17 row boundaries of this tile, lane r holds rowptr[row0 + r]
     int rpi = row0 + (lane < FUSE_ROWS ? lane : FUSE_ROWS);

@@ -62,7 +62,7 @@ def main():
             med, best = timeit(lambda: ctx.spmm(g, capi.W_GCN, x, out), args.iters)
         finally:
             for k in opts:
-                ctx.set_option(k, 1024 if k == "spmm_heavy_threshold" else (1 if k == "spmm_xcd_swizzle" else 0))
+                ctx.set_option(k, 1024 if k == "spmm_heavy_threshold" else (2 if k == "spmm_xcd_swizzle" else 0))
         r = dict(kernel="spmm_gcn", tag=tag, d=d, ms=med, best_ms=best, gedges_s=ne / med / 1e6,
                  alg_gbs=alg_bytes / med / 1e6, frac_8tbs=alg_bytes / med / 1e6 / 8000)
         print(json.dumps(r), flush=True)

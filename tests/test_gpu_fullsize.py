@@ -87,13 +87,13 @@ def test_linearity_symmetry_and_schedule_invariance_full_size(ctx, products):
     assert abs(lhs - rhs) < 1e-6 * (abs(lhs) + nv)
     # other schedules: same sums
     for key, val in [("spmm_heavy_threshold", 256), ("spmm_heavy_threshold", 1 << 20), ("spmm_unroll", 8),
-                     ("spmm_addr_mode", 2), ("spmm_variant", 4), ("spmm_xcd_swizzle", 0), ("spmm_gather_mode", 3)]:
+                     ("spmm_addr_mode", 2), ("spmm_variant", 4), ("spmm_xcd_swizzle", 0), ("spmm_xcd_swizzle", 1), ("spmm_gather_mode", 3)]:
         ctx.set_option(key, val)
         try:
             alt = torch.empty_like(x)
             ctx.spmm(g, capi.W_GCN, x, alt)
         finally:
-            ctx.set_option(key, {"spmm_heavy_threshold": 1024, "spmm_xcd_swizzle": 1}.get(key, 0))
+            ctx.set_option(key, {"spmm_heavy_threshold": 1024, "spmm_xcd_swizzle": 2}.get(key, 0))
         assert (alt - ax).abs().max().item() < 1e-5 * scale, key
     # run-to-run determinism
     again = torch.empty_like(x)
