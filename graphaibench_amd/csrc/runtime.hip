@@ -45,6 +45,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_variant = 0;
   c->spmm_xcd_swizzle = 2;
   c->spmm_unroll = 0;
+  c->spmm_tile_xcd = 0;
   c->spmm_fuse = 1;
   c->spmm_pad = 1;
   c->spmm_chunked = -1;
@@ -255,6 +256,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_pad = (int)value;
   else if (!strcmp(key, "spmm_flat"))
     ctx->spmm_flat = (int)value;
+  else if (!strcmp(key, "spmm_tile_xcd"))
+    ctx->spmm_tile_xcd = (int)value;
   else if (!strcmp(key, "spmm_unroll"))
     ctx->spmm_unroll = (int)value;
   else if (!strcmp(key, "spmm_addr_mode"))

@@ -322,6 +322,7 @@ struct FuseArgs {
   const float* rows2;         // DUAL: second row operand [n_rows][ncols]:  y += rows2[i,:] . op(W2)
   int ldw;                    // row stride of wt / wt2 in floats (== ncols unless the launch handles a K-slab of a wider matrix)
   int y_accum;                // y += instead of y = (the second K-slab of a 129..256-wide aggregation; not with DUAL)
+  int tile_xcd;               // 1: tiles off eight per-XCD counters over interleaved 256-row chunks; 0: one global counter
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -335,7 +336,7 @@ constexpr int FUSE_WAVES = 16;
 // 12 M edges over 2.4 M rows, 1.3 ms of traffic).  Here the edges of a strip's rows are ONE stream: column ids and
 // weights are loaded 64 edges at a time, U gathers are in flight whatever rows they belong to, and the running sum
 // moves to the next row when the edge index passes a row boundary (wave-uniform control).  Same edge order, same sums.
-template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL, bool FLAT = false>
+template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL, bool FLAT = false, bool YACC = false>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int K = 64 * VEC;  // padded inner dimension; a.ncols (<= K) columns are real
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   // ranges finish at different times); the static per-XCD ranges of spmm_w64_kernel 5.0 ms / 25 GB.  An XCD whose chunks
   // are used up draws from the next XCD's counter.
   constexpr int TCH = 16;
-  int own = (int)(blockIdx.x & 7);  // the XCD whose counter this wave is drawing from
-  int tried = 0, k_next = 0, k_left = 0;
+  int own = f.tile_xcd ? (int)(blockIdx.x & 7) : 0;  // the XCD whose counter this wave is drawing from
+  int tried = f.tile_xcd ? 0 : 7, k_next = 0, k_left = 0;
   const int nwaves4 = ((int)gridDim.x * FUSE_WAVES * 4) / 8 > 0 ? ((int)gridDim.x * FUSE_WAVES * 4) / 8 : 1;
   const int per_xcd_tiles = (ntiles + 7) / 8;  // about what one XCD's chunks hold
   for (;;) {
@@ -382,13 +383,16 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
       if (tried >= 8) break;
       int want = 1;
       if constexpr (FLAT) {  // guided: (tiles this XCD has left) / (4 x its waves), at most 8, single tiles at the end
-        want = (per_xcd_tiles - k_next > 0 ? per_xcd_tiles - k_next : 0) / nwaves4;
+        const int left = f.tile_xcd ? per_xcd_tiles - k_next : (ntiles - k_next) / 8;
+        want = (left > 0 ? left : 0) / nwaves4;
         want = want < 1 ? 1 : (want > 8 ? 8 : want);
       }
       int k0 = 0;
       if (lane == 0) k0 = atomicAdd(f.tile_counter + own, want);
       k0 = __builtin_amdgcn_readfirstlane(k0);
-      if (((k0 / TCH) * 8 + own) * TCH >= ntiles) {  // this XCD's chunks are used up: on to the next one's
+      if (!f.tile_xcd) {  // one global counter: tiles in order
+        if (k0 >= ntiles) break;
+      } else if (((k0 / TCH) * 8 + own) * TCH >= ntiles) {  // this XCD's chunks are used up: on to the next one's
         own = (own + 1) & 7;
         ++tried;
         k_next = 0;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
     }
     const int kk = k_next++;
     --k_left;
-    const int t = ((kk / TCH) * 8 + own) * TCH + (kk % TCH);
+    const int t = f.tile_xcd ? ((kk / TCH) * 8 + own) * TCH + (kk % TCH) : kk;
     if (t >= ntiles) continue;  // the ragged end of the last chunk
     const int row0 = t * FUSE_ROWS;
     // the 17 row boundaries of this tile, lane r holds rowptr[row0 + r]
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
           const int row = row0 + 4 * kq + reg;  // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
           if (row < a.n_rows) {
             float v = c[reg];
-            if (f.y_accum) v += f.y[(int64_t)row * f.ldy + n0 + i];
+            if constexpr (YACC) v += f.y[(int64_t)row * f.ldy + n0 + i];  // the second K-slab of a wide aggregation
             if (f.relu) v = v > 0.f ? v : 0.f;
             f.y[(int64_t)row * f.ldy + n0 + i] = v;
           }
@@ -695,19 +699,30 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   // more than 64 KB of dynamic LDS has to be asked for
   // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
   // spill and are reloaded inside the MFMA loop)
-#define GAIB_FUSED_LAUNCH(GM, STRIP, DUAL, FLAT)                                                                \
-  do {                                                                                                          \
-    constexpr int UU = FLAT ? 8 : U;                                                                            \
-    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT>,          \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
-    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>( \
-        a, f);                                                                                                  \
+#define GAIB_FUSED_LAUNCH_Y(GM, STRIP, DUAL, FLAT, YACC)                                                              \
+  do {                                                                                                                \
+    constexpr int UU = FLAT ? 8 : U;                                                                                  \
+    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC>,          \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC><<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>( \
+        a, f);                                                                                                        \
   } while (0)
+#define GAIB_FUSED_LAUNCH(GM, STRIP, DUAL, FLAT) GAIB_FUSED_LAUNCH_Y(GM, STRIP, DUAL, FLAT, false)
   // short rows (fewer than 12 edges per row on average: halo-column halves, citation graphs): the edge-stream form
   // (scripts/ab_flat.py: -34 % at 3 edges per row, -20 % at 5, even at 12, +2 % at 30)
-  const bool flat = !dual && strip == 8 &&
+  const bool flat = !dual && strip == 8 && !f.y_accum &&
                     (ctx->spmm_flat == 1 || (ctx->spmm_flat < 0 && g->ne < 12 * (int64_t)a.n_rows));
-  if (buf) {
+  if (f.y_accum) {  // the second K-slab of a 129..256-column aggregation (VEC == 2 only; never dual or flat)
+    if constexpr (VEC == 2) {
+      if (buf) {
+        if (strip == 2) GAIB_FUSED_LAUNCH_Y(1, 2, false, false, true);
+        else GAIB_FUSED_LAUNCH_Y(1, 8, false, false, true);
+      } else {
+        if (strip == 2) GAIB_FUSED_LAUNCH_Y(0, 2, false, false, true);
+        else GAIB_FUSED_LAUNCH_Y(0, 8, false, false, true);
+      }
+    }
+  } else if (buf) {
     if (dual) GAIB_FUSED_LAUNCH(1, 2, true, false);
     else if (strip == 2) GAIB_FUSED_LAUNCH(1, 2, false, false);
     else if (flat) GAIB_FUSED_LAUNCH(1, 8, false, true);
@@ -719,6 +734,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     else GAIB_FUSED_LAUNCH(0, 8, false, false);
   }
 #undef GAIB_FUSED_LAUNCH
+#undef GAIB_FUSED_LAUNCH_Y
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -1122,6 +1138,7 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
       f.tile_counter = counter;
       f.agg_in = (flags & GAIB_ACCUMULATE) ? d_agg + k0 : nullptr;
       f.y_accum = k0 > 0;
+      f.tile_xcd = ctx->spmm_tile_xcd;
       f.relu = ((flags & GAIB_RELU) && !dual && k0 + 128 >= len_in) ? 1 : 0;
       f.heavy_agg = hv + k0;
       f.heavy_rows = g->heavy_rows;
@@ -1170,6 +1187,7 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   f.rows2 = d_rows2;
   f.ldw = len_in;
   f.y_accum = 0;
+  f.tile_xcd = ctx->spmm_tile_xcd;
   f.y = d_out;
   f.ldy = len_out;
   f.n_out = len_out;
