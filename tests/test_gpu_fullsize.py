@@ -147,6 +147,14 @@ def test_fused_aggregation_product_full_size(ctx, products):
     finally:
         ctx.set_option("spmm_fuse", 1)
     assert ((y2 - y).norm() / y.norm()).item() < 1e-6
+    # which wave takes which tile (one global counter / per-XCD counters over interleaved chunks) changes nothing
+    ctx.set_option("spmm_tile_xcd", 1)
+    try:
+        y3, agg3 = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+        ctx.spmm_gemm(g1, capi.W_GCN, x, agg3, W, y3, relu=True)
+    finally:
+        ctx.set_option("spmm_tile_xcd", 0)
+    assert torch.equal(y3, y) and torch.equal(agg3, agg_ref)
     # weight gradient with the d_relu folded in
     gr = torch.randn(nv, D, device="cuda")
     gm = torch.where(y > 0, gr, torch.zeros_like(gr))
