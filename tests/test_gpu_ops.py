@@ -953,7 +953,7 @@ def test_spmm_gemm_fused(ctx, flat_option, len_in, len_out, kind, transW, relu, 
 
 
 @pytest.mark.parametrize("flat", [0, 1])
-@pytest.mark.parametrize("d,d_out", [(128, 128), (64, 48), (96, 32)])
+@pytest.mark.parametrize("d,d_out", [(128, 128), (64, 48), (96, 32), (256, 128), (192, 256)])
 def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     """the multi-GPU own/halo split through the fused kernel: gaib_spmm on the low-column edges, then
     gaib_spmm_gemm(GAIB_ACCUMULATE) on the high-column edges continues the sums and carries the product"""
@@ -984,7 +984,7 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     ctx.spmm_gemm(gb, capi.W_EDGE, xd, agg, dev(W), y, relu=True, edge_w=dev(ewb), accumulate=True)
     assert rel_err(agg.cpu().numpy(), agg_w) < 1e-5
     assert_close(y.cpu().numpy(), y_w, floor=LONG_SUM_FLOOR)  # the hub row: 2500 terms, split in two halves
-    if d in (64, 128):  # fused shapes: light rows continue the CSR-order sum bit for bit
+    if d in (64, 128, 192, 256):  # fused shapes (one pass or two K-slabs): light rows continue the CSR-order sum bit for bit
         light = (np.diff(rpa) <= 1024) & (np.diff(rpb) <= 1024)
         assert np.array_equal(agg.cpu().numpy()[light].view(np.uint32), agg_w[light].view(np.uint32))
     # an empty second half (a rank without halo edges) leaves the sums alone and still applies the product
