@@ -1,5 +1,6 @@
 // context.cpp -- process-wide device context + per-op timers of the host API.
 #include <chrono>
+#include <string>
 #include "gpu_context.h"
 #include "global.h"
 #include "host_util.h"
@@ -28,6 +29,22 @@ void gpu_context::set(int device, void* hip_stream) {
   check(gaib_ctx_create(device, hip_stream, &g_ctx), "gaib_ctx_create");
   const char* s = getenv("GAIB_SYNC_TIMERS");
   g_sync_timers = s && atoi(s) != 0;
+  // development knobs for A/B runs of the drivers: GAIB_OPTS="key=value,key=value" -> gaib_set_option
+  if (const char* o = getenv("GAIB_OPTS")) {
+    std::string opts(o);
+    size_t pos = 0;
+    while (pos < opts.size()) {
+      size_t end = opts.find(',', pos);
+      if (end == std::string::npos) end = opts.size();
+      const std::string kv = opts.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos) {
+        check(gaib_set_option(g_ctx, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)), "gaib_set_option (GAIB_OPTS)");
+        fprintf(stderr, "[gaib] option %s\n", kv.c_str());
+      }
+      pos = end + 1;
+    }
+  }
 }
 
 gaib_ctx* gpu_context::get() {
