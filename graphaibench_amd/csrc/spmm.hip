@@ -1089,10 +1089,19 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   // inside the fused kernel: two kernels there
   const bool dense = ctx->spmm_chunked != 0 && len_in % 4 == 0 && (al & 15) == 0 &&
                      (ctx->spmm_chunked == 1 || chunk_rule(ctx, g, len_in));
-  const bool fusable = ctx->spmm_fuse != 0 && !dense && len_in >= 1 && len_in <= 128 && lanes_ok &&
-                       fuse_strip_rows(kpad, len_out, dual) != 0 && g->ne > 0 && g->nv >= 1 &&
-                       (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
-                        weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
+  const bool shape_ok = ctx->spmm_fuse != 0 && !dense && len_in >= 1 && len_in <= 128 && lanes_ok && g->ne > 0 &&
+                        g->nv >= 1 &&
+                        (weight_kind == GAIB_W_GCN || weight_kind == GAIB_W_MEAN ||
+                         weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
+  // two products whose matrices do not fit LDS together (SAGE's 100 -> 256 input layer): the neighbour product still
+  // rides on the aggregation, the self term follows as an accumulating GEMM that also applies the activation
+  if (shape_ok && dual && fuse_strip_rows(kpad, len_out, true) == 0 && fuse_strip_rows(kpad, len_out, false) != 0) {
+    GAIB_TRY(spmm_gemm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, d_W, transW, nullptr, nullptr, len_out, d_out,
+                            flags & ~GAIB_RELU));
+    return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_rows2, d_W2,
+                         GAIB_ACCUMULATE | ((flags & GAIB_RELU) ? GAIB_RELU : 0), d_out);
+  }
+  const bool fusable = shape_ok && fuse_strip_rows(kpad, len_out, dual) != 0;
   // 129..256 columns (the hidden width 256 of scripts/run-sage-products.sh): op(W) does not fit LDS next to the strips,
   // so the aggregation runs as two 128-column K-slabs through the same kernel, each with its [len_out x 128] slab of
   // op(W) in LDS: slab 0 writes y = agg[:, :128] . op(W)[:128, :], slab 1 adds agg[:, 128:] . op(W)[128:, :] (and applies

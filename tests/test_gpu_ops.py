@@ -1072,7 +1072,8 @@ def test_sgemm_experimental_variants_agree(ctx, variant):
     (47, 128, "mean_t", True, False),    # output layer backward (odd K)
     (128, 47, "mean", False, False),
     (64, 200, "gcn", False, True),
-    (128, 160, "mean", False, True),     # two matrices do not fit LDS: three-kernel path
+    (128, 160, "mean", False, True),     # two matrices do not fit LDS: neighbour product fused, self term as a GEMM
+    (100, 256, "mean", False, True),     # SAGE input layer at hidden 256: the same
     (256, 64, "mean", False, True),      # K > 128: two K-slabs through the fused kernel + an accumulating GEMM
     (256, 256, "mean", False, True),     # SAGE hidden 256 forward
     (256, 256, "mean_t", True, False),   # ... and backward
