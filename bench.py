@@ -501,7 +501,7 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     ctx.prof_enable(False)
-    keys = ["gat_vertex_dots", "gat_edge_softmax", "gat_bwd_fused", "gat_sddmm", "gat_softmax_bwd_alpha", "spmm_chunk", "spmm_chunk_reduce",
+    keys = ["gat_vertex_dots", "gat_edge_softmax", "gat_fwd_fused", "gat_bwd_fused", "gat_sddmm", "gat_softmax_bwd_alpha", "spmm_chunk", "spmm_chunk_reduce",
             "spmm_light", "spmm_heavy", "spmm_gemm_fused", "sgemm", "relu", "d_relu"]
     prof = {}
     for k in keys:
@@ -528,7 +528,11 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         "spmm_chunk": ne * (4 + 4 * Dg + 4 * H) + (ne // 64) * 4 * Dg,          # col + gathered row + weights, partial rows
         # the fused edge side of backward: col, rev, p_e, p_rev, rowdot of the column vertex and TWO gathered rows per edge
         # (h_c, grad_c); partial rows per chunk written and read once; nothing per edge is written
-        "gat_bwd_fused": ne * (4 + 4 + 2 * 4 * H + 2 * 4 * Dg + 4 * H) + (ne // 64) * (4 * Dg + 8 * H) * 2,
+        # (with the one-sweep forward the attention is formed again from row statistics: 8 B per (edge, head) of stats
+        # instead of p_e, p_rev and rev)
+        "gat_bwd_fused": ne * (4 + 2 * 4 * H + 2 * 4 * Dg + 4 * H) + (ne // 64) * (4 * Dg + 8 * H) * 2,
+        # one-sweep forward: col + ONE gathered row per edge; partial rows and (max, sum) per chunk written and read once
+        "gat_fwd_fused": ne * (4 + 4 * Dg) + (ne // 64) * (4 * Dg + 8 * H) * 2 + nv * (4 * Dg + 8 * H),
     }
     dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
     roof = None

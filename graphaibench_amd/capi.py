@@ -66,7 +66,8 @@ SIGNATURES = {
     "gaib_edge_gather_perm": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "gaib_edge_rowsum": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_alpha_grads": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "gaib_gat_backward_fused": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "gaib_gat_backward_fused": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "gaib_gat_forward_fused": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "gaib_edge_transpose_mh": (_i, [_vp, _vp, _i, _vp, _vp]),
     "gaib_gat_scores": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -365,12 +366,23 @@ class Context:
                                                       _ptr(lgrad), _ptr(rgrad), _ptr(grad_rows),
                                                       _ptr(fwd_out_rows), _ptr(norm_t)), "gaib_gat_softmax_bwd_alpha")
 
+    def gat_forward_fused(self, g, h, alpha_l, alpha_r, out, row_stats, eps: float = 0.2, heads: int = 1,
+                          relu: bool = False) -> bool:
+        """one-sweep forward; row_stats [nv, heads, 2] receives (row max, 1 / row sum).  False = not applicable"""
+        rc = self.lib.gaib_gat_forward_fused(self.h, g.h, h.shape[1], heads, _ptr(h), _ptr(alpha_l), _ptr(alpha_r), eps,
+                                             int(relu), _ptr(out), _ptr(row_stats))
+        if rc == -5:
+            return False
+        _check(rc, "gaib_gat_forward_fused")
+        return True
+
     def gat_backward_fused(self, g, feat, grad, fwd_out, alpha_l, alpha_r, norm, grad_out, lgrad, rgrad, eps: float = 0.2,
-                           heads: int = 1) -> bool:
-        """False when the fused path does not apply (GAIB_ERR_UNSUPPORTED, nothing touched)"""
+                           heads: int = 1, row_stats=None) -> bool:
+        """False when the fused path does not apply (GAIB_ERR_UNSUPPORTED, nothing touched).  row_stats (from
+        gat_forward_fused): the attention is formed again, norm may be None"""
         rc = self.lib.gaib_gat_backward_fused(self.h, g.h, feat.shape[1], heads, _ptr(feat), _ptr(grad), _ptr(fwd_out),
-                                              _ptr(alpha_l), _ptr(alpha_r), _ptr(norm), eps, _ptr(grad_out), _ptr(lgrad),
-                                              _ptr(rgrad))
+                                              _ptr(alpha_l), _ptr(alpha_r), _ptr(norm), _ptr(row_stats), eps,
+                                              _ptr(grad_out), _ptr(lgrad), _ptr(rgrad))
         if rc == -5:
             return False
         _check(rc, "gaib_gat_backward_fused")

@@ -73,6 +73,7 @@ struct gaib_ctx {
   int gat_chunk_sort;        // 1 = SDDMM edge chunks ordered by column block (set before the graph's first SDDMM)
   int gat_row_waves;         // rows (= waves) per workgroup in the GAT row-owner kernels: 1, 2 or 4
   int gat_fused_bwd;         // the one-pass edge side of GAT backward: -1 = dense graphs (aggregation's rule), 0 never, 1 whenever the shape fits
+  int gat_fused_fwd;         // the one-sweep forward (scores + online softmax + aggregation): -1 = dense graphs, 0 never, 1 whenever the shape fits
   int gat_fused_unroll;      // gathers in flight per lane and table in the fused backward sweep: 4 (default; measured 10.7 vs 10.9 ms) or 8
   int graph_rev_search;      // 1 = reverse-edge permutation by per-edge binary search (the reference's way) instead of the sort
   // in-stream kernel timing (gaib_prof_*)

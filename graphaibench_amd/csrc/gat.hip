@@ -821,12 +821,16 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H,
 // scalars one EDGE per lane (H-vectors) and met the column layout through LDS: 64 different lines per wave instruction
 // for each of five H-vector fetches, a dependent post-phase and 178 -> 142 VGPRs made it 10.5 ms at the reddit shape
 // against 12.3 ms for the staged kernels.
-template <int G, int H, int U>
+// RECOMP: the attention values are not read but formed again from the forward sweep's row statistics
+// (gat_fwd_fused_chunk_kernel): p_e = exp(lrelu(sl_i + sr_c) - M_i) / S_i and p_r = exp(lrelu(sl_c + sr_i) - M_c) / S_c
+// with stats[v][h] = (M, 1/S) -- one 8-B gather from a 15 MB table instead of 4 B linear + 4 B random + rev per edge, and
+// no [ne][H] array exists at all.
+template <int G, int H, int U, bool RECOMP>
 __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
-    const float* p, const float* rowdot, const float* alpha_l, const float* alpha_r, float eps, float* out_partial,
-    float* rc_partial) {
+    const float* p, const float2* stats, const float* rowdot, const float* alpha_l, const float* alpha_r, float eps,
+    float* out_partial, float* rc_partial) {
   constexpr int LH = G / H;  // lanes per head
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
@@ -839,7 +843,8 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   const int n = rem < 64 ? (int)rem : 64;
   const int64_t el = eb + (lane < n ? lane : 0);
   const uint32_t cl = col[el];
-  const uint32_t rl = rev[el];
+  uint32_t rl = 0;
+  if constexpr (!RECOMP) rl = rev[el];
   const int coff = sl * 4;  // len == 4 * G
   const int head = sl / LH;
   const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)len + coff);
@@ -857,22 +862,29 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     sr_i += __shfl_xor(sr_i, o, 64);
   }
   const float rd_i = rowdot[row * H + head];
+  float2 st_i = {0.f, 0.f};
+  if constexpr (RECOMP) st_i = stats[row * H + head];
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   float s_e = 0.f, s_r = 0.f;
 #pragma unroll
   for (int j = 0; j < G; j += U) {
     f4 xg[U], xh[U];
     float pe[U], pr[U], rd[U];
+    float2 stc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ei = gbase + j + u;
       const uint32_t cj = (uint32_t)__shfl((int)cl, ei, 64);
-      const uint32_t rj = (uint32_t)__shfl((int)rl, ei, 64);
       xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
       rd[u] = rowdot[(int64_t)cj * H + head];
-      pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
-      pr[u] = p[(int64_t)rj * H + head];
+      if constexpr (RECOMP) {
+        stc[u] = stats[(int64_t)cj * H + head];
+      } else {
+        const uint32_t rj = (uint32_t)__shfl((int)rl, ei, 64);
+        pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
+        pr[u] = p[(int64_t)rj * H + head];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first one is consumed
 #pragma unroll
@@ -889,11 +901,19 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
         sl_c += __shfl_xor(sl_c, o, 64);
         sr_c += __shfl_xor(sr_c, o, 64);
       }
-      const float a = pe[u], b = pr[u];
+      const float t_e = sl_i + sr_c, t_r = sl_c + sr_i;  // pre-activation scores of (i -> c) and (c -> i)
+      float a, b;
+      if constexpr (RECOMP) {
+        a = expf((t_e > 0.0f ? t_e : eps * t_e) - st_i.x) * st_i.y;
+        b = expf((t_r > 0.0f ? t_r : eps * t_r) - stc[u].x) * stc[u].y;
+      } else {
+        a = pe[u];
+        b = pr[u];
+      }
       const float dse = a * (1.0f - a) * dpe - (rd_i - a * dpe) * a;
       const float dsr = b * (1.0f - b) * dpr - (rd[u] - b * dpr) * b;
-      const float ge = dse * ((sl_i + sr_c) > 0.0f ? 1.0f : eps);  // leaky-relu' at the score of (i -> c)
-      const float gr = dsr * ((sl_c + sr_i) > 0.0f ? 1.0f : eps);  //              at the score of (c -> i)
+      const float ge = dse * (t_e > 0.0f ? 1.0f : eps);  // leaky-relu' at the score of (i -> c)
+      const float gr = dsr * (t_r > 0.0f ? 1.0f : eps);  //              at the score of (c -> i)
       if (live) {  // (lanes past the end of a short chunk looked at the chunk's first edge: nothing of it is added)
         s_e += ge;
         s_r += gr;
@@ -920,6 +940,122 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
       rc_partial[slot * 2 * H + H + head] = s_r;  // partial column sum of g (-> alpha_r gradient)
     }
   }
+}
+
+// ---- forward in ONE sweep: scores, edge softmax and aggregation over the ordered chunk list ---------------------------
+// GAT_Aggregator::aggregate (gat_aggregator.cpp:57-97) staged = per-vertex dots, a row-owner pass writing p [ne][H]
+// (two sweeps over long rows), then the aggregation reading p.  Here a chunk's wave gathers the rows h_c once, forms
+// sr_c = a_r . h_c from the gathered row, t = leaky_relu(sl_i + sr_c), and keeps an ONLINE softmax per lane group:
+// running maximum m, running sum s of exp(t - m) and the running weighted row sum, rescaled by exp(m_old - m_new) when
+// the maximum moves; the four groups and then the row's chunks are combined the same way (gat_fwd_reduce_kernel):
+//   out_i = sum_c exp(m_c - M) acc_c / S,   S = sum_c exp(m_c - M) s_c,   M = max_c m_c
+// which is the reference's max-subtracted softmax (math_functions.cpp:485-494) up to fp32 rounding.  Nothing per edge is
+// written: backward forms p again from stats[v][h] = (M, 1/S) (gat_bwd_fused_chunk_kernel<RECOMP>).
+constexpr float GAT_NEG = -1.0e30f;  // "no edge yet": finite, so exp(NEG - m) = 0 and NEG - NEG = 0 (not NaN)
+
+template <int G, int H, int U>
+__global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
+    int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
+    const int64_t* rowptr, const uint32_t* col, int len, const float* feat, const float* alpha_l, const float* alpha_r,
+    float eps, float* out_partial, float2* ms_partial) {
+  constexpr int LH = G / H;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rb = rowptr[row];
+  const int64_t rem = rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const uint32_t cl = col[eb + (lane < n ? lane : 0)];
+  const int coff = sl * 4;
+  const int head = sl / LH;
+  const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
+  const f4 al4 = *reinterpret_cast<const f4*>(alpha_l + coff);
+  const f4 ar4 = *reinterpret_cast<const f4*>(alpha_r + coff);
+  float sl_i = al4[0] * hi[0] + al4[1] * hi[1] + al4[2] * hi[2] + al4[3] * hi[3];
+#pragma unroll
+  for (int o = LH / 2; o > 0; o >>= 1) sl_i += __shfl_xor(sl_i, o, 64);
+  float m = GAT_NEG, ssum = 0.f;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < G; j += U) {
+    f4 xh[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t cj = (uint32_t)__shfl((int)cl, gbase + j + u, 64);
+      xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float sr_c = ar4[0] * xh[u][0] + ar4[1] * xh[u][1] + ar4[2] * xh[u][2] + ar4[3] * xh[u][3];
+#pragma unroll
+      for (int o = LH / 2; o > 0; o >>= 1) sr_c += __shfl_xor(sr_c, o, 64);
+      if (gbase + j + u < n) {  // wave-uniform per group; lanes past the end of a short chunk add nothing
+        const float t0 = sl_i + sr_c;
+        const float t = t0 > 0.0f ? t0 : eps * t0;
+        const float mn = t > m ? t : m;
+        const float sc = expf(m - mn), e = expf(t - mn);
+        ssum = ssum * sc + e;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] * sc + e * xh[u][k];
+        m = mn;
+      }
+    }
+  }
+  // the four groups meet: same rescaling
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(ssum, o, 64);
+    const float mn = mo > m ? mo : m;
+    const float a = expf(m - mn), b = expf(mo - mn);
+    ssum = ssum * a + so * b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = acc[k] * a + __shfl_xor(acc[k], o, 64) * b;
+    m = mn;
+  }
+  const int64_t slot = (int64_t)chunk_start[row] + (eb - rb) / 64;
+  if (gbase == 0) {
+    *reinterpret_cast<f4*>(out_partial + slot * len + coff) = acc;
+    if ((sl & (LH - 1)) == 0) ms_partial[slot * H + head] = float2{m, ssum};
+  }
+}
+
+// per row: combine the chunks' (m, s, acc) in chunk order; out = act(sum / S); stats[row][h] = (M, 1/S)
+__global__ __launch_bounds__(256) void gat_fwd_reduce_kernel(int64_t nv, int len, int H, const uint32_t* chunk_start,
+                                                             const float* out_partial, const float2* ms_partial, int relu,
+                                                             float* out, float2* stats) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  if (lane * 4 >= len) return;
+  const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
+  const int dh = len / H, head = (lane * 4) / dh;
+  float M = GAT_NEG;
+  for (int64_t k = c0; k < c1; ++k) {
+    const float mk = ms_partial[k * H + head].x;
+    M = mk > M ? mk : M;
+  }
+  float S = 0.f;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t k = c0; k < c1; ++k) {
+    const float2 ms = ms_partial[k * H + head];
+    const float w = expf(ms.x - M);
+    S += ms.y * w;
+    const f4 t = *reinterpret_cast<const f4*>(out_partial + k * len + lane * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] += t[q] * w;
+  }
+  const float inv = S > 0.f ? 1.0f / S : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    s[q] *= inv;
+    if (relu) s[q] = s[q] > 0.f ? s[q] : 0.f;
+  }
+  *reinterpret_cast<f4*>(out + row * (int64_t)len + lane * 4) = s;
+  if ((lane * 4) % dh == 0) stats[row * H + head] = float2{M, inv};
 }
 
 // out[row] = sum of the row's chunk partials in chunk order; rs / cs [row][H] the same for the g sums
@@ -1225,29 +1361,86 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
 // gat_fused_bwd: -1 = graphs with >= 1/4 of their edges in heavy rows and a feature table of <= 512 MB -- the
 // dense-graph rule of the aggregation; 0 = never; 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and
 // nothing was touched: the caller runs the staged entry points.
-extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
-                                       const float* d_grad, const float* d_fwd_out, const float* d_alpha_l,
-                                       const float* d_alpha_r, const float* d_norm_scores, float epsilon,
-                                       float* d_grad_out, float* d_alpha_lgrad, float* d_alpha_rgrad) {
-  GAIB_CHECK(ctx && g, "gaib_gat_backward_fused: NULL ctx/graph");
-  GAIB_TRY(check_heads("gaib_gat_backward_fused", len, heads));
-  GAIB_CHECK(d_feat && d_grad && d_fwd_out && d_alpha_l && d_alpha_r && d_norm_scores && d_grad_out && d_alpha_lgrad &&
-                 d_alpha_rgrad, "gaib_gat_backward_fused: NULL pointer");
-  GAIB_CHECK(d_grad_out != d_feat && d_grad_out != d_grad, "gaib_gat_backward_fused: d_grad_out must not alias an input");
-  GAIB_HIP(hipSetDevice(ctx->device));
+static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, int knob, uintptr_t align_or, int* rc) {
+  *rc = GAIB_OK;
   const bool shape_ok = len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) &&
-                        g->nc == g->nv && g->ne > 0 &&
-                        ((((uintptr_t)d_feat | (uintptr_t)d_grad | (uintptr_t)d_norm_scores | (uintptr_t)d_grad_out) & 15) == 0);
-  bool use = shape_ok && ctx->gat_fused_bwd != 0;
-  if (use && ctx->gat_fused_bwd < 0) {
-    GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
+                        g->nc == g->nv && g->ne > 0 && (align_or & 15) == 0;
+  bool use = shape_ok && knob != 0;
+  if (use && knob < 0) {
+    *rc = gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold);
+    if (*rc != GAIB_OK) return false;
     use = g->n_heavy > 0 && 4 * g->heavy_edges >= g->ne && (int64_t)g->nv * len * 4 <= ((int64_t)512 << 20);
   }
+  return use;
+}
+
+// Forward in one sweep (gat_fwd_fused_chunk_kernel): d_out = act(P h) and d_row_stats [nv][heads][2] = (row maximum of
+// the leaky-relu'd scores, 1 / row sum of exp) -- everything backward needs to form the attention again; no [ne][heads]
+// array is written.  Same cover and auto rule as gaib_gat_backward_fused (option "gat_fused_fwd"); otherwise
+// GAIB_ERR_UNSUPPORTED, nothing touched, and the caller runs gaib_gat_scores_mh + gaib_spmm_mh.
+extern "C" int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h,
+                                      const float* d_alpha_l, const float* d_alpha_r, float epsilon, int relu,
+                                      float* d_out, float* d_row_stats) {
+  GAIB_CHECK(ctx && g, "gaib_gat_forward_fused: NULL ctx/graph");
+  GAIB_TRY(check_heads("gaib_gat_forward_fused", len, heads));
+  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_out && d_row_stats && d_out != d_h, "gaib_gat_forward_fused: NULL or aliased pointer");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  int rc = GAIB_OK;
+  const bool use = gat_fused_applies(ctx, g, len, heads, ctx->gat_fused_fwd,
+                                     (uintptr_t)d_h | (uintptr_t)d_out | (uintptr_t)d_row_stats | (uintptr_t)d_alpha_l |
+                                         (uintptr_t)d_alpha_r, &rc);
+  if (rc != GAIB_OK) return rc;
+  if (!use) {
+    gaib_set_error("gaib_gat_forward_fused: not applicable to this shape / graph (len %d, heads %d)", len, heads);
+    return GAIB_ERR_UNSUPPORTED;
+  }
+  GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+  auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+  const size_t n_op = up4((size_t)g->n_chunks * len), n_ms = up4((size_t)g->n_chunks * heads * 2);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (n_op + n_ms)));
+  float* out_partial = (float*)ctx->ws;
+  float2* ms_partial = reinterpret_cast<float2*>(out_partial + n_op);
+  ProfScope ps(ctx, "gat_fwd_fused");
+  const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+#define GAIB_FF(HH)                                                                                                       \
+  gat_fwd_fused_chunk_kernel<16, HH, 8><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,          \
+                                                                       g->chunk_start, g->rowptr, g->colidx, len, d_h,     \
+                                                                       d_alpha_l, d_alpha_r, epsilon, out_partial, ms_partial)
+  switch (heads) {
+    case 1: GAIB_FF(1); break;
+    case 2: GAIB_FF(2); break;
+    case 4: GAIB_FF(4); break;
+    case 8: GAIB_FF(8); break;
+    default: GAIB_FF(16); break;
+  }
+#undef GAIB_FF
+  GAIB_LAUNCH_CHECK();
+  gat_fwd_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial, ms_partial,
+                                                                 relu ? 1 : 0, d_out, reinterpret_cast<float2*>(d_row_stats));
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
+                                       const float* d_grad, const float* d_fwd_out, const float* d_alpha_l,
+                                       const float* d_alpha_r, const float* d_norm_scores, const float* d_row_stats,
+                                       float epsilon, float* d_grad_out, float* d_alpha_lgrad, float* d_alpha_rgrad) {
+  GAIB_CHECK(ctx && g, "gaib_gat_backward_fused: NULL ctx/graph");
+  GAIB_TRY(check_heads("gaib_gat_backward_fused", len, heads));
+  GAIB_CHECK(d_feat && d_grad && d_fwd_out && d_alpha_l && d_alpha_r && (d_norm_scores || d_row_stats) && d_grad_out &&
+                 d_alpha_lgrad && d_alpha_rgrad, "gaib_gat_backward_fused: NULL pointer");
+  GAIB_CHECK(d_grad_out != d_feat && d_grad_out != d_grad, "gaib_gat_backward_fused: d_grad_out must not alias an input");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  int rc0 = GAIB_OK;
+  const bool use = gat_fused_applies(ctx, g, len, heads, ctx->gat_fused_bwd,
+                                     (uintptr_t)d_feat | (uintptr_t)d_grad | (uintptr_t)d_norm_scores |
+                                         (uintptr_t)d_row_stats | (uintptr_t)d_grad_out, &rc0);
+  if (rc0 != GAIB_OK) return rc0;
   if (!use) {
     gaib_set_error("gaib_gat_backward_fused: not applicable to this shape / graph (len %d, heads %d)", len, heads);
     return GAIB_ERR_UNSUPPORTED;
   }
-  GAIB_TRY(gaib_graph_ensure_rev(ctx, g));
+  if (!d_row_stats) GAIB_TRY(gaib_graph_ensure_rev(ctx, g));  // p[rev e] is read only when p is not formed again
   GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
   const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
   const int64_t rows_per_block = cdiv64(g->nv, nblocks);
@@ -1266,15 +1459,20 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   GAIB_LAUNCH_CHECK();
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
   // edges in flight per group: 8 or 4 (option gat_fused_unroll)
-#define GAIB_FB_U(HH, UU)                                                                                                 \
-  gat_bwd_fused_chunk_kernel<16, HH, UU><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,        \
-                                                                        g->chunk_start, g->rowptr, g->colidx, g->rev, len, \
-                                                                        d_feat, d_grad, d_norm_scores, rowdot, d_alpha_l,  \
-                                                                        d_alpha_r, epsilon, out_partial, rc_partial)
-#define GAIB_FB(HH)                      \
-  do {                                   \
-    if (ctx->gat_fused_unroll == 8) GAIB_FB_U(HH, 8); \
-    else GAIB_FB_U(HH, 4);               \
+#define GAIB_FB_U(HH, UU, RC)                                                                                              \
+  gat_bwd_fused_chunk_kernel<16, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
+      g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, g->rev, len, d_feat, d_grad,        \
+      d_norm_scores, reinterpret_cast<const float2*>(d_row_stats), rowdot, d_alpha_l, d_alpha_r, epsilon, out_partial,     \
+      rc_partial)
+#define GAIB_FB(HH)                                          \
+  do {                                                       \
+    if (d_row_stats) {                                       \
+      if (ctx->gat_fused_unroll == 8) GAIB_FB_U(HH, 8, true); \
+      else GAIB_FB_U(HH, 4, true);                           \
+    } else {                                                 \
+      if (ctx->gat_fused_unroll == 8) GAIB_FB_U(HH, 8, false); \
+      else GAIB_FB_U(HH, 4, false);                          \
+    }                                                        \
   } while (0)
   switch (heads) {
     case 1: GAIB_FB(1); break;

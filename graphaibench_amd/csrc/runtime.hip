@@ -60,6 +60,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_chunk_colsum = -1;
   c->graph_rev_search = 0;
   c->gat_fused_bwd = -1;
+  c->gat_fused_fwd = -1;
   c->gat_fused_unroll = 4;
   c->prof_on = 0;
   *out = c;
@@ -274,6 +275,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->gat_chunk_colsum = (int)value;
   else if (!strcmp(key, "gat_chunk_sort"))
     ctx->gat_chunk_sort = (int)value;
+  else if (!strcmp(key, "gat_fused_fwd"))
+    ctx->gat_fused_fwd = (int)value;
   else if (!strcmp(key, "gat_fused_unroll"))
     ctx->gat_fused_unroll = (int)value;
   else if (!strcmp(key, "gat_fused_bwd"))

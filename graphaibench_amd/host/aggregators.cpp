@@ -110,7 +110,8 @@ GAT_Aggregator::GAT_Aggregator()
     : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
       d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), d_tbuf(NULL), tbuf_floats(0), d_ptab(NULL), d_pout(NULL),
-      d_prs(NULL), d_pcs(NULL), ptab_floats(0), pvec_floats(0), alpha_opt(NULL) {}
+      d_prs(NULL), d_pcs(NULL), ptab_floats(0), pvec_floats(0), d_row_stats(NULL), stats_floats(0), stats_valid(false),
+      last_graph(NULL), last_in(NULL), last_len(0), alpha_opt(NULL) {}
 
 void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   length = l;
@@ -248,6 +249,30 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
     fprintf(stderr, "GAT_Aggregator: this partitioned graph was built without build_gat_structures()\n");
     exit(EXIT_FAILURE);
   }
+  // dense graphs at 64 columns: scores, edge softmax and aggregation in ONE sweep; only the row statistics (maximum,
+  // 1 / sum) are kept and backward forms the attention again -- no [ne][heads] array is written or read.  norm_scores_ptr()
+  // materialises the attention on demand (tests, checkpoints).
+  {
+    const size_t need = (size_t)g.size() * heads * 2;
+    if (need > stats_floats) {
+      if (d_row_stats) float_free_device(d_row_stats);
+      float_malloc_device64(need, d_row_stats);
+      stats_floats = need;
+    }
+    OpTimer t(OP_SPARSEMM);
+    const int rc = gaib_gat_forward_fused(C(), dev(g), len, heads, in, d_alpha_l, d_alpha_r, epsilon, fuse_relu ? 1 : 0,
+                                          out, d_row_stats);
+    if (rc == GAIB_OK) {
+      fuse_relu = false;
+      stats_valid = true;
+      last_graph = &g;
+      last_in = in;
+      last_len = len;
+      return;
+    }
+    if (rc != GAIB_ERR_UNSUPPORTED) GAIB_OR_DIE(rc);
+    stats_valid = false;
+  }
   if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
     num_edges = g.sizeEdges();
     float** arrays[] = {&d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
@@ -292,7 +317,8 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
       tbuf_floats = need;
     }
     const int rc = gaib_gat_backward_fused(C(), dev(g), len, heads, feat_in, grad_in, fwd_out, d_alpha_l, d_alpha_r,
-                                           d_norm_scores, epsilon, d_tbuf, d_alpha_lgrad, d_alpha_rgrad);
+                                           stats_valid ? NULL : d_norm_scores, stats_valid ? d_row_stats : NULL, epsilon,
+                                           d_tbuf, d_alpha_lgrad, d_alpha_rgrad);
     if (rc == GAIB_OK) {
       fwd_out = NULL;
       GAIB_OR_DIE(gaib_memcpy_d2d(C(), grad_out, d_tbuf, sizeof(float) * need));
@@ -300,6 +326,7 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
     }
     if (rc != GAIB_ERR_UNSUPPORTED) GAIB_OR_DIE(rc);  // a real failure; UNSUPPORTED = this shape / graph takes the staged path
   }
+  if (stats_valid) materialise_scores();  // (the staged kernels read the attention array)
   {
     OpTimer t(OP_SCORE);
     GAIB_OR_DIE(gaib_sddmm_mh(C(), dev(g), len, heads, grad_in, feat_in, d_norm_scores_grad));
@@ -323,6 +350,31 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
   }
   OpTimer t(OP_SPARSEMM);
   GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores_t, heads, len, grad_in, grad_out, 0));
+}
+
+// the attention [ne][heads] of the last forward, for callers that want the array the one-sweep forward did not write
+void GAT_Aggregator::materialise_scores() {
+  if (!stats_valid || !last_graph) return;
+  Graph& g = *last_graph;
+  if (g.sizeEdges() > num_edges) {
+    num_edges = g.sizeEdges();
+    float** arrays[] = {&d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
+    for (float** a : arrays) {
+      float_free_device(*a);
+      *a = gaib_host::dmalloc<float>(num_edges * heads);
+    }
+    if (d_temp_scores) {
+      float_free_device(d_temp_scores);
+      d_temp_scores = gaib_host::dmalloc<float>(num_edges * heads);
+    }
+  }
+  GAIB_OR_DIE(gaib_gat_scores_mh(C(), dev(g), last_len, heads, last_in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores, NULL,
+                                 d_norm_scores));
+  stats_valid = false;
+}
+float* GAT_Aggregator::norm_scores_ptr() {
+  materialise_scores();
+  return d_norm_scores;
 }
 
 void GAT_Aggregator::update_weights(optimizer*) {

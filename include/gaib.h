@@ -211,13 +211,21 @@ int gaib_gat_softmax_bwd_alpha_re(gaib_ctx* ctx, gaib_graph* g, int len, int hea
 /* The whole edge side of GAT_Aggregator::d_aggregate (gat_aggregator.cpp:99-200: SDDMM, softmax backward + leaky-relu',
  * alpha gradients, transpose, gradient aggregation) in ONE sweep over the edges.  d_fwd_out is the aggregation's forward
  * output (sum_e p_e dp_e of a row == <grad_i, out_i>); d_grad_out [nv x len] must not alias an input.  Nothing per edge is
- * written: the per-edge arrays dp / ds / p^T of the staged entry points do not exist on this path.  Applies to len == 64
+ * written: the per-edge arrays dp / ds / p^T of the staged entry points do not exist on this path.  The attention comes
+ * from d_norm_scores [ne][heads], or -- when d_row_stats (gaib_gat_forward_fused) is given -- is formed again.  Applies to len == 64
  * with 1, 2, 4, 8 or 16 heads on dense graphs (option "gat_fused_bwd": -1 auto, 0 never, 1 whenever the shape fits);
  * otherwise returns GAIB_ERR_UNSUPPORTED without touching anything and the caller uses the staged entry points. */
 int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat, const float* d_grad,
                             const float* d_fwd_out, const float* d_alpha_l, const float* d_alpha_r,
-                            const float* d_norm_scores, float epsilon, float* d_grad_out, float* d_alpha_lgrad,
-                            float* d_alpha_rgrad);
+                            const float* d_norm_scores, const float* d_row_stats, float epsilon, float* d_grad_out,
+                            float* d_alpha_lgrad, float* d_alpha_rgrad);
+/* GAT_Aggregator::aggregate (gat_aggregator.cpp:57-97) in ONE sweep: scores, edge softmax (online: running maximum and
+ * sum per chunk, combined per row) and the attention-weighted aggregation; d_out = act(P h), and d_row_stats
+ * [nv][heads][2] = (row maximum of the leaky-relu'd scores, 1 / row sum of exp) is everything backward needs to form the
+ * attention again: pass it to gaib_gat_backward_fused as d_row_stats (d_norm_scores may then be NULL) and no [ne][heads]
+ * array exists at all.  Same cover as gaib_gat_backward_fused (option "gat_fused_fwd"); GAIB_ERR_UNSUPPORTED otherwise. */
+int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h, const float* d_alpha_l,
+                           const float* d_alpha_r, float epsilon, int relu, float* d_out, float* d_row_stats);
 /* GAT backward on a RECTANGULAR graph (a rank's rows over [owned | halo] columns), where the reverse
  * edge of (i -> c) lives on another rank and the reverse-edge permutation is replaced by the rank's transposed local
  * structure (rows = owned + halo vertices, columns = owned rows; include/gnn/partition.h).  gaib_gat_scores_mh and

@@ -80,7 +80,7 @@ class GAT_Aggregator : public aggregator {
   float* alpha_r_ptr() { return d_alpha_r; }
   float* alpha_lgrad_ptr() { return d_alpha_lgrad; }
   float* alpha_rgrad_ptr() { return d_alpha_rgrad; }
-  float* norm_scores_ptr() { return d_norm_scores; }
+  float* norm_scores_ptr();  // (materialised on demand after a one-sweep forward, which keeps only row statistics)
   float* temp_scores_ptr() { return d_temp_scores; }  // NULL for 4, 8, 16 heads: not materialised either
   float* scores_ptr() { return NULL; }  // leaky_relu(temp_scores): not materialised by this backend
   float* norm_scores_grad_ptr() { return d_norm_scores_grad; }
@@ -105,5 +105,13 @@ class GAT_Aggregator : public aggregator {
   void ensure_partition_buffers(Graph& g, int len);
   void aggregate_partition(int len, Graph& g, const float* in, float* out);
   void d_aggregate_partition(int len, Graph& g, const float* grad_in, float* grad_out);
+  // one-sweep forward (gaib_gat_forward_fused): per (row, head) the softmax's maximum and 1 / sum
+  float* d_row_stats;
+  size_t stats_floats;
+  bool stats_valid;   // the last forward kept statistics instead of the attention array
+  Graph* last_graph;  // ... of this graph and input, should the array be asked for
+  const float* last_in;
+  int last_len;
+  void materialise_scores();
   optimizer* alpha_opt;
 };

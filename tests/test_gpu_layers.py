@@ -108,8 +108,10 @@ def gat_bwd_mode(request, _ctx):
     """GAT backward through the staged kernels (what these small graphs get by the auto rule) and through the one-sweep
     kernel (gaib_gat_backward_fused, what dense graphs get at 64 columns)"""
     _ctx.set_option("gat_fused_bwd", request.param)
+    _ctx.set_option("gat_fused_fwd", request.param)  # (the one-sweep forward with it: row statistics instead of p)
     yield request.param
     _ctx.set_option("gat_fused_bwd", -1)
+    _ctx.set_option("gat_fused_fwd", -1)
 
 
 @pytest.mark.parametrize("din,dout,level", [(100, 64, 0), (64, 64, 1), (64, 8, 1)])

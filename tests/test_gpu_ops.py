@@ -259,6 +259,52 @@ def test_gat_backward_fused(ctx, heads, hub, unroll):
     assert rel_err(lg.cpu().numpy(), lg2.cpu().numpy()) < 1e-4 and rel_err(rg.cpu().numpy(), rg2.cpu().numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("heads,hub", [(1, 0), (2, 700), (8, 0), (8, 1400), (16, 0)])
+def test_gat_forward_fused_and_backward_from_row_stats(ctx, heads, hub):
+    """gaib_gat_forward_fused: scores + online edge softmax + aggregation in one sweep == the oracle's aggregate
+    (gat_aggregator.cpp:57-97), and its row statistics (max, 1 / sum) reproduce the attention: exp(t - M) / S == the
+    oracle's norm_scores; gaib_gat_backward_fused fed with the statistics (no [ne][H] array at all) == d_aggregate."""
+    d = 64
+    rp, ci = random_graph(1500, 8, seed=heads + 11, power_law=True, hub_deg=hub)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    h = feat(g_o.nv, d, 1)
+    gin = feat(g_o.nv, d, 4)
+    al = feat(1, d, 2).ravel() * 0.2
+    ar = feat(1, d, 3).ravel() * 0.2
+    out_w, temp, _, norm = orc.gat_aggregate_mh(g_o, h, al, ar, heads)
+    want_go, _, _, want_lg, want_rg = orc.gat_d_aggregate_mh(g_o, h, gin, norm, temp, heads)
+    hd, gd = dev(h), dev(gin)
+    fl = LONG_SUM_FLOOR if hub else 1e-6
+    ctx.set_option("gat_fused_fwd", 1)
+    ctx.set_option("gat_fused_bwd", 1)
+    try:
+        out = torch.full((g_o.nv, d), 7.0, device="cuda")
+        stats = torch.empty(g_o.nv, heads, 2, device="cuda")
+        assert ctx.gat_forward_fused(g_d, hd, dev(al), dev(ar), out, stats, heads=heads)
+        out2 = torch.empty_like(out)
+        stats2 = torch.empty_like(stats)
+        assert ctx.gat_forward_fused(g_d, hd, dev(al), dev(ar), out2, stats2, heads=heads, relu=True)
+        assert torch.equal(out2, torch.relu(out)) and torch.equal(stats2, stats)  # deterministic; relu in the store
+        assert_close(out.cpu().numpy(), out_w, "forward", floor=fl)
+        # the statistics reproduce the attention of every edge
+        rows = np.repeat(np.arange(g_o.nv), np.diff(g_o.rowptr))
+        t = np.asarray(temp).reshape(g_o.ne, heads).astype(np.float64)
+        t = np.where(t > 0, t, 0.2 * t)
+        st = stats.cpu().numpy().astype(np.float64)
+        p_re = np.exp(t - st[rows, :, 0]) * st[rows, :, 1]
+        assert_close(p_re, np.asarray(norm).reshape(g_o.ne, heads), "attention from the row statistics", floor=LONG_SUM_FLOOR)
+        go = torch.full((g_o.nv, d), 7.0, device="cuda")
+        lg, rg = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+        assert ctx.gat_backward_fused(g_d, hd, gd, dev(out_w), dev(al), dev(ar), None, go, lg, rg, heads=heads,
+                                      row_stats=stats)
+    finally:
+        ctx.set_option("gat_fused_fwd", -1)
+        ctx.set_option("gat_fused_bwd", -1)
+    assert_close(go.cpu().numpy(), want_go, "grad_out", floor=fl)
+    assert_close(lg.cpu().numpy(), want_lg, "alpha_l grad", floor=LONG_SUM_FLOOR)
+    assert_close(rg.cpu().numpy(), want_rg, "alpha_r grad", floor=LONG_SUM_FLOOR)
+
+
 def test_spmm_chunked_short_chunk_does_not_touch_missing_edges(ctx):
     """a 70-edge row = one full 64-edge chunk + a 6-edge chunk whose idle lanes point at the chunk's first column.
     With an Inf in that column's feature row the sum must come out +Inf (the real edge carries it), not NaN
