@@ -357,14 +357,16 @@ extern "C" int gaib_comm_destroy(gaib_comm* c) {
   return GAIB_OK;
 }
 
+extern "C" int gaib_allreduce_f32(gaib_comm* c, float* d_buf, int64_t n);
+
 extern "C" int gaib_comm_barrier(gaib_comm* c) {
   GAIB_CHECK(c, "gaib_comm_barrier: comm is NULL");
   GAIB_HIP(hipStreamSynchronize(c->ctx->stream));
   if (c->transport == GAIB_COMM_IPC) return shm_barrier(c, "gaib_comm_barrier");
-  float* d = nullptr;  // a 1-element all-reduce is RCCL's barrier
+  // RCCL: a 1-element all-reduce, issued like every other collective of this communicator (on its communication stream)
   GAIB_TRY(gaib_ws_reserve(c->ctx, 256));
-  d = (float*)c->ctx->ws;
-  GAIB_NCCL(g_rccl.AllReduce(d, d, 1, ncclFloat32, ncclSum, c->nccl, c->ctx->stream));
+  GAIB_HIP(hipMemsetAsync(c->ctx->ws, 0, sizeof(float), c->ctx->stream));
+  GAIB_TRY(gaib_allreduce_f32(c, (float*)c->ctx->ws, 1));
   GAIB_HIP(hipStreamSynchronize(c->ctx->stream));
   return GAIB_OK;
 }
