@@ -62,6 +62,7 @@ struct gaib_ctx {
   int spmm_pad;              // 1 = re-stride odd-width input tables where that saves >10 % of the gathered lines, 0 = never
   int spmm_fuse;             // 1 = gaib_spmm_gemm may fuse the dense product into the aggregation
   int spmm_flat;             // fused kernel, edge-stream form for short rows: -1 = by average degree, 0 = never, 1 = always
+  int spmm_fuse_cus;         // fused kernel: persistent workgroups (= CUs it occupies); 0 = all CUs.  Fewer leave whole CUs to a kernel on another stream
   int spmm_tile_xcd;         // fused kernel: 1 = tiles off per-XCD counters over interleaved 256-row chunks, 0 = one global counter
   int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8
   int spmm_addr_mode;        // 0 = auto (buffer loads when the table is < 4 GB), 2 = force 64-bit global

@@ -46,6 +46,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_xcd_swizzle = 2;
   c->spmm_unroll = 0;
   c->spmm_tile_xcd = 0;
+  c->spmm_fuse_cus = 0;
   c->spmm_fuse = 1;
   c->spmm_pad = 1;
   c->spmm_chunked = -1;
@@ -257,7 +258,10 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_pad = (int)value;
   else if (!strcmp(key, "spmm_flat"))
     ctx->spmm_flat = (int)value;
-  else if (!strcmp(key, "spmm_tile_xcd"))
+  else if (!strcmp(key, "spmm_fuse_cus")) {
+    GAIB_CHECK(value >= 0 && value <= ctx->num_cus, "spmm_fuse_cus: 0 (all) .. %d", ctx->num_cus);
+    ctx->spmm_fuse_cus = (int)value;
+  } else if (!strcmp(key, "spmm_tile_xcd"))
     ctx->spmm_tile_xcd = (int)value;
   else if (!strcmp(key, "spmm_unroll"))
     ctx->spmm_unroll = (int)value;

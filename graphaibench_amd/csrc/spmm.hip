@@ -693,7 +693,8 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   const int strip = fuse_strip_rows(K, f.n_out, dual);  // 8, 2 or 0 (does not fit: the caller checked)
   const size_t lds = fuse_lds_bytes(K, f.n_out, dual, strip);
   const int64_t ntiles = cdiv64(a.n_rows, FUSE_ROWS);
-  const unsigned grid = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, FUSE_WAVES));
+  const int cus = ctx->spmm_fuse_cus > 0 ? ctx->spmm_fuse_cus : ctx->num_cus;
+  const unsigned grid = (unsigned)std::min<int64_t>(cus, cdiv64(ntiles, FUSE_WAVES));
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, 8 * sizeof(int), ctx->stream));  // one counter per XCD
   ProfScope ps(ctx, "spmm_gemm_fused");
   // more than 64 KB of dynamic LDS has to be asked for
