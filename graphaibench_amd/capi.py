@@ -26,7 +26,21 @@ SIGNATURES = {
     "gaib_ctx_create": (_i, [_i, _vp, _pp]),
     "gaib_ctx_destroy": (_i, [_vp]),
     "gaib_ctx_set_stream": (_i, [_vp, _vp]),
+    "gaib_ctx_own_stream": (_i, [_vp]),
     "gaib_sync": (_i, [_vp]),
+    "gaib_capture_begin": (_i, [_vp]),
+    "gaib_capture_end": (_i, [_vp, _pp]),
+    "gaib_capture_abort": (_i, [_vp]),
+    "gaib_exec_launch": (_i, [_vp, _vp]),
+    "gaib_exec_nodes": (_i64, [_vp]),
+    "gaib_exec_destroy": (_i, [_vp]),
+    "gaib_host_alloc": (_i, [_vp, C.c_size_t, _pp]),
+    "gaib_host_free": (_i, [_vp, _vp]),
+    "gaib_memcpy_d2h_async": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "gaib_masked_avg_loss_dev": (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "gaib_masked_accuracy_single_dev": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "gaib_masked_f1_counts_dev": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "gaib_adam_step_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp]),
     "gaib_side_begin": (_i, [_vp]),
     "gaib_side_end": (_i, [_vp]),
     "gaib_side_wait": (_i, [_vp]),
@@ -249,6 +263,25 @@ def _ptr(x) -> int | None:
     return x.data_ptr()
 
 
+class Exec:
+    """a recorded call sequence (gaib_capture_begin / end)"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    @property
+    def nodes(self) -> int:
+        return self.ctx.lib.gaib_exec_nodes(self.h)
+
+    def launch(self):
+        _check(self.ctx.lib.gaib_exec_launch(self.ctx.h, self.h), "gaib_exec_launch")
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.gaib_exec_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """gaib_ctx bound to one device and one HIP stream (default: torch's current stream)."""
 
@@ -286,6 +319,22 @@ class Context:
 
     def side_wait(self):
         _check(self.lib.gaib_side_wait(self.h), "gaib_side_wait")
+
+    # ---- HIP graphs: record a call sequence, replay it with one launch ---------------------------
+    def own_stream(self):
+        """switch to a stream created by the context (the null stream cannot be recorded)"""
+        _check(self.lib.gaib_ctx_own_stream(self.h), "gaib_ctx_own_stream")
+
+    def capture_begin(self):
+        _check(self.lib.gaib_capture_begin(self.h), "gaib_capture_begin")
+
+    def capture_end(self) -> "Exec":
+        x = C.c_void_p()
+        _check(self.lib.gaib_capture_end(self.h, C.byref(x)), "gaib_capture_end")
+        return Exec(self, x)
+
+    def capture_abort(self):
+        _check(self.lib.gaib_capture_abort(self.h), "gaib_capture_abort")
 
     def set_option(self, key: str, value: int):
         _check(self.lib.gaib_set_option(self.h, key.encode(), int(value)), f"gaib_set_option({key})")
@@ -472,6 +521,19 @@ class Context:
     def adam_step(self, dW, W, m, v, alpha, b1_t, b2_t, b1=0.9, b2=0.999, eps=1e-8):
         _check(self.lib.gaib_adam_step(self.h, W.numel(), _ptr(dW), _ptr(W), _ptr(m), _ptr(v), alpha, b1, b2,
                                        b1_t, b2_t, eps), "gaib_adam_step")
+
+    def adam_step_dev(self, dW, W, m, v, alpha, d_pow, b1=0.9, b2=0.999, eps=1e-8):
+        """beta powers in device memory (d_pow = [b1^t, b2^t]), advanced there: the recordable form"""
+        _check(self.lib.gaib_adam_step_dev(self.h, W.numel(), _ptr(dW), _ptr(W), _ptr(m), _ptr(v), alpha, b1, b2, eps,
+                                           _ptr(d_pow)), "gaib_adam_step_dev")
+
+    def masked_avg_loss_dev(self, loss, begin, end, d_result, masks=None):
+        _check(self.lib.gaib_masked_avg_loss_dev(self.h, begin, end, _ptr(masks), _ptr(loss), _ptr(d_result)),
+               "gaib_masked_avg_loss_dev")
+
+    def masked_accuracy_single_dev(self, preds, labels, begin, end, d_result, masks=None):
+        _check(self.lib.gaib_masked_accuracy_single_dev(self.h, begin, end, preds.shape[1], _ptr(masks), _ptr(preds),
+                                                        _ptr(labels), _ptr(d_result)), "gaib_masked_accuracy_single_dev")
 
     def gather_rows(self, idx, x, out):
         _check(self.lib.gaib_gather_rows(self.h, idx.numel(), _ptr(idx), x.shape[1], _ptr(x), _ptr(out)),

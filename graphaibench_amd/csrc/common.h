@@ -38,6 +38,13 @@ void gaib_set_error(const char* fmt, ...);
 
 #define GAIB_LAUNCH_CHECK() GAIB_HIP(hipGetLastError())
 
+// Calls that wait for the stream or (re)allocate cannot be recorded into a HIP graph: inside a capture they are an
+// error that says so, instead of a hipErrorStreamCaptureUnsupported from somewhere below.
+#define GAIB_NOT_WHILE_CAPTURING(ctx, what)                                                                        \
+  GAIB_CHECK(!(ctx)->capturing, "%s inside gaib_capture_begin/end: it waits for the stream or allocates -- run the " \
+                                "sequence once before capturing it (buffers and lazily built tables then exist)", what)
+
+
 struct gaib_ctx {
   int device;
   hipStream_t stream;
@@ -77,6 +84,8 @@ struct gaib_ctx {
   int gat_fused_fwd;         // the one-sweep forward (scores + online softmax + aggregation): -1 = dense graphs, 0 never, 1 whenever the shape fits
   int gat_fused_unroll;      // gathers in flight per lane and table in the fused backward sweep: 4 (default; measured 10.7 vs 10.9 ms) or 8
   int graph_rev_search;      // 1 = reverse-edge permutation by per-edge binary search (the reference's way) instead of the sort
+  hipStream_t owned_stream;  // gaib_ctx_own_stream: a stream the context created (destroyed with it), else NULL
+  int capturing;             // 1 between gaib_capture_begin and gaib_capture_end: calls are recorded into a HIP graph, nothing runs
   // in-stream kernel timing (gaib_prof_*)
   int prof_on;
   struct ProfRec { const char* key; hipEvent_t a, b; };
@@ -88,7 +97,7 @@ struct ProfScope {
   gaib_ctx* c;
   size_t idx;
   ProfScope(gaib_ctx* ctx, const char* key) : c(ctx), idx((size_t)-1) {
-    if (!c->prof_on) return;
+    if (!c->prof_on || c->capturing) return;
     gaib_ctx::ProfRec r;
     r.key = key;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;

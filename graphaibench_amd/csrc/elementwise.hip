@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n_idx, const i
 }
 
 int finish_partial(gaib_ctx* ctx, int nblocks, float* d_part, float* h_result) {
+  GAIB_NOT_WHILE_CAPTURING(ctx, "a metric with a host result (use the *_dev form)");
   float h[2 * 1024];
   GAIB_HIP(hipMemcpyAsync(h, d_part, sizeof(float) * 2 * nblocks, hipMemcpyDeviceToHost, ctx->stream));
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
@@ -383,6 +384,42 @@ int finish_partial(gaib_ctx* ctx, int nblocks, float* d_part, float* h_result) {
   }
   *h_result = c > 0.f ? s / c : 0.f;
   return GAIB_OK;
+}
+
+// the device-side twin of finish_partial: the block partials are added in block order by ONE thread (the host loop's
+// order and roundings), result[0] = sum / count
+__global__ void finish_partial_kernel(int nblocks, const float* part, float* result) {
+  __shared__ float sh[2 * 1024];
+  for (int t = threadIdx.x; t < 2 * nblocks; t += blockDim.x) sh[t] = part[t];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f, c = 0.f;
+    for (int b = 0; b < nblocks; ++b) {
+      s += sh[2 * b];
+      c += sh[2 * b + 1];
+    }
+    result[0] = c > 0.f ? s / c : 0.f;
+  }
+}
+
+// Adam with the beta powers in device memory (pw[0] = b1^t, pw[1] = b2^t): a recorded (HIP graph) step cannot take
+// them by value.  adam_advance_kernel is the host's `b1_t *= b1; b2_t *= b2` (optimizer.cpp), same float products.
+__global__ void adam_dev_kernel(int64_t n, const float* dW, float* W, float* m, float* v, float alpha, float b1,
+                                float b2, const float* pw, float eps) {
+  const float b1_t = pw[0], b2_t = pw[1];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float g = dW[i];
+    const float mt = b1 * m[i] + (1.0f - b1) * g;
+    const float vt = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mt;
+    v[i] = vt;
+    W[i] -= alpha * (mt / (1.0f - b1_t)) / sqrtf((vt / (1.0f - b2_t)) + eps);
+  }
+}
+__global__ void adam_advance_kernel(float* pw, float b1, float b2) {
+  pw[0] *= b1;
+  pw[1] *= b2;
 }
 
 }  // namespace
@@ -498,6 +535,7 @@ extern "C" int gaib_masked_f1_micro(gaib_ctx* ctx, int64_t begin, int64_t end, i
                                     const uint8_t* d_labels, float* h_result, int64_t* h_counts) {
   GAIB_CHECK(ctx && d_preds && d_labels && h_result, "gaib_masked_f1_micro: NULL argument");
   GAIB_CHECK(begin >= 0 && end >= begin && num_cls > 0, "gaib_masked_f1_micro: bad range");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_masked_f1_micro (use gaib_masked_f1_counts_dev)");
   *h_result = 0.f;
   unsigned long long c[3] = {0, 0, 0};
   if (end > begin) {
@@ -551,6 +589,52 @@ extern "C" int gaib_masked_accuracy_single(gaib_ctx* ctx, int64_t begin, int64_t
   return finish_partial(ctx, nblocks, (float*)ctx->ws, h_result);
 }
 
+// tp, fp, fn of the multi-label head left in device memory (d_counts[3], 64-bit); the F1 is the caller's arithmetic
+extern "C" int gaib_masked_f1_counts_dev(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls, const uint8_t* d_masks,
+                                         const float* d_preds, const uint8_t* d_labels, uint64_t* d_counts) {
+  GAIB_CHECK(ctx && d_preds && d_labels && d_counts, "gaib_masked_f1_counts_dev: NULL argument");
+  GAIB_CHECK(begin >= 0 && end >= begin && num_cls > 0, "gaib_masked_f1_counts_dev: bad range");
+  GAIB_HIP(hipMemsetAsync(d_counts, 0, 3 * sizeof(uint64_t), ctx->stream));
+  if (end > begin) {
+    unsigned grid = stream_grid((end - begin) * num_cls, 256);
+    f1_counts_kernel<<<grid, 256, 0, ctx->stream>>>(num_cls, begin, end, d_masks, d_preds, d_labels,
+                                                    (unsigned long long*)d_counts);
+    GAIB_LAUNCH_CHECK();
+  }
+  return GAIB_OK;
+}
+
+// the two metrics with the result left in DEVICE memory (d_result[0]); no host wait, recordable
+extern "C" int gaib_masked_avg_loss_dev(gaib_ctx* ctx, int64_t begin, int64_t end, const uint8_t* d_masks,
+                                        const float* d_loss, float* d_result) {
+  GAIB_CHECK(ctx && d_loss && d_result, "gaib_masked_avg_loss_dev: NULL argument");
+  GAIB_CHECK(begin >= 0 && end >= begin, "gaib_masked_avg_loss_dev: bad range");
+  if (end == begin) return gaib_fill_f32(ctx, 1, 0.f, d_result);
+  const int nblocks = (int)stream_grid(end - begin, 256) > 1024 ? 1024 : (int)stream_grid(end - begin, 256);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * 1024));
+  masked_loss_partial_kernel<<<nblocks, 256, 0, ctx->stream>>>(begin, end, d_masks, d_loss, (float*)ctx->ws);
+  GAIB_LAUNCH_CHECK();
+  finish_partial_kernel<<<1, 256, 0, ctx->stream>>>(nblocks, (const float*)ctx->ws, d_result);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_masked_accuracy_single_dev(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                                               const uint8_t* d_masks, const float* d_preds,
+                                               const uint8_t* d_labels, float* d_result) {
+  GAIB_CHECK(ctx && d_preds && d_labels && d_result, "gaib_masked_accuracy_single_dev: NULL argument");
+  GAIB_CHECK(begin >= 0 && end >= begin && num_cls > 0, "gaib_masked_accuracy_single_dev: bad range");
+  if (end == begin) return gaib_fill_f32(ctx, 1, 0.f, d_result);
+  const int nblocks = (int)stream_grid(end - begin, 256) > 1024 ? 1024 : (int)stream_grid(end - begin, 256);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * 2 * 1024));
+  masked_acc_partial_kernel<<<nblocks, 256, 0, ctx->stream>>>(begin, end, num_cls, d_masks, d_preds, d_labels,
+                                                              (float*)ctx->ws);
+  GAIB_LAUNCH_CHECK();
+  finish_partial_kernel<<<1, 256, 0, ctx->stream>>>(nblocks, (const float*)ctx->ws, d_result);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
 extern "C" int gaib_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_in, float* d_out) {
   GAIB_CHECK(ctx && ((d_in && d_out) || n == 0), "gaib_l2norm: NULL argument");
   if (n <= 0 || dim <= 0) return GAIB_OK;
@@ -576,6 +660,18 @@ extern "C" int gaib_adam_step(gaib_ctx* ctx, int64_t n, const float* d_dW, float
   if (n <= 0) return GAIB_OK;
   adam_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, d_dW, d_W, d_m, d_v, alpha, b1, b2,
                                                             b1_t, b2_t, eps);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_adam_step_dev(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, float* d_m, float* d_v,
+                                  float alpha, float b1, float b2, float eps, float* d_pow) {
+  GAIB_CHECK(ctx && d_pow && ((d_dW && d_W && d_m && d_v) || n == 0), "gaib_adam_step_dev: NULL argument");
+  if (n > 0) {
+    adam_dev_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, d_dW, d_W, d_m, d_v, alpha, b1, b2, d_pow, eps);
+    GAIB_LAUNCH_CHECK();
+  }
+  adam_advance_kernel<<<1, 1, 0, ctx->stream>>>(d_pow, b1, b2);  // once per call, also for an empty buffer (Q6)
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }

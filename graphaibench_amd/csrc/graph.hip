@@ -308,6 +308,7 @@ extern "C" int gaib_graph_compute_edge_data(gaib_ctx* ctx, gaib_graph* g) {
 
 int gaib_graph_ensure_inv_deg(gaib_ctx* ctx, gaib_graph* g) {
   if (g->inv_deg) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's 1/degree table");
   GAIB_HIP(hipMalloc(&g->inv_deg, sizeof(float) * (size_t)(g->nv > 0 ? g->nv : 1)));
   g->dev_bytes += sizeof(float) * g->nv;
   inv_deg_kernel<<<grid1d(g->nv, 256), 256, 0, ctx->stream>>>(g->nv, g->rowptr, g->inv_deg);
@@ -317,6 +318,7 @@ int gaib_graph_ensure_inv_deg(gaib_ctx* ctx, gaib_graph* g) {
 
 int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g) {
   if (g->w_gcn) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's GCN edge weights");
   if (!g->vdata) GAIB_TRY(gaib_graph_compute_vertex_data(ctx, g));
   GAIB_HIP(hipMalloc(&g->w_gcn, sizeof(float) * (size_t)(g->ne > 0 ? g->ne : 1)));
   g->dev_bytes += sizeof(float) * g->ne;
@@ -330,6 +332,7 @@ int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g) {
 
 int gaib_graph_ensure_w_mean_t(gaib_ctx* ctx, gaib_graph* g) {
   if (g->w_mean_t) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's transpose-mean edge weights");
   GAIB_TRY(gaib_graph_ensure_inv_deg(ctx, g));
   GAIB_HIP(hipMalloc(&g->w_mean_t, sizeof(float) * (size_t)(g->ne > 0 ? g->ne : 1)));
   g->dev_bytes += sizeof(float) * g->ne;
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void rev_check_kernel(int64_t nv, const int64_
 
 int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g) {
   if (g->rev) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's reverse-edge permutation");
   GAIB_CHECK(g->nc == g->nv, "reverse-edge permutation: square graphs only");
   uint32_t* rev = nullptr;
   int* bad = nullptr;
@@ -435,6 +439,7 @@ int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g) {
 
 int gaib_graph_ensure_heavy(gaib_ctx* ctx, gaib_graph* g, int thr) {
   if (g->heavy_thr == thr) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's heavy-row list");
   unsigned long long* cnt = nullptr;
   GAIB_HIP(hipMalloc(&cnt, 3 * sizeof(unsigned long long)));
   struct Release {  // (every early return below goes through GAIB_HIP / GAIB_LAUNCH_CHECK)
@@ -506,6 +511,7 @@ int gaib_graph_ensure_hot_flags(gaib_ctx* ctx, gaib_graph* g, int len) {
   if (hot_rows > g->nv) hot_rows = g->nv;
   // threshold = degree of the hot_rows-th highest-degree vertex
   if (g->colidx_flagged && g->hot_rows == hot_rows) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's hot-column flags");
   std::vector<int64_t> rp((size_t)g->nv + 1);
   GAIB_HIP(hipMemcpyAsync(rp.data(), g->rowptr, sizeof(int64_t) * (g->nv + 1), hipMemcpyDeviceToHost, ctx->stream));
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
@@ -568,6 +574,7 @@ __global__ void chunk_permute_kernel(int64_t n, const uint32_t* order, const uin
 
 int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g) {
   if (g->chunk_row) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's edge-chunk list");
   GAIB_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int64_t nv = g->nv;

@@ -64,6 +64,8 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_fused_fwd = -1;
   c->gat_fused_unroll = 4;
   c->prof_on = 0;
+  c->capturing = 0;
+  c->owned_stream = nullptr;
   *out = c;
   return GAIB_OK;
 }
@@ -75,6 +77,7 @@ extern "C" int gaib_ctx_destroy(gaib_ctx* ctx) {
   if (ctx->pad) (void)hipFree(ctx->pad);
   if (ctx->ws_side) (void)hipFree(ctx->ws_side);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
@@ -86,6 +89,19 @@ extern "C" int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream) {
   GAIB_CHECK(!ctx->forked, "gaib_ctx_set_stream: a side section is open");
   ctx->stream = (hipStream_t)stream;
   ctx->main_stream = ctx->stream;
+  return GAIB_OK;
+}
+
+// A stream of the context's own (non-blocking, i.e. not ordered against the null stream): what a caller without a
+// stream of its own -- the C++ drivers -- needs before gaib_capture_begin, since the null stream cannot be captured.
+extern "C" int gaib_ctx_own_stream(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_ctx_own_stream: ctx is NULL");
+  GAIB_CHECK(!ctx->forked && !ctx->capturing, "gaib_ctx_own_stream: a side section or capture is open");
+  if (ctx->owned_stream && ctx->stream == ctx->owned_stream) return GAIB_OK;
+  GAIB_HIP(hipSetDevice(ctx->device));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));  // what was enqueued on the old stream is done before the switch
+  if (!ctx->owned_stream) GAIB_HIP(hipStreamCreateWithFlags(&ctx->owned_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->main_stream = ctx->owned_stream;
   return GAIB_OK;
 }
 
@@ -128,12 +144,14 @@ extern "C" int gaib_side_wait(gaib_ctx* ctx) {
 
 extern "C" int gaib_sync(gaib_ctx* ctx) {
   GAIB_CHECK(ctx, "gaib_sync: ctx is NULL");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_sync");
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
   return GAIB_OK;
 }
 
 int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "growing the workspace");
   // the old buffer may still be in use by enqueued kernels
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->ws) GAIB_HIP(hipFree(ctx->ws));
@@ -151,6 +169,7 @@ int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes) {
 
 int gaib_pad_reserve(gaib_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pad_bytes) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "growing the padded-table buffer");
   GAIB_HIP(hipStreamSynchronize(ctx->stream));  // the old buffer may still be read by enqueued kernels
   if (ctx->pad) GAIB_HIP(hipFree(ctx->pad));
   ctx->pad = nullptr;
@@ -166,6 +185,7 @@ int gaib_pad_reserve(gaib_ctx* ctx, size_t bytes) {
 
 extern "C" int gaib_malloc(gaib_ctx* ctx, size_t bytes, void** d_ptr) {
   GAIB_CHECK(ctx && d_ptr, "gaib_malloc: NULL argument");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_malloc");
   GAIB_HIP(hipSetDevice(ctx->device));
   *d_ptr = nullptr;
   if (bytes == 0) return GAIB_OK;
@@ -179,6 +199,7 @@ extern "C" int gaib_malloc(gaib_ctx* ctx, size_t bytes, void** d_ptr) {
 
 extern "C" int gaib_free(gaib_ctx* ctx, void* d_ptr) {
   GAIB_CHECK(ctx, "gaib_free: ctx is NULL");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_free");
   if (d_ptr) GAIB_HIP(hipFree(d_ptr));
   return GAIB_OK;
 }
@@ -186,6 +207,7 @@ extern "C" int gaib_free(gaib_ctx* ctx, void* d_ptr) {
 extern "C" int gaib_memcpy_h2d(gaib_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   GAIB_CHECK(ctx, "gaib_memcpy_h2d: ctx is NULL");
   if (bytes == 0) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_memcpy_h2d");
   GAIB_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   // pageable source: make the call safe to return from (source may be freed by caller)
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
@@ -195,6 +217,7 @@ extern "C" int gaib_memcpy_h2d(gaib_ctx* ctx, void* d_dst, const void* h_src, si
 extern "C" int gaib_memcpy_d2h(gaib_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   GAIB_CHECK(ctx, "gaib_memcpy_d2h: ctx is NULL");
   if (bytes == 0) return GAIB_OK;
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_memcpy_d2h");
   GAIB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
   return GAIB_OK;
@@ -207,8 +230,124 @@ extern "C" int gaib_memcpy_d2d(gaib_ctx* ctx, void* d_dst, const void* d_src, si
   return GAIB_OK;
 }
 
+// ---- pinned host memory + stream-ordered read-back (results of a captured sequence) ---------------------------------
+extern "C" int gaib_host_alloc(gaib_ctx* ctx, size_t bytes, void** h_ptr) {
+  GAIB_CHECK(ctx && h_ptr, "gaib_host_alloc: NULL argument");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_host_alloc");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  *h_ptr = nullptr;
+  if (bytes == 0) return GAIB_OK;
+  hipError_t e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    gaib_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return GAIB_ERR_NOMEM;
+  }
+  memset(*h_ptr, 0, bytes);
+  return GAIB_OK;
+}
+
+extern "C" int gaib_host_free(gaib_ctx* ctx, void* h_ptr) {
+  GAIB_CHECK(ctx, "gaib_host_free: ctx is NULL");
+  if (h_ptr) GAIB_HIP(hipHostFree(h_ptr));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_memcpy_d2h_async(gaib_ctx* ctx, void* h_pinned_dst, const void* d_src, size_t bytes) {
+  GAIB_CHECK(ctx && (bytes == 0 || (h_pinned_dst && d_src)), "gaib_memcpy_d2h_async: NULL argument");
+  if (bytes == 0) return GAIB_OK;
+  GAIB_HIP(hipMemcpyAsync(h_pinned_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return GAIB_OK;
+}
+
+// ---- HIP graphs: a recorded call sequence replayed with one launch ------------------------------------------------
+// The models of BASELINE configs 1-2 (cora / citeseer: 2 layers, 16 hidden columns, ~13 k edges) are launch bound: an
+// epoch is ~40 kernels of a few microseconds each, and the host spends longer enqueueing one than the GPU running it.
+// Between gaib_capture_begin and gaib_capture_end every call on this context is RECORDED on its stream (relaxed capture
+// mode: only this stream, other threads are not affected), nothing runs; gaib_exec_launch replays the whole sequence.
+// Pointers and scalar arguments are frozen at capture time: what changes from replay to replay must live in device
+// memory (gaib_adam_step_dev keeps the beta powers there; gaib_masked_*_dev leave their results there).
+struct gaib_exec {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int device;
+  size_t nodes;
+};
+
+extern "C" int gaib_capture_begin(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_capture_begin: ctx is NULL");
+  GAIB_CHECK(!ctx->capturing, "gaib_capture_begin: a capture is already open");
+  GAIB_CHECK(!ctx->forked, "gaib_capture_begin: a side section is open");
+  GAIB_CHECK(ctx->stream != nullptr, "gaib_capture_begin: the context runs on the null stream, which cannot be captured "
+                                     "(create the context on a stream of its own)");
+  GAIB_CHECK(!ctx->prof_on, "gaib_capture_begin: in-stream kernel timing is on (gaib_prof_enable)");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  GAIB_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  ctx->capturing = 1;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_capture_abort(gaib_ctx* ctx) {
+  GAIB_CHECK(ctx, "gaib_capture_abort: ctx is NULL");
+  if (!ctx->capturing) return GAIB_OK;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(ctx->stream, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  ctx->capturing = 0;
+  return GAIB_OK;
+}
+
+extern "C" int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out) {
+  GAIB_CHECK(ctx && out, "gaib_capture_end: NULL argument");
+  GAIB_CHECK(ctx->capturing, "gaib_capture_end: no open capture");
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  ctx->capturing = 0;
+  if (e != hipSuccess || !g) {
+    gaib_set_error("gaib_capture_end: hipStreamEndCapture: %s (a call inside the capture cannot be recorded)",
+                   hipGetErrorString(e));
+    if (g) (void)hipGraphDestroy(g);
+    return GAIB_ERR_HIP;
+  }
+  gaib_exec* x = new gaib_exec();
+  x->graph = g;
+  x->exec = nullptr;
+  x->device = ctx->device;
+  x->nodes = 0;
+  (void)hipGraphGetNodes(g, nullptr, &x->nodes);
+  e = hipGraphInstantiate(&x->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_capture_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+    (void)hipGraphDestroy(g);
+    delete x;
+    return GAIB_ERR_HIP;
+  }
+  *out = x;
+  return GAIB_OK;
+}
+
+extern "C" int64_t gaib_exec_nodes(const gaib_exec* x) { return x ? (int64_t)x->nodes : 0; }
+
+extern "C" int gaib_exec_launch(gaib_ctx* ctx, gaib_exec* x) {
+  GAIB_CHECK(ctx && x, "gaib_exec_launch: NULL argument");
+  GAIB_CHECK(!ctx->capturing, "gaib_exec_launch: inside a capture");
+  GAIB_CHECK(x->device == ctx->device, "gaib_exec_launch: recorded on device %d, context on device %d", x->device, ctx->device);
+  GAIB_HIP(hipGraphLaunch(x->exec, ctx->stream));
+  return GAIB_OK;
+}
+
+extern "C" int gaib_exec_destroy(gaib_exec* x) {
+  if (!x) return GAIB_OK;
+  if (x->exec) (void)hipGraphExecDestroy(x->exec);
+  if (x->graph) (void)hipGraphDestroy(x->graph);
+  delete x;
+  return GAIB_OK;
+}
+
 extern "C" int gaib_prof_enable(gaib_ctx* ctx, int on) {
   GAIB_CHECK(ctx, "gaib_prof_enable: ctx is NULL");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_prof_enable");
   ctx->prof_on = on ? 1 : 0;
   return GAIB_OK;
 }

@@ -505,10 +505,14 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
   const int64_t tiles = tiles_m * tiles_n;
   GAIB_CHECK(tiles < (int64_t)1 << 31, "gaib_sgemm: too many tiles");
   // split K when the output has too few tiles to fill 256 CUs and K is long (weight grads)
+  // Also for the small graphs (cora: 2 708 vertices, 1 433 features): without a split the products of a layer are a
+  // handful of workgroups walking K one 32-column step after another, two barriers and a memory latency per step --
+  // 214 + 181 + 120 us of a 690 us epoch (profiles/r02/cora_kernel_stats_before_split.csv).  From K = 512 on, K is
+  // dealt out in pieces of at least two steps.
   int splits = 1;
-  if (tiles < 2 * ctx->num_cus && g.K >= 8192) {
+  if (tiles < 2 * ctx->num_cus && g.K >= 512 && ctx->sgemm_variant != 50) {
     int64_t want = cdiv64(2 * (int64_t)ctx->num_cus, tiles);
-    int64_t maxs = g.K / (8 * BK);
+    int64_t maxs = g.K >= 8192 ? g.K / (8 * BK) : g.K / (2 * BK);
     splits = (int)(want < maxs ? want : maxs);
     if (splits < 1) splits = 1;
   }

@@ -2,6 +2,10 @@
 #include "optimizer.h"
 #include "host_util.h"
 
+static bool g_powers_on_device = false;
+void adam::keep_powers_on_device(bool on) { g_powers_on_device = on; }
+bool adam::powers_on_device() { return g_powers_on_device; }
+
 void adam::update_gpu(const size_t n, const float_t* dW, float_t* W) {
   gaib_ctx* c = gpu_context::get();
   auto it = dev_state.find(W);
@@ -17,6 +21,15 @@ void adam::update_gpu(const size_t n, const float_t* dW, float_t* W) {
   assert(it->second.n == n);
   // vertex-range partitions: the gradient of a replicated weight is the sum of the ranks' partial gradients
   if (gaib_comm* cm = gpu_context::comm()) GAIB_OR_DIE(gaib_allreduce_f32(cm, const_cast<float_t*>(dW), (int64_t)n));
+  if (g_powers_on_device) {
+    if (!d_pow) {  // first step this way: the powers move to the device at their current value
+      d_pow = gaib_host::dmalloc<float>(2);
+      const float h[2] = {b1_t, b2_t};
+      GAIB_OR_DIE(gaib_memcpy_h2d(c, d_pow, h, sizeof(h)));
+    }
+    GAIB_OR_DIE(gaib_adam_step_dev(c, (int64_t)n, dW, W, it->second.m, it->second.v, alpha, b1, b2, eps, d_pow));
+    return;  // advanced on the device
+  }
   GAIB_OR_DIE(gaib_adam_step(c, (int64_t)n, dW, W, it->second.m, it->second.v, alpha, b1, b2, b1_t, b2_t, eps));
   b1_t *= b1;  // once per call: a shared optimizer advances per layer (Q6)
   b2_t *= b2;
@@ -46,6 +59,10 @@ void adam::reset() {
   }
   dev_state.clear();
   host_state.clear();
+  if (d_pow) {
+    gaib_free(c, d_pow);
+    d_pow = nullptr;
+  }
   b1_t = b1;
   b2_t = b2;
 }

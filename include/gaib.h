@@ -51,6 +51,9 @@ const char* gaib_version(void);
 int gaib_ctx_create(int device, void* stream, gaib_ctx** out);
 int gaib_ctx_destroy(gaib_ctx* ctx);
 int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream);
+/* switch the context to a (non-blocking) stream of its own, created once and destroyed with the context: for callers
+ * without a stream to lend -- the null stream cannot be recorded by gaib_capture_begin */
+int gaib_ctx_own_stream(gaib_ctx* ctx);
 int gaib_sync(gaib_ctx* ctx); /* CudaTest()'s cudaDeviceSynchronize, cutils.h:18-28 */
 /* Side stream for work that is independent of the calls that follow it (the weight-gradient GEMM
  * next to the aggregation of the input gradient: an MFMA-bound and an HBM-bound kernel overlap).
@@ -63,6 +66,23 @@ int gaib_sync(gaib_ctx* ctx); /* CudaTest()'s cudaDeviceSynchronize, cutils.h:18
 int gaib_side_begin(gaib_ctx* ctx);
 int gaib_side_end(gaib_ctx* ctx);
 int gaib_side_wait(gaib_ctx* ctx);
+/* HIP graphs: record a call sequence once, replay it with one launch.  The 2-layer, 16-column models of the
+ * reference's shipped datasets (cora / citeseer, inputs/) are launch bound -- an epoch is ~40 kernels of a few
+ * microseconds -- where the reference's GPU build pays a cudaDeviceSynchronize per op (cutils.h:18-28).
+ *   gaib_capture_begin: every call on this context is RECORDED on its stream from here (nothing runs) ...
+ *   gaib_capture_end:   ... to here; *out replays the sequence.  gaib_capture_abort drops an open capture.
+ * Inside a capture, calls that wait for the stream or allocate return GAIB_ERR_INVALID with a message (gaib_sync,
+ * gaib_memcpy_h2d/d2h, metrics with host results, a workspace or lazily built graph table that does not exist
+ * yet): run the sequence once eagerly first.  Pointers and by-value scalars are frozen in the recording; per-replay
+ * state lives in device memory (gaib_adam_step_dev, gaib_masked_*_dev, gaib_memcpy_d2h_async).  The context must
+ * own a real stream (not the null stream), without a side section or kernel timing switched on. */
+typedef struct gaib_exec gaib_exec;
+int gaib_capture_begin(gaib_ctx* ctx);
+int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out);
+int gaib_capture_abort(gaib_ctx* ctx);
+int gaib_exec_launch(gaib_ctx* ctx, gaib_exec* exec);
+int64_t gaib_exec_nodes(const gaib_exec* exec); /* graph nodes recorded (kernels, memsets, copies) */
+int gaib_exec_destroy(gaib_exec* exec);
 
 /* ---- memory: float/uint/uint8_malloc_device, *_free_device, copy_*_device, copy_float_host,
  * init_const_gpu  (include/utils/math_functions.hh:161-173, math_functions.cu:12-14;
@@ -72,6 +92,10 @@ int gaib_free(gaib_ctx* ctx, void* d_ptr);
 int gaib_memcpy_h2d(gaib_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int gaib_memcpy_d2h(gaib_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* syncs */
 int gaib_memcpy_d2d(gaib_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* pinned host memory and a stream-ordered read-back into it (valid after the next gaib_sync) */
+int gaib_host_alloc(gaib_ctx* ctx, size_t bytes, void** h_ptr);
+int gaib_host_free(gaib_ctx* ctx, void* h_ptr);
+int gaib_memcpy_d2h_async(gaib_ctx* ctx, void* h_pinned_dst, const void* d_src, size_t bytes);
 int gaib_fill_f32(gaib_ctx* ctx, int64_t n, float value, float* d_x);
 /* x <- alpha * x  (scale, math_functions.cpp:336-356 / scal_gpu; the partitioned trainer rescales the loss gradient
  * from 1/(local range) to 1/(global range), softmax_loss_layer.cpp:31) */
@@ -317,6 +341,17 @@ int gaib_masked_avg_loss(gaib_ctx* ctx, int64_t begin, int64_t end, const uint8_
 int gaib_masked_accuracy_single(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
                                 const uint8_t* d_masks, const float* d_preds,
                                 const uint8_t* d_labels, float* h_result); /* syncs */
+/* The same reductions with the result left in DEVICE memory (d_result[0]; d_counts[3] = tp, fp, fn): no host wait,
+ * so they can be part of a recorded sequence (gaib_capture_begin).  Block partials are added in the order of the
+ * host forms: identical bits. */
+int gaib_masked_avg_loss_dev(gaib_ctx* ctx, int64_t begin, int64_t end, const uint8_t* d_masks,
+                             const float* d_loss, float* d_result);
+int gaib_masked_accuracy_single_dev(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                                    const uint8_t* d_masks, const float* d_preds,
+                                    const uint8_t* d_labels, float* d_result);
+int gaib_masked_f1_counts_dev(gaib_ctx* ctx, int64_t begin, int64_t end, int num_cls,
+                              const uint8_t* d_masks, const float* d_preds, const uint8_t* d_labels,
+                              uint64_t* d_counts);
 
 /* ---- l2norm / d_l2norm (math_functions.cu:158-196) ---- */
 int gaib_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_in, float* d_out);
@@ -327,6 +362,11 @@ int gaib_d_l2norm(gaib_ctx* ctx, int64_t n, int dim, const float* d_feat_in,
  * The caller owns m/v state and the beta powers (optimizer.h:99-116). ---- */
 int gaib_adam_step(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, float* d_m,
                    float* d_v, float alpha, float b1, float b2, float b1_t, float b2_t, float eps);
+/* The same step with the beta powers in device memory: d_pow[0] = b1^t, d_pow[1] = b2^t are read by the step and
+ * then advanced ON THE DEVICE (the host's `b1_t *= b1; b2_t *= b2`, optimizer.cpp:34-35 -- the same float products),
+ * so a recorded step replays correctly.  Initialise d_pow to {b1, b2}. */
+int gaib_adam_step_dev(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, float* d_m, float* d_v,
+                       float alpha, float b1, float b2, float eps, float* d_pow);
 
 /* ---- multi-GPU helpers (no reference counterpart) --------------------------
  * pack rows for the halo exchange: d_out[k,:] = d_in[d_idx[k],:] */

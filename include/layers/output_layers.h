@@ -64,6 +64,7 @@ class loss_layer {
   virtual acc_t get_prediction_loss(size_t begin, size_t end, size_t count, mask_t* masks) { return 0; }
   float* get_feat_in() { return feat_in; }    // logits
   float* get_feat_out() { return feat_out; }  // probabilities
+  float* loss_buffer() { return d_losses; }   // per-vertex losses of the last forward (device)
   void set_labels_ptr(label_t* ptr) { labels = ptr; }
   void set_netphase(net_phase phase) { phase_ = phase; }
   void update_dim_size(int sz);

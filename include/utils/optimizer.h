@@ -26,9 +26,15 @@ struct adam : public optimizer {
   void update_gpu(const size_t n, const float_t* dW, float_t* W) override;
   void reset() override;
   float_t alpha, b1, b2, b1_t, b2_t;
+  // Beta powers in DEVICE memory (gaib_adam_step_dev), advanced there: what a recorded epoch (HIP graph) needs, since
+  // by-value kernel arguments are frozen in the recording.  A one-way switch for all instances, made before the run's
+  // first update; b1_t / b2_t above then stay at the value they had when an instance first stepped this way.
+  static void keep_powers_on_device(bool on);
+  static bool powers_on_device();
 
  private:
   float_t eps;
+  float* d_pow = nullptr;  // {b1^t, b2^t} on the device
   struct state { float* m; float* v; size_t n; };
   std::unordered_map<const float_t*, state> dev_state;  // keyed by the weight's device address
   std::unordered_map<const vec_t*, std::pair<vec_t, vec_t>> host_state;

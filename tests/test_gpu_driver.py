@@ -215,3 +215,33 @@ def test_driver_rank_failure_exits_nonzero(tmp_path):
                GAIB_COMM_ID_FILE=str(tmp_path / "comm_id"), GAIB_COMM_TIMEOUT_S="3")
     r = subprocess.run([str(exe), "cora", "2", "1", "softmax"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "timed out" in r.stderr, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("arch,loss", [("gcn", "softmax"), ("sage", "softmax"), ("gat", "softmax"), ("gcn", "sigmoid")])
+def test_driver_recorded_epochs_equal_call_by_call(tmp_path, arch, loss):
+    """GAIB_EPOCH_GRAPH: the epoch as two HIP-graph launches (forward + loss + metrics; backward + optimizer steps, the
+    Adam beta powers advanced on the device) prints the same log as the epoch enqueued call by call"""
+    root, x, labels, splits = make_dataset(tmp_path)
+    exe = ROOT / "bin" / f"gpu_train_{arch}"
+    cmd = [str(exe), "cora", "14", "2", loss, "16", "0", "0", "0.01", "2", "0", "5", "0"]
+    out = {}
+    for mode in ("0", "1"):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DATASET_PATH=root, GAIB_EPOCH_GRAPH=mode))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert ("epochs recorded as HIP graphs" in r.stderr) == (mode == "1"), r.stderr[-1000:]
+        out[mode] = (re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", r.stdout),
+                     re.findall(r"val_acc ([0-9.]+)", r.stdout), re.findall(r"Test accuracy: ([0-9.]+)", r.stdout))
+    assert len(out["0"][0]) == 14 and len(out["0"][1]) == 2 and len(out["0"][2]) == 1
+    assert out["0"] == out["1"]
+    assert float(out["1"][0][-1][0]) < float(out["1"][0][0][0])  # it learns
+
+
+def test_driver_recording_is_skipped_where_it_cannot_apply(tmp_path):
+    """dropout draws its mask seed per call (a by-value argument): such a run stays call by call and says so"""
+    root, *_ = make_dataset(tmp_path)
+    cmd = [str(ROOT / "bin" / "gpu_train_gcn"), "cora", "4", "2", "softmax", "16", "0", "0.3", "0.01", "2", "0", "50", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DATASET_PATH=root, GAIB_EPOCH_GRAPH="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GAIB_EPOCH_GRAPH=1 ignored" in r.stderr and "recorded as HIP graphs" not in r.stderr

@@ -1180,3 +1180,112 @@ def test_probe_stream_copy(ctx):
             capi.probe_peer_copy(0, 1, 1 << 20, 2)
     else:
         assert capi.probe_peer_copy(0, 1, 1 << 26, 5) > 10.0
+
+
+# ---- HIP graphs: a recorded call sequence (gaib_capture_*) ------------------------------------------------------------
+@pytest.fixture()
+def sctx():
+    """a context on a stream of its own (the null stream cannot be recorded)"""
+    c = capi.Context(0)
+    c.own_stream()
+    yield c
+    c.close()
+
+
+def test_capture_replay_equals_call_by_call(sctx):
+    """GEMM + relu + aggregation + Adam with device-resident beta powers, recorded once and replayed: every replay
+    leaves the bits the same calls leave when made one by one"""
+    rp, ci = random_graph(3000, 12, seed=3)
+    g = sctx.graph(rp, ci.view(np.int32)).add_selfloop()
+    n, d = g.nv, 64
+    torch.manual_seed(1)
+    x = torch.randn(n, d, device="cuda")
+    W0 = torch.randn(d, d, device="cuda") * 0.1
+    torch.cuda.synchronize()
+
+    def fresh():
+        return dict(W=W0.clone(), m=torch.zeros(d, d, device="cuda"), v=torch.zeros(d, d, device="cuda"),
+                    pw=torch.tensor([0.9, 0.999], device="cuda"), y=torch.empty(n, d, device="cuda"),
+                    a=torch.empty(n, d, device="cuda"), dW=torch.empty(d, d, device="cuda"))
+
+    def seq(c, b):
+        c.sgemm(x, b["W"], b["y"], relu=True)
+        c.spmm(g, capi.W_GCN, b["y"], b["a"])
+        c.sgemm(x, b["a"], b["dW"], transA=True)
+        c.adam_step_dev(b["dW"], b["W"], b["m"], b["v"], 0.01, b["pw"])
+
+    eager, rec = fresh(), fresh()
+    torch.cuda.synchronize()
+    seq(sctx, rec)  # once call by call: workspace and the graph's lazily built tables exist afterwards
+    sctx.sync()
+    for k in ("W", "m", "v", "pw"):
+        rec[k].copy_(fresh()[k])
+    torch.cuda.synchronize()
+    sctx.capture_begin()
+    seq(sctx, rec)
+    ex = sctx.capture_end()
+    assert ex.nodes >= 4
+    for _ in range(4):
+        seq(sctx, eager)
+        ex.launch()
+    sctx.sync()
+    for k in ("W", "m", "v", "pw", "a", "y"):
+        assert torch.equal(eager[k], rec[k]), k
+    assert not torch.equal(eager["W"], W0)
+    ex.close()
+
+
+def test_capture_refuses_calls_that_wait(sctx):
+    x = torch.zeros(1 << 20, device="cuda")
+    torch.cuda.synchronize()
+    sctx.capture_begin()
+    with pytest.raises(capi.GaibError, match="gaib_capture_begin/end"):
+        sctx.sync()
+    with pytest.raises(capi.GaibError, match="gaib_capture_begin/end"):
+        sctx.masked_avg_loss(x, 0, 1000)
+    with pytest.raises(capi.GaibError, match="already open"):
+        sctx.capture_begin()
+    sctx.capture_abort()
+    sctx.sync()  # the stream is usable again
+    assert sctx.masked_avg_loss(x, 0, 1000) == 0.0
+    # a context on the null stream says why it cannot record
+    c0 = capi.Context(0, stream=0)
+    with pytest.raises(capi.GaibError, match="null stream"):
+        c0.capture_begin()
+    c0.close()
+
+
+@pytest.mark.parametrize("n,begin,end", [(5000, 0, 5000), (300000, 1234, 290001), (1000, 10, 10)])
+def test_metrics_left_on_device_equal_host_forms(ctx, n, begin, end):
+    rng = np.random.default_rng(n)
+    C_ = 7
+    logits = dev(rng.standard_normal((n, C_)).astype(np.float32))
+    labels = dev(rng.integers(0, C_, n).astype(np.uint8))
+    masks = dev((rng.random(n) < 0.7).astype(np.uint8))
+    loss = dev(rng.random(n).astype(np.float32))
+    res = torch.full((2,), -1.0, device="cuda")
+    for mk in (None, masks):
+        ctx.masked_avg_loss_dev(loss, begin, end, res[0:], masks=mk)
+        ctx.masked_accuracy_single_dev(logits, labels, begin, end, res[1:], masks=mk)
+        want = (ctx.masked_avg_loss(loss, begin, end, masks=mk), ctx.masked_accuracy_single(logits, labels, begin, end, masks=mk))
+        got = res.cpu().numpy()
+        assert np.float32(want[0]).view(np.uint32) == got[0].view(np.uint32)
+        assert np.float32(want[1]).view(np.uint32) == got[1].view(np.uint32)
+
+
+def test_adam_device_powers_equal_by_value_powers(ctx):
+    n = 100 * 47
+    W = torch.from_numpy(feat(1, n, 1).ravel()).cuda()
+    a = dict(W=W.clone(), m=torch.zeros(n, device="cuda"), v=torch.zeros(n, device="cuda"))
+    b = dict(W=W.clone(), m=torch.zeros(n, device="cuda"), v=torch.zeros(n, device="cuda"))
+    pw = torch.tensor([0.9, 0.999], device="cuda")
+    b1_t, b2_t = np.float32(0.9), np.float32(0.999)
+    for step in range(6):
+        dW = dev(feat(1, n, 10 + step).ravel())
+        ctx.adam_step(dW, a["W"], a["m"], a["v"], 0.01, float(b1_t), float(b2_t))
+        ctx.adam_step_dev(dW, b["W"], b["m"], b["v"], 0.01, pw)
+        b1_t = np.float32(b1_t * np.float32(0.9))
+        b2_t = np.float32(b2_t * np.float32(0.999))
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert np.array_equal(pw.cpu().numpy(), np.array([b1_t, b2_t], np.float32))
