@@ -540,11 +540,24 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         n_dom, ms_dom = prof[dom]
         avg_ms = ms_dom / n_dom
         ach = alg[dom] / (avg_ms * 1e-3) / 1e9
+        # `traffic`: like the GCN line, from the committed PMC summary of this command (separate rocprofv3 passes)
+        traffic = traffic_src = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists() and args.scale == 1.0:
+            try:
+                tj = json.loads(tf.read_text()).get("gat_reddit", {})
+                traffic = tj.get(f"{dom}_bytes_per_launch")
+                if traffic:
+                    traffic_src = f"profiles/hbm_traffic.json gat_reddit (rocprofv3 --pmc passes at commit {tj.get('commit', '?')})"
+            except Exception:
+                traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "peak_measured": peak_measured,
                 "frac_of_measured": ach / peak_measured if peak_measured else None,
                 # MI355X_MICROARCH.md: a 38 MB table gathered uniformly out of the Infinity Cache: 8.6 TB/s
-                "peak_cache_resident_gather": 8600.0, "traffic": None,
+                "peak_cache_resident_gather": 8600.0, "traffic": traffic, "traffic_source": traffic_src,
+                # L2 -> fabric bytes per launch over the algorithmic bytes: what the 4 MB L2s filter out of the gathers
+                "traffic_over_alg": (traffic / alg[dom]) if traffic else None,
                 "alg_bytes_per_launch": alg[dom], "avg_launch_ms": avg_ms, "launches": n_dom}
     result = {
         "metric": "GAT-layer fwd+bwd aggregated edges/sec", "value": 2 * ne * args.steps / elapsed, "unit": "edges/s",

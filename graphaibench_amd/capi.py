@@ -33,6 +33,7 @@ SIGNATURES = {
     "gaib_capture_abort": (_i, [_vp]),
     "gaib_exec_launch": (_i, [_vp, _vp]),
     "gaib_exec_nodes": (_i64, [_vp]),
+    "gaib_exec_elapsed_ms": (_i, [_vp, _vp]),
     "gaib_exec_destroy": (_i, [_vp]),
     "gaib_host_alloc": (_i, [_vp, C.c_size_t, _pp]),
     "gaib_host_free": (_i, [_vp, _vp]),
@@ -275,6 +276,12 @@ class Exec:
 
     def launch(self):
         _check(self.ctx.lib.gaib_exec_launch(self.ctx.h, self.h), "gaib_exec_launch")
+
+    def elapsed_ms(self) -> float:
+        """device time of the last launch (call after ctx.sync())"""
+        v = C.c_float()
+        _check(self.ctx.lib.gaib_exec_elapsed_ms(self.h, C.byref(v)), "gaib_exec_elapsed_ms")
+        return v.value
 
     def close(self):
         if self.h:

@@ -271,6 +271,8 @@ struct gaib_exec {
   hipGraphExec_t exec;
   int device;
   size_t nodes;
+  hipEvent_t ev0, ev1;  // around the last launch (gaib_exec_elapsed_ms)
+  int launched;
 };
 
 extern "C" int gaib_capture_begin(gaib_ctx* ctx) {
@@ -315,6 +317,8 @@ extern "C" int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out) {
   x->exec = nullptr;
   x->device = ctx->device;
   x->nodes = 0;
+  x->ev0 = x->ev1 = nullptr;
+  x->launched = 0;
   (void)hipGraphGetNodes(g, nullptr, &x->nodes);
   e = hipGraphInstantiate(&x->exec, g, nullptr, nullptr, 0);
   if (e != hipSuccess) {
@@ -333,12 +337,29 @@ extern "C" int gaib_exec_launch(gaib_ctx* ctx, gaib_exec* x) {
   GAIB_CHECK(ctx && x, "gaib_exec_launch: NULL argument");
   GAIB_CHECK(!ctx->capturing, "gaib_exec_launch: inside a capture");
   GAIB_CHECK(x->device == ctx->device, "gaib_exec_launch: recorded on device %d, context on device %d", x->device, ctx->device);
+  if (!x->ev0) {
+    GAIB_HIP(hipEventCreate(&x->ev0));
+    GAIB_HIP(hipEventCreate(&x->ev1));
+  }
+  GAIB_HIP(hipEventRecord(x->ev0, ctx->stream));
   GAIB_HIP(hipGraphLaunch(x->exec, ctx->stream));
+  GAIB_HIP(hipEventRecord(x->ev1, ctx->stream));
+  x->launched = 1;
+  return GAIB_OK;
+}
+
+// device time of the last launch (after the stream reached its end: gaib_sync)
+extern "C" int gaib_exec_elapsed_ms(gaib_exec* x, float* h_ms) {
+  GAIB_CHECK(x && h_ms, "gaib_exec_elapsed_ms: NULL argument");
+  GAIB_CHECK(x->launched, "gaib_exec_elapsed_ms: never launched");
+  GAIB_HIP(hipEventElapsedTime(h_ms, x->ev0, x->ev1));
   return GAIB_OK;
 }
 
 extern "C" int gaib_exec_destroy(gaib_exec* x) {
   if (!x) return GAIB_OK;
+  if (x->ev0) (void)hipEventDestroy(x->ev0);
+  if (x->ev1) (void)hipEventDestroy(x->ev1);
   if (x->exec) (void)hipGraphExecDestroy(x->exec);
   if (x->graph) (void)hipGraphDestroy(x->graph);
   delete x;

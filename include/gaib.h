@@ -81,6 +81,7 @@ int gaib_capture_begin(gaib_ctx* ctx);
 int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out);
 int gaib_capture_abort(gaib_ctx* ctx);
 int gaib_exec_launch(gaib_ctx* ctx, gaib_exec* exec);
+int gaib_exec_elapsed_ms(gaib_exec* exec, float* h_ms); /* device time of the last launch; after gaib_sync */
 int64_t gaib_exec_nodes(const gaib_exec* exec); /* graph nodes recorded (kernels, memsets, copies) */
 int gaib_exec_destroy(gaib_exec* exec);
 

@@ -39,6 +39,20 @@ for name, frag in (("spmm_gemm_kernel", "spmm_gemm_kernel"), ("spmm_heavy_kernel
     f, w = find(pmc, "FETCH_SIZE", frag), find(pmc, "WRITE_SIZE", frag)
     out[name] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w}
     out[f"{name}_bytes_per_launch"] = f * 1024 * 2.0 + w * 1024
+# the GAT bench line (bench.py --workload gat-reddit): its one-sweep kernels.  The 64-B-per-lane-group gathers of 256-B
+# rows use the same x2 correction (the guide's rule for wide reads; not separately calibrated)
+gp = src / "gat_pmc_summary.json"
+if gp.exists():
+    gat = json.loads(gp.read_text())
+    rec = {"workload": "bench.py --workload gat-reddit: reddit-shaped graph, 8-head GAT layer 64->64 fwd+bwd", "commit": commit}
+    for key, frag in (("gat_fwd_fused", "gat_fwd_fused_chunk_kernel"), ("gat_bwd_fused", "gat_bwd_fused_chunk_kernel")):
+        try:
+            f, w = find(gat, "FETCH_SIZE", frag), find(gat, "WRITE_SIZE", frag)
+        except SystemExit:
+            continue
+        rec[key] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w}
+        rec[f"{key}_bytes_per_launch"] = f * 1024 * 2.0 + w * 1024
+    out["gat_reddit"] = rec
 out["note"] = ("FETCH_SIZE counts L2 -> fabric requests; Infinity-Cache hits are included (MI355X_MICROARCH.md), so "
                "these are upper bounds on the HBM bytes.")
 Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")

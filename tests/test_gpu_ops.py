@@ -1229,6 +1229,7 @@ def test_capture_replay_equals_call_by_call(sctx):
         seq(sctx, eager)
         ex.launch()
     sctx.sync()
+    assert 0.0 < ex.elapsed_ms() < 50.0
     for k in ("W", "m", "v", "pw", "a", "y"):
         assert torch.equal(eager[k], rec[k]), k
     assert not torch.equal(eager["W"], W0)
