@@ -759,7 +759,16 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // 256 -> 256 layer step: 17.9 vs 19.5 ms for the six GEMMs (scripts/ab_gemm_in_layer.py); at K = 128 a tile is too
   // short for this form (1.00 vs 0.90 ms).
   const bool stream_shape = !transA && K % 8 == 0 && K <= 256 && avec;
-  if (stream_shape && ctx->sgemm_variant != 40 && (ctx->sgemm_variant == 41 || (ctx->sgemm_variant == 0 && M >= 65536 && K > 128)))
+  // Round 2, measured again after the whole-tile C += epilogue (scripts/gemm_variants.py, 2.45 M rows): K = 128 NN 0.78-0.80
+  // vs 0.89 ms for the LDS-tiled kernel (torch.mm / rocBLAS 0.98), K = 256 NN 2.63-2.66 vs 3.05-3.11 (rocBLAS 2.51-2.53),
+  // so the streaming form is the default from K = 128 on (sgemm_variant 44: only above 128, the round-1 rule).
+  // Tried on top of it and dropped: the next tile's first operand requested before the epilogue (no change: 2.63 vs
+  // 2.65); 64-column operand groups in two register sets with the prefetch running on across tiles and the B
+  // fragments double-buffered out of LDS (184 VGPRs, every wait in the ISA where it should be -- and 2.82 ms vs 2.68).
+  const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : 128;
+  const int sv = ctx->sgemm_variant;
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 30 || sv == 31 || sv == 33;  // (30 / 31 / 33 concern the weight gradient only)
+  if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
   if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);

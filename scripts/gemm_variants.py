@@ -37,12 +37,17 @@ def main():
             t_nn = timeit(lambda: ctx.sgemm(x, W, y))
             e_nn = ((y[:4096].double() - ref_nn).norm() / ref_nn.norm()).item()
             t_nt = timeit(lambda: ctx.sgemm(x, W, y, False, True))
+            e_nt = ((y[:4096].double() - x[:4096].double() @ W.double().T).norm() / ref_nn.norm()).item()
+            t_acc = timeit(lambda: ctx.sgemm(x, W, y, accum=True, relu=True))  # the C += / relu epilogue
             t_tn = timeit(lambda: ctx.sgemm(x, g, dW, True, False))
             e_tn = ((dW.double() - ref_tn).norm() / ref_tn.norm()).item()
             fl = 2.0 * nv * d * d
-            print(f"d={d} variant={variant}: NN {t_nn:.3f} ms ({fl/t_nn/1e9:.0f} TF) err {e_nn:.1e} | NT {t_nt:.3f} ms | "
+            print(f"d={d} variant={variant}: NN {t_nn:.3f} ms ({fl/t_nn/1e9:.0f} TF) err {e_nn:.1e} | NT {t_nt:.3f} ms err {e_nt:.1e} | NN+= {t_acc:.3f} | "
                   f"TN {t_tn:.3f} ms ({fl/t_tn/1e9:.0f} TF) err {e_tn:.1e}", flush=True)
         ctx.set_option("sgemm_variant", 0)
+        t_mm = timeit(lambda: torch.mm(x, W, out=y))
+        t_mt = timeit(lambda: torch.mm(x, W.T, out=y))
+        print(f"d={d} torch.mm (rocBLAS / hipBLASLt): NN {t_mm:.3f} ms | NT {t_mt:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,8 @@ def main():
     run_layer(ctx, L.GCN, "GCN 128->128", "ogbn-products", 128, 128, True, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 100->128 (layer 0 shape, level 1)", "ogbn-products", 100, 128, True, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 128->47", "ogbn-products", 128, 47, True, args.steps, args.scale)
+    run_layer(ctx, L.SAGE, "SAGE 128->47", "ogbn-products", 128, 47, False, args.steps, args.scale)
+    run_layer(ctx, L.SAGE, "SAGE 100->128 (layer 0 shape, level 1)", "ogbn-products", 100, 128, False, args.steps, args.scale)
     run_layer(ctx, L.GCN, "GCN 64->64 reddit-shaped", "reddit", 64, 64, True, args.steps, args.scale)
     run_layer(ctx, L.SAGE, "SAGE 64->64 reddit-shaped", "reddit", 64, 64, False, args.steps, args.scale)
     run_layer(ctx, L.GAT, "GAT 64->64", "reddit", 64, 64, True, args.steps, args.scale)
