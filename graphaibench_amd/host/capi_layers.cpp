@@ -96,6 +96,10 @@ void gaibl_layer_set_feat_in(void* layer, float* p) {
   LayerBox* b = static_cast<LayerBox*>(layer);
   DISPATCH(b, set_feat_in(p));
 }
+void gaibl_layer_set_input_constant(void* layer, int on) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  DISPATCH(b, set_input_constant(on != 0));
+}
 void gaibl_layer_set_heads(void* layer, int heads) {
   LayerBox* b = static_cast<LayerBox*>(layer);
   if (b->kind != GAIBL_GAT) {

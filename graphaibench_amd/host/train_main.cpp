@@ -353,6 +353,11 @@ struct Trainer {
     if (use_l2norm) l2 = new l2norm_layer(nv, dim_hid);
     if (use_dense) dense = new dense_layer(nv, dim_hid, num_cls, lrate);
     layers[0].set_feat_in(d_features);
+    // a full-batch run feeds layer 0 the same features over the same graph every epoch: where that layer aggregates
+    // first, its aggregated input is computed by the first forward and kept (GAIB_CACHE_INPUT_AGG=0: re-aggregated
+    // every epoch, as the reference does).  Not with sampling (the subgraph's features are copied into one buffer).
+    const char* ca = getenv("GAIB_CACHE_INPUT_AGG");
+    if (subg_size == 0 && feat_drop == 0.f && !(ca && atoi(ca) == 0)) layers[0].set_input_constant(true);
     if (is_sigmoid) loss = new sigmoid_loss_layer(nv, num_cls, d_labels);
     else loss = new softmax_loss_layer(nv, num_cls, d_labels);
   }

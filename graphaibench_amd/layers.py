@@ -34,6 +34,7 @@ SIGNATURES = {
     "gaibl_layer_set_feat_in": (None, [_vp, _vp]),
     "gaibl_layer_set_phase": (None, [_vp, _i]),
     "gaibl_layer_set_heads": (None, [_vp, _i]),
+    "gaibl_layer_set_input_constant": (None, [_vp, _i]),
     "gaibl_layer_ptr": (_vp, [_vp, _i]),
     "gaibl_sample_subgraph": (C.c_uint32, [C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint,
                                            C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -166,6 +167,11 @@ class Layer:
 
     def set_heads(self, heads: int):
         self.lib.gaibl_layer_set_heads(self.h, heads)
+
+    def set_input_constant(self, on: bool = True):
+        """the caller promises that feat_in's contents and the graph stay the same between forward calls: the layer
+        keeps its aggregated input (gconv_state::set_input_constant)"""
+        self.lib.gaibl_layer_set_input_constant(self.h, int(on))
 
     def set_feat_in(self, t):
         self._feat_keepalive = t

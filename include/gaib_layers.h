@@ -70,6 +70,7 @@ void gaibl_layer_update_weight(void* layer, void* optimizer);
 void gaibl_layer_set_feat_in(void* layer, float* d_ptr);
 void gaibl_layer_set_phase(void* layer, int phase); /* 0 TRAIN 1 TEST 2 VAL */
 void gaibl_layer_set_heads(void* layer, int heads); /* GAT only: GAT_Aggregator::set_num_heads */
+void gaibl_layer_set_input_constant(void* layer, int on); /* gconv_state::set_input_constant (layer 0, full batch) */
 float* gaibl_layer_ptr(void* layer, int which);
 
 /* host-only test hook for the GraphSAINT sampler (include/gnn/sampler.h): samples up to n vertices

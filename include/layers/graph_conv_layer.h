@@ -20,8 +20,8 @@ class gconv_state {
   // ---- the reference's accessors -------------------------------------------------------------------------------
   float* get_feat_in() { return feat_in; }
   float* get_grad_in() { return grad_in; }
-  void set_feat_in(float* ptr) { feat_in = ptr; }
-  void set_graph_ptr(Graph* ptr) { graph = ptr; }
+  void set_feat_in(float* ptr) { feat_in = ptr; agg_valid_ = false; }
+  void set_graph_ptr(Graph* ptr) { graph = ptr; agg_valid_ = false; }
   void set_netphase(net_phase phase) { phase_ = phase; }
   void update_dim_size(size_t sz);  // number of vertices (subgraph sampling); buffers grow on demand
   void print_layer_info() {
@@ -35,6 +35,15 @@ class gconv_state {
   float* weight_self_grad_ptr() { return d_W_self_grad; }
   int get_dim_in() const { return dim_in; }
   int get_dim_out() const { return dim_out; }
+  // ---- extension: a constant input -----------------------------------------------------------------------------
+  // The driver promises that the CONTENTS of feat_in and the graph do not change between forward calls: layer 0 of a
+  // full-batch run without feature dropout (the reference re-aggregates the same features every epoch,
+  // gcn_layer.cpp:22-25, sage_layer.cpp:17-21).  Where the layer aggregates first (dim_in <= dim_out) the aggregated
+  // input A.X is then the same every epoch; the first forward computes it -- it is kept anyway, for the weight
+  // gradient -- and later forwards run only the dense product(s) on it.  set_feat_in, set_graph_ptr, update_dim_size
+  // and this call drop the kept aggregate.  Off unless asked for.
+  void set_input_constant(bool on) { input_constant_ = on; agg_valid_ = false; }
+  bool input_constant() const { return input_constant_; }
 
  protected:
   gconv_state(int id, int nv, int din, int dout, Graph* g, bool act, bool concat, float lr, float feat_drop,
@@ -47,6 +56,7 @@ class gconv_state {
   net_phase phase_;
   size_t capacity_;        // rows the HBM buffers were sized for
   uint64_t dropout_calls;  // counter feeding the dropout RNG
+  bool input_constant_ = false, agg_valid_ = false;  // set_input_constant: d_in_temp1 holds A.feat_in of the current graph
   // HBM buffers
   float* feat_in;     // [nv x dim_in]   level 0: the input features, set by the model
   float* grad_in;     // [nv x dim_out]

@@ -20,6 +20,10 @@ run() {  # name, binary, args...
 }
 echo "=== config 3 at hidden 128: gpu_train_sage ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0"
 run sage128 $ROOT/bin/gpu_train_sage ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0
+echo "=== the same with GAIB_CACHE_INPUT_AGG=0 (layer 0 re-aggregates its constant input every epoch, as the reference does)"
+GAIB_CACHE_INPUT_AGG=0 run sage128_nocache $ROOT/bin/gpu_train_sage ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0
+echo "=== GCN hidden 128"
+run gcn128 $ROOT/bin/gpu_train_gcn ogbn-products 10 32 softmax 128 0 0 0.01 3 0 50 0
 echo "=== config 3 as scripted (hidden 256): gpu_train_sage ogbn-products 10 32 softmax 256 0 0 0.01 3 0 50 0"
 run sage256 $ROOT/bin/gpu_train_sage ogbn-products 10 32 softmax 256 0 0 0.01 3 0 50 0
 echo "=== config 4: GAIB_GAT_HEADS=8 gpu_train_gat reddit 10 32 softmax 64 0 0 0.01 2 0 50 0"

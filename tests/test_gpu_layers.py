@@ -234,3 +234,39 @@ def test_gat_layer_8_heads(gat_bwd_mode):
     assert_close(ld.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), orc.matmul(x, T, True, False))
     assert_close(ld.tensor(L.ALPHA_LGRAD, (dout,)).cpu().numpy(), lg)
     assert_close(ld.tensor(L.ALPHA_RGRAD, (dout,)).cpu().numpy(), rg)
+
+
+@pytest.mark.parametrize("kind,din,dout", [("gcn", 100, 128), ("sage", 100, 128), ("sage", 64, 64), ("gcn", 128, 47)])
+def test_constant_input_keeps_the_aggregate(kind, din, dout):
+    """set_input_constant (layer 0 of a full-batch run): the first forward aggregates, later ones run only the dense
+    product(s) on the kept A.X -- same outputs and gradients as the layer that re-aggregates every time, also after a
+    weight update, and set_feat_in drops the kept aggregate.  (128 -> 47 multiplies first: nothing to keep, flag inert.)"""
+    rp, ci = random_graph(3000, 24, seed=11, power_law=True)
+    sl = kind == "gcn"
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=sl)
+    n = 3000
+    K = L.GCN if kind == "gcn" else L.SAGE
+    a, b = L.Layer(K, 0, n, din, dout, g_d, True), L.Layer(K, 0, n, din, dout, g_d, True)
+    b.set_input_constant(True)
+    x = dev(feat(n, din, 3))
+    a.set_feat_in(x)
+    b.set_feat_in(x)
+    oa, ob = torch.empty(n, dout, device="cuda"), torch.empty(n, dout, device="cuda")
+    opt_a, opt_b = L.adam(0.01), L.adam(0.01)
+    for step in range(3):
+        a.forward(oa)
+        b.forward(ob)
+        assert_close(ob.cpu().numpy(), oa.cpu().numpy())
+        gin = dev(feat(n, dout, 20 + step))
+        for l, o in ((a, oa), (b, ob)):
+            l.write(L.GRAD_IN, gin)
+            l.backward(o, None)
+        assert_close(b.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), a.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy())
+        a.update_weight(opt_a)
+        b.update_weight(opt_b)
+    x2 = dev(feat(n, din, 4))  # another input: set_feat_in must make the layer aggregate again
+    a.set_feat_in(x2)
+    b.set_feat_in(x2)
+    a.forward(oa)
+    b.forward(ob)
+    assert_close(ob.cpu().numpy(), oa.cpu().numpy())
