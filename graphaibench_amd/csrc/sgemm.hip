@@ -612,14 +612,16 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
   const int li = lane & 31, lh = lane >> 5;
   const int64_t n0 = (int64_t)blockIdx.y * (32 * NT);
   const int K = (int)g.K;
-  // stage the slab: Bs[k][n] = op(B)[k][n0 + n], zero past N
-  for (int t = threadIdx.x; t < K * 32 * NT; t += NNP_WAVES * 64) {
+  const int Kfull = K & ~7;        // whole 8-column steps; K % 8 == 4 (the 100 input features of the products shape)
+  const int Kpad = (K + 7) & ~7;   // leaves a half step: its upper four B rows are zero and lane half 1 feeds zeros
+  // stage the slab: Bs[k][n] = op(B)[k][n0 + n], zero past N and past K
+  for (int t = threadIdx.x; t < Kpad * 32 * NT; t += NNP_WAVES * 64) {
     int k, n;
-    if constexpr (BT) { n = t / K; k = t - n * K; }  // coalesced along k of B[n][:]
+    if constexpr (BT) { n = t / Kpad; k = t - n * Kpad; }  // coalesced along k of B[n][:]
     else { k = t / (32 * NT); n = t - k * (32 * NT); }
     const int64_t nn = n0 + n;
     float v = 0.f;
-    if (nn < g.N) v = BT ? g.B[nn * g.K + k] : g.B[(int64_t)k * g.N + nn];
+    if (nn < g.N && k < K) v = BT ? g.B[nn * g.K + k] : g.B[(int64_t)k * g.N + nn];
     nnp_lds[k * NNP_LDB + n] = v;
   }
   __syncthreads();
@@ -638,10 +640,14 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
     // two operand sets: the load of step k0 + 8 is in flight while step k0 runs on the matrix cores.  (Measured at
     // 2.45 M x 256 x 256: this form 2.82 ms; 16 waves + two steps ahead 2.97 ms; 32-wide K blocks with whole-line
     // loads 2.94 ms; the LDS-tiled kernel 3.0-3.1 ms in every tiling; rocBLAS 2.63 ms.)
-    f4 a_cur = *reinterpret_cast<const f4*>(arow);
-    for (int k0 = 0; k0 < K; k0 += 8) {
+    // (the half step's operand: both lane halves read the row's last four columns -- inside the row -- and half 1 is
+    // zeroed before use)
+    const float* atail = g.A + row * g.K + Kfull;
+    f4 a_cur = *reinterpret_cast<const f4*>(Kfull ? arow : atail);
+    for (int k0 = 0; k0 < Kfull; k0 += 8) {
       f4 a_nxt = a_cur;
-      if (k0 + 8 < K) a_nxt = *reinterpret_cast<const f4*>(arow + k0 + 8);
+      if (k0 + 8 < Kfull) a_nxt = *reinterpret_cast<const f4*>(arow + k0 + 8);
+      else if (Kfull < K) a_nxt = *reinterpret_cast<const f4*>(atail);
       const float* bk = bcol + (k0 + 4 * lh) * NNP_LDB;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -650,6 +656,16 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bk[s * NNP_LDB + 32 * b], acc[b], 0, 0, 0);
       }
       a_cur = a_nxt;
+    }
+    if (Kfull < K) {
+      const float* bk = bcol + (Kfull + 4 * lh) * NNP_LDB;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = lh ? 0.f : a_cur[s];
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bk[s * NNP_LDB + 32 * b], acc[b], 0, 0, 0);
+      }
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool full_rows = m0 + 32 <= g.M;
@@ -692,7 +708,7 @@ template <bool BT>
 int launch_stream(gaib_ctx* ctx, const GemmArgs& g) {
   const int nt = g.N > 96 ? 4 : (g.N > 64 ? 3 : (g.N > 32 ? 2 : 1));
   const unsigned slabs = (unsigned)cdiv64(g.N, 32 * nt);
-  const size_t lds = sizeof(float) * (size_t)g.K * NNP_LDB;
+  const size_t lds = sizeof(float) * (size_t)((g.K + 7) & ~(int64_t)7) * NNP_LDB;
   const int64_t ntiles = cdiv64(g.M, 32);
   unsigned gx = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus / slabs > 0 ? ctx->num_cus / slabs : 1, cdiv64(ntiles, NNP_WAVES));
   if (slabs == 1) gx = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, NNP_WAVES));
@@ -758,16 +774,16 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // (sgemm_variant 40 keeps the LDS-tiled kernel, 41 forces this one wherever the shape allows).  Inside the SAGE
   // 256 -> 256 layer step: 17.9 vs 19.5 ms for the six GEMMs (scripts/ab_gemm_in_layer.py); at K = 128 a tile is too
   // short for this form (1.00 vs 0.90 ms).
-  const bool stream_shape = !transA && K % 8 == 0 && K <= 256 && avec;
+  const bool stream_shape = !transA && K % 4 == 0 && K >= 8 && K <= 256 && avec;
   // Round 2, measured again after the whole-tile C += epilogue (scripts/gemm_variants.py, 2.45 M rows): K = 128 NN 0.78-0.80
   // vs 0.89 ms for the LDS-tiled kernel (torch.mm / rocBLAS 0.98), K = 256 NN 2.63-2.66 vs 3.05-3.11 (rocBLAS 2.51-2.53),
   // so the streaming form is the default from K = 128 on (sgemm_variant 44: only above 128, the round-1 rule).
   // Tried on top of it and dropped: the next tile's first operand requested before the epilogue (no change: 2.63 vs
   // 2.65); 64-column operand groups in two register sets with the prefetch running on across tiles and the B
   // fragments double-buffered out of LDS (184 VGPRs, every wait in the ISA where it should be -- and 2.82 ms vs 2.68).
-  const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : 128;
+  const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 30 || sv == 31 || sv == 33;  // (30 / 31 / 33 concern the weight gradient only)
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || sv == 30 || sv == 31 || sv == 33;  // (30 / 31 / 33 concern the weight gradient only)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);

@@ -1070,7 +1070,8 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
 @pytest.mark.parametrize("x,y,z,tB,accum,relu", [
     (1000, 128, 128, 0, 0, 0), (777, 128, 96, 1, 0, 1), (200, 72, 264, 0, 0, 0), (5001, 256, 256, 0, 1, 1), (4099, 256, 256, 1, 0, 0),
     (31, 47, 128, 0, 0, 0), (33, 47, 128, 1, 1, 0), (3000, 100, 256, 0, 0, 1), (3000, 200, 104, 1, 0, 0), (2049, 16, 16, 0, 0, 0),
-    (70001, 64, 64, 0, 0, 0), (70001, 48, 200, 1, 0, 1), (1, 128, 8, 0, 0, 0)])
+    (70001, 64, 64, 0, 0, 0), (70001, 48, 200, 1, 0, 1), (1, 128, 8, 0, 0, 0),
+    (3001, 256, 100, 0, 0, 1), (3001, 128, 100, 1, 1, 0), (65, 47, 12, 0, 0, 0), (70001, 128, 100, 0, 0, 0), (999, 33, 252, 1, 0, 0)])
 def test_sgemm_streaming_kernel(ctx, x, y, z, tB, accum, relu):
     """the persistent streaming kernel (sgemm_variant 41) at every slab / tile-count / tail shape: same product as the LDS-tiled kernel and the oracle"""
     rng = np.random.default_rng(x + y + z)
@@ -1082,7 +1083,7 @@ def test_sgemm_streaming_kernel(ctx, x, y, z, tB, accum, relu):
         want = np.maximum(want, 0)
     res = []
     try:
-        for variant in ((41, 40) if z % 8 == 0 and z <= 256 else (40,)):
+        for variant in ((41, 40) if z % 4 == 0 and 8 <= z <= 256 else (40,)):  # (K % 8 == 4: a half step at the end)
             ctx.set_option("sgemm_variant", variant)
             Cd = dev(C0.copy())
             ctx.sgemm(dev(A), dev(B), Cd, False, bool(tB), bool(accum), relu=bool(relu))
