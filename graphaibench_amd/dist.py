@@ -383,30 +383,46 @@ def make_comm(ctx, rank: int, world: int, log):
     backend = os.environ.get("GAIB_DIST_BACKEND", "rccl")
     if backend in ("nccl", "gloo"):
         return None, f"torch.distributed/{dist.get_backend()}"
-    transport = capi.COMM_IPC if backend == "ipc" else capi.COMM_RCCL
-    ok, comm, err = 1, None, ""
-    try:
-        uid = [capi.comm_unique_id(transport) if rank == 0 else None]
-    except capi.GaibError as e:
-        uid, ok, err = [None], 0, str(e)
-    dist.broadcast_object_list(uid, src=0)
-    if uid[0] is None:
-        ok = 0
-    if ok:
+
+    def attempt(transport):
+        """every rank tries; the outcome is agreed on by all of them (all-reduce(MIN) of the success flag)"""
+        ok, comm, err = 1, None, ""
         try:
-            comm = capi.Comm(ctx, rank, world, uid[0], transport)
+            uid = [capi.comm_unique_id(transport) if rank == 0 else None]
         except capi.GaibError as e:
-            ok, err = 0, str(e)
-    flag = torch.tensor([ok], dtype=torch.int32)
-    if dist.get_backend() == "nccl":
-        flag = flag.cuda()
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
-        log(f"[bench r{rank}] gaib_comm({backend}) unavailable on some rank ({err or 'peer'}): torch.distributed carries the halo")
+            uid, ok, err = [None], 0, str(e)
+        dist.broadcast_object_list(uid, src=0)
+        if uid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                comm = capi.Comm(ctx, rank, world, uid[0], transport)
+            except capi.GaibError as e:
+                ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            return None, err or "a peer failed"
+        return comm, ""
+
+    # rccl (default): if it cannot be set up on some rank, the peer-to-peer pull transport (hipIpc handles, device-to-
+    # device copies over xGMI) is tried before torch.distributed carries the rows
+    order = [capi.COMM_IPC] if backend == "ipc" else [capi.COMM_RCCL, capi.COMM_IPC]
+    failed = []
+    for transport in order:
+        name = "ipc" if transport == capi.COMM_IPC else "rccl"
+        comm, err = attempt(transport)
         if comm is not None:
-            comm.close()
-        return None, f"torch.distributed/{dist.get_backend()} (gaib_comm {backend} failed at set-up)"
-    return comm, f"gaib_comm/{'ipc' if transport == capi.COMM_IPC else 'rccl'}"
+            note = f" (after {', '.join(failed)} failed at set-up)" if failed else ""
+            return comm, f"gaib_comm/{name}{note}"
+        log(f"[bench r{rank}] gaib_comm({name}) unavailable on some rank: {err}")
+        failed.append(name)
+    log(f"[bench r{rank}] torch.distributed/{dist.get_backend()} carries the halo")
+    return None, f"torch.distributed/{dist.get_backend()} (gaib_comm {', '.join(failed)} failed at set-up)"
 
 
 def _bench_case(ctx, comm, args, rank, world, D, log, rows, label):

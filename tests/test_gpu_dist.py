@@ -82,15 +82,17 @@ def test_two_ranks_on_one_gpu_match_global_oracle(arch):
     assert all(r[1] == "ok" for r in res), res
 
 
-@pytest.mark.parametrize("backend,scaling", [("gloo", "weak"), ("ipc", "weak"), ("ipc", "strong")])
+@pytest.mark.parametrize("backend,scaling", [("gloo", "weak"), ("ipc", "weak"), ("ipc", "strong"), ("rccl", "weak")])
 def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
     """bench.py's N>1 leg end to end (graph generator with cut edges, partition, split aggregation, dW all-reduce,
     JSON line) with 2 ranks sharing cuda:0 at 2 % scale: over torch.distributed/gloo (host-staged), and over the
-    C ABI's gaib_comm (hipIpc peer-to-peer pull) in both scaling modes.  Every field the record promises is there."""
+    C ABI's gaib_comm (hipIpc peer-to-peer pull) in both scaling modes.  Every field the record promises is there.
+    backend rccl (the default of a real run): RCCL refuses two ranks on one device, so here it exercises the set-up
+    fallback -- all ranks agree that RCCL is out and move to the peer-to-peer pull transport together."""
     import json
     import subprocess
 
-    port = 29900 + (os.getpid() % 90) + {"gloo": 0, "ipc": 100}[backend] + (200 if scaling == "strong" else 0)
+    port = 29900 + (os.getpid() % 90) + {"gloo": 0, "ipc": 100, "rccl": 300}[backend] + (200 if scaling == "strong" else 0)
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
@@ -105,7 +107,8 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
     cfg = res["config"]
     assert res["n_gpus"] == 2 and res["value"] > 0 and cfg["halo_rows_total"] > 0
     assert res["scaling"] == scaling and res["roofline"]["achieved"] > 0
-    assert cfg["transport"].startswith("gaib_comm/ipc" if backend == "ipc" else "torch.distributed/gloo")
+    want = {"ipc": "gaib_comm/ipc", "gloo": "torch.distributed/gloo", "rccl": "gaib_comm/ipc (after rccl failed"}[backend]
+    assert cfg["transport"].startswith(want), cfg["transport"]
     assert cfg["rccl_ranks"] == 0 and "xgmi_link_probe" in cfg  # one GPU here: no RCCL ranks, no link to probe
     assert cfg["halo_exchange_standalone_ms"] > 0 and cfg["halo_bytes_per_step_total"] > 0
     if scaling == "weak":
