@@ -534,9 +534,8 @@ struct Trainer {
       acc_t train_acc = 0.0;
       double t0, t1, t2;
       if (graph_mode && itr >= 1) {
-        // epoch 0 ran call by call (it allocates optimizer state and builds the graph's lazily made tables); from
-        // epoch 1 on an epoch is two graph launches
-        if (!fw_exec) record_epoch(opt);
+        // epoch 0 ran call by call (it allocates optimizer state and builds the graph's lazily made tables) and was
+        // followed by the recording; from epoch 1 on an epoch is two graph launches
         gaib_ctx* c = gpu_context::get();
         // one host wait per epoch; the forward / backward split of the log line comes from events around the launches
         t0 = omp_get_wtime();
@@ -558,6 +557,7 @@ struct Trainer {
         gpu_context::sync();
         t2 = omp_get_wtime();
       }
+      if (graph_mode && itr == 0) record_epoch(opt);  // (outside the timed part of the epoch, before its log line ends)
       const double fw = t1 - t0, bw = t2 - t1, epoch_time = fw + bw;
       total += epoch_time;
       std::cout << "train_loss " << std::setprecision(3) << std::fixed << train_loss << " train_acc " << train_acc << " ";
