@@ -643,11 +643,16 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
     // (the half step's operand: both lane halves read the row's last four columns -- inside the row -- and half 1 is
     // zeroed before use)
     const float* atail = g.A + row * g.K + Kfull;
+    const float* atail_or_first = Kfull < K ? atail : arow;  // what the last whole step prefetches (the row's first operand again when there is no half step: a valid address, unused)
     f4 a_cur = *reinterpret_cast<const f4*>(Kfull ? arow : atail);
     for (int k0 = 0; k0 < Kfull; k0 += 8) {
-      f4 a_nxt = a_cur;
-      if (k0 + 8 < Kfull) a_nxt = *reinterpret_cast<const f4*>(arow + k0 + 8);
-      else if (Kfull < K) a_nxt = *reinterpret_cast<const f4*>(atail);
+      // the next step's operand is requested now and used after this step's 16 MFMAs.  One unconditional load from a
+      // selected address: with the load under a branch (two of them once the half step came in) the compiler moved it
+      // to the end of the step and waited for it at once -- 3.05 instead of 2.65 ms at 2.45 M x 256 x 256
+      const float* pn = arow + k0 + 8;
+      if (k0 + 8 >= Kfull) pn = atail_or_first;
+      const f4 a_nxt = *reinterpret_cast<const f4*>(pn);
+      __builtin_amdgcn_sched_barrier(0);  // (... and without this it sinks the load behind the step's MFMAs to save four registers)
       const float* bk = bcol + (k0 + 4 * lh) * NNP_LDB;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -780,7 +785,9 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // so the streaming form is the default from K = 128 on (sgemm_variant 44: only above 128, the round-1 rule).
   // Tried on top of it and dropped: the next tile's first operand requested before the epilogue (no change: 2.63 vs
   // 2.65); 64-column operand groups in two register sets with the prefetch running on across tiles and the B
-  // fragments double-buffered out of LDS (184 VGPRs, every wait in the ISA where it should be -- and 2.82 ms vs 2.68).
+  // fragments double-buffered out of LDS (184 VGPRs, every wait in the ISA where it should be -- and 2.82 ms vs 2.68);
+  // the second wave of every SIMD started half a tile late, so that the two waves' epilogues do not fall together
+  // (2.63 vs 2.68 NN, nothing at NT or K = 128).
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
   const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || sv == 30 || sv == 31 || sv == 33;  // (30 / 31 / 33 concern the weight gradient only)
