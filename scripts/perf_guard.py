@@ -1,0 +1,146 @@
+"""Performance guard: the kernels and layer steps whose times DESIGN.md quotes, measured in one process and compared with
+the committed figures (profiles/perf_baseline.json).  A change that costs more than the tolerance (default 6 %) on any line
+is reported and the exit code is 1 -- correctness tests do not see a prefetch that the compiler moved or a dispatch rule
+that quietly picks another kernel (the streaming SGEMM lost 15 % that way in round 2 without a test failing).
+
+    python scripts/perf_guard.py            # compare with the baseline
+    python scripts/perf_guard.py --update   # rewrite the baseline from this run (after an intended change)
+
+Run on the GPU box: gpurun -- python scripts/perf_guard.py
+"""
+import argparse
+import json
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from graphaibench_amd import capi, layers as L, synth  # noqa: E402
+
+BASE = ROOT / "profiles" / "perf_baseline.json"
+
+
+def ev_time(fn, iters=8, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def layer_step(kind, graph_name, din, dout, selfloop, heads=1, steps=6):
+    ctx = L.init(0)
+    sg = synth.make(graph_name, device="cuda")
+    g = ctx.graph(sg.rowptr, sg.colidx)
+    if selfloop:
+        g2 = g.add_selfloop()
+        g.close()
+        g = g2
+    nv = g.nv
+    lg = L.LGraph.adopt(g)
+    layer = L.Layer(kind, 1, nv, din, dout, lg, act=True)
+    if heads > 1:
+        layer.set_heads(heads)
+    layer.write(L.FEAT_IN, torch.randn(nv, din, device="cuda"))
+    layer.write(L.GRAD_IN, torch.randn(nv, dout, device="cuda"))
+    out = torch.empty(nv, dout, device="cuda")
+    gout = torch.empty(nv, din, device="cuda")
+
+    def step():
+        layer.forward(out)
+        layer.backward(out, gout)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del layer, out, gout, lg
+    torch.cuda.empty_cache()
+    return ms
+
+
+def cora_epoch_ms():
+    data = Path("/tmp/gaib_data_pg")
+    subprocess.run([sys.executable, str(ROOT / "scripts" / "make_synth_dataset.py"), "cora", str(data)], check=True,
+                   stdout=subprocess.DEVNULL)
+    best = None
+    for _ in range(2):
+        r = subprocess.run([str(ROOT / "bin" / "gpu_train_gcn"), "cora", "400", "32", "softmax", "16", "0", "0", "0.01", "2", "0",
+                            "500", "0"], capture_output=True, text=True, env={"DATASET_PATH": str(data) + "/", "PATH": "/usr/bin:/bin"})
+        for line in r.stdout.splitlines():
+            if line.startswith("Average training time per epoch"):
+                eps = float(line.split("Throughput")[1].split()[0])
+                best = max(best or 0.0, eps)
+    return 1e3 / best if best else float("nan")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--update", action="store_true")
+    ap.add_argument("--tol", type=float, default=0.06)
+    args = ap.parse_args()
+    ctx = capi.Context(0)
+    nv = 2_449_029
+    res = {}
+    for d in (128, 256):
+        x = torch.randn(nv, d, device="cuda")
+        g = torch.randn(nv, d, device="cuda")
+        W = torch.randn(d, d, device="cuda") * 0.1
+        y = torch.empty(nv, d, device="cuda")
+        dW = torch.empty(d, d, device="cuda")
+        ev_time(lambda: ctx.sgemm(x, W, y), iters=3)  # clocks up
+        res[f"sgemm NN 2.45M x {d} x {d}"] = ev_time(lambda: ctx.sgemm(x, W, y))
+        res[f"sgemm NT 2.45M x {d} x {d}"] = ev_time(lambda: ctx.sgemm(x, W, y, False, True))
+        res[f"sgemm TN {d} x {d}, K = 2.45M"] = ev_time(lambda: ctx.sgemm(x, g, dW, True, False))
+        del x, g, W, y, dW
+    x100 = torch.randn(nv, 100, device="cuda")
+    W100 = torch.randn(100, 128, device="cuda")
+    y128 = torch.empty(nv, 128, device="cuda")
+    res["sgemm NN 2.45M x 128 x 100"] = ev_time(lambda: ctx.sgemm(x100, W100, y128))
+    del x100, W100, y128
+    torch.cuda.empty_cache()
+    ctx.close()
+    res["GCN 128->128 layer step, products shape (the bench step)"] = layer_step(L.GCN, "ogbn-products", 128, 128, True)
+    res["SAGE 128->128 layer step, products shape"] = layer_step(L.SAGE, "ogbn-products", 128, 128, False)
+    res["SAGE 256->256 layer step, products shape"] = layer_step(L.SAGE, "ogbn-products", 256, 256, False)
+    res["GCN 128->47 layer step, products shape"] = layer_step(L.GCN, "ogbn-products", 128, 47, True)
+    res["GAT 64->64 8 heads layer step, reddit shape"] = layer_step(L.GAT, "reddit", 64, 64, True, heads=8)
+    res["cora GCN 2-layer epoch (trainer, recorded epochs)"] = cora_epoch_ms()
+    for k, v in res.items():
+        print(f"{v:9.3f} ms  {k}", flush=True)
+    if args.update or not BASE.exists():
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+        text = json.dumps({"commit": commit or "?", "unit": "ms", "times": res}, indent=1) + "\n"
+        BASE.write_text(text)
+        out = ROOT / "gpurun_out"  # (what travels back from the GPU box)
+        out.mkdir(exist_ok=True)
+        (out / "perf_baseline.json").write_text(text)
+        print(f"baseline written: {BASE} (copy: gpurun_out/perf_baseline.json)")
+        return 0
+    base = json.loads(BASE.read_text())["times"]
+    bad = []
+    for k, v in res.items():
+        if k in base and v > base[k] * (1.0 + args.tol):
+            bad.append(f"{k}: {v:.3f} ms vs {base[k]:.3f} ms (+{(v / base[k] - 1) * 100:.1f} %)")
+    if bad:
+        print("SLOWER THAN THE BASELINE:\n  " + "\n  ".join(bad))
+        return 1
+    print(f"all {len(res)} lines within {args.tol * 100:.0f} % of profiles/perf_baseline.json")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
