@@ -787,7 +787,8 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // 2.65); 64-column operand groups in two register sets with the prefetch running on across tiles and the B
   // fragments double-buffered out of LDS (184 VGPRs, every wait in the ISA where it should be -- and 2.82 ms vs 2.68);
   // the second wave of every SIMD started half a tile late, so that the two waves' epilogues do not fall together
-  // (2.63 vs 2.68 NN, nothing at NT or K = 128).
+  // (2.63 vs 2.68 NN, nothing at NT or K = 128); 64-row wave tiles, so that every B fragment read from LDS feeds two
+  // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
   const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || sv == 30 || sv == 31 || sv == 33;  // (30 / 31 / 33 concern the weight gradient only)
