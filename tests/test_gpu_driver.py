@@ -177,7 +177,7 @@ def test_driver_subgraph_sampling_and_inductive(tmp_path, arch):
         assert acc > 0.3, r.stdout[-1500:]  # 7 classes; the synthetic features carry the label
 
 
-@pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 3), ("gat", 2), ("gcn", 5), ("gat", 4)])  # (the box allows 6 GPU processes, pytest included)
+@pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 3), ("gat", 2), ("gcn", 4), ("gat", 3)])  # (the box allows 6 GPU processes, pytest included: margin of one)
 def test_driver_multi_rank_matches_single_rank(tmp_path, arch, world):
     """bin/gpu_train_* as N processes (one per rank; here all on cuda:0 over the IPC transport): vertex-range
     partition, halo exchange before every aggregation, gradient all-reduce before every optimizer step -- all behind
