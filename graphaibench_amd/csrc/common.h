@@ -170,6 +170,36 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// ---- DPP (data-parallel primitives: a lane permutation folded into a VALU instruction, no LDS trip) ------------------
+// __shfl / __shfl_xor compile to ds_bpermute_b32 -- an LDS instruction plus its wait -- also where the pattern is fixed at
+// compile time.  Inside a 16-lane row the fixed patterns are free: quad_perm, row_half_mirror, row_mirror for sums over
+// aligned groups of 2 / 4 / 8 / 16 lanes, row_newbcast for "lane n of my row".
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over the aligned group of LH consecutive lanes (LH = 1, 2, 4, 8, 16) this lane belongs to; every lane gets it
+template <int LH>
+__device__ __forceinline__ float lanes_sum(float v) {
+  static_assert(LH == 1 || LH == 2 || LH == 4 || LH == 8 || LH == 16, "aligned power-of-two groups inside a 16-lane row");
+  if constexpr (LH >= 2) v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (LH >= 4) v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (LH >= 8) v += dpp_f32<0x141>(v);   // row_half_mirror: the other quad of the half row
+  if constexpr (LH >= 16) v += dpp_f32<0x140>(v);  // row_mirror: the other half row
+  return v;
+}
+// lane n (0..15, a compile-time constant after unrolling) of this lane's 16-lane row
+__device__ __forceinline__ int row_lane(int v, int n) {
+#define GAIB_RB(N) case N: return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false);
+  switch (n & 15) {
+    GAIB_RB(0) GAIB_RB(1) GAIB_RB(2) GAIB_RB(3) GAIB_RB(4) GAIB_RB(5) GAIB_RB(6) GAIB_RB(7)
+    GAIB_RB(8) GAIB_RB(9) GAIB_RB(10) GAIB_RB(11) GAIB_RB(12) GAIB_RB(13) GAIB_RB(14) default: GAIB_RB(15)
+  }
+#undef GAIB_RB
+}
+__device__ __forceinline__ float dot4_fma(const float (&a)[4], const float (&b)[4]) {
+  return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
+}
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }

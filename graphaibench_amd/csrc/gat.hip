@@ -854,13 +854,14 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   // floats, small enough for the L2, where a (rowdot, sl, sr) record per (vertex, head) cost a 128-B line per edge
   const f4 al4 = *reinterpret_cast<const f4*>(alpha_l + coff);
   const f4 ar4 = *reinterpret_cast<const f4*>(alpha_r + coff);
-  float sl_i = al4[0] * hi[0] + al4[1] * hi[1] + al4[2] * hi[2] + al4[3] * hi[3];
-  float sr_i = ar4[0] * hi[0] + ar4[1] * hi[1] + ar4[2] * hi[2] + ar4[3] * hi[3];
-#pragma unroll
-  for (int o = LH / 2; o > 0; o >>= 1) {
-    sl_i += __shfl_xor(sl_i, o, 64);
-    sr_i += __shfl_xor(sr_i, o, 64);
-  }
+  // (instruction count is what bounds this kernel -- 2 000 VALU / LDS instructions per 64-edge chunk, 1 720 chunks per
+  // SIMD: 5.7 ms of issue at the reddit shape before a byte moves -- so: dot products as FMA chains, sums over a head's
+  // lanes and "column id of edge j" by DPP instead of ds_bpermute, one fast exponential per attention value)
+  auto d4 = [](const f4& a, const f4& b) {
+    return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
+  };
+  const float sl_i = lanes_sum<LH>(d4(al4, hi));
+  const float sr_i = lanes_sum<LH>(d4(ar4, hi));
   const float rd_i = rowdot[row * H + head];
   float2 st_i = {0.f, 0.f};
   if constexpr (RECOMP) st_i = stats[row * H + head];
@@ -874,14 +875,14 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ei = gbase + j + u;
-      const uint32_t cj = (uint32_t)__shfl((int)cl, ei, 64);
+      const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
       xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
       rd[u] = rowdot[(int64_t)cj * H + head];
       if constexpr (RECOMP) {
         stc[u] = stats[(int64_t)cj * H + head];
       } else {
-        const uint32_t rj = (uint32_t)__shfl((int)rl, ei, 64);
+        const uint32_t rj = (uint32_t)row_lane((int)rl, j + u);
         pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
         pr[u] = p[(int64_t)rj * H + head];
       }
@@ -890,22 +891,15 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool live = gbase + j + u < n;
-      float dpe = gi[0] * xh[u][0] + gi[1] * xh[u][1] + gi[2] * xh[u][2] + gi[3] * xh[u][3];
-      float dpr = xg[u][0] * hi[0] + xg[u][1] * hi[1] + xg[u][2] * hi[2] + xg[u][3] * hi[3];
-      float sl_c = al4[0] * xh[u][0] + al4[1] * xh[u][1] + al4[2] * xh[u][2] + al4[3] * xh[u][3];
-      float sr_c = ar4[0] * xh[u][0] + ar4[1] * xh[u][1] + ar4[2] * xh[u][2] + ar4[3] * xh[u][3];
-#pragma unroll
-      for (int o = LH / 2; o > 0; o >>= 1) {
-        dpe += __shfl_xor(dpe, o, 64);
-        dpr += __shfl_xor(dpr, o, 64);
-        sl_c += __shfl_xor(sl_c, o, 64);
-        sr_c += __shfl_xor(sr_c, o, 64);
-      }
+      const float dpe = lanes_sum<LH>(d4(gi, xh[u]));
+      const float dpr = lanes_sum<LH>(d4(xg[u], hi));
+      const float sl_c = lanes_sum<LH>(d4(al4, xh[u]));
+      const float sr_c = lanes_sum<LH>(d4(ar4, xh[u]));
       const float t_e = sl_i + sr_c, t_r = sl_c + sr_i;  // pre-activation scores of (i -> c) and (c -> i)
       float a, b;
       if constexpr (RECOMP) {
-        a = expf((t_e > 0.0f ? t_e : eps * t_e) - st_i.x) * st_i.y;
-        b = expf((t_r > 0.0f ? t_r : eps * t_r) - stc[u].x) * stc[u].y;
+        a = __expf((t_e > 0.0f ? t_e : eps * t_e) - st_i.x) * st_i.y;
+        b = __expf((t_r > 0.0f ? t_r : eps * t_r) - stc[u].x) * stc[u].y;
       } else {
         a = pe[u];
         b = pr[u];
@@ -918,10 +912,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
         s_e += ge;
         s_r += gr;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float t = b * xg[u][k];
-          acc[k] = acc[k] + t;
-        }
+        for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(b, xg[u][k], acc[k]);
       }
     }
   }
@@ -974,9 +965,10 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
   const f4 al4 = *reinterpret_cast<const f4*>(alpha_l + coff);
   const f4 ar4 = *reinterpret_cast<const f4*>(alpha_r + coff);
-  float sl_i = al4[0] * hi[0] + al4[1] * hi[1] + al4[2] * hi[2] + al4[3] * hi[3];
-#pragma unroll
-  for (int o = LH / 2; o > 0; o >>= 1) sl_i += __shfl_xor(sl_i, o, 64);
+  auto d4 = [](const f4& a, const f4& b) {
+    return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
+  };
+  const float sl_i = lanes_sum<LH>(d4(al4, hi));  // (DPP sums / broadcasts, FMA chains: see the backward kernel)
   float m = GAT_NEG, ssum = 0.f;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -984,24 +976,24 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
     f4 xh[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t cj = (uint32_t)__shfl((int)cl, gbase + j + u, 64);
+      const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float sr_c = ar4[0] * xh[u][0] + ar4[1] * xh[u][1] + ar4[2] * xh[u][2] + ar4[3] * xh[u][3];
-#pragma unroll
-      for (int o = LH / 2; o > 0; o >>= 1) sr_c += __shfl_xor(sr_c, o, 64);
+      const float sr_c = lanes_sum<LH>(d4(ar4, xh[u]));
       if (gbase + j + u < n) {  // wave-uniform per group; lanes past the end of a short chunk add nothing
         const float t0 = sl_i + sr_c;
         const float t = t0 > 0.0f ? t0 : eps * t0;
-        const float mn = t > m ? t : m;
-        const float sc = expf(m - mn), e = expf(t - mn);
-        ssum = ssum * sc + e;
+        // online softmax: one of exp(m - max), exp(t - max) is exp(0) -- ONE exponential per edge
+        const float d = t - m;
+        const float ex = __expf(d > 0.f ? -d : d);
+        const float sc = d > 0.f ? ex : 1.f, e = d > 0.f ? 1.f : ex;
+        ssum = __builtin_fmaf(ssum, sc, e);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = acc[k] * sc + e * xh[u][k];
-        m = mn;
+        for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(e, xh[u][k], acc[k] * sc);
+        m = d > 0.f ? t : m;
       }
     }
   }
