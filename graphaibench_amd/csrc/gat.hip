@@ -841,7 +841,12 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   const int64_t rb = rowptr[row];
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
-  const int64_t el = eb + (lane < n ? lane : 0);
+  // edge t * 4 + g of the chunk is step t of lane group g: a chunk of n edges takes ceil(n / 4) steps whatever n is (with
+  // group g on edges 16 g .. 16 g + 15, the 17-edge tail of a row took all 16).
+  // Lane (g, t) fetches that edge's column id, so "step t of my group" is lane t of my 16-lane row (DPP).
+  const int grp = lane >> 4;
+  const int my_e = sl * 4 + grp;
+  const int64_t el = eb + (my_e < n ? my_e : 0);
   const uint32_t cl = col[el];
   uint32_t rl = 0;
   if constexpr (!RECOMP) rl = rev[el];
@@ -869,12 +874,13 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   float s_e = 0.f, s_r = 0.f;
 #pragma unroll
   for (int j = 0; j < G; j += U) {
+    if (j * 4 >= n) break;  // (wave-uniform: no edge of the chunk is left for any group)
     f4 xg[U], xh[U];
     float pe[U], pr[U], rd[U];
     float2 stc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int ei = gbase + j + u;
+      const int ei = (j + u) * 4 + grp;
       const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
       xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first one is consumed
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool live = gbase + j + u < n;
+      const bool live = (j + u) * 4 + grp < n;
       const float dpe = lanes_sum<LH>(d4(gi, xh[u]));
       const float dpr = lanes_sum<LH>(d4(xg[u], hi));
       const float sl_c = lanes_sum<LH>(d4(al4, xh[u]));
@@ -959,7 +965,9 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   const int64_t rb = rowptr[row];
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
-  const uint32_t cl = col[eb + (lane < n ? lane : 0)];
+  const int grp = lane >> 4;  // edge t * 4 + g = step t of lane group g (see the backward kernel)
+  const int my_e = sl * 4 + grp;
+  const uint32_t cl = col[eb + (my_e < n ? my_e : 0)];
   const int coff = sl * 4;
   const int head = sl / LH;
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
@@ -973,6 +981,7 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < G; j += U) {
+    if (j * 4 >= n) break;  // (wave-uniform)
     f4 xh[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -983,7 +992,7 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float sr_c = lanes_sum<LH>(d4(ar4, xh[u]));
-      if (gbase + j + u < n) {  // wave-uniform per group; lanes past the end of a short chunk add nothing
+      if ((j + u) * 4 + grp < n) {  // uniform per group; lanes past the end of a short chunk add nothing
         const float t0 = sl_i + sr_c;
         const float t = t0 > 0.0f ? t0 : eps * t0;
         // online softmax: one of exp(m - max), exp(t - max) is exp(0) -- ONE exponential per edge
