@@ -1025,38 +1025,52 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
 }
 
 // per row: combine the chunks' (m, s, acc) in chunk order; out = act(sum / S); stats[row][h] = (M, 1/S)
+// (len == 64: a row is 16 lanes of 4 columns, so the wave's four 16-lane groups take the row's chunks k, k + 1, k + 2,
+// k + 3, ... and meet at the end -- a row with 330 chunks is 83 steps deep instead of 330, and no lane idles)
 __global__ __launch_bounds__(256) void gat_fwd_reduce_kernel(int64_t nv, int len, int H, const uint32_t* chunk_start,
                                                              const float* out_partial, const float2* ms_partial, int relu,
                                                              float* out, float2* stats) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
-  if (lane * 4 >= len) return;
+  const int sl = lane & 15, grp = lane >> 4;
   const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
-  const int dh = len / H, head = (lane * 4) / dh;
+  const int dh = len / H, head = (sl * 4) / dh;
   float M = GAT_NEG;
-  for (int64_t k = c0; k < c1; ++k) {
+  for (int64_t k = c0 + grp; k < c1; k += 4) {
     const float mk = ms_partial[k * H + head].x;
     M = mk > M ? mk : M;
   }
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(M, o, 64);
+    M = mo > M ? mo : M;
+  }
   float S = 0.f;
   f4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t k = c0; k < c1; ++k) {
+  for (int64_t k = c0 + grp; k < c1; k += 4) {
     const float2 ms = ms_partial[k * H + head];
-    const float w = expf(ms.x - M);
+    const float w = __expf(ms.x - M);
     S += ms.y * w;
-    const f4 t = *reinterpret_cast<const f4*>(out_partial + k * len + lane * 4);
+    const f4 t = *reinterpret_cast<const f4*>(out_partial + k * len + sl * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[q] += t[q] * w;
   }
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {  // fixed order: deterministic
+    S += __shfl_xor(S, o, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], o, 64);
+  }
+  if (grp != 0) return;
   const float inv = S > 0.f ? 1.0f / S : 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     s[q] *= inv;
     if (relu) s[q] = s[q] > 0.f ? s[q] : 0.f;
   }
-  *reinterpret_cast<f4*>(out + row * (int64_t)len + lane * 4) = s;
-  if ((lane * 4) % dh == 0) stats[row * H + head] = float2{M, inv};
+  *reinterpret_cast<f4*>(out + row * (int64_t)len + sl * 4) = s;
+  if ((sl * 4) % dh == 0) stats[row * H + head] = float2{M, inv};
 }
 
 // out[row] = sum of the row's chunk partials in chunk order; rs / cs [row][H] the same for the g sums
@@ -1066,33 +1080,33 @@ __global__ __launch_bounds__(256) void gat_fused_reduce_kernel(int64_t nv, int l
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
+  const int sl = lane & 15, grp = lane >> 4;  // len == 64: four lane groups share the row's chunks (see the forward's)
   const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
-  if (lane * 4 < len) {
-    f4 s = {0.f, 0.f, 0.f, 0.f};
-    const float* pp = out_partial + lane * 4;
-    int64_t k = c0;
-    for (; k + 4 <= c1; k += 4) {
-      f4 t[4];
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  float r = 0.f, r2 = 0.f;  // this lane's share of the 2 H row / column sums: entries sl and sl + 16
+  const float* pp = out_partial + sl * 4;
+  for (int64_t k = c0 + grp; k < c1; k += 4) {
+    const f4 t = *reinterpret_cast<const f4*>(pp + k * len);
+    if (sl < 2 * H) r += rc_partial[k * 2 * H + sl];
+    if (sl + 16 < 2 * H) r2 += rc_partial[k * 2 * H + sl + 16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f4*>(pp + (k + u) * len);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] += t[u][q];
-    }
-    for (; k < c1; ++k) {
-      const f4 t = *reinterpret_cast<const f4*>(pp + k * len);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s[q] += t[q];
-    }
-    *reinterpret_cast<f4*>(out + row * (int64_t)len + lane * 4) = s;
+    for (int q = 0; q < 4; ++q) s[q] += t[q];
   }
-  if (lane < 2 * H) {  // lanes 0..H-1: rs, H..2H-1: cs
-    float s = 0.f;
-    for (int64_t k = c0; k < c1; ++k) s += rc_partial[k * 2 * H + lane];
-    if (lane < H) rs[row * H + lane] = s;
-    else cs[row * H + lane - H] = s;
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {  // fixed order: deterministic
+    r += __shfl_xor(r, o, 64);
+    r2 += __shfl_xor(r2, o, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], o, 64);
   }
+  if (grp != 0) return;
+  *reinterpret_cast<f4*>(out + row * (int64_t)len + sl * 4) = s;
+  // entries 0..H-1: rs, H..2H-1: cs
+  if (sl < 2 * H) {
+    if (sl < H) rs[row * H + sl] = r;
+    else cs[row * H + sl - H] = r;
+  }
+  if (sl + 16 < 2 * H) cs[row * H + sl + 16 - H] = r2;  // (16 heads: entries 16..31 are all column sums)
 }
 
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
