@@ -796,6 +796,17 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int64_t nv, int len, int H,
   }
 }
 
+// rec[v, h] = (rowdot[v, h], row maximum, 1 / row sum, 0): what the one-sweep backward needs about a COLUMN vertex beside
+// its two rows, as one 16-byte record -- 128 B = one line per vertex at 8 heads, where rowdot [nv][H] and the forward's
+// statistics [nv][H][2] were two tables, two lines and two load instructions per edge
+__global__ void gat_rec_kernel(int64_t n, const float* rowdot, const float2* stats, f4* rec) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const float2 st = stats[t];
+    rec[t] = f4{rowdot[t], st.x, st.y, 0.f};
+  }
+}
+
 // ---- the whole edge side of GAT backward in ONE pass over the ordered 64-edge chunk list ---------------------------
 // GAT_Aggregator::d_aggregate (gat_aggregator.cpp:99-200) is four sweeps over the edges: SDDMM dp_e = <grad_i, h_c>;
 // softmax backward + leaky-relu' -> g_e, with the row sums rs and the column sums cs of g for the alpha gradients;
@@ -830,7 +841,8 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
     const float* p, const float2* stats, const float* rowdot, const float* alpha_l, const float* alpha_r, float eps,
-    float* out_partial, float* rc_partial) {
+    float* out_partial, float* rc_partial, const f4* rec) {
+  // rec (RECOMP): (rowdot, row maximum, 1 / row sum) per (vertex, head) as one 16-byte record, see gat_rec_kernel
   constexpr int LH = G / H;  // lanes per head
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
@@ -867,9 +879,15 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   };
   const float sl_i = lanes_sum<LH>(d4(al4, hi));
   const float sr_i = lanes_sum<LH>(d4(ar4, hi));
-  const float rd_i = rowdot[row * H + head];
+  float rd_i;
   float2 st_i = {0.f, 0.f};
-  if constexpr (RECOMP) st_i = stats[row * H + head];
+  if constexpr (RECOMP) {
+    const f4 ri = rec[row * H + head];
+    rd_i = ri[0];
+    st_i = float2{ri[1], ri[2]};
+  } else {
+    rd_i = rowdot[row * H + head];
+  }
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   float s_e = 0.f, s_r = 0.f;
 #pragma unroll
@@ -884,10 +902,12 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
       const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
       xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
-      rd[u] = rowdot[(int64_t)cj * H + head];
       if constexpr (RECOMP) {
-        stc[u] = stats[(int64_t)cj * H + head];
+        const f4 rc = rec[(int64_t)cj * H + head];
+        rd[u] = rc[0];
+        stc[u] = float2{rc[1], rc[2]};
       } else {
+        rd[u] = rowdot[(int64_t)cj * H + head];
         const uint32_t rj = (uint32_t)row_lane((int)rl, j + u);
         pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
         pr[u] = p[(int64_t)rj * H + head];
@@ -1462,8 +1482,9 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
   const size_t n_v = up4((size_t)g->nv * heads);
   const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (3 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
-  float* rowdot = (float*)ctx->ws;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (7 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
+  f4* rec = reinterpret_cast<f4*>(ctx->ws);  // [nv][H] 16-byte records (first: alignment)
+  float* rowdot = (float*)ctx->ws + 4 * n_v;
   float* rs = rowdot + n_v;
   float* cs = rs + n_v;
   float* out_partial = cs + n_v;
@@ -1472,13 +1493,19 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   ProfScope ps(ctx, "gat_bwd_fused");
   rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
   GAIB_LAUNCH_CHECK();
+  if (d_row_stats) {
+    const int64_t nrec = g->nv * (int64_t)heads;
+    gat_rec_kernel<<<(unsigned)cdiv64(nrec, 256), 256, 0, ctx->stream>>>(nrec, rowdot, reinterpret_cast<const float2*>(d_row_stats),
+                                                                        rec);
+    GAIB_LAUNCH_CHECK();
+  }
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
   // edges in flight per group: 8 or 4 (option gat_fused_unroll)
 #define GAIB_FB_U(HH, UU, RC)                                                                                              \
   gat_bwd_fused_chunk_kernel<16, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
       g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, g->rev, len, d_feat, d_grad,        \
       d_norm_scores, reinterpret_cast<const float2*>(d_row_stats), rowdot, d_alpha_l, d_alpha_r, epsilon, out_partial,     \
-      rc_partial)
+      rc_partial, rec)
 #define GAIB_FB(HH)                                          \
   do {                                                       \
     if (d_row_stats) {                                       \
