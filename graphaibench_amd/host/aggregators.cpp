@@ -4,6 +4,9 @@
 #include "host_util.h"
 
 using gaib_host::OpTimer;
+// edges aggregated so far by this process: one count of the graph's edges per aggregation call (BASELINE's
+// "aggregated edges"; bench.py counts the same way)
+static inline void count_edges(Graph& g) { gpu_context::add_aggregated_edges((uint64_t)g.sizeEdges()); }
 static inline gaib_ctx* C() { return gpu_context::get(); }
 
 static gaib_graph* dev(Graph& g) {
@@ -14,6 +17,7 @@ static gaib_graph* dev(Graph& g) {
 // One aggregation.  On a vertex-range partition the owned-column edges are summed while the halo
 // rows are in flight (separate RCCL stream), then the halo-column edges are added to the same rows.
 static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* out, bool relu = false) {
+  count_edges(g);
   const int act = relu ? GAIB_RELU : 0;
   if (!g.has_halo()) {
     GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, out, act));
@@ -31,6 +35,7 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
                                        const float* W, bool transW, int len_out, float* out, bool relu,
                                        const float* rows2, const float* W2) {
   OpTimer t(OP_SPARSEMM);
+  count_edges(g);
   const int flags = (relu ? GAIB_RELU : 0) | (keep_agg ? 0 : GAIB_AGG_SCRATCH);
   auto fused = [&](gaib_graph* dg, const float* src, int fl) {
     if (rows2)
@@ -241,6 +246,7 @@ void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_
 }
 
 void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
+  count_edges(g);
   if (g.gat_full_graph()) {
     aggregate_partition(len, g, in, out);
     return;
@@ -302,6 +308,7 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
 // feat_in is last read by the alpha-gradient step, grad_out is first written by the final SpMM.
 void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in,
                                  float* grad_out) {
+  count_edges(g);
   if (g.gat_full_graph()) {
     d_aggregate_partition(len, g, grad_in, grad_out);
     return;

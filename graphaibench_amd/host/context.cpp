@@ -11,6 +11,9 @@ static gaib_ctx* g_ctx = nullptr;
 static bool g_sync_timers = false;
 static gaib_comm* g_comm = nullptr;
 
+static unsigned long long g_agg_edges = 0;
+void gpu_context::add_aggregated_edges(unsigned long long n) { g_agg_edges += n; }
+unsigned long long gpu_context::aggregated_edges() { return g_agg_edges; }
 void gpu_context::set_comm(gaib_comm* comm) { g_comm = comm; }
 gaib_comm* gpu_context::comm() { return g_comm; }
 

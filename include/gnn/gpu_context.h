@@ -21,6 +21,9 @@ class gpu_context {
   // optimizer step first sums its gradient buffer over the ranks (gaib_allreduce_f32: weights and Adam state stay
   // replicated and bit-identical on all ranks), and LearningGraphs built by make_partitioned_graph exchange halo rows
   // on it.  The context borrows it.
+  // edges aggregated by this process so far (the aggregators add the graph's edge count per aggregation call)
+  static void add_aggregated_edges(unsigned long long n);
+  static unsigned long long aggregated_edges();
   static void set_comm(gaib_comm* comm);
   static gaib_comm* comm();
 };
