@@ -9,7 +9,16 @@ A step = one pass of the hot path: GCN_layer(128 -> 128, hidden layer, relu)::fo
 inputs resident in HBM when the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1, either way:
+      * plainly, as above: with no WORLD_SIZE in the environment bench.py is its own launcher -- the parent touches no
+        GPU API, starts N fresh rank processes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*), relays rank 0's JSON line
+        as its last stdout line, and on the first failing rank or at --deadline-s kills the rest and exits non-zero
+        (one entry point drives all devices, like the reference's multi-GPU programs: src/triangle/multigpu_induced.cu:31-84);
+      * python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...  (the ranks given from outside).
+    Ranks map to devices as LOCAL_RANK % visible devices; with fewer devices than ranks (a one-GPU box) the data path is
+    the peer-to-peer pull transport, which lets several ranks share a device, and the record says so (config.transport).
+    --workload gcn-papers: BASELINE config 5's layer (GCN 128 -> 128 on the ogbn-papers100M-shaped graph in vertex ranges
+    of 1/8 of it: at N = 8 the whole graph); --check-oracle compares every rank's outputs with the oracle's GLOBAL run.
 
 One JSON line on rank 0.  `roofline` prices the dominant kernel (spmm_gemm_kernel: the one-wave-per-row
 aggregation with the dense product riding on it) by ALGORITHMIC bytes per launch / mean launch time measured
@@ -209,6 +218,109 @@ def parity_record(torch, L, layer, feat_out, grad_out, gin_h, want: dict, tol=1e
     return rec
 
 
+class DistOracleCheck:
+    """--check-oracle on the partitioned path: every rank's share of the layer's forward output and input gradient, and
+    the weight gradient summed over the ranks, against the oracle's run on the GLOBAL graph (the block generator is
+    seeded per range, so rank 0 regenerates every range and joins them; rows keep the global column order).  Same
+    scheme as parity_record: forward as is, backward re-run on the ORACLE's forward output (identical relu masks).
+    The partitioned aggregation adds a row's owned-column edges before its halo-column edges -- another order than
+    the oracle's ascending columns -- so every row is a re-ordered fp32 sum: floor 1e-5 max|b| (tests/util.py
+    LONG_SUM_FLOOR), the weight gradient's floor from the oracle's own distance to fp64 as in parity_record."""
+
+    TOL, FLOOR = 1e-4, 1e-5
+
+    def __init__(self, torch, dist, synth, L, gdist, ctx, comm, args, rank, world, shape, cut):
+        self.torch, self.dist, self.synth, self.L, self.gdist = torch, dist, synth, L, gdist
+        self.ctx, self.comm, self.args, self.rank, self.world, self.shape, self.cut = ctx, comm, args, rank, world, shape, cut
+
+    @staticmethod
+    def inputs(rank: int, nv: int):
+        import numpy as np
+
+        rng = np.random.default_rng(4300 + rank)
+        return rng.standard_normal((nv, D), dtype=np.float32), rng.standard_normal((nv, D), dtype=np.float32)
+
+    def _oracle_global(self, nv):
+        import numpy as np
+        from oracle import binding as orc
+
+        torch, synth = self.torch, self.synth
+        rps, cis, off = [np.zeros(1, np.int64)], [], 0
+        for q in range(self.world):
+            rows = synth.block_rows(self.shape, q, self.world, seed=42, cut_fraction=self.cut, device="cuda",
+                                    scale=self.args.scale, selfloops=True)
+            assert rows.n_local == nv
+            rps.append(rows.rowptr[1:].cpu().numpy() + off)
+            cis.append(rows.colidx_global.cpu().numpy().astype(np.uint32))
+            off += int(rows.rowptr[-1])
+            del rows
+        torch.cuda.empty_cache()
+        g = orc.Graph(np.concatenate(rps), np.concatenate(cis))  # self loops are in (block_rows(selfloops=True), net.cpp:96)
+        xs = [self.inputs(q, nv) for q in range(self.world)]
+        x, gin = np.concatenate([a for a, _ in xs]), np.concatenate([b for _, b in xs])
+        del xs
+        orc.set_threads(usable_cores())
+        lay = orc.GCNLayer(1, g, D, D, True)
+        t0 = time.perf_counter()
+        fwd = lay.forward(x)
+        go = lay.backward(gin)  # gin is masked in place (Q9)
+        t = time.perf_counter() - t0
+        return dict(forward=fwd, grad_out=go, W_grad=lay.W_grad, agg_x=lay.in_temp1, masked_grad=gin, seconds=t,
+                    edges=g.ne, nv=g.nv)
+
+    def __call__(self, part, layer, feat_out, grad_out):
+        torch, dist, L = self.torch, self.dist, self.L
+        nv = part.n_own
+        x_h, gin_h = self.inputs(self.rank, nv)
+        want = self._oracle_global(nv) if self.rank == 0 else None
+        # rank 0 hands every rank its rows of the oracle's outputs (control plane: gloo / the launcher's group)
+        def scatter(key):
+            mine = torch.empty(nv, D)
+            parts = [torch.from_numpy(want[key][q * nv:(q + 1) * nv]) for q in range(self.world)] if self.rank == 0 else None
+            if dist.get_backend() == "nccl":
+                mine = mine.cuda()
+                parts = [p_.cuda() for p_ in parts] if parts else None
+            dist.scatter(mine, parts, src=0)
+            return mine.cuda()
+
+        fwd_o, go_o = scatter("forward"), scatter("grad_out")
+        layer.write(L.FEAT_IN, torch.from_numpy(x_h).cuda())
+        layer.forward(feat_out)
+        torch.cuda.synchronize()
+        e_f = _errs(torch, feat_out, fwd_o, self.TOL, self.FLOOR)
+        flips = int(((feat_out > 0) != (fwd_o > 0)).sum().item())
+        layer.write(L.GRAD_IN, torch.from_numpy(gin_h).cuda())
+        layer.backward(fwd_o, grad_out)  # the oracle's forward output: identical relu masks
+        self.gdist.allreduce_layer_grads(self.ctx, layer, [L.W_NEIGH_GRAD], (D, D), comm=self.comm)
+        torch.cuda.synchronize()
+        e_g = _errs(torch, grad_out, go_o, self.TOL, self.FLOOR)
+        t = torch.tensor([e_f["elem"], e_f["inf"], e_g["elem"], e_g["inf"], float(flips)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rec = None
+        if self.rank == 0:
+            w_gpu = layer.tensor(L.W_NEIGH_GRAD, (D, D))
+            wg_o = torch.from_numpy(want["W_grad"]).cuda()
+            w64 = torch.from_numpy(want["agg_x"]).cuda().double().t() @ torch.from_numpy(want["masked_grad"]).cuda().double()
+            sc = w64.abs().max().item()
+            gpu64 = (w_gpu.double() - w64).abs().max().item() / sc
+            orc64 = (wg_o.double() - w64).abs().max().item() / sc
+            w_floor = max(self.FLOOR, 2.0 * orc64)
+            e_w = _errs(torch, w_gpu, wg_o, self.TOL, w_floor)
+            rec = {"tol": self.TOL, "floor_frac_of_max": self.FLOOR, "against": "oracle GCN layer on the GLOBAL graph "
+                   f"({want['nv']} vertices, {want['edges']} edges incl. self loops, {want['seconds']:.1f} s on the host), "
+                   f"max over {self.world} ranks", "cut_fraction": self.cut,
+                   "forward": {"elem": float(t[0]), "inf": float(t[1])}, "grad_out": {"elem": float(t[2]), "inf": float(t[3])},
+                   "relu_mask_flips_max_per_rank": int(t[4]),
+                   "W_grad": {**e_w, "elem_floor": w_floor}, "W_grad_vs_fp64_inf": {"gpu": gpu64, "oracle": orc64}}
+            rec["ok"] = bool(max(float(v) for v in t[:4]) <= self.TOL and e_w["elem"] <= self.TOL and e_w["inf"] <= self.TOL
+                             and gpu64 <= 2e-5)
+            log(f"[bench] parity vs the oracle's GLOBAL run (cut {self.cut:.3f}): {rec}")
+        dist.barrier()
+        return rec
+
+
 def emit(result: dict) -> None:
     """the ONE JSON line, last on stdout: libraries that write to C stdio (RCCL prints its library path
     there) sit in libc's buffer until exit and would otherwise land after it"""
@@ -216,6 +328,103 @@ def emit(result: dict) -> None:
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(result), flush=True)
+
+
+def launch_ranks(args, argv, entry=None) -> int:
+    """`python bench.py --gpus N` without ranks from outside: start them.  This parent imports no torch and calls no
+    GPU API (a process that has touched the GPU must never be replaced or forked into ranks on this pool); every rank
+    is a FRESH interpreter in a session of its own.  Rank 0's stdout is collected (its last JSON line is relayed as
+    this process's last stdout line), everything else of every rank goes to stderr.  Supervision: the first rank that
+    exits non-zero, or the wall-clock deadline, ends the run -- the remaining ranks (exactly the process groups started
+    here) get SIGTERM, then SIGKILL, and the exit status is non-zero.  That is also the watchdog the RCCL transport
+    lacks on its own (a rank waiting in a collective for a dead peer has no deadline inside RCCL).
+    entry: the rank program (default: this file; the CPU tests of the supervision pass a stand-in)."""
+    import signal
+    import socket
+    import subprocess
+
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    nonce = f"{os.getpid()}-{int(time.time())}"
+    procs, lines = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAIB_LAUNCH_NONCE=nonce)
+        procs.append(subprocess.Popen([sys.executable, str(entry or Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
+                                      start_new_session=True))
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line.rstrip("\n"))
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)  # the session (= process group) started above, nothing else
+                except ProcessLookupError:
+                    pass
+
+    def on_signal(signum, frame):
+        log(f"[bench launcher] signal {signum}: stopping the ranks")
+        stop_all(signal.SIGTERM)
+        time.sleep(2)
+        stop_all(signal.SIGKILL)
+        os._exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    deadline = time.time() + args.deadline_s
+    rc, why = 0, ""
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = (bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]), f"rank {bad[0][0]} exited with {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc, why = 124, f"deadline of {args.deadline_s:.0f} s passed (ranks still running: " \
+                           f"{[r for r, c in enumerate(codes) if c is None]})"
+            break
+        time.sleep(0.1)
+    if rc:
+        log(f"[bench launcher] {why}: stopping the other ranks")
+        stop_all(signal.SIGTERM)
+        t_end = time.time() + 10
+        while time.time() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(0.1)
+        stop_all(signal.SIGKILL)
+    th.join(timeout=10)
+    out = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not out or l is not out[-1]:
+            log(l)
+    if rc == 0 and not out:
+        log("[bench launcher] rank 0 printed no JSON line")
+        rc = 1
+    if out and (rc == 0 or procs[0].poll() in (3, 4)):  # 3 / 4: rank 0's own verdict on a record it DID emit
+        print(out[-1], flush=True)
+    return rc
+
+
+def _arm_deadline(seconds: float, rank: int) -> None:
+    """inside a rank: a collective that waits for a dead peer never returns (RCCL has no deadline of its own), so the
+    rank ends itself when the run's deadline passes -- under torch.distributed.run that ends the job as well"""
+    def fire():
+        log(f"[bench r{rank}] deadline of {seconds:.0f} s passed: exiting 124")
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
 
 
 def main():
@@ -231,33 +440,56 @@ def main():
     ap.add_argument("--cut-fraction", type=float, default=None,
                     help="N>1, weak scaling: fraction of each partition's edges that cross partitions (default: 0.1 as "
                          "`value` and (N-1)/N as config.random_order, both in one run)")
-    ap.add_argument("--workload", choices=["gcn-products", "gat-reddit"], default="gcn-products",
+    ap.add_argument("--workload", choices=["gcn-products", "gat-reddit", "gcn-papers"], default="gcn-products",
                     help="gcn-products: BASELINE's headline (default).  gat-reddit: BASELINE config 4, one 8-head GAT layer "
-                         "64 -> 64 forward + backward on the reddit-shaped graph (same JSON schema)")
+                         "64 -> 64 forward + backward on the reddit-shaped graph (same JSON schema; one GPU).  gcn-papers: "
+                         "BASELINE config 5's layer, GCN 128 -> 128 on the ogbn-papers100M-shaped graph, one vertex range of "
+                         "1/8 of it per GPU (N = 8: the whole graph), halo rows + dW over the collectives")
+    ap.add_argument("--check-oracle", action="store_true",
+                    help="N>1 (or gcn-papers): compare every rank's forward output, input gradient and the summed weight "
+                         "gradient element-wise with the oracle's run on the GLOBAL graph (sizes the host finishes in "
+                         "seconds: use --scale); exit code 3 above 1e-4")
+    ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("GAIB_BENCH_DEADLINE_S", "1500")),
+                    help="wall-clock limit of an N>1 run: the launcher stops all ranks, a rank ends itself")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = one products-shaped vertex range per GPU; strong = the single-GPU bench graph "
                          "partitioned N ways")
     args = ap.parse_args()
+    if args.workload == "gat-reddit" and args.gpus > 1:
+        ap.error("--workload gat-reddit is a one-GPU workload (config 4); N > 1 runs gcn-products or gcn-papers")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))  # no torch, no GPU API in this process
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1:
-        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.gpus != world:
+        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: give bench.py the ranks (torch.distributed.run "
+            f"--nproc-per-node {args.gpus}) or none at all (it starts them itself)")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev
+    if world > 1:
+        _arm_deadline(args.deadline_s, rank)
+        if world > ndev and "GAIB_DIST_BACKEND" not in os.environ:
+            # ranks share devices (a one-GPU box): RCCL refuses that by design, the peer-to-peer pull transport does not
+            os.environ["GAIB_DIST_BACKEND"] = "ipc"
+            log(f"[bench r{rank}] {world} ranks on {ndev} device(s): data path = gaib_comm/ipc (several ranks per device)")
+    torch.cuda.set_device(device)
 
     from graphaibench_amd import capi, layers as L, synth
 
-    ctx = L.init(local_rank)
+    ctx = L.init(device)
     for kv in filter(None, os.environ.get("GAIB_OPTS", "").split(",")):  # development knobs: GAIB_OPTS="key=value,..."
         k, v = kv.split("=")
         ctx.set_option(k.strip(), int(v))
         log(f"[bench] option {k.strip()} = {int(v)}")
 
-    if world > 1 or os.environ.get("GAIB_FORCE_DIST") == "1":  # the env knob runs the N>1 code on one GPU
+    # the env knob runs the N>1 code on one GPU; config 5's workload is defined on the partitioned path at any N
+    if world > 1 or os.environ.get("GAIB_FORCE_DIST") == "1" or args.workload == "gcn-papers":
         import torch.distributed as dist
         from graphaibench_amd import dist as gdist
 
@@ -268,14 +500,31 @@ def main():
         # ranks timing): gloo over 127.0.0.1 unless the data path is torch's nccl
         backend = os.environ.get("GAIB_DIST_BACKEND", "rccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log)
+        make_check = None
+        if args.check_oracle:
+            make_check = lambda shape, cut, comm: DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, args, rank, world,
+                                                                  shape, cut)
+        result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check)
         dist.barrier()
+        rc = 0
         if rank == 0:
+            cfg = result["config"]
+            cfg["launcher"] = ("bench.py itself (parent without GPU state, fresh rank processes, supervised)"
+                               if os.environ.get("GAIB_LAUNCH_NONCE") else "ranks given from outside (torch.distributed.run)")
+            # a record that says RCCL must have been carried by all N ranks (never a silent subset)
+            if cfg["transport"].startswith("gaib_comm/rccl") and cfg["rccl_ranks"] != world:
+                log(f"[bench] transport {cfg['transport']} but rccl_ranks = {cfg['rccl_ranks']} != {world}")
+                rc = 4
+            if result.get("parity") is not None and not result["parity"]["ok"]:
+                log("[bench] PARITY FAILED (> 1e-4)")
+                rc = 3
             emit(result)
         dist.destroy_process_group()
+        if rc:
+            sys.exit(rc)
         return
 
     if args.workload == "gat-reddit":

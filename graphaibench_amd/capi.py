@@ -111,6 +111,8 @@ SIGNATURES = {
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "gaib_device_count": (_i, [C.POINTER(_i)]),
+    "gaib_comm_transport_available": (_i, [_i]),
     "gaib_comm_unique_id": (_i, [_i, _vp]),
     "gaib_comm_init": (_i, [_vp, _i, _i, _vp, _i, _pp]),
     "gaib_comm_destroy": (_i, [_vp]),
@@ -140,6 +142,11 @@ COMM_RCCL, COMM_IPC = 0, 1
 COMM_ID_BYTES = 128
 
 
+def comm_transport_available(transport: int = COMM_RCCL) -> bool:
+    """local and cheap: can this process use the transport (RCCL: librccl loads with every entry point)"""
+    return load().gaib_comm_transport_available(transport) == 0
+
+
 def comm_unique_id(transport: int = COMM_RCCL) -> bytes:
     """called by ONE rank; the bytes travel to the others by whatever the launcher has (a file, torch's store ...)"""
     buf = C.create_string_buffer(COMM_ID_BYTES)
@@ -156,6 +163,11 @@ class Comm:
         h = C.c_void_p()
         _check(self.lib.gaib_comm_init(ctx.h, rank, nranks, C.c_char_p(unique_id), transport, C.byref(h)), "gaib_comm_init")
         self.h = h
+
+    @property
+    def size(self) -> int:
+        """ranks of the communicator as the transport itself reports them (RCCL: ncclCommCount)"""
+        return int(self.lib.gaib_comm_size(self.h))
 
     def barrier(self):
         _check(self.lib.gaib_comm_barrier(self.h), "gaib_comm_barrier")

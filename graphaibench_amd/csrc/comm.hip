@@ -42,6 +42,8 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -71,6 +73,8 @@ int rccl_load() {
   GAIB_SYM(GetUniqueId, "ncclGetUniqueId")
   GAIB_SYM(CommInitRank, "ncclCommInitRank")
   GAIB_SYM(CommDestroy, "ncclCommDestroy")
+  GAIB_SYM(CommCount, "ncclCommCount")
+  GAIB_SYM(CommUserRank, "ncclCommUserRank")
   GAIB_SYM(GetErrorString, "ncclGetErrorString")
   GAIB_SYM(AllReduce, "ncclAllReduce")
   GAIB_SYM(Send, "ncclSend")
@@ -139,7 +143,7 @@ struct gaib_comm {
   ShmSeg* seg;
   char shm_name[80];
   uint32_t sense;
-  int n_halos;
+  uint32_t halo_slots;  // bitmap of the slot rows in use (plans are created and destroyed collectively: same bits on every rank)
   float* h_stage;  // pinned staging for the IPC all-reduce
 };
 
@@ -153,6 +157,11 @@ struct gaib_halo {
   size_t send_cap;
   float* table;
   size_t table_cap;
+  // IPC: which ALLOCATION of each buffer the peers hold a handle of.  Either entry point may reallocate either buffer
+  // (an exchange reserves the table, a reduce lands its arrivals in the send buffer), so "did MY reserve() reallocate"
+  // is not the question -- "is the published allocation still the current one" is.
+  uint64_t send_serial, table_serial;          // bumped by every (re)allocation
+  uint64_t pub_send_serial, pub_table_serial;  // allocation the handle in the segment belongs to (0 = none)
   int pending_len;
   struct Peer {
     uint64_t gen;
@@ -200,7 +209,7 @@ int fail(gaib_comm* c, int rc) {  // tell the peers, keep the message
   return rc;
 }
 
-int reserve(float** p, size_t* cap, size_t bytes, hipStream_t s) {
+int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t s) {
   if (bytes <= *cap && *p) return 0;
   if (*p) {
     GAIB_HIP(hipStreamSynchronize(s));
@@ -215,10 +224,19 @@ int reserve(float** p, size_t* cap, size_t bytes, hipStream_t s) {
     return GAIB_ERR_NOMEM;
   }
   *cap = want;
+  ++*serial;
   return 1;  // (re)allocated
 }
 
 }  // namespace
+
+// can this process use the transport at all?  (RCCL: the library loads and has every entry point.)  Cheap and local:
+// what ranks agree on BEFORE anybody enters the collective, deadline-less ncclCommInitRank.
+extern "C" int gaib_comm_transport_available(int transport) {
+  if (transport == GAIB_COMM_IPC) return GAIB_OK;
+  GAIB_CHECK(transport == GAIB_COMM_RCCL, "gaib_comm_transport_available: unknown transport %d", transport);
+  return rccl_load();
+}
 
 extern "C" int gaib_comm_unique_id(int transport, void* h_id) {
   GAIB_CHECK(h_id, "gaib_comm_unique_id: h_id is NULL");
@@ -277,6 +295,17 @@ extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h
       delete c;
       return GAIB_ERR_COMM;
     }
+    // what RCCL itself says it built: gaib_comm_size reports THIS (bench.py's config.rccl_ranks), not the argument
+    int cnt = -1, me = -1;
+    if (g_rccl.CommCount(c->nccl, &cnt) != ncclSuccess || g_rccl.CommUserRank(c->nccl, &me) != ncclSuccess || cnt != nranks ||
+        me != rank) {
+      gaib_set_error("gaib_comm_init: RCCL built a communicator of %d ranks (this one: %d), asked for rank %d of %d", cnt, me,
+                     rank, nranks);
+      (void)g_rccl.CommDestroy(c->nccl);
+      delete c;
+      return GAIB_ERR_COMM;
+    }
+    c->nranks = cnt;
     *out = c;
     return GAIB_OK;
   }
@@ -453,13 +482,15 @@ extern "C" int gaib_allreduce_host_f64(gaib_comm* c, double* h_buf, int n) {
 extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, const int64_t* send_idx, int idx_on_device,
                                 const int64_t* h_recv_counts, gaib_halo** out) {
   GAIB_CHECK(c && h_send_counts && h_recv_counts && out, "gaib_halo_create: NULL argument");
-  GAIB_CHECK(c->n_halos < GAIB_COMM_MAX_HALOS, "gaib_halo_create: at most %d halo plans per communicator", GAIB_COMM_MAX_HALOS);
+  int slot = 0;
+  while (slot < GAIB_COMM_MAX_HALOS && (c->halo_slots >> slot & 1u)) slot++;
+  GAIB_CHECK(slot < GAIB_COMM_MAX_HALOS, "gaib_halo_create: at most %d halo plans alive per communicator", GAIB_COMM_MAX_HALOS);
   GAIB_HIP(hipSetDevice(c->ctx->device));
   gaib_halo* h = new (std::nothrow) gaib_halo();
   GAIB_CHECK(h, "gaib_halo_create: out of memory");
   memset((void*)h, 0, sizeof(*h));
   h->c = c;
-  h->id = c->n_halos++;
+  h->id = slot;  // taken (bit set) only once every argument check has passed
   h->send_off[0] = h->recv_off[0] = 0;
   for (int r = 0; r < c->nranks; r++) {
     if (h_send_counts[r] < 0 || h_recv_counts[r] < 0 || (r == c->rank && (h_send_counts[r] || h_recv_counts[r]))) {
@@ -487,6 +518,7 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
       return GAIB_ERR_HIP;
     }
   }
+  c->halo_slots |= 1u << slot;
   *out = h;
   return GAIB_OK;
 }
@@ -508,6 +540,7 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (h->d_send_idx) (void)hipFree(h->d_send_idx);
   if (h->sendbuf) (void)hipFree(h->sendbuf);
   if (h->table) (void)hipFree(h->table);
+  c->halo_slots &= ~(1u << h->id);  // after the barrier above: the slot row can serve the next plan
   delete h;
   return GAIB_OK;
 }
@@ -528,9 +561,9 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
   GAIB_CHECK(n_send == 0 || d_rows, "gaib_halo_exchange_begin: d_rows is NULL");
   const size_t row_bytes = sizeof(float) * (size_t)len;
-  int ra = reserve(&h->sendbuf, &h->send_cap, row_bytes * (size_t)n_send, ctx->stream);
+  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream);
   if (ra < 0) return fail(c, ra);
-  int rb = reserve(&h->table, &h->table_cap, row_bytes * (size_t)n_recv, ctx->stream);
+  int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream);
   if (rb < 0) return fail(c, rb);
   if (n_send) {
     int rc = gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
@@ -558,7 +591,7 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   }
   // ---- IPC pull ----
   ShmSlot* mine = &c->seg->slot[h->id][c->rank];
-  if (ra == 1 || mine->gen == 0) {
+  if (h->pub_send_serial != h->send_serial) {  // also after a gaib_halo_reduce grew the send buffer
     hipError_t e = hipIpcGetMemHandle(&mine->handle, h->sendbuf);
     if (e != hipSuccess) {
       gaib_set_error("gaib_halo_exchange_begin: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
@@ -568,6 +601,7 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
     mine->device = ctx->device;
     for (int r = 0; r <= c->nranks; r++) mine->send_off[r] = h->send_off[r];
     mine->gen++;
+    h->pub_send_serial = h->send_serial;
   }
   hipError_t e = hipEventSynchronize(c->ev_ready);  // the pack is done: peers may read the buffer
   if (e != hipSuccess) {
@@ -654,7 +688,7 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
   GAIB_CHECK((n_recv == 0 || d_halo_rows) && (n_send == 0 || d_rows), "gaib_halo_reduce: NULL rows");
   const size_t row_bytes = sizeof(float) * (size_t)len;
-  int ra = reserve(&h->sendbuf, &h->send_cap, row_bytes * (size_t)n_send, ctx->stream);  // arrivals land here
+  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream);  // arrivals land here
   if (ra < 0) return fail(c, ra);
   if (c->transport == GAIB_COMM_RCCL) {
     GAIB_HIP(hipEventRecord(c->ev_ready, ctx->stream));
@@ -676,16 +710,17 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   } else {
     // IPC: stage the partial rows in this plan's own table allocation (a whole allocation can be exported), publish it,
     // and let the owners pull their segments
-    int rb = reserve(&h->table, &h->table_cap, row_bytes * (size_t)n_recv, ctx->stream);
+    int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream);
     if (rb < 0) return fail(c, rb);
     hipError_t e = hipSuccess;
     if (n_recv && d_halo_rows != h->table)
       e = hipMemcpyAsync(h->table, d_halo_rows, row_bytes * (size_t)n_recv, hipMemcpyDeviceToDevice, ctx->stream);
     ShmSlot* mine = &c->seg->slot[h->id][c->rank];
-    if (e == hipSuccess && (rb == 1 || mine->gen_t == 0)) {
+    if (e == hipSuccess && h->pub_table_serial != h->table_serial) {  // also after an exchange grew the table
       e = hipIpcGetMemHandle(&mine->handle_t, h->table);
       for (int r = 0; r <= c->nranks; r++) mine->recv_off[r] = h->recv_off[r];
       mine->gen_t++;
+      h->pub_table_serial = h->table_serial;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {

@@ -86,6 +86,11 @@ struct gaib_ctx {
   int graph_rev_search;      // 1 = reverse-edge permutation by per-edge binary search (the reference's way) instead of the sort
   hipStream_t owned_stream;  // gaib_ctx_own_stream: a stream the context created (destroyed with it), else NULL
   int capturing;             // 1 between gaib_capture_begin and gaib_capture_end: calls are recorded into a HIP graph, nothing runs
+  // recorded sequences (gaib_exec) freeze the ws / pad pointers of their capture in their kernel nodes: while any of
+  // them is alive a workspace that has to grow is RETIRED (kept allocated) instead of freed, and released with the
+  // last exec or the context
+  int live_execs;
+  std::vector<void*> retired;
   // in-stream kernel timing (gaib_prof_*)
   int prof_on;
   struct ProfRec { const char* key; hipEvent_t a, b; };

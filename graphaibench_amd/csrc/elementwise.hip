@@ -680,6 +680,7 @@ extern "C" int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_i
                                 const float* d_in, float* d_out) {
   GAIB_CHECK(ctx && ((d_idx && d_in && d_out) || n_idx == 0), "gaib_gather_rows: NULL argument");
   if (n_idx <= 0 || len <= 0) return GAIB_OK;
+  ProfScope prof(ctx, "gather_rows");
   const bool vec_ok = (len % 4 == 0) && ((((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0);
   if (vec_ok) {
     const int n4 = len / 4;

@@ -19,6 +19,13 @@ void gaib_set_error(const char* fmt, ...) {
 extern "C" const char* gaib_last_error(void) { return g_err; }
 extern "C" const char* gaib_version(void) { return "graphaibench_amd 0.1 (gfx950)"; }
 
+extern "C" int gaib_device_count(int* h_count) {
+  GAIB_CHECK(h_count, "gaib_device_count: h_count is NULL");
+  *h_count = 0;
+  GAIB_HIP(hipGetDeviceCount(h_count));
+  return GAIB_OK;
+}
+
 extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   GAIB_CHECK(out != nullptr, "gaib_ctx_create: out is NULL");
   int ndev = 0;
@@ -65,6 +72,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_fused_unroll = 4;
   c->prof_on = 0;
   c->capturing = 0;
+  c->live_execs = 0;
   c->owned_stream = nullptr;
   *out = c;
   return GAIB_OK;
@@ -72,10 +80,13 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
 
 extern "C" int gaib_ctx_destroy(gaib_ctx* ctx) {
   if (!ctx) return GAIB_OK;
+  GAIB_CHECK(ctx->live_execs == 0, "gaib_ctx_destroy: %d recorded sequence(s) of this context are still alive "
+                                   "(gaib_exec_destroy them first: they hold its scratch pointers)", ctx->live_execs);
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->pad) (void)hipFree(ctx->pad);
   if (ctx->ws_side) (void)hipFree(ctx->ws_side);
+  for (void* p : ctx->retired) (void)hipFree(p);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -149,12 +160,25 @@ extern "C" int gaib_sync(gaib_ctx* ctx) {
   return GAIB_OK;
 }
 
+// A buffer whose address may sit in the kernel nodes of a recorded sequence must outlive that sequence: with execs
+// alive it is parked on ctx->retired (a replay keeps using it as ITS scratch, calls made outside the replay use the
+// new one -- scratch carries nothing from call to call), otherwise freed.
+static int release_or_retire(gaib_ctx* ctx, void* p) {
+  if (!p) return GAIB_OK;
+  if (ctx->live_execs > 0) {
+    ctx->retired.push_back(p);
+    return GAIB_OK;
+  }
+  GAIB_HIP(hipFree(p));
+  return GAIB_OK;
+}
+
 int gaib_ws_reserve(gaib_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return GAIB_OK;
   GAIB_NOT_WHILE_CAPTURING(ctx, "growing the workspace");
   // the old buffer may still be in use by enqueued kernels
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->ws) GAIB_HIP(hipFree(ctx->ws));
+  GAIB_TRY(release_or_retire(ctx, ctx->ws));
   ctx->ws = nullptr;
   ctx->ws_bytes = 0;
   size_t want = bytes + (bytes >> 2);
@@ -171,7 +195,7 @@ int gaib_pad_reserve(gaib_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pad_bytes) return GAIB_OK;
   GAIB_NOT_WHILE_CAPTURING(ctx, "growing the padded-table buffer");
   GAIB_HIP(hipStreamSynchronize(ctx->stream));  // the old buffer may still be read by enqueued kernels
-  if (ctx->pad) GAIB_HIP(hipFree(ctx->pad));
+  GAIB_TRY(release_or_retire(ctx, ctx->pad));
   ctx->pad = nullptr;
   ctx->pad_bytes = 0;
   hipError_t e = hipMalloc(&ctx->pad, bytes);
@@ -267,6 +291,7 @@ extern "C" int gaib_memcpy_d2h_async(gaib_ctx* ctx, void* h_pinned_dst, const vo
 // Pointers and scalar arguments are frozen at capture time: what changes from replay to replay must live in device
 // memory (gaib_adam_step_dev keeps the beta powers there; gaib_masked_*_dev leave their results there).
 struct gaib_exec {
+  gaib_ctx* ctx;  // the context it was recorded on (must outlive it: its retired workspaces are released with the last exec)
   hipGraph_t graph;
   hipGraphExec_t exec;
   int device;
@@ -313,6 +338,7 @@ extern "C" int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out) {
     return GAIB_ERR_HIP;
   }
   gaib_exec* x = new gaib_exec();
+  x->ctx = ctx;
   x->graph = g;
   x->exec = nullptr;
   x->device = ctx->device;
@@ -327,6 +353,7 @@ extern "C" int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out) {
     delete x;
     return GAIB_ERR_HIP;
   }
+  ctx->live_execs++;
   *out = x;
   return GAIB_OK;
 }
@@ -336,7 +363,7 @@ extern "C" int64_t gaib_exec_nodes(const gaib_exec* x) { return x ? (int64_t)x->
 extern "C" int gaib_exec_launch(gaib_ctx* ctx, gaib_exec* x) {
   GAIB_CHECK(ctx && x, "gaib_exec_launch: NULL argument");
   GAIB_CHECK(!ctx->capturing, "gaib_exec_launch: inside a capture");
-  GAIB_CHECK(x->device == ctx->device, "gaib_exec_launch: recorded on device %d, context on device %d", x->device, ctx->device);
+  GAIB_CHECK(x->ctx == ctx, "gaib_exec_launch: the sequence was recorded on another context (its scratch pointers belong there)");
   if (!x->ev0) {
     GAIB_HIP(hipEventCreate(&x->ev0));
     GAIB_HIP(hipEventCreate(&x->ev1));
@@ -362,6 +389,13 @@ extern "C" int gaib_exec_destroy(gaib_exec* x) {
   if (x->ev1) (void)hipEventDestroy(x->ev1);
   if (x->exec) (void)hipGraphExecDestroy(x->exec);
   if (x->graph) (void)hipGraphDestroy(x->graph);
+  gaib_ctx* ctx = x->ctx;
+  if (ctx && --ctx->live_execs == 0 && !ctx->retired.empty()) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);  // a replay that used them may still be running
+    for (void* p : ctx->retired) (void)hipFree(p);
+    ctx->retired.clear();
+  }
   delete x;
   return GAIB_OK;
 }

@@ -409,12 +409,31 @@ def make_comm(ctx, rank: int, world: int, log):
             return None, err or "a peer failed"
         return comm, ""
 
+    def rccl_possible():
+        """the cheap preconditions of ncclCommInitRank, agreed by all ranks BEFORE anybody enters it (the call is
+        collective and has no deadline: a rank that cannot load RCCL, or two ranks on one device, would leave the
+        others waiting inside it): librccl loads on every rank, and every rank has a device of its own"""
+        mine = [ctx.device, 1 if capi.comm_transport_available(capi.COMM_RCCL) else 0]
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if not all(e[1] for e in every):
+            return False, "librccl.so.1 does not load on rank(s) " + str([r for r, e in enumerate(every) if not e[1]])
+        if len({e[0] for e in every}) != world:
+            return False, f"ranks share devices ({[e[0] for e in every]}): RCCL wants one GPU per rank"
+        return True, ""
+
     # rccl (default): if it cannot be set up on some rank, the peer-to-peer pull transport (hipIpc handles, device-to-
     # device copies over xGMI) is tried before torch.distributed carries the rows
     order = [capi.COMM_IPC] if backend == "ipc" else [capi.COMM_RCCL, capi.COMM_IPC]
     failed = []
     for transport in order:
         name = "ipc" if transport == capi.COMM_IPC else "rccl"
+        if transport == capi.COMM_RCCL:
+            ok, err = rccl_possible()
+            if not ok:
+                log(f"[bench r{rank}] gaib_comm(rccl) not attempted: {err}")
+                failed.append("rccl")
+                continue
         comm, err = attempt(transport)
         if comm is not None:
             note = f" (after {', '.join(failed)} failed at set-up)" if failed else ""
@@ -425,8 +444,10 @@ def make_comm(ctx, rank: int, world: int, log):
     return None, f"torch.distributed/{dist.get_backend()} (gaib_comm {', '.join(failed)} failed at set-up)"
 
 
-def _bench_case(ctx, comm, args, rank, world, D, log, rows, label):
-    """one timed case: partition `rows`, build the layer, warm up, time args.steps steps"""
+def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None):
+    """one timed case: partition `rows`, build the layer, warm up, time args.steps steps.
+    check(part, layer, feat_out, grad_out, inputs): bench.py's comparison with the oracle's GLOBAL run (test
+    infrastructure stays outside this package); the layer then runs on inputs(rank, nv) -> (x, grad_in) host arrays"""
     from . import layers as L
 
     t0 = time.time()
@@ -438,8 +459,14 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label):
     nv = part.n_own
     torch.manual_seed(43 + rank)
     layer = L.Layer(L.GCN, 1, nv, D, D, dg.lgraph, act=True, lr=0.01)
-    layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda"))
-    layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda"))
+    if check is not None:
+        x_h, gin_h = check.inputs(rank, nv)
+        layer.write(L.FEAT_IN, torch.from_numpy(x_h).cuda())
+        layer.write(L.GRAD_IN, torch.from_numpy(gin_h).cuda())
+        del x_h, gin_h
+    else:
+        layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda"))
+        layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda"))
     feat_out = torch.empty(nv, D, device="cuda")
     grad_out = torch.empty(nv, D, device="cuda")
 
@@ -465,7 +492,11 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label):
     ctx.prof_enable(False)
     n_light, ms_light = ctx.prof_get("spmm_light")
     n_fused, ms_fused = ctx.prof_get("spmm_gemm_fused")
+    n_heavy, ms_heavy = ctx.prof_get("spmm_heavy")
+    n_gemm, ms_gemm = ctx.prof_get("sgemm")
+    n_pack, ms_pack = ctx.prof_get("gather_rows")
     ctx.prof_reset()
+    parity = check(part, layer, feat_out, grad_out) if check is not None else None
     # diagnostics outside the timed region (collective: every rank runs them): one halo exchange of a [nv x D]
     # matrix on its own (pack + all-to-all + wait) and the pack alone -- what the owned-edge SpMM has to hide
     bytes_timed = dg.ex.bytes_sent
@@ -511,14 +542,19 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label):
     res = dict(elapsed=float(t[0]), exch_ms=float(t[1]), pack_ms=float(t[2]), total_edges=float(e[0]),
                halo_rows_total=int(e[1]), halo_bytes_per_step_total=float(e[2]) / args.steps, nv=nv,
                owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
-               avg_ms=avg_ms, launches=n_dom,
+               avg_ms=avg_ms, launches=n_dom, parity=parity,
+               # rank 0's kernels per step: the owned-column pass, the halo-column half (fused with the dense product),
+               # heavy rows, the weight gradient, the pack of the rows on the send lists
+               breakdown=dict(owned_edge_spmm_ms=ms_light / args.steps, halo_half_ms=ms_fused / args.steps,
+                              heavy_rows_ms=ms_heavy / args.steps, sgemm_ms=ms_gemm / args.steps,
+                              pack_ms=ms_pack / args.steps),
                value=2 * float(e[0]) * args.steps / float(t[0]), ms_per_step=float(t[0]) / args.steps * 1e3)
     del layer, feat_out, grad_out, dg
     torch.cuda.empty_cache()
     return res
 
 
-def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
+def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=None):
     """bench.py's N > 1 leg.  GCN hidden layer D -> D forward + backward per step, halo exchange before each of the 2
     SpMM, one all-reduce of dW per step.
 
@@ -527,12 +563,18 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
     ends are measured in one invocation: `value` at --cut-fraction (default 0.1, a locality-preserving order) and
     `config.random_order` at (N-1)/N (a random vertex order: the adversarial end).
     --scaling strong: the SAME 2.45 M-vertex products-shaped graph of the single-GPU bench, partitioned N ways by
-    vertex range (its vertex order is random, so the cut is (N-1)/N)."""
+    vertex range (its vertex order is random, so the cut is (N-1)/N).
+    --workload gcn-papers (BASELINE config 5): the same layer on the ogbn-papers100M-shaped graph, one vertex range of
+    1/8 of it per rank -- at N = 8 the whole 111 M-vertex / 3.2 G-edge graph -- again at both ends of the partition-quality
+    axis.  make_check(shape, cut) -> bench.py's oracle comparison for one case (--check-oracle), or None."""
     import os
 
     from . import capi, synth
 
     comm, transport = make_comm(ctx, rank, world, log)
+    papers = getattr(args, "workload", "gcn-products") == "gcn-papers"
+    shape = "ogbn-papers100M/8" if papers else "ogbn-products"
+    mk = (lambda c: make_check(shape, c, comm)) if make_check is not None else (lambda c: None)
     # the xGMI link, measured (rank 0 while the others wait): replaces the 153 GB/s spec constant in the record
     link = None
     if rank == 0 and torch.cuda.device_count() >= 2:
@@ -560,32 +602,47 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
         rows = synth.BlockRows((rp_all[lo:hi + 1] - e0).contiguous(), ci_all[e0:e1].contiguous(), n_global, hi - lo)
         del rp_all, ci_all, sg
         torch.cuda.empty_cache()
+        assert not papers, "--scaling strong partitions the single-GPU products graph; gcn-papers is defined per range"
         main = _bench_case(ctx, comm, args, rank, world, D, log, rows, "strong scaling, products graph")
         workload = (f"the single-GPU bench's ogbn-products-shaped graph (seed 42, random vertex order) partitioned into "
                     f"{world} vertex ranges, GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
         cut_main = (world - 1) / world
     else:
-        rows = synth.block_rows("ogbn-products", rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
+        rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
                                 selfloops=True)  # GCN aggregates over A + I (net.cpp:96)
-        main = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}")
+        main = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}", check=mk(cut))
         del rows
         torch.cuda.empty_cache()
         cut_main = cut
-        workload = ("block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
-                    "GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
-        if os.environ.get("GAIB_BENCH_RANDOM_ORDER", "1") != "0" and args.cut_fraction is None:
+        if papers:
+            workload = (f"BASELINE config 5: block Chung-Lu graph of {world} vertex range(s), each 1/8 of the ogbn-papers100M "
+                        f"shape (seed 42; N = 8: 111 M vertices, 3.2 G edges), GCN hidden layer 128->128 fwd+bwd, halo "
+                        f"exchange before each SpMM + dW all-reduce")
+        else:
+            workload = ("block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
+                        "GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
+        if os.environ.get("GAIB_BENCH_RANDOM_ORDER", "1") != "0" and args.cut_fraction is None and world > 1:
             rcut = (world - 1) / world
-            rows = synth.block_rows("ogbn-products", rank, world, seed=42, cut_fraction=rcut, device="cuda",
+            rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=rcut, device="cuda",
                                     scale=args.scale, selfloops=True)
-            r = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"random order, cut {rcut:.3f}")
+            r = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"random order, cut {rcut:.3f}", check=mk(rcut))
             extra = {"cut_fraction": rcut, "value": r["value"], "ms_per_step": r["ms_per_step"],
                      "halo_rows_total": r["halo_rows_total"], "halo_bytes_per_step_total": r["halo_bytes_per_step_total"],
                      "halo_exchange_standalone_ms": r["exch_ms"], "halo_pack_ms": r["pack_ms"],
-                     "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"]}
+                     "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"],
+                     "breakdown_ms_per_step_rank0": r["breakdown"], "parity": r["parity"]}
     achieved = main["alg_bytes"] / (main["avg_ms"] * 1e-3) / 1e9 if main["avg_ms"] > 0 else 0.0
     if comm is not None:
         comm.barrier()
+    rccl_ranks = comm.size if (comm is not None and transport.startswith("gaib_comm/rccl")) else 0
+    parity = main["parity"]
+    if extra is not None:
+        rp = extra.pop("parity", None)
+        if parity is not None and rp is not None:
+            parity = {**parity, "random_order": rp, "ok": bool(parity["ok"] and rp["ok"])}
+    res_parity = {"parity": parity} if parity is not None else {}
     return {
+        **res_parity,
         "metric": "GCN-layer fwd+bwd aggregated edges/sec",
         "value": main["value"],
         "unit": "edges/s",
@@ -607,8 +664,10 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log):
             # pack alone, and the owned-edge aggregation kernels of one step that run while the two exchanges fly
             "halo_exchange_standalone_ms": main["exch_ms"], "halo_pack_ms": main["pack_ms"],
             "owned_edge_spmm_ms_per_step": main["owned_edge_spmm_ms_per_step"],
+            "breakdown_ms_per_step_rank0": main["breakdown"],
             "parallelism": f"vertex-range x{world}",
-            "transport": transport, "rccl_ranks": world if transport.startswith("gaib_comm/rccl") else 0,
+            # rccl_ranks: what ncclCommCount reports for the communicator that carried the halo rows (0: RCCL not used)
+            "transport": transport, "rccl_ranks": rccl_ranks,
             # the other end of the partition-quality axis, same invocation (weak scaling only)
             "random_order": extra,
             "xgmi_link_probe": link,

@@ -54,7 +54,12 @@ gaib_ctx* gpu_context::get() {
   if (!g_ctx) {
     int dev = 0;
     if (const char* e = getenv("GAIB_DEVICE")) dev = atoi(e);
-    else if (const char* l = getenv("LOCAL_RANK")) dev = atoi(l);
+    else if (const char* l = getenv("LOCAL_RANK")) {
+      // rank -> device: round robin over the visible devices (more ranks than devices: a one-GPU box, peer-to-peer transport)
+      int ndev = 0;
+      check(gaib_device_count(&ndev), "gaib_device_count");
+      dev = ndev > 0 ? atoi(l) % ndev : 0;
+    }
     set(dev, nullptr);
   }
   return g_ctx;

@@ -20,9 +20,17 @@
 // travels from rank 0 to the others through the file GAIB_COMM_ID_FILE (default /dev/shm/gaib_id_<MASTER_PORT>).
 // Loss / accuracy are all-reduced; rank 0 prints the reference's log lines.  Any rank that fails exits non-zero and
 // the others follow (deadline in every wait).
+// One command for N GPUs: GAIB_RANKS=N bin/gpu_train_gcn <the reference's arguments> -- the process then is a LAUNCHER
+// (no GPU API is touched in it): it starts N copies of itself with RANK / WORLD_SIZE / LOCAL_RANK set and an id file of
+// this launch, forwards rank 0's output, and when a rank exits non-zero (or GAIB_RANKS_DEADLINE_S passes) stops the
+// others and exits non-zero -- one entry point drives all devices, as the reference's multi-GPU programs do from one
+// main (src/triangle/multigpu_induced.cu:31-84); RCCL itself has no deadline for a peer that died.
 #include <omp.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 #include "partition.h"
 #include "cutils.h"
@@ -109,12 +117,23 @@ struct Trainer {
     world = env_int("GAIB_WORLD", "WORLD_SIZE", 1);
     if (world <= 1) return;
     const char* tr = getenv("GAIB_COMM");
-    const int transport = (tr && std::string(tr) == "ipc") ? GAIB_COMM_IPC : GAIB_COMM_RCCL;
+    int transport = (tr && std::string(tr) == "ipc") ? GAIB_COMM_IPC : GAIB_COMM_RCCL;
+    int ndev = 0;
+    GAIB_OR_DIE(gaib_device_count(&ndev));
+    if (!tr && world > ndev) {  // ranks share devices (a one-GPU box): RCCL refuses that, the peer-to-peer pull does not
+      transport = GAIB_COMM_IPC;
+      if (rank == 0) std::cerr << world << " ranks on " << ndev << " device(s): GAIB_COMM=ipc\n";
+    }
     std::string path = getenv("GAIB_COMM_ID_FILE") ? getenv("GAIB_COMM_ID_FILE")
                                                   : std::string("/dev/shm/gaib_id_") +
                                                         (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "default");
     unsigned char id[GAIB_COMM_ID_BYTES];
+    // a file left behind by a crashed run under the same name must not be taken for this run's id: rank 0 removes
+    // the name before it draws the id, and the others ignore a file written well before they started (the launcher
+    // -- GAIB_RANKS, bench.py -- gives every launch a name of its own, so this only matters for hand-started ranks)
+    const time_t started = time(nullptr);
     if (rank == 0) {
+      unlink(path.c_str());
       GAIB_OR_DIE(gaib_comm_unique_id(transport, id));
       const std::string tmp = path + ".tmp";
       FILE* f = fopen(tmp.c_str(), "wb");
@@ -128,7 +147,8 @@ struct Trainer {
       const double deadline = omp_get_wtime() + 120.0;
       size_t got = 0;
       while (omp_get_wtime() < deadline) {
-        FILE* f = fopen(path.c_str(), "rb");
+        struct stat st;
+        FILE* f = (stat(path.c_str(), &st) == 0 && st.st_mtime + 60 >= started) ? fopen(path.c_str(), "rb") : nullptr;
         if (f) {
           got = fread(id, 1, sizeof(id), f);
           fclose(f);
@@ -604,9 +624,91 @@ void print_timers() {
   std::cout << "--------------------\n";
 }
 
+// GAIB_RANKS=N: this process only starts and supervises the ranks.  Nothing here may touch the GPU (a process that
+// has initialised it must not fork ranks): plain fork + exec of this very binary, before any gaib_* call.
+int launch_ranks(int n, char** argv) {
+  const char* dl = getenv("GAIB_RANKS_DEADLINE_S");
+  const double deadline_s = dl ? atof(dl) : 0.0;  // 0: none (training runs have no natural bound); a dead rank still ends the job
+  char idfile[96], nbuf[16];
+  snprintf(idfile, sizeof(idfile), "/dev/shm/gaib_id_%d_%ld", (int)getpid(), (long)time(nullptr));
+  snprintf(nbuf, sizeof(nbuf), "%d", n);
+  std::vector<pid_t> pids(n, -1);
+  for (int r = 0; r < n; r++) {
+    pid_t p = fork();
+    if (p < 0) {
+      perror("fork");
+      for (int q = 0; q < r; q++) kill(pids[q], SIGKILL);
+      return 1;
+    }
+    if (p == 0) {
+      char rbuf[16];
+      snprintf(rbuf, sizeof(rbuf), "%d", r);
+      setenv("RANK", rbuf, 1);
+      setenv("LOCAL_RANK", rbuf, 1);
+      setenv("WORLD_SIZE", nbuf, 1);
+      if (!getenv("GAIB_COMM_ID_FILE")) setenv("GAIB_COMM_ID_FILE", idfile, 1);
+      unsetenv("GAIB_RANKS");
+      execv("/proc/self/exe", argv);
+      perror("execv");
+      _exit(127);
+    }
+    pids[r] = p;
+  }
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  int alive = n, rc = 0;
+  while (alive > 0 && rc == 0) {
+    int st = 0;
+    pid_t p = waitpid(-1, &st, WNOHANG);
+    if (p > 0) {
+      for (int r = 0; r < n; r++)
+        if (pids[r] == p) {
+          pids[r] = -1;
+          alive--;
+          const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+          if (code != 0) {
+            fprintf(stderr, "[launcher] rank %d exited with %d: stopping the other ranks\n", r, code);
+            rc = code;
+          }
+        }
+      continue;
+    }
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (deadline_s > 0 && (t1.tv_sec - t0.tv_sec) > deadline_s) {
+      fprintf(stderr, "[launcher] GAIB_RANKS_DEADLINE_S = %.0f s passed: stopping the ranks\n", deadline_s);
+      rc = 124;
+    }
+    usleep(20000);
+  }
+  if (rc) {  // exactly the children started above
+    for (int r = 0; r < n; r++)
+      if (pids[r] > 0) kill(pids[r], SIGTERM);
+    for (int i = 0; i < 250 && alive > 0; i++) {
+      int st;
+      pid_t p = waitpid(-1, &st, WNOHANG);
+      if (p > 0) {
+        for (int r = 0; r < n; r++)
+          if (pids[r] == p) pids[r] = -1, alive--;
+      } else
+        usleep(20000);
+    }
+    for (int r = 0; r < n; r++)
+      if (pids[r] > 0) {
+        kill(pids[r], SIGKILL);
+        waitpid(pids[r], nullptr, 0);
+      }
+  }
+  unlink(idfile);
+  return rc;
+}
+
 }  // namespace
 
 int main(int argc, char* argv[]) {
+  if (const char* nr = getenv("GAIB_RANKS")) {
+    if (atoi(nr) > 1 && !getenv("RANK") && !getenv("GAIB_RANK")) return launch_ranks(atoi(nr), argv);
+  }
   if (argc <= 4 || (argc > 9 && argc != 13)) {
     std::cout << "Usage: ./train data num_epochs num_threads type_loss "
               << "hidden(16) score_drop_rate(0.) feat_drop_rate(0.) "

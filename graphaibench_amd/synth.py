@@ -19,6 +19,8 @@ SHAPES = {
     "reddit": (232_965, 114_615_892, 21_657, 602, 41),
     # symmetrised edge count as SURVEY.md 8 quotes it; the maximum degree is an assumption (not in the public stats)
     "ogbn-papers100M": (111_059_956, 3_231_371_744, 30_000, 128, 172),
+    # one of 8 vertex ranges of it (BASELINE config 5: "vertex-partitioned across 8 x MI355X"): block_rows' per-range shape
+    "ogbn-papers100M/8": (13_882_495, 403_921_468, 30_000, 128, 172),
     "cora": (2_708, 10_556, 168, 1433, 7),
     "tiny": (20_000, 400_000, 800, 32, 7),
 }

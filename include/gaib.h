@@ -48,6 +48,7 @@ const char* gaib_version(void);
  * replaces the static cuBLAS/cuSPARSE/cuRAND handle holder `gpu_context`
  * (include/gnn/gpu_context.h:4-16, src/utilities/random.cpp:62-80).
  * `stream` is a hipStream_t (NULL = the device's null stream); it is borrowed. */
+int gaib_device_count(int* h_count); /* visible devices (initialises the HIP runtime: rank processes only, never a launcher) */
 int gaib_ctx_create(int device, void* stream, gaib_ctx** out);
 int gaib_ctx_destroy(gaib_ctx* ctx);
 int gaib_ctx_set_stream(gaib_ctx* ctx, void* stream);
@@ -75,7 +76,11 @@ int gaib_side_wait(gaib_ctx* ctx);
  * gaib_memcpy_h2d/d2h, metrics with host results, a workspace or lazily built graph table that does not exist
  * yet): run the sequence once eagerly first.  Pointers and by-value scalars are frozen in the recording; per-replay
  * state lives in device memory (gaib_adam_step_dev, gaib_masked_*_dev, gaib_memcpy_d2h_async).  The context must
- * own a real stream (not the null stream), without a side section or kernel timing switched on. */
+ * own a real stream (not the null stream), without a side section or kernel timing switched on.
+ * Scratch: a recording holds the addresses of the context's internal workspaces.  While any gaib_exec of a context
+ * is alive, a workspace that has to grow (a later, larger call outside the replay) is kept allocated next to its
+ * replacement and released with the last gaib_exec -- replays stay valid.  A gaib_exec is launched on the context it
+ * was recorded on, and destroyed before it (gaib_ctx_destroy refuses otherwise). */
 typedef struct gaib_exec gaib_exec;
 int gaib_capture_begin(gaib_ctx* ctx);
 int gaib_capture_end(gaib_ctx* ctx, gaib_exec** out);
@@ -394,11 +399,15 @@ typedef struct gaib_halo gaib_halo;
 #define GAIB_COMM_ID_BYTES 128
 #define GAIB_COMM_RCCL 0
 #define GAIB_COMM_IPC 1
+/* local and cheap: GAIB_OK if this process can use the transport at all (RCCL: librccl.so.1 loads and has every entry
+ * point used here).  What the ranks agree on -- together with "every rank has a device of its own" -- BEFORE any of
+ * them enters gaib_comm_init(GAIB_COMM_RCCL): ncclCommInitRank is collective and has no deadline. */
+int gaib_comm_transport_available(int transport);
 int gaib_comm_unique_id(int transport, void* h_id);
 int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h_id, int transport, gaib_comm** out);
 int gaib_comm_destroy(gaib_comm* comm);
 int gaib_comm_rank(const gaib_comm* comm);
-int gaib_comm_size(const gaib_comm* comm);
+int gaib_comm_size(const gaib_comm* comm); /* RCCL: what ncclCommCount reports for the communicator that was built */
 int gaib_comm_barrier(gaib_comm* comm); /* syncs the compute stream first */
 /* in-place sum over ranks on the context's stream: the weight / alpha gradients of a layer (<= 256 KB each);
  * every rank ends with the same bits */
@@ -409,7 +418,9 @@ int gaib_allreduce_host_f64(gaib_comm* comm, double* h_buf, int n);
  *   h_send_counts[r] rows go to rank r: their local row ids are send_idx[sum(h_send_counts[:r]) ...] (host or device
  *   array, copied); h_recv_counts[r] rows arrive from rank r; both 0 for the rank itself.  The table an exchange fills
  *   is [sum(h_recv_counts) x len], grouped by source rank in rank order -- the order of the halo column ids of
- *   gaib_graph_create_rect's column space after the owned rows.  Collective; plans are numbered in creation order. */
+ *   gaib_graph_create_rect's column space after the owned rows.  Collective (create and destroy, in the same order
+ *   on every rank); at most 8 plans alive per communicator, a destroyed plan's slot is reused.  One plan serves any
+ *   mix of row lengths and directions: its buffers grow as needed and peers re-map them when they do. */
 int gaib_halo_create(gaib_comm* comm, const int64_t* h_send_counts, const int64_t* send_idx, int idx_on_device,
                      const int64_t* h_recv_counts, gaib_halo** out);
 int gaib_halo_destroy(gaib_halo* halo);

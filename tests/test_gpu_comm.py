@@ -172,6 +172,74 @@ def _gat_worker(rank, world, idfile, q, heads):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
+def _halo_realloc_worker(rank, world, idfile, q):
+    """raw halo plan: exchange and reverse exchange with GROWING row lengths in the order that left a stale hipIpc
+    handle behind (exchange 16, reduce 16, exchange 64, reduce 64: the reduce's table was reallocated by the exchange
+    before it, the exchange's send buffer by the reduce before it), and more plans over a communicator's life than it
+    has slot rows (ids are released by gaib_halo_destroy)"""
+    sys.path.insert(0, str(ROOT))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    try:
+        from graphaibench_amd import capi, layers as L
+
+        ctx = L.init(0)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, capi.COMM_IPC, capi), capi.COMM_IPC)
+        n_own = 5000
+        rng = np.random.default_rng(100)  # the same plan on every rank: rank r needs rows need[r][q] of rank q
+        need = [[np.sort(rng.choice(n_own, 700 + 50 * (r + q), replace=False)) if q != r else np.empty(0, np.int64)
+                 for q in range(world)] for r in range(world)]
+        send_idx = np.concatenate([need[q][rank] for q in range(world)]).astype(np.int64)  # grouped by destination
+        send_counts = [len(need[q][rank]) for q in range(world)]
+        recv_counts = [len(need[rank][q]) for q in range(world)]
+
+        def rows_of(r, length, salt):  # rank r's rows, reproducible on every rank
+            return np.random.default_rng(1000 * r + length + salt).standard_normal((n_own, length)).astype(np.float32)
+
+        def check(halo, length, salt):
+            mine = torch.from_numpy(rows_of(rank, length, salt)).cuda()
+            halo.begin(mine, length)
+            ptr = halo.end()
+            ctx.sync()
+            got = torch.empty(max(halo.rows, 1), length, device="cuda")
+            capi._check(ctx.lib.gaib_memcpy_d2d(ctx.h, got.data_ptr(), ptr, halo.rows * length * 4), "d2d")
+            ctx.sync()
+            want = np.concatenate([rows_of(q, length, salt)[need[rank][q]] for q in range(world)])
+            assert np.array_equal(got[:halo.rows].cpu().numpy(), want), f"exchange len {length}"
+            # reverse: every rank returns (its copy of the halo rows) * (rank + 1); owners add peer by peer
+            partial = got[:halo.rows] * float(rank + 1)
+            acc = torch.zeros(n_own, length, device="cuda")
+            halo.reduce(partial, acc, length)
+            ctx.sync()
+            want_acc = np.zeros((n_own, length), np.float32)
+            for q in range(world):
+                if q != rank:
+                    want_acc[need[q][rank]] += rows_of(rank, length, salt)[need[q][rank]] * np.float32(q + 1)
+            assert np.array_equal(acc.cpu().numpy(), want_acc), f"reduce len {length}"
+
+        halo = comm.halo(send_counts, send_idx, recv_counts)
+        for salt, length in enumerate((16, 16, 64, 8, 200)):
+            check(halo, length, salt)
+        halo.close()
+        for k in range(10):  # > GAIB_COMM_MAX_HALOS plans, one alive at a time
+            h2 = comm.halo(send_counts, send_idx, recv_counts)
+            check(h2, 24 + k, 50 + k)
+            h2.close()
+        with pytest.raises(capi.GaibError):  # a refused plan does not leak its slot
+            comm.halo([1] * world, send_idx, recv_counts)
+        alive = [comm.halo(send_counts, send_idx, recv_counts) for _ in range(8)]
+        with pytest.raises(capi.GaibError, match="at most 8"):
+            comm.halo(send_counts, send_idx, recv_counts)
+        check(alive[7], 32, 99)
+        for h in alive:
+            h.close()
+        comm.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
 def _spawn(world, target, args, timeout=600):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -193,6 +261,12 @@ def test_ipc_ranks_on_one_gpu_match_global_oracle(tmp_path, arch, world):
 @pytest.mark.parametrize("heads,world", [(1, 2), (8, 2), (8, 3)])
 def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world):
     res = _spawn(world, _gat_worker, (str(tmp_path / "id"), heads))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ipc_halo_buffers_regrow_between_exchange_and_reduce(tmp_path, world):
+    res = _spawn(world, _halo_realloc_worker, (str(tmp_path / "id"),))
     assert all(r[1] == "ok" for r in res), res
 
 

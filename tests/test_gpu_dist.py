@@ -117,3 +117,59 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
         assert cfg["random_order"]["value"] > 0 and cfg["random_order"]["halo_rows_total"] > cfg["halo_rows_total"]
     else:
         assert cfg["cut_fraction"] == 0.5 and cfg["random_order"] is None
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                              "MASTER_PORT", "GAIB_DIST_BACKEND", "GAIB_FORCE_DIST")}
+
+
+def test_bench_plain_invocation_config5_shape_matches_global_oracle():
+    """BASELINE config 5 as a test (reference shape: include/gnn/configs.h:8-11, "ogbn-papers100M"): `python bench.py
+    --gpus 4 --workload gcn-papers` INVOKED PLAINLY -- no ranks from outside, bench.py starts and supervises them -- on the
+    papers100M-shaped graph at 1/50 (2.2 M vertices, 64 M edges) as 4 vertex ranges / 4 processes sharing this box's GPU
+    over the peer-to-peer transport, both ends of the partition-quality axis; every rank's forward output and input
+    gradient and the summed weight gradient are compared ELEMENT-WISE with the oracle's run on the global graph."""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--workload", "gcn-papers", "--scale", "0.04",
+                        "--steps", "2", "--warmup", "1", "--check-oracle", "--deadline-s", "1000"],
+                       capture_output=True, text=True, timeout=1100, env=dict(_clean_env(), GAIB_COMM_TIMEOUT_S="300"))
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = r.stdout.strip().splitlines()[-1]
+    res = json.loads(line)
+    cfg, par = res["config"], res["parity"]
+    assert res["n_gpus"] == 4 and res["value"] > 0 and "config 5" in cfg["workload"]
+    assert cfg["launcher"].startswith("bench.py itself")
+    assert cfg["nv_per_gpu"] * 4 == pytest.approx(111_059_956 / 50, rel=0.01)
+    assert cfg["transport"].startswith("gaib_comm/ipc") and cfg["rccl_ranks"] == 0  # 4 ranks on one device
+    assert cfg["cut_fraction"] == 0.1 and cfg["random_order"]["cut_fraction"] == 0.75
+    assert cfg["random_order"]["halo_rows_total"] > cfg["halo_rows_total"] > 0
+    for rec in (par, par["random_order"]):
+        assert rec["ok"], rec
+        assert max(rec["forward"]["elem"], rec["forward"]["inf"], rec["grad_out"]["elem"], rec["grad_out"]["inf"],
+                   rec["W_grad"]["elem"], rec["W_grad"]["inf"]) <= 1e-4, rec
+        assert "GLOBAL graph" in rec["against"]
+    assert par["ok"]
+    bd = cfg["breakdown_ms_per_step_rank0"]
+    assert bd["owned_edge_spmm_ms"] > 0 and bd["halo_half_ms"] > 0 and bd["pack_ms"] > 0
+
+
+def test_bench_plain_two_gpus_default_workload():
+    """VERDICT r2 "done" line: `python3 bench.py --gpus 2 --scale 0.02` with a clean environment exits 0 on a one-GPU
+    box (peer-to-peer transport, named in config.transport) and prints one JSON line"""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1
+    res = json.loads(out[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["transport"].startswith("gaib_comm/")
+    if torch.cuda.device_count() < 2:
+        assert res["config"]["transport"].startswith("gaib_comm/ipc") and res["config"]["rccl_ranks"] == 0
+    else:
+        assert res["config"]["rccl_ranks"] in (0, 2)

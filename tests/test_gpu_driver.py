@@ -207,6 +207,42 @@ def test_driver_multi_rank_matches_single_rank(tmp_path, arch, world):
     assert "train_loss" not in outs[1][0]  # rank 0 prints the log lines
 
 
+@pytest.mark.parametrize("arch,world", [("gcn", 3), ("sage", 2)])
+def test_driver_one_command_launches_all_ranks(tmp_path, arch, world):
+    """GAIB_RANKS=N bin/gpu_train_*: ONE command, no RANK / WORLD_SIZE from outside -- the process is the launcher
+    (it touches no GPU API), starts N copies of itself, and rank 0's log equals the single-process run's.  With more
+    ranks than devices (this box: one GPU) the ranks agree on the peer-to-peer transport by themselves."""
+    root, x, labels, splits = make_dataset(tmp_path)
+    exe = ROOT / "bin" / f"gpu_train_{arch}"
+    cmd = [str(exe), "cora", "5", "2", "softmax", "16", "0", "0", "0.01", "2", "0", "4", "0"]
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GAIB_RANK", "GAIB_WORLD",
+                                                                "GAIB_COMM", "GAIB_DEVICE", "GAIB_COMM_ID_FILE")}
+    base = dict(clean, DATASET_PATH=root)
+    single = subprocess.run(cmd, capture_output=True, text=True, env=base, timeout=600)
+    assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-2000:]
+    want = re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", single.stdout)
+    multi = subprocess.run(cmd, capture_output=True, text=True, env=dict(base, GAIB_RANKS=str(world), GAIB_COMM_TIMEOUT_S="60"),
+                           timeout=600)
+    assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
+    got = re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", multi.stdout)
+    assert len(got) == 5 == len(want)
+    for (gl, ga), (wl, wa) in zip(got, want):
+        assert abs(float(gl) - float(wl)) <= 2e-3 and abs(float(ga) - float(wa)) <= 0.01, (got, want)
+    assert all(f"rank {r} of {world}: rows [" in multi.stdout for r in range(world)), multi.stdout[:3000]
+    if torch_device_count() < world:
+        assert "GAIB_COMM=ipc" in multi.stderr
+    # a rank that dies takes the job down with a non-zero status: an unreadable dataset on every rank
+    bad = subprocess.run([str(exe), "nosuch", "1", "1", "softmax"], capture_output=True, text=True,
+                         env=dict(base, GAIB_RANKS="2"), timeout=120)
+    assert bad.returncode != 0 and "[launcher] rank" in bad.stderr
+
+
+def torch_device_count() -> int:
+    import torch
+
+    return torch.cuda.device_count()
+
+
 def test_driver_rank_failure_exits_nonzero(tmp_path):
     """a rank whose peer never starts gives up after the deadline and exits non-zero (no hang)"""
     root, *_ = make_dataset(tmp_path)

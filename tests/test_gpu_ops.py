@@ -1237,6 +1237,40 @@ def test_capture_replay_equals_call_by_call(sctx):
     ex.close()
 
 
+def test_replay_survives_workspace_growth(sctx):
+    """a recorded sequence holds the workspace pointers of its capture (the split-K partials of the K = n weight
+    gradient): a LARGER call made between replays grows the workspace, which must not free what the recording points
+    at -- the retired buffer lives until the last gaib_exec is destroyed; a context refuses to die before its execs"""
+    n, d = 40000, 64
+    torch.manual_seed(5)
+    x = torch.randn(n, d, device="cuda")
+    g = torch.randn(n, d, device="cuda")
+    dW, dW_ref = torch.empty(d, d, device="cuda"), torch.empty(d, d, device="cuda")
+    sctx.sgemm(x, g, dW_ref, transA=True)  # eager once: the workspace exists at this size
+    sctx.sync()
+    sctx.capture_begin()
+    sctx.sgemm(x, g, dW, transA=True)
+    ex = sctx.capture_end()
+    ex.launch()
+    sctx.sync()
+    assert torch.equal(dW, dW_ref)
+    # a much larger split-K product: its partials do not fit the recorded workspace
+    big_x, big_g = torch.randn(1 << 21, 128, device="cuda"), torch.randn(1 << 21, 128, device="cuda")
+    big = torch.empty(128, 128, device="cuda")
+    sctx.sgemm(big_x, big_g, big, transA=True)
+    sctx.sync()
+    junk = torch.full((1 << 26,), float("nan"), device="cuda")  # lands on freed memory, if any was freed
+    torch.cuda.synchronize()
+    dW.zero_()
+    ex.launch()
+    sctx.sync()
+    assert torch.equal(dW, dW_ref)
+    del junk
+    with pytest.raises(capi.GaibError, match="recorded sequence"):
+        capi._check(sctx.lib.gaib_ctx_destroy(sctx.h), "gaib_ctx_destroy")
+    ex.close()
+
+
 def test_capture_refuses_calls_that_wait(sctx):
     x = torch.zeros(1 << 20, device="cuda")
     torch.cuda.synchronize()

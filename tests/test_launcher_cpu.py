@@ -1,0 +1,147 @@
+"""CPU suite: the one-command N-rank launchers (bench.py --gpus N without ranks from outside; GAIB_RANKS=N
+bin/gpu_train_*).  No GPU here, so the ranks are stand-in scripts (bench.py's launcher takes the rank program as an
+argument for exactly this) or fail at their first GPU call -- what is checked is the supervision: rank 0's JSON line is
+relayed last, the first failing rank ends the job with a non-zero status, the deadline ends a job that hangs, and no
+rank process is left behind (one entry point drives all ranks, /root/reference/src/triangle/multigpu_induced.cu:31-84)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import time
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def _args(n, deadline=60.0):
+    import argparse
+
+    return argparse.Namespace(gpus=n, deadline_s=deadline)
+
+
+def _alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    # a zombie of a session we do not parent would still count; the launcher reaps its own children
+    try:
+        return open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+    except FileNotFoundError:
+        return False
+
+
+def _run_launcher(tmp_path, body, n, deadline=60.0):
+    """run bench.launch_ranks in a child interpreter (it installs signal handlers) on a stand-in rank program"""
+    rank_prog = tmp_path / "rank.py"
+    rank_prog.write_text(textwrap.dedent(body))
+    driver = tmp_path / "drive.py"
+    driver.write_text(textwrap.dedent(f"""
+        import argparse, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        rc = bench.launch_ranks(argparse.Namespace(gpus={n}, deadline_s={deadline}), [{str(tmp_path)!r}], entry={str(rank_prog)!r})
+        sys.exit(rc)
+    """))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, timeout=120)
+    return r, time.time() - t0
+
+
+def test_launcher_relays_rank0_json_last_and_sets_rank_environment(tmp_path):
+    body = """
+        import json, os, sys
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["GAIB_LAUNCH_NONCE"]
+        open(os.path.join(sys.argv[1], f"pid{r}"), "w").write(str(os.getpid()))
+        print(f"chatter from rank {r}")
+        if r == 0:
+            print(json.dumps({"value": 1.0, "n_gpus": w}))
+    """
+    r, _ = _run_launcher(tmp_path, body, 3)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert json.loads(lines[-1]) == {"value": 1.0, "n_gpus": 3}
+    assert len(lines) == 1  # chatter of every rank went to stderr
+    assert "chatter from rank 0" in r.stderr and "chatter from rank 2" in r.stderr
+    assert sorted(p.name for p in tmp_path.glob("pid*")) == ["pid0", "pid1", "pid2"]
+
+
+def test_launcher_first_failing_rank_ends_the_job(tmp_path):
+    body = """
+        import os, sys, time
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{r}"), "w").write(str(os.getpid()))
+        if r == 1:
+            time.sleep(0.5)
+            sys.exit(7)
+        time.sleep(300)  # a rank waiting in a collective for the dead peer
+    """
+    r, took = _run_launcher(tmp_path, body, 3)
+    assert r.returncode == 7 and took < 30, (r.returncode, took, r.stderr)
+    assert "rank 1 exited with 7" in r.stderr
+    assert r.stdout.strip() == ""
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text())), f"rank process {f.name} survived the launcher"
+
+
+def test_launcher_deadline_ends_a_hanging_job(tmp_path):
+    body = """
+        import os, sys, time, signal
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{r}"), "w").write(str(os.getpid()))
+        if r == 0:
+            signal.signal(signal.SIGTERM, signal.SIG_IGN)  # a rank that ignores the first signal is still killed
+        time.sleep(300)
+    """
+    r, took = _run_launcher(tmp_path, body, 2, deadline=2.0)
+    assert r.returncode == 124 and took < 40, (r.returncode, took, r.stderr)
+    assert "deadline" in r.stderr
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text()))
+
+
+def test_bench_plain_invocation_without_gpu_fails_fast_and_clean():
+    """`python bench.py --gpus 2` with a clean environment on a box without a GPU: the parent starts the ranks, they
+    refuse to run without a GPU (no CPU fallback), the launcher reports it and exits non-zero -- no hang, no JSON"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("the GPU suite runs the real thing (tests/test_gpu_dist.py)")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scale", "0.01"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and "exited with" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rejects_mismatched_world_and_gat_multi_gpu():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "gat-reddit"], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 2 and "one-GPU workload" in r.stderr
+
+
+def test_trainer_launcher_stops_all_ranks_when_one_fails():
+    """GAIB_RANKS=3 bin/gpu_train_gcn on a box without a GPU: every rank dies at its first GPU call; the launcher says
+    which rank, exits with its status and leaves nothing behind"""
+    import torch
+
+    exe = ROOT / "bin" / "gpu_train_gcn"
+    if not exe.exists():
+        pytest.skip("trainer not built")
+    if torch.cuda.is_available():
+        pytest.skip("the GPU suite runs the real thing (tests/test_gpu_driver.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GAIB_RANK")}
+    env.update(GAIB_RANKS="3", DATASET_PATH=str(ROOT / "tests" / "golden") + "/")
+    r = subprocess.run([str(exe), "cora", "1", "1", "softmax"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0
+    assert "[launcher] rank" in r.stderr and "stopping the other ranks" in r.stderr
