@@ -330,18 +330,28 @@ __global__ void splitk_reduce_kernel(int64_t n, int splits, const float* partial
 // pairs of rows per register set: 8 plain, 4 with the mask rows travelling along (register budget)
 template <bool BMASK> struct TnDepth { static constexpr int PD = BMASK ? 4 : 8; };
 
-template <bool BMASK>
+// Outputs of 129..256 rows / columns (the hidden width 256 of scripts/run-sage-products.sh): QM x QN waves of ONE
+// workgroup form a team that owns the QM x QN 128x128 quadrants of the output and walks the SAME K schedule, each wave
+// reading its 512-byte half of the A row and of the B row.  A line of A, B or the mask therefore leaves HBM once: its
+// second reader sits on the same CU (L1) or at worst behind the same XCD's L2 -- the LDS kernel's 128-row tiles re-read
+// every A and B / mask line from HBM twice at 256 x 256 (17.6 GB of traffic for 10 GB).  The masked
+// B is written back by the waves of the first quadrant row only.  <1, 1> is the M, N <= 128 kernel unchanged.
+template <bool BMASK, int QM, int QN>
 __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
   constexpr int TN_PD = TnDepth<BMASK>::PD;
+  constexpr int TS = QM * QN;  // waves per team (1, 2 or 4); 4 / TS teams per workgroup
+  static_assert(TS == 1 || TS == 2 || TS == 4, "a team is 1, 2 or 4 waves of one workgroup");
   const int lane = threadIdx.x & 63;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  const int qm = (wv % TS) / QN, qn = (wv % TS) % QN;  // this wave's quadrant
+  const int64_t wid = (int64_t)blockIdx.x * (4 / TS) + wv / TS;  // team id: position in the K schedule, partial slab
   constexpr int64_t GRP = 2 * TN_PD;  // rows per register set
   // Two ways to deal K out.  Contiguous: wave w owns rows [w * k_chunk, (w + 1) * k_chunk).  Interleaved: set q of
   // 2 * TN_PD rows goes to wave q mod W, so at any time the W waves sweep one compact window of the operands (W sets =
   // a few MB) instead of W places spread over 1.25 GB each.  Below, k and kp are positions inside the wave's own
   // sequence of rows; phys() turns the start of a set into its row in the matrices.
-  const int64_t W = (int64_t)gridDim.x * 4;
+  const int64_t W = (int64_t)gridDim.x * (4 / TS);
   int64_t kbeg, kend;
   if (g.interleave) {
     const int64_t total = (g.K + GRP - 1) / GRP;
@@ -361,8 +371,9 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  const bool mok = 4 * i < g.M, nok = 4 * i < g.N;  // (M, N are multiples of 4: a lane's float4 is all in or all out)
-  const int mo = mok ? 4 * i : 0, no = nok ? 4 * i : 0;
+  const int mcol = 128 * qm + 4 * i, ncol = 128 * qn + 4 * i;
+  const bool mok = mcol < g.M, nok = ncol < g.N;  // (M, N are multiples of 4: a lane's float4 is all in or all out)
+  const int mo = mok ? mcol : 0, no = nok ? ncol : 0;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f4 sa[2][TN_PD], sb[2][TN_PD];
   f4 sm[BMASK ? 2 : 1][BMASK ? TN_PD : 1];  // BMASK: the mask rows travel with the set and are applied when it is consumed
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) vb[e] = mk[e] > 0.f ? vb[e] : 0.f;  // d_relu (math_functions.cu:258-268)
         sb[set][s] = vb;
         const int64_t k = kp + 2 * s + h;
-        if (nok && (full || k < kend)) *reinterpret_cast<f4*>(g.bwrite + (phys(kp) + 2 * s + h) * g.N + no) = vb;
+        if (nok && qm == 0 && (full || k < kend)) *reinterpret_cast<f4*>(g.bwrite + (phys(kp) + 2 * s + h) * g.N + no) = vb;
       }
     }
   };
@@ -450,48 +461,249 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
       }
     }
   }
-  // partial slab of this wave.  C/D map of the 32x32 MFMA: col j = lane&31, row r_ = (r&3) + 8*(r>>2) + 4*(lane>>5);
-  // tile (a, b) holds C[4*r_ + a][4*j + b]
+  // partial slab of this team.  C/D map of the 32x32 MFMA: col j = lane&31, row r_ = (r&3) + 8*(r>>2) + 4*(lane>>5);
+  // tile (a, b) of quadrant (qm, qn) holds C[128*qm + 4*r_ + a][128*qn + 4*j + b]
   float* P = g.C + wid * g.slab;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int64_t nn = 4 * i + b;
+      const int64_t nn = 128 * qn + 4 * i + b;
       if (nn < g.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t mm = 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+          const int64_t mm = 128 * qm + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
           if (mm < g.M) P[mm * g.N + nn] = acc[a][b][r];
         }
       }
     }
 }
 
-// M, N <= 128 weight gradients with a long K: one wave per SIMD of the whole chip
+// ---- weight gradient of the 129..256-wide layers through an LDS ring (round 3) -------------------------------------------
+// The register-resident kernel prefetches ONE register set ahead: 8 rows (plain) or 4 row pairs (masked -- the mask rows
+// need registers too) = 1.7-3.4 us of MFMA work, which under 5 TB/s of streaming load is about one memory latency; the
+// masked 256 x 256 product ran at 0.60 of the matrix peak with it.  Here the prefetch does not live in registers: the four
+// waves of a workgroup (one per SIMD, the accumulator tile of a 128 x 128 output quadrant each, as before) share a ring of
+// STAGES stages in LDS, a stage = TG_R rows of A, G and the mask (256 floats each: one 1-KiB LDS-DMA piece per row and
+// array, `global_load_lds_dwordx4`, no VGPR destination), filled STAGES - 1 stages (7-10 us) ahead.  Every A / G / mask
+// line leaves HBM once and reaches the CU once.
+// One wave per SIMD means nothing hides what a wave does between its MFMAs, so the loop is software-pipelined by hand:
+// while the 64 MFMAs of stage t run out of one register set, the SAME wave -- in the shadow of those MFMAs -- waits for its
+// own pieces of stage t + 1 (counted vmcnt: loads return in order, so "at most NG * (STAGES - 2) outstanding" means stage
+// t + 1 has landed; outstanding stores can only lengthen the wait), passes the ONE raw s_barrier of the stage (everybody's
+// pieces have landed, everybody has read stage t out of its slot), refills that slot with stage t + STAGES, reads stage
+// t + 1's fragments with ds_read_b128 into the other register set (lane (i, h): row 2 s + h, columns 128 q + 4 i .. + 3:
+// the register kernel's fragment shape, so the epilogue is shared), applies the mask and writes the masked G back (the two
+// waves of a column half hold the same values: each writes half of the stage's row pairs).  First version without the
+// interleave (all of that between the stages): 3.06 ms masked / 2.49 plain at 2.45 M x 256 x 256; interleaved and with the
+// wave index scalar: 2.87-2.90 / 2.53.  Timing-only builds without the barrier, without the counted wait and without both
+// ran the plain form in the same 2.52-2.53 ms, i.e. neither memory latency nor barrier skew is what is left; without
+// the write-back the masked form took 2.75.
+constexpr int TG_R = 8;  // rows per stage
+template <bool BMASK> struct TgCfg {
+  static constexpr int ARR = BMASK ? 3 : 2;
+  static constexpr int STAGES = BMASK ? 6 : 8;               // 6 x 24 KB = 144 KB, 8 x 16 KB = 128 KB of the 160 KB
+  static constexpr int NG = ARR * TG_R / 4;                  // LDS-DMA pieces per wave and stage
+  static constexpr int STAGE_F = ARR * TG_R * 256;           // floats per stage
+};
+
+template <bool BMASK>
+__global__ __launch_bounds__(256, 1) void sgemm_tn_glds_kernel(GemmArgs g) {
+  using Cfg = TgCfg<BMASK>;
+  constexpr int STAGES = Cfg::STAGES, NG = Cfg::NG, STAGE_F = Cfg::STAGE_F;
+  constexpr int NS = TG_R / 2;  // row pairs per stage
+  extern __shared__ __attribute__((aligned(16))) float tg_ring[];  // [STAGES][ARR][TG_R][256]  (the ONLY LDS object)
+  const int lane = threadIdx.x & 63;
+  // the wave index as a SCALAR: everything derived from it (the rows a wave loads, its quadrant, the LDS-DMA destinations)
+  // then is scalar arithmetic.  As a plain threadIdx.x >> 6 the compiler kept it per lane, and the 64-bit row addresses of
+  // the six pieces cost ~25 vector instructions each -- more than fits in the shadow of the MFMAs they sit between
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int qm = wv >> 1, qn = wv & 1;  // output quadrant
+  const int team = blockIdx.x, W = gridDim.x;
+  const int total = (int)((g.K + TG_R - 1) / TG_R);                 // sets of TG_R rows, dealt round robin to the teams
+  const int mine = team < total ? (total - team + W - 1) / W : 0;
+  // loader role: lane l brings floats 4l .. 4l + 3 of a 256-float row image; columns past M / N re-read column 0 (never used)
+  const int lca = 4 * lane < g.M ? 4 * lane : 0, lcb = 4 * lane < g.N ? 4 * lane : 0;
+  // piece j (compile time) of stage t of this team -> slot t % STAGES.  Past the team's last set: its last row again
+  // (a valid address; keeps the number of outstanding pieces constant, which is what the counted wait counts on)
+  const float* pa = g.A + lca;
+  const float* pb = g.B + lcb;
+  const float* pm = BMASK ? g.bmask + lcb : nullptr;
+  const int last_set = mine > 0 ? (mine - 1) * W + team : 0;
+  auto issue_piece = [&](int t, int j) {
+    const int set = t < mine ? t * W + team : last_set;
+    float* slot = tg_ring + (t % STAGES) * STAGE_F;
+    const int arr = j >> 1;  // pieces 2 arr, 2 arr + 1 of every wave belong to array arr
+    const int row = 4 * (j & 1) + wv;
+    int64_t k = (int64_t)set * TG_R + row;
+    k = k < g.K ? k : g.K - 1;  // rows past K: a valid address, zeroed by the reader
+    const float* src = arr == 0 ? pa + k * g.M : (arr == 1 ? pb + k * g.N : pm + k * g.N);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(slot + (arr * TG_R + row) * 256), 16, 0, 0);
+  };
+  f16v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int mcol = 128 * qm + 4 * i, ncol = 128 * qn + 4 * i;
+  const bool nok = ncol < g.N;
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads of stage t: pair s -> (fa[s], fb[s], mk[s]); finish(): mask, rows past K, write-back
+  auto read_pair = [&](int t, int s, f4 (&fa)[NS], f4 (&fb)[NS], f4 (&mk)[NS]) {
+    const float* st = tg_ring + (t % STAGES) * STAGE_F;
+    const int row = 2 * s + h;
+    fa[s] = *reinterpret_cast<const f4*>(st + (0 * TG_R + row) * 256 + mcol);
+    fb[s] = *reinterpret_cast<const f4*>(st + (1 * TG_R + row) * 256 + ncol);
+    if constexpr (BMASK) mk[s] = *reinterpret_cast<const f4*>(st + (2 * TG_R + row) * 256 + ncol);
+  };
+  auto finish_pair = [&](int t, int s, f4 (&fa)[NS], f4 (&fb)[NS], f4 (&mk)[NS]) {
+    const int64_t k = ((int64_t)t * W + team) * TG_R + 2 * s + h;
+    const bool live = t < mine && k < g.K;
+    fa[s] = live ? fa[s] : zero4;  // rows past K (the matrix's last set) and stages past the team's end contribute nothing
+    if constexpr (BMASK) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fb[s][e] = mk[s][e] > 0.f ? fb[s][e] : 0.f;  // d_relu (math_functions.cu:258-268)
+      if ((s >> 1) == qm && nok && live) *reinterpret_cast<f4*>(g.bwrite + k * g.N + ncol) = fb[s];
+    }
+  };
+  // one stage: the 64 MFMAs of stage t out of (ca, cb), everything stage t + 1 needs in their shadow, into (na, nb)
+  auto stage = [&](int t, f4 (&ca)[NS], f4 (&cb)[NS], f4 (&na)[NS], f4 (&nb)[NS]) {
+    f4 mk[NS];
+#pragma unroll
+    for (int m = 0; m < 16 * NS; ++m) {
+      const int s = m >> 4, a = (m >> 2) & 3, b = m & 3;
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s][a], cb[s][b], acc[a][b], 0, 0, 0);
+      if (m == 7) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG * (STAGES - 2)) : "memory");  // this wave's pieces of stage t + 1 have landed
+        __builtin_amdgcn_s_barrier();  // ... and everybody else's; everybody has read stage t out of its slot
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (m >= 8 && m < 8 + 2 * NG && ((m - 8) & 1) == 0) {  // refill the slot of stage t, a piece every other MFMA
+        issue_piece(t + STAGES, (m - 8) >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (m >= 24 && m < 24 + 2 * NS && ((m - 24) & 1) == 0) {
+        read_pair(t + 1, (m - 24) >> 1, na, nb, mk);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (m >= 40 && m < 40 + 4 * NS && ((m - 40) & 3) == 0) {  // every fourth MFMA: a pair's selects and its store
+        finish_pair(t + 1, (m - 40) >> 2, na, nb, mk);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  f4 fa0[NS], fb0[NS], fa1[NS], fb1[NS];
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t)
+#pragma unroll
+    for (int j = 0; j < NG; ++j) issue_piece(t, j);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG * (STAGES - 2)) : "memory");  // stage 0
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < NG; ++j) issue_piece(STAGES - 1, j);
+  {
+    f4 mk[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) read_pair(0, s, fa0, fb0, mk);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) finish_pair(0, s, fa0, fb0, mk);
+  }
+  for (int t = 0; t < mine; t += 2) {  // (an odd count runs one stage of zeros: finish_pair zeroes stages past the end)
+    stage(t, fa0, fb0, fa1, fb1);
+    stage(t + 1, fa1, fb1, fa0, fb0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued past the end must not outlive the workgroup's LDS
+  // partial slab of this team.  Same C/D map as sgemm_tn_reg_kernel.
+  float* P = g.C + team * g.slab;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t nn = 128 * qn + 4 * i + b;
+      if (nn < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t mm = 128 * qm + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+          if (mm < g.M) P[mm * g.N + nn] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+// 129..256 x 129..256 weight gradients: the LDS-ring kernel (sgemm_variant 34 keeps the register-resident teams)
+int launch_tn_glds(gaib_ctx* ctx, GemmArgs g) {
+  const int64_t total = cdiv64(g.K, TG_R);
+  const unsigned blocks = (unsigned)std::min<int64_t>(ctx->num_cus, total);
+  float* Cout = g.C;
+  const int accum = g.accum;
+  g.slab = g.M * g.N;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)blocks * g.slab));
+  g.C = (float*)ctx->ws;
+  ProfScope ps(ctx, "sgemm");
+#define GAIB_TG(MASK_)                                                                                                 \
+  do {                                                                                                                 \
+    const size_t lds = sizeof(float) * (size_t)TgCfg<MASK_>::STAGES * TgCfg<MASK_>::STAGE_F;                           \
+    GAIB_HIP(hipFuncSetAttribute((const void*)sgemm_tn_glds_kernel<MASK_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 160 * 1024));                                                                         \
+    sgemm_tn_glds_kernel<MASK_><<<blocks, 256, lds, ctx->stream>>>(g);                                                 \
+  } while (0)
+  if (g.bmask) GAIB_TG(true);
+  else GAIB_TG(false);
+#undef GAIB_TG
+  GAIB_LAUNCH_CHECK();
+  const int64_t n = g.M * g.N;
+  unsigned rg = (unsigned)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
+  splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, (int)blocks, (const float*)ctx->ws, accum, g.relu, Cout);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+// M, N <= 256 weight gradients with a long K: one wave per SIMD of the whole chip, in teams of QM x QN quadrant waves
 int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
-  const int64_t waves = (int64_t)ctx->num_cus * 4;
+  // 256 x 256, measured at K = 2.45 M (scripts/tn256.py): masked -- LDS ring 2.87-2.90 ms, register teams 3.36, LDS-tiled
+  // kernel 3.58; plain -- register teams 2.39-2.41 ms (0.85 of the matrix peak), LDS ring 2.53, LDS-tiled 2.74-2.80.  So the
+  // ring where the mask rows would have halved the register prefetch, the registers elsewhere (sgemm_variant 34 / 35 force
+  // the register teams / the ring for both forms).
+  if (g.M > 128 && g.N > 128 && ctx->sgemm_variant != 34 && (g.bmask || ctx->sgemm_variant == 35)) return launch_tn_glds(ctx, g);
+  const int qm = g.M > 128 ? 2 : 1, qn = g.N > 128 ? 2 : 1, ts = qm * qn;
+  const int64_t teams = (int64_t)ctx->num_cus * 4 / ts;
   const int64_t group = 2 * (g.bmask ? TnDepth<true>::PD : TnDepth<false>::PD);
-  int64_t chunk = cdiv64(cdiv64(g.K, waves), group) * group;  // whole register sets per wave
-  int64_t active = cdiv64(g.K, chunk);            // waves that own rows
-  // sgemm_variant 33: contiguous K ranges per wave; default: sets dealt round robin
+  int64_t chunk = cdiv64(cdiv64(g.K, teams), group) * group;  // whole register sets per team
+  int64_t active = cdiv64(g.K, chunk);             // teams that own rows
+  // sgemm_variant 33: contiguous K ranges per team; default: sets dealt round robin
   g.interleave = ctx->sgemm_variant == 33 ? 0 : 1;
-  if (g.interleave) active = std::min<int64_t>(waves, cdiv64(g.K, group));
-  const unsigned blocks = (unsigned)cdiv64(active, 4);
+  if (g.interleave) active = std::min<int64_t>(teams, cdiv64(g.K, group));
+  const unsigned blocks = (unsigned)cdiv64(active, 4 / ts);
+  const int n_slabs = (int)blocks * (4 / ts);
   float* Cout = g.C;
   const int accum = g.accum;
   g.k_chunk = chunk;
   g.slab = g.M * g.N;
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)blocks * 4 * g.slab));
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)n_slabs * g.slab));
   g.C = (float*)ctx->ws;
   {
     ProfScope ps(ctx, "sgemm");
-    if (g.bmask) sgemm_tn_reg_kernel<true><<<blocks, 256, 0, ctx->stream>>>(g);
-    else sgemm_tn_reg_kernel<false><<<blocks, 256, 0, ctx->stream>>>(g);
+#define GAIB_TN(QM_, QN_)                                                                          \
+  do {                                                                                             \
+    if (g.bmask) sgemm_tn_reg_kernel<true, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);          \
+    else sgemm_tn_reg_kernel<false, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);                 \
+  } while (0)
+    if (qm == 1 && qn == 1) GAIB_TN(1, 1);
+    else if (qm == 2 && qn == 2) GAIB_TN(2, 2);
+    else if (qm == 1) GAIB_TN(1, 2);
+    else GAIB_TN(2, 1);
+#undef GAIB_TN
     GAIB_LAUNCH_CHECK();
     const int64_t n = g.M * g.N;
     unsigned rg = (unsigned)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
-    splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, (int)(blocks * 4), (const float*)ctx->ws, accum, g.relu, Cout);
+    splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, n_slabs, (const float*)ctx->ws, accum, g.relu, Cout);
     GAIB_LAUNCH_CHECK();
   }
   return GAIB_OK;
@@ -772,7 +984,9 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   const bool avec = (((uintptr_t)d_A & 15) == 0) && (lda % 4 == 0);
   const bool bvec = (((uintptr_t)d_B & 15) == 0) && (ldb % 4 == 0);
   // weight gradients of the layer widths: register-resident split-K (sgemm_variant 30 keeps the LDS kernel)
-  if (transA && !transB && M <= 128 && N <= 128 && M % 4 == 0 && N % 4 == 0 && avec && bvec && K >= 32768 &&
+  // (M, N <= 128: one wave per output; up to 256: teams of quadrant waves; sgemm_variant 32: only up to 128, the round-2 rule)
+  const int64_t tn_max = ctx->sgemm_variant == 32 ? 128 : 256;
+  if (transA && !transB && M <= tn_max && N <= tn_max && M % 4 == 0 && N % 4 == 0 && avec && bvec && K >= 32768 &&
       ctx->sgemm_variant != 30)
     return launch_tn_reg(ctx, g);
   // streaming products (rows in the millions, 128 < K <= 256): persistent workgroups with the op(B) slab in LDS
@@ -791,7 +1005,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || sv == 30 || sv == 31 || sv == 33;  // (30 / 31 / 33 concern the weight gradient only)
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 35);  // (30 .. 34 concern the weight gradient only)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
@@ -812,7 +1026,8 @@ extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, 
   // when a set is consumed); sgemm_variant 30 / 31 keep the LDS kernel.  With K dealt out in contiguous per-wave ranges
   // this kernel won alone (1.03 vs 1.16 ms) and lost inside the layer step (1.15 vs 1.10); with the register sets dealt
   // round robin (one compact window over K for all waves) it wins there too: 0.97 vs 1.03 ms (scripts/ab_weight_grad.py).
-  const bool reg_path = aligned && M <= 128 && N <= 128 && K >= 32768 && ctx->sgemm_variant != 30 && ctx->sgemm_variant != 31;
+  const int64_t tn_max = ctx->sgemm_variant == 32 ? 128 : 256;
+  const bool reg_path = aligned && M <= tn_max && N <= tn_max && K >= 32768 && ctx->sgemm_variant != 30 && ctx->sgemm_variant != 31;
   if (M == 0 || N == 0 || K == 0 || (!reg_path && (!aligned || N <= 64))) {
     // shapes the masked kernel is not built for: the two-step form
     if (K > 0 && N > 0) GAIB_TRY(gaib_d_relu(ctx, K * N, d_G, d_mask, d_G));

@@ -1043,7 +1043,11 @@ def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
 
 @pytest.mark.parametrize("m,n,k,accum", [(128, 128, 20011, False), (100, 128, 9000, True), (256, 192, 4097, False),
                                          (128, 128, 50001, False), (100, 47, 40000, True), (16, 7, 33333, False),
-                                         (128, 47, 3000, False), (16, 64, 500, True), (130, 130, 777, False)])
+                                         (128, 47, 3000, False), (16, 64, 500, True), (130, 130, 777, False),
+                                         # 129..256 rows / columns with a long K: teams of quadrant waves (round 3)
+                                         (256, 256, 40001, False), (256, 256, 33000, True), (100, 256, 50003, False),
+                                         (256, 128, 36000, True), (132, 252, 40009, False), (256, 196, 32768, False),
+                                         (64, 256, 33333, False), (128, 132, 32769, True), (256, 256, 32775, False)])
 def test_sgemm_drelu(ctx, m, n, k, accum):
     """weight gradient with d_relu folded in: G masked in place (== d_relu_gpu), C (+)= A^T . G"""
     rng = np.random.default_rng(m + n + k)
@@ -1055,7 +1059,9 @@ def test_sgemm_drelu(ctx, m, n, k, accum):
     Gm = orc.d_relu(G, mask)
     want = orc.matmul(A, Gm, True, False, C0 if accum else None)
     ref64 = A.T.astype(np.float64) @ Gm.astype(np.float64) + (C0 if accum else 0)
-    for variant in (0, 30):  # 30: the LDS-tiled kernel also where the register-resident split-K kernel would run (long K)
+    # 30: the LDS-tiled kernel also where the register-resident split-K kernel would run (long K); 34: register-resident
+    # quadrant teams where the LDS-ring kernel would run (129..256 columns)
+    for variant in (0, 30, 34):
         ctx.set_option("sgemm_variant", variant)
         try:
             Gd, Cd = dev(G.copy()), dev(C0.copy())
@@ -1094,13 +1100,14 @@ def test_sgemm_streaming_kernel(ctx, x, y, z, tB, accum, relu):
         assert rel_err(got, want) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21, 30, 33])
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21, 30, 32, 33, 34, 35])
 def test_sgemm_experimental_variants_agree(ctx, variant):
     """the tiling / double-buffer knobs (gaib_set_option sgemm_variant) change the schedule, not the result"""
     rng = np.random.default_rng(variant)
     try:
         for (x, y, z, tA, tB) in [(1000, 128, 128, 0, 0), (777, 128, 96, 0, 1), (128, 128, 30011, 1, 0), (200, 72, 264, 0, 0),
-                                  (128, 128, 40003, 1, 0), (100, 48, 33001, 1, 0)]:  # (long K: the register-resident kernel; 33 = contiguous K ranges)
+                                  (128, 128, 40003, 1, 0), (100, 48, 33001, 1, 0),  # (long K: the register-resident kernel; 33 = contiguous K ranges)
+                                  (256, 256, 35001, 1, 0), (100, 256, 33001, 1, 0), (200, 128, 40003, 1, 0)]:  # (quadrant teams)
             A = rng.standard_normal((z, x) if tA else (x, z)).astype(np.float32)
             B = rng.standard_normal((y, z) if tB else (z, y)).astype(np.float32)
             want = orc.matmul(A, B, bool(tA), bool(tB))
