@@ -68,6 +68,43 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def blob_hash(path: Path) -> str:
+    """`git hash-object` of a file (the GPU box has the tree, not the repository)"""
+    import hashlib
+
+    data = path.read_bytes()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def traffic_from_profile(key: str, section: str | None = None):
+    """per-launch L2 -> fabric bytes of a kernel from the committed PMC summary (profiles/hbm_traffic.json: separate
+    rocprofv3 --pmc passes of this very command -- counters cannot be read inside the timed run).  The summary names the
+    kernel sources it was taken with (`sources`: path -> git blob hash); if any of them differs from the tree that is
+    running, the figure belongs to other kernels and is DROPPED (None + the reason) instead of being reported.
+    Returns (traffic_bytes_per_launch | None, source_or_reason)."""
+    tf = ROOT / "profiles" / "hbm_traffic.json"
+    if not tf.exists():
+        return None, "profiles/hbm_traffic.json missing"
+    try:
+        tj = json.loads(tf.read_text())
+        sec = tj.get(section, {}) if section else tj
+        srcs = sec.get("sources") or {}
+        if not srcs:
+            return None, "dropped: profiles/hbm_traffic.json names no kernel sources to check against"
+        for rel, want in srcs.items():
+            path = ROOT / rel
+            if not path.exists() or blob_hash(path) != want:
+                return None, (f"dropped: {rel} changed since the PMC passes at commit {sec.get('commit', '?')} "
+                              f"(re-run scripts/profile_round.sh + scripts/make_hbm_traffic.py)")
+        val = sec.get(key)
+        if not val:
+            return None, f"dropped: {key} not in profiles/hbm_traffic.json"
+        return float(val), (f"profiles/hbm_traffic.json{' ' + section if section else ''} (rocprofv3 --pmc passes at commit "
+                            f"{sec.get('commit', '?')}; kernel sources verified by blob hash)")
+    except Exception as e:  # a malformed summary must not take the bench line down
+        return None, f"dropped: {type(e).__name__}: {e}"
+
+
 def host_inputs(nv: int):
     """the layer's inputs, generated ONCE on the host (seed 43) and fed to BOTH legs: the GPU layer and
     the CPU oracle see the same X and the same incoming gradient, so their outputs are comparable element-wise."""
@@ -135,7 +172,10 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, x, gin, budget_s=30.0, want_outputs=T
     if not fits:
         R = min(max(int(nv * budget_s * rate / total_edges), probe_R), nv)
         t, e, _ = run(R)
-    res = dict(value=e / t, unit="edges/s", cores=cores, kind="port",
+    res = dict(value=e / t, unit="edges/s", cores=cores, cores_available=os.cpu_count(),
+               cores_note=f"threads = the {cores} cores this process may use (affinity mask / cgroup quota) of the host's "
+                          f"{os.cpu_count()}; SURVEY 8d's 32-thread figure needs a host share of >= 32 cores",
+               kind="port",
                sample=f"rows [0,{R}) of the same graph ({e // 2} edges incl. self loops), 1 layer fwd+bwd on the GPU "
                       f"leg's inputs, {t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
     nat = orc.native_lib()  # second figure with -march=native built on this host, same sample
@@ -626,18 +666,10 @@ def main():
         n_dom, ms_dom = n_light, ms_light
     avg_ms = ms_dom / max(n_dom, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    # `traffic`: PMC counters need their own rocprofv3 passes (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE
+    # `traffic`: PMC counters need their own rocprofv3 passes (scripts/profile_round.sh: FETCH_SIZE and WRITE_SIZE
     # separately, gfx950 half-count correction), so the per-launch figure comes from the committed summary of the
-    # same command at the commit named inside it -- not measurable inside this process
-    traffic = traffic_src = None
-    tf = ROOT / "profiles" / "hbm_traffic.json"
-    if tf.exists() and args.scale == 1.0:
-        try:
-            tj = json.loads(tf.read_text())
-            traffic = tj.get(traffic_key)
-            traffic_src = f"profiles/hbm_traffic.json (rocprofv3 --pmc passes at commit {tj.get('commit', '?')})"
-        except Exception:
-            traffic = None
+    # same command -- checked against the kernel sources of THIS tree, dropped on any difference
+    traffic, traffic_src = traffic_from_profile(traffic_key) if args.scale == 1.0 else (None, "scale != 1")
     b_min = 2 * nv * 4 * D + 4 * ne
     result = {
         "metric": "GCN-layer fwd+bwd aggregated edges/sec",
@@ -664,6 +696,9 @@ def main():
             # the gathers hit the 256 MB Infinity Cache, so this can exceed what HBM alone delivers (see
             # peak_measured / frac_of_measured): it is a work rate in bytes, not a physical HBM rate.
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # the same with SURVEY 8(d)'s formula to the letter: ONE N x 4D store per launch (the fused kernel's second
+            # stored matrix -- forward keeps A.X for the weight gradient -- not counted)
+            "frac_strict_8d": (alg_bytes - (int(1.5 * nv * 4 * D) - nv * 4 * D if n_fused > 0 else 0)) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "peak_measured": peak_measured,  # stream copy in this run, read + written bytes per second
             "frac_of_measured": (achieved / peak_measured) if peak_measured else None,
             "traffic": traffic, "traffic_source": traffic_src,
@@ -789,25 +824,24 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         n_dom, ms_dom = prof[dom]
         avg_ms = ms_dom / n_dom
         ach = alg[dom] / (avg_ms * 1e-3) / 1e9
-        # `traffic`: like the GCN line, from the committed PMC summary of this command (separate rocprofv3 passes)
-        traffic = traffic_src = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists() and args.scale == 1.0:
-            try:
-                tj = json.loads(tf.read_text()).get("gat_reddit", {})
-                traffic = tj.get(f"{dom}_bytes_per_launch")
-                if traffic:
-                    traffic_src = f"profiles/hbm_traffic.json gat_reddit (rocprofv3 --pmc passes at commit {tj.get('commit', '?')})"
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "peak_measured": peak_measured,
-                "frac_of_measured": ach / peak_measured if peak_measured else None,
-                # MI355X_MICROARCH.md: a 38 MB table gathered uniformly out of the Infinity Cache: 8.6 TB/s
-                "peak_cache_resident_gather": 8600.0, "traffic": traffic, "traffic_source": traffic_src,
+        # `traffic`: like the GCN line, from the committed PMC summary of this command (separate rocprofv3 passes),
+        # verified against this tree's kernel sources
+        traffic, traffic_src = traffic_from_profile(f"{dom}_bytes_per_launch", "gat_reddit") if args.scale == 1.0 else (None, "scale != 1")
+        # What bounds this kernel: the 60 MB feature table lives in the 256 MB Infinity Cache, the 4 MB L2s filter part
+        # of the gathers, and what is left crosses the fabric at the cache-resident gather rate -- MI355X_MICROARCH.md
+        # measures 8.6 TB/s for a table of this size gathered uniformly.  `frac` = (L2 -> fabric bytes per launch, PMC) /
+        # launch time / that rate.  The algorithmic rate (every gathered row counted, L2 hits included) exceeds any
+        # memory peak and is reported beside it, NOT as a roofline fraction.
+        CACHE_GATHER_GBS = 8600.0
+        fabric = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None
+        roof = {"bound": "infinity-cache gather", "kernel": dom, "achieved": fabric, "peak": CACHE_GATHER_GBS, "unit": "GB/s",
+                "frac": (fabric / CACHE_GATHER_GBS) if fabric else None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_gbs": ach, "alg_bytes_per_launch": alg[dom],
                 # L2 -> fabric bytes per launch over the algorithmic bytes: what the 4 MB L2s filter out of the gathers
                 "traffic_over_alg": (traffic / alg[dom]) if traffic else None,
-                "alg_bytes_per_launch": alg[dom], "avg_launch_ms": avg_ms, "launches": n_dom}
+                "hbm_peak": HBM_PEAK_GBS, "peak_measured_stream_copy": peak_measured,
+                "avg_launch_ms": avg_ms, "launches": n_dom}
     result = {
         "metric": "GAT-layer fwd+bwd aggregated edges/sec", "value": 2 * ne * args.steps / elapsed, "unit": "edges/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -827,40 +861,74 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
 
         cores = usable_cores()
         orc.set_threads(cores)
-        hs = 2  # heads sampled
         dh = Dg // H
         g_o = orc.Graph(sg.rowptr.cpu().numpy(), sg.colidx.cpu().numpy().view(np.uint32)).add_selfloop()
         W = orc.init_glorot(Dg, Dg, 1)
         al, ar = orc.init_glorot(Dg, 1, 2).ravel(), orc.init_glorot(Dg, 1, 3).ravel()
         hfeat = orc.matmul(x_h, W)
+        # ALL heads (a head is an independent single-head layer over all edges, gat_aggregator.cpp:57-200): ~10 s on
+        # the box's cores, and the whole layer -- forward, input gradient, weight gradient, alpha gradients -- becomes
+        # comparable element by element (round 2 sampled 2 heads and compared the forward only)
         t1 = time.perf_counter()
         outs, temps, norms = [], [], []
-        for k in range(hs):
+        for k in range(H):
             sl = slice(k * dh, (k + 1) * dh)
             o, t, _, p_ = orc.gat_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(al[sl]),
                                             np.ascontiguousarray(ar[sl]))
             outs.append(np.maximum(o, 0))
             temps.append(t)
             norms.append(p_)
-        for k in range(hs):
+        want = np.concatenate(outs, 1)
+        g_act = np.where(want > 0, gin_h, 0).astype(np.float32)
+        T = np.empty((nv, Dg), np.float32)
+        lg_w, rg_w = np.empty(Dg, np.float32), np.empty(Dg, np.float32)
+        for k in range(H):
             sl = slice(k * dh, (k + 1) * dh)
-            g_act = np.where(outs[k] > 0, gin_h[:, sl], 0).astype(np.float32)
-            orc.gat_d_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), g_act, norms[k], temps[k], fast=True)
+            go, _, _, l_, r_ = orc.gat_d_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(g_act[:, sl]),
+                                                   norms[k], temps[k], fast=True)
+            T[:, sl], lg_w[sl], rg_w[sl] = go, l_, r_
         t_cpu = time.perf_counter() - t1
-        result["cpu_baseline"] = dict(value=2 * ne / (t_cpu * H / hs), unit="edges/s", cores=cores, kind="port",
-                                      sample=f"attention heads 0..{hs - 1} of {H} over the whole graph ({ne} edges incl. self "
-                                             f"loops), score + softmax + aggregation forward and backward (`fast` d_softmax), "
-                                             f"{t_cpu:.2f} s; value scaled by {H}/{hs} heads")
+        result["cpu_baseline"] = dict(value=2 * ne / t_cpu, unit="edges/s", cores=cores, cores_available=os.cpu_count(),
+                                      kind="port",
+                                      sample=f"all {H} attention heads over the whole graph ({ne} edges incl. self loops), score + "
+                                             f"softmax + aggregation forward and backward (`fast` d_softmax), {t_cpu:.2f} s "
+                                             f"(the dense products X.W, T.W^T, X^T.T of the layer are outside the timed CPU region)")
+        want_go = orc.matmul(T, W, False, True)
+        want_wg = orc.matmul(x_h, T, True, False)
+        del norms, outs
+        # parity, as in parity_record: forward as is; backward re-run on the ORACLE's forward output (identical relu masks)
+        tol, floor = 1e-4, 1e-5  # rows of up to 21 k edges, K = 233 k weight gradient: long-sum floor (tests/util.py)
         layer.write(L.GRAD_IN, gin_d)
         layer.forward(feat_out)
         torch.cuda.synchronize()
-        want = torch.from_numpy(np.concatenate(outs, 1)).cuda()
-        rec = _errs(torch, feat_out[:, :hs * dh].contiguous(), want, 1e-4, 1e-5)
-        result["parity"] = {"tol": 1e-4, "floor_frac_of_max": 1e-5, "forward_heads_sampled": rec,
-                            "ok": bool(rec["elem"] <= 1e-4 and rec["inf"] <= 1e-4),
-                            "note": "rows of up to 21 k edges: long-sum floor (tests/util.py LONG_SUM_FLOOR); the full layer "
-                                    "incl. backward is compared element-wise in tests/test_gpu_fullsize.py"}
-        if not result["parity"]["ok"]:
+        want_d = torch.from_numpy(want).cuda()
+        par = {"tol": tol, "floor_frac_of_max": floor, "heads_compared": H,
+               "forward": _errs(torch, feat_out, want_d, tol, floor)}
+        flips = (feat_out > 0) != (want_d > 0)
+        par["relu_mask_flips"] = {"count": int(flips.sum().item()), "of": int(want_d.numel())}
+        layer.write(L.GRAD_IN, gin_d)
+        layer.backward(want_d, grad_out)
+        torch.cuda.synchronize()
+        par["grad_out"] = _errs(torch, grad_out, torch.from_numpy(want_go).cuda(), tol, floor)
+        par["W_grad"] = _errs(torch, layer.tensor(L.W_NEIGH_GRAD, (Dg, Dg)), torch.from_numpy(want_wg).cuda(), tol, floor)
+        # alpha gradients: 64 sums over 9e8 (edge, head) terms with leaky_relu' jumping at 0 -- the oracle's own distance
+        # from the fp64 evaluation of the same formulas is measured here and sets the tolerance (oracle/fp64.py)
+        from oracle import fp64 as truth
+        lg64, rg64, info = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, hfeat, al, ar, g_act, H, temp_fp32=temps)
+        ok_a = True
+        for which, want_a, t64, name in ((L.ALPHA_LGRAD, lg_w, lg64, "alpha_l_grad"), (L.ALPHA_RGRAD, rg_w, rg64, "alpha_r_grad")):
+            got = layer.tensor(which, (Dg,)).double().cpu().numpy()
+            d_orc = truth.inf_dist(want_a, t64)
+            rec_a = {"inf_vs_oracle": truth.inf_dist(got, want_a), "inf_vs_fp64": truth.inf_dist(got, t64),
+                     "oracle_inf_vs_fp64": d_orc, "allowed_vs_oracle": tol + 2.0 * d_orc}
+            ok_a = ok_a and rec_a["inf_vs_oracle"] <= rec_a["allowed_vs_oracle"] and rec_a["inf_vs_fp64"] <= max(tol, 2.0 * d_orc)
+            par[name] = rec_a
+        par["leaky_relu_sign_flips_oracle_vs_fp64"] = info["sign_flips"]
+        par["ok"] = bool(all(par[k]["elem"] <= tol and par[k]["inf"] <= tol for k in ("forward", "grad_out", "W_grad")) and ok_a)
+        result["parity"] = par
+        log(f"[bench] parity vs the oracle's {H}-head run: {par}")
+        if not par["ok"]:
+            log("[bench] PARITY FAILED (> 1e-4)")
             rc = 3
     emit(result)
     return rc

@@ -820,7 +820,8 @@ constexpr int NNP_LDB = 128 + 4;
 template <int NT, bool BT>  // NT = 32-column MFMA tiles per wave (N slab = 32 * NT <= 128); BT: B is [N][K] (op = transpose)
 __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float nnp_lds[];  // [K][NNP_LDB]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the tile loop and its bounds run on the SALU
   const int li = lane & 31, lh = lane >> 5;
   const int64_t n0 = (int64_t)blockIdx.y * (32 * NT);
   const int K = (int)g.K;

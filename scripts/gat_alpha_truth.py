@@ -1,0 +1,133 @@
+"""Where do the GAT layer's alpha gradients at the reddit shape (8 heads, 113 M edges) stand against the truth?
+The layer's one-sweep backward, the staged kernels fed with the oracle's arrays, and the oracle itself are each compared
+with an fp64 evaluation of the same formulas (gat_aggregator.cpp:99-200) on the device, head by head.  Also counts the
+leaky-relu sign flips between the fp32 pre-activation scores of the oracle and an fp64 evaluation (the jump of
+leaky_relu' at 0 is what an alpha gradient is sensitive to) and what those flips are worth.
+    python scripts/gat_alpha_truth.py [--scale 1.0]
+Test infrastructure (imports the oracle): evidence for the tolerance of tests/test_gpu_fullsize.py, DESIGN.md 4."""
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from graphaibench_amd import layers as L, synth  # noqa: E402
+from oracle import binding as orc  # noqa: E402
+
+
+def fp64_head(rows, col, hk, al, ar, g_act_k, n):
+    """one head in fp64 on the device: (alpha_l grad, alpha_r grad, t) -- formulas of gat_aggregator.cpp:57-200"""
+    hk = hk.double()
+    sl, sr = hk @ al.double(), hk @ ar.double()
+    t = sl[rows] + sr[col]
+    s = torch.where(t > 0, t, 0.2 * t)
+    M = torch.full((n,), -float("inf"), dtype=torch.float64, device=t.device).scatter_reduce(0, rows, s, "amax")
+    e = torch.exp(s - M[rows])
+    S = torch.zeros(n, dtype=torch.float64, device=t.device).index_add_(0, rows, e)
+    p = e / S[rows]
+    del e, s
+    dp = torch.zeros_like(p)
+    step = 1 << 24
+    ga = g_act_k.double()
+    for a in range(0, p.numel(), step):  # the gathered rows chunk by chunk
+        dp[a:a + step] = (ga[rows[a:a + step]] * hk[col[a:a + step]]).sum(1)
+    rowdot = torch.zeros(n, dtype=torch.float64, device=t.device).index_add_(0, rows, p * dp)
+    ds = p * (dp - rowdot[rows])
+    ge = ds * torch.where(t > 0, 1.0, 0.2)
+    cs = torch.zeros(n, dtype=torch.float64, device=t.device).index_add_(0, col, ge)
+    rs = torch.zeros(n, dtype=torch.float64, device=t.device).index_add_(0, rows, ge)
+    return rs @ hk, cs @ hk, t, ds
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    args = ap.parse_args()
+    L.init(0)
+    sg = synth.make("reddit", seed=7, device="cuda", scale=args.scale)
+    rp = sg.rowptr.cpu().numpy()
+    ci = sg.colidx.cpu().numpy().view(np.uint32)
+    g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
+    orc.set_threads(len(os.sched_getaffinity(0)))
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    del sg
+    n, ne, d, H = g_o.nv, g_o.ne, 64, 8
+    dh = d // H
+    rng = lambda s: np.random.default_rng(s).standard_normal((n, d), dtype=np.float32)
+    x, gin = rng(3), rng(4)
+    ld = L.Layer(L.GAT, 1, n, d, d, g_d, True)
+    ld.set_heads(H)
+    W = orc.init_glorot(d, d, 1)
+    al, ar = orc.init_glorot(d, 1, 2).ravel(), orc.init_glorot(d, 1, 3).ravel()
+    hfeat = orc.matmul(x, W)
+    agg = np.empty((n, d), np.float32)
+    temps, norms = [], []
+    for k in range(H):
+        sl = slice(k * dh, (k + 1) * dh)
+        o, t, _, p = orc.gat_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(al[sl]), np.ascontiguousarray(ar[sl]))
+        agg[:, sl] = o
+        temps.append(t)
+        norms.append(p)
+    want = orc.relu(agg)
+    g_act = orc.d_relu(gin, want)
+    lg_o, rg_o = np.empty(d, np.float32), np.empty(d, np.float32)
+    for k in range(H):
+        sl = slice(k * dh, (k + 1) * dh)
+        _, _, _, l_, r_ = orc.gat_d_aggregate(g_o, np.ascontiguousarray(hfeat[:, sl]), np.ascontiguousarray(g_act[:, sl]), norms[k], temps[k], fast=True)
+        lg_o[sl], rg_o[sl] = l_, r_
+    # the layer's own path (one sweep), on the oracle's relu mask
+    ld.write(L.FEAT_IN, torch.from_numpy(x).cuda())
+    out = torch.empty(n, d, device="cuda")
+    ld.forward(out)
+    out.copy_(torch.from_numpy(want).cuda())
+    ld.write(L.GRAD_IN, torch.from_numpy(gin).cuda())
+    grad_out = torch.zeros(n, d, device="cuda")
+    ld.backward(out, grad_out)
+    lg_g = ld.tensor(L.ALPHA_LGRAD, (d,)).double().cpu().numpy()
+    rg_g = ld.tensor(L.ALPHA_RGRAD, (d,)).double().cpu().numpy()
+    # fp64 truth, head by head
+    rowptr = torch.from_numpy(g_o.rowptr).cuda()
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), rowptr[1:] - rowptr[:-1])
+    col = torch.from_numpy(g_o.colidx.astype(np.int64)).cuda()
+    hf_d = torch.from_numpy(hfeat).cuda()
+    ga_d = torch.from_numpy(g_act).cuda()
+    lg_t, rg_t = np.empty(d), np.empty(d)
+    flips_total, flip_worth_l, flip_worth_r = 0, np.zeros(d), np.zeros(d)
+    near = 0
+    for k in range(H):
+        sl = slice(k * dh, (k + 1) * dh)
+        l_, r_, t64, ds = fp64_head(rows, col, hf_d[:, sl], torch.from_numpy(al[sl]).cuda(), torch.from_numpy(ar[sl]).cuda(), ga_d[:, sl], n)
+        lg_t[sl], rg_t[sl] = l_.cpu().numpy(), r_.cpu().numpy()
+        t_o = torch.from_numpy(temps[k]).cuda()
+        fl = (t_o > 0) != (t64 > 0)
+        flips_total += int(fl.sum().item())
+        near += int((t64.abs() < 1e-6 * t64.abs().max()).sum().item())
+        if fl.any():  # what the flipped terms are worth: 0.8 |ds_e| |h|
+            w = 0.8 * ds[fl].abs()
+            flip_worth_r[sl] += (w[:, None] * hf_d[:, sl].double()[col[fl]].abs()).sum(0).cpu().numpy()
+            flip_worth_l[sl] += (w[:, None] * hf_d[:, sl].double()[rows[fl]].abs()).sum(0).cpu().numpy()
+        del t64, ds, t_o, fl
+        torch.cuda.empty_cache()
+    def dist(a, b):
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    rec = {
+        "scale": args.scale, "nv": n, "ne": ne, "heads": H,
+        "alpha_l": {"gpu_layer_vs_fp64": dist(lg_g, lg_t), "oracle_vs_fp64": dist(lg_o.astype(np.float64), lg_t),
+                    "gpu_layer_vs_oracle": dist(lg_g, lg_o.astype(np.float64)), "max_abs": float(np.abs(lg_t).max()),
+                    "min_abs": float(np.abs(lg_t).min())},
+        "alpha_r": {"gpu_layer_vs_fp64": dist(rg_g, rg_t), "oracle_vs_fp64": dist(rg_o.astype(np.float64), rg_t),
+                    "gpu_layer_vs_oracle": dist(rg_g, rg_o.astype(np.float64)), "max_abs": float(np.abs(rg_t).max()),
+                    "min_abs": float(np.abs(rg_t).min())},
+        "leaky_relu_sign_flips_oracle_fp32_vs_fp64": flips_total, "scores_within_1e-6_of_zero": near,
+        "flips_worth_over_max": {"alpha_l": float(flip_worth_l.max() / np.abs(lg_t).max()), "alpha_r": float(flip_worth_r.max() / np.abs(rg_t).max())},
+    }
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()

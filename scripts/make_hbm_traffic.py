@@ -6,11 +6,24 @@ Counters are in KB (1024 B).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH
 coalesced read -- re-calibrated for THIS access pattern (64 lanes x 8 B gathers of 512-B rows) with
 scripts/calibrate_fetch.py on a permutation graph whose byte count is known.  FETCH_SIZE counts L2 -> fabric requests:
 Infinity-Cache hits are INCLUDED, so the figures are an upper bound on the HBM share."""
+import hashlib
 import json
 import sys
 from pathlib import Path
 
 src, commit = Path(sys.argv[1]), sys.argv[2]
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def blob_hashes(rels):
+    """path -> `git hash-object`: bench.py recomputes these and drops `traffic` when a kernel source has changed"""
+    out = {}
+    for rel in rels:
+        data = (ROOT / rel).read_bytes()
+        out[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 pmc = json.loads((src / "gcn_pmc_summary.json").read_text())
 cal = json.loads((src / "calib_pmc.json").read_text())
 NV, D = 2_449_029, 128
@@ -33,9 +46,11 @@ out = {
     "calibration": {"known_read_bytes": known_read, "FETCH_SIZE_KB": cf, "ratio_counter_to_known": ratio,
                     "known_write_bytes": known_write, "WRITE_SIZE_KB": cw, "write_ratio": cw * 1024 / known_write},
     "fetch_correction": 2.0,
+    "sources": blob_hashes(["graphaibench_amd/csrc/spmm.hip", "graphaibench_amd/csrc/spmm_core.h", "graphaibench_amd/csrc/common.h",
+                            "graphaibench_amd/csrc/sgemm.hip"]),
 }
 for name, frag in (("spmm_gemm_kernel", "spmm_gemm_kernel"), ("spmm_heavy_kernel", "spmm_heavy_kernel"),
-                   ("sgemm_tn_reg_kernel_masked", "sgemm_tn_reg_kernel<true>")):
+                   ("sgemm_tn_reg_kernel_masked", "sgemm_tn_reg_kernel<true")):
     f, w = find(pmc, "FETCH_SIZE", frag), find(pmc, "WRITE_SIZE", frag)
     out[name] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w}
     out[f"{name}_bytes_per_launch"] = f * 1024 * 2.0 + w * 1024
@@ -44,7 +59,8 @@ for name, frag in (("spmm_gemm_kernel", "spmm_gemm_kernel"), ("spmm_heavy_kernel
 gp = src / "gat_pmc_summary.json"
 if gp.exists():
     gat = json.loads(gp.read_text())
-    rec = {"workload": "bench.py --workload gat-reddit: reddit-shaped graph, 8-head GAT layer 64->64 fwd+bwd", "commit": commit}
+    rec = {"workload": "bench.py --workload gat-reddit: reddit-shaped graph, 8-head GAT layer 64->64 fwd+bwd", "commit": commit,
+           "sources": blob_hashes(["graphaibench_amd/csrc/gat.hip", "graphaibench_amd/csrc/common.h"])}
     for key, frag in (("gat_fwd_fused", "gat_fwd_fused_chunk_kernel"), ("gat_bwd_fused", "gat_bwd_fused_chunk_kernel")):
         try:
             f, w = find(gat, "FETCH_SIZE", frag), find(gat, "WRITE_SIZE", frag)

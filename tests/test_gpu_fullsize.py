@@ -21,7 +21,7 @@ import torch
 
 from graphaibench_amd import capi, layers as L, synth
 from oracle import binding as orc
-from util import LONG_SUM_FLOOR, assert_close_dev
+from util import ELEM_FLOOR, LONG_SUM_FLOOR, assert_close_dev
 
 pytestmark = pytest.mark.gpu
 D = 128
@@ -228,34 +228,51 @@ def _same_relu_mask(out_dev, want):
     out_dev.copy_(w)
 
 
-def test_sage_layer_products_vs_oracle(products):
-    """SAGE_layer 128 -> 128 (hidden layer of BASELINE config 3) forward + backward on the products-shaped graph,
-    every output tensor element-wise against the oracle's layer (sage_layer.cpp:5-53) on the same inputs."""
+@pytest.mark.parametrize("width", [128, 256])
+def test_sage_layer_products_vs_oracle(products, width):
+    """SAGE_layer width -> width forward + backward on the products-shaped graph, every output tensor element-wise
+    against the oracle's layer (sage_layer.cpp:5-53) on the same inputs.  128: the hidden layer of BASELINE config 3;
+    256: the hidden width of the reference's own script (scripts/run-sage-products.sh:1) -- the aggregation as two
+    128-column K-slabs with the neighbour product riding on them, the self term as an accumulating product, and the
+    256 x 256 weight gradients (masked: the LDS-ring kernel; plain: quadrant teams of the register-resident kernel)."""
     lctx = L.init(0)
-    nv = products["nv"]
+    nv, Dw = products["nv"], width
     rp = products["rowptr"].cpu().numpy()
     ci = products["colidx"].cpu().numpy().view(np.uint32)
     orc.set_threads(len(__import__("os").sched_getaffinity(0)))
     g_o = orc.Graph(rp, ci)
     lg = L.LGraph.adopt(lctx.graph(products["rowptr"], products["colidx"]))  # its own copy: adopt takes ownership
-    x, gin = _host_feat(nv, D, 43), _host_feat(nv, D, 44)
-    lo = orc.SAGELayer(1, g_o, D, D, True)
-    ld = L.Layer(L.SAGE, 1, nv, D, D, lg, True)
+    x, gin = _host_feat(nv, Dw, 43), _host_feat(nv, Dw, 44)
+    lo = orc.SAGELayer(1, g_o, Dw, Dw, True)
+    ld = L.Layer(L.SAGE, 1, nv, Dw, Dw, lg, True)
     ld.write(L.FEAT_IN, torch.from_numpy(x).cuda())
-    out = torch.empty(nv, D, device="cuda")
+    out = torch.empty(nv, Dw, device="cuda")
     ld.forward(out)
     want = lo.forward(x)
     assert_close_dev(out, want, "forward")
     _same_relu_mask(out, want)
+    del want
     ld.write(L.GRAD_IN, torch.from_numpy(gin).cuda())
-    grad_out = torch.zeros(nv, D, device="cuda")
+    grad_out = torch.zeros(nv, Dw, device="cuda")
     ld.backward(out, grad_out)
     want_go = lo.backward(gin)  # gin is masked in place (Q9)
-    assert_close_dev(grad_out, want_go, "grad_out")
-    assert_close_dev(ld.tensor(L.GRAD_IN, (nv, D)), gin, "masked grad_in")
+    # The input gradient is M^T (g W_neigh^T) + g W_self^T in the oracle (sage_layer.cpp:44-50) and (M^T g) W_neigh^T +
+    # g W_self^T on the GPU (the product rides on the aggregation): the same numbers in exact arithmetic, two orders of
+    # fp32 rounding.  What the order is worth is MEASURED: 50 000 sampled rows in fp64 on the device; the element-wise
+    # floor is twice the ORACLE's own distance from them (never the GPU's), at least the default (DESIGN.md 4).
+    from oracle import fp64 as truth
+    sample = torch.randperm(nv, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))[:50000]
+    go64 = truth.sage_grad_out_rows_fp64(rp, ci, gin, lo.W_neigh, lo.W_self, sample)
+    sc = go64.abs().max().item()
+    d_orc = (torch.from_numpy(want_go).cuda()[sample].double() - go64).abs().max().item() / sc
+    d_gpu = (grad_out[sample].double() - go64).abs().max().item() / sc
+    print(f"SAGE {Dw}: grad_out rows vs fp64: oracle {d_orc:.2e}, GPU {d_gpu:.2e}")
+    assert d_gpu <= max(2.0 * d_orc, 2e-6), (d_gpu, d_orc)
+    assert_close_dev(grad_out, want_go, "grad_out", floor=max(ELEM_FLOOR, 2.0 * d_orc))
+    assert_close_dev(ld.tensor(L.GRAD_IN, (nv, Dw)), gin, "masked grad_in")
     # K = 2.45 M-term sums on both sides (the oracle's per-thread sequential partials are themselves ~6e-6 max|b| from fp64)
-    assert_close_dev(ld.tensor(L.W_NEIGH_GRAD, (D, D)), lo.W_neigh_grad, "W_neigh_grad", floor=LONG_SUM_FLOOR)
-    assert_close_dev(ld.tensor(L.W_SELF_GRAD, (D, D)), lo.W_self_grad, "W_self_grad", floor=LONG_SUM_FLOOR)
+    assert_close_dev(ld.tensor(L.W_NEIGH_GRAD, (Dw, Dw)), lo.W_neigh_grad, "W_neigh_grad", floor=LONG_SUM_FLOOR)
+    assert_close_dev(ld.tensor(L.W_SELF_GRAD, (Dw, Dw)), lo.W_self_grad, "W_self_grad", floor=LONG_SUM_FLOOR)
 
 
 def test_gat_layer_8_heads_reddit_vs_oracle():
@@ -310,16 +327,26 @@ def test_gat_layer_8_heads_reddit_vs_oracle():
     # 113 M-term alpha gradients: long sums in another order than the oracle's
     assert_close_dev(grad_out, orc.matmul(T, W, False, True), "grad_out", floor=LONG_SUM_FLOOR)
     assert_close_dev(ld.tensor(L.W_NEIGH_GRAD, (d, d)), orc.matmul(x, T, True, False), "W_grad", floor=LONG_SUM_FLOOR)
-    # The alpha gradients sum g_e = ds_e * leaky_relu'(temp_e) over 9e8 (edge, head) pairs, and leaky_relu' jumps from
-    # 0.2 to 1 at temp = 0: a pre-activation score within rounding of zero takes either slope in two correct fp32
-    # evaluations (the layer forms it as sl[i] + sr[col] from per-vertex dots, the reference per edge), and every such
-    # flip moves the sums by 0.8 ds_e h.  So: (1) the layer's alpha gradients agree to 1e-3 norm-wise, (2) the flips are
-    # counted and all sit within rounding of zero, (3) with the ORACLE's temp / attention arrays fed to the same GPU
-    # kernels (no flips possible) the alpha gradients agree to the usual 1e-4.
-    from util import dev_errs
-    for which, want_a, name in ((L.ALPHA_LGRAD, lg_w, "alpha_l grad"), (L.ALPHA_RGRAD, rg_w, "alpha_r grad")):
-        r, _ = dev_errs(ld.tensor(which, (d,)), want_a)
-        assert r <= 1e-3, (name, r)
+    # The alpha gradients sum g_e = ds_e * leaky_relu'(temp_e) over 9e8 (edge, head) pairs in fp32 on both sides, and
+    # leaky_relu' jumps from 0.2 to 1 at temp = 0: a score within rounding of zero takes either slope in two correct
+    # evaluations.  How far such a sum can be trusted is MEASURED, not assumed: the same formulas in fp64 on the device
+    # (oracle/fp64.py) give the oracle's own distance from the exact gradients (measured r3: 1.2e-4 / 5.5e-5 of the
+    # largest entry for alpha_l / alpha_r, 15 sign flips of the oracle's fp32 scores against fp64 worth up to 1.2e-4),
+    # and the layer's OWN gradients -- the one-sweep kernel, no oracle array fed back -- are held to 1e-4 plus twice that
+    # distance against the oracle, and to twice that distance against fp64 (1e-3 norm-wise until round 2).
+    from oracle import fp64 as truth
+    lg64, rg64, info = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, hfeat, al, ar, g_act, H, temp_fp32=temps)
+    for which, want_a, t64, name in ((L.ALPHA_LGRAD, lg_w, lg64, "alpha_l grad"), (L.ALPHA_RGRAD, rg_w, rg64, "alpha_r grad")):
+        got = ld.tensor(which, (d,)).double().cpu().numpy()
+        d_orc = truth.inf_dist(want_a, t64)
+        d_gpu, d_go = truth.inf_dist(got, t64), truth.inf_dist(got, want_a)
+        print(f"{name}: vs fp64: oracle {d_orc:.2e}, GPU layer {d_gpu:.2e}; GPU vs oracle {d_go:.2e}; "
+              f"{info['sign_flips']} leaky-relu sign flips (oracle fp32 vs fp64)")
+        assert d_orc < 5e-4, (name, d_orc)  # the oracle itself stays a meaningful reference
+        assert d_gpu <= max(1e-4, 2.0 * d_orc), (name, d_gpu, d_orc)
+        assert d_go <= 1e-4 + 2.0 * d_orc, (name, d_go, d_orc)
+    assert info["sign_flips"] < 1e-6 * H * ne
+    # with the ORACLE's temp / attention arrays fed to the staged GPU kernels (no flips possible): the usual 1e-4
     lctx = L.init(0)
     gd = g_d.device_graph()
     hf_d = torch.from_numpy(hfeat).cuda()
