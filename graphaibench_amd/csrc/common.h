@@ -70,7 +70,7 @@ struct gaib_ctx {
   int spmm_fuse;             // 1 = gaib_spmm_gemm may fuse the dense product into the aggregation
   int spmm_flat;             // fused kernel, edge-stream form for short rows: -1 = by average degree, 0 = never, 1 = always
   int spmm_fuse_cus;         // fused kernel: persistent workgroups (= CUs it occupies); 0 = all CUs.  Fewer leave whole CUs to a kernel on another stream
-  int spmm_tile_xcd;         // fused kernel: 1 = tiles off per-XCD counters over interleaved 256-row chunks, 0 = one global counter
+  int spmm_tile_xcd;         // fused kernel's tile supply: -1 (default) = by the graph's numbering (XCD-affine chunks of 1024 tiles where the numbering has locality, else one global counter), 0 = global counter, n > 0 = XCD-affine chunks of n tiles
   int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8
   int spmm_addr_mode;        // 0 = auto (buffer loads when the table is < 4 GB), 2 = force 64-bit global
   int spmm_gather_mode;      // 0/1 default cache policy, 2 = nt gathers, 3 = nt for cold columns only
@@ -147,7 +147,10 @@ struct gaib_graph {
   int heavy_thr;
   int64_t max_degree;
   int64_t dev_bytes;
+  float near_frac;  // share of (sampled) edges whose column id lies within 32 768 of the row id: locality of the numbering; < 0 = not measured yet
 };
+
+int gaib_graph_ensure_locality(gaib_ctx* ctx, gaib_graph* g);
 
 int gaib_graph_ensure_inv_deg(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g);

@@ -52,7 +52,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_variant = 0;
   c->spmm_xcd_swizzle = 2;
   c->spmm_unroll = 0;
-  c->spmm_tile_xcd = 0;
+  c->spmm_tile_xcd = -1;
   c->spmm_fuse_cus = 0;
   c->spmm_fuse = 1;
   c->spmm_pad = 1;

@@ -322,8 +322,28 @@ struct FuseArgs {
   const float* rows2;         // DUAL: second row operand [n_rows][ncols]:  y += rows2[i,:] . op(W2)
   int ldw;                    // row stride of wt / wt2 in floats (== ncols unless the launch handles a K-slab of a wider matrix)
   int y_accum;                // y += instead of y = (the second K-slab of a 129..256-wide aggregation; not with DUAL)
-  int tile_xcd;               // 1: tiles off eight per-XCD counters over interleaved 256-row chunks; 0: one global counter
+  int tile_xcd;               // 0: one global counter; n > 0: tiles off eight per-XCD counters over interleaved chunks of 2^(n-1) tiles
 };
+
+// option spmm_tile_xcd -> FuseArgs::tile_xcd (0 = global counter, else log2(chunk length in tiles) + 1).
+// -1 (default): by the graph's numbering -- XCD-affine chunks of 1024 tiles when at least a quarter of the edges stay
+// within 32 768 ids of their row, else the global counter.  Measured (scripts/ab_tile_xcd.py, products size, D = 128): a
+// numbering with planted locality 5.94 -> 5.01 ms at 512-1024 tiles per chunk (6.2 ms at 16-128: an XCD's 512 waves in
+// flight then span 65 536 rows); a random numbering 7.60 -> 7.80 ms with ANY chunk length, and 8.1 ms with eight counters
+// WITHOUT the XCD affinity -- i.e. on a random order the one shared in-order window over the streamed arrays is worth 3 %,
+// hence the rule instead of one setting.  1 = the round-2 form (16-tile chunks); n = chunk length, rounded down to 2^k.
+static int tile_xcd_arg(gaib_ctx* ctx, gaib_graph* g) {
+  int v = ctx->spmm_tile_xcd;
+  if (v < 0) {
+    if (gaib_graph_ensure_locality(ctx, g) != GAIB_OK) return 0;
+    v = g->near_frac >= 0.25f ? 1024 : 0;
+  }
+  if (v <= 0) return 0;
+  if (v == 1) v = 16;
+  int sh = 0;
+  while ((2 << sh) <= v) ++sh;
+  return sh + 1;
+}
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int FUSE_ROWS = 16;
@@ -365,22 +385,22 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   // FLAT: tiles are cheap (a few edges per row), and one atomic per tile on one address becomes the floor (153 k
   // atomics = 0.4 ms at 2.4 M rows).  Guided chunks instead: a wave takes (tiles left) / (4 x waves) tiles at a time,
   // at most 8, down to single tiles at the end.
-  // Tiles come off EIGHT counters, one per XCD (workgroups are dealt to the XCDs round robin: XCD = blockIdx & 7).
-  // XCD x owns the chunks x, x + 8, x + 16, ... of TCH = 16 consecutive tiles (256 rows): consecutive rows of a graph
-  // with locality in its numbering meet in ONE L2 instead of being spread over all eight, and all XCDs advance through
-  // the rows at the same pace, so a numbering with its long rows at one end stays balanced.  Measured
-  // (scripts/locality_study.py, products-sized graph with planted locality, natural order): one global counter 6.7 ms /
-  // 42 GB of fabric traffic; one contiguous range per XCD 5.8 ms but +0.4 ms per bench step on the random order (the
-  // ranges finish at different times); the static per-XCD ranges of spmm_w64_kernel 5.0 ms / 25 GB.  An XCD whose chunks
-  // are used up draws from the next XCD's counter.
-  constexpr int TCH = 16;
+  // XCD-affine supply (option spmm_tile_xcd = chunk length in tiles): tiles come off EIGHT counters, one per XCD
+  // (workgroups are dealt to the XCDs round robin: XCD = blockIdx & 7).  XCD x owns the chunks x, x + 8, x + 16, ... of
+  // 2^tsh consecutive tiles: consecutive rows of a graph with locality in its numbering meet in ONE L2 instead of being
+  // spread over all eight, and all XCDs advance through the rows at the same pace, so a numbering with its long rows at
+  // one end stays balanced.  The chunk has to be LONG: an XCD's 512 waves hold 512 tiles = 8 192 rows at any time, and
+  // with 16-tile chunks those are 32 chunks spread over 65 536 rows of the numbering (round 2: natural order 7.0 ms, no
+  // better than the global counter's 6.7); with chunks of 512 tiles they are one run of consecutive rows.  An XCD whose
+  // chunks are used up steals from the XCD that has the most tiles left.
+  const int tsh = f.tile_xcd - 1;  // log2 of the chunk length in tiles (tile_xcd = 0: one global counter)
   int own = f.tile_xcd ? (int)(blockIdx.x & 7) : 0;  // the XCD whose counter this wave is drawing from
-  int tried = f.tile_xcd ? 0 : 7, k_next = 0, k_left = 0;
+  int k_next = 0, k_left = 0;
   const int nwaves4 = ((int)gridDim.x * FUSE_WAVES * 4) / 8 > 0 ? ((int)gridDim.x * FUSE_WAVES * 4) / 8 : 1;
   const int per_xcd_tiles = (ntiles + 7) / 8;  // about what one XCD's chunks hold
+  const int n_chunks = f.tile_xcd ? (ntiles + (1 << tsh) - 1) >> tsh : 0;
   for (;;) {
     if (k_left == 0) {
-      if (tried >= 8) break;
       int want = 1;
       if constexpr (FLAT) {  // guided: (tiles this XCD has left) / (4 x its waves), at most 8, single tiles at the end
         const int left = f.tile_xcd ? per_xcd_tiles - k_next : (ntiles - k_next) / 8;
@@ -392,9 +412,22 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
       k0 = __builtin_amdgcn_readfirstlane(k0);
       if (!f.tile_xcd) {  // one global counter: tiles in order
         if (k0 >= ntiles) break;
-      } else if (((k0 / TCH) * 8 + own) * TCH >= ntiles) {  // this XCD's chunks are used up: on to the next one's
-        own = (own + 1) & 7;
-        ++tried;
+      } else if ((((k0 >> tsh) * 8 + own) << tsh) >= ntiles) {
+        // this XCD's chunks are used up: steal from the XCD that has the most tiles left (lane x looks at counter x;
+        // counters only grow, so a look that says "nothing left anywhere" is final)
+        int left = 0;
+        if (lane < 8) {
+          const int mine = n_chunks > lane ? ((n_chunks - lane + 7) >> 3) << tsh : 0;  // tiles in XCD `lane`'s chunks
+          left = mine - __hip_atomic_load(f.tile_counter + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int best = -1, best_left = 0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const int lx = __builtin_amdgcn_readlane(left, x);
+          if (lx > best_left) best_left = lx, best = x;
+        }
+        if (best < 0) break;
+        own = best;
         k_next = 0;
         continue;
       }
@@ -403,7 +436,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
     }
     const int kk = k_next++;
     --k_left;
-    const int t = f.tile_xcd ? ((kk / TCH) * 8 + own) * TCH + (kk % TCH) : kk;
+    const int t = f.tile_xcd ? ((((kk >> tsh) * 8 + own) << tsh) + (kk & ((1 << tsh) - 1))) : kk;
     if (t >= ntiles) continue;  // the ragged end of the last chunk
     const int row0 = t * FUSE_ROWS;
     // the 17 row boundaries of this tile, lane r holds rowptr[row0 + r]
@@ -1148,7 +1181,7 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
       f.tile_counter = counter;
       f.agg_in = (flags & GAIB_ACCUMULATE) ? d_agg + k0 : nullptr;
       f.y_accum = k0 > 0;
-      f.tile_xcd = ctx->spmm_tile_xcd;
+      f.tile_xcd = tile_xcd_arg(ctx, g);
       f.relu = ((flags & GAIB_RELU) && !dual && k0 + 128 >= len_in) ? 1 : 0;
       f.heavy_agg = hv + k0;
       f.heavy_rows = g->heavy_rows;
@@ -1197,7 +1230,7 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   f.rows2 = d_rows2;
   f.ldw = len_in;
   f.y_accum = 0;
-  f.tile_xcd = ctx->spmm_tile_xcd;
+  f.tile_xcd = tile_xcd_arg(ctx, g);
   f.y = d_out;
   f.ldy = len_out;
   f.n_out = len_out;
