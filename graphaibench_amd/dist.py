@@ -631,6 +631,35 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                      "halo_exchange_standalone_ms": r["exch_ms"], "halo_pack_ms": r["pack_ms"],
                      "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"],
                      "breakdown_ms_per_step_rank0": r["breakdown"], "parity": r["parity"]}
+    # BASELINE config 5 inside the default 8-GPU run: at N = 8 one vertex range of 1/8 of the papers100M shape per rank IS
+    # the papers100M-shaped graph, so the scaling run that measures the metric's "1/2/4/8" half also yields config 5's number
+    # (locality-preserving end of the partition axis; `--workload gcn-papers` gives both ends).  GAIB_BENCH_CONFIG5=0 skips.
+    config5 = None
+    c5 = os.environ.get("GAIB_BENCH_CONFIG5", "1")  # "force": also at other N / scales (the one-GPU test of this branch)
+    if not papers and not strong and args.cut_fraction is None and ((world == 8 and args.scale == 1.0 and c5 != "0") or c5 == "force"):
+        ok = 1
+        try:
+            t0 = time.time()
+            rows = synth.block_rows("ogbn-papers100M/8", rank, world, seed=42, cut_fraction=0.1, device="cuda",
+                                    scale=args.scale, selfloops=True)
+        except Exception as e:  # noqa: BLE001 -- an allocation failure here must not cost the scaling record
+            log(f"[bench r{rank}] config 5 graph generation failed: {type(e).__name__}: {e}")
+            rows, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank runs the case, or none does
+        if int(flag.item()):
+            r = _bench_case(ctx, comm, args, rank, world, D, log, rows, "config 5: papers100M shape, cut 0.100")
+            config5 = {"workload": "BASELINE config 5: ogbn-papers100M-shaped graph (111 M vertices, 3.2 G edges incl. self loops) "
+                                   "in 8 vertex ranges, GCN hidden layer 128->128 fwd+bwd, cut 0.1",
+                       "value": r["value"], "unit": "edges/s", "ms_per_step": r["ms_per_step"], "nv_per_gpu": r["nv"],
+                       "ne_total_with_selfloops": int(r["total_edges"]), "halo_rows_total": r["halo_rows_total"],
+                       "halo_bytes_per_step_total": r["halo_bytes_per_step_total"],
+                       "halo_exchange_standalone_ms": r["exch_ms"], "halo_pack_ms": r["pack_ms"],
+                       "breakdown_ms_per_step_rank0": r["breakdown"], "set_up_and_run_s": time.time() - t0}
+        else:
+            config5 = {"error": "graph generation failed on some rank (see stderr)"}
+        del rows
+        torch.cuda.empty_cache()
     achieved = main["alg_bytes"] / (main["avg_ms"] * 1e-3) / 1e9 if main["avg_ms"] > 0 else 0.0
     if comm is not None:
         comm.barrier()
@@ -670,6 +699,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             "transport": transport, "rccl_ranks": rccl_ranks,
             # the other end of the partition-quality axis, same invocation (weak scaling only)
             "random_order": extra,
+            "config5_papers100M": config5,
             "xgmi_link_probe": link,
         },
         "roofline": {

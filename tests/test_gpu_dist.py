@@ -162,8 +162,9 @@ def test_bench_plain_two_gpus_default_workload():
     import json
     import subprocess
 
+    # GAIB_BENCH_CONFIG5=force: the sub-record the default 8-GPU run adds (config 5's graph in the same invocation), here at 2 ranks
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=900, env=_clean_env())
+                       capture_output=True, text=True, timeout=900, env=dict(_clean_env(), GAIB_BENCH_CONFIG5="force"))
     assert r.returncode == 0, r.stderr[-4000:]
     out = r.stdout.strip().splitlines()
     assert len(out) == 1
@@ -173,3 +174,6 @@ def test_bench_plain_two_gpus_default_workload():
         assert res["config"]["transport"].startswith("gaib_comm/ipc") and res["config"]["rccl_ranks"] == 0
     else:
         assert res["config"]["rccl_ranks"] in (0, 2)
+    c5 = res["config"]["config5_papers100M"]
+    assert c5["value"] > 0 and c5["halo_rows_total"] > 0 and "config 5" in c5["workload"]
+    assert c5["nv_per_gpu"] == int(13_882_495 * 0.02)
