@@ -112,7 +112,8 @@ void SAGE_Aggregator::d_aggregate(int len, Graph& g, const float*, const float* 
 
 // ---- GAT ---------------------------------------------------------------------------------------
 GAT_Aggregator::GAT_Aggregator()
-    : epsilon(0.2f), attn_drop(0.f), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
+    : epsilon(0.2f), attn_drop(0.f), attn_scale(1.f), training(true), dropped_last(false), d_norm_scores_drop(NULL),
+      d_attn_masks(NULL), drop_cap(0), drop_seed(0xA77E0000ull), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
       d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), d_tbuf(NULL), tbuf_floats(0), d_ptab(NULL), d_pout(NULL),
       d_prs(NULL), d_pcs(NULL), ptab_floats(0), pvec_floats(0), d_row_stats(NULL), stats_floats(0), stats_valid(false),
@@ -123,15 +124,7 @@ void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   n = nv;
   attn_drop = drop_rate;
   assert(attn_drop >= 0. && attn_drop < 1.);
-  if (attn_drop > 0.f) {
-    // not silent: the rate is accepted for API parity but no attention weight is dropped -- the behaviour of the
-    // reference's OpenMP path, whose dropout call is commented out (gat_aggregator.cpp:78-79); its CUDA path masks the
-    // forward weights only (graph_operations.h:326-331, the backward mask is commented out at :419-422)
-    static bool told = false;
-    if (!told) fprintf(stderr, "GAT_Aggregator: score_drop = %g is NOT applied (as in the reference's OpenMP path, "
-                               "gat_aggregator.cpp:78-79); attention weights are used undropped\n", attn_drop);
-    told = true;
-  }
+  attn_scale = 1.f / (1.f - attn_drop);  // gat_aggregator.cpp:7
   num_edges = (size_t)ne;
   // alpha_l / alpha_r: Glorot over (l, 1) with seeds 2 and 3, as the reference's CPU path
   // (gat_aggregator.cpp:11-12)
@@ -152,6 +145,23 @@ void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
   d_norm_scores_t = gaib_host::dmalloc<float>(num_edges);
   epsilon = 0.2f;
   alpha_opt = new adam(lr);
+}
+
+// d_norm_scores (the softmax of this forward) -> p . mask . scale in a buffer of its own: backward needs both the
+// undropped attention (softmax backward) and the dropped one (d_dropout of dp, transposed aggregation)
+const float* GAT_Aggregator::apply_attn_dropout(size_t n_scores) {
+  if (n_scores > drop_cap) {
+    if (d_norm_scores_drop) float_free_device(d_norm_scores_drop);
+    if (d_attn_masks) GAIB_OR_DIE(gaib_free(C(), d_attn_masks));
+    float_malloc_device64(n_scores, d_norm_scores_drop);
+    d_attn_masks = gaib_host::dmalloc<mask_t>(n_scores);
+    drop_cap = n_scores;
+  }
+  OpTimer t(OP_DROPOUT);
+  GAIB_OR_DIE(gaib_dropout(C(), (int64_t)n_scores, attn_scale, attn_drop, drop_seed++, d_norm_scores, d_attn_masks,
+                           d_norm_scores_drop));
+  dropped_last = true;
+  return d_norm_scores_drop;
 }
 
 void GAT_Aggregator::set_num_heads(int h) {
@@ -211,8 +221,10 @@ void GAT_Aggregator::aggregate_partition(int len, Graph& g, const float* in, flo
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), g.gat_full_graph(), len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon,
                                    d_temp_scores, NULL, d_norm_scores));
   }
+  dropped_last = false;
+  const float* attn = dropping() ? apply_attn_dropout((size_t)g.sizeEdges() * heads) : d_norm_scores;
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm_mh(C(), g.gat_full_graph(), GAIB_W_EDGE, d_norm_scores, heads, len, d_ptab, out,
+  GAIB_OR_DIE(gaib_spmm_mh(C(), g.gat_full_graph(), GAIB_W_EDGE, attn, heads, len, d_ptab, out,
                            fuse_relu ? GAIB_RELU : 0));
   fuse_relu = false;
 }
@@ -226,6 +238,8 @@ void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_
   {
     OpTimer t(OP_SCORE);
     GAIB_OR_DIE(gaib_sddmm_mh(C(), full, len, heads, grad_in, d_ptab, d_norm_scores_grad));
+    if (dropped_last)  // d(out)/d(p_e) = mask_e . scale . <grad_i, h_c>
+      GAIB_OR_DIE(gaib_d_dropout(C(), ne * heads, attn_scale, d_norm_scores_grad, d_attn_masks, d_norm_scores_grad));
   }
   {
     OpTimer t(OP_ATTN);
@@ -237,7 +251,8 @@ void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_
   }
   {
     OpTimer t(OP_TRANSPOSE);
-    GAIB_OR_DIE(gaib_edge_gather_perm(C(), ne, heads, g.gat_tperm(), d_norm_scores, d_norm_scores_grad));
+    GAIB_OR_DIE(gaib_edge_gather_perm(C(), ne, heads, g.gat_tperm(), dropped_last ? d_norm_scores_drop : d_norm_scores,
+                                      d_norm_scores_grad));
   }
   OpTimer t(OP_SPARSEMM);
   GAIB_OR_DIE(gaib_spmm_mh(C(), gt, GAIB_W_EDGE, d_norm_scores_grad, heads, len, grad_in, d_pout, 0));
@@ -258,7 +273,8 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
   // dense graphs at 64 columns: scores, edge softmax and aggregation in ONE sweep; only the row statistics (maximum,
   // 1 / sum) are kept and backward forms the attention again -- no [ne][heads] array is written or read.  norm_scores_ptr()
   // materialises the attention on demand (tests, checkpoints).
-  {
+  dropped_last = false;
+  if (!dropping()) {
     const size_t need = (size_t)g.size() * heads * 2;
     if (need > stats_floats) {
       if (d_row_stats) float_free_device(d_row_stats);
@@ -277,8 +293,8 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
       return;
     }
     if (rc != GAIB_ERR_UNSUPPORTED) GAIB_OR_DIE(rc);
-    stats_valid = false;
   }
+  stats_valid = false;
   if (g.sizeEdges() > num_edges) {  // a larger graph than the one the layer was built on (sampling -> full graph)
     num_edges = g.sizeEdges();
     float** arrays[] = {&d_norm_scores, &d_norm_scores_grad, &d_norm_scores_t};
@@ -298,9 +314,9 @@ void GAT_Aggregator::aggregate(int len, Graph& g, const float* in, float* out) {
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), dev(g), len, heads, in, d_alpha_l, d_alpha_r, epsilon, d_temp_scores,
                                    NULL, d_norm_scores));
   }
+  const float* attn = dropping() ? apply_attn_dropout((size_t)g.sizeEdges() * heads) : d_norm_scores;
   OpTimer t(OP_SPARSEMM);
-  GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores, heads, len, in, out,
-                           fuse_relu ? GAIB_RELU : 0));
+  GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, attn, heads, len, in, out, fuse_relu ? GAIB_RELU : 0));
   fuse_relu = false;
 }
 
@@ -313,7 +329,7 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
     d_aggregate_partition(len, g, grad_in, grad_out);
     return;
   }
-  if (fwd_out) {
+  if (fwd_out && !dropped_last) {
     // one sweep over the edges instead of four (gaib_gat_backward_fused): needs the layer's forward output and an
     // output that does not alias feat_in (GAT_layer::backward passes out_temp for both) -> a scratch of its own
     OpTimer t(OP_ATTN);
@@ -337,6 +353,9 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
   {
     OpTimer t(OP_SCORE);
     GAIB_OR_DIE(gaib_sddmm_mh(C(), dev(g), len, heads, grad_in, feat_in, d_norm_scores_grad));
+    if (dropped_last)  // d(out)/d(p_e) = mask_e . scale . <grad_i, h_c>; sum_e p_e dp_e is still <grad_i, out_i>
+      GAIB_OR_DIE(gaib_d_dropout(C(), (int64_t)(g.sizeEdges() * heads), attn_scale, d_norm_scores_grad, d_attn_masks,
+                                 d_norm_scores_grad));
   }
   {
     OpTimer t(OP_ATTN);
@@ -354,6 +373,10 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
       GAIB_OR_DIE(gaib_gat_softmax_bwd_alpha_re(C(), dev(g), len, heads, feat_in, d_alpha_l, d_alpha_r, d_norm_scores,
                                                 d_norm_scores_grad, epsilon, NULL, d_alpha_lgrad, d_alpha_rgrad,
                                                 fwd ? grad_in : NULL, fwd, d_norm_scores_t));
+  }
+  if (dropped_last) {  // the gradient flows back along the DROPPED attention: its transpose replaces the undropped one
+    OpTimer t2(OP_TRANSPOSE);
+    GAIB_OR_DIE(gaib_edge_transpose_mh(C(), dev(g), heads, d_norm_scores_drop, d_norm_scores_t));
   }
   OpTimer t(OP_SPARSEMM);
   GAIB_OR_DIE(gaib_spmm_mh(C(), dev(g), GAIB_W_EDGE, d_norm_scores_t, heads, len, grad_in, grad_out, 0));

@@ -132,6 +132,8 @@ float* gaibl_layer_ptr(void* layer, int which) {
     case GAIBL_TEMP_SCORES: return a.temp_scores_ptr();
     case GAIBL_SCORES: return a.scores_ptr();
     case GAIBL_NORM_SCORES_GRAD: return a.norm_scores_grad_ptr();
+    case GAIBL_NORM_SCORES_DROPPED: return a.norm_scores_dropped_ptr();
+    case GAIBL_ATTN_MASKS: return reinterpret_cast<float*>(a.attn_masks_ptr());
     default: return nullptr;
   }
 }

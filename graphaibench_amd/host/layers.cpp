@@ -206,6 +206,7 @@ void GAT_layer::forward(float* feat_out) {
     in_data = d_in_temp;
   }
   matmul(x, z, y, in_data, d_W_neigh, d_out_temp);    // h = X.W
+  aggr.set_training(phase_ == net_phase::TRAIN);      // attention dropout (score_drop), like feat_drop, only while training
   if (is_act) aggr.fuse_relu_once();
   aggr.aggregate(z, *graph, d_out_temp, feat_out);    // attention over h (+ relu)
 }

@@ -14,7 +14,7 @@ from . import capi
 LIB_PATH = capi.LIB_DIR / "libgaib_gnn.so"
 GCN, SAGE, GAT = 0, 1, 2
 (FEAT_IN, GRAD_IN, W_NEIGH, W_NEIGH_GRAD, W_SELF, W_SELF_GRAD, ALPHA_L, ALPHA_R, ALPHA_LGRAD, ALPHA_RGRAD,
- NORM_SCORES, TEMP_SCORES, SCORES, NORM_SCORES_GRAD) = range(14)
+ NORM_SCORES, TEMP_SCORES, SCORES, NORM_SCORES_GRAD, NORM_SCORES_DROPPED, ATTN_MASKS) = range(16)
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
@@ -164,6 +164,10 @@ class Layer:
 
     def update_weight(self, opt):
         self.lib.gaibl_layer_update_weight(self.h, opt)
+
+    def set_phase(self, phase: int):
+        """set_netphase: 0 TRAIN, 1 TEST, 2 VAL (dropout only while training)"""
+        self.lib.gaibl_layer_set_phase(self.h, phase)
 
     def set_heads(self, heads: int):
         self.lib.gaibl_layer_set_heads(self.h, heads)

@@ -21,7 +21,9 @@ enum {
   GAIBL_FEAT_IN = 0, GAIBL_GRAD_IN = 1, GAIBL_W_NEIGH = 2, GAIBL_W_NEIGH_GRAD = 3, GAIBL_W_SELF = 4,
   GAIBL_W_SELF_GRAD = 5, GAIBL_ALPHA_L = 6, GAIBL_ALPHA_R = 7, GAIBL_ALPHA_LGRAD = 8,
   GAIBL_ALPHA_RGRAD = 9, GAIBL_NORM_SCORES = 10, GAIBL_TEMP_SCORES = 11, GAIBL_SCORES = 12,
-  GAIBL_NORM_SCORES_GRAD = 13
+  GAIBL_NORM_SCORES_GRAD = 13,
+  GAIBL_NORM_SCORES_DROPPED = 14, /* GAT, score_drop > 0: attention . mask . scale of the last training forward */
+  GAIBL_ATTN_MASKS = 15           /* ... and its masks (uint8 [ne][heads], returned through the float* type) */
 };
 
 void gaibl_init(int device, void* hip_stream); /* gpu_context::set */

@@ -75,6 +75,9 @@ class GAT_Aggregator : public aggregator {
   // extension: the next d_aggregate() may read the layer's forward output rows `out` (post-activation is fine as
   // long as grad_in went through the matching d_relu): it replaces the per-row sum_e p_e dp_e by <grad_i, out_i>
   void use_forward_output_once(const float* out) { fwd_out = out; }
+  // attention dropout (score_drop > 0) is applied while training only, like the layers' feature dropout; the layer
+  // passes its phase on before every forward
+  void set_training(bool on) { training = on; }
   // device state (tests / checkpoints)
   float* alpha_l_ptr() { return d_alpha_l; }
   float* alpha_r_ptr() { return d_alpha_r; }
@@ -84,13 +87,27 @@ class GAT_Aggregator : public aggregator {
   float* temp_scores_ptr() { return d_temp_scores; }  // NULL for 4, 8, 16 heads: not materialised either
   float* scores_ptr() { return NULL; }  // leaky_relu(temp_scores): not materialised by this backend
   float* norm_scores_grad_ptr() { return d_norm_scores_grad; }
+  float* norm_scores_dropped_ptr() { return d_norm_scores_drop; }  // NULL unless a training forward dropped attention
+  mask_t* attn_masks_ptr() { return d_attn_masks; }
 
  private:
   // the temp_scores array is kept where re-forming the score is not a gain: 1 or 2 heads (measured on the
   // reddit-shaped graph: 4.0 vs 4.7 ms for scores + softmax backward at 1 head, 10.5 vs 10.1 ms at 8 heads)
   bool needs_temp() const { return !(heads == 4 || heads == 8 || heads == 16); }
   float epsilon;    // LeakyReLU negative slope (0.2)
-  float attn_drop;  // attention dropout: accepted, not applied (reference CPU path has it commented out)
+  // attention dropout: the normalised scores of a training forward are masked and rescaled (the reference's CUDA path,
+  // graph_operations.h:326-331; its OpenMP path has the call commented out, gat_aggregator.cpp:78-79), and backward goes
+  // through the SAME mask: dp_e is masked and rescaled before the softmax backward (d_dropout, graph_operations.h:376-377
+  // -- the `_naive` form; the `_warp` form the reference launches has it commented out at :419-422), and the transposed
+  // aggregation uses the dropped attention.  Masks from the library's counter RNG (gaib_dropout), one per (edge, head).
+  float attn_drop, attn_scale;
+  bool training, dropped_last;  // dropped_last: the last forward applied a mask (backward must take the staged path)
+  float* d_norm_scores_drop;    // [ne][heads] p . mask . scale of the last training forward
+  mask_t* d_attn_masks;         // [ne][heads]
+  size_t drop_cap;
+  uint64_t drop_seed;
+  bool dropping() const { return attn_drop > 0.f && training; }
+  const float* apply_attn_dropout(size_t n_scores);  // d_norm_scores -> d_norm_scores_drop (+ masks); returns the latter
   size_t num_edges;
   int heads;
   float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
