@@ -109,6 +109,7 @@ SIGNATURES = {
     "gaib_prof_enable": (_i, [_vp, _i]),
     "gaib_prof_reset": (_i, [_vp]),
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gaib_graph_reorder": (_i, [_vp, _vp, _i, _pp, _vp, _vp]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "gaib_device_count": (_i, [C.POINTER(_i)]),
@@ -139,6 +140,7 @@ class GaibError(RuntimeError):
 
 
 COMM_RCCL, COMM_IPC = 0, 1
+ORDER_DEGREE, ORDER_BFS = 1, 2
 COMM_ID_BYTES = 128
 
 
@@ -606,6 +608,17 @@ class Graph:
         h = C.c_void_p()
         _check(self.lib.gaib_graph_add_selfloop(self.ctx.h, self.h, C.byref(h)), "gaib_graph_add_selfloop")
         return Graph(self.ctx, _handle=h)
+
+    def reorder(self, method: int = ORDER_BFS):
+        """(relabelled graph, new_of_old, old_of_new) -- gaib_graph_reorder: rows keep their edge order"""
+        import torch
+
+        h = C.c_void_p()
+        new_of_old = torch.empty(self.nv, dtype=torch.int64, device=f"cuda:{self.ctx.device}")
+        old_of_new = torch.empty_like(new_of_old)
+        _check(self.lib.gaib_graph_reorder(self.ctx.h, self.h, method, C.byref(h), new_of_old.data_ptr(), old_of_new.data_ptr()),
+               "gaib_graph_reorder")
+        return Graph(self.ctx, _handle=h), new_of_old, old_of_new
 
     def compute_vertex_data(self):
         _check(self.lib.gaib_graph_compute_vertex_data(self.ctx.h, self.h), "gaib_graph_compute_vertex_data")

@@ -173,7 +173,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--block", type=int, default=16384)
     ap.add_argument("--cut", type=float, default=0.1)
-    ap.add_argument("--order", choices=["rcm", "degree"], default="rcm")
+    ap.add_argument("--order", choices=["rcm", "degree", "bfs-device", "degree-device"], default="rcm",
+                    help="rcm / degree: computed here (scipy on the host / torch); *-device: gaib_graph_reorder, the library's own "
+                         "opt-in relabelling (order AND relabelled graph built on the device)")
     ap.add_argument("--kernel", choices=["w64", "fused"], default="w64")
     ap.add_argument("--opt", action="append", default=[], help="context option key=value (gaib_set_option), repeatable")
     ap.add_argument("--parse", default=None)
@@ -205,11 +207,22 @@ def main():
     err = (out_p[perm] - out_nat).abs().max().item() / out_nat.abs().max().item()
     del out_nat, x_nat
     # recover an order from the permuted graph alone; rows keep their edge order
-    new_of_old, secs = order_from_graph(rp_p, ci_p, args.order)
-    rp_r, ci_r = relabel_keep_row_order(rp_p, ci_p, new_of_old)
+    if args.order.endswith("-device"):
+        gp = ctx.graph(rp_p, ci_p)
+        ctx.sync()
+        t0 = time.time()
+        gr, new_of_old, _ = gp.reorder(capi.ORDER_BFS if args.order.startswith("bfs") else capi.ORDER_DEGREE)
+        ctx.sync()
+        secs = time.time() - t0
+        rp_r, ci_r = gr.rowptr().clone(), gr.colidx().clone()
+        gr.close()
+        gp.close()
+    else:
+        new_of_old, secs = order_from_graph(rp_p, ci_p, args.order)
+        rp_r, ci_r = relabel_keep_row_order(rp_p, ci_p, new_of_old)
     x_r = torch.empty_like(x_p)
     x_r[new_of_old] = x_p
-    out_r = run(ctx, "reordered", rp_r, ci_r, x_r, dict(method=args.order, ordering_seconds_host=secs,
+    out_r = run(ctx, "reordered", rp_r, ci_r, x_r, dict(method=args.order, ordering_seconds=secs,
                                                         natural_vs_permuted_rel_err=err))
     same = torch.equal(out_r[new_of_old], out_p)
     print(json.dumps({"reordered_rows_bit_identical_to_permuted": bool(same)}), flush=True)

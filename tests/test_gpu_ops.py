@@ -1178,6 +1178,69 @@ def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
     assert_close(y.cpu().numpy(), y_w)
 
 
+@pytest.mark.parametrize("method", ["degree", "bfs"])
+def test_graph_reorder_keeps_every_row_bit_identical(ctx, method):
+    """gaib_graph_reorder (opt-in relabelling computed on the device): a permutation; hubs-first is by descending degree,
+    BFS by the distance from the highest-degree vertex (against scipy), unreached vertices last; the relabelled graph is
+    the same graph (every row keeps the ORDER of its edges), so GCN / mean / transpose-mean aggregations -- light rows,
+    heavy rows, and the fused aggregation + product -- are BIT-identical once un-permuted."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order, shortest_path  # noqa: F401
+
+    rp, ci = random_graph(20000, 14, seed=4, power_law=True, hub_deg=3000)
+    # a second component the search from the hub cannot reach: vertices 19990.. form a clique of their own
+    rows = np.repeat(np.arange(20000), np.diff(rp))
+    keep = (rows < 19990) & (ci < 19990)
+    src = np.concatenate([rows[keep], np.repeat(np.arange(19990, 20000), 10)])
+    dst = np.concatenate([ci[keep].astype(np.int64), np.tile(np.arange(19990, 20000), 10)])
+    from util import csr_from_pairs
+    rp, ci = csr_from_pairs(20000, src, dst)
+    g = ctx.graph(rp, ci.view(np.int32)).add_selfloop()
+    n = g.nv
+    r, new_of_old, old_of_new = g.reorder(capi.ORDER_DEGREE if method == "degree" else capi.ORDER_BFS)
+    assert r.nv == n and r.ne == g.ne
+    no, on = new_of_old.cpu().numpy(), old_of_new.cpu().numpy()
+    assert np.array_equal(np.sort(no), np.arange(n)) and np.array_equal(no[on], np.arange(n))
+    deg = np.diff(g.rowptr().cpu().numpy())
+    if method == "degree":
+        d_new = deg[on]
+        assert np.all(d_new[:-1] >= d_new[1:])
+        same = d_new[:-1] == d_new[1:]
+        assert np.all(on[:-1][same] < on[1:][same])  # stable in the old id
+    else:
+        m = sp.csr_matrix((np.ones(len(ci), np.int8), ci, rp), shape=(n, n))
+        hub = int(np.argmax(deg))
+        dist = sp.csgraph.shortest_path(m, unweighted=True, indices=hub)
+        lvl = np.where(np.isinf(dist), dist[~np.isinf(dist)].max() + 1, dist).astype(np.int64)
+        l_new = lvl[on]
+        assert np.all(l_new[:-1] <= l_new[1:]) and on[0] == hub
+        assert set(on[-10:]) == set(range(19990, 20000))  # the unreached component last
+        same = l_new[:-1] == l_new[1:]
+        assert np.all(on[:-1][same] < on[1:][same])
+    # the relabelled rows: row new(v) lists new(c) for the columns c of old row v, in the same order
+    rp_o, ci_o = g.rowptr().cpu().numpy(), g.colidx().cpu().numpy().view(np.uint32)
+    rp_n, ci_n = r.rowptr().cpu().numpy(), r.colidx().cpu().numpy().view(np.uint32)
+    for v in (0, int(np.argmax(deg)), 777, 19995, n - 1):
+        k = no[v]
+        assert np.array_equal(ci_n[rp_n[k]:rp_n[k + 1]], no[ci_o[rp_o[v]:rp_o[v + 1]]])
+    x = dev(feat(n, 128, 5))
+    x_new = torch.empty_like(x)
+    ctx.gather_rows(old_of_new, x, x_new)
+    for kind in (capi.W_GCN, capi.W_MEAN, capi.W_MEAN_T):
+        y, y_new, back = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        ctx.spmm(g, kind, x, y)
+        ctx.spmm(r, kind, x_new, y_new)
+        ctx.gather_rows(new_of_old, y_new, back)
+        assert torch.equal(back, y), kind
+    W = dev(feat(128, 128, 6) * 0.1)
+    agg, yy, agg_n, yy_n, back = (torch.empty_like(x) for _ in range(5))
+    ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, yy, relu=True)
+    ctx.spmm_gemm(r, capi.W_GCN, x_new, agg_n, W, yy_n, relu=True)
+    ctx.gather_rows(new_of_old, yy_n, back)
+    assert torch.equal(back, yy)
+    r.close()
+
+
 def test_probe_stream_copy(ctx):
     """the in-run streaming-rate probe bench.py reports as roofline.peak_measured: between the guide's measured
     stream copy (6.3 TB/s) -20 % and the 8 TB/s spec peak; the peer probe refuses a single device"""
