@@ -109,6 +109,9 @@ SIGNATURES = {
     "gaib_prof_enable": (_i, [_vp, _i]),
     "gaib_prof_reset": (_i, [_vp]),
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gaib_gat_forward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _i]),
+    "gaib_gat_backward_rec": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "gaib_gat_backward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i]),
     "gaib_graph_reorder": (_i, [_vp, _vp, _i, _pp, _vp, _vp]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),

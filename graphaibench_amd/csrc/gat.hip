@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
     const float* p, const float2* stats, const float* rowdot, const float* alpha_l, const float* alpha_r, float eps,
-    float* out_partial, float* rc_partial, const f4* rec) {
+    float* out_partial, float* rc_partial, const f4* rec, int phase, uint32_t own_cols) {
   // rec (RECOMP): (rowdot, row maximum, 1 / row sum) per (vertex, head) as one 16-byte record, see gat_rec_kernel
   constexpr int LH = G / H;  // lanes per head
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -853,6 +853,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   const int64_t rb = rowptr[row];
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
+
   // edge t * 4 + g of the chunk is step t of lane group g: a chunk of n edges takes ceil(n / 4) steps whatever n is (with
   // group g on edges 16 g .. 16 g + 15, the 17-edge tail of a row took all 16).
   // Lane (g, t) fetches that edge's column id, so "step t of my group" is lane t of my 16-lane row (DPP).
@@ -860,6 +861,10 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   const int my_e = sl * 4 + grp;
   const int64_t el = eb + (my_e < n ? my_e : 0);
   const uint32_t cl = col[el];
+  // a rank's rows over [owned | halo] columns (a row keeps the global edge order, so halo ids sit on both sides of the
+  // owned ones): phase 0 sweeps the chunks that touch owned columns only -- while the halo rows are still on the wire --,
+  // phase 1 the others; -1: all
+  if (phase >= 0 && ((__ballot(my_e < n && cl >= own_cols) == 0) != (phase == 0))) return;
   uint32_t rl = 0;
   if constexpr (!RECOMP) rl = rev[el];
   const int coff = sl * 4;  // len == 4 * G
@@ -974,7 +979,7 @@ template <int G, int H, int U>
 __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, int len, const float* feat, const float* alpha_l, const float* alpha_r,
-    float eps, float* out_partial, float2* ms_partial) {
+    float eps, float* out_partial, float2* ms_partial, int phase, uint32_t own_cols) {
   constexpr int LH = G / H;
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
@@ -985,9 +990,11 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   const int64_t rb = rowptr[row];
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
+
   const int grp = lane >> 4;  // edge t * 4 + g = step t of lane group g (see the backward kernel)
   const int my_e = sl * 4 + grp;
   const uint32_t cl = col[eb + (my_e < n ? my_e : 0)];
+  if (phase >= 0 && ((__ballot(my_e < n && cl >= own_cols) == 0) != (phase == 0))) return;  // (see the backward kernel)
   const int coff = sl * 4;
   const int head = sl / LH;
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
@@ -1396,12 +1403,13 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
 // gat_fused_bwd: -1 = graphs with >= 1/4 of their edges in heavy rows and a feature table of <= 512 MB -- the
 // dense-graph rule of the aggregation; 0 = never; 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and
 // nothing was touched: the caller runs the staged entry points.
-static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, int knob, uintptr_t align_or, int* rc) {
+static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, int knob, uintptr_t align_or, int* rc,
+                              bool rect = false) {
   *rc = GAIB_OK;
   const bool shape_ok = len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) &&
-                        g->nc == g->nv && g->ne > 0 && (align_or & 15) == 0;
+                        (rect || g->nc == g->nv) && g->ne > 0 && (align_or & 15) == 0;
   bool use = shape_ok && knob != 0;
-  if (use && knob < 0) {
+  if (use && knob < 0 && !rect) {  // (a rank's share of a partition: the staged pieces there cost two permuted [ne][H] copies more)
     *rc = gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold);
     if (*rc != GAIB_OK) return false;
     use = g->n_heavy > 0 && 4 * g->heavy_edges >= g->ne && (int64_t)g->nv * len * 4 <= ((int64_t)512 << 20);
@@ -1413,20 +1421,24 @@ static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, 
 // the leaky-relu'd scores, 1 / row sum of exp) -- everything backward needs to form the attention again; no [ne][heads]
 // array is written.  Same cover and auto rule as gaib_gat_backward_fused (option "gat_fused_fwd"); otherwise
 // GAIB_ERR_UNSUPPORTED, nothing touched, and the caller runs gaib_gat_scores_mh + gaib_spmm_mh.
-extern "C" int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h,
-                                      const float* d_alpha_l, const float* d_alpha_r, float epsilon, int relu,
-                                      float* d_out, float* d_row_stats) {
-  GAIB_CHECK(ctx && g, "gaib_gat_forward_fused: NULL ctx/graph");
-  GAIB_TRY(check_heads("gaib_gat_forward_fused", len, heads));
-  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_out && d_row_stats && d_out != d_h, "gaib_gat_forward_fused: NULL or aliased pointer");
+// phase: -1 = the whole sweep + the per-row combination (square graphs, or a rectangular one whose table is complete);
+// 0 = only the chunks over owned columns (columns < g->nv), nothing else; 1 = the remaining chunks + the combination.
+// The partial results of phase 0 live in the context's workspace until phase 1: no other call on the context in between.
+static int gat_forward_fused_impl(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h, const float* d_alpha_l,
+                                  const float* d_alpha_r, float epsilon, int relu, float* d_out, float* d_row_stats, int phase,
+                                  bool rect, const char* who) {
+  GAIB_CHECK(ctx && g, "%s: NULL ctx/graph", who);
+  GAIB_TRY(check_heads(who, len, heads));
+  GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_out && d_row_stats && d_out != d_h, "%s: NULL or aliased pointer", who);
+  GAIB_CHECK(phase >= -1 && phase <= 1, "%s: phase is -1, 0 or 1", who);
   GAIB_HIP(hipSetDevice(ctx->device));
   int rc = GAIB_OK;
   const bool use = gat_fused_applies(ctx, g, len, heads, ctx->gat_fused_fwd,
                                      (uintptr_t)d_h | (uintptr_t)d_out | (uintptr_t)d_row_stats | (uintptr_t)d_alpha_l |
-                                         (uintptr_t)d_alpha_r, &rc);
+                                         (uintptr_t)d_alpha_r, &rc, rect);
   if (rc != GAIB_OK) return rc;
   if (!use) {
-    gaib_set_error("gaib_gat_forward_fused: not applicable to this shape / graph (len %d, heads %d)", len, heads);
+    gaib_set_error("%s: not applicable to this shape / graph (len %d, heads %d)", who, len, heads);
     return GAIB_ERR_UNSUPPORTED;
   }
   GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
@@ -1440,7 +1452,8 @@ extern "C" int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int
 #define GAIB_FF(HH)                                                                                                       \
   gat_fwd_fused_chunk_kernel<16, HH, 8><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,          \
                                                                        g->chunk_start, g->rowptr, g->colidx, len, d_h,     \
-                                                                       d_alpha_l, d_alpha_r, epsilon, out_partial, ms_partial)
+                                                                       d_alpha_l, d_alpha_r, epsilon, out_partial, ms_partial, \
+                                                                       phase, (uint32_t)g->nv)
   switch (heads) {
     case 1: GAIB_FF(1); break;
     case 2: GAIB_FF(2); break;
@@ -1450,10 +1463,27 @@ extern "C" int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int
   }
 #undef GAIB_FF
   GAIB_LAUNCH_CHECK();
+  if (phase == 0) return GAIB_OK;
   gat_fwd_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial, ms_partial,
                                                                  relu ? 1 : 0, d_out, reinterpret_cast<float2*>(d_row_stats));
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
+}
+
+extern "C" int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h,
+                                      const float* d_alpha_l, const float* d_alpha_r, float epsilon, int relu,
+                                      float* d_out, float* d_row_stats) {
+  return gat_forward_fused_impl(ctx, g, len, heads, d_h, d_alpha_l, d_alpha_r, epsilon, relu, d_out, d_row_stats, -1, false,
+                                "gaib_gat_forward_fused");
+}
+
+// the same on a rank's RECTANGULAR graph (rows = owned vertices, columns = [owned | halo]): d_tab [nc x len] holds the owned
+// rows of h first, then the halo rows.  phase 0 may run while the halo rows are still arriving (it reads owned rows only).
+extern "C" int gaib_gat_forward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_tab,
+                                           const float* d_alpha_l, const float* d_alpha_r, float epsilon, int relu,
+                                           float* d_out, float* d_row_stats, int phase) {
+  return gat_forward_fused_impl(ctx, g, len, heads, d_tab, d_alpha_l, d_alpha_r, epsilon, relu, d_out, d_row_stats, phase, true,
+                                "gaib_gat_forward_fused_rect");
 }
 
 extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat,
@@ -1505,7 +1535,7 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   gat_bwd_fused_chunk_kernel<16, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
       g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, g->rev, len, d_feat, d_grad,        \
       d_norm_scores, reinterpret_cast<const float2*>(d_row_stats), rowdot, d_alpha_l, d_alpha_r, epsilon, out_partial,     \
-      rc_partial, rec)
+      rc_partial, rec, -1, 0u)
 #define GAIB_FB(HH)                                          \
   do {                                                       \
     if (d_row_stats) {                                       \
@@ -1530,6 +1560,96 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
                                                                    rc_partial, d_grad_out, rs, cs);
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
+                                                                         rows_per_block, partial);
+  GAIB_LAUNCH_CHECK();
+  alpha_final_kernel<<<(unsigned)cdiv64(2 * (int64_t)len, 4), 256, 0, ctx->stream>>>(nblocks, len, partial, d_alpha_lgrad,
+                                                                                    d_alpha_rgrad);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+// ---- the one-sweep backward on a rank's RECTANGULAR graph -------------------------------------------------
+// Everything row i needs about its edge (i -> c) and the reverse edge (c -> i) follows from per-VERTEX quantities of i and
+// c (h, grad, and the record (rowdot, row maximum, 1 / row sum)), and in a structurally symmetric graph the in-edges of i
+// are the reverses of its out-edges: so the rank that owns row i computes rs_i, cs_i and the aggregated gradient of i from
+// i's own edge list alone, given the halo vertices' h rows (still there from forward), grad rows and records.  No
+// transposed structure, no permuted [ne][H] copies, no reverse exchange of partial rows: two forward-direction halo
+// exchanges (grad rows, records) and one sweep.
+//   gaib_gat_backward_rec: the owned vertices' records  rec[v][h] = (<grad_v, out_v>_h, M_vh, 1/S_vh, 0)
+//   gaib_gat_backward_fused_rect: d_feat_tab / d_grad_tab [nc x len], d_rec_tab [nc][heads][4] with the owned rows first;
+//     phase as in gaib_gat_forward_fused_rect (0 reads owned rows only).  The alpha gradients cover the OWNED rows: the
+//     caller sums them over the ranks.
+extern "C" int gaib_gat_backward_rec(gaib_ctx* ctx, int64_t nv, int len, int heads, const float* d_grad, const float* d_fwd_out,
+                                     const float* d_row_stats, float* d_rec) {
+  GAIB_CHECK(ctx && (nv == 0 || (d_grad && d_fwd_out && d_row_stats && d_rec)), "gaib_gat_backward_rec: NULL argument");
+  GAIB_TRY(check_heads("gaib_gat_backward_rec", len, heads));
+  if (nv <= 0) return GAIB_OK;
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const size_t n_v = ((size_t)nv * heads + 3) & ~(size_t)3;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * n_v));
+  float* rowdot = (float*)ctx->ws;
+  rowdot_kernel<<<rowgrid(nv), 256, 0, ctx->stream>>>(nv, len, heads, d_grad, d_fwd_out, rowdot);
+  GAIB_LAUNCH_CHECK();
+  const int64_t nrec = nv * (int64_t)heads;
+  gat_rec_kernel<<<(unsigned)cdiv64(nrec, 256), 256, 0, ctx->stream>>>(nrec, rowdot, reinterpret_cast<const float2*>(d_row_stats),
+                                                                      reinterpret_cast<f4*>(d_rec));
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat_tab,
+                                            const float* d_grad_tab, const float* d_rec_tab, const float* d_alpha_l,
+                                            const float* d_alpha_r, float epsilon, float* d_grad_out, float* d_alpha_lgrad,
+                                            float* d_alpha_rgrad, int phase) {
+  GAIB_CHECK(ctx && g, "gaib_gat_backward_fused_rect: NULL ctx/graph");
+  GAIB_TRY(check_heads("gaib_gat_backward_fused_rect", len, heads));
+  GAIB_CHECK(d_feat_tab && d_grad_tab && d_rec_tab && d_alpha_l && d_alpha_r && d_grad_out && d_alpha_lgrad && d_alpha_rgrad,
+             "gaib_gat_backward_fused_rect: NULL pointer");
+  GAIB_CHECK(d_grad_out != d_feat_tab && d_grad_out != d_grad_tab, "gaib_gat_backward_fused_rect: d_grad_out must not alias an input");
+  GAIB_CHECK(phase >= -1 && phase <= 1, "gaib_gat_backward_fused_rect: phase is -1, 0 or 1");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  int rc0 = GAIB_OK;
+  const bool use = gat_fused_applies(ctx, g, len, heads, ctx->gat_fused_bwd,
+                                     (uintptr_t)d_feat_tab | (uintptr_t)d_grad_tab | (uintptr_t)d_rec_tab | (uintptr_t)d_grad_out,
+                                     &rc0, true);
+  if (rc0 != GAIB_OK) return rc0;
+  if (!use) {
+    gaib_set_error("gaib_gat_backward_fused_rect: not applicable to this shape / graph (len %d, heads %d)", len, heads);
+    return GAIB_ERR_UNSUPPORTED;
+  }
+  GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+  const int nblocks = (int)(g->nv < 2048 ? cdiv64(g->nv, 8) : 1024);
+  const int64_t rows_per_block = cdiv64(g->nv, nblocks);
+  auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+  const size_t n_v = up4((size_t)g->nv * heads);
+  const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (2 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
+  float* rs = (float*)ctx->ws;
+  float* cs = rs + n_v;
+  float* out_partial = cs + n_v;
+  float* rc_partial = out_partial + n_op;
+  float* partial = rc_partial + n_rc;
+  ProfScope ps(ctx, "gat_bwd_fused");
+  const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+#define GAIB_FBR(HH)                                                                                                       \
+  gat_bwd_fused_chunk_kernel<16, HH, 4, true><<<grid, 256, 0, ctx->stream>>>(                                              \
+      g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, nullptr, len, d_feat_tab, d_grad_tab, \
+      nullptr, nullptr, nullptr, d_alpha_l, d_alpha_r, epsilon, out_partial, rc_partial,                                   \
+      reinterpret_cast<const f4*>(d_rec_tab), phase, (uint32_t)g->nv)
+  switch (heads) {
+    case 1: GAIB_FBR(1); break;
+    case 2: GAIB_FBR(2); break;
+    case 4: GAIB_FBR(4); break;
+    case 8: GAIB_FBR(8); break;
+    default: GAIB_FBR(16); break;
+  }
+#undef GAIB_FBR
+  GAIB_LAUNCH_CHECK();
+  if (phase == 0) return GAIB_OK;
+  gat_fused_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial,
+                                                                   rc_partial, d_grad_out, rs, cs);
+  GAIB_LAUNCH_CHECK();
+  alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat_tab, rs, cs,
                                                                          rows_per_block, partial);
   GAIB_LAUNCH_CHECK();
   alpha_final_kernel<<<(unsigned)cdiv64(2 * (int64_t)len, 4), 256, 0, ctx->stream>>>(nblocks, len, partial, d_alpha_lgrad,

@@ -116,7 +116,8 @@ GAT_Aggregator::GAT_Aggregator()
       d_attn_masks(NULL), drop_cap(0), drop_seed(0xA77E0000ull), num_edges(0), heads(1), d_alpha_l(NULL), d_alpha_r(NULL), d_alpha_lgrad(NULL),
       d_alpha_rgrad(NULL), d_temp_scores(NULL), d_norm_scores(NULL),
       d_norm_scores_grad(NULL), d_norm_scores_t(NULL), fwd_out(NULL), d_tbuf(NULL), tbuf_floats(0), d_ptab(NULL), d_pout(NULL),
-      d_prs(NULL), d_pcs(NULL), ptab_floats(0), pvec_floats(0), d_row_stats(NULL), stats_floats(0), stats_valid(false),
+      d_prs(NULL), d_pcs(NULL), ptab_floats(0), pvec_floats(0), d_pgrad(NULL), d_prec(NULL), pgrad_floats(0), prec_floats(0),
+      part_fused_last(false), d_row_stats(NULL), stats_floats(0), stats_valid(false),
       last_graph(NULL), last_in(NULL), last_len(0), alpha_opt(NULL) {}
 
 void GAT_Aggregator::init(int l, int nv, int ne, float lr, float drop_rate) {
@@ -212,16 +213,40 @@ void GAT_Aggregator::ensure_partition_buffers(Graph& g, int len) {
 void GAT_Aggregator::aggregate_partition(int len, Graph& g, const float* in, float* out) {
   const size_t n_own = g.size(), n_halo = g.gat_n_halo();
   ensure_partition_buffers(g, len);
+  dropped_last = false;
+  part_fused_last = false;
+  // One sweep (gaib_gat_forward_fused_rect) where the shape allows: the chunks over owned columns run while the halo rows
+  // of h are on the wire (phase 0), the rest and the per-row combination after they have arrived (phase 1); only the row
+  // statistics are kept.  Otherwise (other widths, attention dropout, gat_fused_fwd = 0) the staged pieces.
+  bool fused = false;
   {
     OpTimer t(OP_SCORE);
     g.halo_begin(len, in);
     GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_ptab, in, sizeof(float) * n_own * len));
+    if (!dropping()) {
+      const size_t need = n_own * heads * 2;
+      if (need > stats_floats) {
+        if (d_row_stats) float_free_device(d_row_stats);
+        float_malloc_device64(need, d_row_stats);
+        stats_floats = need;
+      }
+      const int rc = gaib_gat_forward_fused_rect(C(), g.gat_full_graph(), len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon,
+                                                 fuse_relu ? 1 : 0, out, d_row_stats, 0);
+      if (rc == GAIB_OK) fused = true;
+      else if (rc != GAIB_ERR_UNSUPPORTED) GAIB_OR_DIE(rc);
+    }
     const float* halo = g.halo_end(len);
     if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_ptab + n_own * len, halo, sizeof(float) * n_halo * len));
+    if (fused) {
+      GAIB_OR_DIE(gaib_gat_forward_fused_rect(C(), g.gat_full_graph(), len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon,
+                                              fuse_relu ? 1 : 0, out, d_row_stats, 1));
+      fuse_relu = false;
+      part_fused_last = true;
+      return;
+    }
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), g.gat_full_graph(), len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon,
                                    d_temp_scores, NULL, d_norm_scores));
   }
-  dropped_last = false;
   const float* attn = dropping() ? apply_attn_dropout((size_t)g.sizeEdges() * heads) : d_norm_scores;
   OpTimer t(OP_SPARSEMM);
   GAIB_OR_DIE(gaib_spmm_mh(C(), g.gat_full_graph(), GAIB_W_EDGE, attn, heads, len, d_ptab, out,
@@ -233,8 +258,45 @@ void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_
   const size_t n_own = g.size(), n_halo = g.gat_n_halo(), nc = n_own + n_halo;
   const int64_t ne = (int64_t)g.sizeEdges();
   gaib_graph *full = g.gat_full_graph(), *gt = g.gat_transposed_graph();
+  const float* fwd = fwd_out;
   fwd_out = NULL;
   ensure_partition_buffers(g, len);
+  if (part_fused_last && fwd) {
+    // the one-sweep backward on the rectangular graph: the owner of row i computes everything about i from i's own edge
+    // list, given the halo vertices' h rows (d_ptab, from forward), grad rows and (rowdot, max, 1 / sum) records -- two
+    // forward-direction exchanges, no transposed structure, no reverse exchange.  The chunks over owned columns run while
+    // the grad rows are on the wire.
+    OpTimer t(OP_ATTN);
+    if (nc * len > pgrad_floats) {
+      if (d_pgrad) float_free_device(d_pgrad);
+      float_malloc_device64(nc * len, d_pgrad);
+      pgrad_floats = nc * len;
+    }
+    if (nc * heads * 4 > prec_floats) {
+      if (d_prec) float_free_device(d_prec);
+      float_malloc_device64(nc * heads * 4, d_prec);
+      prec_floats = nc * heads * 4;
+    }
+    GAIB_OR_DIE(gaib_gat_backward_rec(C(), (int64_t)n_own, len, heads, grad_in, fwd, d_row_stats, d_prec));
+    GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_pgrad, grad_in, sizeof(float) * n_own * len));
+    g.halo_begin(len, grad_in);
+    const int rc = gaib_gat_backward_fused_rect(C(), full, len, heads, d_ptab, d_pgrad, d_prec, d_alpha_l, d_alpha_r, epsilon,
+                                                grad_out, d_alpha_lgrad, d_alpha_rgrad, 0);
+    const float* halo = g.halo_end(len);  // (every rank ends every exchange it began, whatever rc says)
+    GAIB_OR_DIE(rc);                      // forward took this path with the same shape: UNSUPPORTED cannot happen here
+    if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_pgrad + n_own * len, halo, sizeof(float) * n_halo * len));
+    g.halo_begin(4 * heads, d_prec);
+    halo = g.halo_end(4 * heads);
+    if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_prec + n_own * heads * 4, halo, sizeof(float) * n_halo * heads * 4));
+    GAIB_OR_DIE(gaib_gat_backward_fused_rect(C(), full, len, heads, d_ptab, d_pgrad, d_prec, d_alpha_l, d_alpha_r, epsilon,
+                                             grad_out, d_alpha_lgrad, d_alpha_rgrad, 1));
+    return;
+  }
+  if (part_fused_last) {  // forward kept statistics only and backward has no forward output to use: the attention, staged
+    GAIB_OR_DIE(gaib_gat_scores_mh(C(), full, len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon, d_temp_scores, NULL,
+                                   d_norm_scores));
+    part_fused_last = false;
+  }
   {
     OpTimer t(OP_SCORE);
     GAIB_OR_DIE(gaib_sddmm_mh(C(), full, len, heads, grad_in, d_ptab, d_norm_scores_grad));

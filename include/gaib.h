@@ -268,6 +268,24 @@ int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, co
  * array exists at all.  Same cover as gaib_gat_backward_fused (option "gat_fused_fwd"); GAIB_ERR_UNSUPPORTED otherwise. */
 int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h, const float* d_alpha_l,
                            const float* d_alpha_r, float epsilon, int relu, float* d_out, float* d_row_stats);
+/* The one-sweep forward / backward on a rank's RECTANGULAR graph (rows = owned vertices, columns = [owned | halo]; tables
+ * [nc x len] with the owned rows first).  In a structurally symmetric graph the in-edges of an owned vertex are the
+ * reverses of its out-edges, so rs_i, cs_i and the aggregated gradient of i follow from i's own edge list given the halo
+ * vertices' h rows, grad rows and records rec[v][h] = (<grad_v, out_v>_h, row maximum, 1 / row sum, 0): two
+ * forward-direction halo exchanges (grad rows, records = 4 * heads floats per vertex) and one sweep -- no transposed
+ * structure, no reverse exchange.  phase: -1 = everything; 0 = only the chunks over owned columns (may run while the halo
+ * rows are still arriving: it reads owned rows only); 1 = the remaining chunks + the per-row combination (phase 0's
+ * partial results wait in the context's workspace: no other call on the context in between).  The alpha gradients cover
+ * the owned rows; the caller sums them over the ranks.  Same shape cover as gaib_gat_backward_fused (len == 64; 1, 2, 4,
+ * 8 or 16 heads; options gat_fused_fwd / gat_fused_bwd = 0 switch them off), else GAIB_ERR_UNSUPPORTED. */
+int gaib_gat_forward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_tab, const float* d_alpha_l,
+                                const float* d_alpha_r, float epsilon, int relu, float* d_out, float* d_row_stats, int phase);
+int gaib_gat_backward_rec(gaib_ctx* ctx, int64_t nv, int len, int heads, const float* d_grad, const float* d_fwd_out,
+                          const float* d_row_stats, float* d_rec);
+int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat_tab,
+                                 const float* d_grad_tab, const float* d_rec_tab, const float* d_alpha_l,
+                                 const float* d_alpha_r, float epsilon, float* d_grad_out, float* d_alpha_lgrad,
+                                 float* d_alpha_rgrad, int phase);
 /* GAT backward on a RECTANGULAR graph (a rank's rows over [owned | halo] columns), where the reverse
  * edge of (i -> c) lives on another rank and the reverse-edge permutation is replaced by the rank's transposed local
  * structure (rows = owned + halo vertices, columns = owned rows; include/gnn/partition.h).  gaib_gat_scores_mh and

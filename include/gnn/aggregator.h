@@ -119,6 +119,10 @@ class GAT_Aggregator : public aggregator {
   // the column sums of g
   float *d_ptab, *d_pout, *d_prs, *d_pcs;
   size_t ptab_floats, pvec_floats;
+  // ... and of the one-sweep path on a partition: the [owned | halo] tables of gradient rows and (rowdot, max, 1/sum) records
+  float *d_pgrad, *d_prec;
+  size_t pgrad_floats, prec_floats;
+  bool part_fused_last;  // the last partition forward was the one-sweep kernel (row statistics only)
   void ensure_partition_buffers(Graph& g, int len);
   void aggregate_partition(int len, Graph& g, const float* in, float* out);
   void d_aggregate_partition(int len, Graph& g, const float* grad_in, float* grad_out);

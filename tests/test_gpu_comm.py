@@ -114,7 +114,7 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def _gat_worker(rank, world, idfile, q, heads):
+def _gat_worker(rank, world, idfile, q, heads, mode="fused"):
     """GAT_layer 64 -> 64 on a vertex-range partition (h halo rows for the scores, partial gradient rows returned to
     their owners, alpha gradients all-reduced) against the GLOBAL oracle: head by head for heads > 1"""
     sys.path.insert(0, str(ROOT))
@@ -126,6 +126,9 @@ def _gat_worker(rank, world, idfile, q, heads):
         from util import LONG_SUM_FLOOR, assert_close, random_graph
 
         ctx = L.init(0)
+        if mode == "staged":  # the round-2 pieces (SDDMM, row-side softmax backward, transposed SpMM, reverse exchange)
+            ctx.set_option("gat_fused_fwd", 0)
+            ctx.set_option("gat_fused_bwd", 0)
         comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, capi.COMM_IPC, capi), capi.COMM_IPC)
         L.set_comm(comm)
         rp, ci = random_graph(2500, 14, seed=21, power_law=True, hub_deg=1300)
@@ -156,7 +159,12 @@ def _gat_worker(rank, world, idfile, q, heads):
         out.copy_(torch.from_numpy(want[lo:hi]).cuda())  # identical relu masks
         layer.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
         grad_out = torch.empty(hi - lo, din, device="cuda")
+        ctx.prof_reset()
+        ctx.prof_enable(True)
         layer.backward(out, grad_out)
+        ctx.prof_enable(False)
+        n_fused, _ = ctx.prof_get("gat_bwd_fused")
+        assert (n_fused > 0) == (mode == "fused"), (mode, n_fused)  # the path that was asked for is the one that ran
         assert_close(grad_out.cpu().numpy(), want_go[lo:hi], "grad_out", floor=LONG_SUM_FLOOR)
         # weight and alpha gradients are partial sums until the optimizer step all-reduces them
         for which, shape, want_g, name in ((L.W_NEIGH_GRAD, (din, d), want_wg, "W_grad"), (L.ALPHA_LGRAD, (d,), lg_w, "alpha_l"),
@@ -258,9 +266,14 @@ def test_ipc_ranks_on_one_gpu_match_global_oracle(tmp_path, arch, world):
     assert all(r[1] == "ok" for r in res), res
 
 
-@pytest.mark.parametrize("heads,world", [(1, 2), (8, 2), (8, 3)])
-def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world):
-    res = _spawn(world, _gat_worker, (str(tmp_path / "id"), heads))
+@pytest.mark.parametrize("heads,world,mode", [(1, 2, "fused"), (8, 2, "fused"), (8, 3, "fused"), (4, 3, "fused"),
+                                              (1, 2, "staged"), (8, 3, "staged")])
+def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world, mode):
+    """GAT_layer 48 -> 64 on a vertex-range partition against the GLOBAL oracle.  fused: the one-sweep kernels on the
+    rank's rectangular [owned | halo] graph (forward: h halo rows, the chunks over owned columns swept while they travel;
+    backward: grad rows + (rowdot, max, 1 / sum) records of the halo vertices, everything about an owned row from its
+    own edge list -- no transposed structure, no reverse exchange).  staged: the round-2 pieces (options off)."""
+    res = _spawn(world, _gat_worker, (str(tmp_path / "id"), heads, mode))
     assert all(r[1] == "ok" for r in res), res
 
 
