@@ -911,19 +911,35 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         torch.cuda.synchronize()
         par["grad_out"] = _errs(torch, grad_out, torch.from_numpy(want_go).cuda(), tol, floor)
         par["W_grad"] = _errs(torch, layer.tensor(L.W_NEIGH_GRAD, (Dg, Dg)), torch.from_numpy(want_wg).cuda(), tol, floor)
-        # alpha gradients: 64 sums over 9e8 (edge, head) terms with leaky_relu' jumping at 0 -- the oracle's own distance
-        # from the fp64 evaluation of the same formulas is measured here and sets the tolerance (oracle/fp64.py)
+        # alpha gradients: 64 sums over 9e8 (edge, head) terms with leaky_relu' jumping at 0 -- a score within rounding of
+        # zero takes either slope in two correct fp32 evaluations, and ~15 such flips are worth ~1e-4 of the largest
+        # entry.  So arithmetic is compared the way backward is compared on the oracle's relu mask: the signs each
+        # implementation takes (the GPU's: gaib_gat_score_signs, the kernels' exact arithmetic) are imposed on an fp64
+        # evaluation of the same formulas on the device (oracle/fp64.py), and each is held to 1e-4 of ITS fp64 counterpart
         from oracle import fp64 as truth
-        lg64, rg64, info = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, hfeat, al, ar, g_act, H, temp_fp32=temps)
-        ok_a = True
-        for which, want_a, t64, name in ((L.ALPHA_LGRAD, lg_w, lg64, "alpha_l_grad"), (L.ALPHA_RGRAD, rg_w, rg64, "alpha_r_grad")):
+        # (the GPU's own h = X.W, by the product kernel the layer runs: it differs from the oracle's h in the last place,
+        # which is enough to move a score across zero)
+        h_gpu = torch.empty(nv, Dg, device="cuda")
+        ctx.sgemm(torch.from_numpy(x_h).cuda(), torch.from_numpy(W).cuda(), h_gpu)
+        ctx.sync()
+        signs_gpu = ctx.gat_score_signs(lg.device_graph(), h_gpu, torch.from_numpy(al).cuda(), torch.from_numpy(ar).cuda(), heads=H)
+        signs_orc = torch.from_numpy(np.stack(temps, 1) > 0).cuda().to(torch.uint8)
+        par["leaky_relu_signs_gpu_vs_oracle_differ"] = int((signs_gpu != signs_orc).sum().item())
+        lg_g64, rg_g64, info = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, h_gpu, al, ar, g_act, H, signs=signs_gpu)
+        del h_gpu
+        lg_o64, rg_o64, info_o = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, hfeat, al, ar, g_act, H, signs=signs_orc)
+        ok_a = info["imposed_flips_max_abs_t_over_scale"] < 1e-5 and info_o["imposed_flips_max_abs_t_over_scale"] < 1e-5
+        for which, want_a, g64, o64, name in ((L.ALPHA_LGRAD, lg_w, lg_g64, lg_o64, "alpha_l_grad"),
+                                              (L.ALPHA_RGRAD, rg_w, rg_g64, rg_o64, "alpha_r_grad")):
             got = layer.tensor(which, (Dg,)).double().cpu().numpy()
-            d_orc = truth.inf_dist(want_a, t64)
-            rec_a = {"inf_vs_oracle": truth.inf_dist(got, want_a), "inf_vs_fp64": truth.inf_dist(got, t64),
-                     "oracle_inf_vs_fp64": d_orc, "allowed_vs_oracle": tol + 2.0 * d_orc}
-            ok_a = ok_a and rec_a["inf_vs_oracle"] <= rec_a["allowed_vs_oracle"] and rec_a["inf_vs_fp64"] <= max(tol, 2.0 * d_orc)
+            rec_a = {"inf_vs_fp64_on_own_signs": truth.inf_dist(got, g64),
+                     "oracle_inf_vs_fp64_on_own_signs": truth.inf_dist(want_a, o64),
+                     "inf_vs_oracle_as_they_are": truth.inf_dist(got, want_a)}
+            ok_a = ok_a and rec_a["inf_vs_fp64_on_own_signs"] <= tol and rec_a["oracle_inf_vs_fp64_on_own_signs"] <= tol
             par[name] = rec_a
-        par["leaky_relu_sign_flips_oracle_vs_fp64"] = info["sign_flips"]
+        par["leaky_relu_sign_flips_vs_fp64"] = {"gpu": info["imposed_sign_flips_vs_fp64"], "oracle": info_o["imposed_sign_flips_vs_fp64"],
+                                                "max_abs_score_over_scale": max(info["imposed_flips_max_abs_t_over_scale"],
+                                                                                info_o["imposed_flips_max_abs_t_over_scale"])}
         par["ok"] = bool(all(par[k]["elem"] <= tol and par[k]["inf"] <= tol for k in ("forward", "grad_out", "W_grad")) and ok_a)
         result["parity"] = par
         log(f"[bench] parity vs the oracle's {H}-head run: {par}")

@@ -109,6 +109,7 @@ SIGNATURES = {
     "gaib_prof_enable": (_i, [_vp, _i]),
     "gaib_prof_reset": (_i, [_vp]),
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gaib_gat_score_signs": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "gaib_gat_forward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _i]),
     "gaib_gat_backward_rec": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "gaib_gat_backward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i]),
@@ -419,6 +420,15 @@ class Context:
     def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2, heads: int = 1):
         _check(self.lib.gaib_gat_scores_mh(self.h, g.h, h.shape[1], heads, _ptr(h), _ptr(alpha_l), _ptr(alpha_r),
                                            eps, _ptr(temp), _ptr(scores), _ptr(norm)), "gaib_gat_scores")
+
+    def gat_score_signs(self, g, h, alpha_l, alpha_r, heads: int = 1):
+        """[ne x heads] uint8: (pre-activation score > 0) exactly as the one-sweep kernels form it (test / diagnostic)"""
+        import torch
+
+        out = torch.empty(g.ne, heads, dtype=torch.uint8, device=h.device)
+        _check(self.lib.gaib_gat_score_signs(self.h, g.h, h.shape[1], heads, _ptr(h), _ptr(alpha_l), _ptr(alpha_r), _ptr(out)),
+               "gaib_gat_score_signs")
+        return out
 
     def sddmm(self, g, grad, feat, out_e, heads: int = 1):
         _check(self.lib.gaib_sddmm_mh(self.h, g.h, grad.shape[1], heads, _ptr(grad), _ptr(feat), _ptr(out_e)),

@@ -1051,6 +1051,48 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   }
 }
 
+// sign(t_e) of every (edge, head) pre-activation score EXACTLY as the one-sweep kernels above form it (the same FMA
+// chains, the same DPP sums, the same add): leaky_relu' jumps at t = 0, and a score within rounding of zero takes either
+// slope in two correct fp32 evaluations -- a test that wants to compare ARITHMETIC with an fp64 evaluation of the alpha
+// gradients imposes these signs on it (the way the relu mask of the oracle's forward output is imposed on the GPU's
+// backward).  Test / diagnostic entry point (gaib_gat_score_signs); not on the training path.
+template <int G, int H>
+__global__ __launch_bounds__(256) void gat_score_sign_kernel(int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase,
+                                                             const int64_t* rowptr, const uint32_t* col, int len, const float* feat,
+                                                             const float* alpha_l, const float* alpha_r, uint8_t* sign_out) {
+  constexpr int LH = G / H;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & (G - 1);
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rem = rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const int grp = lane >> 4;
+  const int my_e = sl * 4 + grp;
+  const uint32_t cl = col[eb + (my_e < n ? my_e : 0)];
+  const int coff = sl * 4;
+  const int head = sl / LH;
+  const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
+  const f4 al4 = *reinterpret_cast<const f4*>(alpha_l + coff);
+  const f4 ar4 = *reinterpret_cast<const f4*>(alpha_r + coff);
+  auto d4 = [](const f4& a, const f4& b) {
+    return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
+  };
+  const float sl_i = lanes_sum<LH>(d4(al4, hi));
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    if (j * 4 >= n) break;
+    const uint32_t cj = (uint32_t)row_lane((int)cl, j);
+    const f4 xh = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
+    const float sr_c = lanes_sum<LH>(d4(ar4, xh));
+    const float t_e = sl_i + sr_c;
+    const int ei = j * 4 + grp;
+    if (ei < n && (sl & (LH - 1)) == 0) sign_out[(eb + ei) * H + head] = t_e > 0.0f ? 1 : 0;
+  }
+}
+
 // per row: combine the chunks' (m, s, acc) in chunk order; out = act(sum / S); stats[row][h] = (M, 1/S)
 // (len == 64: a row is 16 lanes of 4 columns, so the wave's four 16-lane groups take the row's chunks k, k + 1, k + 2,
 // k + 3, ... and meet at the end -- a row with 330 chunks is 83 steps deep instead of 330, and no lane idles)
@@ -1564,6 +1606,31 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   GAIB_LAUNCH_CHECK();
   alpha_final_kernel<<<(unsigned)cdiv64(2 * (int64_t)len, 4), 256, 0, ctx->stream>>>(nblocks, len, partial, d_alpha_lgrad,
                                                                                     d_alpha_rgrad);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_gat_score_signs(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h, const float* d_alpha_l,
+                                    const float* d_alpha_r, uint8_t* d_sign_out) {
+  GAIB_CHECK(ctx && g && d_h && d_alpha_l && d_alpha_r && d_sign_out, "gaib_gat_score_signs: NULL argument");
+  GAIB_TRY(check_heads("gaib_gat_score_signs", len, heads));
+  GAIB_CHECK(len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16),
+             "gaib_gat_score_signs: the one-sweep kernels' shapes only (len 64; 1, 2, 4, 8 or 16 heads)");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (g->ne == 0) return GAIB_OK;
+  GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
+  const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+#define GAIB_SS(HH)                                                                                                     \
+  gat_score_sign_kernel<16, HH><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->rowptr,     \
+                                                               g->colidx, len, d_h, d_alpha_l, d_alpha_r, d_sign_out)
+  switch (heads) {
+    case 1: GAIB_SS(1); break;
+    case 2: GAIB_SS(2); break;
+    case 4: GAIB_SS(4); break;
+    case 8: GAIB_SS(8); break;
+    default: GAIB_SS(16); break;
+  }
+#undef GAIB_SS
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }

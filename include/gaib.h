@@ -268,6 +268,12 @@ int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, co
  * array exists at all.  Same cover as gaib_gat_backward_fused (option "gat_fused_fwd"); GAIB_ERR_UNSUPPORTED otherwise. */
 int gaib_gat_forward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h, const float* d_alpha_l,
                            const float* d_alpha_r, float epsilon, int relu, float* d_out, float* d_row_stats);
+/* Test / diagnostic: d_sign_out [ne][heads] (uint8) = (t_e > 0) of every pre-activation score a_l.h[i] + a_r.h[col_e]
+ * EXACTLY as the one-sweep kernels form it.  leaky_relu' jumps at 0, so a score within rounding of zero takes either
+ * slope in two correct fp32 evaluations; a comparison of the alpha gradients with an fp64 evaluation imposes these signs
+ * on it to measure arithmetic only (the counterpart of running backward on the oracle's relu mask).  d_h [nc x len]. */
+int gaib_gat_score_signs(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_h, const float* d_alpha_l,
+                         const float* d_alpha_r, uint8_t* d_sign_out);
 /* The one-sweep forward / backward on a rank's RECTANGULAR graph (rows = owned vertices, columns = [owned | halo]; tables
  * [nc x len] with the owned rows first).  In a structurally symmetric graph the in-edges of an owned vertex are the
  * reverses of its out-edges, so rs_i, cs_i and the aggregated gradient of i follow from i's own edge list given the halo

@@ -16,12 +16,16 @@ def _rows_of(rowptr: torch.Tensor) -> torch.Tensor:
     return torch.repeat_interleave(torch.arange(n, device=rowptr.device), rowptr[1:] - rowptr[:-1])
 
 
-def gat_alpha_grads_fp64(rowptr, colidx, hfeat, alpha_l, alpha_r, g_act, heads: int, temp_fp32=None):
+def gat_alpha_grads_fp64(rowptr, colidx, hfeat, alpha_l, alpha_r, g_act, heads: int, temp_fp32=None, signs=None):
     """alpha gradients of GAT_Aggregator::d_aggregate (gat_aggregator.cpp:99-165) in fp64, head by head.
     rowptr int64 [n+1], colidx [ne] (with self loops), hfeat / g_act fp32 [n x d] (g_act = the gradient after d_relu),
     alpha_* fp32 [d]: numpy or device tensors.  Returns (alpha_l grad [d] f64 numpy, alpha_r grad [d] f64 numpy, info);
     info counts the leaky-relu sign flips between temp_fp32 ([heads] list of [ne] fp32 score arrays, e.g. the oracle's)
-    and the fp64 scores, and bounds what those flips are worth per entry (sum of 0.8 |ds_e| |h| over the flipped edges)."""
+    and the fp64 scores, and bounds what those flips are worth per entry (sum of 0.8 |ds_e| |h| over the flipped edges).
+    signs: [ne x heads] uint8 device tensor / array (t_e > 0) to IMPOSE on leaky_relu' (the softmax itself keeps the fp64
+    scores: leaky_relu is continuous, only its derivative jumps) -- with an implementation's own signs the result is what
+    that implementation's arithmetic should reproduce; info then also counts how many signs differ from fp64's and the
+    largest |t| (relative to max |t|) among them."""
     dev = "cuda"
     t_ = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a).to(dev)
     rowptr = t_(rowptr).to(torch.int64)
@@ -34,6 +38,7 @@ def gat_alpha_grads_fp64(rowptr, colidx, hfeat, alpha_l, alpha_r, g_act, heads: 
     dh = d // heads
     lg, rg = np.empty(d), np.empty(d)
     flips, worth_l, worth_r = 0, np.zeros(d), np.zeros(d)
+    imposed_flips, imposed_worst = 0, 0.0
     step = 1 << 24
     for k in range(heads):
         sl = slice(k * dh, (k + 1) * dh)
@@ -53,7 +58,15 @@ def gat_alpha_grads_fp64(rowptr, colidx, hfeat, alpha_l, alpha_r, g_act, heads: 
         rowdot = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, p * dp)
         ds = p * (dp - rowdot[rows])
         del dp
-        ge = ds * torch.where(t > 0, 1.0, 0.2)
+        pos = t > 0
+        if signs is not None:
+            sg = t_(signs)[:, k].to(torch.bool)
+            diff = sg != pos
+            imposed_flips += int(diff.sum().item())
+            if diff.any():
+                imposed_worst = max(imposed_worst, float((t[diff].abs().max() / t.abs().max()).item()))
+            pos = sg
+        ge = ds * torch.where(pos, 1.0, 0.2)
         cs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, col, ge)
         rs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, ge)
         lg[sl], rg[sl] = (rs @ hk).cpu().numpy(), (cs @ hk).cpu().numpy()
@@ -67,7 +80,8 @@ def gat_alpha_grads_fp64(rowptr, colidx, hfeat, alpha_l, alpha_r, g_act, heads: 
             del fl
         del t, p, ds, ge, cs, rs
         torch.cuda.empty_cache()
-    return lg, rg, {"sign_flips": flips, "flips_worth_l": worth_l, "flips_worth_r": worth_r}
+    return lg, rg, {"sign_flips": flips, "flips_worth_l": worth_l, "flips_worth_r": worth_r,
+                    "imposed_sign_flips_vs_fp64": imposed_flips, "imposed_flips_max_abs_t_over_scale": imposed_worst}
 
 
 def inf_dist(a, b) -> float:

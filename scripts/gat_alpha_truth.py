@@ -48,7 +48,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=1.0)
     args = ap.parse_args()
-    L.init(0)
+    lctx = L.init(0)
+    for kv in filter(None, os.environ.get("GAIB_OPTS", "").split(",")):  # e.g. gat_fused_bwd=0: the staged backward
+        k, v = kv.split("=")
+        lctx.set_option(k.strip(), int(v))
     sg = synth.make("reddit", seed=7, device="cuda", scale=args.scale)
     rp = sg.rowptr.cpu().numpy()
     ci = sg.colidx.cpu().numpy().view(np.uint32)
@@ -115,6 +118,19 @@ def main():
         torch.cuda.empty_cache()
     def dist(a, b):
         return float(np.abs(a - b).max() / np.abs(b).max())
+    # the same with each implementation's OWN leaky-relu signs imposed on the fp64 evaluation (arithmetic only)
+    from oracle import fp64 as truth
+    al_d, ar_d = torch.from_numpy(al).cuda(), torch.from_numpy(ar).cuda()
+    h_gpu = torch.empty(n, d, device="cuda")  # the GPU's own X.W (the layer's product kernel: identical bits)
+    lctx.sgemm(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), h_gpu)
+    lctx.sync()
+    signs_gpu = lctx.gat_score_signs(g_d.device_graph(), h_gpu, al_d, ar_d, heads=H)
+    signs_orc = torch.from_numpy(np.stack(temps, 1) > 0).cuda().to(torch.uint8)
+    lg_g64, rg_g64, _ = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, h_gpu, al, ar, g_act, H, signs=signs_gpu)
+    lg_o64, rg_o64, _ = truth.gat_alpha_grads_fp64(g_o.rowptr, g_o.colidx, hfeat, al, ar, g_act, H, signs=signs_orc)
+    own = {"alpha_l": {"gpu_vs_fp64_on_gpu_signs": dist(lg_g, lg_g64), "oracle_vs_fp64_on_oracle_signs": dist(lg_o.astype(np.float64), lg_o64),
+                       "gpu_err_per_entry_over_max": ((lg_g - lg_g64) / np.abs(lg_g64).max()).round(7).tolist()},
+           "alpha_r": {"gpu_vs_fp64_on_gpu_signs": dist(rg_g, rg_g64), "oracle_vs_fp64_on_oracle_signs": dist(rg_o.astype(np.float64), rg_o64)}}
     rec = {
         "scale": args.scale, "nv": n, "ne": ne, "heads": H,
         "alpha_l": {"gpu_layer_vs_fp64": dist(lg_g, lg_t), "oracle_vs_fp64": dist(lg_o.astype(np.float64), lg_t),
@@ -123,6 +139,7 @@ def main():
         "alpha_r": {"gpu_layer_vs_fp64": dist(rg_g, rg_t), "oracle_vs_fp64": dist(rg_o.astype(np.float64), rg_t),
                     "gpu_layer_vs_oracle": dist(rg_g, rg_o.astype(np.float64)), "max_abs": float(np.abs(rg_t).max()),
                     "min_abs": float(np.abs(rg_t).min())},
+        "own_signs": own, "opts": os.environ.get("GAIB_OPTS", ""),
         "leaky_relu_sign_flips_oracle_fp32_vs_fp64": flips_total, "scores_within_1e-6_of_zero": near,
         "flips_worth_over_max": {"alpha_l": float(flip_worth_l.max() / np.abs(lg_t).max()), "alpha_r": float(flip_worth_r.max() / np.abs(rg_t).max())},
     }
