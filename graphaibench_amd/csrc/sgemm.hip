@@ -893,7 +893,9 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
       if (nn < g.N) {
         float* pc = g.C + (m0 + 4 * lh) * g.N + nn;
         if (full_rows) {
-          // whole tile: the 16 old values (C += form) are requested together, not one dependent load per element
+          // whole tile: the 16 old values (C += form) are requested together, not one dependent load per element.
+          // (Round 3 tried to request them one tile AHEAD and seed the accumulators with them: 4.24 vs 2.85 ms -- vmcnt
+          // returns in order, so every wait for an A operand behind the 64 prefetch loads waits for them too.)
           float cv[16];
           if (g.accum) {
 #pragma unroll

@@ -628,7 +628,51 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         }
       }
     };
-    if constexpr (!DUAL) {
+    if constexpr (!DUAL && YACC) {
+      // y += : the tile's OLD values are requested all at once, before the matrix-core phase, instead of one dependent
+      // load per element right before its store (the second K-slab ran 8.15 ms against 7.6 for the first: 0.5 ms of
+      // exposed latency per launch).  n_out <= 256: at most 16 output tiles x 4 values per lane; the gather registers are
+      // dead by now.
+      // Two batches of 8 tiles (32 registers each): all 16 at once spilled three registers at the kernel's 128-VGPR cap.
+      constexpr int NTY = 8;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        if (nb * NTY * 16 >= n_pad) break;
+        f32x4_t yo[NTY];
+#pragma unroll
+        for (int q = 0; q < NTY; ++q) {
+          const int nt = nb * NTY + q;
+          yo[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (nt * 16 < n_pad && nt * 16 + i < f.n_out) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int row = row0 + 4 * kq + reg;
+              yo[q][reg] = f.y[(int64_t)(row < a.n_rows ? row : 0) * f.ldy + nt * 16 + i];
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NTY; ++q) {
+          const int nt = nb * NTY + q;
+          if (nt * 16 < n_pad) {
+            const f32x4_t c = mfma_tile(wbase + nt * 16 * LDT, yo[q]);  // the old values seed the accumulators
+            const int n0 = nt * 16;
+            if (n0 + i < f.n_out) {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int row = row0 + 4 * kq + reg;
+                if (row < a.n_rows) {
+                  float v = c[reg];
+                  if (f.relu) v = v > 0.f ? v : 0.f;
+                  f.y[(int64_t)row * f.ldy + n0 + i] = v;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else if constexpr (!DUAL) {
       for (int n0 = 0; n0 < n_pad; n0 += 16) {
         const f32x4_t c = mfma_tile(wbase + n0 * LDT, f32x4_t{0.f, 0.f, 0.f, 0.f});
         store_tile(n0, c);
