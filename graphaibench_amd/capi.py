@@ -113,6 +113,7 @@ SIGNATURES = {
     "gaib_gat_forward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _i]),
     "gaib_gat_backward_rec": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "gaib_gat_backward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i]),
+    "gaib_gather_scatter_rows": (_i, [_vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "gaib_graph_reorder": (_i, [_vp, _vp, _i, _pp, _vp, _vp]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
@@ -568,6 +569,10 @@ class Context:
     def masked_accuracy_single_dev(self, preds, labels, begin, end, d_result, masks=None):
         _check(self.lib.gaib_masked_accuracy_single_dev(self.h, begin, end, preds.shape[1], _ptr(masks), _ptr(preds),
                                                         _ptr(labels), _ptr(d_result)), "gaib_masked_accuracy_single_dev")
+
+    def gather_scatter_rows(self, src_idx, dst_idx, x, out):
+        _check(self.lib.gaib_gather_scatter_rows(self.h, src_idx.numel(), _ptr(src_idx), _ptr(dst_idx), x.shape[1], _ptr(x),
+                                                 _ptr(out)), "gaib_gather_scatter_rows")
 
     def gather_rows(self, idx, x, out):
         _check(self.lib.gaib_gather_rows(self.h, idx.numel(), _ptr(idx), x.shape[1], _ptr(x), _ptr(out)),

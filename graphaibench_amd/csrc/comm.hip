@@ -28,6 +28,7 @@
 #include <unistd.h>
 #include <atomic>
 #include <new>
+#include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 #include "common.h"
 
@@ -153,6 +154,10 @@ struct gaib_halo {
   int64_t send_counts[GAIB_COMM_MAX_RANKS], recv_counts[GAIB_COMM_MAX_RANKS];
   int64_t send_off[GAIB_COMM_MAX_RANKS + 1], recv_off[GAIB_COMM_MAX_RANKS + 1];
   int64_t* d_send_idx;
+  // the pack in SOURCE order: the (row, slot) pairs of the send list sorted by row.  A row that several peers list
+  // (2.9 x on average at 8 ranks, 6.6 x on a random vertex order) is then read from HBM once, its repeats hit the cache:
+  // 1.26 -> 0.83 ms and 3.11 -> 1.79 ms for the two ends of the bench's partition axis (scripts/ab_pack.py)
+  int64_t *d_pack_row, *d_pack_slot;
   float* sendbuf;
   size_t send_cap;
   float* table;
@@ -162,6 +167,14 @@ struct gaib_halo {
   // is not the question -- "is the published allocation still the current one" is.
   uint64_t send_serial, table_serial;          // bumped by every (re)allocation
   uint64_t pub_send_serial, pub_table_serial;  // allocation the handle in the segment belongs to (0 = none)
+  // IPC: a buffer that has to grow is RETIRED, not freed, until the plan is destroyed.  Peers hold a mapping of it
+  // (hipIpcOpenMemHandle) and close that mapping only when they meet the new handle at the next hand-over; freeing the
+  // memory first made their hipIpcCloseMemHandle act on memory that no longer existed, and -- depending on where the next
+  // allocations landed -- later pulls through the re-opened mapping read wrong rows at non-zero offsets (found by
+  // test_ipc_halo_buffers_regrow_between_exchange_and_reduce[3] when plan creation began to allocate scratch of its own).
+  // gaib_halo_destroy closes every mapping on every rank, passes a barrier, and only then frees.
+  void* retired[48];
+  int n_retired;
   int pending_len;
   struct Peer {
     uint64_t gen;
@@ -204,20 +217,32 @@ int shm_barrier(gaib_comm* c, const char* what) {
   return GAIB_OK;
 }
 
+__global__ void iota_i64_kernel(int64_t n, int64_t* x) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) x[t] = t;
+}
+
 int fail(gaib_comm* c, int rc) {  // tell the peers, keep the message
   if (c && c->seg) c->seg->error.store(1);
   return rc;
 }
 
-int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t s) {
+int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t s, gaib_halo* keep = nullptr) {
   if (bytes <= *cap && *p) return 0;
   if (*p) {
     GAIB_HIP(hipStreamSynchronize(s));
-    GAIB_HIP(hipFree(*p));
+    if (keep && keep->n_retired < (int)(sizeof(keep->retired) / sizeof(keep->retired[0])))
+      keep->retired[keep->n_retired++] = *p;  // IPC: peers may still have it mapped (see gaib_halo::retired)
+    else
+      GAIB_HIP(hipFree(*p));
     *p = nullptr;
     *cap = 0;
   }
-  size_t want = bytes < 256 ? 256 : bytes;
+  // whole 2-MiB pieces: these buffers are exported through hipIpcGetMemHandle, and a small allocation can share its
+  // backing object with other small allocations of the process -- exporting a second one out of the same object failed
+  // with "invalid argument" (and, before buffers were retired, handed peers a mapping that read wrong rows)
+  const size_t gran = (size_t)2 << 20;
+  size_t want = ((bytes < 1 ? 1 : bytes) + gran - 1) / gran * gran;
   hipError_t e = hipMalloc((void**)p, want);
   if (e != hipSuccess) {
     gaib_set_error("gaib_halo: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
@@ -517,6 +542,35 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
       delete h;
       return GAIB_ERR_HIP;
     }
+    // (row, slot) pairs sorted by row (stable radix sort of the row ids with the slot numbers as values); if anything
+    // here fails the plan packs in destination order, as before
+    int64_t *iota = nullptr, *srow = nullptr, *sslot = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    e = hipMalloc((void**)&iota, sizeof(int64_t) * n_send);
+    if (e == hipSuccess) e = hipMalloc((void**)&srow, sizeof(int64_t) * n_send);
+    if (e == hipSuccess) e = hipMalloc((void**)&sslot, sizeof(int64_t) * n_send);
+    if (e == hipSuccess) {
+      iota_i64_kernel<<<(unsigned)cdiv64(n_send, 256), 256, 0, c->ctx->stream>>>(n_send, iota);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && n_send < ((int64_t)1 << 31))
+      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_send_idx, srow, iota, sslot, (int)n_send, 0, 48, c->ctx->stream);
+    else if (e == hipSuccess) e = hipErrorInvalidValue;
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+    if (e == hipSuccess)
+      e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_send_idx, srow, iota, sslot, (int)n_send, 0, 48, c->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (iota) (void)hipFree(iota);
+    if (e == hipSuccess) {
+      h->d_pack_row = srow;
+      h->d_pack_slot = sslot;
+    } else {
+      (void)hipGetLastError();
+      if (srow) (void)hipFree(srow);
+      if (sslot) (void)hipFree(sslot);
+    }
   }
   c->halo_slots |= 1u << slot;
   *out = h;
@@ -538,8 +592,11 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
     if (c->seg && !c->seg->error.load()) (void)shm_barrier(c, "gaib_halo_destroy");
   }
   if (h->d_send_idx) (void)hipFree(h->d_send_idx);
+  if (h->d_pack_row) (void)hipFree(h->d_pack_row);
+  if (h->d_pack_slot) (void)hipFree(h->d_pack_slot);
   if (h->sendbuf) (void)hipFree(h->sendbuf);
   if (h->table) (void)hipFree(h->table);
+  for (int k = 0; k < h->n_retired; k++) (void)hipFree(h->retired[k]);
   c->halo_slots &= ~(1u << h->id);  // after the barrier above: the slot row can serve the next plan
   delete h;
   return GAIB_OK;
@@ -561,12 +618,14 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
   GAIB_CHECK(n_send == 0 || d_rows, "gaib_halo_exchange_begin: d_rows is NULL");
   const size_t row_bytes = sizeof(float) * (size_t)len;
-  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream);
+  gaib_halo* keep = c->transport == GAIB_COMM_IPC ? h : nullptr;
+  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream, keep);
   if (ra < 0) return fail(c, ra);
-  int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream);
+  int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
   if (rb < 0) return fail(c, rb);
   if (n_send) {
-    int rc = gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
+    int rc = h->d_pack_row ? gaib_gather_scatter_rows(ctx, n_send, h->d_pack_row, h->d_pack_slot, len, d_rows, h->sendbuf)
+                           : gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
     if (rc != GAIB_OK) return fail(c, rc);
   }
   h->bytes_sent += (int64_t)row_bytes * n_send;
@@ -688,7 +747,8 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
   GAIB_CHECK((n_recv == 0 || d_halo_rows) && (n_send == 0 || d_rows), "gaib_halo_reduce: NULL rows");
   const size_t row_bytes = sizeof(float) * (size_t)len;
-  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream);  // arrivals land here
+  gaib_halo* keep = c->transport == GAIB_COMM_IPC ? h : nullptr;
+  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream, keep);  // arrivals land here
   if (ra < 0) return fail(c, ra);
   if (c->transport == GAIB_COMM_RCCL) {
     GAIB_HIP(hipEventRecord(c->ev_ready, ctx->stream));
@@ -710,21 +770,27 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   } else {
     // IPC: stage the partial rows in this plan's own table allocation (a whole allocation can be exported), publish it,
     // and let the owners pull their segments
-    int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream);
+    int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
     if (rb < 0) return fail(c, rb);
     hipError_t e = hipSuccess;
+    const char* step = "staging copy";
     if (n_recv && d_halo_rows != h->table)
       e = hipMemcpyAsync(h->table, d_halo_rows, row_bytes * (size_t)n_recv, hipMemcpyDeviceToDevice, ctx->stream);
     ShmSlot* mine = &c->seg->slot[h->id][c->rank];
     if (e == hipSuccess && h->pub_table_serial != h->table_serial) {  // also after an exchange grew the table
+      step = "hipIpcGetMemHandle(halo table)";
       e = hipIpcGetMemHandle(&mine->handle_t, h->table);
       for (int r = 0; r <= c->nranks; r++) mine->recv_off[r] = h->recv_off[r];
       mine->gen_t++;
       h->pub_table_serial = h->table_serial;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) {
+      step = "stream sync after staging";
+      e = hipStreamSynchronize(ctx->stream);
+    }
     if (e != hipSuccess) {
-      gaib_set_error("gaib_halo_reduce: %s", hipGetErrorString(e));
+      gaib_set_error("gaib_halo_reduce(rank %d, len %d, %lld halo rows, table %p cap %zu): %s: %s", c->rank, len, (long long)n_recv,
+                     (void*)h->table, h->table_cap, step, hipGetErrorString(e));
       return fail(c, GAIB_ERR_HIP);
     }
     int rc = shm_barrier(c, "gaib_halo_reduce (all staged)");

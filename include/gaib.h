@@ -414,6 +414,10 @@ int gaib_adam_step_dev(gaib_ctx* ctx, int64_t n, const float* d_dW, float* d_W, 
  * pack rows for the halo exchange: d_out[k,:] = d_in[d_idx[k],:] */
 int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_idx, int len,
                      const float* d_in, float* d_out);
+/* out[dst_idx[k], :] = in[src_idx[k], :], dst rows distinct.  The halo plans pack with it in SOURCE order (src ascending):
+ * a row that goes to several peers is read from HBM once (its repeats hit the cache) instead of once per peer. */
+int gaib_gather_scatter_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_src_idx, const int64_t* d_dst_idx, int len,
+                             const float* d_in, float* d_out);
 
 /* ---- collectives of the vertex-range partitioned path ("halo_exchange(handle,D,buf)",
  * "allreduce(buf,n)"; 8e) -------------------------------------------------------------------------------------

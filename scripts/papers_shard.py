@@ -66,10 +66,14 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M"):
     sendbuf = torch.empty(max(send_idx.numel(), 1), D, device="cuda")
     pack_calls = [0]
 
+    # the halo plans pack in SOURCE order (gaib_gather_scatter_rows: a row that several peers list is read once)
+    pack_row, pack_slot = torch.sort(send_idx, stable=True)
+    pack_slot = pack_slot.contiguous()
+
     def begin(length, src_ptr):  # pack the rows the 7 peers need (the all-to-all would start here)
         if send_idx.numel():
-            capi._check(ctx.lib.gaib_gather_rows(ctx.h, send_idx.numel(), send_idx.data_ptr(), length, src_ptr,
-                                                 sendbuf.data_ptr()), "gaib_gather_rows")
+            capi._check(ctx.lib.gaib_gather_scatter_rows(ctx.h, send_idx.numel(), pack_row.data_ptr(), pack_slot.data_ptr(),
+                                                         length, src_ptr, sendbuf.data_ptr()), "gaib_gather_scatter_rows")
             pack_calls[0] += 1
 
     def end(length):  # (and finish here: the table is resident instead)

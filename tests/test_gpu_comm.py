@@ -257,6 +257,9 @@ def _spawn(world, target, args, timeout=600):
     res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for r in res:  # (pytest shortens the assertion's repr: the ranks' own messages in full)
+        if r[1] != "ok":
+            print(f"--- rank {r[0]}: {r[1]}", file=sys.stderr)
     return res
 
 
