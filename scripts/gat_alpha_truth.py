@@ -56,7 +56,9 @@ def main():
     rp = sg.rowptr.cpu().numpy()
     ci = sg.colidx.cpu().numpy().view(np.uint32)
     g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
-    orc.set_threads(len(os.sched_getaffinity(0)))
+    sys.path.insert(0, str(ROOT / "tests"))
+    from util import usable_cores
+    orc.set_threads(usable_cores())
     g_o = orc.Graph(rp, ci).add_selfloop()
     del sg
     n, ne, d, H = g_o.nv, g_o.ne, 64, 8

@@ -10,6 +10,13 @@ if str(ROOT) not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+sys.path.insert(0, str(ROOT / "tests"))
+from util import usable_cores as _usable_cores  # noqa: E402
+
+# the oracle's OpenMP loops (oracle/libgnn_oracle.so) and the host C++ mirror: before either library starts its runtime
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cores()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

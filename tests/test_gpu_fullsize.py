@@ -21,7 +21,7 @@ import torch
 
 from graphaibench_amd import capi, layers as L, synth
 from oracle import binding as orc
-from util import ELEM_FLOOR, LONG_SUM_FLOOR, assert_close_dev
+from util import ELEM_FLOOR, LONG_SUM_FLOOR, assert_close_dev, usable_cores
 
 pytestmark = pytest.mark.gpu
 D = 128
@@ -239,7 +239,7 @@ def test_sage_layer_products_vs_oracle(products, width):
     nv, Dw = products["nv"], width
     rp = products["rowptr"].cpu().numpy()
     ci = products["colidx"].cpu().numpy().view(np.uint32)
-    orc.set_threads(len(__import__("os").sched_getaffinity(0)))
+    orc.set_threads(usable_cores())
     g_o = orc.Graph(rp, ci)
     lg = L.LGraph.adopt(lctx.graph(products["rowptr"], products["colidx"]))  # its own copy: adopt takes ownership
     x, gin = _host_feat(nv, Dw, 43), _host_feat(nv, Dw, 44)
@@ -284,7 +284,7 @@ def test_gat_layer_8_heads_reddit_vs_oracle():
     rp = sg.rowptr.cpu().numpy()
     ci = sg.colidx.cpu().numpy().view(np.uint32)
     g_d = L.LGraph.from_host(rp, ci, add_selfloop=True)
-    orc.set_threads(len(__import__("os").sched_getaffinity(0)))
+    orc.set_threads(usable_cores())
     g_o = orc.Graph(rp, ci).add_selfloop()
     del sg
     n, ne, d, H = g_o.nv, g_o.ne, 64, 8

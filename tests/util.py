@@ -4,6 +4,21 @@ from __future__ import annotations
 import numpy as np
 
 
+def usable_cores() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup quota (a GPU box shows the host's 256
+    CPUs and grants 16: an OpenMP runtime that starts 256 threads there spends seconds per parallel region)"""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def csr_from_pairs(n: int, src, dst):
     """symmetric, sorted, duplicate-free, self-loop-free CSR (int64 rowptr, uint32 colidx)."""
     src = np.asarray(src, np.int64)
