@@ -722,6 +722,15 @@ def main():
     if sustained:
         result["sustained_ms_per_step"] = sustained["ms_per_step"]
         result["sustained"] = sustained
+    # The bench graph's vertex ids are randomly permuted ON PURPOSE (no locality: traffic / b_min = 19).  Beside it, the
+    # same kernel on a graph of the same shape whose numbering carries locality (planted communities of 16 384 consecutive
+    # ids, 10 % of a vertex's edges leave its community): what the XCD-affine tile supply and the L2s are worth when the
+    # numbering offers something.  Not part of `value`.
+    if args.scale == 1.0 and os.environ.get("GAIB_BENCH_LOCALITY", "1") != "0":
+        try:
+            result["roofline"]["planted_locality"] = locality_leg(torch, ctx, capi, synth)
+        except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline record
+            result["roofline"]["planted_locality"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     rc = 0
     if not args.no_cpu_baseline:
         t1 = time.time()
@@ -737,6 +746,36 @@ def main():
     emit(result)
     if rc:
         sys.exit(rc)
+
+
+def locality_leg(torch, ctx, capi, synth, reps: int = 6) -> dict:
+    """the fused aggregation + product kernel (the headline's dominant kernel) on the planted-locality graph"""
+    sg = synth.planted_locality("ogbn-products", 16384, 0.1, seed=42, device="cuda")
+    g = ctx.graph(sg.rowptr, sg.colidx)
+    nv, ne = g.nv, g.ne
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    x = torch.randn(nv, D, device="cuda", generator=gen)
+    W = torch.randn(D, D, device="cuda", generator=gen) * 0.1
+    agg, y = torch.empty_like(x), torch.empty_like(x)
+    ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y)
+    ctx.sync()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(reps):
+        ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y)
+    ctx.prof_enable(False)
+    n, ms = ctx.prof_get("spmm_gemm_fused")
+    st = ctx.graph_stats(g)
+    ctx.prof_reset()
+    avg_ms = ms / max(n, 1)
+    alg = (ne - st["heavy_edges"]) * (4 * D + 8) + 2 * nv * 4 * D + (nv + 1) * 8
+    b_min = 2 * nv * 4 * D + 4 * ne
+    traffic, src = traffic_from_profile("spmm_gemm_kernel_bytes_per_launch", "planted_locality")
+    g.close()
+    return {"graph": sg.name, "nv": nv, "ne_with_selfloops": ne, "kernel_ms": avg_ms, "achieved": alg / (avg_ms * 1e-3) / 1e9,
+            "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg, "b_min_bytes_per_launch": b_min,
+            "traffic": traffic, "traffic_source": src, "traffic_over_b_min": (traffic / b_min) if traffic else None}
 
 
 def bench_gat_reddit(args, torch, ctx, L, synth) -> int:

@@ -104,6 +104,55 @@ def make(name: str, seed: int = 42, device="cuda", scale: float = 1.0) -> SynthG
     return chung_lu(name, nv_s, nnz_s, max_s, seed, device)
 
 
+# ---- a graph whose NUMBERING carries locality ------------------------------------------
+def planted_locality(name: str = "ogbn-products", block: int = 16384, cut: float = 0.1, seed: int = 42, device="cuda",
+                     relabel=None, selfloops: bool = True) -> SynthGraph:
+    """The named shape with PLANTED communities: vertices in blocks of `block` consecutive ids, a share 1 - cut of every
+    vertex's edges stays inside its block (endpoints by the same power-law weights, hubs spread over the blocks) -- what a
+    dataset with community structure in its numbering looks like, where make() permutes the ids at random.  relabel: an
+    optional [nv] int64 permutation applied to both endpoints (the same graph under another numbering)."""
+    device = torch.device(device)
+    nv, nnz, max_deg, _, _ = SHAPES[name]
+    max_deg = min(max_deg, nv // 4)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    w = _weights(nv, nnz / nv, max_deg, device)
+    w = w[torch.randperm(nv, generator=gen, device=device)]
+    cdf = torch.cumsum(w, 0)
+    cdf = cdf / cdf[-1]
+    m = nnz // 2
+    keys = []
+    step = 1 << 24
+    for s0 in range(0, m, step):
+        k = min(step, m - s0)
+        u = torch.searchsorted(cdf, torch.rand(k, dtype=torch.float64, generator=gen, device=device)).clamp_(max=nv - 1)
+        b0 = (u // block) * block
+        b1 = torch.clamp(b0 + block, max=nv)
+        lo = torch.where(b0 > 0, cdf[(b0 - 1).clamp_(min=0)], torch.zeros_like(cdf[b0]))
+        hi = cdf[b1 - 1]
+        r = torch.rand(k, dtype=torch.float64, generator=gen, device=device)
+        local = torch.rand(k, dtype=torch.float64, generator=gen, device=device) >= cut
+        v = torch.searchsorted(cdf, torch.where(local, lo + r * (hi - lo), r)).clamp_(max=nv - 1)
+        keep = u != v
+        u, v = u[keep], v[keep]
+        keys.append(torch.minimum(u, v) * nv + torch.maximum(u, v))
+    key = torch.unique(torch.cat(keys))
+    del keys
+    a, b = key // nv, key % nv
+    if relabel is not None:
+        a, b = relabel[a], relabel[b]
+    parts = [a * nv + b, b * nv + a]
+    if selfloops:
+        i = torch.arange(nv, dtype=torch.int64, device=device)
+        parts.append(i * nv + i)
+    key2, _ = torch.sort(torch.cat(parts))
+    rows = key2 // nv
+    cols = (key2 - rows * nv).to(torch.int32)
+    rowptr = torch.zeros(nv + 1, dtype=torch.int64, device=device)
+    torch.cumsum(torch.bincount(rows, minlength=nv), 0, out=rowptr[1:])
+    return SynthGraph(name + f" (planted locality: blocks of {block}, cut {cut})", nv, rowptr, cols, seed)
+
+
 # ---- block generator for the multi-GPU bench -------------------------------------------------------
 @dataclass
 class BlockRows:

@@ -36,8 +36,8 @@ REPS = 5
 
 
 def planted_graph(nv, nnz, max_deg, block, cut, seed, device="cuda"):
-    """symmetric edge list (u, v) with u != v, duplicate-free, ids block-contiguous: endpoint u by power-law weight over
-    the whole graph, v inside u's block with probability 1 - cut (by the same weights restricted to the block)"""
+    """symmetric edge list (u, v), duplicate-free, of graphaibench_amd.synth.planted_locality's graph (same draws: bench.py's
+    `roofline.planted_locality` leg measures the graph this study's `natural` order is)"""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     w = synth._weights(nv, nnz / nv, max_deg, torch.device(device))

@@ -69,6 +69,17 @@ if gp.exists():
         rec[key] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w}
         rec[f"{key}_bytes_per_launch"] = f * 1024 * 2.0 + w * 1024
     out["gat_reddit"] = rec
+# the planted-locality graph of bench.py's `roofline.planted_locality` leg: FETCH_SIZE of the fused kernel from
+# `rocprofv3 --pmc FETCH_SIZE -- python3 scripts/locality_study.py --kernel fused` (+ --parse), natural order; the stored
+# rows (2 N x 4D per launch) are added as written bytes
+lp = src / "locality_fused_fetch.jsonl"
+if lp.exists():
+    nat = [json.loads(l) for l in lp.read_text().splitlines() if l.startswith("{") and '"FETCH_SIZE_KB"' in l and '"natural"' in l]
+    if nat:
+        fkb = nat[-1]["FETCH_SIZE_KB"]
+        out["planted_locality"] = {"workload": "scripts/locality_study.py --kernel fused, natural order (= synth.planted_locality)",
+                                   "commit": commit, "sources": out["sources"], "spmm_gemm_kernel": {"FETCH_SIZE_KB": fkb},
+                                   "spmm_gemm_kernel_bytes_per_launch": fkb * 1024 * 2.0 + 2 * NV * 4 * D}
 out["note"] = ("FETCH_SIZE counts L2 -> fabric requests; Infinity-Cache hits are included (MI355X_MICROARCH.md), so "
                "these are upper bounds on the HBM bytes.")
 Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -31,4 +31,10 @@ if [ "$WHAT" = gcn ] || [ "$WHAT" = all ]; then
   tail -3 "$OUT/calib_fetch.log" > "$OUT/calib_known_bytes.txt"
   rm -rf "$OUT/calib_fetch" "$OUT/calib_write"
 fi
+if [ "$WHAT" = gcn ] || [ "$WHAT" = all ]; then
+  # the planted-locality leg of the bench record: FETCH_SIZE of the fused kernel on the natural order
+  ( cd /tmp && timeout 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/loc_fetch" -- python3 "$ROOT/scripts/locality_study.py" --kernel fused --order degree > "$OUT/locality_fused_fetch.jsonl" 2> "$OUT/locality_fused_fetch.log" )
+  python3 scripts/locality_study.py --parse "$OUT/loc_fetch" >> "$OUT/locality_fused_fetch.jsonl"
+  rm -rf "$OUT/loc_fetch"
+fi
 ls -la "$OUT"
