@@ -485,6 +485,9 @@ def main():
                          "64 -> 64 forward + backward on the reddit-shaped graph (same JSON schema; one GPU).  gcn-papers: "
                          "BASELINE config 5's layer, GCN 128 -> 128 on the ogbn-papers100M-shaped graph, one vertex range of "
                          "1/8 of it per GPU (N = 8: the whole graph), halo rows + dW over the collectives")
+    ap.add_argument("--no-locality", action="store_true",
+                    help="skip the planted-locality leg of the N = 1 record (profiling runs: its launches of the dominant kernel "
+                         "on ANOTHER graph would be averaged into the per-kernel statistics)")
     ap.add_argument("--check-oracle", action="store_true",
                     help="N>1 (or gcn-papers): compare every rank's forward output, input gradient and the summed weight "
                          "gradient element-wise with the oracle's run on the GLOBAL graph (sizes the host finishes in "
@@ -726,7 +729,7 @@ def main():
     # same kernel on a graph of the same shape whose numbering carries locality (planted communities of 16 384 consecutive
     # ids, 10 % of a vertex's edges leave its community): what the XCD-affine tile supply and the L2s are worth when the
     # numbering offers something.  Not part of `value`.
-    if args.scale == 1.0 and os.environ.get("GAIB_BENCH_LOCALITY", "1") != "0":
+    if args.scale == 1.0 and not args.no_locality and os.environ.get("GAIB_BENCH_LOCALITY", "1") != "0":
         try:
             result["roofline"]["planted_locality"] = locality_leg(torch, ctx, capi, synth)
         except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline record

@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run_one() {  # name, bench args
   local name=$1; shift
-  local ARGS="$ROOT/bench.py $* --steps 5 --warmup 2 --no-cpu-baseline --sustain-s 0"
+  local ARGS="$ROOT/bench.py $* --steps 5 --warmup 2 --no-cpu-baseline --no-locality --sustain-s 0"
   timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${name}_stats" -- python3 $ARGS > "$OUT/${name}_stats.log" 2>&1
   timeout 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${name}_fetch" -- python3 $ARGS > "$OUT/${name}_fetch.log" 2>&1
   timeout 420 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${name}_write" -- python3 $ARGS > "$OUT/${name}_write.log" 2>&1
