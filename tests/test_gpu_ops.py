@@ -1241,6 +1241,23 @@ def test_graph_reorder_keeps_every_row_bit_identical(ctx, method):
     r.close()
 
 
+@pytest.mark.parametrize("n_rows,n_idx,length", [(5000, 12000, 128), (5000, 12000, 200), (300, 17, 64), (4000, 9000, 47), (1000, 1, 4),
+                                                 (70000, 150001, 32)])
+def test_gather_scatter_rows(ctx, n_rows, n_idx, length):
+    """gaib_gather_scatter_rows: out[dst[k]] = in[src[k]] with src ascending and repeated (the source-ordered halo pack):
+    bit-identical to gaib_gather_rows in destination order, every row width / alignment path, ragged last wave"""
+    rng = np.random.default_rng(n_idx + length)
+    send_idx = rng.integers(0, n_rows, n_idx).astype(np.int64)  # destination order: slot k takes row send_idx[k]
+    x = dev(feat(n_rows, length, 1))
+    want = torch.empty(n_idx, length, device="cuda")
+    ctx.gather_rows(dev(send_idx), x, want)
+    assert np.array_equal(want.cpu().numpy(), x.cpu().numpy()[send_idx])
+    order = np.argsort(send_idx, kind="stable")
+    got = torch.full((n_idx, length), float("nan"), device="cuda")
+    ctx.gather_scatter_rows(dev(send_idx[order]), dev(order.astype(np.int64)), x, got)
+    assert torch.equal(got, want)
+
+
 def test_probe_stream_copy(ctx):
     """the in-run streaming-rate probe bench.py reports as roofline.peak_measured: between the guide's measured
     stream copy (6.3 TB/s) -20 % and the 8 TB/s spec peak; the peer probe refuses a single device"""
