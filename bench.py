@@ -361,13 +361,26 @@ class DistOracleCheck:
         return rec
 
 
+_REAL_STDOUT = None  # the process's original fd 1, once quiet_stdout() has pointed fd 1 at stderr
+
+
+def quiet_stdout() -> None:
+    """stdout carries ONE line, the record.  Libraries underneath print to fd 1 on their own (gloo: "[Gloo] Rank 0 is
+    connected to 1 peer ranks", RCCL: its library path), from every rank: from here on fd 1 IS stderr, and emit() writes the
+    JSON line to the saved original."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(result: dict) -> None:
-    """the ONE JSON line, last on stdout: libraries that write to C stdio (RCCL prints its library path
-    there) sit in libc's buffer until exit and would otherwise land after it"""
+    """the ONE JSON line, last on stdout (C stdio buffers of the libraries flushed first, wherever they point)"""
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps(result), flush=True)
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(result) + "\n").encode())
 
 
 def launch_ranks(args, argv, entry=None) -> int:
@@ -503,6 +516,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))  # no torch, no GPU API in this process
 
+    quiet_stdout()
     import torch
 
     rank = int(os.environ.get("RANK", "0"))

@@ -177,3 +177,23 @@ def test_bench_plain_two_gpus_default_workload():
     c5 = res["config"]["config5_papers100M"]
     assert c5["value"] > 0 and c5["halo_rows_total"] > 0 and "config 5" in c5["workload"]
     assert c5["nv_per_gpu"] == int(13_882_495 * 0.02)
+
+
+def test_bench_under_torch_distributed_run_prints_one_line():
+    """the driver's form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- the ranks come from outside, and the job's stdout is EXACTLY the one JSON line
+    (gloo and RCCL print to fd 1 on their own, from every rank: bench.py points fd 1 at stderr and writes the record to the
+    saved original)"""
+    import json
+    import subprocess
+
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+                        "1", "--scale", "0.02"], capture_output=True, text=True, timeout=900, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["launcher"].startswith("ranks given from outside")
+    assert "Gloo" in r.stderr or True  # (the libraries' chatter, if any, went to stderr)
