@@ -626,7 +626,19 @@ void print_timers() {
 
 // GAIB_RANKS=N: this process only starts and supervises the ranks.  Nothing here may touch the GPU (a process that
 // has initialised it must not fork ranks): plain fork + exec of this very binary, before any gaib_* call.
+static pid_t g_rank_pids[64];
+static int g_rank_n = 0;
+extern "C" void launcher_on_signal(int sig) {  // the launcher is asked to stop: so are the ranks it started (and only those)
+  for (int r = 0; r < g_rank_n; r++)
+    if (g_rank_pids[r] > 0) kill(g_rank_pids[r], SIGTERM);
+  _exit(128 + sig);
+}
+
 int launch_ranks(int n, char** argv) {
+  if (n > 64) {
+    fprintf(stderr, "GAIB_RANKS: at most 64 ranks\n");
+    return 1;
+  }
   const char* dl = getenv("GAIB_RANKS_DEADLINE_S");
   const double deadline_s = dl ? atof(dl) : 0.0;  // 0: none (training runs have no natural bound); a dead rank still ends the job
   char idfile[96], nbuf[16];
@@ -653,7 +665,11 @@ int launch_ranks(int n, char** argv) {
       _exit(127);
     }
     pids[r] = p;
+    g_rank_pids[r] = p;
+    g_rank_n = r + 1;
   }
+  signal(SIGTERM, launcher_on_signal);
+  signal(SIGINT, launcher_on_signal);
   struct timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   int alive = n, rc = 0;
