@@ -115,6 +115,7 @@ SIGNATURES = {
     "gaib_gat_backward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i]),
     "gaib_gather_scatter_rows": (_i, [_vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "gaib_graph_reorder": (_i, [_vp, _vp, _i, _pp, _vp, _vp]),
+    "gaib_graph_locality": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "gaib_device_count": (_i, [C.POINTER(_i)]),
@@ -569,6 +570,11 @@ class Context:
     def masked_accuracy_single_dev(self, preds, labels, begin, end, d_result, masks=None):
         _check(self.lib.gaib_masked_accuracy_single_dev(self.h, begin, end, preds.shape[1], _ptr(masks), _ptr(preds),
                                                         _ptr(labels), _ptr(d_result)), "gaib_masked_accuracy_single_dev")
+
+    def graph_locality(self, g) -> float:
+        v = C.c_float()
+        _check(self.lib.gaib_graph_locality(self.h, g.h, C.byref(v)), "gaib_graph_locality")
+        return float(v.value)
 
     def gather_scatter_rows(self, src_idx, dst_idx, x, out):
         _check(self.lib.gaib_gather_scatter_rows(self.h, src_idx.numel(), _ptr(src_idx), _ptr(dst_idx), x.shape[1], _ptr(x),

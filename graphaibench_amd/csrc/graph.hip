@@ -845,6 +845,14 @@ extern "C" int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib
   return GAIB_OK;
 }
 
+extern "C" int gaib_graph_locality(gaib_ctx* ctx, gaib_graph* g, float* h_near_frac) {
+  GAIB_CHECK(ctx && g && h_near_frac, "gaib_graph_locality: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  GAIB_TRY(gaib_graph_ensure_locality(ctx, g));
+  *h_near_frac = g->near_frac;
+  return GAIB_OK;
+}
+
 extern "C" int gaib_graph_stats(gaib_ctx* ctx, gaib_graph* g, int64_t* h_n_heavy, int64_t* h_heavy_edges,
                                 int64_t* h_max_degree) {
   GAIB_CHECK(ctx && g, "gaib_graph_stats: NULL argument");

@@ -147,14 +147,17 @@ def test_fused_aggregation_product_full_size(ctx, products):
     finally:
         ctx.set_option("spmm_fuse", 1)
     assert ((y2 - y).norm() / y.norm()).item() < 1e-6
-    # which wave takes which tile (one global counter / per-XCD counters over interleaved chunks) changes nothing
-    ctx.set_option("spmm_tile_xcd", 1)
-    try:
-        y3, agg3 = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
-        ctx.spmm_gemm(g1, capi.W_GCN, x, agg3, W, y3, relu=True)
-    finally:
-        ctx.set_option("spmm_tile_xcd", 0)
-    assert torch.equal(y3, y) and torch.equal(agg3, agg_ref)
+    # which wave takes which tile (one global counter / per-XCD counters over interleaved chunks of 16, 64 or 1024 tiles,
+    # with stealing at the tail) changes nothing
+    assert ctx.graph_locality(g1) < 0.1  # the bench graph's ids are randomly permuted: the auto rule keeps the global counter
+    for chunk in (0, 1, 64, 1024):
+        ctx.set_option("spmm_tile_xcd", chunk)
+        try:
+            y3, agg3 = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+            ctx.spmm_gemm(g1, capi.W_GCN, x, agg3, W, y3, relu=True)
+        finally:
+            ctx.set_option("spmm_tile_xcd", -1)
+        assert torch.equal(y3, y) and torch.equal(agg3, agg_ref), chunk
     # weight gradient with the d_relu folded in
     gr = torch.randn(nv, D, device="cuda")
     gm = torch.where(y > 0, gr, torch.zeros_like(gr))
@@ -164,6 +167,40 @@ def test_fused_aggregation_product_full_size(ctx, products):
     assert torch.equal(g_inout, gm)
     want_dw = agg_ref.double().T @ gm.double()
     assert ((dW.double() - want_dw).norm() / want_dw.norm()).item() < 1e-5
+
+
+def test_tile_supply_follows_the_numbering(ctx):
+    """a graph of the products shape whose numbering carries locality (synth.planted_locality): the measured statistic says
+    so, the fused kernel's auto rule then deals tiles XCD-affine in long chunks -- and whichever way the tiles are dealt
+    (auto, global counter, chunks of 16 / 1024 tiles) aggregate and product are bit-identical; on the same graph under a random
+    relabelling the statistic is that of a random order"""
+    sg = synth.planted_locality("ogbn-products", 16384, 0.1, seed=42, device="cuda")
+    g = ctx.graph(sg.rowptr, sg.colidx)
+    nv = g.nv
+    assert ctx.graph_locality(g) > 0.8
+    torch.manual_seed(9)
+    x = torch.randn(nv, D, device="cuda")
+    W = torch.randn(D, D, device="cuda") * 0.1
+    ref_agg, ref_y = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+    ctx.spmm_gemm(g, capi.W_GCN, x, ref_agg, W, ref_y, relu=True)  # auto: XCD-affine here
+    for chunk in (0, 1, 1024):
+        ctx.set_option("spmm_tile_xcd", chunk)
+        try:
+            agg, y = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+            ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y, relu=True)
+        finally:
+            ctx.set_option("spmm_tile_xcd", -1)
+        assert torch.equal(agg, ref_agg) and torch.equal(y, ref_y), chunk
+    plain = torch.empty(nv, D, device="cuda")
+    ctx.spmm(g, capi.W_GCN, x, plain)
+    assert torch.equal(plain, ref_agg)
+    g.close()
+    del sg
+    perm = torch.randperm(nv, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    sg2 = synth.planted_locality("ogbn-products", 16384, 0.1, seed=42, device="cuda", relabel=perm)
+    g2 = ctx.graph(sg2.rowptr, sg2.colidx)
+    assert ctx.graph_locality(g2) < 0.1
+    g2.close()
 
 
 def test_gat_properties_reddit_size(ctx):
