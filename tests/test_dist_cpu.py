@@ -239,3 +239,98 @@ def test_cpp_partition_gat_structures(nv, world):
         for v in range(nc):  # rows of a column ascending (stable counting sort)
             seg = P.colidx_t[P.rowptr_t[v]:P.rowptr_t[v + 1]]
             assert np.all(np.diff(seg.astype(np.int64)) > 0)
+
+
+# ---- the graph generator of bench.py's N > 1 legs (synth.block_rows): every rank generates ITS rows, from seeds shared
+# by the two owners of a cross block -- the global graph must come out symmetric whoever assembles it ---------------------
+@pytest.mark.parametrize("shape,world,cut", [("ogbn-papers100M/8", 8, 0.1), ("ogbn-papers100M/8", 8, 0.875), ("ogbn-products", 4, 0.1),
+                                             ("ogbn-products", 2, 0.5)])
+def test_block_rows_ranks_agree_on_one_symmetric_graph(shape, world, cut):
+    """BASELINE config 5's graph (8 vertex ranges of the papers100M shape) and the weak-scaling products graph at toy scale, on
+    the CPU: the ranks' row blocks join into ONE structurally symmetric graph with sorted, duplicate-free rows and a self
+    loop per vertex; the share of edges that leave a range is the requested cut; and the joined graph partitions, rank by
+    rank, into exactly the rows each rank generated (dist.split_by_owner keeps every edge)."""
+    from graphaibench_amd import dist as gd, synth
+
+    scale = 3e-4 if shape.startswith("ogbn-papers") else 2e-3
+    blocks = [synth.block_rows(shape, r, world, seed=42, cut_fraction=cut, device="cpu", scale=scale, selfloops=True)
+              for r in range(world)]
+    nv_p = blocks[0].n_local
+    n = nv_p * world
+    assert all(b.n_local == nv_p and b.n_global == n for b in blocks)
+    rp = np.concatenate([[0]] + [b.rowptr[1:].numpy() + sum(int(c.rowptr[-1]) for c in blocks[:r]) for r, b in enumerate(blocks)])
+    ci = np.concatenate([b.colidx_global.numpy() for b in blocks])
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    key = rows * n + ci
+    assert np.all(np.diff(key) > 0)                      # rows sorted, no duplicates
+    assert np.array_equal(np.sort(ci * n + rows), key)   # symmetric: the transpose is the same edge set
+    assert np.all(ci[rp[:-1] + np.searchsorted(key, np.arange(n) * n + np.arange(n)) - rp[:-1]] == np.arange(n))  # self loops
+    cross = (rows // nv_p) != (ci // nv_p)
+    share = cross.sum() / (len(ci) - n)
+    assert abs(share - cut) < 0.25 * cut + 0.02, (share, cut)  # (duplicates removed inside a range shift it a little)
+    for r, b in enumerate(blocks):
+        lo, hi = r * nv_p, (r + 1) * nv_p
+        rp_own, ci_own, rp_halo, ci_halo, halo, deg = gd.split_by_owner(b.rowptr, b.colidx_global, lo, hi)
+        assert np.array_equal(deg.numpy(), np.diff(rp)[lo:hi])
+        assert int(rp_own[-1]) + int(rp_halo[-1]) == int(b.rowptr[-1])
+        assert np.all((halo.numpy() < lo) | (halo.numpy() >= hi)) and np.all(np.diff(halo.numpy()) > 0)
+        owned_cols = ci[rp[lo]:rp[hi]]
+        assert (ci_own.numel() == ((owned_cols >= lo) & (owned_cols < hi)).sum())
+
+
+def _worker8(rank, world, port, q):
+    """one of EIGHT ranks of config 5's set-up path over gloo: this rank's rows of the papers100M/8-shaped block graph,
+    build_partition (the all-to-all of counts and halo ids), one halo exchange of feature rows, the normalisers"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphaibench_amd import dist as gd, synth
+
+        torch.set_num_threads(1)
+        rows = synth.block_rows("ogbn-papers100M/8", rank, world, seed=42, cut_fraction=0.875, device="cpu", scale=1e-4,
+                                selfloops=True)
+        part = gd.build_partition(rows.rowptr, rows.colidx_global, rows.n_global, rank, world)
+        nv = part.n_own
+        assert (part.lo, part.hi) == (rank * nv, (rank + 1) * nv) and part.recv_counts[rank] == 0 == part.send_counts[rank]
+        # every rank's feature rows are a function of the GLOBAL row id: what arrives must be the owners' rows
+        D = 8
+        gid = torch.arange(part.lo, part.hi, dtype=torch.float32).reshape(-1, 1)
+        x = (gid * 3.0 + torch.arange(D, dtype=torch.float32)).contiguous()
+        ex = gd.HaloExchanger(part)
+        got = ex.exchange(x, D)
+        want = part.halo_gids.to(torch.float32).reshape(-1, 1) * 3.0 + torch.arange(D, dtype=torch.float32)
+        assert torch.equal(got, want)
+        vd, inv, vd_h, inv_h = gd.global_normalisers(part, ex)
+        # a halo vertex's normaliser comes from its owner's FULL degree: gather all degrees and compare
+        degs = [torch.empty(nv, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(degs, part.degree)
+        deg_all = torch.cat(degs).to(torch.float32)
+        assert torch.equal(inv_h, (1.0 / deg_all[part.halo_gids].double()).float())
+        send_total = torch.tensor([float(sum(part.send_counts)), float(sum(part.recv_counts))])
+        dist.all_reduce(send_total)
+        assert send_total[0] == send_total[1]  # every row sent is a row received
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_set_up_config5_over_gloo():
+    """a rehearsal of the 8-rank control plane (the GPU box has one GPU; the 8-GPU lease is the driver's): eight gloo ranks on
+    the CPU build config 5's partition from their own rows and exchange halo rows, random-order end (every rank talks to
+    every other)"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 700)
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
