@@ -17,19 +17,13 @@ ARGS="ogbn-papers100M 8 32 softmax 128 0 0 0.01 2 0 4 0"
 echo "=== 1 process: gpu_train_gcn $ARGS"
 $ROOT/bin/gpu_train_gcn $ARGS > $OUT/world1.log 2> $OUT/world1.err
 grep -E "Epoch|Average|Test acc" $OUT/world1.log
-echo "=== $R processes on one GPU (GAIB_COMM=ipc): gpu_train_gcn $ARGS"
-rm -f /dev/shm/gaib_id_c5
-pids=()
-for r in $(seq 0 $((R - 1))); do
-  RANK=$r WORLD_SIZE=$R LOCAL_RANK=0 GAIB_DEVICE=0 GAIB_COMM=ipc GAIB_COMM_ID_FILE=/dev/shm/gaib_id_c5 GAIB_COMM_TIMEOUT_S=300 \
-    $ROOT/bin/gpu_train_gcn $ARGS > $OUT/world${R}_r$r.log 2> $OUT/world${R}_r$r.err &
-  pids+=($!)
-done
-rc=0
-for p in "${pids[@]}"; do wait $p || rc=1; done
+echo "=== $R ranks on one GPU, ONE command: GAIB_RANKS=$R gpu_train_gcn $ARGS  (the launcher starts and supervises the ranks;"
+echo "    more ranks than devices: they agree on the peer-to-peer transport by themselves)"
+GAIB_RANKS=$R GAIB_COMM_TIMEOUT_S=300 $ROOT/bin/gpu_train_gcn $ARGS > $OUT/world${R}_r0.log 2> $OUT/world${R}.err
+rc=$?
 echo "ranks exit: $rc"
 grep -E "Epoch|Average|Test acc" $OUT/world${R}_r0.log
-grep -h "rank .* of" $OUT/world${R}_r*.log | head -$R
+grep -h "rank .* of" $OUT/world${R}_r0.log | head -$R
 python3 - <<P
 import re, sys
 a = re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+)", open("$OUT/world1.log").read())
