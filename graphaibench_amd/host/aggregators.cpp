@@ -283,14 +283,18 @@ void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_
     const int rc = gaib_gat_backward_fused_rect(C(), full, len, heads, d_ptab, d_pgrad, d_prec, d_alpha_l, d_alpha_r, epsilon,
                                                 grad_out, d_alpha_lgrad, d_alpha_rgrad, 0);
     const float* halo = g.halo_end(len);  // (every rank ends every exchange it began, whatever rc says)
-    GAIB_OR_DIE(rc);                      // forward took this path with the same shape: UNSUPPORTED cannot happen here
-    if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_pgrad + n_own * len, halo, sizeof(float) * n_halo * len));
-    g.halo_begin(4 * heads, d_prec);
-    halo = g.halo_end(4 * heads);
-    if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_prec + n_own * heads * 4, halo, sizeof(float) * n_halo * heads * 4));
-    GAIB_OR_DIE(gaib_gat_backward_fused_rect(C(), full, len, heads, d_ptab, d_pgrad, d_prec, d_alpha_l, d_alpha_r, epsilon,
-                                             grad_out, d_alpha_lgrad, d_alpha_rgrad, 1));
-    return;
+    if (rc == GAIB_OK) {
+      if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_pgrad + n_own * len, halo, sizeof(float) * n_halo * len));
+      g.halo_begin(4 * heads, d_prec);
+      halo = g.halo_end(4 * heads);
+      if (n_halo) GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_prec + n_own * heads * 4, halo, sizeof(float) * n_halo * heads * 4));
+      GAIB_OR_DIE(gaib_gat_backward_fused_rect(C(), full, len, heads, d_ptab, d_pgrad, d_prec, d_alpha_l, d_alpha_r, epsilon,
+                                               grad_out, d_alpha_lgrad, d_alpha_rgrad, 1));
+      return;
+    }
+    // forward took the one-sweep path and backward may not (option gat_fused_bwd = 0 on every rank -- options are set per
+    // process, the same on all): the exchange above was for nothing, the staged pieces below form the attention again
+    if (rc != GAIB_ERR_UNSUPPORTED) GAIB_OR_DIE(rc);
   }
   if (part_fused_last) {  // forward kept statistics only and backward has no forward output to use: the attention, staged
     GAIB_OR_DIE(gaib_gat_scores_mh(C(), full, len, heads, d_ptab, d_alpha_l, d_alpha_r, epsilon, d_temp_scores, NULL,

@@ -129,6 +129,8 @@ def _gat_worker(rank, world, idfile, q, heads, mode="fused"):
         if mode == "staged":  # the round-2 pieces (SDDMM, row-side softmax backward, transposed SpMM, reverse exchange)
             ctx.set_option("gat_fused_fwd", 0)
             ctx.set_option("gat_fused_bwd", 0)
+        if mode == "fwd-only":  # one-sweep forward (row statistics only), staged backward: the attention is formed again
+            ctx.set_option("gat_fused_bwd", 0)
         comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, capi.COMM_IPC, capi), capi.COMM_IPC)
         L.set_comm(comm)
         rp, ci = random_graph(2500, 14, seed=21, power_law=True, hub_deg=1300)
@@ -270,7 +272,7 @@ def test_ipc_ranks_on_one_gpu_match_global_oracle(tmp_path, arch, world):
 
 
 @pytest.mark.parametrize("heads,world,mode", [(1, 2, "fused"), (8, 2, "fused"), (8, 3, "fused"), (4, 3, "fused"),
-                                              (1, 2, "staged"), (8, 3, "staged")])
+                                              (1, 2, "staged"), (8, 3, "staged"), (8, 2, "fwd-only")])
 def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world, mode):
     """GAT_layer 48 -> 64 on a vertex-range partition against the GLOBAL oracle.  fused: the one-sweep kernels on the
     rank's rectangular [owned | halo] graph (forward: h halo rows, the chunks over owned columns swept while they travel;
