@@ -481,6 +481,8 @@ def _arm_deadline(seconds: float, rank: int) -> None:
 
 
 def main():
+    if os.environ.get("GAIB_RCCL_LIB"):  # (tests/fake_rccl's double is for call-pattern tests; a record must name the real RCCL)
+        sys.exit("bench.py: GAIB_RCCL_LIB is set -- the bench measures the system's RCCL only; unset it")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

@@ -116,6 +116,11 @@ def build_oracle(force: bool = False, ref: bool = True) -> Path:
     _run(["make", "-C", ORACLE, "all"])
     if ref and REFERENCE.exists():
         _run(["make", "-C", ORACLE, "ref"])
+    fake = ROOT / "tests" / "fake_rccl"  # the strict RCCL double of tests/test_gpu_comm.py (test infrastructure too)
+    if fake.exists():
+        if force:
+            _run(["make", "-C", fake, "clean"])
+        _run(["make", "-C", fake, "all"])
     return ORACLE / "libgnn_oracle.so"
 
 

@@ -58,10 +58,17 @@ int rccl_load() {
   if (g_rccl.dl) return GAIB_OK;
   const char* cands[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
-  for (const char* c : cands)
-    if ((h = dlopen(c, RTLD_NOW | RTLD_LOCAL))) break;
+  // GAIB_RCCL_LIB names THE library to bind (another RCCL build; tests/fake_rccl's strict double, which carries the
+  // same calls between processes that share one GPU): no fallback to the system's when it does not load
+  const char* named = getenv("GAIB_RCCL_LIB");
+  if (named && *named) {
+    h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    for (const char* c : cands)
+      if ((h = dlopen(c, RTLD_NOW | RTLD_LOCAL))) break;
+  }
   if (!h) {
-    gaib_set_error("gaib_comm: cannot dlopen librccl.so.1 (%s)", dlerror());
+    gaib_set_error("gaib_comm: cannot dlopen %s (%s)", named && *named ? named : "librccl.so.1", dlerror());
     return GAIB_ERR_UNSUPPORTED;
   }
 #define GAIB_SYM(field, name)                                        \

@@ -46,3 +46,24 @@ def test_error_path_without_gpu():
     assert b"NULL" in lib.gaib_last_error()
     assert lib.gaib_spmm(None, None, 0, None, 4, None, None) != 0
     assert lib.gaib_sgemm(None, 0, 0, 1, 1, 1, None, None, 0, None) != 0
+
+
+def test_rccl_double_covers_every_entry_point_comm_hip_binds():
+    """tests/fake_rccl (the strict stand-in the N > 1 tests bind comm.hip's RCCL branch to on a one-GPU box) exports each
+    symbol the library dlsym()s -- and nothing that is NOT test infrastructure loads it: the product sources never name it"""
+    import ctypes
+    import re
+
+    root = Path(__file__).resolve().parent.parent
+    src = (root / "graphaibench_amd" / "csrc" / "comm.hip").read_text()
+    wanted = re.findall(r'GAIB_SYM\(\w+, "(nccl\w+)"\)', src)
+    assert len(wanted) == 11, wanted
+    fake = root / "tests" / "fake_rccl" / "librccl_fake.so"
+    assert fake.exists(), "python -m graphaibench_amd.build"
+    lib = ctypes.CDLL(str(fake))
+    for name in wanted:
+        assert hasattr(lib, name), name
+    for p in list((root / "graphaibench_amd").rglob("*.py")) + list((root / "graphaibench_amd").rglob("*.cpp")) + \
+            list((root / "graphaibench_amd").rglob("*.hip")) + [root / "bench.py", root / "__graft_entry__.py"]:
+        text = p.read_text()
+        assert "librccl_fake" not in text, p

@@ -5,8 +5,12 @@ One GPU is all this box has, so:
   * the IPC transport (peer-to-peer pull through hipIpc handles) runs for real with 2 and 3 PROCESSES sharing cuda:0:
     partition -> LearningGraph with a halo plan -> C++ GCN / SAGE layer forward + backward + optimizer step, against the
     oracle's GLOBAL result;
-  * the RCCL transport runs with one rank (init, all-reduce, an exchange without peers): RCCL refuses two ranks on
-    one device, which the two-rank case asserts as a clean error on both ranks;
+  * the RCCL transport runs on the system's library with one rank (init, all-reduce, an exchange without peers): RCCL
+    refuses two ranks on one device;
+  * the RCCL BRANCH of comm.hip (grouped ncclSend / ncclRecv with per-peer offsets and counts, the reverse exchange,
+    the all-reduces on the communication stream) runs with 2 and 3 ranks bound to tests/fake_rccl -- a strict double
+    that moves the same calls' bytes between processes sharing cuda:0 and refuses every count / datatype / peer /
+    address-range mismatch the real library would hang or fault on.  It proves the call pattern, not RCCL or xGMI;
   * a rank whose peer never arrives returns GAIB_ERR_COMM within the deadline instead of hanging.
 """
 import os
@@ -21,6 +25,20 @@ import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
+
+
+FAKE_RCCL = ROOT / "tests" / "fake_rccl" / "librccl_fake.so"
+
+
+def _transport(name, capi):
+    """"ipc" | "rccl" (the system's library: one rank per device) | "fake-rccl": the RCCL branch of comm.hip bound to
+    tests/fake_rccl's strict double, which carries the same ncclSend / ncclRecv / ncclAllReduce calls between processes
+    that share one GPU and fails on any count, datatype, peer or address-range mismatch"""
+    if name == "fake-rccl":
+        assert FAKE_RCCL.exists(), f"{FAKE_RCCL} not built (python -m graphaibench_amd.build)"
+        os.environ["GAIB_RCCL_LIB"] = str(FAKE_RCCL)
+        return capi.COMM_RCCL
+    return capi.COMM_IPC if name == "ipc" else capi.COMM_RCCL
 
 
 def _id_via_file(path, rank, transport, capi):
@@ -49,7 +67,7 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         from oracle import binding as orc
         from util import LONG_SUM_FLOOR, assert_close, random_graph
 
-        transport = capi.COMM_IPC if transport_name == "ipc" else capi.COMM_RCCL
+        transport = _transport(transport_name, capi)
         ctx = L.init(0)
         comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
         # raw collectives first
@@ -114,7 +132,7 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def _gat_worker(rank, world, idfile, q, heads, mode="fused"):
+def _gat_worker(rank, world, idfile, q, heads, mode="fused", transport_name="ipc"):
     """GAT_layer 64 -> 64 on a vertex-range partition (h halo rows for the scores, partial gradient rows returned to
     their owners, alpha gradients all-reduced) against the GLOBAL oracle: head by head for heads > 1"""
     sys.path.insert(0, str(ROOT))
@@ -131,7 +149,8 @@ def _gat_worker(rank, world, idfile, q, heads, mode="fused"):
             ctx.set_option("gat_fused_bwd", 0)
         if mode == "fwd-only":  # one-sweep forward (row statistics only), staged backward: the attention is formed again
             ctx.set_option("gat_fused_bwd", 0)
-        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, capi.COMM_IPC, capi), capi.COMM_IPC)
+        transport = _transport(transport_name, capi)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
         L.set_comm(comm)
         rp, ci = random_graph(2500, 14, seed=21, power_law=True, hub_deg=1300)
         g = orc.Graph(rp, ci).add_selfloop()
@@ -182,7 +201,7 @@ def _gat_worker(rank, world, idfile, q, heads, mode="fused"):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def _halo_realloc_worker(rank, world, idfile, q):
+def _halo_realloc_worker(rank, world, idfile, q, transport_name="ipc"):
     """raw halo plan: exchange and reverse exchange with GROWING row lengths in the order that left a stale hipIpc
     handle behind (exchange 16, reduce 16, exchange 64, reduce 64: the reduce's table was reallocated by the exchange
     before it, the exchange's send buffer by the reduce before it), and more plans over a communicator's life than it
@@ -193,7 +212,8 @@ def _halo_realloc_worker(rank, world, idfile, q):
         from graphaibench_amd import capi, layers as L
 
         ctx = L.init(0)
-        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, capi.COMM_IPC, capi), capi.COMM_IPC)
+        transport = _transport(transport_name, capi)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
         n_own = 5000
         rng = np.random.default_rng(100)  # the same plan on every rank: rank r needs rows need[r][q] of rank q
         need = [[np.sort(rng.choice(n_own, 700 + 50 * (r + q), replace=False)) if q != r else np.empty(0, np.int64)
@@ -285,6 +305,96 @@ def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world
 @pytest.mark.parametrize("world", [2, 3])
 def test_ipc_halo_buffers_regrow_between_exchange_and_reduce(tmp_path, world):
     res = _spawn(world, _halo_realloc_worker, (str(tmp_path / "id"),))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 2), ("gcn", 3)])
+def test_rccl_branch_with_strict_double_matches_global_oracle(tmp_path, arch, world):
+    """comm.hip's RCCL branch AS WRITTEN with N > 1 ranks: grouped send / recv of the halo exchange and of the reverse
+    exchange (offsets, counts, peers), fp32 / fp64 all-reduces on the communication stream, layer results against the
+    GLOBAL oracle.  The bytes travel through tests/fake_rccl (this box has one GPU and RCCL wants one per rank)."""
+    res = _spawn(world, _worker, (str(tmp_path / "id"), arch, "fake-rccl"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("heads,world,mode", [(8, 2, "fused"), (4, 3, "fused"), (8, 3, "staged")])
+def test_rccl_branch_gat_on_partition(tmp_path, heads, world, mode):
+    res = _spawn(world, _gat_worker, (str(tmp_path / "id"), heads, mode, "fake-rccl"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_branch_exchange_and_reduce_with_growing_rows(tmp_path, world):
+    res = _spawn(world, _halo_realloc_worker, (str(tmp_path / "id"), "fake-rccl"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+def _double_is_strict(rank, world, idfile, q):
+    """the double itself, through its C entry points: what it must REFUSE"""
+    import ctypes
+
+    try:
+        lib = ctypes.CDLL(str(FAKE_RCCL))
+        os.environ["GAIB_FAKE_RCCL_TIMEOUT_S"] = "20"
+
+        class Uid(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_char * 128)]
+
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, Uid, ctypes.c_int]
+        for f in (lib.ncclSend, lib.ncclRecv):
+            f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        F32, SUM = 7, 0  # ncclFloat32, ncclSum (rccl.h)
+        uid = Uid()
+        if rank == 0:
+            assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(bytes(uid.internal))
+            os.replace(idfile + ".tmp", idfile)
+        else:
+            t0 = time.time()
+            while not os.path.exists(idfile) and time.time() - t0 < 60:
+                time.sleep(0.005)
+            raw = open(idfile, "rb").read()
+            ctypes.memmove(ctypes.byref(uid), raw.ljust(128, b"\0"), 128)
+        comm = ctypes.c_void_p()
+        assert lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
+        t = torch.arange(1000, dtype=torch.float32, device="cuda") + 1000 * rank
+        peer = 1 - rank
+        # 1. a matched pair works and carries the bytes
+        got = torch.empty(1000, device="cuda")
+        if rank == 0:
+            assert lib.ncclSend(t.data_ptr(), 1000, F32, peer, comm, None) == 0
+            assert lib.ncclRecv(got.data_ptr(), 1000, F32, peer, comm, None) == 0
+        else:
+            assert lib.ncclRecv(got.data_ptr(), 1000, F32, peer, comm, None) == 0
+            assert lib.ncclSend(t.data_ptr(), 1000, F32, peer, comm, None) == 0
+        assert torch.equal(got, torch.arange(1000, dtype=torch.float32, device="cuda") + 1000 * peer)
+        # 2. all-reduce: the sum, identical on both
+        a = torch.full((333,), float(rank + 1), device="cuda")
+        assert lib.ncclAllReduce(a.data_ptr(), a.data_ptr(), 333, F32, SUM, comm, None) == 0
+        assert torch.all(a == 3.0)
+        # 3. a range that leaves its allocation is refused before anything moves (local check, both ranks)
+        small = torch.empty(16, device="cuda")
+        assert lib.ncclSend(small.data_ptr(), 1 << 22, F32, peer, comm, None) != 0
+        assert lib.ncclSend(t.data_ptr(), 10, F32, world, comm, None) != 0  # peer out of range
+        # 4. counts that do not pair up: the receive fails (the real library would hang or overwrite)
+        if rank == 0:
+            assert lib.ncclSend(t.data_ptr(), 100, F32, peer, comm, None) == 0
+        else:
+            assert lib.ncclRecv(got.data_ptr(), 50, F32, peer, comm, None) != 0
+        lib.ncclCommDestroy(comm)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def test_the_rccl_double_refuses_what_the_real_library_would_not_survive(tmp_path):
+    res = _spawn(2, _double_is_strict, (str(tmp_path / "id"),), timeout=180)
     assert all(r[1] == "ok" for r in res), res
 
 
