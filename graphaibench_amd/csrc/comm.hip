@@ -153,6 +153,20 @@ struct gaib_comm {
   uint32_t sense;
   uint32_t halo_slots;  // bitmap of the slot rows in use (plans are created and destroyed collectively: same bits on every rank)
   float* h_stage;  // pinned staging for the IPC all-reduce
+  // IPC: every buffer this communicator ever exported.  hipFree does not give an exported buffer's memory back to the
+  // device (measured: 8 x {hipMalloc 2 MiB, hipIpcGetMemHandle, hipFree} = 16 MiB less free memory, also when no peer ever
+  // opened the handle; scripts/ipc_leak_probe.py), so a process that builds and drops partitions would lose its halo
+  // buffers each time.  They are therefore pooled: a plan takes its send buffer / halo table from here (best fit), hands
+  // them back when it is destroyed (after the peers closed their mappings and a barrier), the handle of a buffer is
+  // exported once, and hipFree is left to gaib_comm_destroy.  The RCCL transport draws from the same pool (no export
+  // there; it saves the synchronising hipMalloc / hipFree pair when partitions are rebuilt, e.g. per sampled subgraph).
+  struct IpcBuf {
+    void* p;
+    size_t cap;
+    hipIpcMemHandle_t handle;
+    bool exported, in_use;
+  } ipc_bufs[256];
+  int n_ipc_bufs;
 };
 
 struct gaib_halo {
@@ -234,12 +248,41 @@ int fail(gaib_comm* c, int rc) {  // tell the peers, keep the message
   return rc;
 }
 
+// IPC buffers come out of (and go back into) the communicator's pool -- see gaib_comm::ipc_bufs
+gaib_comm::IpcBuf* pool_find(gaib_comm* c, const void* p) {
+  for (int k = 0; k < c->n_ipc_bufs; k++)
+    if (c->ipc_bufs[k].p == p) return &c->ipc_bufs[k];
+  return nullptr;
+}
+void pool_release(gaib_comm* c, void* p) {
+  if (!p) return;
+  gaib_comm::IpcBuf* b = pool_find(c, p);
+  if (b) b->in_use = false;
+  else (void)hipFree(p);  // (the pool was full when it was allocated)
+}
+// the handle of a pooled buffer: exported once
+hipError_t pool_handle(gaib_comm* c, void* p, hipIpcMemHandle_t* out) {
+  gaib_comm::IpcBuf* b = pool_find(c, p);
+  if (b && b->exported) {
+    *out = b->handle;
+    return hipSuccess;
+  }
+  hipError_t e = hipIpcGetMemHandle(out, p);
+  if (e == hipSuccess && b) {
+    b->handle = *out;
+    b->exported = true;
+  }
+  return e;
+}
+
 int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t s, gaib_halo* keep = nullptr) {
   if (bytes <= *cap && *p) return 0;
   if (*p) {
     GAIB_HIP(hipStreamSynchronize(s));
-    if (keep && keep->n_retired < (int)(sizeof(keep->retired) / sizeof(keep->retired[0])))
+    if (keep && keep->c->transport == GAIB_COMM_IPC && keep->n_retired < (int)(sizeof(keep->retired) / sizeof(keep->retired[0])))
       keep->retired[keep->n_retired++] = *p;  // IPC: peers may still have it mapped (see gaib_halo::retired)
+    else if (keep)
+      pool_release(keep->c, *p);
     else
       GAIB_HIP(hipFree(*p));
     *p = nullptr;
@@ -250,10 +293,32 @@ int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t 
   // with "invalid argument" (and, before buffers were retired, handed peers a mapping that read wrong rows)
   const size_t gran = (size_t)2 << 20;
   size_t want = ((bytes < 1 ? 1 : bytes) + gran - 1) / gran * gran;
+  if (keep) {  // best fit among the pooled buffers nobody uses
+    gaib_comm* c = keep->c;
+    gaib_comm::IpcBuf* best = nullptr;
+    for (int k = 0; k < c->n_ipc_bufs; k++) {
+      gaib_comm::IpcBuf* b = &c->ipc_bufs[k];
+      if (!b->in_use && b->cap >= want && (!best || b->cap < best->cap)) best = b;
+    }
+    if (best && best->cap <= 2 * want) {  // (not a buffer far larger than asked for: the next large plan wants it)
+      best->in_use = true;
+      *p = (float*)best->p;
+      *cap = best->cap;
+      ++*serial;
+      return 1;
+    }
+  }
   hipError_t e = hipMalloc((void**)p, want);
   if (e != hipSuccess) {
     gaib_set_error("gaib_halo: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     return GAIB_ERR_NOMEM;
+  }
+  if (keep && keep->c->n_ipc_bufs < (int)(sizeof(keep->c->ipc_bufs) / sizeof(keep->c->ipc_bufs[0]))) {
+    gaib_comm::IpcBuf* b = &keep->c->ipc_bufs[keep->c->n_ipc_bufs++];
+    memset((void*)b, 0, sizeof(*b));
+    b->p = *p;
+    b->cap = want;
+    b->in_use = true;
   }
   *cap = want;
   ++*serial;
@@ -410,6 +475,7 @@ extern "C" int gaib_comm_destroy(gaib_comm* c) {
   (void)hipStreamSynchronize(c->cstream);
   if (c->transport == GAIB_COMM_RCCL && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (int k = 0; k < c->n_ipc_bufs; k++) (void)hipFree(c->ipc_bufs[k].p);  // (every plan is gone: gaib_halo_destroy comes first)
   if (c->seg) munmap(c->seg, sizeof(ShmSeg));
   (void)hipEventDestroy(c->ev_ready);
   (void)hipEventDestroy(c->ev_done);
@@ -601,9 +667,9 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (h->d_send_idx) (void)hipFree(h->d_send_idx);
   if (h->d_pack_row) (void)hipFree(h->d_pack_row);
   if (h->d_pack_slot) (void)hipFree(h->d_pack_slot);
-  if (h->sendbuf) (void)hipFree(h->sendbuf);
-  if (h->table) (void)hipFree(h->table);
-  for (int k = 0; k < h->n_retired; k++) (void)hipFree(h->retired[k]);
+  pool_release(c, h->sendbuf);  // back into the communicator's pool (see gaib_comm::ipc_bufs)
+  pool_release(c, h->table);
+  for (int k = 0; k < h->n_retired; k++) pool_release(c, h->retired[k]);
   c->halo_slots &= ~(1u << h->id);  // after the barrier above: the slot row can serve the next plan
   delete h;
   return GAIB_OK;
@@ -625,7 +691,7 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
   GAIB_CHECK(n_send == 0 || d_rows, "gaib_halo_exchange_begin: d_rows is NULL");
   const size_t row_bytes = sizeof(float) * (size_t)len;
-  gaib_halo* keep = c->transport == GAIB_COMM_IPC ? h : nullptr;
+  gaib_halo* keep = h;  // (both transports draw from the communicator's pool; only IPC retires, see reserve)
   int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream, keep);
   if (ra < 0) return fail(c, ra);
   int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
@@ -658,7 +724,7 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   // ---- IPC pull ----
   ShmSlot* mine = &c->seg->slot[h->id][c->rank];
   if (h->pub_send_serial != h->send_serial) {  // also after a gaib_halo_reduce grew the send buffer
-    hipError_t e = hipIpcGetMemHandle(&mine->handle, h->sendbuf);
+    hipError_t e = pool_handle(c, h->sendbuf, &mine->handle);
     if (e != hipSuccess) {
       gaib_set_error("gaib_halo_exchange_begin: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
       return fail(c, GAIB_ERR_HIP);
@@ -754,7 +820,7 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   const int64_t n_send = h->send_off[c->nranks], n_recv = h->recv_off[c->nranks];
   GAIB_CHECK((n_recv == 0 || d_halo_rows) && (n_send == 0 || d_rows), "gaib_halo_reduce: NULL rows");
   const size_t row_bytes = sizeof(float) * (size_t)len;
-  gaib_halo* keep = c->transport == GAIB_COMM_IPC ? h : nullptr;
+  gaib_halo* keep = h;  // (both transports draw from the communicator's pool; only IPC retires, see reserve)
   int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream, keep);  // arrivals land here
   if (ra < 0) return fail(c, ra);
   if (c->transport == GAIB_COMM_RCCL) {
@@ -786,7 +852,7 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
     ShmSlot* mine = &c->seg->slot[h->id][c->rank];
     if (e == hipSuccess && h->pub_table_serial != h->table_serial) {  // also after an exchange grew the table
       step = "hipIpcGetMemHandle(halo table)";
-      e = hipIpcGetMemHandle(&mine->handle_t, h->table);
+      e = pool_handle(c, h->table, &mine->handle_t);
       for (int r = 0; r <= c->nranks; r++) mine->recv_off[r] = h->recv_off[r];
       mine->gen_t++;
       h->pub_table_serial = h->table_serial;

@@ -165,6 +165,28 @@ const float* GAT_Aggregator::apply_attn_dropout(size_t n_scores) {
   return d_norm_scores_drop;
 }
 
+void GAT_Aggregator::release() {
+  gaib_ctx* c = C();
+  float** owned[] = {&d_alpha_l, &d_alpha_r, &d_alpha_lgrad, &d_alpha_rgrad, &d_temp_scores, &d_norm_scores, &d_norm_scores_grad,
+                     &d_norm_scores_t, &d_norm_scores_drop, &d_tbuf, &d_ptab, &d_pout, &d_prs, &d_pcs, &d_pgrad, &d_prec,
+                     &d_row_stats};
+  for (float** p : owned) {
+    if (*p) GAIB_OR_DIE(gaib_free(c, *p));
+    *p = NULL;
+  }
+  if (d_attn_masks) GAIB_OR_DIE(gaib_free(c, d_attn_masks));
+  d_attn_masks = NULL;
+  drop_cap = tbuf_floats = ptab_floats = pvec_floats = pgrad_floats = prec_floats = stats_floats = 0;
+  stats_valid = part_fused_last = dropped_last = false;
+  last_graph = NULL;
+  last_in = fwd_out = NULL;
+  if (alpha_opt) {
+    alpha_opt->reset();
+    delete alpha_opt;
+    alpha_opt = NULL;
+  }
+}
+
 void GAT_Aggregator::set_num_heads(int h) {
   if (h < 1 || length % h != 0) {
     fprintf(stderr, "GAT_Aggregator::set_num_heads(%d): must divide the feature length %d\n", h, length);

@@ -73,6 +73,15 @@ void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* g
   return b;
 }
 
+void gaibl_layer_free(void* layer) {
+  LayerBox* b = static_cast<LayerBox*>(layer);
+  if (!b) return;
+  if (b->gcn) b->gcn->release_all(), delete b->gcn;
+  if (b->sage) b->sage->release_all(), delete b->sage;
+  if (b->gat) b->gat->release_all(), delete b->gat;
+  delete b;
+}
+
 #define DISPATCH(b, call)                          \
   do {                                             \
     if ((b)->kind == GAIBL_GCN) (b)->gcn->call;    \

@@ -51,6 +51,27 @@ gconv_state::gconv_state(int id, int nv, int din, int dout, Graph* g, bool act, 
   optm = new adam(lr);
 }
 
+// see include/layers/graph_conv_layer.h: there is no destructor (layers are copied by value)
+void gconv_state::release() {
+  gaib_ctx* c = C();
+  float** owned[] = {&grad_in, &d_in_temp, &d_in_temp1, &d_out_temp, &d_W_neigh, &d_W_neigh_grad, &d_W_self, &d_W_self_grad};
+  for (float** p : owned) {
+    if (*p) GAIB_OR_DIE(gaib_free(c, *p));
+    *p = NULL;
+  }
+  if (level_ > 0 && feat_in) GAIB_OR_DIE(gaib_free(c, feat_in));  // level 0's input belongs to the model (set_feat_in)
+  feat_in = NULL;
+  if (dropout_mask) GAIB_OR_DIE(gaib_free(c, dropout_mask));
+  dropout_mask = NULL;
+  if (optm) {
+    optm->reset();  // its per-weight moment buffers
+    delete optm;
+    optm = NULL;
+  }
+  capacity_ = 0;
+  agg_valid_ = false;
+}
+
 // number of rows changes with subgraph sampling (training on subgraphs, evaluation on the full
 // graph); buffers grow when needed (reference GPU build: src/gnn/graph_conv_layer.cu:57-83)
 void gconv_state::update_dim_size(size_t x) {

@@ -155,6 +155,17 @@ void LearningGraph::dealloc() {
   vertex_data_ = edge_data_ = NULL;
   if (dev_) gaib_graph_destroy(dev_);
   dev_ = NULL;
+  if (owns_partition_) {
+    if (halo_plan_) gaib_halo_destroy(halo_plan_);
+    if (halo_dev_) gaib_graph_destroy(halo_dev_);
+    if (gat_full_) gaib_graph_destroy(gat_full_);
+    if (gat_t_) gaib_graph_destroy(gat_t_);
+    if (gat_tperm_) gaib_free(gpu_context::get(), gat_tperm_);
+  }
+  halo_plan_ = NULL;
+  halo_dev_ = gat_full_ = gat_t_ = NULL;
+  gat_tperm_ = NULL;
+  owns_partition_ = false;
 }
 
 void LearningGraph::print_graph() {

@@ -51,6 +51,8 @@ void adam::update(const vec_t& dW, vec_t& W) {
   b2_t *= b2;
 }
 
+adam::~adam() { reset(); }
+
 void adam::reset() {
   gaib_ctx* c = gpu_context::get();
   for (auto& kv : dev_state) {

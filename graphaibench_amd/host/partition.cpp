@@ -185,6 +185,7 @@ LearningGraph* make_partitioned_graph(const VertexRangePartition& P, gaib_comm* 
     if (ne) GAIB_OR_DIE(gaib_memcpy_h2d(ctx, d_tperm, P.tperm.data(), sizeof(index_t) * (size_t)ne));
     lg->set_gat_partition(g_full, g_t, d_tperm, n_halo, ne);
   }
+  lg->own_partition_objects();
   float* tmp[] = {d_vd, d_inv, d_vd_h, d_inv_h};  // set_vertex_norm copied them
   for (float* p : tmp) GAIB_OR_DIE(gaib_free(ctx, p));
   return lg;

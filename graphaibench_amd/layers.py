@@ -28,6 +28,7 @@ SIGNATURES = {
     "gaibl_graph_free": (None, [_vp]),
     "gaibl_graph_set_halo": (None, [_vp, _vp, _vp, _vp, _vp]),
     "gaibl_layer_create": (_vp, [_i, _i, _i, _i, _i, _vp, _i, _f, _f, _f]),
+    "gaibl_layer_free": (None, [_vp]),
     "gaibl_layer_forward": (None, [_vp, _vp]),
     "gaibl_layer_backward": (None, [_vp, _vp, _vp]),
     "gaibl_layer_update_weight": (None, [_vp, _vp]),
@@ -131,6 +132,13 @@ class LGraph:
     def ne(self) -> int:
         return int(load().gaibl_graph_num_edges(self.h))
 
+    def close(self):
+        """LearningGraph::dealloc + delete: the device CSR with its caches; for a graph made by HostPartition.make_graph
+        also the halo graph, the exchange plan (close it BEFORE its communicator) and the GAT structures"""
+        if getattr(self, "h", None):
+            load().gaibl_graph_free(self.h)
+            self.h = None
+
     def set_halo(self, halo_graph: capi.Graph, begin, end):
         """begin(len:int, d_in:int) -> None ; end(len:int) -> int (device pointer of the halo table)"""
         BEGIN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
@@ -155,6 +163,12 @@ class Layer:
         self.kind, self.level, self.nv, self.din, self.dout = kind, level, nv, din, dout
         self.graph = graph
         self.h = self.lib.gaibl_layer_create(kind, level, nv, din, dout, graph.h, int(act), lr, feat_drop, score_drop)
+
+    def close(self):
+        """every device buffer of the layer and of its aggregator goes back (gconv_state::release)"""
+        if getattr(self, "h", None):
+            self.lib.gaibl_layer_free(self.h)
+            self.h = None
 
     def forward(self, feat_out):
         self.lib.gaibl_layer_forward(self.h, feat_out.data_ptr())
@@ -260,6 +274,11 @@ def set_comm(comm) -> None:
 
 def adam(lr: float):
     return load().gaibl_adam_create(lr)
+
+
+def adam_free(opt) -> None:
+    """delete the optimizer and its per-weight moment buffers on the device"""
+    load().gaibl_adam_free(opt)
 
 
 def sample_subgraph(rowptr, colidx, train_masks, n: int, m: int, seed: int):

@@ -66,6 +66,7 @@ void gaibl_graph_set_halo_plan(void* graph, void* halo_graph, void* plan);
 
 void* gaibl_layer_create(int kind, int level, int nv, int din, int dout, void* graph, int act, float lr,
                          float feat_drop, float score_drop);
+void gaibl_layer_free(void* layer); /* gconv_state::release + the aggregator's: every device buffer of the layer */
 void gaibl_layer_forward(void* layer, float* d_feat_out);
 void gaibl_layer_backward(void* layer, float* d_feat_out, float* d_grad_out);
 void gaibl_layer_update_weight(void* layer, void* optimizer);

@@ -14,6 +14,9 @@ class aggregator {
   // extension: the next aggregate() call clamps its output at 0 (the layer's relu_gpu fused
   // into the aggregation's store); cleared by that call
   void fuse_relu_once() { fuse_relu = true; }
+  // extension: free what the operator allocated (nothing for GCN / SAGE; GAT: attention vectors, per-edge arrays,
+  // partition tables, its Adam state).  See gconv_state::release.
+  void release() {}
 
  protected:
   // extension shared by the GCN / SAGE operators: agg = Op.in followed by out = act(agg . op(W)) -- the
@@ -68,6 +71,7 @@ class GAT_Aggregator : public aggregator {
   void aggregate(int len, Graph& g, const float* in, float* out);
   void d_aggregate(int len, Graph& g, const float* feat_in, const float* grad_in, float* grad_out);
   void update_weights(optimizer* opt);
+  void release();
   // extension (BASELINE config "GAT 8-head"; the reference is single-head): h independent attentions
   // on the column slices of width length/h.  Call right after init().
   void set_num_heads(int h);

@@ -36,6 +36,7 @@ class LearningGraph {
   gaib_graph* gat_t_;
   index_t* gat_tperm_;
   index_t gat_n_halo_;
+  bool owns_partition_;  // make_partitioned_graph built halo_dev_ / halo_plan_ / gat_*: dealloc() releases them too
 
  public:
   typedef size_t iterator;
@@ -43,7 +44,7 @@ class LearningGraph {
       : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
         colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_dev_(NULL),
         halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL), gat_full_(NULL), gat_t_(NULL),
-        gat_tperm_(NULL), gat_n_halo_(0) {}
+        gat_tperm_(NULL), gat_n_halo_(0), owns_partition_(false) {}
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -97,6 +98,9 @@ class LearningGraph {
     halo_plan_ = plan;
   }
   gaib_halo* halo_plan() { return halo_plan_; }
+  // the halo graph, the exchange plan and the GAT structures handed over so far belong to this object from here on:
+  // dealloc() destroys them (the plan before its communicator -- the caller's order, as with gaib_halo_destroy)
+  void own_partition_objects() { owns_partition_ = true; }
   // ne_full = all edges of the owned rows (owned- and halo-column): what sizeEdges() reports from here on, so that
   // per-edge buffers of the aggregators are sized for the combined graph
   void set_gat_partition(gaib_graph* full, gaib_graph* transposed, index_t* d_tperm, size_t n_halo, size_t ne_full) {

@@ -44,6 +44,12 @@ class gconv_state {
   // and this call drop the kept aggregate.  Off unless asked for.
   void set_input_constant(bool on) { input_constant_ = on; agg_valid_ = false; }
   bool input_constant() const { return input_constant_; }
+  // ---- extension: give the HBM back ------------------------------------------------------------------------------
+  // Layers are copied by value (std::vector<layer_type>, include/gnn/net.h:57), so there is no destructor; a host that
+  // builds and drops models in one process calls release() on the ONE copy it keeps (LearningGraph::dealloc's idiom):
+  // weights, gradients, activations, masks and the layer's Adam state are freed, the object must not be used afterwards.
+  // The concrete layers add their aggregator's buffers (release_all).
+  void release();
 
  protected:
   gconv_state(int id, int nv, int din, int dout, Graph* g, bool act, bool concat, float lr, float feat_drop,
@@ -76,6 +82,10 @@ class graph_conv_layer : public gconv_state {
                    float score_drop)
       : gconv_state(id, nv, din, dout, g, act, concat, lr, feat_drop, score_drop) {}
   Aggregator& get_aggregator() { return aggr; }
+  void release_all() {  // the layer's buffers and the aggregator's
+    aggr.release();
+    release();
+  }
 
  protected:
   Aggregator aggr;

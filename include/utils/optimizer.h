@@ -22,6 +22,7 @@ struct adam : public optimizer {
       : alpha(lr), b1(float_t(0.9)), b2(float_t(0.999)), b1_t(float_t(0.9)), b2_t(float_t(0.999)),
         eps(float_t(1e-8)) {}
   adam() : adam(0.01) {}
+  ~adam() override;  // the per-weight moment buffers in HBM go back (the reference's instances live as long as the process)
   void update(const vec_t& dW, vec_t& W) override;
   void update_gpu(const size_t n, const float_t* dW, float_t* W) override;
   void reset() override;

@@ -169,7 +169,11 @@ ncclResult_t publish(ncclComm* c, const char* name, const void* d_src, size_t by
       close(fd);
       return fail(ncclSystemError, "mmap failed, errno %lld", errno);
     }
-    hipError_t e = hipMemcpy(m, d_src, bytes, hipMemcpyDeviceToHost);
+    // through a heap buffer: the runtime pins what it copies into, and a pinned page of an shm object that is
+    // unmapped and unlinked a moment later is not something to leave behind in it
+    std::vector<char> bounce(bytes);
+    hipError_t e = hipMemcpy(bounce.data(), d_src, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) memcpy(m, bounce.data(), bytes);
     munmap(m, bytes);
     if (e != hipSuccess) {
       close(fd);
@@ -236,7 +240,11 @@ ncclResult_t do_recv(const Op& o) {
   r = open_msg(name, bytes, &m);
   shm_unlink(name);
   if (r != ncclSuccess) return r;
-  hipError_t e = bytes ? hipMemcpy(o.buf, m, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  hipError_t e = hipSuccess;
+  if (bytes) {
+    std::vector<char> bounce((const char*)m, (const char*)m + bytes);  // (see publish)
+    e = hipMemcpy(o.buf, bounce.data(), bytes, hipMemcpyHostToDevice);
+  }
   if (m) munmap(m, bytes);
   b.taken.store(seq + 1, std::memory_order_release);
   if (e != hipSuccess) return fail(ncclUnhandledCudaError, "rank %lld: host -> device copy failed (%lld)", c->rank, (long long)e);

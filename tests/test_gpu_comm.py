@@ -125,6 +125,37 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         tot = comm.allreduce_host([s])[0]
         assert abs(tot - world * s) <= 1e-9 * abs(tot), (tot, s)
         comm.barrier()
+        # a partition's LearningGraph owns its halo graph and exchange plan: dealloc gives them back (the ranks share
+        # the device, so every reading of the free memory sits between two barriers)
+        def free_now():
+            L.sync()
+            comm.barrier()
+            f = torch.cuda.mem_get_info()[0]
+            comm.barrier()
+            return f
+
+        def build_use_close():
+            lg2 = part.make_graph(comm)
+            l2 = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, hi - lo, D, D, lg2, True)
+            l2.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+            l2.forward(out)
+            L.sync()
+            l2.close()
+            lg2.close()
+
+        build_use_close()
+        base = free_now()
+        for _ in range(3):
+            build_use_close()
+        def lost_now():  # the same number on every rank (so that all of them leave the loop below together)
+            return comm.allreduce_host([float(base - free_now())])[0] / world
+
+        lost, tries = lost_now(), 0
+        while lost > (4 << 20) * world and tries < 20:  # (the driver hands a peer's freed memory back a little later)
+            time.sleep(0.25)
+            lost, tries = lost_now(), tries + 1
+        assert lost <= (4 << 20) * world, f"{lost / 2**20:.1f} MiB of the device not returned by {world} ranks after {tries} polls"
+        comm.barrier()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -351,7 +382,7 @@ def _double_is_strict(rank, world, idfile, q):
         if rank == 0:
             assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
             with open(idfile + ".tmp", "wb") as f:
-                f.write(bytes(uid.internal))
+                f.write(ctypes.string_at(ctypes.byref(uid), 128))  # (uid.internal would stop at the first NUL)
             os.replace(idfile + ".tmp", idfile)
         else:
             t0 = time.time()
