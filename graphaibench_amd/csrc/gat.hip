@@ -1471,6 +1471,14 @@ static int gat_forward_fused_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
                                   bool rect, const char* who) {
   GAIB_CHECK(ctx && g, "%s: NULL ctx/graph", who);
   GAIB_TRY(check_heads(who, len, heads));
+  if (g->nv == 0) {
+    // a rank without rows (fewer vertices than ranks): nothing to write, its buffers may be NULL -- but WHICH path "ran" must be
+    // what the ranks with rows decide, from the shape and the option alone: the two paths differ in their exchanges
+    if (rect && len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) && ctx->gat_fused_fwd != 0)
+      return GAIB_OK;
+    gaib_set_error("%s: not applicable to this shape / graph (len %d, heads %d)", who, len, heads);
+    return GAIB_ERR_UNSUPPORTED;
+  }
   GAIB_CHECK(d_h && d_alpha_l && d_alpha_r && d_out && d_row_stats && d_out != d_h, "%s: NULL or aliased pointer", who);
   GAIB_CHECK(phase >= -1 && phase <= 1, "%s: phase is -1, 0 or 1", who);
   GAIB_HIP(hipSetDevice(ctx->device));
@@ -1534,6 +1542,12 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
                                        float epsilon, float* d_grad_out, float* d_alpha_lgrad, float* d_alpha_rgrad) {
   GAIB_CHECK(ctx && g, "gaib_gat_backward_fused: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_backward_fused", len, heads));
+  if (g->nv == 0) {  // no rows: the alpha gradients of this graph are zero, nothing else is written
+    GAIB_HIP(hipSetDevice(ctx->device));
+    if (d_alpha_lgrad) GAIB_HIP(hipMemsetAsync(d_alpha_lgrad, 0, sizeof(float) * len, ctx->stream));
+    if (d_alpha_rgrad) GAIB_HIP(hipMemsetAsync(d_alpha_rgrad, 0, sizeof(float) * len, ctx->stream));
+    return GAIB_OK;
+  }
   GAIB_CHECK(d_feat && d_grad && d_fwd_out && d_alpha_l && d_alpha_r && (d_norm_scores || d_row_stats) && d_grad_out &&
                  d_alpha_lgrad && d_alpha_rgrad, "gaib_gat_backward_fused: NULL pointer");
   GAIB_CHECK(d_grad_out != d_feat && d_grad_out != d_grad, "gaib_gat_backward_fused: d_grad_out must not alias an input");
@@ -1670,6 +1684,19 @@ extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int le
                                             float* d_alpha_rgrad, int phase) {
   GAIB_CHECK(ctx && g, "gaib_gat_backward_fused_rect: NULL ctx/graph");
   GAIB_TRY(check_heads("gaib_gat_backward_fused_rect", len, heads));
+  if (g->nv == 0) {  // a rank without rows: zero alpha gradients (they are summed over the ranks afterwards), nothing else
+    GAIB_CHECK(phase >= -1 && phase <= 1, "gaib_gat_backward_fused_rect: phase is -1, 0 or 1");
+    if (!(len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) && ctx->gat_fused_bwd != 0)) {
+      gaib_set_error("gaib_gat_backward_fused_rect: not applicable to this shape / graph (len %d, heads %d)", len, heads);
+      return GAIB_ERR_UNSUPPORTED;  // (the decision of the ranks WITH rows: shape and option alone, see the forward)
+    }
+    if (phase != 0) {
+      GAIB_HIP(hipSetDevice(ctx->device));
+      if (d_alpha_lgrad) GAIB_HIP(hipMemsetAsync(d_alpha_lgrad, 0, sizeof(float) * len, ctx->stream));
+      if (d_alpha_rgrad) GAIB_HIP(hipMemsetAsync(d_alpha_rgrad, 0, sizeof(float) * len, ctx->stream));
+    }
+    return GAIB_OK;
+  }
   GAIB_CHECK(d_feat_tab && d_grad_tab && d_rec_tab && d_alpha_l && d_alpha_r && d_grad_out && d_alpha_lgrad && d_alpha_rgrad,
              "gaib_gat_backward_fused_rect: NULL pointer");
   GAIB_CHECK(d_grad_out != d_feat_tab && d_grad_out != d_grad_tab, "gaib_gat_backward_fused_rect: d_grad_out must not alias an input");
@@ -1737,11 +1764,11 @@ extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int le
 extern "C" int gaib_gat_softmax_bwd_rows(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_norm_scores,
                                          const float* d_norm_scores_grad, const float* d_temp_scores, float epsilon,
                                          float* d_g_out, float* d_rs_out) {
-  GAIB_CHECK(ctx && g && d_norm_scores && d_norm_scores_grad && d_temp_scores && d_g_out && d_rs_out,
-             "gaib_gat_softmax_bwd_rows: NULL argument");
+  GAIB_CHECK(ctx && g, "gaib_gat_softmax_bwd_rows: NULL ctx/graph");
   GAIB_CHECK(heads >= 1, "gaib_gat_softmax_bwd_rows: heads must be >= 1");
+  if (g->nv == 0) return GAIB_OK;  // (a rank without rows: its per-edge arrays may be NULL)
+  GAIB_CHECK(d_norm_scores && d_norm_scores_grad && d_temp_scores && d_g_out && d_rs_out, "gaib_gat_softmax_bwd_rows: NULL argument");
   GAIB_HIP(hipSetDevice(ctx->device));
-  if (g->nv == 0) return GAIB_OK;
   const bool al16 = (((uintptr_t)d_norm_scores | (uintptr_t)d_norm_scores_grad | (uintptr_t)d_temp_scores |
                       (uintptr_t)d_g_out | (uintptr_t)d_rs_out) & 15) == 0;
   ProfScope ps(ctx, "gat_softmax_bwd_alpha");
@@ -1803,9 +1830,10 @@ __global__ __launch_bounds__(256) void edge_rowsum_kernel(int64_t nv, int H, con
 }
 
 extern "C" int gaib_edge_rowsum(gaib_ctx* ctx, gaib_graph* g, int heads, const float* d_in_e, float* d_out_rows) {
-  GAIB_CHECK(ctx && g && heads >= 1 && d_out_rows && (d_in_e || g->ne == 0), "gaib_edge_rowsum: bad argument");
+  GAIB_CHECK(ctx && g && heads >= 1, "gaib_edge_rowsum: bad argument");
+  if (g->nv == 0) return GAIB_OK;  // (a rank without rows: the arrays may be NULL)
+  GAIB_CHECK(d_out_rows && (d_in_e || g->ne == 0), "gaib_edge_rowsum: NULL pointer");
   GAIB_HIP(hipSetDevice(ctx->device));
-  if (g->nv == 0) return GAIB_OK;
   edge_rowsum_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, d_in_e, d_out_rows);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
@@ -1813,10 +1841,15 @@ extern "C" int gaib_edge_rowsum(gaib_ctx* ctx, gaib_graph* g, int heads, const f
 
 extern "C" int gaib_gat_alpha_grads(gaib_ctx* ctx, int64_t nv, int len, int heads, const float* d_x, const float* d_rs,
                                     const float* d_cs, float* d_alpha_lgrad, float* d_alpha_rgrad) {
-  GAIB_CHECK(ctx && d_x && d_rs && d_cs && d_alpha_lgrad && d_alpha_rgrad && nv >= 1,
-             "gaib_gat_alpha_grads: bad argument");
+  GAIB_CHECK(ctx && d_alpha_lgrad && d_alpha_rgrad && nv >= 0, "gaib_gat_alpha_grads: bad argument");
   GAIB_TRY(check_heads("gaib_gat_alpha_grads", len, heads));
   GAIB_HIP(hipSetDevice(ctx->device));
+  if (nv == 0) {  // no vertices (a rank without rows): both gradients are zero
+    GAIB_HIP(hipMemsetAsync(d_alpha_lgrad, 0, sizeof(float) * len, ctx->stream));
+    GAIB_HIP(hipMemsetAsync(d_alpha_rgrad, 0, sizeof(float) * len, ctx->stream));
+    return GAIB_OK;
+  }
+  GAIB_CHECK(d_x && d_rs && d_cs, "gaib_gat_alpha_grads: NULL pointer");
   const int nblocks = (int)(nv < 2048 ? cdiv64(nv, 8) : 1024);
   const int64_t rows_per_block = cdiv64(nv, nblocks);
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)nblocks * 2 * len));

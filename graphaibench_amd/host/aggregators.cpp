@@ -281,9 +281,11 @@ void GAT_Aggregator::d_aggregate_partition(int len, Graph& g, const float* grad_
   const int64_t ne = (int64_t)g.sizeEdges();
   gaib_graph *full = g.gat_full_graph(), *gt = g.gat_transposed_graph();
   const float* fwd = fwd_out;
+  const bool fwd_given = fwd_out_given;
   fwd_out = NULL;
+  fwd_out_given = false;
   ensure_partition_buffers(g, len);
-  if (part_fused_last && fwd) {
+  if (part_fused_last && fwd_given) {
     // the one-sweep backward on the rectangular graph: the owner of row i computes everything about i from i's own edge
     // list, given the halo vertices' h rows (d_ptab, from forward), grad rows and (rowdot, max, 1 / sum) records -- two
     // forward-direction exchanges, no transposed structure, no reverse exchange.  The chunks over owned columns run while
@@ -432,6 +434,7 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
                                            d_tbuf, d_alpha_lgrad, d_alpha_rgrad);
     if (rc == GAIB_OK) {
       fwd_out = NULL;
+      fwd_out_given = false;
       GAIB_OR_DIE(gaib_memcpy_d2d(C(), grad_out, d_tbuf, sizeof(float) * need));
       return;
     }
@@ -451,6 +454,7 @@ void GAT_Aggregator::d_aggregate(int len, Graph& g, const float* feat_in, const 
     // sum_e p_e dp_e == <grad_i, out_i> (out_i = sum_e p_e h_col; where relu cut out_i the gradient is 0 too)
     const float* fwd = fwd_out;
     fwd_out = NULL;
+    fwd_out_given = false;
     // the pass that walks rev anyway also leaves the transposed attention p[rev(e)] in d_norm_scores_t, so the
     // gradient aggregation reads its weights linearly
     if (d_temp_scores)

@@ -78,7 +78,7 @@ class GAT_Aggregator : public aggregator {
   int num_heads() const { return heads; }
   // extension: the next d_aggregate() may read the layer's forward output rows `out` (post-activation is fine as
   // long as grad_in went through the matching d_relu): it replaces the per-row sum_e p_e dp_e by <grad_i, out_i>
-  void use_forward_output_once(const float* out) { fwd_out = out; }
+  void use_forward_output_once(const float* out) { fwd_out = out; fwd_out_given = true; }
   // attention dropout (score_drop > 0) is applied while training only, like the layers' feature dropout; the layer
   // passes its phase on before every forward
   void set_training(bool on) { training = on; }
@@ -117,6 +117,7 @@ class GAT_Aggregator : public aggregator {
   float *d_alpha_l, *d_alpha_r, *d_alpha_lgrad, *d_alpha_rgrad;
   float *d_temp_scores, *d_norm_scores, *d_norm_scores_grad, *d_norm_scores_t;
   const float* fwd_out;  // see use_forward_output_once
+  bool fwd_out_given = false;  // ... was called (a rank WITHOUT rows passes NULL and must still take the path the others take)
   float* d_tbuf;         // output of the fused backward sweep (the layer aliases feat_in and grad_out)
   size_t tbuf_floats;
   // vertex-range partitions: the [owned | halo] column table, the transposed aggregation's output, padded row sums and

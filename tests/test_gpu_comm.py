@@ -360,6 +360,43 @@ def test_rccl_branch_exchange_and_reduce_with_growing_rows(tmp_path, world):
     assert all(r[1] == "ok" for r in res), res
 
 
+def _fewer_vertices_than_ranks(rank, world, idfile, q, transport_name):
+    """ranks WITHOUT rows (2 vertices on 3 ranks, 1 vertex on 3 ranks) take part in every exchange, reverse exchange and
+    all-reduce with empty buffers, take the SAME path (one sweep / staged) as the ranks with rows -- the choice follows
+    from the shape and the options alone -- and contribute zero gradients; plus a few larger cases through the same
+    checker (scripts/fuzz_partition.py::run_case: the layer against the fp64 GLOBAL evaluation)"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT / "scripts"))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "30"
+    os.environ["GAIB_FAKE_RCCL_TIMEOUT_S"] = "30"
+    try:
+        from fuzz_partition import run_case
+        from graphaibench_amd import capi, layers as L
+
+        transport = _transport(transport_name, capi)
+        ctx = L.init(0)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
+        L.set_comm(comm)
+        for n, avg in ((1, 0.0), (2, 4.0), (3, 0.7), (5, 4.0), (300, 6.0)):
+            for arch, d, heads in (("gcn", 64, 1), ("gcn", 16, 1), ("sage", 64, 1), ("gat", 64, 8), ("gat", 64, 1), ("gat", 128, 4),
+                                   ("gat", 16, 2)):
+                cfg = dict(n=n, avg=avg, hub=0, gseed=1234 + n, arch=arch, din=48, d=d, heads=heads)
+                run_case(comm, rank, world, cfg)
+        comm.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("transport_name", ["ipc", "fake-rccl"])
+def test_ranks_without_rows_follow_the_others(tmp_path, transport_name):
+    res = _spawn(3, _fewer_vertices_than_ranks, (str(tmp_path / "id"), transport_name), timeout=300)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def _double_is_strict(rank, world, idfile, q):
     """the double itself, through its C entry points: what it must REFUSE"""
     import ctypes
