@@ -85,6 +85,13 @@ def run_case(comm, rank, world, cfg):
         y, go64, wg, lg64, rg64, t, mag = fp64_layer(rowptr, col, x, W, al, ar, gin, heads, False)
         want = dict(out=y, grad_out=go64, W_grad=wg, alpha_l=lg64, alpha_r=rg64)
         sums["alpha_l"], sums["alpha_r"] = layer.tensor(L.ALPHA_LGRAD, (d,)), layer.tensor(L.ALPHA_RGRAD, (d,))
+        # a score within rounding of zero makes leaky_relu' a coin flip between two correct fp32 evaluations (and fp64): the
+        # gradients that go through it are then not compared (scripts/fuzz_gat_layer.py does the same; the tests impose the
+        # GPU's own signs on the fp64 evaluation instead, tests/test_gpu_fullsize.py)
+        if bool((t.abs() < 1e-5 * t.abs().max()).any()):
+            for k in ("alpha_l", "alpha_r"):
+                want.pop(k)
+                sums.pop(k)
     for name, tns in sums.items():  # gradients of replicated parameters: the sum over the ranks
         tns = tns.contiguous()
         comm.allreduce(tns)
@@ -93,7 +100,7 @@ def run_case(comm, rank, world, cfg):
         ref = want[name][lo:hi] if name in ("out", "grad_out") else want[name]
         scale = max(float(want[name].abs().max()), 1e-30)
         if name.startswith("alpha"):
-            scale = max(float(want["alpha_l"].abs().max()), float(want["alpha_r"].abs().max()), 1e-2 * mag)
+            scale = max(float(lg64.abs().max()), float(rg64.abs().max()), 1e-2 * mag)
         if not torch.isfinite(gv).all():
             raise AssertionError(f"{name}: non-finite")
         e = float((gv.double() - ref).abs().max()) / scale if gv.numel() else 0.0
