@@ -283,7 +283,11 @@ int gaib_gat_score_signs(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const
  * rows are still arriving: it reads owned rows only); 1 = the remaining chunks + the per-row combination (phase 0's
  * partial results wait in the context's workspace: no other call on the context in between).  The alpha gradients cover
  * the owned rows; the caller sums them over the ranks.  Same shape cover as gaib_gat_backward_fused (len == 64; 1, 2, 4,
- * 8 or 16 heads; options gat_fused_fwd / gat_fused_bwd = 0 switch them off), else GAIB_ERR_UNSUPPORTED. */
+ * 8 or 16 heads; options gat_fused_fwd / gat_fused_bwd = 0 switch them off), else GAIB_ERR_UNSUPPORTED.
+ * A graph WITHOUT rows (a rank of a partition with fewer vertices than ranks) is accepted with NULL buffers: the answer --
+ * GAIB_OK or GAIB_ERR_UNSUPPORTED -- then follows from len, heads and the option alone, i.e. it is what the ranks that do have
+ * rows get (the two paths differ in their halo exchanges: all ranks must take the same one), nothing is written except zero
+ * alpha gradients. */
 int gaib_gat_forward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_tab, const float* d_alpha_l,
                                 const float* d_alpha_r, float epsilon, int relu, float* d_out, float* d_row_stats, int phase);
 int gaib_gat_backward_rec(gaib_ctx* ctx, int64_t nv, int len, int heads, const float* d_grad, const float* d_fwd_out,
