@@ -225,6 +225,38 @@ def _gat_worker(rank, world, idfile, q, heads, mode="fused", transport_name="ipc
             comm.allreduce(t)
             assert_close(t.cpu().numpy().reshape(shape), want_g, name, floor=LONG_SUM_FLOOR)
         comm.barrier()
+        # the GAT structures of a partition (the [owned | halo] graph, its transpose, the edge permutation), the aggregator's
+        # partition tables and per-edge arrays go back with LearningGraph::dealloc / GAT_Aggregator::release
+        def free_now():
+            L.sync()
+            comm.barrier()
+            f = torch.cuda.mem_get_info()[0]
+            comm.barrier()
+            return f
+
+        def build_use_close():
+            lg2 = part.make_graph(comm)
+            l2 = L.Layer(L.GAT, 1, hi - lo, din, d, lg2, True)
+            if heads > 1:
+                l2.set_heads(heads)
+            l2.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+            l2.forward(out)
+            l2.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
+            l2.backward(out, grad_out)
+            L.sync()
+            l2.close()
+            lg2.close()
+
+        build_use_close()
+        base = free_now()
+        for _ in range(3):
+            build_use_close()
+        lost, tries = comm.allreduce_host([float(base - free_now())])[0] / world, 0
+        while lost > (4 << 20) * world and tries < 12:  # (see _worker: a peer's freed memory can come back a little later)
+            time.sleep(0.25)
+            lost, tries = comm.allreduce_host([float(base - free_now())])[0] / world, tries + 1
+        assert lost <= (4 << 20) * world, f"{lost / 2**20:.1f} MiB of the device not returned by {world} ranks"
+        comm.barrier()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
