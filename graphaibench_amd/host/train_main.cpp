@@ -202,6 +202,77 @@ struct Trainer {
     }
   }
 
+  // GAIB_REORDER=bfs|degree (extension; the reference keeps the file's numbering, reader.cpp:414-457): the dataset under the
+  // vertex numbering gaib_graph_reorder computes from the graph alone -- breadth-first levels from the highest-degree vertex,
+  // or hubs first -- for files whose numbering has no locality.  Everything that is indexed by vertex is
+  // permuted with it on the host, once: rows (columns relabelled and sorted again, so that every later step sees an ordinary
+  // dataset), features, labels, masks -- inside each interval between the boundaries of the train / val / test ranges, which
+  // therefore keep their vertex sets (see below).  Every rank does the same.
+  void relabel(const char* how, std::vector<float>& feats, std::vector<label_t>& labels, std::vector<mask_t>& mtrain,
+               std::vector<mask_t>& mval, std::vector<mask_t>& mtest) {
+    const std::string m(how);
+    if (m != "bfs" && m != "degree") {
+      std::cerr << "GAIB_REORDER=" << m << ": bfs or degree\n";
+      exit(EXIT_FAILURE);
+    }
+    const size_t n = graph->size(), ne = graph->sizeEdges();
+    gaib_ctx* c = gpu_context::get();
+    gaib_graph *g0 = nullptr, *g1 = nullptr;
+    GAIB_OR_DIE(gaib_graph_create(c, (int64_t)n, (int64_t)ne, graph->row_start_host_ptr(), 32, graph->edge_dst_host_ptr(), 0, &g0));
+    int64_t *d_no = nullptr, *d_on = nullptr;
+    GAIB_OR_DIE(gaib_malloc(c, sizeof(int64_t) * n, (void**)&d_no));
+    GAIB_OR_DIE(gaib_malloc(c, sizeof(int64_t) * n, (void**)&d_on));
+    GAIB_OR_DIE(gaib_graph_reorder(c, g0, m == "bfs" ? GAIB_ORDER_BFS : GAIB_ORDER_DEGREE, &g1, d_no, d_on));
+    std::vector<int64_t> no(n), on(n);
+    GAIB_OR_DIE(gaib_memcpy_d2h(c, no.data(), d_no, sizeof(int64_t) * n));
+    GAIB_OR_DIE(gaib_memcpy_d2h(c, on.data(), d_on, sizeof(int64_t) * n));
+    GAIB_OR_DIE(gaib_free(c, d_no));
+    GAIB_OR_DIE(gaib_free(c, d_on));
+    GAIB_OR_DIE(gaib_graph_destroy(g0));
+    GAIB_OR_DIE(gaib_graph_destroy(g1));
+    // The loss layers divide by (end - begin) of the split's RANGE (softmax_loss_layer.cpp:31, quirk Q8), so the ranges
+    // must keep their vertex sets: the new order is applied INSIDE each interval between two range boundaries (train / val /
+    // test vertices stay where the file put them as a set; a dataset whose three ranges are all [0, n) is relabelled whole)
+    {
+      std::vector<size_t> cuts = {0, n, train_begin, train_end, val_begin, val_end, test_begin, test_end};
+      for (auto& c2 : cuts) c2 = std::min(c2, n);
+      std::sort(cuts.begin(), cuts.end());
+      cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+      std::vector<int64_t> on2(n);
+      for (size_t s2 = 0; s2 + 1 < cuts.size(); s2++) {
+        const size_t a = cuts[s2], b = cuts[s2 + 1];
+        for (size_t v = a; v < b; v++) on2[v] = (int64_t)v;
+        std::sort(on2.begin() + a, on2.begin() + b, [&](int64_t x, int64_t y) { return no[x] < no[y]; });
+      }
+      on.swap(on2);
+      for (size_t k = 0; k < n; k++) no[on[k]] = (int64_t)k;
+    }
+    index_t* rp = graph->row_start_host_ptr();
+    index_t* ci = graph->edge_dst_host_ptr();
+    std::vector<index_t> rp2(n + 1, 0), ci2(ne);
+    for (size_t k = 0; k < n; k++) rp2[k + 1] = rp2[k] + (rp[on[k] + 1] - rp[on[k]]);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t k = 0; k < n; k++) {
+      const size_t v = (size_t)on[k];
+      index_t* dst = ci2.data() + rp2[k];
+      const size_t deg = rp[v + 1] - rp[v];
+      for (size_t e = 0; e < deg; e++) dst[e] = (index_t)no[ci[rp[v] + e]];
+      std::sort(dst, dst + deg);
+    }
+    std::copy(rp2.begin(), rp2.end(), rp);
+    std::copy(ci2.begin(), ci2.end(), ci);
+    auto rows = [&](auto& vec, size_t width) {
+      typename std::remove_reference<decltype(vec)>::type out(vec.size());
+      for (size_t k = 0; k < n; k++) std::copy(vec.begin() + (size_t)on[k] * width, vec.begin() + ((size_t)on[k] + 1) * width, out.begin() + k * width);
+      vec.swap(out);
+    };
+    rows(feats, (size_t)dim_init);
+    rows(labels, label_width);
+    rows(mtrain, 1), rows(mval, 1), rows(mtest, 1);
+    graph->degree_counting();
+    if (root()) std::cout << "GAIB_REORDER=" << m << ": vertices relabelled (" << n << " vertices, " << ne << " edges)\n";
+  }
+
   void load() {
     graph = new Graph(true);
     Reader reader(dataset);
@@ -228,6 +299,8 @@ struct Trainer {
       std::cerr << "dataset has no features (feat_len = 0 in graph.meta.txt)\n";
       exit(1);
     }
+    if (const char* ro = getenv("GAIB_REORDER"))
+      if (*ro && std::string(ro) != "0") relabel(ro, feats, labels, mtrain, mval, mtest);
     g_train_begin = train_begin, g_train_end = train_end;
     g_val_begin = val_begin, g_val_end = val_end;
     g_test_begin = test_begin, g_test_end = test_end;

@@ -263,6 +263,39 @@ def test_driver_ranks_over_the_rccl_branch(tmp_path, arch, world):
         assert abs(float(gl) - float(wl)) <= 2e-3 and abs(float(ga) - float(wa)) <= 0.01, (got, want)
 
 
+@pytest.mark.parametrize("arch,how,world", [("gcn", "bfs", 1), ("sage", "degree", 1), ("gat", "bfs", 1), ("gcn", "degree", 2)])
+def test_driver_reordered_dataset_trains_the_same(tmp_path, arch, how, world):
+    """GAIB_REORDER=bfs|degree: the trainer relabels the dataset once on the host with the numbering gaib_graph_reorder
+    computes (rows, features, labels, masks) -- the same model on the same graph, so the loss curve and the accuracies are
+    the plain run's up to fp32 summation order, on one rank and on a partition"""
+    root, x, labels, splits = make_dataset(tmp_path)
+    exe = ROOT / "bin" / f"gpu_train_{arch}"
+    cmd = [str(exe), "cora", "6", "2", "softmax", "16", "0", "0", "0.01", "2", "0", "3", "0"]
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GAIB_RANK", "GAIB_WORLD",
+                                                                "GAIB_COMM", "GAIB_DEVICE", "GAIB_COMM_ID_FILE", "GAIB_REORDER")}
+    base = dict(clean, DATASET_PATH=root, GAIB_COMM_TIMEOUT_S="60")
+    if world > 1:
+        base["GAIB_RANKS"] = str(world)
+    plain = subprocess.run(cmd, capture_output=True, text=True, env=base, timeout=600)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-2000:]
+    re_run = subprocess.run(cmd, capture_output=True, text=True, env=dict(base, GAIB_REORDER=how), timeout=600)
+    assert re_run.returncode == 0, re_run.stdout[-2000:] + re_run.stderr[-2000:]
+    assert f"GAIB_REORDER={how}: vertices relabelled" in re_run.stdout
+    pat = r"train_loss ([0-9.]+) train_acc ([0-9.]+)"
+    want, got = re.findall(pat, plain.stdout), re.findall(pat, re_run.stdout)
+    assert len(want) == 6 == len(got)
+    for (wl, wa), (gl, ga) in zip(want, got):
+        assert abs(float(wl) - float(gl)) <= 2e-3 and abs(float(wa) - float(ga)) <= 0.01, (want, got)
+    pv = r"val_acc ([0-9.]+)"
+    assert len(re.findall(pv, plain.stdout)) == len(re.findall(pv, re_run.stdout)) > 0
+    for wa, ga in zip(re.findall(pv, plain.stdout), re.findall(pv, re_run.stdout)):
+        assert abs(float(wa) - float(ga)) <= 0.01
+    pt = r"Test accuracy: ([0-9.]+)"
+    assert abs(float(re.search(pt, plain.stdout).group(1)) - float(re.search(pt, re_run.stdout).group(1))) <= 0.01
+    bad = subprocess.run(cmd, capture_output=True, text=True, env=dict(base, GAIB_REORDER="metis"), timeout=120)
+    assert bad.returncode != 0 and "bfs or degree" in bad.stderr
+
+
 def torch_device_count() -> int:
     import torch
 
