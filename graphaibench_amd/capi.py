@@ -146,7 +146,7 @@ class GaibError(RuntimeError):
 
 
 COMM_RCCL, COMM_IPC = 0, 1
-ORDER_DEGREE, ORDER_BFS = 1, 2
+ORDER_DEGREE, ORDER_BFS, ORDER_CM = 1, 2, 3
 COMM_ID_BYTES = 128
 
 

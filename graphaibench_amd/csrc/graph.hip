@@ -689,6 +689,8 @@ int gaib_graph_ensure_chunks(gaib_ctx* ctx, gaib_graph* g) {
 //   GAIB_ORDER_DEGREE     hubs first: vertices by descending degree (stable in the old id)
 //   GAIB_ORDER_BFS        breadth-first levels from the highest-degree vertex, inside a level by old id; vertices the
 //                         search does not reach keep their relative order at the end
+//   GAIB_ORDER_CM         the same levels, inside a level by the position of the first parent (Cuthill-McKee): children of
+//                         one vertex, and of neighbouring vertices, become neighbours -- what meshes / road-like graphs want
 // The caller permutes feature rows with gaib_gather_rows(old_of_new) and un-permutes outputs with
 // gaib_gather_rows(new_of_old).
 __global__ void degree_key_kernel(int64_t nv, const int64_t* rowptr, uint32_t maxdeg, uint32_t* key) {
@@ -720,6 +722,33 @@ __global__ void argmax_degree_kernel(int64_t nv, const int64_t* rowptr, unsigned
   const unsigned long long k = ((unsigned long long)(rowptr[v + 1] - rowptr[v]) << 32) | (0xffffffffu - (uint32_t)v);
   atomicMax(best, k);
 }
+// Cuthill-McKee inside the breadth-first levels (GAIB_ORDER_CM): a vertex of level L sorts by the POSITION of its first parent
+// (the smallest new position among its neighbours of level L - 1), so the children of one vertex -- and of neighbouring
+// vertices -- become neighbours in the numbering.  One wave per vertex of the level's segment.
+__global__ __launch_bounds__(256) void cm_key_kernel(int64_t seg_begin, int64_t seg_count, const uint32_t* order,
+                                                     const int64_t* rowptr, const uint32_t* col, const uint32_t* level,
+                                                     uint32_t L, const uint32_t* pos, uint32_t* key) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= seg_count) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t v = order[seg_begin + i];
+  uint32_t best = 0xffffffffu;
+  for (int64_t e = rowptr[v] + lane; e < rowptr[v + 1]; e += 64) {
+    const uint32_t c = col[e];
+    if (level[c] + 1 == L) best = min(best, pos[c]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+  if (lane == 0) key[i] = best;
+}
+__global__ void set_pos_kernel(int64_t seg_begin, int64_t seg_count, const uint32_t* order, uint32_t* pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < seg_count) pos[order[seg_begin + i]] = (uint32_t)(seg_begin + i);
+}
+__global__ void level_hist_kernel(int64_t nv, const uint32_t* level, uint32_t nlevels, unsigned* hist) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < nv) atomicAdd(&hist[min(level[v], nlevels - 1)], 1u);
+}
 __global__ void invert_order_kernel(int64_t nv, const uint32_t* old_of_new, int64_t* new_of_old, int64_t* old_of_new64,
                                     const int64_t* rowptr, int64_t* deg_new) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -744,7 +773,8 @@ extern "C" int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib
                                   int64_t* d_old_of_new) {
   GAIB_CHECK(ctx && g && out && d_new_of_old, "gaib_graph_reorder: NULL argument");
   GAIB_CHECK(g->nc == g->nv, "gaib_graph_reorder: square graphs only");
-  GAIB_CHECK(method == GAIB_ORDER_DEGREE || method == GAIB_ORDER_BFS, "gaib_graph_reorder: unknown method %d", method);
+  GAIB_CHECK(method == GAIB_ORDER_DEGREE || method == GAIB_ORDER_BFS || method == GAIB_ORDER_CM,
+             "gaib_graph_reorder: unknown method %d", method);
   GAIB_CHECK(g->nv < ((int64_t)1 << 31), "gaib_graph_reorder: more than 2^31 vertices");
   GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_graph_reorder");
   GAIB_HIP(hipSetDevice(ctx->device));
@@ -783,6 +813,7 @@ extern "C" int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib
   GAIB_HIP(hipStreamSynchronize(st));
   const uint32_t maxdeg = (uint32_t)(best >> 32), hub = 0xffffffffu - (uint32_t)(best & 0xffffffffu);
   int key_bits = 32;
+  uint32_t cm_levels = 0;
   if (method == GAIB_ORDER_DEGREE) {
     degree_key_kernel<<<grid1d(nv, 256), 256, 0, st>>>(nv, g->rowptr, maxdeg, key);
     GAIB_LAUNCH_CHECK();
@@ -804,6 +835,7 @@ extern "C" int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib
     }
     cap_level_kernel<<<grid1d(nv, 256), 256, 0, st>>>(nv, cur + 1, key);  // unreached vertices: after the last level
     GAIB_LAUNCH_CHECK();
+    cm_levels = cur;
     key_bits = 1;
     while (key_bits < 32 && ((cur + 1) >> key_bits)) ++key_bits;
   }
@@ -814,6 +846,43 @@ extern "C" int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib
   void* tmp = nullptr;
   GAIB_TRY(bufs.get(&tmp, tmp_bytes));
   GAIB_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key, key2, ids, order, (int)nv, 0, key_bits, st));  // stable
+  if (method == GAIB_ORDER_CM && nv > 1) {
+    // level by level, in order: the positions of level L - 1 are final when level L is keyed.  `order` holds the vertices by
+    // (level, old id): a level is a contiguous segment of it; a segment is re-sorted by its keys (stable: ties keep the old id
+    // order) and its positions are published before the next level reads them.  The unreached vertices (last segment) stay.
+    const uint32_t nlevels = cm_levels + 2;  // levels 0 .. cm_levels, + the capped "unreached" level
+    unsigned* hist = nullptr;
+    uint32_t *pos = nullptr, *seg_key = nullptr, *seg_key2 = nullptr, *seg_ord2 = nullptr;
+    GAIB_TRY(bufs.get((void**)&hist, sizeof(unsigned) * nlevels));
+    GAIB_TRY(bufs.get((void**)&pos, sizeof(uint32_t) * nv));
+    GAIB_TRY(bufs.get((void**)&seg_key, sizeof(uint32_t) * nv));
+    GAIB_TRY(bufs.get((void**)&seg_key2, sizeof(uint32_t) * nv));
+    GAIB_TRY(bufs.get((void**)&seg_ord2, sizeof(uint32_t) * nv));
+    GAIB_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * nlevels, st));
+    level_hist_kernel<<<grid1d(nv, 256), 256, 0, st>>>(nv, key, nlevels, hist);
+    GAIB_LAUNCH_CHECK();
+    std::vector<unsigned> h_hist(nlevels);
+    GAIB_HIP(hipMemcpyAsync(h_hist.data(), hist, sizeof(unsigned) * nlevels, hipMemcpyDeviceToHost, st));
+    GAIB_HIP(hipStreamSynchronize(st));
+    set_pos_kernel<<<grid1d(nv, 256), 256, 0, st>>>(0, nv, order, pos);  // the (level, id) order to start from
+    GAIB_LAUNCH_CHECK();
+    int64_t seg_begin = h_hist[0];
+    for (uint32_t L = 1; L <= cm_levels; ++L) {
+      const int64_t cnt = h_hist[L];
+      if (cnt > 1) {
+        cm_key_kernel<<<grid1d(cnt, 4), 256, 0, st>>>(seg_begin, cnt, order, g->rowptr, g->colidx, key, L, pos, seg_key);
+        GAIB_LAUNCH_CHECK();
+        size_t need = 0;
+        GAIB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, seg_key, seg_key2, order + seg_begin, seg_ord2, (int)cnt, 0, 32, st));
+        GAIB_CHECK(need <= tmp_bytes, "gaib_graph_reorder: sort workspace");
+        GAIB_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, need, seg_key, seg_key2, order + seg_begin, seg_ord2, (int)cnt, 0, 32, st));
+        GAIB_HIP(hipMemcpyAsync(order + seg_begin, seg_ord2, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, st));
+        set_pos_kernel<<<grid1d(cnt, 256), 256, 0, st>>>(seg_begin, cnt, order, pos);
+        GAIB_LAUNCH_CHECK();
+      }
+      seg_begin += cnt;
+    }
+  }
   invert_order_kernel<<<grid1d(nv, 256), 256, 0, st>>>(nv, order, d_new_of_old, d_old_of_new, g->rowptr, deg_new);
   GAIB_LAUNCH_CHECK();
   gaib_graph* r = nullptr;

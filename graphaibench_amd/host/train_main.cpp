@@ -202,17 +202,17 @@ struct Trainer {
     }
   }
 
-  // GAIB_REORDER=bfs|degree (extension; the reference keeps the file's numbering, reader.cpp:414-457): the dataset under the
-  // vertex numbering gaib_graph_reorder computes from the graph alone -- breadth-first levels from the highest-degree vertex,
-  // or hubs first -- for files whose numbering has no locality.  Everything that is indexed by vertex is
+  // GAIB_REORDER=cm|bfs|degree (extension; the reference keeps the file's numbering, reader.cpp:414-457): the dataset under the
+  // vertex numbering gaib_graph_reorder computes from the graph alone -- Cuthill-McKee / plain breadth-first levels from the
+  // highest-degree vertex, or hubs first -- for files whose numbering has no locality.  Everything that is indexed by vertex is
   // permuted with it on the host, once: rows (columns relabelled and sorted again, so that every later step sees an ordinary
   // dataset), features, labels, masks -- inside each interval between the boundaries of the train / val / test ranges, which
   // therefore keep their vertex sets (see below).  Every rank does the same.
   void relabel(const char* how, std::vector<float>& feats, std::vector<label_t>& labels, std::vector<mask_t>& mtrain,
                std::vector<mask_t>& mval, std::vector<mask_t>& mtest) {
     const std::string m(how);
-    if (m != "bfs" && m != "degree") {
-      std::cerr << "GAIB_REORDER=" << m << ": bfs or degree\n";
+    if (m != "bfs" && m != "degree" && m != "cm") {
+      std::cerr << "GAIB_REORDER=" << m << ": cm, bfs or degree\n";
       exit(EXIT_FAILURE);
     }
     const size_t n = graph->size(), ne = graph->sizeEdges();
@@ -222,7 +222,7 @@ struct Trainer {
     int64_t *d_no = nullptr, *d_on = nullptr;
     GAIB_OR_DIE(gaib_malloc(c, sizeof(int64_t) * n, (void**)&d_no));
     GAIB_OR_DIE(gaib_malloc(c, sizeof(int64_t) * n, (void**)&d_on));
-    GAIB_OR_DIE(gaib_graph_reorder(c, g0, m == "bfs" ? GAIB_ORDER_BFS : GAIB_ORDER_DEGREE, &g1, d_no, d_on));
+    GAIB_OR_DIE(gaib_graph_reorder(c, g0, m == "cm" ? GAIB_ORDER_CM : (m == "bfs" ? GAIB_ORDER_BFS : GAIB_ORDER_DEGREE), &g1, d_no, d_on));
     std::vector<int64_t> no(n), on(n);
     GAIB_OR_DIE(gaib_memcpy_d2h(c, no.data(), d_no, sizeof(int64_t) * n));
     GAIB_OR_DIE(gaib_memcpy_d2h(c, on.data(), d_on, sizeof(int64_t) * n));

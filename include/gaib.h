@@ -133,7 +133,8 @@ int gaib_graph_destroy(gaib_graph* g);
 /* LearningGraph::add_selfloop (lgraph.h:185-218) as a device-side rebuild. */
 int gaib_graph_add_selfloop(gaib_ctx* ctx, const gaib_graph* g, gaib_graph** out);
 /* Opt-in relabelling: the same graph under a new vertex numbering computed on the device from the graph alone
- * (GAIB_ORDER_DEGREE: hubs first; GAIB_ORDER_BFS: breadth-first levels from the highest-degree vertex).  A numbering with
+ * (GAIB_ORDER_DEGREE: hubs first; GAIB_ORDER_BFS: breadth-first levels from the highest-degree vertex; GAIB_ORDER_CM:
+ * Cuthill-McKee inside those levels).  A numbering with
  * locality is worth up to 1.2-1.6x to the aggregation; the library never relabels on its own.  Every
  * row keeps the ORDER of its edges, so aggregation outputs are bit-identical once un-permuted.
  *   d_new_of_old [nv] (required), d_old_of_new [nv] (may be NULL): int64 device arrays the call fills.
@@ -142,6 +143,7 @@ int gaib_graph_add_selfloop(gaib_ctx* ctx, const gaib_graph* g, gaib_graph** out
  * The reference has no counterpart (its reader keeps the file's numbering, reader.cpp:414-457). */
 #define GAIB_ORDER_DEGREE 1
 #define GAIB_ORDER_BFS 2
+#define GAIB_ORDER_CM 3 /* the BFS levels, inside a level by the position of the first parent (Cuthill-McKee) */
 int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib_graph** out, int64_t* d_new_of_old,
                        int64_t* d_old_of_new);
 int64_t gaib_graph_nv(const gaib_graph* g);

@@ -60,7 +60,7 @@ def main():
                 n = int(rng.choice([1, 2, 9, 300, 5000, 40000]))
                 avg = float(rng.choice([0.0, 0.6, 3, 20]))
                 hub = int(rng.choice([0, 2500])) if n >= 5000 else 0
-                method = int(rng.choice([capi.ORDER_DEGREE, capi.ORDER_BFS]))
+                method = int(rng.choice([capi.ORDER_DEGREE, capi.ORDER_BFS, capi.ORDER_CM]))
                 gseed = int(rng.integers(1 << 30))
                 cfg.update(n=n, avg=avg, hub=hub, method=method, gseed=gseed)
                 rp, ci = random_graph(n, avg, seed=gseed, power_law=bool(gseed & 1), hub_deg=hub)

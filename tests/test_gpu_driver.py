@@ -263,9 +263,9 @@ def test_driver_ranks_over_the_rccl_branch(tmp_path, arch, world):
         assert abs(float(gl) - float(wl)) <= 2e-3 and abs(float(ga) - float(wa)) <= 0.01, (got, want)
 
 
-@pytest.mark.parametrize("arch,how,world", [("gcn", "bfs", 1), ("sage", "degree", 1), ("gat", "bfs", 1), ("gcn", "degree", 2)])
+@pytest.mark.parametrize("arch,how,world", [("gcn", "cm", 1), ("sage", "degree", 1), ("gat", "bfs", 1), ("gcn", "cm", 2)])
 def test_driver_reordered_dataset_trains_the_same(tmp_path, arch, how, world):
-    """GAIB_REORDER=bfs|degree: the trainer relabels the dataset once on the host with the numbering gaib_graph_reorder
+    """GAIB_REORDER=cm|bfs|degree: the trainer relabels the dataset once on the host with the numbering gaib_graph_reorder
     computes (rows, features, labels, masks) -- the same model on the same graph, so the loss curve and the accuracies are
     the plain run's up to fp32 summation order, on one rank and on a partition"""
     root, x, labels, splits = make_dataset(tmp_path)
@@ -293,7 +293,7 @@ def test_driver_reordered_dataset_trains_the_same(tmp_path, arch, how, world):
     pt = r"Test accuracy: ([0-9.]+)"
     assert abs(float(re.search(pt, plain.stdout).group(1)) - float(re.search(pt, re_run.stdout).group(1))) <= 0.01
     bad = subprocess.run(cmd, capture_output=True, text=True, env=dict(base, GAIB_REORDER="metis"), timeout=120)
-    assert bad.returncode != 0 and "bfs or degree" in bad.stderr
+    assert bad.returncode != 0 and "cm, bfs or degree" in bad.stderr
 
 
 def torch_device_count() -> int:

@@ -1178,7 +1178,7 @@ def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
     assert_close(y.cpu().numpy(), y_w)
 
 
-@pytest.mark.parametrize("method", ["degree", "bfs"])
+@pytest.mark.parametrize("method", ["degree", "bfs", "cm"])
 def test_graph_reorder_keeps_every_row_bit_identical(ctx, method):
     """gaib_graph_reorder (opt-in relabelling computed on the device): a permutation; hubs-first is by descending degree,
     BFS by the distance from the highest-degree vertex (against scipy), unreached vertices last; the relabelled graph is
@@ -1197,11 +1197,12 @@ def test_graph_reorder_keeps_every_row_bit_identical(ctx, method):
     rp, ci = csr_from_pairs(20000, src, dst)
     g = ctx.graph(rp, ci.view(np.int32)).add_selfloop()
     n = g.nv
-    r, new_of_old, old_of_new = g.reorder(capi.ORDER_DEGREE if method == "degree" else capi.ORDER_BFS)
+    r, new_of_old, old_of_new = g.reorder({"degree": capi.ORDER_DEGREE, "bfs": capi.ORDER_BFS, "cm": capi.ORDER_CM}[method])
     assert r.nv == n and r.ne == g.ne
     no, on = new_of_old.cpu().numpy(), old_of_new.cpu().numpy()
     assert np.array_equal(np.sort(no), np.arange(n)) and np.array_equal(no[on], np.arange(n))
     deg = np.diff(g.rowptr().cpu().numpy())
+    rp_all, ci_all = g.rowptr().cpu().numpy(), g.colidx().cpu().numpy().view(np.uint32).astype(np.int64)
     if method == "degree":
         d_new = deg[on]
         assert np.all(d_new[:-1] >= d_new[1:])
@@ -1216,7 +1217,19 @@ def test_graph_reorder_keeps_every_row_bit_identical(ctx, method):
         assert np.all(l_new[:-1] <= l_new[1:]) and on[0] == hub
         assert set(on[-10:]) == set(range(19990, 20000))  # the unreached component last
         same = l_new[:-1] == l_new[1:]
-        assert np.all(on[:-1][same] < on[1:][same])
+        if method == "bfs":
+            assert np.all(on[:-1][same] < on[1:][same])
+        else:  # Cuthill-McKee: inside a level by the new position of the first parent, ties by the old id
+            first_parent = np.full(n, np.iinfo(np.int64).max)
+            rows_o = np.repeat(np.arange(n), np.diff(rp_all))
+            par = lvl[ci_all] + 1 == lvl[rows_o]  # edges (v -> c) with c one level up
+            np.minimum.at(first_parent, rows_o[par], no[ci_all[par]])
+            fp_new = first_parent[on]
+            reached = l_new < lvl.max()  # (the unreached clique sits on the capped last level and keeps its id order)
+            inside = same & reached[:-1] & reached[1:] & (l_new[:-1] >= 1)
+            assert np.all(fp_new[:-1][inside] <= fp_new[1:][inside])
+            ties = inside & (fp_new[:-1] == fp_new[1:])
+            assert np.all(on[:-1][ties] < on[1:][ties])
     # the relabelled rows: row new(v) lists new(c) for the columns c of old row v, in the same order
     rp_o, ci_o = g.rowptr().cpu().numpy(), g.colidx().cpu().numpy().view(np.uint32)
     rp_n, ci_n = r.rowptr().cpu().numpy(), r.colidx().cpu().numpy().view(np.uint32)
