@@ -1,5 +1,5 @@
 """Randomised sweep of the row movers and of the relabelling: gaib_gather_rows / gaib_gather_scatter_rows (the halo pack) over
-widths 1 .. 300, empty and repeated index lists, and gaib_graph_reorder (degree / BFS order) on random graphs -- one vertex,
+widths 1 .. 300, empty and repeated index lists, and gaib_graph_reorder (degree / BFS / Cuthill-McKee order) on random graphs -- one vertex,
 isolated vertices, several components, hubs -- checked for: a permutation, its inverse, rows that keep their edge order,
 and aggregations that are BIT-identical once un-permuted.
     python scripts/fuzz_rows_and_order.py [--seconds 90] [--seed 0]
