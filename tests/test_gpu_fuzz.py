@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
     ("fuzz_aggregation.py", []),
     ("fuzz_sgemm.py", []),
     ("fuzz_gat_layer.py", []),
+    ("fuzz_layers.py", []),
     ("fuzz_rows_and_order.py", []),
     ("fuzz_partition.py", ["--world", "3"]),
     ("fuzz_partition.py", ["--world", "2", "--transport", "fake-rccl"]),
