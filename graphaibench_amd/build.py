@@ -21,7 +21,7 @@ INCLUDE = ROOT / "include"
 ORACLE = ROOT / "oracle"
 REFERENCE = Path("/root/reference")
 
-HIP_SOURCES = ["runtime.hip", "graph.hip", "spmm.hip", "gat.hip", "sgemm.hip", "elementwise.hip", "probe.hip", "comm.hip"]
+HIP_SOURCES = ["runtime.hip", "graph.hip", "spmm.hip", "spmm_part.hip", "gat.hip", "sgemm.hip", "elementwise.hip", "probe.hip", "comm.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -59,7 +59,7 @@ def build_hip(force: bool = False) -> Path:
     LIB.mkdir(exist_ok=True)
     out = LIB / "libgaib_hip.so"
     hipcc = _hipcc()
-    headers = [CSRC / "common.h", CSRC / "spmm_core.h", INCLUDE / "gaib.h"]
+    headers = [CSRC / "common.h", CSRC / "spmm_core.h", CSRC / "spmm_kernels.h", INCLUDE / "gaib.h"]
     objs, jobs = [], []
     for src in HIP_SOURCES:
         s = CSRC / src

@@ -58,6 +58,7 @@ SIGNATURES = {
     "gaib_graph_add_selfloop": (_i, [_vp, _vp, _pp]),
     "gaib_graph_nv": (_i64, [_vp]),
     "gaib_graph_ne": (_i64, [_vp]),
+    "gaib_graph_nc": (_i64, [_vp]),
     "gaib_graph_rowptr": (_vp, [_vp]),
     "gaib_graph_colidx": (_vp, [_vp]),
     "gaib_graph_compute_vertex_data": (_i, [_vp, _vp]),
@@ -72,6 +73,12 @@ SIGNATURES = {
     "gaib_spmm_gemm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i]),
     "gaib_spmm_gemm2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i]),
     "gaib_spmm_mh": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i]),
+    "gaib_graph_split_classes": (_i, [_vp, _vp, _vp, _pp, _pp, _pp, _pp, C.POINTER(_i64), C.POINTER(_i64), _i]),
+    "gaib_graph_set_row_map": (_i, [_vp, _vp, _vp, _i64]),
+    "gaib_graph_row_map": (_vp, [_vp]),
+    "gaib_spmm_2t": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _i]),
+    "gaib_spmm_gemm_2t": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _vp, _i]),
+    "gaib_spmm_gemm_fusable": (_i, [_vp, _i, _i, _i, _i]),
     "gaib_gat_scores_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "gaib_sddmm_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gaib_gat_softmax_bwd_alpha_mh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -91,6 +98,10 @@ SIGNATURES = {
     "gaib_sgemm": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
     "gaib_sgemm_drelu": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _vp]),
     "gaib_sgemm_ex": (_i, [_vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
+    "gaib_bias_add": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "gaib_colsum": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "gaib_rng_uniform": (_i, [_vp, _i64, _f, _f, _u64, _vp]),
+    "gaib_csr2csc": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gaib_relu": (_i, [_vp, _i64, _vp, _vp]),
     "gaib_d_relu": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "gaib_dropout": (_i, [_vp, _i64, _f, _f, _u64, _vp, _vp, _vp]),
@@ -133,6 +144,7 @@ SIGNATURES = {
     "gaib_halo_rows": (_i64, [_vp]),
     "gaib_halo_send_rows": (_i64, [_vp]),
     "gaib_halo_bytes_sent": (_i64, [_vp]),
+    "gaib_halo_link_rows": (_i64, [_vp]),
     "gaib_halo_exchange_begin": (_i, [_vp, _i, _vp]),
     "gaib_halo_exchange_end": (_i, [_vp, _pp]),
     "gaib_halo_reduce": (_i, [_vp, _i, _vp, _vp]),
@@ -419,6 +431,43 @@ class Context:
                                        1 if transW else 0, len_out, _ptr(out), flags), "gaib_spmm_gemm")
         return out
 
+    def spmm_2t(self, g: "Graph", kind: int, x, x2, n_first: int, out, edge_w=None, accumulate: bool = False,
+                relu: bool = False):
+        """aggregation over two feature tables: column ids >= n_first index x2 (gaib_spmm_2t)"""
+        assert x.is_contiguous() and out.is_contiguous() and (x2 is None or x2.is_contiguous())
+        flags = (1 if accumulate else 0) | (2 if relu else 0)
+        _check(self.lib.gaib_spmm_2t(self.h, g.h, kind, _ptr(edge_w), x.shape[1], _ptr(x), _ptr(x2), n_first, _ptr(out),
+                                     flags), "gaib_spmm_2t")
+        return out
+
+    def spmm_gemm_2t(self, g: "Graph", kind: int, x, x2, n_first: int, agg, W, out, transW: bool = False,
+                     relu: bool = False, agg_scratch: bool = False, edge_w=None, accumulate: bool = False, rows2=None,
+                     W2=None):
+        """gaib_spmm_gemm_2t: the fused aggregation + product over two feature tables"""
+        len_in, len_out = agg.shape[1], out.shape[1]
+        flags = (2 if relu else 0) | (4 if agg_scratch else 0) | (1 if accumulate else 0)
+        _check(self.lib.gaib_spmm_gemm_2t(self.h, g.h, kind, _ptr(edge_w), len_in, _ptr(x), _ptr(x2), n_first, _ptr(agg),
+                                          _ptr(W), 1 if transW else 0, _ptr(rows2), _ptr(W2), len_out, _ptr(out), flags),
+               "gaib_spmm_gemm_2t")
+        return out
+
+    def spmm_gemm_fusable(self, kind: int, len_in: int, len_out: int, dual: bool = False) -> bool:
+        return bool(self.lib.gaib_spmm_gemm_fusable(self.h, kind, len_in, len_out, int(dual)))
+
+    def split_classes(self, g_own: "Graph", g_halo: "Graph", interior=True, bnd_own=True, bnd_halo=True, bnd_full=True,
+                      all_boundary: bool = False):
+        """gaib_graph_split_classes -> dict(interior=, bnd_own=, bnd_halo=, bnd_full= Graph or None, n_boundary=,
+        boundary_edges=)"""
+        hs = [C.c_void_p() for _ in range(4)]
+        want = [interior, bnd_own, bnd_halo, bnd_full]
+        nb, be = _i64(), _i64()
+        _check(self.lib.gaib_graph_split_classes(self.h, g_own.h, g_halo.h, *[C.byref(h) if w else None for h, w in zip(hs, want)],
+                                                 C.byref(nb), C.byref(be), int(all_boundary)), "gaib_graph_split_classes")
+        out = {k: (Graph(self, _handle=h) if w else None)
+               for k, h, w in zip(("interior", "bnd_own", "bnd_halo", "bnd_full"), hs, want)}
+        out["n_boundary"], out["boundary_edges"] = nb.value, be.value
+        return out
+
     def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2, heads: int = 1):
         _check(self.lib.gaib_gat_scores_mh(self.h, g.h, h.shape[1], heads, _ptr(h), _ptr(alpha_l), _ptr(alpha_r),
                                            eps, _ptr(temp), _ptr(scores), _ptr(norm)), "gaib_gat_scores")
@@ -494,6 +543,19 @@ class Context:
         return Cm
 
     # ---- elementwise / loss / optimizer -----------------------------------------------------
+    def bias_add(self, x, b):
+        _check(self.lib.gaib_bias_add(self.h, x.shape[0], x.shape[1], _ptr(x), _ptr(b)), "gaib_bias_add")
+
+    def colsum(self, x, a):
+        _check(self.lib.gaib_colsum(self.h, x.shape[0], x.shape[1], _ptr(x), _ptr(a)), "gaib_colsum")
+
+    def rng_uniform(self, out, a: float = 0.0, b: float = 1.0, seed: int = 1):
+        _check(self.lib.gaib_rng_uniform(self.h, out.numel(), a, b, seed, _ptr(out)), "gaib_rng_uniform")
+
+    def csr2csc(self, nrows, ncols, values, rowptr, colidx, valuesT, rowptrT, colidxT):
+        _check(self.lib.gaib_csr2csc(self.h, nrows, ncols, colidx.numel(), _ptr(values), _ptr(rowptr), _ptr(colidx),
+                                     _ptr(valuesT), _ptr(rowptrT), _ptr(colidxT)), "gaib_csr2csc")
+
     def relu(self, x, out):
         _check(self.lib.gaib_relu(self.h, x.numel(), _ptr(x), _ptr(out)), "gaib_relu")
 
@@ -682,6 +744,14 @@ class Graph:
     def edge_data(self):
         import torch
         return self._dev_tensor(self.lib.gaib_graph_edge_data(self.h), self.ne, torch.float32)
+
+    def row_map(self):
+        """[nv] int64 copy of the row map of a class graph (gaib_graph_split_classes), or None"""
+        import torch
+        p = self.lib.gaib_graph_row_map(self.h)
+        if not p:
+            return None
+        return self._dev_tensor(p, self.nv, torch.int32).to(torch.int64)
 
     def device_bytes(self) -> int:
         return self.lib.gaib_graph_device_bytes(self.h)

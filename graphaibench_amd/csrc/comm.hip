@@ -677,6 +677,15 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
 
 extern "C" int64_t gaib_halo_rows(const gaib_halo* h) { return h ? h->recv_off[h->c->nranks] : 0; }
 extern "C" int64_t gaib_halo_send_rows(const gaib_halo* h) { return h ? h->send_off[h->c->nranks] : 0; }
+extern "C" int64_t gaib_halo_link_rows(const gaib_halo* h) {
+  if (!h) return 0;
+  int64_t m = 0;
+  for (int r = 0; r < h->c->nranks; ++r) {
+    if (h->send_counts[r] > m) m = h->send_counts[r];
+    if (h->recv_counts[r] > m) m = h->recv_counts[r];
+  }
+  return m;
+}
 extern "C" int64_t gaib_halo_bytes_sent(const gaib_halo* h) { return h ? h->bytes_sent : 0; }
 
 // 1. pack the owned rows the peers asked for (compute stream), 2. start moving them.  Every rank calls it for every

@@ -147,6 +147,10 @@ struct gaib_graph {
   int heavy_thr;
   int64_t max_degree;
   int64_t dev_bytes;
+  // row classes of a vertex-range partition (gaib_graph_split_classes): this graph holds a SUBSET of a rank's rows, compact;
+  // row r stands for row row_map[r] of the caller's [n_out_rows x len] matrices.  NULL: an ordinary graph.
+  uint32_t* row_map;
+  int64_t n_out_rows;
   float near_frac;  // share of (sampled) edges whose column id lies within 32 768 of the row id: locality of the numbering; < 0 = not measured yet
 };
 

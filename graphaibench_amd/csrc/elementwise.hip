@@ -431,6 +431,38 @@ __global__ void finish_partial_kernel(int nblocks, const float* part, float* res
   }
 }
 
+// bias_mv (math_functions.cu:207-221): x[i, j] += b[j]
+__global__ void bias_add_kernel(int64_t total, int len, float* x, const float* b) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) x[i] = x[i] + b[i % len];
+}
+// reduce_sum (math_functions.cpp:246-262: a[j] = sum_i x[i, j]; the reference's CUDA kernel, math_functions.cu:224-229,
+// adds into a[j] from every thread without atomics).  Two levels in a fixed order: block b sums its run of rows per
+// column, then the block partials are added in block order -- the same bits on every run.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, int len, int64_t rows_per_block, const float* x,
+                                                             float* part) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  for (int j = threadIdx.x; j < len; j += blockDim.x) {
+    float s = 0.f;
+    for (int64_t i = r0; i < r1; ++i) s += x[i * len + j];
+    part[(int64_t)blockIdx.x * len + j] = s;
+  }
+}
+__global__ void colsum_finish_kernel(int nblocks, int len, const float* part, float* a) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * len + j];
+  a[j] = s;
+}
+// rng_uniform_gpu / gpu_rng_uniform (math_functions.cu:39-50): r = a + (b - a) * u, u uniform on [0, 1) from the
+// library's counter RNG (the reference draws cuRAND XORWOW numbers: streams are not comparable, statistics are)
+__global__ void rng_uniform_kernel(int64_t n, float a, float range, uint64_t seed, float* r) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) r[i] = a + range * u01(seed, (uint64_t)i);
+}
+
 // Adam with the beta powers in device memory (pw[0] = b1^t, pw[1] = b2^t): a recorded (HIP graph) step cannot take
 // them by value.  adam_advance_kernel is the host's `b1_t *= b1; b2_t *= b2` (optimizer.cpp), same float products.
 __global__ void adam_dev_kernel(int64_t n, const float* dW, float* W, float* m, float* v, float alpha, float b1,
@@ -742,6 +774,43 @@ extern "C" int gaib_gather_scatter_rows(gaib_ctx* ctx, int64_t n_idx, const int6
   } else {
     scatter_rows_kernel<<<(unsigned)cdiv64(n_idx, 4), 256, 0, ctx->stream>>>(n_idx, d_src_idx, d_dst_idx, len, d_in, d_out);
   }
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_bias_add(gaib_ctx* ctx, int64_t n, int len, float* d_x, const float* d_b) {
+  GAIB_CHECK(ctx && n >= 0 && len >= 0, "gaib_bias_add: bad argument");
+  if (n == 0 || len == 0) return GAIB_OK;
+  GAIB_CHECK(d_x && d_b, "gaib_bias_add: NULL pointer");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  bias_add_kernel<<<stream_grid(n * len, 256), 256, 0, ctx->stream>>>(n * len, len, d_x, d_b);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_colsum(gaib_ctx* ctx, int64_t n, int len, const float* d_x, float* d_a) {
+  GAIB_CHECK(ctx && n >= 0 && len >= 0, "gaib_colsum: bad argument");
+  if (len == 0) return GAIB_OK;
+  GAIB_CHECK(d_a && (d_x || n == 0), "gaib_colsum: NULL pointer");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (n == 0) return gaib_fill_f32(ctx, len, 0.f, d_a);
+  int64_t nblocks = (n + 63) / 64;
+  if (nblocks > 1024) nblocks = 1024;
+  const int64_t rows_per_block = (n + nblocks - 1) / nblocks;
+  nblocks = (n + rows_per_block - 1) / rows_per_block;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)nblocks * (size_t)len));
+  colsum_partial_kernel<<<(unsigned)nblocks, 256, 0, ctx->stream>>>(n, len, rows_per_block, d_x, (float*)ctx->ws);
+  GAIB_LAUNCH_CHECK();
+  colsum_finish_kernel<<<(len + 255) / 256, 256, 0, ctx->stream>>>((int)nblocks, len, (const float*)ctx->ws, d_a);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+extern "C" int gaib_rng_uniform(gaib_ctx* ctx, int64_t n, float a, float b, uint64_t seed, float* d_r) {
+  GAIB_CHECK(ctx && n >= 0 && (d_r || n == 0), "gaib_rng_uniform: bad argument");
+  if (n == 0) return GAIB_OK;
+  GAIB_HIP(hipSetDevice(ctx->device));
+  rng_uniform_kernel<<<stream_grid(n, 256), 256, 0, ctx->stream>>>(n, a, b - a, seed, d_r);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }

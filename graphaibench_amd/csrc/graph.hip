@@ -246,7 +246,7 @@ extern "C" int gaib_graph_destroy(gaib_graph* g) {
   (void)hipSetDevice(g->device);
   void* ptrs[] = {g->rowptr, g->colidx,   g->vdata, g->edata,      g->inv_deg,  g->col_vdata,
                   g->col_inv_deg, g->w_gcn, g->w_mean_t, g->rev,   g->heavy_rows,
-                  g->chunk_row, g->chunk_ebase, g->chunk_start, g->colidx_flagged};
+                  g->chunk_row, g->chunk_ebase, g->chunk_start, g->colidx_flagged, g->row_map};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -255,6 +255,7 @@ extern "C" int gaib_graph_destroy(gaib_graph* g) {
 
 extern "C" int64_t gaib_graph_nv(const gaib_graph* g) { return g ? g->nv : -1; }
 extern "C" int64_t gaib_graph_ne(const gaib_graph* g) { return g ? g->ne : -1; }
+extern "C" int64_t gaib_graph_nc(const gaib_graph* g) { return g ? g->nc : -1; }
 extern "C" const int64_t* gaib_graph_rowptr(const gaib_graph* g) { return g ? g->rowptr : nullptr; }
 extern "C" const uint32_t* gaib_graph_colidx(const gaib_graph* g) { return g ? g->colidx : nullptr; }
 extern "C" const float* gaib_graph_vertex_data(const gaib_graph* g) { return g ? g->vdata : nullptr; }
@@ -930,5 +931,310 @@ extern "C" int gaib_graph_stats(gaib_ctx* ctx, gaib_graph* g, int64_t* h_n_heavy
   if (h_n_heavy) *h_n_heavy = g->n_heavy;
   if (h_heavy_edges) *h_heavy_edges = g->heavy_edges;
   if (h_max_degree) *h_max_degree = g->max_degree;
+  return GAIB_OK;
+}
+
+
+// ---- row classes of a vertex-range partition --------------------------------------------------------------------------
+// The reference partitioner's local graph marks the owned (master) rows and appends the halo vertices behind them
+// (src/partitioner/graph_partition.cc:70-80, include/graph_partition.h:21-22,36-37).  An owned row whose edges all stay
+// inside the range -- an INTERIOR row -- needs nothing from the exchange: its aggregation (and the dense product riding on
+// it) is complete in one pass while the halo rows travel.  Only BOUNDARY rows wait for them.  From the rank's owned-column
+// graph and halo-column graph (same rows) this builds the class graphs, each COMPACT (row k = the k-th row of the class, in
+// ascending order) with the map back to the rank's rows and the normalisers of its rows and columns:
+//   interior : the rows without halo-column edges                         columns: owned
+//   bnd_own  : the boundary rows' owned-column edges                      columns: owned
+//   bnd_halo : the boundary rows' halo-column edges                       columns: halo
+//   bnd_full : both, per row [owned-column edges..., halo-column edges...]  columns: [owned | halo] (halo id + n_own)
+// Edge order inside a row is kept, so the sums of a class graph are the sums of the graphs it was cut from.
+namespace {
+
+__global__ void class_flag_kernel(int64_t nv, const int64_t* rp_halo, int all_boundary, uint32_t* is_bnd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nv) is_bnd[i] = (all_boundary || rp_halo[i + 1] > rp_halo[i]) ? 1u : 0u;
+}
+// pos_b = exclusive scan of is_bnd: boundary row i is row pos_b[i] of its class, interior row i is row i - pos_b[i]
+__global__ void class_map_kernel(int64_t nv, const uint32_t* is_bnd, const uint32_t* pos_b, uint32_t* map_b, uint32_t* map_i) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nv) return;
+  if (is_bnd[i]) map_b[pos_b[i]] = (uint32_t)i;
+  else map_i[i - pos_b[i]] = (uint32_t)i;
+}
+// deg[k] = edges of class row k in source a (+ source b); deg[n] = 0 closes the exclusive scan into a rowptr
+__global__ void class_deg_kernel(int64_t n, const uint32_t* map, const int64_t* rp_a, const int64_t* rp_b, int64_t* deg) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n) return;
+  if (k == n) {
+    deg[k] = 0;
+    return;
+  }
+  const int64_t r = map[k];
+  int64_t d = rp_a[r + 1] - rp_a[r];
+  if (rp_b) d += rp_b[r + 1] - rp_b[r];
+  deg[k] = d;
+}
+// one wave per class row: its edges from source a, then from source b with the column ids shifted by `shift_b`
+__global__ __launch_bounds__(256) void class_copy_kernel(int64_t n, const uint32_t* map, const int64_t* rp_a, const uint32_t* col_a,
+                                                         const int64_t* rp_b, const uint32_t* col_b, uint32_t shift_b,
+                                                         const int64_t* rp_out, uint32_t* col_out) {
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = map[k];
+  int64_t o = rp_out[k];
+  const int64_t a0 = rp_a[r], a1 = rp_a[r + 1];
+  for (int64_t e = a0 + lane; e < a1; e += 64) col_out[o + (e - a0)] = col_a[e];
+  if (rp_b) {
+    o += a1 - a0;
+    const int64_t b0 = rp_b[r], b1 = rp_b[r + 1];
+    for (int64_t e = b0 + lane; e < b1; e += 64) col_out[o + (e - b0)] = col_b[e] + shift_b;
+  }
+}
+__global__ void gather_f32_kernel(int64_t n, const uint32_t* idx, const float* in, float* out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = in[idx[k]];
+}
+
+// one class graph: rows map[0..n) of source a (+ b), nc columns
+int build_class(gaib_ctx* ctx, int64_t n, const uint32_t* map, int64_t n_rows_all, const gaib_graph* a, const gaib_graph* b,
+                uint32_t shift_b, int64_t nc, gaib_graph** out) {
+  gaib_graph* g = nullptr;
+  // rowptr first (the edge count comes out of the scan)
+  int64_t* deg = nullptr;
+  GAIB_HIP(hipMalloc(&deg, sizeof(int64_t) * (size_t)(n + 1)));
+  struct Release {
+    void* p;
+    ~Release() { (void)hipFree(p); }
+  } rel_deg{deg};
+  class_deg_kernel<<<grid1d(n + 1, 256), 256, 0, ctx->stream>>>(n, map, a->rowptr, b ? b->rowptr : nullptr, deg);
+  GAIB_LAUNCH_CHECK();
+  int64_t* rp = nullptr;
+  GAIB_HIP(hipMalloc(&rp, sizeof(int64_t) * (size_t)(n + 1)));
+  Release rel_rp{rp};
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  GAIB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg, rp, (int)(n + 1), ctx->stream));
+  GAIB_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 8));
+  Release rel_tmp{tmp};
+  GAIB_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, deg, rp, (int)(n + 1), ctx->stream));
+  int64_t ne = 0;
+  GAIB_HIP(hipMemcpyAsync(&ne, rp + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  GAIB_CHECK(ne < (int64_t)1 << 32, "gaib_graph_split_classes: a class with %lld edges (edge ids are uint32)", (long long)ne);
+  GAIB_TRY(new_graph(n, ne, ctx->device, &g));
+  g->nc = nc;
+  GAIB_HIP(hipMemcpyAsync(g->rowptr, rp, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  if (n > 0) {
+    class_copy_kernel<<<grid1d(n, 4), 256, 0, ctx->stream>>>(n, map, a->rowptr, a->colidx, b ? b->rowptr : nullptr,
+                                                             b ? b->colidx : nullptr, shift_b, g->rowptr, g->colidx);
+    GAIB_LAUNCH_CHECK();
+  }
+  GAIB_HIP(hipMalloc(&g->row_map, sizeof(uint32_t) * (size_t)(n > 0 ? n : 1)));
+  if (n > 0) GAIB_HIP(hipMemcpyAsync(g->row_map, map, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  g->n_out_rows = n_rows_all;
+  g->dev_bytes += sizeof(uint32_t) * n;
+  // normalisers: the rows' through the map; the columns' from the source graphs (a: owned space, b: halo space)
+  const size_t n1 = (size_t)(n > 0 ? n : 1), nc1 = (size_t)(nc > 0 ? nc : 1);
+  GAIB_HIP(hipMalloc(&g->vdata, sizeof(float) * n1));
+  GAIB_HIP(hipMalloc(&g->inv_deg, sizeof(float) * n1));
+  GAIB_HIP(hipMalloc(&g->col_vdata, sizeof(float) * nc1));
+  GAIB_HIP(hipMalloc(&g->col_inv_deg, sizeof(float) * nc1));
+  g->dev_bytes += sizeof(float) * (2 * n + 2 * nc);
+  if (n > 0) {
+    gather_f32_kernel<<<grid1d(n, 256), 256, 0, ctx->stream>>>(n, map, a->vdata, g->vdata);
+    gather_f32_kernel<<<grid1d(n, 256), 256, 0, ctx->stream>>>(n, map, a->inv_deg, g->inv_deg);
+    GAIB_LAUNCH_CHECK();
+  }
+  GAIB_HIP(hipMemcpyAsync(g->col_vdata, a->col_vdata, sizeof(float) * a->nc, hipMemcpyDeviceToDevice, ctx->stream));
+  GAIB_HIP(hipMemcpyAsync(g->col_inv_deg, a->col_inv_deg, sizeof(float) * a->nc, hipMemcpyDeviceToDevice, ctx->stream));
+  const int64_t off = a->nc;
+  if (b) {
+    GAIB_HIP(hipMemcpyAsync(g->col_vdata + off, b->col_vdata, sizeof(float) * b->nc, hipMemcpyDeviceToDevice, ctx->stream));
+    GAIB_HIP(hipMemcpyAsync(g->col_inv_deg + off, b->col_inv_deg, sizeof(float) * b->nc, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  *out = g;
+  return GAIB_OK;
+}
+
+}  // namespace
+
+extern "C" int gaib_graph_set_row_map(gaib_ctx* ctx, gaib_graph* g, const uint32_t* d_row_map, int64_t n_out_rows) {
+  GAIB_CHECK(ctx && g, "gaib_graph_set_row_map: NULL argument");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (!d_row_map) {
+    if (g->row_map) GAIB_HIP(hipFree(g->row_map));
+    g->row_map = nullptr;
+    g->n_out_rows = 0;
+    return GAIB_OK;
+  }
+  GAIB_CHECK(n_out_rows >= g->nv, "gaib_graph_set_row_map: %lld output rows for a graph of %lld rows", (long long)n_out_rows,
+             (long long)g->nv);
+  if (!g->row_map) {
+    GAIB_HIP(hipMalloc(&g->row_map, sizeof(uint32_t) * (size_t)(g->nv > 0 ? g->nv : 1)));
+    g->dev_bytes += sizeof(uint32_t) * g->nv;
+  }
+  GAIB_HIP(hipMemcpyAsync(g->row_map, d_row_map, sizeof(uint32_t) * (size_t)g->nv, hipMemcpyDeviceToDevice, ctx->stream));
+  g->n_out_rows = n_out_rows;
+  return GAIB_OK;
+}
+
+extern "C" const uint32_t* gaib_graph_row_map(const gaib_graph* g) { return g ? g->row_map : nullptr; }
+
+extern "C" int gaib_graph_split_classes(gaib_ctx* ctx, const gaib_graph* g_own, const gaib_graph* g_halo, gaib_graph** interior,
+                                        gaib_graph** bnd_own, gaib_graph** bnd_halo, gaib_graph** bnd_full,
+                                        int64_t* h_n_boundary, int64_t* h_boundary_edges, int flags) {
+  GAIB_CHECK(ctx && g_own && g_halo, "gaib_graph_split_classes: NULL argument");
+  GAIB_CHECK((flags & ~GAIB_SPLIT_ALL_BOUNDARY) == 0, "gaib_graph_split_classes: unknown flags %d", flags);
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_graph_split_classes");
+  GAIB_CHECK(g_own->nv == g_halo->nv, "gaib_graph_split_classes: the two graphs must hold the same rows (%lld vs %lld)",
+             (long long)g_own->nv, (long long)g_halo->nv);
+  GAIB_CHECK(g_own->nc == g_own->nv, "gaib_graph_split_classes: the owned-column graph must be square");
+  GAIB_CHECK(!g_own->row_map && !g_halo->row_map, "gaib_graph_split_classes: class graphs cannot be split again");
+  GAIB_CHECK(g_own->col_vdata && g_own->vdata && g_own->inv_deg && g_halo->col_vdata && g_halo->vdata && g_halo->inv_deg,
+             "gaib_graph_split_classes: call gaib_graph_set_vertex_norm (rows and columns) on both graphs first");
+  GAIB_CHECK(g_own->nc + g_halo->nc < (int64_t)1 << 32, "gaib_graph_split_classes: owned + halo columns must be < 2^32");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const int64_t nv = g_own->nv;
+  uint32_t *is_bnd = nullptr, *pos = nullptr, *map_b = nullptr, *map_i = nullptr;
+  void* tmp = nullptr;
+  const size_t n1 = (size_t)(nv + 1);
+  hipError_t e = hipMalloc(&is_bnd, sizeof(uint32_t) * n1);
+  if (e == hipSuccess) e = hipMalloc(&pos, sizeof(uint32_t) * n1);
+  if (e == hipSuccess) e = hipMalloc(&map_b, sizeof(uint32_t) * n1);
+  if (e == hipSuccess) e = hipMalloc(&map_i, sizeof(uint32_t) * n1);
+  struct Release {
+    void** p;
+    int n;
+    ~Release() {
+      for (int i = 0; i < n; ++i)
+        if (p[i]) (void)hipFree(p[i]);
+    }
+  };
+  void* owned[] = {is_bnd, pos, map_b, map_i, nullptr};
+  Release rel{owned, 5};
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_graph_split_classes: %s", hipGetErrorString(e));
+    return GAIB_ERR_NOMEM;
+  }
+  GAIB_HIP(hipMemsetAsync(is_bnd, 0, sizeof(uint32_t) * n1, ctx->stream));
+  if (nv > 0) {
+    class_flag_kernel<<<grid1d(nv, 256), 256, 0, ctx->stream>>>(nv, g_halo->rowptr, (flags & GAIB_SPLIT_ALL_BOUNDARY) ? 1 : 0,
+                                                                is_bnd);
+    GAIB_LAUNCH_CHECK();
+  }
+  size_t tmp_bytes = 0;
+  GAIB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, is_bnd, pos, (int)(nv + 1), ctx->stream));
+  GAIB_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 8));
+  owned[4] = tmp;
+  GAIB_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, is_bnd, pos, (int)(nv + 1), ctx->stream));
+  uint32_t n_b32 = 0;
+  GAIB_HIP(hipMemcpyAsync(&n_b32, pos + nv, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t n_b = n_b32, n_i = nv - n_b;
+  if (nv > 0) {
+    class_map_kernel<<<grid1d(nv, 256), 256, 0, ctx->stream>>>(nv, is_bnd, pos, map_b, map_i);
+    GAIB_LAUNCH_CHECK();
+  }
+  gaib_graph* made[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rc = GAIB_OK;
+  if (interior) rc = build_class(ctx, n_i, map_i, nv, g_own, nullptr, 0, g_own->nc, &made[0]);
+  if (rc == GAIB_OK && bnd_own) rc = build_class(ctx, n_b, map_b, nv, g_own, nullptr, 0, g_own->nc, &made[1]);
+  if (rc == GAIB_OK && bnd_halo) rc = build_class(ctx, n_b, map_b, nv, g_halo, nullptr, 0, g_halo->nc, &made[2]);
+  if (rc == GAIB_OK && bnd_full)
+    rc = build_class(ctx, n_b, map_b, nv, g_own, g_halo, (uint32_t)g_own->nc, g_own->nc + g_halo->nc, &made[3]);
+  if (rc != GAIB_OK) {
+    for (gaib_graph* m : made) gaib_graph_destroy(m);
+    return rc;
+  }
+  if (interior) *interior = made[0];
+  if (bnd_own) *bnd_own = made[1];
+  if (bnd_halo) *bnd_halo = made[2];
+  if (bnd_full) *bnd_full = made[3];
+  if (h_n_boundary) *h_n_boundary = n_b;
+  if (h_boundary_edges) {
+    // edges (owned- and halo-column) of the boundary rows: what waits for the exchange in the one-pass form
+    int64_t be = 0;
+    if (made[3]) be = made[3]->ne;
+    else if (made[1] && made[2]) be = made[1]->ne + made[2]->ne;
+    else if (made[0]) be = g_own->ne + g_halo->ne - made[0]->ne;
+    else be = -1;
+    *h_boundary_edges = be;
+  }
+  return GAIB_OK;
+}
+
+// ---- csr2csc (math_functions.hh:45; cusparseCsr2cscEx2, math_functions.cu:345-358): the transpose of a general CSR matrix
+// with 32-bit offsets, everything in device memory.  A stable radix sort of the edges by column id: inside a column the
+// rows come out ascending (the order of cuSPARSE's ALG1).
+namespace {
+__global__ __launch_bounds__(256) void expand_rows_kernel(int nrows, const int* rowptr, uint32_t* rows) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  for (int e = rowptr[r] + (threadIdx.x & 63); e < rowptr[r + 1]; e += 64) rows[e] = (uint32_t)r;
+}
+__global__ void csc_fill_kernel(int64_t nnz, const uint32_t* perm, const uint32_t* rows, const float* values, float* valuesT,
+                                int* colidxT) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const uint32_t e = perm[k];
+  colidxT[k] = (int)rows[e];
+  if (values) valuesT[k] = values[e];
+}
+// rowptrT[c] = first position of a key >= c in the sorted column ids
+__global__ void csc_offsets_kernel(int ncols, int64_t nnz, const uint32_t* sorted_cols, int* rowptrT) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > ncols) return;
+  int64_t lo = 0, hi = nnz;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_cols[mid] < (uint32_t)c) lo = mid + 1;
+    else hi = mid;
+  }
+  rowptrT[c] = (int)lo;
+}
+}  // namespace
+
+extern "C" int gaib_csr2csc(gaib_ctx* ctx, int nrows, int ncols, int nnz, const float* d_values, const int* d_rowptr,
+                            const int* d_colidx, float* d_valuesT, int* d_rowptrT, int* d_colidxT) {
+  GAIB_CHECK(ctx && nrows >= 0 && ncols >= 0 && nnz >= 0, "gaib_csr2csc: bad size");
+  GAIB_CHECK(d_rowptr && d_rowptrT && (nnz == 0 || (d_colidx && d_colidxT)), "gaib_csr2csc: NULL pointer");
+  GAIB_CHECK((d_values == nullptr) == (d_valuesT == nullptr) || nnz == 0, "gaib_csr2csc: values and valuesT go together");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_csr2csc");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  if (nnz == 0) {
+    GAIB_HIP(hipMemsetAsync(d_rowptrT, 0, sizeof(int) * (size_t)(ncols + 1), ctx->stream));
+    return GAIB_OK;
+  }
+  uint32_t *keys_out = nullptr, *ids = nullptr, *perm = nullptr, *rows = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int end_bit = 1;
+  while (end_bit < 32 && ((int64_t)1 << end_bit) < ncols) end_bit++;
+  const uint32_t* keys_in = reinterpret_cast<const uint32_t*>(d_colidx);
+  hipError_t e = hipMalloc(&keys_out, sizeof(uint32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hipMalloc(&ids, sizeof(uint32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hipMalloc(&perm, sizeof(uint32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hipMalloc(&rows, sizeof(uint32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, ids, perm, nnz, 0, end_bit, ctx->stream);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes);
+  if (e == hipSuccess) {
+    iota_u32_kernel<<<grid1d(nnz, 256), 256, 0, ctx->stream>>>(nnz, ids);
+    expand_rows_kernel<<<grid1d(nrows, 4), 256, 0, ctx->stream>>>(nrows, d_rowptr, rows);
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, ids, perm, nnz, 0, end_bit, ctx->stream);
+  }
+  if (e == hipSuccess) {
+    csc_fill_kernel<<<grid1d(nnz, 256), 256, 0, ctx->stream>>>(nnz, perm, rows, d_values, d_valuesT, d_colidxT);
+    csc_offsets_kernel<<<grid1d(ncols + 1, 256), 256, 0, ctx->stream>>>(ncols, nnz, keys_out, d_rowptrT);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  void* owned[] = {keys_out, ids, perm, rows, tmp};
+  for (void* p : owned)
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) {
+    gaib_set_error("gaib_csr2csc: %s", hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? GAIB_ERR_NOMEM : GAIB_ERR_HIP;
+  }
   return GAIB_OK;
 }

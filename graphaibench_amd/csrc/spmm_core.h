@@ -31,7 +31,19 @@ struct SpmmArgs {
   int heads;                 // WMODE 3/4: edge weights are [ne][heads]; head of a column = col / dh
   int dh;
   int compact;               // heavy kernel: row k of row_list is written to out row k (fused path's scratch)
+  // PART kernels (row classes of a vertex-range partition, spmm_part.hip) -- ignored by the others:
+  const uint32_t* row_map;   // row r of the graph is row row_map[r] of out / the continued partial sums / rows2 / y (NULL: r itself)
+  const float* in2;          // column ids >= n_first index this second table (row id - n_first): the halo table behind the
+  uint32_t n_first;          //   rank's own rows.  in2 == NULL: one table, n_first = 0xffffffff
+  uint32_t in2_bytes;        // BUF kernels: size of the second table (< 4 GB)
 };
+
+// the row of the caller's matrices that row r of the graph stands for
+template <bool PART>
+__device__ __forceinline__ int64_t out_row(const SpmmArgs& a, int64_t r) {
+  if constexpr (PART) return a.row_map ? (int64_t)a.row_map[r] : r;
+  else return r;
+}
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { typedef float type; };
@@ -109,20 +121,38 @@ typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 // GM (gather mode): 0 = 64-bit global_load; 1 = buffer_load, default cache policy; 2 = buffer_load nt
 // (streaming) for every gather; 3 = buffer_load, nt only for COLD columns (top bit of the column id
 // set by gaib_graph_ensure_hot_flags), so the few thousand hub rows keep their place in the 4 MB L2.
-template <int VEC, int GM>
+// PART: two tables -- column ids below n_first index `in`, the others `in2` (a rank's own rows and its halo table, which
+// live in different allocations); the choice is a scalar select on the (wave-uniform) column id.
+template <int VEC, int GM, bool PART = false>
 struct RowGather {
   static constexpr bool BUF = GM != 0;
-  __amdgpu_buffer_rsrc_t rsrc;
-  const char* inb;
+  __amdgpu_buffer_rsrc_t rsrc, rsrc2;
+  const char *inb, *inb2;  // inb2 is biased by -n_first rows: row base = inb2 + col * ldb
   int64_t ldb;
+  uint32_t n_first;
   __device__ __forceinline__ RowGather(const SpmmArgs& a) {
     inb = reinterpret_cast<const char*>(a.in);
     ldb = a.ld * 4;
     if constexpr (BUF) rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    if constexpr (PART) {
+      n_first = a.in2 ? a.n_first : 0xffffffffu;
+      inb2 = reinterpret_cast<const char*>(a.in2) - (int64_t)a.n_first * ldb;
+      if constexpr (BUF) rsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in2, 0, (int)a.in2_bytes, 0x00020000);
+    }
   }
   __device__ __forceinline__ typename VecT<VEC>::type load(uint32_t cj, uint32_t voff) const {
     typedef typename VecT<VEC>::type vec_t;
-    if constexpr (GM == 3) {
+    if constexpr (PART) {
+      static_assert(GM == 0 || GM == 1, "two-table gathers: plain buffer or global loads");
+      const bool second = cj >= n_first;  // scalar
+      if constexpr (GM == 1) {
+        const int soff = (int)((second ? cj - n_first : cj) * (uint32_t)ldb);
+        return load_rsrc<0>(second ? rsrc2 : rsrc, soff, voff);  // (scalar selects: straight-line code)
+      } else {
+        const char* rowp = (second ? inb2 : inb) + (int64_t)cj * ldb;
+        return *reinterpret_cast<const vec_t*>(rowp + voff);
+      }
+    } else if constexpr (GM == 3) {
       const uint32_t c = cj & 0x7fffffffu;
       if (cj & 0x80000000u) return load_buf<2>(c, voff);  // wave-uniform branch (cj is scalar)
       return load_buf<0>(c, voff);
@@ -137,8 +167,11 @@ struct RowGather {
   }
   template <int AUX>
   __device__ __forceinline__ typename VecT<VEC>::type load_buf(uint32_t cj, uint32_t voff) const {
+    return load_rsrc<AUX>(rsrc, (int)(cj * (uint32_t)ldb), voff);
+  }
+  template <int AUX>
+  __device__ __forceinline__ typename VecT<VEC>::type load_rsrc(__amdgpu_buffer_rsrc_t rsrc, int soff, uint32_t voff) const {
     typedef typename VecT<VEC>::type vec_t;
-    const int soff = (int)(cj * (uint32_t)ldb);
     if constexpr (VEC == 1) {
       return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, AUX));
     } else if constexpr (VEC == 2) {
@@ -163,13 +196,13 @@ struct RowGather {
 // voff[ct] is the lane's BYTE offset inside a feature row; lanes whose columns fall outside
 // the row are pointed at offset 0, so every gather is unconditional (a predicated load makes
 // hipcc branch on EXEC and drain vmcnt after each one); what they accumulate is never stored.
-template <int VEC, int CT, int WMODE, int U, int BUF>
+template <int VEC, int CT, int WMODE, int U, int BUF, bool PART = false>
 __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int64_t eb, int64_t ee,
                                                 int64_t chunk_stride, float roww,
                                                 const uint32_t (&voff)[CT],
                                                 typename VecT<VEC>::type (&acc)[CT]) {
   typedef typename VecT<VEC>::type vec_t;
-  const RowGather<VEC, BUF> gather(a);
+  const RowGather<VEC, BUF, PART> gather(a);
   vec_t x[U][CT];  // gather destinations; the tail's piece p lives in x[p .. 2p-1]
   constexpr bool MH = WMODE >= 3;  // multi-head: every lane fetches the weight of ITS head itself
   int hd[CT];

@@ -14,13 +14,32 @@ static gaib_graph* dev(Graph& g) {
   return g.device_graph();
 }
 
-// One aggregation.  On a vertex-range partition the owned-column edges are summed while the halo
-// rows are in flight (separate RCCL stream), then the halo-column edges are added to the same rows.
-static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* out, bool relu = false) {
-  count_edges(g);
+// One aggregation.  On a vertex-range partition the work that needs no halo row runs while the halo rows are in flight
+// (separate RCCL stream), the rest after they have arrived -- by row class (LearningGraph::partition_mode):
+//   PART_SPLIT    owned-column edges of all rows meanwhile, halo-column edges added to the same rows after
+//   PART_CLASSES  interior rows complete + the boundary rows' owned-column edges meanwhile, their halo-column edges after
+//   PART_ONEPASS  interior rows complete meanwhile, the boundary rows in one pass over [owned | halo] after
+static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* out, bool relu = false, bool count = true) {
+  if (count) count_edges(g);
   const int act = relu ? GAIB_RELU : 0;
   if (!g.has_halo()) {
     GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, out, act));
+    return;
+  }
+  const int mode = g.partition_mode(len);
+  if (mode != Graph::PART_SPLIT) {
+    g.halo_begin(len, in);
+    GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_interior(), kind, NULL, len, in, out, act));
+    if (mode == Graph::PART_CLASSES) {
+      const bool have_halo_edges = gaib_graph_ne(g.class_boundary_halo()) > 0;  // (else: no boundary row either)
+      GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_boundary_own(), kind, NULL, len, in, out, have_halo_edges ? 0 : act));
+      const float* halo = g.halo_end(len);
+      if (have_halo_edges)
+        GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_boundary_halo(), kind, NULL, len, halo, out, GAIB_ACCUMULATE | act));
+    } else {
+      const float* halo = g.halo_end(len);
+      GAIB_OR_DIE(gaib_spmm_2t(C(), g.class_boundary_full(), kind, NULL, len, in, halo, (int64_t)g.size(), out, act));
+    }
     return;
   }
   g.halo_begin(len, in);
@@ -43,6 +62,35 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
     else
       GAIB_OR_DIE(gaib_spmm_gemm(C(), dg, kind, NULL, len, src, agg, W, transW ? 1 : 0, len_out, out, fl));
   };
+  const int mode = g.has_halo() ? g.partition_mode(len) : Graph::PART_SPLIT;
+  if (mode != Graph::PART_SPLIT) {
+    // the classes fill disjoint rows of ONE output: all of them take the fused kernel, or -- a shape it does not cover --
+    // the aggregation runs class by class and the product(s) once over all rows
+    if (!gaib_spmm_gemm_fusable(C(), kind, len, len_out, rows2 ? 1 : 0)) {
+      aggregate_rows(g, kind, len, in, agg, false, false);
+      const int act = relu ? GAIB_RELU : 0;
+      GAIB_OR_DIE(gaib_sgemm_ex(C(), 0, transW ? 1 : 0, (int64_t)g.size(), len_out, len, agg, W, rows2 ? 0 : act, out));
+      if (rows2)
+        GAIB_OR_DIE(gaib_sgemm_ex(C(), 0, transW ? 1 : 0, (int64_t)g.size(), len_out, len, rows2, W2, GAIB_ACCUMULATE | act, out));
+      return;
+    }
+    g.halo_begin(len, in);
+    fused(g.class_interior(), in, flags);
+    if (mode == Graph::PART_CLASSES) {
+      if (gaib_graph_ne(g.class_boundary_halo()) == 0) {  // no boundary row
+        g.halo_end(len);
+        return;
+      }
+      GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_boundary_own(), kind, NULL, len, in, agg, 0));
+      const float* halo = g.halo_end(len);
+      fused(g.class_boundary_halo(), halo, flags | GAIB_ACCUMULATE);
+    } else {
+      const float* halo = g.halo_end(len);
+      GAIB_OR_DIE(gaib_spmm_gemm_2t(C(), g.class_boundary_full(), kind, NULL, len, in, halo, (int64_t)g.size(), agg, W,
+                                    transW ? 1 : 0, rows2, W2, len_out, out, flags));
+    }
+    return;
+  }
   if (g.has_halo()) {
     // owned-column edges while the halo rows travel; the halo-column edges then continue the sums and
     // carry the dense product(s)

@@ -225,6 +225,15 @@ void gaibl_graph_set_halo_plan(void* graph, void* halo_graph, void* plan) {
   static_cast<Graph*>(graph)->set_halo_plan(static_cast<gaib_graph*>(halo_graph), static_cast<gaib_halo*>(plan));
 }
 void* gaibl_graph_halo_plan(void* graph) { return static_cast<Graph*>(graph)->halo_plan(); }
+void gaibl_graph_set_partition_mode(void* graph, int mode) { static_cast<Graph*>(graph)->set_partition_mode(mode); }
+void gaibl_graph_set_halo_link_rows(void* graph, int64_t rows) { static_cast<Graph*>(graph)->set_halo_link_rows(rows); }
+int gaibl_graph_partition_mode(void* graph, int len, int64_t* n_boundary, int64_t* boundary_edges) {
+  Graph* g = static_cast<Graph*>(graph);
+  const int mode = g->partition_mode(len);
+  if (n_boundary) *n_boundary = g->n_boundary();
+  if (boundary_edges) *boundary_edges = g->boundary_edges();
+  return mode;
+}
 
 void* gaibl_adam_create(float lr) { return static_cast<optimizer*>(new adam(lr)); }
 void gaibl_adam_free(void* opt) { delete static_cast<optimizer*>(opt); }

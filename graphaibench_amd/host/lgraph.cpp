@@ -1,6 +1,8 @@
 // lgraph.cpp -- LearningGraph: host CSR construction + HBM residency.
 // API parity with the reference class (include/gnn/lgraph.h, src/gnn/lgraph.{cpp,cu}); the
 // normalisers are computed by the device kernels behind gaib_graph_compute_*.
+#include <stdlib.h>
+#include <string.h>
 #include "lgraph.h"
 #include "host_util.h"
 
@@ -21,6 +23,86 @@ const float* LearningGraph::halo_end(int len) {
   const float* table = NULL;
   GAIB_OR_DIE(gaib_halo_exchange_end(halo_plan_, &table));
   return table;
+}
+
+// The mode of a partitioned graph's aggregations.  GAIB_PART_MODE = split | classes | onepass | onepass_all | auto (default), or
+// set_partition_mode.  The rule (auto) prices what each form leaves exposed, per aggregation:
+//   one pass    : the exchange minus what hides it -- the interior rows' work (the boundary rows wait for the halo rows)
+//   column split: everything overlaps, but the boundary rows' partial sums are written and read once more and the
+//                 halo-column half runs below the gather rate
+// with the exchange priced at GAIB_LINK_GBS per peer pair (default 100: the guide's 153 GB/s per xGMI link at the share
+// RCCL send/recv pairs are expected to reach; unmeasured on this pool's one-GPU boxes) and the kernels at the rates
+// measured on the shard benchmarks (scripts/papers_shard.py, profiles/r04/shard_*.jsonl: DESIGN.md 6).  Where next to no
+// row is interior (a random vertex order, or cut edges spread over every vertex: under 10 % of the edges in interior
+// rows) the classes are not worth their second launch: the column split then runs over all rows as in round 3, the one
+// pass over all rows of one [owned | halo] graph.  A rank decides for itself: every form runs the same exchange, so
+// ranks need not agree.
+int LearningGraph::partition_mode(int len) {
+  if (part_mode_ >= 0) return part_mode_;
+  if (!has_halo()) return part_mode_ = PART_SPLIT;
+  int want = part_mode_wanted_;
+  if (want < 0) {
+    const char* e = getenv("GAIB_PART_MODE");
+    if (e && *e) {
+      if (!strcmp(e, "split") || !strcmp(e, "0")) want = PART_SPLIT;
+      else if (!strcmp(e, "classes") || !strcmp(e, "1")) want = PART_CLASSES;
+      else if (!strcmp(e, "onepass") || !strcmp(e, "2")) want = PART_ONEPASS;
+      else if (!strcmp(e, "onepass_all") || !strcmp(e, "3")) want = PART_ONEPASS_ALL;
+      else if (strcmp(e, "auto")) {
+        fprintf(stderr, "GAIB_PART_MODE=%s: want split | classes | onepass | onepass_all | auto\n", e);
+        exit(EXIT_FAILURE);
+      }
+    }
+  }
+  gaib_ctx* ctx = gpu_context::get();
+  if (want == PART_SPLIT) return part_mode_ = PART_SPLIT;
+  // the interior class first: its size decides (auto) and every class form needs it
+  gaib_graph* gi = NULL;
+  GAIB_OR_DIE(gaib_graph_split_classes(ctx, dev_, halo_dev_, &gi, NULL, NULL, NULL, &n_boundary_, &boundary_edges_, 0));
+  const int64_t ne_all = gaib_graph_ne(dev_) + gaib_graph_ne(halo_dev_);
+  const int64_t ne_int = gaib_graph_ne(gi), ne_bhalo = gaib_graph_ne(halo_dev_);
+  const bool few_interior = 10 * ne_int < ne_all;
+  bool all_boundary = want == PART_ONEPASS_ALL;
+  int mode = all_boundary ? (int)PART_ONEPASS : want;
+  if (mode < 0) {
+    const double link_gbs = getenv("GAIB_LINK_GBS") ? atof(getenv("GAIB_LINK_GBS")) : 100.0;
+    int64_t link_rows = link_rows_;
+    if (link_rows < 0 && halo_plan_) link_rows = gaib_halo_link_rows(halo_plan_);
+    if (link_rows < 0) link_rows = (ne_bhalo ? gaib_graph_nc(halo_dev_) : 0) / 7 + 1;  // (a callback transport that gave no figure: 8 ranks)
+    const double row_bytes = 4.0 * len;
+    const double t_exchange = link_rows * row_bytes / (link_gbs * 1e9);
+    const double gather_rate = 7.5e12;  // bytes/s the aggregation kernels reach on 512-B rows
+    const double t_interior = few_interior ? 0.0 : ne_int * (row_bytes + 8) / gather_rate;
+    const double exposed_onepass = t_exchange > t_interior ? t_exchange - t_interior : 0.0;
+    // the split's extra cost: the boundary rows' partial sums written and read again (6 TB/s), and the halo-column half
+    // at 5.2 TB/s of its 1 + 12.6 M edges x 520 B instead of the gather rate
+    const int64_t split_rows = few_interior ? (int64_t)size() : n_boundary_;
+    const double split_cost = 2.0 * split_rows * row_bytes / 6.0e12 + ne_bhalo * (row_bytes + 8) * (1.0 / 5.2e12 - 1.0 / gather_rate);
+    const bool onepass = exposed_onepass <= split_cost;
+    mode = onepass ? PART_ONEPASS : (few_interior ? PART_SPLIT : PART_CLASSES);
+    all_boundary = onepass && few_interior;
+    if (getenv("GAIB_PART_VERBOSE"))
+      fprintf(stderr, "[gaib] partition mode %s%s: %lld of %lld rows on the boundary (%.1f %% of the edges in interior rows), "
+              "exchange %.2f ms per link, interior work %.2f ms, split cost %.2f ms\n",
+              mode == PART_ONEPASS ? "onepass" : (mode == PART_CLASSES ? "classes" : "split"), all_boundary ? " (all rows)" : "",
+              (long long)n_boundary_, (long long)size(), 100.0 * ne_int / (ne_all > 0 ? ne_all : 1), t_exchange * 1e3,
+              t_interior * 1e3, split_cost * 1e3);
+  }
+  if (mode == PART_SPLIT) {
+    gaib_graph_destroy(gi);
+    return part_mode_ = PART_SPLIT;
+  }
+  if (all_boundary) {  // one [owned | halo] graph over all rows (the interior class is empty)
+    gaib_graph_destroy(gi);
+    gi = NULL;
+    GAIB_OR_DIE(gaib_graph_split_classes(ctx, dev_, halo_dev_, &gi, NULL, NULL, &cls_bfull_, NULL, NULL, GAIB_SPLIT_ALL_BOUNDARY));
+  } else if (mode == PART_ONEPASS) {
+    GAIB_OR_DIE(gaib_graph_split_classes(ctx, dev_, halo_dev_, NULL, NULL, NULL, &cls_bfull_, NULL, NULL, 0));
+  } else {
+    GAIB_OR_DIE(gaib_graph_split_classes(ctx, dev_, halo_dev_, NULL, &cls_bown_, &cls_bhalo_, NULL, NULL, NULL, 0));
+  }
+  cls_int_ = gi;
+  return part_mode_ = mode;
 }
 
 void LearningGraph::allocateFrom(index_t nv, index_t ne) {
@@ -155,6 +237,11 @@ void LearningGraph::dealloc() {
   vertex_data_ = edge_data_ = NULL;
   if (dev_) gaib_graph_destroy(dev_);
   dev_ = NULL;
+  gaib_graph* cls[] = {cls_int_, cls_bown_, cls_bhalo_, cls_bfull_};  // built by this object, whoever owns the rest
+  for (gaib_graph* c : cls)
+    if (c) gaib_graph_destroy(c);
+  cls_int_ = cls_bown_ = cls_bhalo_ = cls_bfull_ = NULL;
+  part_mode_ = -1;
   if (owns_partition_) {
     if (halo_plan_) gaib_halo_destroy(halo_plan_);
     if (halo_dev_) gaib_graph_destroy(halo_dev_);

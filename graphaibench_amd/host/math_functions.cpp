@@ -106,6 +106,66 @@ void symmetric_csr_transpose(LearningGraph& g, const float* A_nonzeros, float* B
   GAIB_OR_DIE(gaib_edge_transpose(C(), g.device_graph(), A_nonzeros, B_nonzeros));
 }
 
+void bias_mv(int n, int len, float* x, float* b) {
+  OpTimer t(OP_BIAS);
+  GAIB_OR_DIE(gaib_bias_add(C(), n, len, x, b));
+}
+void reduce_sum(int n, int len, float* x, float* a) {
+  OpTimer t(OP_REDUCE);
+  GAIB_OR_DIE(gaib_colsum(C(), n, len, x, a));
+}
+void reduce_sum(int n, int len, float* x, vec_t& a) {
+  float* d = gaib_host::dmalloc<float>((size_t)(len > 0 ? len : 1));
+  reduce_sum(n, len, x, d);
+  a.resize(len);
+  if (len > 0) copy_float_host(len, d, a.data());
+  GAIB_OR_DIE(gaib_free(C(), d));
+}
+void csr2csc(int nrows, int ncols, int nnz, const float* values, const int* rowptr, const int* colidx, float* valuesT,
+             int* rowptrT, int* colidxT) {
+  OpTimer t(OP_TRANSPOSE);
+  GAIB_OR_DIE(gaib_csr2csc(C(), nrows, ncols, nnz, values, rowptr, colidx, valuesT, rowptrT, colidxT));
+}
+void spmm(size_t x, size_t y, size_t z, size_t nnz, float* A_nonzeros, int* A_idx_ptr, int* A_nnz_idx, const float* B,
+          float* C_, float*, bool transA, bool transB, bool accum) {
+  OpTimer t(OP_SPARSEMM);
+  if (transB) {
+    fprintf(stderr, "spmm: transB is not supported (no call site of the reference uses it)\n");
+    exit(EXIT_FAILURE);
+  }
+  gaib_ctx* c = C();
+  const int* rp = A_idx_ptr;
+  const uint32_t* ci = reinterpret_cast<const uint32_t*>(A_nnz_idx);
+  const float* val = A_nonzeros;
+  int *rpT = NULL, *ciT = NULL;
+  float* valT = NULL;
+  size_t rows = x, cols = z;
+  if (transA) {  // C[x*y] = A^T . B for A [z x x]: transpose once, then the same row-major aggregation
+    rpT = gaib_host::dmalloc<int>(x + 1);
+    ciT = gaib_host::dmalloc<int>(nnz > 0 ? nnz : 1);
+    valT = gaib_host::dmalloc<float>(nnz > 0 ? nnz : 1);
+    GAIB_OR_DIE(gaib_csr2csc(c, (int)z, (int)x, (int)nnz, A_nonzeros, A_idx_ptr, A_nnz_idx, valT, rpT, ciT));
+    rp = rpT;
+    ci = reinterpret_cast<const uint32_t*>(ciT);
+    val = valT;
+  }
+  gaib_graph* g = NULL;
+  GAIB_OR_DIE(gaib_graph_create_rect(c, (int64_t)rows, (int64_t)cols, (int64_t)nnz, rp, 32, ci, 1, &g));
+  GAIB_OR_DIE(gaib_spmm_ex(c, g, GAIB_W_EDGE, val, (int)y, B, C_, accum ? GAIB_ACCUMULATE : 0));
+  GAIB_OR_DIE(gaib_sync(c));  // the graph and the transposed arrays are released below
+  GAIB_OR_DIE(gaib_graph_destroy(g));
+  if (transA) {
+    GAIB_OR_DIE(gaib_free(c, rpT));
+    GAIB_OR_DIE(gaib_free(c, ciT));
+    GAIB_OR_DIE(gaib_free(c, valT));
+  }
+}
+static uint64_t g_rng_stream = 1;  // (the reference seeds cuRAND with 1, random.cpp:76-78)
+void rng_uniform_gpu(size_t n, const float_t a, const float_t b, float_t* r) {
+  GAIB_OR_DIE(gaib_rng_uniform(C(), (int64_t)n, a, b, g_rng_stream++, r));
+}
+void gpu_rng_uniform(size_t n, float* r) { rng_uniform_gpu(n, 0.f, 1.f, r); }
+
 void float_malloc_device64(size_t n, float_t*& ptr) { ptr = gaib_host::dmalloc<float>(n); }
 void float_malloc_device(int n, float_t*& ptr) { ptr = gaib_host::dmalloc<float>((size_t)n); }
 void float_free_device(float_t*& ptr) { GAIB_OR_DIE(gaib_free(C(), ptr)); ptr = NULL; }

@@ -49,6 +49,9 @@ SIGNATURES = {
     "gaibl_set_comm": (None, [_vp]),
     "gaibl_graph_halo_plan": (_vp, [_vp]),
     "gaibl_graph_set_halo_plan": (None, [_vp, _vp, _vp]),
+    "gaibl_graph_set_partition_mode": (None, [_vp, _i]),
+    "gaibl_graph_set_halo_link_rows": (None, [_vp, C.c_int64]),
+    "gaibl_graph_partition_mode": (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
     "gaibl_time_op": (C.c_double, [C.c_char]),
@@ -147,6 +150,24 @@ class LGraph:
         self._halo_graph = halo_graph  # keep alive
         load().gaibl_graph_set_halo(self.h, halo_graph.h, C.cast(self._cb[0], C.c_void_p),
                                     C.cast(self._cb[1], C.c_void_p), None)
+
+    PART_AUTO, PART_SPLIT, PART_CLASSES, PART_ONEPASS, PART_ONEPASS_ALL = -1, 0, 1, 2, 3
+    PART_NAMES = {0: "split", 1: "classes", 2: "onepass"}
+
+    def set_partition_mode(self, mode: int):
+        """how a partitioned graph aggregates (LearningGraph::partition_mode): PART_SPLIT = the column split over all rows,
+        PART_CLASSES = interior rows in one pass + column split of the boundary rows, PART_ONEPASS = interior rows in one
+        pass + boundary rows in one pass over [owned | halo]; PART_AUTO = by the rule"""
+        load().gaibl_graph_set_partition_mode(self.h, int(mode))
+
+    def set_halo_link_rows(self, rows: int):
+        load().gaibl_graph_set_halo_link_rows(self.h, int(rows))
+
+    def partition_mode(self, length: int):
+        """(mode, boundary rows, boundary edges): decides and builds the class graphs on first use"""
+        nb, be = C.c_int64(), C.c_int64()
+        m = load().gaibl_graph_partition_mode(self.h, int(length), C.byref(nb), C.byref(be))
+        return m, nb.value, be.value
 
     def set_halo_plan(self, halo_graph: capi.Graph, plan: "capi.Halo"):
         """the exchange runs behind the C ABI (gaib_halo_exchange_begin/end inside the C++ aggregators)"""

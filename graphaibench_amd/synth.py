@@ -181,14 +181,40 @@ def _sample(cdf, perm, k: int, gen, device):
     return torch.cat(out) if out else torch.empty(0, dtype=torch.int64, device=device)
 
 
+def _band_sampler(cdf, perm, lo: int, hi: int):
+    """the power-law weights of one range restricted to the local ids [lo, hi): (cdf over those ids, lo)"""
+    w = torch.empty_like(cdf)
+    w[0] = cdf[0]
+    w[1:] = cdf[1:] - cdf[:-1]
+    by_id = torch.empty_like(w)
+    by_id[perm] = w  # perm[r] = the id that carries the r-th largest weight
+    c = torch.cumsum(by_id[lo:hi], 0)
+    return c / c[-1], lo
+
+
+def _sample_band(band, k: int, gen, device):
+    cdf, lo = band
+    out = []
+    step = 1 << 24
+    for s in range(0, k, step):
+        r = torch.rand(min(step, k - s), dtype=torch.float64, generator=gen, device=device)
+        out.append(torch.searchsorted(cdf, r).clamp_(max=cdf.numel() - 1) + lo)
+    return torch.cat(out) if out else torch.empty(0, dtype=torch.int64, device=device)
+
+
 def block_rows(name: str, rank: int, world: int, seed: int = 42, cut_fraction: float = 0.1, device="cuda",
-               scale: float = 1.0, selfloops: bool = False) -> BlockRows:
+               scale: float = 1.0, selfloops: bool = False, boundary: str = "uniform", band: float = 0.2) -> BlockRows:
     """Rows [rank*nv_p, (rank+1)*nv_p) of a symmetric global graph with world*nv_p vertices.  Each
     vertex range is a Chung-Lu graph of the named shape; a fraction `cut_fraction` of a range's
     stored entries point into the other ranges (spread evenly, endpoints drawn by the same
     power-law weights).  Block (p, q) is generated from a seed shared by p and q, so both owners
     see the same undirected edges.  cut_fraction models the partitioner: ~(world-1)/world is a
-    random vertex order, small values a locality-preserving (METIS-like) order."""
+    random vertex order, small values a locality-preserving (METIS-like) order.
+    boundary = "uniform": a cut edge may end at ANY vertex of the two ranges -- with 50 edges per vertex nearly every row
+    then has a neighbour elsewhere, which no partitioner produces.  boundary = "clustered": the cut edges land on a
+    BOUNDARY BAND, the first `band` share of every range's ids, cut into world - 1 slices, one facing each peer (what a
+    partition by METIS or a breadth-first order looks like: most vertices are interior, the cut runs through a surface):
+    the same number of cut edges, on band x band endpoints drawn by the same weights restricted to the slices."""
     device = torch.device(device)
     nv, nnz, max_deg, _, _ = SHAPES[name]
     nv_p = max(int(nv * scale), 16)
@@ -228,8 +254,19 @@ def block_rows(name: str, rank: int, world: int, seed: int = 42, cut_fraction: f
             gen.manual_seed(seed * 7919 + a_p * 65537 + b_p)
             ca, pa = sampler(a_p)
             cb, pb = sampler(b_p)
-            a = _sample(ca, pa, m_x, gen, device)  # local id in range a_p
-            b = _sample(cb, pb, m_x, gen, device)  # local id in range b_p
+            if boundary == "clustered":
+                nb = max(int(band * nv_p), world - 1)
+
+                def face(owner, peer):  # the slice of owner's band that faces peer
+                    k = peer if peer < owner else peer - 1
+                    return (k * nb) // (world - 1), max(((k + 1) * nb) // (world - 1), (k * nb) // (world - 1) + 1)
+
+                a = _sample_band(_band_sampler(ca, pa, *face(a_p, b_p)), m_x, gen, device)
+                b = _sample_band(_band_sampler(cb, pb, *face(b_p, a_p)), m_x, gen, device)
+            else:
+                assert boundary == "uniform", boundary
+                a = _sample(ca, pa, m_x, gen, device)  # local id in range a_p
+                b = _sample(cb, pb, m_x, gen, device)  # local id in range b_p
             if rank == a_p:
                 keys.append(a * n_global + (b + b_p * nv_p))
             else:

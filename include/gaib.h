@@ -148,6 +148,7 @@ int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib_graph** ou
                        int64_t* d_old_of_new);
 int64_t gaib_graph_nv(const gaib_graph* g);
 int64_t gaib_graph_ne(const gaib_graph* g);
+int64_t gaib_graph_nc(const gaib_graph* g); /* columns = rows of the feature table its column ids index (nv unless rectangular) */
 const int64_t* gaib_graph_rowptr(const gaib_graph* g);  /* device, int64[nv+1] */
 const uint32_t* gaib_graph_colidx(const gaib_graph* g); /* device, uint32[ne]  */
 /* compute_vertex_data (lgraph.cpp:22-34 / lgraph.cu:94-105): deg^-1/2, 0 for isolated. */
@@ -321,6 +322,44 @@ int gaib_gat_alpha_grads(gaib_ctx* ctx, int64_t nv, int len, int heads, const fl
  *   d_out_e[rev(e)] = d_in_e[e].  The reverse-edge permutation is built once per graph. */
 int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float* d_out_e);
 
+/* ---- row classes of a vertex-range partition ---------------------------------------------------------
+ * The reference partitioner's local graph marks the owned (master) rows and appends the halo vertices behind them
+ * (src/partitioner/graph_partition.cc:70-80,128-178, include/graph_partition.h:21-22,36-37).  An owned row whose edges all
+ * stay inside the range -- an INTERIOR row -- needs nothing from the exchange; only BOUNDARY rows wait for the halo rows.
+ * gaib_graph_split_classes cuts a rank's owned-column graph and halo-column graph (same rows, gaib_graph_set_vertex_norm
+ * applied to both) into class graphs.  Each is COMPACT -- row k is the k-th row of the class, ascending -- and carries a
+ * row map: every aggregation entry point (gaib_spmm*, gaib_spmm_gemm*) treats row k of such a graph as row map[k] of its
+ * [n_rows x len] output / partial-sum / rows2 matrices, so the classes of one partition fill disjoint rows of the same
+ * matrices.  Edge order inside a row is kept: the sums are those of the graphs the classes were cut from.
+ *   *interior : rows without halo-column edges                               columns: owned
+ *   *bnd_own  : the boundary rows' owned-column edges                        columns: owned
+ *   *bnd_halo : the boundary rows' halo-column edges                         columns: halo
+ *   *bnd_full : both, per row [owned-column ..., halo-column ...]              columns: [owned | halo]: halo id + n_own
+ * Any of the four out pointers may be NULL (not built).  h_n_boundary / h_boundary_edges (optional): boundary rows and
+ * their edges.  Class graphs take GAIB_W_GCN / _MEAN / _MEAN_T / single-head _EDGE weights.
+ * flags: GAIB_SPLIT_ALL_BOUNDARY = every row counts as a boundary row (*interior gets no rows): where next to no row is
+ * interior, one pass over all rows of bnd_full beats two launches. */
+#define GAIB_SPLIT_ALL_BOUNDARY 1
+int gaib_graph_split_classes(gaib_ctx* ctx, const gaib_graph* g_own, const gaib_graph* g_halo, gaib_graph** interior,
+                             gaib_graph** bnd_own, gaib_graph** bnd_halo, gaib_graph** bnd_full, int64_t* h_n_boundary,
+                             int64_t* h_boundary_edges, int flags);
+/* the row map by hand (uint32 [nv] device array, copied; n_out_rows = rows of the matrices it indexes; NULL removes it) */
+int gaib_graph_set_row_map(gaib_ctx* ctx, gaib_graph* g, const uint32_t* d_row_map, int64_t n_out_rows);
+const uint32_t* gaib_graph_row_map(const gaib_graph* g); /* device, uint32[nv], or NULL */
+/* Aggregation over TWO feature tables: column ids below n_first index d_in, the others d_in2 (row id - n_first) -- a
+ * rank's own rows and the halo table behind them, two allocations read side by side in one pass over [owned | halo]
+ * (bnd_full above, n_first = n_own).  Otherwise gaib_spmm_ex / gaib_spmm_gemm(2) (d_rows2 / d_W2: both or NULL). */
+int gaib_spmm_2t(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len, const float* d_in,
+                 const float* d_in2, int64_t n_first, float* d_out, int flags);
+int gaib_spmm_gemm_2t(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len_in, const float* d_in,
+                      const float* d_in2, int64_t n_first, float* d_agg, const float* d_W, int transW, const float* d_rows2,
+                      const float* d_W2, int len_out, float* d_out, int flags);
+/* 1 if gaib_spmm_gemm(2) would run this shape as ONE kernel (shape only: widths, weight kind, the option "spmm_fuse").
+ * The classes of a partition fill one output: all of them take the fused kernel or none does -- on a class graph
+ * gaib_spmm_gemm* returns GAIB_ERR_UNSUPPORTED for a shape this says 0 to, and the caller aggregates class by class
+ * and multiplies all rows at once. */
+int gaib_spmm_gemm_fusable(gaib_ctx* ctx, int weight_kind, int len_in, int len_out, int dual);
+
 /* ---- aggregation fused with the dense product: the `din <= dout` branch of the layers
  * (gcn_layer.cpp:19-24, sage_layer.cpp:25-34): agg = A.in (gaib_spmm semantics, [nv x len_in]),
  * out = act(agg . op(W)), op(W) = W [len_in x len_out] or, with transW, W^T for W [len_out x len_in]
@@ -362,6 +401,20 @@ int gaib_dropout(gaib_ctx* ctx, int64_t n, float scale, float drop_rate, uint64_
                  const float* d_in, uint8_t* d_masks, float* d_out);
 int gaib_d_dropout(gaib_ctx* ctx, int64_t n, float scale, const float* d_in,
                    const uint8_t* d_masks, float* d_out);
+
+/* bias_mv (include/utils/math_functions.hh:36; math_functions.cu:207-221): x[i, j] += b[j] for x [n x len] */
+int gaib_bias_add(gaib_ctx* ctx, int64_t n, int len, float* d_x, const float* d_b);
+/* reduce_sum (math_functions.hh:37-38; math_functions.cpp:246-262, .cu:224-238): a[j] = sum_i x[i, j], overwritten.
+ * Deterministic (two levels in a fixed order; the reference's CUDA kernel adds into a[j] from all threads unguarded). */
+int gaib_colsum(gaib_ctx* ctx, int64_t n, int len, const float* d_x, float* d_a);
+/* rng_uniform_gpu / gpu_rng_uniform (math_functions.hh:156,174; math_functions.cu:39-50): r[i] uniform on [a, b) from the
+ * library's counter RNG (element i of stream `seed`).  The reference draws cuRAND XORWOW numbers: streams differ. */
+int gaib_rng_uniform(gaib_ctx* ctx, int64_t n, float a, float b, uint64_t seed, float* d_r);
+/* csr2csc (math_functions.hh:45; cusparseCsr2cscEx2, math_functions.cu:345-358): the transpose of a general
+ * [nrows x ncols] CSR matrix with 32-bit offsets, all arrays in device memory: d_rowptrT [ncols + 1], d_colidxT [nnz]
+ * (row ids, ascending inside a column), d_valuesT [nnz] (d_values / d_valuesT may both be NULL: structure only).  Syncs. */
+int gaib_csr2csc(gaib_ctx* ctx, int nrows, int ncols, int nnz, const float* d_values, const int* d_rowptr,
+                 const int* d_colidx, float* d_valuesT, int* d_rowptrT, int* d_colidxT);
 
 /* ---- loss / metrics: softmax_cross_entropy_gpu, d_softmax_cross_entropy_gpu,
  * masked_avg_loss_gpu, masked_accuracy_single (math_functions.cu:516-564,749-761,886-942) ---- */
@@ -472,6 +525,8 @@ int gaib_halo_create(gaib_comm* comm, const int64_t* h_send_counts, const int64_
 int gaib_halo_destroy(gaib_halo* halo);
 int64_t gaib_halo_rows(const gaib_halo* halo);      /* rows of the halo table */
 int64_t gaib_halo_send_rows(const gaib_halo* halo); /* rows this rank packs per exchange */
+int64_t gaib_halo_link_rows(const gaib_halo* halo); /* the most rows one peer pair moves per exchange, either direction:
+                                                      * what one xGMI link carries (every pair has its own) */
 int64_t gaib_halo_bytes_sent(const gaib_halo* halo);
 /* one exchange = begin (pack the requested rows of d_rows [n_own x len] on the compute stream, start moving them)
  * ... independent work on the compute stream (the owned-column edges of the aggregation) ... end (the compute stream

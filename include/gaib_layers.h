@@ -84,6 +84,15 @@ uint32_t gaibl_sample_subgraph(uint32_t nv, uint32_t ne, const uint32_t* rowptr,
                                uint32_t** sub_rowptr, uint32_t** sub_colidx, uint32_t** kept_ids);
 void gaibl_free_host(void* p);
 
+/* row classes of a partitioned graph (LearningGraph::partition_mode, include/gnn/lgraph.h): mode 0 = column split over
+ * all rows, 1 = interior rows in one pass + column split of the boundary rows, 2 = interior rows in one pass + the
+ * boundary rows in one pass over [owned | halo]; -1 = by the rule (default; GAIB_PART_MODE overrides).
+ * gaibl_graph_partition_mode decides (once per graph, for aggregations of `len` columns), builds the class graphs and
+ * reports the mode, the boundary rows and their edges. */
+void gaibl_graph_set_partition_mode(void* graph, int mode);
+void gaibl_graph_set_halo_link_rows(void* graph, int64_t rows); /* callback transports: rows one peer pair moves per exchange */
+int gaibl_graph_partition_mode(void* graph, int len, int64_t* n_boundary, int64_t* boundary_edges);
+
 void* gaibl_adam_create(float lr);
 void gaibl_adam_free(void* opt);
 

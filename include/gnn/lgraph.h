@@ -37,6 +37,16 @@ class LearningGraph {
   index_t* gat_tperm_;
   index_t gat_n_halo_;
   bool owns_partition_;  // make_partitioned_graph built halo_dev_ / halo_plan_ / gat_*: dealloc() releases them too
+  // Row classes of the partition (gaib_graph_split_classes; the reference partitioner's owned rows / halo vertices,
+  // src/partitioner/graph_partition.cc:70-80): INTERIOR rows -- no halo-column edge -- are aggregated in one pass (with
+  // the dense product riding on it) while the halo rows travel; BOUNDARY rows either keep the column split (owned-column
+  // edges meanwhile, halo-column edges after arrival: everything overlaps, one more pass over their partial sums) or are
+  // aggregated in ONE pass over [owned | halo] after arrival (no partial sums; only the interior work hides the
+  // exchange).  Decided once per graph at its first aggregation (partition_mode) and built then.
+  gaib_graph *cls_int_, *cls_bown_, *cls_bhalo_, *cls_bfull_;
+  int part_mode_;         // PART_*, -1 = not decided yet
+  int part_mode_wanted_;  // set_partition_mode / GAIB_PART_MODE; -1 = by the rule
+  int64_t n_boundary_, boundary_edges_, link_rows_;
 
  public:
   typedef size_t iterator;
@@ -44,7 +54,8 @@ class LearningGraph {
       : is_device(use_gpu), num_vertices_(0), num_edges_(0), max_degree(0), rowptr_(NULL),
         colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_dev_(NULL),
         halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL), gat_full_(NULL), gat_t_(NULL),
-        gat_tperm_(NULL), gat_n_halo_(0), owns_partition_(false) {}
+        gat_tperm_(NULL), gat_n_halo_(0), owns_partition_(false), cls_int_(NULL), cls_bown_(NULL), cls_bhalo_(NULL),
+        cls_bfull_(NULL), part_mode_(-1), part_mode_wanted_(-1), n_boundary_(0), boundary_edges_(0), link_rows_(-1) {}
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -114,6 +125,24 @@ class LearningGraph {
   gaib_graph* gat_transposed_graph() { return gat_t_; }
   const index_t* gat_tperm() { return gat_tperm_; }
   size_t gat_n_halo() { return gat_n_halo_; }
+  // ---- row classes (see above) ----
+  enum { PART_SPLIT = 0,    // round 3: owned-column pass over ALL rows, halo-column pass over all rows
+         PART_CLASSES = 1,  // interior rows in one pass; boundary rows by the column split
+         PART_ONEPASS = 2,  // interior rows in one pass; boundary rows in one pass over [owned | halo] after arrival
+         PART_ONEPASS_ALL = 3  // (a wish only; partition_mode reports PART_ONEPASS) every row counts as a boundary row:
+                               // one pass over all rows of one [owned | halo] graph after arrival
+  };
+  void set_partition_mode(int mode) { part_mode_wanted_ = mode; part_mode_ = -1; }  // -1: by the rule
+  // callback transports (set_halo): the most rows one peer pair moves per exchange (the plan form knows: gaib_halo_link_rows)
+  void set_halo_link_rows(int64_t rows) { link_rows_ = rows; }
+  // the mode of this graph's aggregations of `len` columns; the first call decides and builds the class graphs
+  int partition_mode(int len);
+  gaib_graph* class_interior() { return cls_int_; }
+  gaib_graph* class_boundary_own() { return cls_bown_; }
+  gaib_graph* class_boundary_halo() { return cls_bhalo_; }
+  gaib_graph* class_boundary_full() { return cls_bfull_; }
+  int64_t n_boundary() const { return n_boundary_; }
+  int64_t boundary_edges() const { return boundary_edges_; }
   bool has_halo() const { return halo_dev_ != NULL; }
   gaib_graph* halo_graph() { return halo_dev_; }
   void halo_begin(int len, const float* d_in);

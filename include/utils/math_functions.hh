@@ -43,6 +43,23 @@ float masked_accuracy_multi(int begin, int end, int count, int num_classes, mask
                             label_t* ground_truth);
 float masked_accuracy_single(int begin, int end, int count, int num_classes, mask_t* masks,
                              float* preds, label_t* ground_truth);
+// bias and its gradient (reference math_functions.hh:36-38; used by the layers when is_bias: gcn_layer.cu:23,34,
+// dense_layer.cpp:48,62).  x [n x len], b / a [len], DEVICE pointers; the vec_t overload receives the sums on the host.
+void bias_mv(int n, int len, float* x, float* b);
+void reduce_sum(int n, int len, float* x, float* a);
+void reduce_sum(int n, int len, float* x, vec_t& a);
+// transpose of a general CSR matrix, 32-bit offsets, device arrays (reference math_functions.hh:45, gat_aggregator.cu:89)
+void csr2csc(int nrows, int ncols, int nnz, const float* values, const int* rowptr, const int* colidx, float* valuesT,
+             int* rowptrT, int* colidxT);
+// C[x*y] (=|+=) op(A)[x*z] . B[z*y], A sparse in CSR with 32-bit offsets, device arrays (reference math_functions.hh:54-57;
+// csrmm_gpu, math_functions.cu:419-429).  temp is unused (the reference's cuSPARSE path transposes through it); transB must
+// be false, as in the reference's own call sites
+void spmm(size_t x, size_t y, size_t z, size_t nnz, float* A_nonzeros, int* A_idx_ptr, int* A_nnz_idx, const float* B,
+          float* C, float* temp = NULL, bool transA = false, bool transB = false, bool accum = false);
+// uniform random numbers on the device (reference math_functions.hh:156,174): [a, b) and [0, 1); a process-wide stream
+// counter stands in for cuRAND's generator state
+void rng_uniform_gpu(size_t n, const float_t a, const float_t b, float_t* r);
+void gpu_rng_uniform(size_t n, float* r);
 // symmetric sparse transpose of per-edge values on the device graph (math_functions.cpp:46-74)
 class LearningGraph;
 void symmetric_csr_transpose(LearningGraph& g, const float* A_nonzeros, float* B_nonzeros);

@@ -147,7 +147,7 @@ def sage_d_aggregate(g: Graph, x) -> np.ndarray:
 
 def spmm_edge(g: Graph, ew, x) -> np.ndarray:
     x, ew = _f(x), _f(ew)
-    out = np.empty_like(x)
+    out = np.empty((g.nv, x.shape[1]), np.float32)  # (a rectangular matrix has g.nv rows and gathers from x's)
     lib().orc_spmm_edge(C.c_int64(g.nv), _p(g.rowptr), _p(g.colidx), _p(ew), C.c_int(x.shape[1]), _p(x), _p(out))
     return out
 

@@ -6,7 +6,15 @@ are exact (the graph is symmetric: the rows a peer needs from this rank are the 
 the peer's range), so the pack runs as in the real step; what is NOT measured is the wire time, which is reported as
 bytes and as the time 7 xGMI links would need at the guide's 153 GB/s per link.
 
-    python scripts/papers_shard.py [--cut 0.1 0.875] [--rank 0] [--steps 5]
+    python scripts/papers_shard.py [--cut 0.1 0.875] [--rank 0] [--steps 5] [--boundary uniform clustered]
+                                   [--mode split classes onepass]
+
+boundary: where the generator puts the cut edges (synth.block_rows) -- anywhere (uniform: nearly every row then has a remote
+neighbour) or on a boundary band of the range (clustered: what a METIS / breadth-first partition looks like).
+mode: how the rank aggregates (LearningGraph::partition_mode): split = round 3's column split over all rows; classes =
+interior rows in one pass, boundary rows by the column split; onepass = interior rows in one pass, boundary rows in one pass
+over [owned | halo] after the halo rows arrived; auto = the library's rule.  The record says what of a step can overlap the
+exchange (`overlappable_ms`) next to the time 7 xGMI links would need.
 
 cut = fraction of a rank's edges that leave its vertex range: 0.875 = a random vertex order (7/8 of the neighbours
 live elsewhere), 0.1 = a locality-preserving order (METIS-like).  Development aid + the numbers quoted in DESIGN 6.
@@ -27,13 +35,17 @@ WORLD, D = 8, 128
 XGMI_LINK_GBS = 153.0
 
 
-def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M"):
+MODES = {"split": L.LGraph.PART_SPLIT, "classes": L.LGraph.PART_CLASSES, "onepass": L.LGraph.PART_ONEPASS,
+         "onepass_all": L.LGraph.PART_ONEPASS_ALL, "auto": L.LGraph.PART_AUTO}
+
+
+def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",)):
     t0 = time.time()
     # papers: the named graph is the GLOBAL one (each rank owns 1/8 of it); products: bench.py's weak-scaling
     # workload, one products-shaped range per rank
     per_rank = scale / WORLD if shape == "ogbn-papers100M" else scale
     rows = synth.block_rows(shape, rank, WORLD, seed=42, cut_fraction=cut, device="cuda", scale=per_rank,
-                            selfloops=True)
+                            selfloops=True, boundary=boundary, band=band)
     nv = rows.n_local
     lo, hi = rank * nv, (rank + 1) * nv
     rp_own, ci_own, rp_halo, ci_halo, halo, deg = gd.split_by_owner(rows.rowptr, rows.colidx_global, lo, hi)
@@ -55,14 +67,27 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M"):
     vd = torch.where(degf > 0, degf.rsqrt(), torch.zeros_like(degf))
     inv = torch.where(degf > 0, 1.0 / degf, torch.zeros_like(degf))
     pick = torch.randint(0, nv, (max(n_halo, 1),), device="cuda")
-    g_own = ctx.graph(rp_own, ci_own)
+    ne_own, ne_halo = int(ci_own.numel()), int(ci_halo.numel())
+    halo_table = torch.randn(max(n_halo, 1), D, device="cuda")
+    setup_s = time.time() - t0
+    x_in = torch.randn(nv, D, device="cuda")
+    g_in = torch.randn(nv, D, device="cuda")
+    for mode in modes:
+        run_mode(ctx, mode, locals(), steps)
+
+
+def run_mode(ctx, mode, S, steps):
+    """one mode on the shard held in S (run()'s locals)"""
+    (rank, cut, scale, shape, boundary, band, nv, n_halo, ne_own, ne_halo, halo_table, send_idx, send_counts, recv_counts, vd, inv,
+     pick, setup_s) = (S[k] for k in ("rank", "cut", "scale", "shape", "boundary", "band", "nv", "n_halo", "ne_own", "ne_halo",
+                                      "halo_table", "send_idx", "send_counts", "recv_counts", "vd", "inv", "pick", "setup_s"))
+    g_own = ctx.graph(S["rp_own"], S["ci_own"])
     g_own.set_vertex_norm(vd, vd, inv, row_inv_deg=inv)
     lg = L.LGraph.adopt(g_own)
-    g_halo = ctx.graph(rp_halo, ci_halo, ncols=max(n_halo, 1))
+    g_halo = ctx.graph(S["rp_halo"], S["ci_halo"], ncols=max(n_halo, 1))
     g_halo.set_vertex_norm(vd, vd[pick], inv[pick], row_inv_deg=inv)
-    ne_own, ne_halo = int(ci_own.numel()), int(ci_halo.numel())
-    del rp_own, ci_own, rp_halo, ci_halo, pick
-    halo_table = torch.randn(max(n_halo, 1), D, device="cuda")
+    lg.set_partition_mode(MODES[mode])
+    lg.set_halo_link_rows(max(max(send_counts), max(recv_counts)))
     sendbuf = torch.empty(max(send_idx.numel(), 1), D, device="cuda")
     pack_calls = [0]
 
@@ -75,18 +100,26 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M"):
             capi._check(ctx.lib.gaib_gather_scatter_rows(ctx.h, send_idx.numel(), pack_row.data_ptr(), pack_slot.data_ptr(),
                                                          length, src_ptr, sendbuf.data_ptr()), "gaib_gather_scatter_rows")
             pack_calls[0] += 1
+        if timing[0]:  # what runs between here and end() is what the exchange can hide under
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            windows.append(ev)
 
     def end(length):  # (and finish here: the table is resident instead)
+        if timing[0] and windows:
+            windows[-1][1].record()
         return halo_table.data_ptr()
 
+    timing, windows = [False], []
+
     lg.set_halo(g_halo, begin, end)
+    mode_used, n_bnd, bnd_edges = lg.partition_mode(D)
     layer = L.Layer(L.GCN, 1, nv, D, D, lg, act=True)
-    layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda"))
-    layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda"))
+    layer.write(L.FEAT_IN, S["x_in"])
+    layer.write(L.GRAD_IN, S["g_in"])
     fo = torch.empty(nv, D, device="cuda")
     go = torch.empty(nv, D, device="cuda")
     torch.cuda.synchronize()
-    setup_s = time.time() - t0
 
     def step():
         layer.forward(fo)
@@ -103,9 +136,15 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M"):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     ctx.prof_enable(False)
+    timing[0] = True  # one more step with the begin..end windows timed (events would perturb the timed steps)
+    step()
+    torch.cuda.synchronize()
+    timing[0] = False
+    overlap_ms = [a.elapsed_time(b) for a, b in windows]
     exchanges = (pack_calls[0] * steps) // (steps + 2) // steps if send_idx.numel() else 2
     br = {}
-    for k in ("spmm_gemm_fused", "spmm_light", "spmm_heavy", "sgemm", "gather_rows"):
+    for k in ("spmm_gemm_fused", "spmm_light", "spmm_heavy", "sgemm", "gather_rows", "part_fused", "part_fused_acc", "part_fused_2t",
+              "part_light", "part_light_acc", "part_light_2t"):
         n, t = ctx.prof_get(k)
         if n:
             br[k] = round(t / steps, 3)
@@ -117,16 +156,23 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M"):
     pack_ms = (time.perf_counter() - t0) / 3 * 1e3
     per_link = max(max(send_counts), max(recv_counts)) * D * 4
     out = dict(config="%s-shaped, vertex-range x8, rank %d's shard on one GPU" % (shape, rank), cut_fraction=cut,
+               boundary=boundary, band=band if boundary == "clustered" else None, mode_asked=mode,
+               mode=L.LGraph.PART_NAMES[mode_used], boundary_rows=n_bnd, boundary_row_share=n_bnd / nv,
+               boundary_edges=bnd_edges, boundary_edge_share=bnd_edges / (ne_own + ne_halo) if mode_used else None,
                scale=scale, n_own=nv, ne_own_columns=ne_own, ne_halo_columns=ne_halo, n_halo_rows=n_halo,
                send_rows=int(send_idx.numel()), halo_table_gb=n_halo * D * 4 / 1e9,
                exchanges_per_step=exchanges,
                send_gb_per_exchange=send_idx.numel() * D * 4 / 1e9, recv_gb_per_exchange=n_halo * D * 4 / 1e9,
                xgmi_ms_per_exchange_at_153GBs_per_link=per_link / (XGMI_LINK_GBS * 1e9) * 1e3,
                compute_ms_per_step=ms, pack_ms_per_exchange=pack_ms, breakdown_ms_per_step=br,
+               # per exchange: the kernel time between its begin and its end -- what the wire time can hide under
+               overlappable_ms_per_exchange=[round(v, 3) for v in overlap_ms],
                gedges_per_s_compute_only=2 * (ne_own + ne_halo) / ms / 1e6, setup_s=round(setup_s, 1),
                hbm_gb_in_use=torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9)
     print(json.dumps(out), flush=True)
-    del layer, lg, g_halo, halo_table, sendbuf, fo, go
+    layer.close()
+    lg.close()
+    del layer, lg, g_halo, sendbuf, fo, go
     torch.cuda.empty_cache()
 
 
@@ -138,10 +184,18 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the whole graph (CPU-sized smoke runs)")
     ap.add_argument("--shape", default="ogbn-papers100M", choices=["ogbn-papers100M", "ogbn-products"],
                     help="ogbn-products = one rank of bench.py --gpus 8 (weak scaling, a products-shaped range per rank)")
+    ap.add_argument("--boundary", nargs="+", default=["uniform"], choices=["uniform", "clustered"])
+    ap.add_argument("--band", type=float, default=0.2, help="clustered: share of a range's ids that form its boundary band")
+    ap.add_argument("--mode", nargs="+", default=["split", "classes", "onepass", "onepass_all", "auto"], choices=list(MODES))
+    ap.add_argument("--link-gbs", type=float, default=None, help="GAIB_LINK_GBS for the auto rule (default: the library's 100)")
     args = ap.parse_args()
+    if args.link_gbs is not None:
+        import os
+        os.environ["GAIB_LINK_GBS"] = str(args.link_gbs)
     ctx = L.init(0)
     for cut in args.cut:
-        run(ctx, args.rank, cut, args.steps, args.scale, args.shape)
+        for boundary in args.boundary:
+            run(ctx, args.rank, cut, args.steps, args.scale, args.shape, boundary, args.band, args.mode)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,277 @@
+"""Row classes of a vertex-range partition (gaib_graph_split_classes, gaib_spmm_2t, gaib_spmm_gemm_2t; csrc/spmm_part.hip):
+interior rows in one pass while the halo rows travel, boundary rows by the column split or in one pass over
+[owned | halo] -- every form against the oracle's run on the GLOBAL graph and against the round-3 split (owned-column
+pass over all rows + halo-column pass), with which the sums must agree bit for bit on light rows (same edge order)."""
+import numpy as np
+import pytest
+import torch
+
+from graphaibench_amd import capi
+from oracle import binding as orc
+from util import random_graph, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def feat(n, d, seed):
+    return np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+
+
+class Shard:
+    """rows [lo, hi) of a global graph the way dist.split_by_owner / host/partition.cpp cut them"""
+
+    def __init__(self, ctx, g_o, lo, hi):
+        self.lo, self.hi, self.n = lo, hi, hi - lo
+        rp, ci = g_o.rowptr.astype(np.int64), g_o.colidx.astype(np.int64)
+        e0, e1 = rp[lo], rp[hi]
+        cols = ci[e0:e1]
+        rows = np.repeat(np.arange(self.n), np.diff(rp[lo:hi + 1]))
+        own = (cols >= lo) & (cols < hi)
+        self.halo = np.unique(cols[~own])
+
+        def csr(mask, ids):
+            cnt = np.bincount(rows[mask], minlength=self.n)
+            return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ids.astype(np.int32)
+
+        self.rp_own, self.ci_own = csr(own, cols[own] - lo)
+        self.rp_halo, self.ci_halo = csr(~own, np.searchsorted(self.halo, cols[~own]))
+        deg = np.diff(rp).astype(np.float32)
+        vd = g_o.vertex_data()
+        inv = (1.0 / deg.astype(np.float64)).astype(np.float32)
+        nh = max(len(self.halo), 1)
+        pad = lambda a: a if len(self.halo) else np.zeros(1, np.float32)
+        self.g_own = ctx.graph(self.rp_own, self.ci_own)
+        self.g_own.set_vertex_norm(dev(vd[lo:hi]), dev(vd[lo:hi]), dev(inv[lo:hi]), row_inv_deg=dev(inv[lo:hi]))
+        self.g_halo = ctx.graph(self.rp_halo, self.ci_halo, ncols=nh)
+        self.g_halo.set_vertex_norm(dev(vd[lo:hi]), dev(pad(vd[self.halo])), dev(pad(inv[self.halo])), row_inv_deg=dev(inv[lo:hi]))
+        self.cls = ctx.split_classes(self.g_own, self.g_halo)
+        self.is_bnd = np.diff(self.rp_halo) > 0
+        self.light = (np.diff(self.rp_own) <= 1024) & (np.diff(self.rp_halo) <= 1024)
+
+    def tables(self, x):
+        xo = dev(x[self.lo:self.hi])
+        xh = dev(x[self.halo]) if len(self.halo) else torch.zeros(1, x.shape[1], device="cuda")
+        return xo, xh
+
+
+def make_shard(ctx, n=3000, deg=14, lo=900, hi=2100, seed=5, selfloop=True, hub=1500):
+    rp, ci = random_graph(n, deg, seed=seed, power_law=True, hub_deg=hub)
+    g_o = orc.Graph(rp, ci)
+    if selfloop:
+        g_o = g_o.add_selfloop()
+    return g_o, Shard(ctx, g_o, lo, hi)
+
+
+def test_class_graphs_structure(ctx):
+    g_o, s = make_shard(ctx)
+    c = s.cls
+    n_b = int(s.is_bnd.sum())
+    assert c["n_boundary"] == n_b and 0 < n_b < s.n
+    gi, gbo, gbh, gbf = c["interior"], c["bnd_own"], c["bnd_halo"], c["bnd_full"]
+    assert gi.nv == s.n - n_b and gbo.nv == gbh.nv == gbf.nv == n_b
+    map_i, map_b = gi.row_map().cpu().numpy(), gbo.row_map().cpu().numpy()
+    assert np.array_equal(map_i, np.nonzero(~s.is_bnd)[0]) and np.array_equal(map_b, np.nonzero(s.is_bnd)[0])
+    assert np.array_equal(gbh.row_map().cpu().numpy(), map_b) and np.array_equal(gbf.row_map().cpu().numpy(), map_b)
+    assert c["boundary_edges"] == gbf.ne == gbo.ne + gbh.ne
+    assert gi.ne + gbo.ne == s.g_own.ne and gbh.ne == s.g_halo.ne
+
+    def rows_of(g):
+        rp, ci = g.rowptr().cpu().numpy(), g.colidx().cpu().numpy().view(np.uint32)
+        return [ci[rp[k]:rp[k + 1]] for k in range(g.nv)]
+
+    for k, r in zip(map_i, rows_of(gi)):
+        assert np.array_equal(r, s.ci_own[s.rp_own[k]:s.rp_own[k + 1]].view(np.uint32))
+    for k, ro, rh, rf in zip(map_b, rows_of(gbo), rows_of(gbh), rows_of(gbf)):
+        eo = s.ci_own[s.rp_own[k]:s.rp_own[k + 1]].view(np.uint32)
+        eh = s.ci_halo[s.rp_halo[k]:s.rp_halo[k + 1]].view(np.uint32)
+        assert np.array_equal(ro, eo) and np.array_equal(rh, eh)
+        assert np.array_equal(rf, np.concatenate([eo, eh + np.uint32(s.n)]))  # [owned ..., halo + n_own ...]
+
+
+KINDS = [(capi.W_GCN, "gcn"), (capi.W_MEAN, "mean"), (capi.W_MEAN_T, "mean_t")]
+
+
+def oracle_rows(g_o, kind, x, lo, hi):
+    if kind == capi.W_GCN:
+        return orc.gcn_aggregate(g_o, x)[lo:hi]
+    if kind == capi.W_MEAN:
+        return orc.sage_aggregate(g_o, x)[lo:hi]
+    return orc.sage_d_aggregate(g_o, x)[lo:hi]
+
+
+@pytest.mark.parametrize("d", [16, 47, 64, 128, 200, 300])
+@pytest.mark.parametrize("kind,name", KINDS)
+def test_class_aggregation_matches_oracle_and_round3_split(ctx, d, kind, name):
+    g_o, s = make_shard(ctx, selfloop=(kind == capi.W_GCN))
+    x = feat(g_o.nv, d, 11)
+    want = oracle_rows(g_o, kind, x, s.lo, s.hi)
+    xo, xh = s.tables(x)
+    # round 3: owned-column pass over all rows, halo-column pass added
+    ref = torch.empty(s.n, d, device="cuda")
+    ctx.spmm(s.g_own, kind, xo, ref)
+    ctx.spmm(s.g_halo, kind, xh, ref, accumulate=True)
+    ref = ref.cpu().numpy()
+    assert rel_err(ref, want) < 1e-5
+    c = s.cls
+    # classes, boundary rows by the column split
+    out1 = torch.full((s.n, d), float("nan"), device="cuda")
+    ctx.spmm(c["interior"], kind, xo, out1)
+    ctx.spmm(c["bnd_own"], kind, xo, out1)
+    ctx.spmm(c["bnd_halo"], kind, xh, out1, accumulate=True)
+    # classes, boundary rows in one pass over [owned | halo]
+    out2 = torch.full((s.n, d), float("nan"), device="cuda")
+    ctx.spmm(c["interior"], kind, xo, out2)
+    ctx.spmm_2t(c["bnd_full"], kind, xo, xh, s.n, out2)
+    for got in (out1.cpu().numpy(), out2.cpu().numpy()):
+        assert np.isfinite(got).all()  # every row belongs to exactly one class
+        assert np.array_equal(got[s.light].view(np.uint32), ref[s.light].view(np.uint32))
+        assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("din,dout", [(128, 128), (64, 32), (100, 128), (128, 47), (16, 16)])
+@pytest.mark.parametrize("kind,name", KINDS)
+@pytest.mark.parametrize("transW", [False, True])
+def test_class_fused_product_matches_round3_split(ctx, din, dout, kind, name, transW):
+    g_o, s = make_shard(ctx, selfloop=(kind == capi.W_GCN), seed=8)
+    if not ctx.spmm_gemm_fusable(kind, din, dout):
+        pytest.skip("shape not fused")
+    x = feat(g_o.nv, din, 3)
+    W = dev(feat(dout, din, 4) if transW else feat(din, dout, 4))
+    xo, xh = s.tables(x)
+    agg_r = torch.empty(s.n, din, device="cuda")
+    y_r = torch.empty(s.n, dout, device="cuda")
+    ctx.spmm(s.g_own, kind, xo, agg_r)
+    ctx.spmm_gemm(s.g_halo, kind, xh, agg_r, W, y_r, transW=transW, relu=True, accumulate=True)
+    want_agg = oracle_rows(g_o, kind, x, s.lo, s.hi)
+    Wh = W.cpu().numpy().astype(np.float64)
+    want_y = np.maximum(want_agg.astype(np.float64) @ (Wh.T if transW else Wh), 0)
+    assert rel_err(agg_r.cpu().numpy(), want_agg) < 1e-5 and rel_err(y_r.cpu().numpy(), want_y) < 2e-5
+    c = s.cls
+    for mode in (1, 2):
+        agg = torch.full((s.n, din), float("nan"), device="cuda")
+        y = torch.full((s.n, dout), float("nan"), device="cuda")
+        ctx.spmm_gemm(c["interior"], kind, xo, agg, W, y, transW=transW, relu=True)
+        if mode == 1:
+            ctx.spmm(c["bnd_own"], kind, xo, agg)
+            ctx.spmm_gemm(c["bnd_halo"], kind, xh, agg, W, y, transW=transW, relu=True, accumulate=True)
+        else:
+            ctx.spmm_gemm_2t(c["bnd_full"], kind, xo, xh, s.n, agg, W, y, transW=transW, relu=True)
+        a, yy = agg.cpu().numpy(), y.cpu().numpy()
+        assert np.isfinite(a).all() and np.isfinite(yy).all()
+        assert np.array_equal(a[s.light].view(np.uint32), agg_r.cpu().numpy()[s.light].view(np.uint32)), mode
+        # same aggregate bits through the same matrix-core product: the same y bits on those rows
+        assert np.array_equal(yy[s.light].view(np.uint32), y_r.cpu().numpy()[s.light].view(np.uint32)), mode
+        assert rel_err(yy, want_y) < 2e-5
+        # the aggregate as scratch (backward): y alone
+        y2 = torch.full((s.n, dout), float("nan"), device="cuda")
+        scratch = torch.empty(s.n, din, device="cuda")
+        ctx.spmm_gemm(c["interior"], kind, xo, scratch, W, y2, transW=transW, relu=True, agg_scratch=True)
+        if mode == 1:
+            ctx.spmm(c["bnd_own"], kind, xo, scratch)
+            ctx.spmm_gemm(c["bnd_halo"], kind, xh, scratch, W, y2, transW=transW, relu=True, accumulate=True, agg_scratch=True)
+        else:
+            ctx.spmm_gemm_2t(c["bnd_full"], kind, xo, xh, s.n, scratch, W, y2, transW=transW, relu=True, agg_scratch=True)
+        assert np.array_equal(y2.cpu().numpy().view(np.uint32), yy.view(np.uint32))
+
+
+@pytest.mark.parametrize("din,dout", [(128, 128), (64, 64)])
+def test_class_fused_two_products_sage(ctx, din, dout):
+    """the SAGE layer's self term in the same store (gaib_spmm_gemm2 on class graphs; rows2 through the row map)"""
+    g_o, s = make_shard(ctx, selfloop=False, seed=9)
+    kind = capi.W_MEAN
+    x = feat(g_o.nv, din, 5)
+    W, W2 = dev(feat(din, dout, 6)), dev(feat(din, dout, 7))
+    xo, xh = s.tables(x)
+    agg_r = torch.empty(s.n, din, device="cuda")
+    y_r = torch.empty(s.n, dout, device="cuda")
+    ctx.spmm(s.g_own, kind, xo, agg_r)
+    ctx.spmm_gemm(s.g_halo, kind, xh, agg_r, W, y_r, accumulate=True, rows2=xo, W2=W2)
+    want = oracle_rows(g_o, kind, x, s.lo, s.hi).astype(np.float64) @ W.cpu().numpy().astype(np.float64) + \
+        x[s.lo:s.hi].astype(np.float64) @ W2.cpu().numpy().astype(np.float64)
+    assert rel_err(y_r.cpu().numpy(), want) < 2e-5
+    c = s.cls
+    for mode in (1, 2):
+        agg = torch.full((s.n, din), float("nan"), device="cuda")
+        y = torch.full((s.n, dout), float("nan"), device="cuda")
+        ctx.spmm_gemm(c["interior"], kind, xo, agg, W, y, rows2=xo, W2=W2)
+        if mode == 1:
+            ctx.spmm(c["bnd_own"], kind, xo, agg)
+            ctx.spmm_gemm(c["bnd_halo"], kind, xh, agg, W, y, accumulate=True, rows2=xo, W2=W2)
+        else:
+            ctx.spmm_gemm_2t(c["bnd_full"], kind, xo, xh, s.n, agg, W, y, rows2=xo, W2=W2)
+        yy = y.cpu().numpy()
+        assert np.isfinite(yy).all()
+        assert np.array_equal(yy[s.light].view(np.uint32), y_r.cpu().numpy()[s.light].view(np.uint32))
+        assert rel_err(yy, want) < 2e-5
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 3000), (0, 1), (1500, 1501), (2999, 3000), (0, 1500)])
+def test_class_edge_cases(ctx, lo, hi):
+    """a range that holds the whole graph (no boundary row), single-row ranges (the hub row 0 alone: a heavy boundary
+    row; an ordinary row), the first half"""
+    g_o, s = make_shard(ctx, lo=lo, hi=hi, hub=2500)
+    kind, d = capi.W_GCN, 128
+    x = feat(g_o.nv, d, 2)
+    want = oracle_rows(g_o, kind, x, lo, hi)
+    xo, xh = s.tables(x)
+    W = dev(feat(d, d, 4))
+    c = s.cls
+    if lo == 0 and hi == 3000:
+        assert c["n_boundary"] == 0 and c["bnd_full"].nv == 0 and c["interior"].nv == 3000
+    agg = torch.full((s.n, d), float("nan"), device="cuda")
+    y = torch.full((s.n, d), float("nan"), device="cuda")
+    ctx.spmm_gemm(c["interior"], kind, xo, agg, W, y)
+    ctx.spmm_gemm_2t(c["bnd_full"], kind, xo, xh, s.n, agg, W, y)
+    assert rel_err(agg.cpu().numpy(), want) < 1e-5
+    assert rel_err(y.cpu().numpy(), want.astype(np.float64) @ W.cpu().numpy().astype(np.float64)) < 2e-5
+    out = torch.full((s.n, d), float("nan"), device="cuda")
+    ctx.spmm(c["interior"], kind, xo, out)
+    ctx.spmm(c["bnd_own"], kind, xo, out)
+    ctx.spmm(c["bnd_halo"], kind, xh, out, accumulate=True)
+    assert rel_err(out.cpu().numpy(), want) < 1e-5
+
+
+def test_class_graph_refusals(ctx):
+    g_o, s = make_shard(ctx)
+    c = s.cls
+    x = feat(g_o.nv, 200, 1)
+    xo, xh = s.tables(x)
+    out = torch.empty(s.n, 200, device="cuda")
+    ew = torch.ones(c["bnd_full"].ne, device="cuda")
+    with pytest.raises(capi.GaibError):  # the reverse-edge permutation does not exist on a class graph
+        ctx.spmm(c["interior"], capi.W_EDGE_T, xo, out, edge_w=ew)
+    W = dev(feat(200, 64, 2))
+    y = torch.empty(s.n, 64, device="cuda")
+    assert not ctx.spmm_gemm_fusable(capi.W_GCN, 200, 64)
+    with pytest.raises(capi.GaibError, match="fusable"):  # one dense product over all rows instead (the caller's job)
+        ctx.spmm_gemm(c["interior"], capi.W_GCN, xo, out, W, y)
+    with pytest.raises(capi.GaibError):  # class graphs are not split again
+        ctx.split_classes(c["interior"], c["bnd_halo"])
+
+
+def test_two_tables_larger_than_the_buffer_range(ctx):
+    """tables of 4 GB and more take 64-bit addresses: force that path (option spmm_addr_mode = 2) on small tables"""
+    g_o, s = make_shard(ctx, seed=12)
+    kind, d = capi.W_GCN, 128
+    x = feat(g_o.nv, d, 2)
+    want = oracle_rows(g_o, kind, x, s.lo, s.hi)
+    xo, xh = s.tables(x)
+    W = dev(feat(d, d, 4))
+    c = s.cls
+    ctx.set_option("spmm_addr_mode", 2)
+    try:
+        agg = torch.full((s.n, d), float("nan"), device="cuda")
+        y = torch.full((s.n, d), float("nan"), device="cuda")
+        ctx.spmm_gemm(c["interior"], kind, xo, agg, W, y)
+        ctx.spmm_gemm_2t(c["bnd_full"], kind, xo, xh, s.n, agg, W, y)
+        out = torch.full((s.n, d), float("nan"), device="cuda")
+        ctx.spmm(c["interior"], kind, xo, out)
+        ctx.spmm_2t(c["bnd_full"], kind, xo, xh, s.n, out)
+    finally:
+        ctx.set_option("spmm_addr_mode", 0)
+    assert rel_err(agg.cpu().numpy(), want) < 1e-5 and rel_err(out.cpu().numpy(), want) < 1e-5
+    assert np.array_equal(agg.cpu().numpy()[s.light].view(np.uint32), out.cpu().numpy()[s.light].view(np.uint32))

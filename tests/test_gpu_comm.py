@@ -163,6 +163,68 @@ def _worker(rank, world, idfile, q, arch, transport_name):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
+def _mode_worker(rank, world, idfile, q, arch, mode, din, dout, transport_name="ipc"):
+    """one GCN / SAGE layer din -> dout on a vertex-range partition in a GIVEN row-class mode (LearningGraph::
+    partition_mode: split = round 3's column split over all rows, classes = interior rows in one pass + column split of the
+    boundary rows, onepass = interior rows in one pass + boundary rows in one pass over [owned | halo]) against the GLOBAL
+    oracle.  din == dout = 128 / 64: the product rides on the aggregation in every class; 200 -> 64: not a fused shape, the
+    classes aggregate and one product follows; 128 -> 47: the layer multiplies first and aggregates 47 columns"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    os.environ["GAIB_PART_MODE"] = mode
+    try:
+        from graphaibench_amd import capi, layers as L
+        from oracle import binding as orc
+        from util import LONG_SUM_FLOOR, assert_close, random_graph
+
+        transport = _transport(transport_name, capi)
+        ctx = L.init(0)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
+        L.set_comm(comm)
+        rp, ci = random_graph(3000, 10, seed=17, power_law=True, hub_deg=1500)
+        g = orc.Graph(rp, ci)
+        if arch == "gcn":
+            g = g.add_selfloop()
+        n = g.nv
+        x = np.random.default_rng(5).standard_normal((n, din)).astype(np.float32)
+        gin = np.random.default_rng(6).standard_normal((n, dout)).astype(np.float32)
+        lo_ = (orc.GCNLayer if arch == "gcn" else orc.SAGELayer)(1, g, din, dout, True)
+        want = lo_.forward(x)
+        want_go = lo_.backward(gin.copy())
+        part = L.HostPartition(g.rowptr, g.colidx, rank, world)
+        lo, hi = part.lo, part.hi
+        lg = part.make_graph(comm)
+        used, n_bnd, bnd_edges = lg.partition_mode(din)
+        assert L.LGraph.PART_NAMES[used] == mode, (used, mode)
+        if mode != "split":  # the classes are real: some rows of this 10-edges-per-row graph are interior, some are not
+            assert 0 < n_bnd < hi - lo, (n_bnd, hi - lo)
+        layer = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, hi - lo, din, dout, lg, True)
+        layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+        out = torch.full((hi - lo, dout), float("nan"), device="cuda")
+        layer.forward(out)
+        assert_close(out.cpu().numpy(), want[lo:hi], "forward", floor=LONG_SUM_FLOOR)
+        out.copy_(torch.from_numpy(want[lo:hi]).cuda())  # identical relu masks
+        layer.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
+        grad_out = torch.full((hi - lo, din), float("nan"), device="cuda")
+        layer.backward(out, grad_out)
+        assert_close(grad_out.cpu().numpy(), want_go[lo:hi], "grad_out", floor=LONG_SUM_FLOOR)
+        layer.update_weight(L.adam(0.01))  # (sums the gradient over the ranks first)
+        want_wg = lo_.W_grad if arch == "gcn" else lo_.W_neigh_grad
+        assert_close(layer.tensor(L.W_NEIGH_GRAD, (din, dout)).cpu().numpy(), want_wg, "W_grad", floor=LONG_SUM_FLOOR)
+        if arch == "sage":
+            assert_close(layer.tensor(L.W_SELF_GRAD, (din, dout)).cpu().numpy(), lo_.W_self_grad, "W_self_grad",
+                         floor=LONG_SUM_FLOOR)
+        comm.barrier()
+        layer.close()
+        lg.close()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
 def _gat_worker(rank, world, idfile, q, heads, mode="fused", transport_name="ipc"):
     """GAT_layer 64 -> 64 on a vertex-range partition (h halo rows for the scores, partial gradient rows returned to
     their owners, alpha gradients all-reduced) against the GLOBAL oracle: head by head for heads > 1"""
@@ -351,6 +413,20 @@ def _spawn(world, target, args, timeout=600):
 @pytest.mark.parametrize("arch,world", [("gcn", 2), ("sage", 2), ("gcn", 3)])
 def test_ipc_ranks_on_one_gpu_match_global_oracle(tmp_path, arch, world):
     res = _spawn(world, _worker, (str(tmp_path / "id"), arch, "ipc"))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("mode", ["split", "classes", "onepass"])
+@pytest.mark.parametrize("arch,world,din,dout", [("gcn", 2, 128, 128), ("sage", 3, 128, 128), ("gcn", 3, 64, 64),
+                                                 ("gcn", 2, 200, 64), ("sage", 2, 128, 47), ("sage", 2, 100, 128)])
+def test_ipc_row_class_modes_match_global_oracle(tmp_path, arch, world, din, dout, mode):
+    res = _spawn(world, _mode_worker, (str(tmp_path / "id"), arch, mode, din, dout))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("mode", ["classes", "onepass"])
+def test_rccl_branch_row_class_modes(tmp_path, mode):
+    res = _spawn(2, _mode_worker, (str(tmp_path / "id"), "gcn", mode, 128, 128, "fake-rccl"))
     assert all(r[1] == "ok" for r in res), res
 
 

@@ -2,8 +2,11 @@
 Compiles the REFERENCE's own src/gnn/train.cpp and src/gnn/net.cpp, from where they lie and
 unmodified, against THIS repo's include/{gnn,layers,utils} (plus the reference's own driver header
 net.h, reached through a symlink so that no other reference header is visible) and links them with
-libgaib_gnn.so + libgaib_hip.so.  Skipped where /root/reference does not exist (GPU box)."""
+libgaib_gnn.so + libgaib_hip.so.  The object list is the one INTEGRATION.md documents (the `gpu_train_gcn:` rule of its Makefile hunk), read from
+that file: what a maintainer is told to build is what is built here.
+Skipped where /root/reference does not exist (GPU box)."""
 import os
+import re
 import subprocess
 from pathlib import Path
 
@@ -12,6 +15,23 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 REF = Path("/root/reference")
 LIB = ROOT / "graphaibench_amd" / "lib"
+
+
+def documented_objects():
+    """the prerequisites of the `gpu_train_gcn:` rule in INTEGRATION.md's Makefile hunk -> reference source files"""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    m = re.search(r"^gpu_train_gcn:(.*)$", text, re.M)
+    assert m, "INTEGRATION.md lost its gpu_train_gcn rule"
+    objs = m.group(1).split("#")[0].split()
+    assert objs and all(re.fullmatch(r"\w+\.o", o) for o in objs), objs  # no ellipsis, no placeholders
+    return [o[:-2] + ".cpp" for o in objs]
+
+
+def test_documented_object_list_is_exact():
+    srcs = documented_objects()
+    assert "train.cpp" in srcs and "net.cpp" in srcs
+    if REF.exists():
+        assert all((REF / "src" / "gnn" / s).exists() for s in srcs), srcs
 
 
 @pytest.mark.parametrize("flag,name", [("", "gcn"), ("-DUSE_SAGE", "sage"), ("-DUSE_GAT", "gat")])
@@ -25,7 +45,7 @@ def test_reference_driver_compiles_and_links_unchanged(tmp_path, flag, name):
     inc = [f"-I{ROOT/'include'}", f"-I{ROOT/'include'/'gnn'}", f"-I{ROOT/'include'/'layers'}",
            f"-I{ROOT/'include'/'utils'}", f"-I{hdr}"]
     objs = []
-    for src in ("train.cpp", "net.cpp"):
+    for src in documented_objects():
         o = tmp_path / (src + ".o")
         cmd = ["g++", "-O1", "-std=c++17", "-fopenmp", *inc, "-c", str(REF / "src" / "gnn" / src), "-o", str(o)]
         if flag:
