@@ -45,6 +45,9 @@ D = 128  # feature width of the layer under test (north star: D = 128)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured stream copy)
 
 
+T_START = time.time()  # the process's start: what --budget-s and --deadline-s count from
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -463,21 +466,72 @@ def launch_ranks(args, argv, entry=None) -> int:
     if rc == 0 and not out:
         log("[bench launcher] rank 0 printed no JSON line")
         rc = 1
-    if out and (rc == 0 or procs[0].poll() in (3, 4)):  # 3 / 4: rank 0's own verdict on a record it DID emit
+    # a record rank 0 DID emit is relayed whatever ended the run (exit 3 / 4: its own verdict on the record; exit 0 after
+    # the deadline or a signal: the record it held, marked partial -- RecordGuard)
+    if out and (rc == 0 or procs[0].poll() in (0, 3, 4)):
         print(out[-1], flush=True)
+        if rc == 124 and procs[0].poll() == 0:  # the deadline cut the sub-cases short, the headline record is out
+            rc = 0
     return rc
 
 
-def _arm_deadline(seconds: float, rank: int) -> None:
-    """inside a rank: a collective that waits for a dead peer never returns (RCCL has no deadline of its own), so the
-    rank ends itself when the run's deadline passes -- under torch.distributed.run that ends the job as well"""
-    def fire():
-        log(f"[bench r{rank}] deadline of {seconds:.0f} s passed: exiting 124")
+class RecordGuard:
+    """The N > 1 record cannot be lost: rank 0 HOLDS the record as soon as the headline case is measured (hold), the
+    sub-cases that follow only add to it, and whatever ends the run early -- the deadline, SIGTERM from the launcher or the
+    driver, a sub-case that hangs in a collective -- makes rank 0 print the record it holds, marked `partial`, and exit 0.
+    Exactly one JSON line leaves the process (final / bail race under a lock).  The watchers are THREADS (a timer, and
+    sigwait on the blocked SIGTERM / SIGINT): a Python signal handler would not run while the main thread sits in a C call."""
+
+    def __init__(self, rank: int):
+        self.rank, self.lock, self.held, self.done = rank, threading.Lock(), None, False
+
+    def hold(self, record: dict) -> None:
+        with self.lock:
+            self.held = record
+
+    def final(self, record: dict) -> None:
+        with self.lock:
+            if not self.done:
+                self.done = True
+                emit(record)
+
+    def bail(self, reason: str) -> None:
+        """from a watcher thread: print what is held (rank 0) and leave"""
+        with self.lock:
+            if self.done:  # the record is out already: let the process end by itself
+                return
+            self.done = True
+            held = self.held
+        if self.rank == 0 and held is not None:
+            held = dict(held)
+            held["partial"] = {"reason": reason, "note": "the headline case was measured in full; sub-cases that had not "
+                                                          "finished are null or say why"}
+            log(f"[bench r0] {reason}: printing the record held so far")
+            emit(held)
+            os._exit(0)
+        log(f"[bench r{self.rank}] {reason}: exiting 124")
         os._exit(124)
 
-    t = threading.Timer(seconds, fire)
+
+def install_rank_guard(rank: int, deadline_s: float) -> RecordGuard:
+    """inside a rank: a collective that waits for a dead peer never returns (RCCL has no deadline of its own), so the
+    rank ends itself when the run's deadline passes -- under torch.distributed.run that ends the job as well -- and on
+    SIGTERM / SIGINT; rank 0 prints the record it holds first (RecordGuard)"""
+    import signal
+
+    guard = RecordGuard(rank)
+    sigs = {signal.SIGTERM, signal.SIGINT}
+    signal.pthread_sigmask(signal.SIG_BLOCK, sigs)  # (threads started from here on inherit the mask)
+
+    def wait_signal():
+        s = signal.sigwait(sigs)
+        guard.bail(f"signal {s}")
+
+    threading.Thread(target=wait_signal, daemon=True).start()
+    t = threading.Timer(deadline_s, lambda: guard.bail(f"deadline of {deadline_s:.0f} s passed"))
     t.daemon = True
     t.start()
+    return guard
 
 
 def main():
@@ -507,8 +561,13 @@ def main():
                     help="N>1 (or gcn-papers): compare every rank's forward output, input gradient and the summed weight "
                          "gradient element-wise with the oracle's run on the GLOBAL graph (sizes the host finishes in "
                          "seconds: use --scale); exit code 3 above 1e-4")
-    ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("GAIB_BENCH_DEADLINE_S", "1500")),
-                    help="wall-clock limit of an N>1 run: the launcher stops all ranks, a rank ends itself")
+    ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("GAIB_BENCH_DEADLINE_S", "560")),
+                    help="wall-clock limit of an N>1 run (under the 600 s the driver grants a bench run): the launcher stops "
+                         "all ranks, a rank ends itself; rank 0 prints the record it holds first")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("GAIB_BENCH_BUDGET_S", "420")),
+                    help="N>1: wall-clock budget of the whole run, counted from the rank's start.  The headline case always runs; "
+                         "every further sub-case (CPU baseline, random vertex order, config 5) starts only if all ranks agree that "
+                         "its estimated time still fits, else the record says {\"skipped\": \"budget\", ...}")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = one products-shaped vertex range per GPU; strong = the single-GPU bench graph "
                          "partitioned N ways")
@@ -531,8 +590,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     ndev = torch.cuda.device_count()
     device = local_rank % ndev
+    guard = None
     if world > 1:
-        _arm_deadline(args.deadline_s, rank)
+        guard = install_rank_guard(rank, args.deadline_s)
         if world > ndev and "GAIB_DIST_BACKEND" not in os.environ:
             # ranks share devices (a one-GPU box): RCCL refuses that by design, the peer-to-peer pull transport does not
             os.environ["GAIB_DIST_BACKEND"] = "ipc"
@@ -566,13 +626,31 @@ def main():
         if args.check_oracle:
             make_check = lambda shape, cut, comm: DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, args, rank, world,
                                                                   shape, cut)
-        result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check)
+        launcher = ("bench.py itself (parent without GPU state, fresh rank processes, supervised)"
+                    if os.environ.get("GAIB_LAUNCH_NONCE") else "ranks given from outside (torch.distributed.run)")
+
+        def hold(record):  # (rank 0) the headline case is measured: from here on the record cannot be lost
+            if guard is not None and rank == 0:
+                record["config"]["launcher"] = launcher
+                guard.hold(record)
+
+        def cpu_leg(budget_s):  # (rank 0) the N = 1 workload's CPU baseline on a bounded sample, named as such
+            sg = synth.make("ogbn-products", seed=42, device="cuda", scale=min(args.scale, 0.1))
+            x_h, gin_h = host_inputs(sg.nv)
+            rec, _ = cpu_baseline(sg.rowptr, sg.colidx, sg.nv, x_h, gin_h, budget_s=budget_s, want_outputs=False)
+            rec["of"] = (f"the N = 1 workload (ogbn-products shape, seed 42) at scale {min(args.scale, 0.1)}: {sg.nv} vertices; "
+                         "timed on rank 0's host cores while the other ranks wait")
+            del sg
+            torch.cuda.empty_cache()
+            return rec
+
+        result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
+                                       cpu_leg=None if args.no_cpu_baseline else cpu_leg)
         dist.barrier()
         rc = 0
         if rank == 0:
             cfg = result["config"]
-            cfg["launcher"] = ("bench.py itself (parent without GPU state, fresh rank processes, supervised)"
-                               if os.environ.get("GAIB_LAUNCH_NONCE") else "ranks given from outside (torch.distributed.run)")
+            cfg["launcher"] = launcher
             # a record that says RCCL must have been carried by all N ranks (never a silent subset)
             if cfg["transport"].startswith("gaib_comm/rccl") and cfg["rccl_ranks"] != world:
                 log(f"[bench] transport {cfg['transport']} but rccl_ranks = {cfg['rccl_ranks']} != {world}")
@@ -580,7 +658,10 @@ def main():
             if result.get("parity") is not None and not result["parity"]["ok"]:
                 log("[bench] PARITY FAILED (> 1e-4)")
                 rc = 3
-            emit(result)
+            if guard is not None:
+                guard.final(result)
+            else:
+                emit(result)
         dist.destroy_process_group()
         if rc:
             sys.exit(rc)
