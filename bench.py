@@ -386,6 +386,17 @@ def emit(result: dict) -> None:
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(result) + "\n").encode())
 
 
+def profiler_preload() -> str:
+    """non-empty if this process runs under a profiler that preloads a GPU-touching library (rocprofv3 / rocprofiler-sdk)"""
+    if os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return "ROCP_TOOL_LIBRARIES is set"
+    for var in ("LD_PRELOAD", "HSA_TOOLS_LIB"):
+        v = os.environ.get(var, "")
+        if "rocprof" in v or "roctracer" in v or "rocprofiler" in v:
+            return f"{var} names a profiler library ({v[:80]})"
+    return ""
+
+
 def launch_ranks(args, argv, entry=None) -> int:
     """`python bench.py --gpus N` without ranks from outside: start them.  This parent imports no torch and calls no
     GPU API (a process that has touched the GPU must never be replaced or forked into ranks on this pool); every rank
@@ -399,6 +410,12 @@ def launch_ranks(args, argv, entry=None) -> int:
     import socket
     import subprocess
 
+    why = profiler_preload()
+    if why:  # the tool library has initialised the GPU in THIS process already: starting ranks from it is the forbidden exec
+        log(f"[bench launcher] {why}: a profiler's preloaded library touches the GPU before main, and a process that has "
+            "must not start rank programs on this pool.  Profile ONE rank program directly after `--` (ranks from outside: "
+            "RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT set per process), or profile the N = 1 run.")
+        return 2
     n = args.gpus
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free rendezvous port on the loopback
         sk.bind(("127.0.0.1", 0))

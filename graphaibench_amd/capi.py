@@ -126,6 +126,7 @@ SIGNATURES = {
     "gaib_gat_backward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i]),
     "gaib_gather_scatter_rows": (_i, [_vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "gaib_graph_reorder": (_i, [_vp, _vp, _i, _pp, _vp, _vp]),
+    "gaib_graph_sort_rows": (_i, [_vp, _vp]),
     "gaib_graph_locality": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
@@ -705,6 +706,10 @@ class Graph:
         _check(self.lib.gaib_graph_reorder(self.ctx.h, self.h, method, C.byref(h), new_of_old.data_ptr(), old_of_new.data_ptr()),
                "gaib_graph_reorder")
         return Graph(self.ctx, _handle=h), new_of_old, old_of_new
+
+    def sort_rows(self):
+        """sort every row's column ids (a relabelled graph keeps its rows' edge order: GAT backward needs sorted rows)"""
+        _check(self.lib.gaib_graph_sort_rows(self.ctx.h, self.h), "gaib_graph_sort_rows")
 
     def compute_vertex_data(self):
         _check(self.lib.gaib_graph_compute_vertex_data(self.ctx.h, self.h), "gaib_graph_compute_vertex_data")

@@ -165,8 +165,10 @@ struct gaib_comm {
     size_t cap;
     hipIpcMemHandle_t handle;
     bool exported, in_use;
-  } ipc_bufs[256];
-  int n_ipc_bufs;
+  };
+  std::vector<IpcBuf>* ipc_bufs;  // (a pointer: the struct is zero-filled after construction; EVERY buffer is in it -- a
+                                  // buffer outside the pool would be hipFree'd while exported, the leak the pool exists against)
+  ~gaib_comm() { delete ipc_bufs; }
 };
 
 struct gaib_halo {
@@ -194,8 +196,7 @@ struct gaib_halo {
   // allocations landed -- later pulls through the re-opened mapping read wrong rows at non-zero offsets (found by
   // test_ipc_halo_buffers_regrow_between_exchange_and_reduce[3] when plan creation began to allocate scratch of its own).
   // gaib_halo_destroy closes every mapping on every rank, passes a barrier, and only then frees.
-  void* retired[48];
-  int n_retired;
+  std::vector<void*> retired;  // (growable: a full list must never push a possibly-mapped buffer back into the pool early)
   int pending_len;
   struct Peer {
     uint64_t gen;
@@ -250,15 +251,14 @@ int fail(gaib_comm* c, int rc) {  // tell the peers, keep the message
 
 // IPC buffers come out of (and go back into) the communicator's pool -- see gaib_comm::ipc_bufs
 gaib_comm::IpcBuf* pool_find(gaib_comm* c, const void* p) {
-  for (int k = 0; k < c->n_ipc_bufs; k++)
-    if (c->ipc_bufs[k].p == p) return &c->ipc_bufs[k];
+  for (gaib_comm::IpcBuf& b : *c->ipc_bufs)
+    if (b.p == p) return &b;
   return nullptr;
 }
 void pool_release(gaib_comm* c, void* p) {
   if (!p) return;
   gaib_comm::IpcBuf* b = pool_find(c, p);
-  if (b) b->in_use = false;
-  else (void)hipFree(p);  // (the pool was full when it was allocated)
+  if (b) b->in_use = false;  // (every buffer reserve() hands out is in the pool; hipFree is left to gaib_comm_destroy)
 }
 // the handle of a pooled buffer: exported once
 hipError_t pool_handle(gaib_comm* c, void* p, hipIpcMemHandle_t* out) {
@@ -279,8 +279,8 @@ int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t 
   if (bytes <= *cap && *p) return 0;
   if (*p) {
     GAIB_HIP(hipStreamSynchronize(s));
-    if (keep && keep->c->transport == GAIB_COMM_IPC && keep->n_retired < (int)(sizeof(keep->retired) / sizeof(keep->retired[0])))
-      keep->retired[keep->n_retired++] = *p;  // IPC: peers may still have it mapped (see gaib_halo::retired)
+    if (keep && keep->c->transport == GAIB_COMM_IPC)
+      keep->retired.push_back(*p);  // IPC: peers may still have it mapped (see gaib_halo::retired)
     else if (keep)
       pool_release(keep->c, *p);
     else
@@ -296,10 +296,8 @@ int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t 
   if (keep) {  // best fit among the pooled buffers nobody uses
     gaib_comm* c = keep->c;
     gaib_comm::IpcBuf* best = nullptr;
-    for (int k = 0; k < c->n_ipc_bufs; k++) {
-      gaib_comm::IpcBuf* b = &c->ipc_bufs[k];
-      if (!b->in_use && b->cap >= want && (!best || b->cap < best->cap)) best = b;
-    }
+    for (gaib_comm::IpcBuf& b : *c->ipc_bufs)
+      if (!b.in_use && b.cap >= want && (!best || b.cap < best->cap)) best = &b;
     if (best && best->cap <= 2 * want) {  // (not a buffer far larger than asked for: the next large plan wants it)
       best->in_use = true;
       *p = (float*)best->p;
@@ -313,12 +311,13 @@ int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t 
     gaib_set_error("gaib_halo: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     return GAIB_ERR_NOMEM;
   }
-  if (keep && keep->c->n_ipc_bufs < (int)(sizeof(keep->c->ipc_bufs) / sizeof(keep->c->ipc_bufs[0]))) {
-    gaib_comm::IpcBuf* b = &keep->c->ipc_bufs[keep->c->n_ipc_bufs++];
-    memset((void*)b, 0, sizeof(*b));
-    b->p = *p;
-    b->cap = want;
-    b->in_use = true;
+  if (keep) {
+    gaib_comm::IpcBuf b;
+    memset((void*)&b, 0, sizeof(b));
+    b.p = *p;
+    b.cap = want;
+    b.in_use = true;
+    keep->c->ipc_bufs->push_back(b);
   }
   *cap = want;
   ++*serial;
@@ -364,6 +363,7 @@ extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h
   gaib_comm* c = new (std::nothrow) gaib_comm();
   GAIB_CHECK(c, "gaib_comm_init: out of memory");
   memset((void*)c, 0, sizeof(*c));
+  c->ipc_bufs = new std::vector<gaib_comm::IpcBuf>();
   c->ctx = ctx;
   c->rank = rank;
   c->nranks = nranks;
@@ -475,7 +475,7 @@ extern "C" int gaib_comm_destroy(gaib_comm* c) {
   (void)hipStreamSynchronize(c->cstream);
   if (c->transport == GAIB_COMM_RCCL && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
-  for (int k = 0; k < c->n_ipc_bufs; k++) (void)hipFree(c->ipc_bufs[k].p);  // (every plan is gone: gaib_halo_destroy comes first)
+  for (gaib_comm::IpcBuf& b : *c->ipc_bufs) (void)hipFree(b.p);  // (every plan is gone: gaib_halo_destroy comes first)
   if (c->seg) munmap(c->seg, sizeof(ShmSeg));
   (void)hipEventDestroy(c->ev_ready);
   (void)hipEventDestroy(c->ev_done);
@@ -585,8 +585,7 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
   GAIB_CHECK(slot < GAIB_COMM_MAX_HALOS, "gaib_halo_create: at most %d halo plans alive per communicator", GAIB_COMM_MAX_HALOS);
   GAIB_HIP(hipSetDevice(c->ctx->device));
   gaib_halo* h = new (std::nothrow) gaib_halo();
-  GAIB_CHECK(h, "gaib_halo_create: out of memory");
-  memset((void*)h, 0, sizeof(*h));
+  GAIB_CHECK(h, "gaib_halo_create: out of memory");  // (value-initialised: every plain member is zero, `retired` is empty)
   h->c = c;
   h->id = slot;  // taken (bit set) only once every argument check has passed
   h->send_off[0] = h->recv_off[0] = 0;
@@ -669,7 +668,7 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (h->d_pack_slot) (void)hipFree(h->d_pack_slot);
   pool_release(c, h->sendbuf);  // back into the communicator's pool (see gaib_comm::ipc_bufs)
   pool_release(c, h->table);
-  for (int k = 0; k < h->n_retired; k++) pool_release(c, h->retired[k]);
+  for (void* q : h->retired) pool_release(c, q);
   c->halo_slots &= ~(1u << h->id);  // after the barrier above: the slot row can serve the next plan
   delete h;
   return GAIB_OK;

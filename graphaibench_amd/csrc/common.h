@@ -83,6 +83,8 @@ struct gaib_ctx {
   int gat_fused_bwd;         // the one-pass edge side of GAT backward: -1 = dense graphs (aggregation's rule), 0 never, 1 whenever the shape fits
   int gat_fused_fwd;         // the one-sweep forward (scores + online softmax + aggregation): -1 = dense graphs, 0 never, 1 whenever the shape fits
   int gat_fused_unroll;      // gathers in flight per lane and table in the fused backward sweep: 4 (default; measured 10.7 vs 10.9 ms) or 8
+  int gat_interleave;        // one-sweep GAT backward: 1 = gather from ONE interleaved [h | grad | records] row per vertex (built per call), 0 = three tables
+  int gat_chunk_xcd;         // one-sweep GAT kernels: 1 = every XCD walks a contiguous eighth of the column-block-ordered chunk list, 0 = round robin
   int graph_rev_search;      // 1 = reverse-edge permutation by per-edge binary search (the reference's way) instead of the sort
   hipStream_t owned_stream;  // gaib_ctx_own_stream: a stream the context created (destroyed with it), else NULL
   int capturing;             // 1 between gaib_capture_begin and gaib_capture_end: calls are recorded into a HIP graph, nothing runs
@@ -151,6 +153,8 @@ struct gaib_graph {
   // row r stands for row row_map[r] of the caller's [n_out_rows x len] matrices.  NULL: an ordinary graph.
   uint32_t* row_map;
   int64_t n_out_rows;
+  int rows_unsorted;  // 1: a row's column ids are not ascending (gaib_graph_reorder keeps the edge ORDER of every row);
+                      // the reverse-edge permutation needs sorted rows: gaib_graph_sort_rows first
   float near_frac;  // share of (sampled) edges whose column id lies within 32 768 of the row id: locality of the numbering; < 0 = not measured yet
 };
 

@@ -836,15 +836,35 @@ __global__ void gat_rec_kernel(int64_t n, const float* rowdot, const float2* sta
 // (gat_fwd_fused_chunk_kernel): p_e = exp(lrelu(sl_i + sr_c) - M_i) / S_i and p_r = exp(lrelu(sl_c + sr_i) - M_c) / S_c
 // with stats[v][h] = (M, 1/S) -- one 8-B gather from a 15 MB table instead of 4 B linear + 4 B random + rev per edge, and
 // no [ne][H] array exists at all.
+// T[v] = [h_v (len) | grad_v (len) | rec_v (4 H)]: what the backward sweep gathers per edge, as ONE row per vertex
+__global__ __launch_bounds__(256) void gat_interleave_kernel(int64_t nv, int len4, int H, const f4* feat, const f4* grad,
+                                                             const f4* rec, f4* T) {
+  const int ldt4 = 2 * len4 + H;
+  const int64_t total = nv * ldt4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / ldt4;
+    const int k = (int)(i - v * ldt4);
+    T[i] = k < len4 ? feat[v * len4 + k] : (k < 2 * len4 ? grad[v * len4 + k - len4] : rec[v * H + k - 2 * len4]);
+  }
+}
+
 template <int G, int H, int U, bool RECOMP>
 __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, const uint32_t* rev, int len, const float* feat, const float* grad,
     const float* p, const float2* stats, const float* rowdot, const float* alpha_l, const float* alpha_r, float eps,
-    float* out_partial, float* rc_partial, const f4* rec, int phase, uint32_t own_cols) {
+    float* out_partial, float* rc_partial, const f4* rec, int phase, uint32_t own_cols, int ld, int rec_ld, int per_xcd) {
   // rec (RECOMP): (rowdot, row maximum, 1 / row sum) per (vertex, head) as one 16-byte record, see gat_rec_kernel
+  // ld / rec_ld: row strides of the feat / grad tables (floats) and of the record table (16-byte records): len and H for
+  // three separate tables; 2 len + 4 H and that / 4 when the three live INTERLEAVED, one [h | grad | records] row per vertex
+  // (gat_interleave_kernel) -- one contiguous 640-B region per edge instead of three.
+  // per_xcd > 0: workgroups are dealt to the XCDs round robin (XCD = blockIdx & 7); XCD x then walks the CONTIGUOUS range
+  // [x per_xcd, (x + 1) per_xcd) of the column-block-ordered chunk list, so each L2 sees its own eighth of the columns
+  // instead of all eight L2s caching the same window.
   constexpr int LH = G / H;  // lanes per head
-  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t blk = blockIdx.x;
+  if (per_xcd > 0) blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t c = blk * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
   const int lane = threadIdx.x & 63;
   const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
@@ -869,8 +889,8 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   if constexpr (!RECOMP) rl = rev[el];
   const int coff = sl * 4;  // len == 4 * G
   const int head = sl / LH;
-  const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)len + coff);
-  const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
+  const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)ld + coff);
+  const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)ld + coff);
   // the per-vertex dots a_l.h_v, a_r.h_v are formed again from the gathered rows (4 FMAs + the head's shuffle each)
   // instead of being gathered: only rowdot, which needs the vertex's forward output, comes from a table -- [nv][H]
   // floats, small enough for the L2, where a (rowdot, sl, sr) record per (vertex, head) cost a 128-B line per edge
@@ -887,7 +907,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   float rd_i;
   float2 st_i = {0.f, 0.f};
   if constexpr (RECOMP) {
-    const f4 ri = rec[row * H + head];
+    const f4 ri = rec[row * rec_ld + head];
     rd_i = ri[0];
     st_i = float2{ri[1], ri[2]};
   } else {
@@ -905,10 +925,10 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     for (int u = 0; u < U; ++u) {
       const int ei = (j + u) * 4 + grp;
       const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
-      xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * len + coff);
-      xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
+      xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * ld + coff);
+      xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * ld + coff);
       if constexpr (RECOMP) {
-        const f4 rc = rec[(int64_t)cj * H + head];
+        const f4 rc = rec[(int64_t)cj * rec_ld + head];
         rd[u] = rc[0];
         stc[u] = float2{rc[1], rc[2]};
       } else {
@@ -979,9 +999,11 @@ template <int G, int H, int U>
 __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
     int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase, const uint32_t* chunk_start,
     const int64_t* rowptr, const uint32_t* col, int len, const float* feat, const float* alpha_l, const float* alpha_r,
-    float eps, float* out_partial, float2* ms_partial, int phase, uint32_t own_cols) {
+    float eps, float* out_partial, float2* ms_partial, int phase, uint32_t own_cols, int per_xcd) {
   constexpr int LH = G / H;
-  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t blk = blockIdx.x;  // (per_xcd: see gat_bwd_fused_chunk_kernel)
+  if (per_xcd > 0) blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t c = blk * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
   const int lane = threadIdx.x & 63;
   const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
@@ -1448,10 +1470,22 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
 static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, int knob, uintptr_t align_or, int* rc,
                               bool rect = false) {
   *rc = GAIB_OK;
-  const bool shape_ok = len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) &&
-                        (rect || g->nc == g->nv) && g->ne > 0 && (align_or & 15) == 0;
+  // On a rank's rectangular graph the answer must follow from rank-INVARIANT inputs alone -- len, heads, the option:
+  // the one-sweep and the staged path run different collectives in backward, so a rank that has rows but no edges (an
+  // empty sweep is a valid sweep) or a misaligned buffer must not take another path than its peers (the latter is an
+  // error, not a reason to fall back).
+  const bool heads_ok = len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16);
+  if (rect) {
+    if (heads_ok && knob != 0 && (align_or & 15) != 0) {
+      gaib_set_error("one-sweep GAT on a partition: buffers must be 16-byte aligned");
+      *rc = GAIB_ERR_INVALID;
+      return false;
+    }
+    return heads_ok && knob != 0;
+  }
+  const bool shape_ok = heads_ok && g->nc == g->nv && g->ne > 0 && (align_or & 15) == 0;
   bool use = shape_ok && knob != 0;
-  if (use && knob < 0 && !rect) {  // (a rank's share of a partition: the staged pieces there cost two permuted [ne][H] copies more)
+  if (use && knob < 0) {  // (not on a rank's share of a partition: the staged pieces there cost two permuted [ne][H] copies more)
     *rc = gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold);
     if (*rc != GAIB_OK) return false;
     use = g->n_heavy > 0 && 4 * g->heavy_edges >= g->ne && (int64_t)g->nv * len * 4 <= ((int64_t)512 << 20);
@@ -1498,12 +1532,17 @@ static int gat_forward_fused_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   float* out_partial = (float*)ctx->ws;
   float2* ms_partial = reinterpret_cast<float2*>(out_partial + n_op);
   ProfScope ps(ctx, "gat_fwd_fused");
-  const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+  unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);  // (0 on a rank whose rows have no edges: nothing to sweep)
+  int per_xcd = 0;
+  if (ctx->gat_chunk_xcd == 1 && grid >= 64) {
+    per_xcd = (int)cdiv64(grid, 8);
+    grid = (unsigned)per_xcd * 8u;
+  }
 #define GAIB_FF(HH)                                                                                                       \
-  gat_fwd_fused_chunk_kernel<16, HH, 8><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,          \
+  if (grid > 0) gat_fwd_fused_chunk_kernel<16, HH, 8><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,          \
                                                                        g->chunk_start, g->rowptr, g->colidx, len, d_h,     \
                                                                        d_alpha_l, d_alpha_r, epsilon, out_partial, ms_partial, \
-                                                                       phase, (uint32_t)g->nv)
+                                                                       phase, (uint32_t)g->nv, per_xcd)
   switch (heads) {
     case 1: GAIB_FF(1); break;
     case 2: GAIB_FF(2); break;
@@ -1568,7 +1607,11 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
   const size_t n_v = up4((size_t)g->nv * heads);
   const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
-  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (7 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len)));
+  // option gat_interleave: the three per-vertex tables of the sweep as one [h | grad | records] row per vertex
+  const bool inter = ctx->gat_interleave == 1 && d_row_stats != nullptr;
+  const int ldt = 2 * len + 4 * heads;
+  const size_t n_t = inter ? up4((size_t)g->nv * ldt) : 0;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (7 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len + n_t)));
   f4* rec = reinterpret_cast<f4*>(ctx->ws);  // [nv][H] 16-byte records (first: alignment)
   float* rowdot = (float*)ctx->ws + 4 * n_v;
   float* rs = rowdot + n_v;
@@ -1576,6 +1619,7 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   float* out_partial = cs + n_v;
   float* rc_partial = out_partial + n_op;
   float* partial = rc_partial + n_rc;
+  float* T = partial + (size_t)nblocks * 2 * len;
   ProfScope ps(ctx, "gat_bwd_fused");
   rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
   GAIB_LAUNCH_CHECK();
@@ -1585,13 +1629,33 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
                                                                         rec);
     GAIB_LAUNCH_CHECK();
   }
-  const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+  const float *k_feat = d_feat, *k_grad = d_grad;
+  const f4* k_rec = rec;
+  int k_ld = len, k_rec_ld = heads;
+  if (inter) {
+    const int64_t tot4 = g->nv * (int64_t)(ldt / 4);
+    gat_interleave_kernel<<<(unsigned)std::min<int64_t>(cdiv64(tot4, 256), (int64_t)ctx->num_cus * 16), 256, 0, ctx->stream>>>(
+        g->nv, len / 4, heads, reinterpret_cast<const f4*>(d_feat), reinterpret_cast<const f4*>(d_grad), rec,
+        reinterpret_cast<f4*>(T));
+    GAIB_LAUNCH_CHECK();
+    k_feat = T;
+    k_grad = T + len;
+    k_rec = reinterpret_cast<const f4*>(T + 2 * len);
+    k_ld = ldt;
+    k_rec_ld = ldt / 4;
+  }
+  unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
+  int per_xcd = 0;
+  if (ctx->gat_chunk_xcd == 1 && grid >= 64) {
+    per_xcd = (int)cdiv64(grid, 8);
+    grid = (unsigned)per_xcd * 8u;
+  }
   // edges in flight per group: 8 or 4 (option gat_fused_unroll)
 #define GAIB_FB_U(HH, UU, RC)                                                                                              \
   gat_bwd_fused_chunk_kernel<16, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
-      g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, g->rev, len, d_feat, d_grad,        \
+      g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, g->rev, len, k_feat, k_grad,        \
       d_norm_scores, reinterpret_cast<const float2*>(d_row_stats), rowdot, d_alpha_l, d_alpha_r, epsilon, out_partial,     \
-      rc_partial, rec, -1, 0u)
+      rc_partial, k_rec, -1, 0u, k_ld, k_rec_ld, per_xcd)
 #define GAIB_FB(HH)                                          \
   do {                                                       \
     if (d_row_stats) {                                       \
@@ -1726,10 +1790,10 @@ extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int le
   ProfScope ps(ctx, "gat_bwd_fused");
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
 #define GAIB_FBR(HH)                                                                                                       \
-  gat_bwd_fused_chunk_kernel<16, HH, 4, true><<<grid, 256, 0, ctx->stream>>>(                                              \
+  if (grid > 0) gat_bwd_fused_chunk_kernel<16, HH, 4, true><<<grid, 256, 0, ctx->stream>>>(                                              \
       g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, nullptr, len, d_feat_tab, d_grad_tab, \
       nullptr, nullptr, nullptr, d_alpha_l, d_alpha_r, epsilon, out_partial, rc_partial,                                   \
-      reinterpret_cast<const f4*>(d_rec_tab), phase, (uint32_t)g->nv)
+      reinterpret_cast<const f4*>(d_rec_tab), phase, (uint32_t)g->nv, len, HH, 0)
   switch (heads) {
     case 1: GAIB_FBR(1); break;
     case 2: GAIB_FBR(2); break;

@@ -378,6 +378,11 @@ int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g) {
   if (g->rev) return GAIB_OK;
   GAIB_NOT_WHILE_CAPTURING(ctx, "building the graph's reverse-edge permutation");
   GAIB_CHECK(g->nc == g->nv, "reverse-edge permutation: square graphs only");
+  if (g->rows_unsorted) {
+    gaib_set_error("reverse-edge permutation: this graph's rows are not sorted by column id (gaib_graph_reorder keeps every "
+                   "row's edge order): call gaib_graph_sort_rows first -- GAT backward / gaib_edge_transpose need sorted rows");
+    return GAIB_ERR_UNSUPPORTED;
+  }
   uint32_t* rev = nullptr;
   int* bad = nullptr;
   const int64_t ne = g->ne;
@@ -911,7 +916,71 @@ extern "C" int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib
     (void)gaib_graph_destroy(r);
     return rc;
   }
+  r->rows_unsorted = 1;  // (each row kept its edge order under new names)
   *out = r;
+  return GAIB_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void row_col_key_kernel(int64_t nv, const int64_t* rowptr, const uint32_t* col, uint64_t* key) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nv) return;
+  for (int64_t e = rowptr[r] + (threadIdx.x & 63); e < rowptr[r + 1]; e += 64) key[e] = ((uint64_t)r << 32) | col[e];
+}
+__global__ void key_low_kernel(int64_t ne, const uint64_t* key, uint32_t* col) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) col[e] = (uint32_t)(key[e] & 0xffffffffull);
+}
+}  // namespace
+
+// Sort every row's column ids ascending (one radix sort of (row, column) keys).  For graphs that gaib_graph_reorder
+// relabelled and that GAT backward / gaib_edge_transpose are to run on: those derive the reverse-edge permutation from
+// sorted rows (math_functions.cpp:32-44 searches them).  Aggregations over the sorted graph sum a row's terms in another
+// order than the original numbering did: equal up to fp32 rounding, no longer bit for bit.  Per-edge caches are dropped.
+extern "C" int gaib_graph_sort_rows(gaib_ctx* ctx, gaib_graph* g) {
+  GAIB_CHECK(ctx && g, "gaib_graph_sort_rows: NULL argument");
+  GAIB_CHECK(!g->row_map, "gaib_graph_sort_rows: not on a class graph");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_graph_sort_rows");
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const int64_t ne = g->ne, nv = g->nv;
+  if (ne > 0) {
+    uint64_t *key = nullptr, *key2 = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int end_bit = 33;
+    while (end_bit < 64 && ((int64_t)1 << (end_bit - 32)) < nv) end_bit++;
+    hipError_t e = hipMalloc(&key, sizeof(uint64_t) * ne);
+    if (e == hipSuccess) e = hipMalloc(&key2, sizeof(uint64_t) * ne);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, key, key2, (int)ne, 0, end_bit, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes);
+    if (e == hipSuccess) {
+      row_col_key_kernel<<<grid1d(nv, 4), 256, 0, ctx->stream>>>(nv, g->rowptr, g->colidx, key);
+      e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, key, key2, (int)ne, 0, end_bit, ctx->stream);
+    }
+    if (e == hipSuccess) {
+      key_low_kernel<<<grid1d(ne, 256), 256, 0, ctx->stream>>>(ne, key2, g->colidx);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    void* owned[] = {key, key2, tmp};
+    for (void* p : owned)
+      if (p) (void)hipFree(p);
+    if (e != hipSuccess) {
+      gaib_set_error("gaib_graph_sort_rows: %s", hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? GAIB_ERR_NOMEM : GAIB_ERR_HIP;
+    }
+  }
+  // everything laid out per edge follows the old order
+  void** per_edge[] = {(void**)&g->edata, (void**)&g->w_gcn, (void**)&g->w_mean_t, (void**)&g->rev, (void**)&g->chunk_row,
+                       (void**)&g->chunk_ebase, (void**)&g->chunk_start, (void**)&g->colidx_flagged};
+  for (void** p : per_edge) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  g->n_chunks = 0;
+  g->hot_threshold = -1;
+  g->near_frac = -1.f;
+  g->rows_unsorted = 0;
   return GAIB_OK;
 }
 

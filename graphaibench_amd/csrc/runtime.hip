@@ -70,6 +70,8 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_fused_bwd = -1;
   c->gat_fused_fwd = -1;
   c->gat_fused_unroll = 4;
+  c->gat_interleave = 0;
+  c->gat_chunk_xcd = 0;
   c->prof_on = 0;
   c->capturing = 0;
   c->live_execs = 0;
@@ -477,6 +479,10 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->gat_fused_fwd = (int)value;
   else if (!strcmp(key, "gat_fused_unroll"))
     ctx->gat_fused_unroll = (int)value;
+  else if (!strcmp(key, "gat_interleave"))
+    ctx->gat_interleave = (int)value;
+  else if (!strcmp(key, "gat_chunk_xcd"))
+    ctx->gat_chunk_xcd = (int)value;
   else if (!strcmp(key, "gat_fused_bwd"))
     ctx->gat_fused_bwd = (int)value;
   else if (!strcmp(key, "graph_rev_search"))

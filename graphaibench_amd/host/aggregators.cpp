@@ -293,7 +293,7 @@ void GAT_Aggregator::aggregate_partition(int len, Graph& g, const float* in, flo
     OpTimer t(OP_SCORE);
     g.halo_begin(len, in);
     GAIB_OR_DIE(gaib_memcpy_d2d(C(), d_ptab, in, sizeof(float) * n_own * len));
-    if (!dropping()) {
+    if (!dropping() && g.gat_symmetric()) {  // (an asymmetric graph: the staged path, which walks the transposed structure)
       const size_t need = n_own * heads * 2;
       if (need > stats_floats) {
         if (d_row_stats) float_free_device(d_row_stats);

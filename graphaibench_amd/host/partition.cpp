@@ -110,6 +110,17 @@ void build_gat_structures(VertexRangePartition& P, const index_t* rowptr, const 
     for (index_t e = rowptr[P.lo + i]; e < rowptr[P.lo + i + 1]; e++) P.colidx_full[k++] = local_of(colidx[e]);
   }
   P.colidx_full.resize(ne);
+  // structural symmetry of this rank's rows, checked against the global CSR (sorted rows): the reverse of every edge exists
+  int asym = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(| : asym)
+  for (int64_t i = 0; i < n_own; i++) {
+    const index_t v = (index_t)(P.lo + i);
+    for (index_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+      const index_t c = colidx[e];
+      if (!std::binary_search(colidx + rowptr[c], colidx + rowptr[c + 1], v)) asym = 1;
+    }
+  }
+  P.rows_symmetric = asym == 0;
   // transpose by counting sort on the local column id; stable, so the rows of a column come out ascending
   P.rowptr_t.assign(nc + 1, 0);
   for (int64_t e = 0; e < ne; e++) P.rowptr_t[P.colidx_full[e] + 1]++;
@@ -184,6 +195,14 @@ LearningGraph* make_partitioned_graph(const VertexRangePartition& P, gaib_comm* 
     index_t* d_tperm = gaib_host::dmalloc<index_t>((size_t)ne);
     if (ne) GAIB_OR_DIE(gaib_memcpy_h2d(ctx, d_tperm, P.tperm.data(), sizeof(index_t) * (size_t)ne));
     lg->set_gat_partition(g_full, g_t, d_tperm, n_halo, ne);
+    // the one-sweep kernels need a structurally symmetric GLOBAL graph: every rank checked its rows; all ranks take the
+    // same path (they run different collectives in backward), so the verdict is the sum over the ranks
+    double asym = P.rows_symmetric ? 0.0 : 1.0;
+    if (P.world > 1) GAIB_OR_DIE(gaib_allreduce_host_f64(comm, &asym, 1));
+    lg->set_gat_symmetric(asym == 0.0);
+    if (asym != 0.0 && P.rank == 0)
+      fprintf(stderr, "make_partitioned_graph: the graph is not structurally symmetric (%d rank(s) hold an edge without its "
+              "reverse): GAT on this partition takes the staged path (transposed structure + reverse exchange)\n", (int)asym);
   }
   lg->own_partition_objects();
   float* tmp[] = {d_vd, d_inv, d_vd_h, d_inv_h};  // set_vertex_norm copied them

@@ -712,6 +712,24 @@ int launch_ranks(int n, char** argv) {
     fprintf(stderr, "GAIB_RANKS: at most 64 ranks\n");
     return 1;
   }
+  // under a profiler the tool's preloaded library has initialised the GPU in THIS process before main: forking and
+  // exec'ing ranks from it is the exec this pool forbids.  Refuse, and say what works.
+  {
+    const char* tool = getenv("ROCP_TOOL_LIBRARIES");
+    const char* pre = getenv("LD_PRELOAD");
+    const char* hsa = getenv("HSA_TOOLS_LIB");
+    auto names_profiler = [](const char* v) { return v && (strstr(v, "rocprof") || strstr(v, "roctracer")); };
+    if ((tool && *tool) || names_profiler(pre) || names_profiler(hsa)) {
+      fprintf(stderr, "[launcher] GAIB_RANKS under a profiler (ROCP_TOOL_LIBRARIES / LD_PRELOAD / HSA_TOOLS_LIB name one): its "
+                      "library touches the GPU before main, and such a process must not start rank programs.  Profile ONE "
+                      "rank directly: RANK=r WORLD_SIZE=N LOCAL_RANK=r GAIB_COMM_ID_FILE=<shared path> rocprofv3 ... -- %s ...\n",
+              argv[0]);
+      return 2;
+    }
+  }
+  // several ranks per device (more ranks than GPUs: tests, one-GPU boxes) move the rows over hipIpc handles, and the host
+  // driver of this pool only supports the dmabuf kind
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
   const char* dl = getenv("GAIB_RANKS_DEADLINE_S");
   const double deadline_s = dl ? atof(dl) : 0.0;  // 0: none (training runs have no natural bound); a dead rank still ends the job
   char idfile[96], nbuf[16];

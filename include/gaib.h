@@ -146,6 +146,12 @@ int gaib_graph_add_selfloop(gaib_ctx* ctx, const gaib_graph* g, gaib_graph** out
 #define GAIB_ORDER_CM 3 /* the BFS levels, inside a level by the position of the first parent (Cuthill-McKee) */
 int gaib_graph_reorder(gaib_ctx* ctx, gaib_graph* g, int method, gaib_graph** out, int64_t* d_new_of_old,
                        int64_t* d_old_of_new);
+/* A relabelled graph's rows keep their edge order, i.e. their column ids are NOT ascending: it is an aggregation-only
+ * graph -- gaib_edge_transpose / GAIB_W_EDGE_T / the GAT backward entry points, which derive the reverse-edge permutation
+ * from sorted rows (math_functions.cpp:32-44), refuse it with GAIB_ERR_UNSUPPORTED.  gaib_graph_sort_rows sorts every row's
+ * column ids (in place; per-edge caches are rebuilt on demand): everything runs on it, and aggregation results are then equal
+ * to the original numbering's up to fp32 summation order instead of bit for bit. */
+int gaib_graph_sort_rows(gaib_ctx* ctx, gaib_graph* g);
 int64_t gaib_graph_nv(const gaib_graph* g);
 int64_t gaib_graph_ne(const gaib_graph* g);
 int64_t gaib_graph_nc(const gaib_graph* g); /* columns = rows of the feature table its column ids index (nv unless rectangular) */

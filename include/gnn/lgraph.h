@@ -37,6 +37,7 @@ class LearningGraph {
   index_t* gat_tperm_;
   index_t gat_n_halo_;
   bool owns_partition_;  // make_partitioned_graph built halo_dev_ / halo_plan_ / gat_*: dealloc() releases them too
+  bool gat_symmetric_ = true;
   // Row classes of the partition (gaib_graph_split_classes; the reference partitioner's owned rows / halo vertices,
   // src/partitioner/graph_partition.cc:70-80): INTERIOR rows -- no halo-column edge -- are aggregated in one pass (with
   // the dense product riding on it) while the halo rows travel; BOUNDARY rows either keep the column split (owned-column
@@ -121,6 +122,10 @@ class LearningGraph {
     gat_n_halo_ = (index_t)n_halo;
     num_edges_ = (index_t)ne_full;
   }
+  // false: an edge of the GLOBAL graph lacks its reverse (make_partitioned_graph checks, summed over the ranks): the
+  // one-sweep GAT kernels on the partition are then wrong (they read a row's in-edges off its out-edges); staged path
+  void set_gat_symmetric(bool yes) { gat_symmetric_ = yes; }
+  bool gat_symmetric() const { return gat_symmetric_; }
   gaib_graph* gat_full_graph() { return gat_full_; }
   gaib_graph* gat_transposed_graph() { return gat_t_; }
   const index_t* gat_tperm() { return gat_tperm_; }

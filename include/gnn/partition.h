@@ -32,6 +32,10 @@ struct VertexRangePartition {
   std::vector<int64_t> rowptr_t;      // [n_own + n_halo + 1]
   std::vector<index_t> colidx_t;      // owned row ids
   std::vector<index_t> tperm;         // tperm[k] = edge id (in rowptr_full / colidx_full order) of transposed entry k
+  // build_gat_structures: every edge (i -> c) of this rank's rows has its reverse (c -> i) in the GLOBAL graph.  The
+  // one-sweep GAT kernels on a partition read the in-edges of a row off its out-edges and are only correct on a
+  // structurally symmetric graph; make_partitioned_graph sums the flag over the ranks (all of them must take the same path)
+  bool rows_symmetric = true;
   int64_t n_own() const { return hi - lo; }
   int64_t n_halo() const { return (int64_t)halo_gids.size(); }
 };

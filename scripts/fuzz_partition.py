@@ -38,6 +38,11 @@ def run_case(comm, rank, world, cfg):
         rp = np.zeros(n + 1, np.int64)
         np.add.at(rp, key // n + 1, 1)
         rp, ci = np.cumsum(rp), (key % n).astype(np.uint32)
+    if cfg.get("drop_reverse", 0.0) > 0:  # a DIRECTED graph: a share of the edges u -> v (u < v) goes, v -> u stays
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        keep = ~((rows < ci) & (np.random.default_rng(gseed + 7).random(len(ci)) < cfg["drop_reverse"]))
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=n))]).astype(np.int64)
+        ci = ci[keep]
     part = L.HostPartition(rp, ci, rank, world, gat=arch == "gat")
     lo, hi = part.lo, part.hi
     lg = part.make_graph(comm)

@@ -486,6 +486,12 @@ def _fewer_vertices_than_ranks(rank, world, idfile, q, transport_name):
         ctx = L.init(0)
         comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
         L.set_comm(comm)
+        # a DIRECTED graph (the one-sweep kernels read a row's in-edges off its out-edges, which is only right on a
+        # structurally symmetric graph): make_partitioned_graph finds the missing reverse edges, all ranks agree, and the layer
+        # takes the staged path -- transposed structure + reverse exchange -- whose results match the fp64 evaluation
+        for heads in (1, 8):
+            run_case(comm, rank, world, dict(n=2500, avg=12.0, hub=0, gseed=77, arch="gat", din=48, d=64, heads=heads,
+                                             drop_reverse=0.3))
         for n, avg in ((1, 0.0), (2, 4.0), (3, 0.7), (5, 4.0), (300, 6.0)):
             for arch, d, heads in (("gcn", 64, 1), ("gcn", 16, 1), ("sage", 64, 1), ("gat", 64, 8), ("gat", 64, 1), ("gat", 128, 4),
                                    ("gat", 16, 2)):

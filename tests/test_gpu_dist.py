@@ -152,8 +152,12 @@ def test_bench_plain_invocation_config5_shape_matches_global_oracle():
                    rec["W_grad"]["elem"], rec["W_grad"]["inf"]) <= 1e-4, rec
         assert "GLOBAL graph" in rec["against"]
     assert par["ok"]
-    bd = cfg["breakdown_ms_per_step_rank0"]
-    assert bd["owned_edge_spmm_ms"] > 0 and bd["halo_half_ms"] > 0 and bd["pack_ms"] > 0
+    bd, pm = cfg["breakdown_ms_per_step_rank0"], cfg["partition_mode_rank0"]
+    assert bd["pack_ms"] > 0 and pm["mode"] in ("split", "classes", "onepass") and 0 < pm["boundary_rows"] <= cfg["nv_per_gpu"]
+    if pm["mode"] == "split":
+        assert bd["owned_edge_spmm_ms"] > 0 and bd["halo_half_ms"] > 0
+    else:  # row classes: the interior pass and one of the boundary forms
+        assert bd["part_fused_ms"] > 0 and (bd.get("part_fused_2t_ms", 0) > 0 or bd.get("part_fused_acc_ms", 0) > 0)
 
 
 def test_bench_plain_two_gpus_default_workload():
@@ -163,12 +167,24 @@ def test_bench_plain_two_gpus_default_workload():
     import subprocess
 
     # GAIB_BENCH_CONFIG5=force: the sub-record the default 8-GPU run adds (config 5's graph in the same invocation), here at 2 ranks
+    import time
+
+    t0 = time.time()
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, env=dict(_clean_env(), GAIB_BENCH_CONFIG5="force"))
+    wall = time.time() - t0
     assert r.returncode == 0, r.stderr[-4000:]
     out = r.stdout.strip().splitlines()
     assert len(out) == 1
     res = json.loads(out[0])
+    # every sub-case is budgeted: the whole run stays inside --budget-s (default 420 s, under the driver's 600 s)
+    bud = res["config"]["budget"]
+    assert wall < bud["budget_s"] and bud["elapsed_s"] < bud["budget_s"] and "partial" not in res
+    # the sub-records of the default run: the clustered-boundary generator next to the uniform one, the N = 1 CPU baseline
+    cl = res["config"]["clustered_boundary"]
+    assert cl["value"] > 0 and 0 < cl["halo_rows_total"] < res["config"]["halo_rows_total"]
+    assert cl["partition_mode_rank0"]["boundary_row_share"] < res["config"]["partition_mode_rank0"]["boundary_row_share"]
+    assert res["cpu_baseline"]["value"] > 0 and "N = 1 workload" in res["cpu_baseline"]["of"]
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["transport"].startswith("gaib_comm/")
     if torch.cuda.device_count() < 2:
         assert res["config"]["transport"].startswith("gaib_comm/ipc") and res["config"]["rccl_ranks"] == 0
@@ -177,6 +193,25 @@ def test_bench_plain_two_gpus_default_workload():
     c5 = res["config"]["config5_papers100M"]
     assert c5["value"] > 0 and c5["halo_rows_total"] > 0 and "config 5" in c5["workload"]
     assert c5["nv_per_gpu"] == int(13_882_495 * 0.02)
+
+
+def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
+    """--budget-s smaller than any sub-case: the headline case runs, every further slot says {"skipped": "budget", ...},
+    exit 0, one line"""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                        "--budget-s", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(_clean_env(), GAIB_BENCH_CONFIG5="force"))
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1
+    res = json.loads(out[0])
+    assert res["value"] > 0 and res["ms_per_step"] > 0
+    for slot in (res["cpu_baseline"], res["config"]["clustered_boundary"], res["config"]["random_order"],
+                 res["config"]["config5_papers100M"]):
+        assert slot["skipped"] == "budget" and slot["elapsed_s"] > 1 and slot["needed_s_estimate"] > 0, slot
 
 
 def test_bench_under_torch_distributed_run_prints_one_line():

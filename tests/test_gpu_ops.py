@@ -1178,6 +1178,35 @@ def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
     assert_close(y.cpu().numpy(), y_w)
 
 
+def test_reordered_graph_is_aggregation_only_until_its_rows_are_sorted(ctx):
+    """gaib_graph_reorder keeps every row's edge ORDER, so the relabelled rows are not sorted by column id, and the
+    reverse-edge permutation (GAT backward, edge_transpose) is derived from sorted rows: on such a graph it is refused with a
+    message that names the remedy -- not a false "graph is not symmetric" -- and gaib_graph_sort_rows makes it work: the
+    transposed edge values then equal the oracle's on the relabelled graph"""
+    rp, ci = random_graph(4000, 12, seed=9, power_law=True, hub_deg=1500)
+    g = ctx.graph(rp, ci.view(np.int32)).add_selfloop()
+    r, new_of_old, old_of_new = g.reorder(capi.ORDER_BFS)
+    ew = torch.rand(r.ne, device="cuda")
+    out = torch.empty_like(ew)
+    with pytest.raises(capi.GaibError, match="gaib_graph_sort_rows"):
+        ctx.edge_transpose(r, ew, out)
+    x = dev(feat(r.nv, 64, 1))
+    agg_before = torch.empty(r.nv, 64, device="cuda")
+    ctx.spmm(r, capi.W_GCN, x, agg_before)  # aggregation is fine on the unsorted graph
+    r.sort_rows()
+    rp_n, ci_n = r.rowptr().cpu().numpy(), r.colidx().cpu().numpy().view(np.uint32)
+    for k in range(0, r.nv, 97):
+        row = ci_n[rp_n[k]:rp_n[k + 1]]
+        assert np.all(row[:-1] < row[1:])
+    g_o = orc.Graph(rp_n, ci_n)
+    ctx.edge_transpose(r, ew, out)
+    assert np.array_equal(out.cpu().numpy(), orc.symmetric_csr_transpose(g_o, ew.cpu().numpy()))
+    agg_after = torch.empty(r.nv, 64, device="cuda")
+    ctx.spmm(r, capi.W_GCN, x, agg_after)  # the same sums in another order
+    assert rel_err(agg_after.cpu().numpy(), agg_before.cpu().numpy()) < 1e-5
+    assert rel_err(agg_after.cpu().numpy(), orc.gcn_aggregate(g_o, x.cpu().numpy())) < 1e-5
+
+
 @pytest.mark.parametrize("method", ["degree", "bfs", "cm"])
 def test_graph_reorder_keeps_every_row_bit_identical(ctx, method):
     """gaib_graph_reorder (opt-in relabelling computed on the device): a permutation; hubs-first is by descending degree,

@@ -106,6 +106,92 @@ def test_launcher_deadline_ends_a_hanging_job(tmp_path):
         assert not _alive(int(f.read_text()))
 
 
+def test_rank_guard_prints_the_held_record_when_the_deadline_cuts_a_sub_case(tmp_path):
+    """the N > 1 record cannot be lost: rank 0 holds the headline record, a later sub-case hangs (here: sleeps in C), the
+    rank's own deadline fires -> rank 0 prints the held record marked partial and exits 0, the other rank exits 124, the
+    launcher relays the line and reports success"""
+    body = f"""
+        import os, sys, time
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{{r}}"), "w").write(str(os.getpid()))
+        g = bench.install_rank_guard(r, 2.0)
+        if r == 0:
+            g.hold({{"value": 42.0, "n_gpus": 2, "config": {{"random_order": None}}}})
+        time.sleep(300)  # the sub-case that never returns
+    """
+    r, took = _run_launcher(tmp_path, body, 2, deadline=60.0)
+    assert r.returncode == 0 and took < 30, (r.returncode, took, r.stderr)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 42.0 and "deadline" in rec["partial"]["reason"]
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text()))
+
+
+def test_rank_guard_prints_the_held_record_on_sigterm(tmp_path):
+    """... and when the launcher (or the driver) ends the run from outside: SIGTERM reaches a rank that sits in a C call,
+    a watcher thread -- not a Python signal handler -- prints what is held"""
+    body = f"""
+        import ctypes, os, sys, time
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{{r}}"), "w").write(str(os.getpid()))
+        g = bench.install_rank_guard(r, 500.0)
+        if r == 0:
+            g.hold({{"value": 7.0, "n_gpus": 2, "config": {{}}}})
+        ctypes.CDLL(None).sleep(300)  # blocked inside C: no bytecode runs, a Python-level handler would never fire
+    """
+    r, took = _run_launcher(tmp_path, body, 2, deadline=2.0)
+    assert r.returncode == 0 and took < 30, (r.returncode, took, r.stderr)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 7.0 and "signal" in rec["partial"]["reason"]
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text()))
+
+
+def test_rank_guard_emits_exactly_one_line(tmp_path):
+    """final() after hold(): one line, not marked partial; a bail() that races with it prints nothing more"""
+    prog = tmp_path / "one.py"
+    prog.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        g = bench.install_rank_guard(0, 500.0)
+        g.hold({{"value": 1.0}})
+        g.final({{"value": 2.0}})
+        g.bail("late")  # returns: the record is out
+        g.final({{"value": 3.0}})
+    """))
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert [json.loads(l) for l in r.stdout.strip().splitlines()] == [{"value": 2.0}]
+
+
+def test_budget_skips_sub_cases_collectively():
+    """dist.Budget: a sub-case starts only if EVERY rank still has its estimated time (all-reduce(MIN)); a skipped slot says so"""
+    from graphaibench_amd.dist import Budget
+
+    now = [100.0]
+    votes = []
+
+    def reduce_min(flag):  # rank B of a two-rank run is always 30 s behind
+        other = 1 if (400.0 - (now[0] + 30.0 - 100.0)) >= votes[-1] else 0
+        return min(flag, other)
+
+    b = Budget(400.0, 100.0, reduce_min, clock=lambda: now[0])
+    votes.append(50.0)
+    assert b.agree(50.0)  # 400 s left here, 370 on the other rank
+    now[0] = 100.0 + 340.0
+    votes.append(50.0)
+    assert b.left() == 60.0 and not b.agree(50.0)  # this rank could (60 s left), the other cannot (30 s): nobody runs it
+    sk = b.skipped(50.0)
+    assert sk == {"skipped": "budget", "elapsed_s": 340.0, "budget_s": 400.0, "needed_s_estimate": 50.0}
+    votes.append(500.0)
+    assert not b.agree(500.0)
+
+
 def test_bench_plain_invocation_without_gpu_fails_fast_and_clean():
     """`python bench.py --gpus 2` with a clean environment on a box without a GPU: the parent starts the ranks, they
     refuse to run without a GPU (no CPU fallback), the launcher reports it and exits non-zero -- no hang, no JSON"""
