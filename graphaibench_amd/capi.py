@@ -130,6 +130,7 @@ SIGNATURES = {
     "gaib_graph_locality": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "gaib_graph_stats": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gaib_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "gaib_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "gaib_device_count": (_i, [C.POINTER(_i)]),
     "gaib_comm_transport_available": (_i, [_i]),
     "gaib_comm_unique_id": (_i, [_i, _vp]),
@@ -378,6 +379,11 @@ class Context:
 
     def set_option(self, key: str, value: int):
         _check(self.lib.gaib_set_option(self.h, key.encode(), int(value)), f"gaib_set_option({key})")
+
+    def get_option(self, key: str) -> int:
+        v = _i64()
+        _check(self.lib.gaib_get_option(self.h, key.encode(), C.byref(v)), f"gaib_get_option({key})")
+        return v.value
 
     # ---- in-stream kernel timing ----------------------------------------------------------
     def prof_enable(self, on: bool = True):

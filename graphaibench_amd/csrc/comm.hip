@@ -403,6 +403,12 @@ extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h
       return GAIB_ERR_COMM;
     }
     c->nranks = cnt;
+    // RCCL's send / recv kernels need CUs to land on while the persistent fused aggregation runs (GAIB_OVERLAPS_TRANSFER):
+    // one eighth of the chip, measured to cost that kernel 1.5 %; GAIB_COMM_RESERVE_CUS / the option override
+    if (cnt > 1 && ctx->comm_reserve_cus == 0) {
+      const char* e = getenv("GAIB_COMM_RESERVE_CUS");
+      ctx->comm_reserve_cus = e ? atoi(e) : 32;
+    }
     *out = c;
     return GAIB_OK;
   }

@@ -45,6 +45,8 @@ void gaib_set_error(const char* fmt, ...);
                                 "sequence once before capturing it (buffers and lazily built tables then exist)", what)
 
 
+#define GAIB_FLAT_RING_DEFAULT 1  // spmm_flat_ring's default (see spmm_kernels.h RING)
+
 struct gaib_ctx {
   int device;
   hipStream_t stream;
@@ -69,6 +71,10 @@ struct gaib_ctx {
   int spmm_pad;              // 1 = re-stride odd-width input tables where that saves >10 % of the gathered lines, 0 = never
   int spmm_fuse;             // 1 = gaib_spmm_gemm may fuse the dense product into the aggregation
   int spmm_flat;             // fused kernel, edge-stream form for short rows: -1 = by average degree, 0 = never, 1 = always
+  int spmm_flat_ring;        // edge-stream form: 1 (default) = software-pipelined gathers (U always in flight), 0 = batches of U
+  int comm_reserve_cus;      // CUs the persistent fused kernel leaves free while a halo exchange is in flight (GAIB_OVERLAPS_TRANSFER):
+                             // set by gaib_comm_init -- 32 under RCCL with more than one rank (its send / recv kernels need CUs to
+                             // land on: the fused kernel holds every register of the CUs it sits on until its last tile), 0 otherwise
   int spmm_fuse_cus;         // fused kernel: persistent workgroups (= CUs it occupies); 0 = all CUs.  Fewer leave whole CUs to a kernel on another stream
   int spmm_tile_xcd;         // fused kernel's tile supply: -1 (default) = by the graph's numbering (XCD-affine chunks of 1024 tiles where the numbering has locality, else one global counter), 0 = global counter, n > 0 = XCD-affine chunks of n tiles
   int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8

@@ -408,8 +408,8 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   GAIB_CHECK(len_in >= 0 && len_out >= 0, "gaib_spmm_gemm: negative length");
   GAIB_CHECK(ctx->device == g->device, "gaib_spmm_gemm: graph lives on device %d, ctx on %d", g->device,
              ctx->device);
-  GAIB_CHECK((flags & ~(GAIB_RELU | GAIB_AGG_SCRATCH | GAIB_ACCUMULATE)) == 0, "gaib_spmm_gemm: unsupported flags %d",
-             flags);
+  GAIB_CHECK((flags & ~(GAIB_RELU | GAIB_AGG_SCRATCH | GAIB_ACCUMULATE | GAIB_OVERLAPS_TRANSFER)) == 0,
+             "gaib_spmm_gemm: unsupported flags %d", flags);
   GAIB_CHECK((d_rows2 == nullptr) == (d_W2 == nullptr), "gaib_spmm_gemm2: rows2 and W2 go together");
   if (g->nv == 0 || len_out == 0) return GAIB_OK;
   GAIB_CHECK(d_in && d_agg && d_W && d_out, "gaib_spmm_gemm: NULL pointer");
@@ -494,6 +494,7 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
       f.tile_counter = counter;
       f.agg_in = (flags & GAIB_ACCUMULATE) ? d_agg + k0 : nullptr;
       f.y_accum = k0 > 0;
+      f.overlaps_transfer = (flags & GAIB_OVERLAPS_TRANSFER) ? 1 : 0;
       f.tile_xcd = tile_xcd_arg(ctx, g);
       f.relu = ((flags & GAIB_RELU) && !dual && k0 + 128 >= len_in) ? 1 : 0;
       f.heavy_agg = hv + k0;
@@ -543,6 +544,7 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   f.rows2 = d_rows2;
   f.ldw = len_in;
   f.y_accum = 0;
+  f.overlaps_transfer = (flags & GAIB_OVERLAPS_TRANSFER) ? 1 : 0;
   f.tile_xcd = tile_xcd_arg(ctx, g);
   f.y = d_out;
   f.ldy = len_out;

@@ -304,6 +304,7 @@ struct FuseArgs {
   const float* rows2;         // DUAL: second row operand [n_rows][ncols]:  y += rows2[i,:] . op(W2)
   int ldw;                    // row stride of wt / wt2 in floats (== ncols unless the launch handles a K-slab of a wider matrix)
   int y_accum;                // y += instead of y = (the second K-slab of a 129..256-wide aggregation; not with DUAL)
+  int overlaps_transfer;      // GAIB_OVERLAPS_TRANSFER: leave ctx->comm_reserve_cus CUs to the transport's kernels
   int tile_xcd;               // 0: one global counter; n > 0: tiles off eight per-XCD counters over interleaved chunks of 2^(n-1) tiles
 };
 
@@ -338,7 +339,18 @@ constexpr int FUSE_WAVES = 16;
 // 12 M edges over 2.4 M rows, 1.3 ms of traffic).  Here the edges of a strip's rows are ONE stream: column ids and
 // weights are loaded 64 edges at a time, U gathers are in flight whatever rows they belong to, and the running sum
 // moves to the next row when the edge index passes a row boundary (wave-uniform control).  Same edge order, same sums.
-template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL, bool FLAT = false, bool YACC = false, bool PART = false>
+// RING (with FLAT): the strip's edge stream as a software pipeline instead of batches.  Batch by batch a wave holds U
+// gathers in flight, waits for all of them, consumes them, issues the next U: the bytes in flight follow a sawtooth
+// between U and 0 rows, and at 16 waves per CU that average is what bounds the halo-column half of a partitioned
+// aggregation (3-5 edges per row: 5.2 TB/s of the bytes it moves where the row kernels reach 7.5).  Here edge e's gather
+// is re-issued into the register edge e - U has just been consumed from: U rows are in flight from the strip's first edge to
+// its last.  The column ids of the strip's first 64 edges are requested BEFORE the partial sums the strip continues (the
+// gathers hang on the former only), those of the next 64 while the current ones are consumed.  Same edge order, same sums.
+// AFFINE: the XCD-affine tile supply is compiled in.  A template flag, not a run-time test: with both supplies in one loop the
+// global-counter form -- the headline's, a random vertex order -- ran 0.5 % slower than before the affine supply existed
+// (7.597 -> 7.635 ms per launch, bisected to that change on one box: scripts/drift_ab.sh, profiles/r04/drift_*.jsonl).
+template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL, bool FLAT = false, bool YACC = false, bool PART = false,
+          bool RING = false, bool AFFINE = false>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int K = 64 * VEC;  // padded inner dimension; a.ncols (<= K) columns are real
@@ -375,24 +387,24 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
   // with 16-tile chunks those are 32 chunks spread over 65 536 rows of the numbering (round 2: natural order 7.0 ms, no
   // better than the global counter's 6.7); with chunks of 512 tiles they are one run of consecutive rows.  An XCD whose
   // chunks are used up steals from the XCD that has the most tiles left.
-  const int tsh = f.tile_xcd - 1;  // log2 of the chunk length in tiles (tile_xcd = 0: one global counter)
-  int own = f.tile_xcd ? (int)(blockIdx.x & 7) : 0;  // the XCD whose counter this wave is drawing from
+  const int tsh = AFFINE ? f.tile_xcd - 1 : 0;  // log2 of the chunk length in tiles
+  int own = AFFINE ? (int)(blockIdx.x & 7) : 0;  // the XCD whose counter this wave is drawing from
   int k_next = 0, k_left = 0;
   const int nwaves4 = ((int)gridDim.x * FUSE_WAVES * 4) / 8 > 0 ? ((int)gridDim.x * FUSE_WAVES * 4) / 8 : 1;
   const int per_xcd_tiles = (ntiles + 7) / 8;  // about what one XCD's chunks hold
-  const int n_chunks = f.tile_xcd ? (ntiles + (1 << tsh) - 1) >> tsh : 0;
+  const int n_chunks = AFFINE ? (ntiles + (1 << tsh) - 1) >> tsh : 0;
   for (;;) {
     if (k_left == 0) {
       int want = 1;
       if constexpr (FLAT) {  // guided: (tiles this XCD has left) / (4 x its waves), at most 8, single tiles at the end
-        const int left = f.tile_xcd ? per_xcd_tiles - k_next : (ntiles - k_next) / 8;
+        const int left = AFFINE ? per_xcd_tiles - k_next : (ntiles - k_next) / 8;
         want = (left > 0 ? left : 0) / nwaves4;
         want = want < 1 ? 1 : (want > 8 ? 8 : want);
       }
       int k0 = 0;
       if (lane == 0) k0 = atomicAdd(f.tile_counter + own, want);
       k0 = __builtin_amdgcn_readfirstlane(k0);
-      if (!f.tile_xcd) {  // one global counter: tiles in order
+      if constexpr (!AFFINE) {  // one global counter: tiles in order
         if (k0 >= ntiles) break;
       } else if ((((k0 >> tsh) * 8 + own) << tsh) >= ntiles) {
         // this XCD's chunks are used up: steal from the XCD that has the most tiles left (lane x looks at counter x;
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
     }
     const int kk = k_next++;
     --k_left;
-    const int t = f.tile_xcd ? ((((kk >> tsh) * 8 + own) << tsh) + (kk & ((1 << tsh) - 1))) : kk;
+    const int t = AFFINE ? ((((kk >> tsh) * 8 + own) << tsh) + (kk & ((1 << tsh) - 1))) : kk;
     if (t >= ntiles) continue;  // the ragged end of the last chunk
     const int row0 = t * FUSE_ROWS;
     // PART: lane r holds the row of the caller's matrices that tile row r stands for (rows past the end: the last one's)
@@ -464,6 +476,23 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
           const int64_t e_lo = rp_at(rbase), e_hi = rp_at(rbase + HALF);
           const RowGather<VEC, GM, PART> gather(a);
           float* trow_w = tile + lane * VEC;  // this lane's columns of strip row 0
+          // RING: ids and weights of the strip's first (and second) 64 edges, lane l holds edge 64 q + l
+          const int total = (int)(e_hi - e_lo);  // (a strip without heavy rows: at most HALF x heavy_thr edges)
+          uint32_t c_cur = 0, c_nxt = 0;
+          float w_cur = 0.f, w_nxt = 0.f;
+          auto load_ids = [&](int q, uint32_t& c, float& w) {
+            const int64_t e = e_lo + 64 * (int64_t)q + lane;
+            c = 0;
+            w = 0.f;
+            if (e < e_hi) {
+              c = a.col[e];
+              if constexpr (WMODE == 1 || WMODE == 2) w = load_edge_w<WMODE>(a, e);
+            }
+          };
+          if constexpr (RING) {
+            load_ids(0, c_cur, w_cur);
+            if (total > 64) load_ids(1, c_nxt, w_nxt);
+          }
           if (f.agg_in) {
             // accumulate mode: the strip starts out as the partial sums of its rows (all requests first)
             vec_t t[HALF];
@@ -494,7 +523,43 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
               if constexpr (WMODE == 0) roww = readlane_f(rwv, rbase + r);
             }
           };
-          for (int64_t base = e_lo; base < e_hi; base += 64) {
+          if constexpr (RING) {
+            vec_t x[U];
+            if (total > 0) {
+#pragma unroll
+              for (int u = 0; u < U; ++u)  // (edges past the strip's end read row 0 of the table: never consumed)
+                x[u] = gather.load((uint32_t)__builtin_amdgcn_readlane((int)c_cur, u), voff[0]);
+            }
+            for (int k = 0; k < total; k += U) {
+              const int kc = k & 63;
+              if (kc == 0 && k > 0) {  // entering the next 64 edges: their ids are here, request the ones after them
+                c_cur = c_nxt;
+                w_cur = w_nxt;
+                if (k + 64 < total) load_ids((k >> 6) + 1, c_nxt, w_nxt);
+              }
+              const bool wrap = kc == 64 - U;  // the refills of this batch belong to the next 64 edges
+              const uint32_t c_src = wrap ? c_nxt : c_cur;
+              if (k + 2 * U <= total) {  // a full batch with a full batch behind it: straight-line
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  while (e_lo + k + u == row_end) flush();
+                  vacc<VEC>(acc, (WMODE == 0) ? roww : readlane_f(w_cur, kc + u), x[u]);
+                  x[u] = gather.load((uint32_t)__builtin_amdgcn_readlane((int)c_src, (kc + u + U) & 63), voff[0]);
+                }
+              } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  if (k + u < total) {
+                    while (e_lo + k + u == row_end) flush();
+                    vacc<VEC>(acc, (WMODE == 0) ? roww : readlane_f(w_cur, kc + u), x[u]);
+                  }
+                  if (k + u + U < total)
+                    x[u] = gather.load((uint32_t)__builtin_amdgcn_readlane((int)c_src, (kc + u + U) & 63), voff[0]);
+                }
+              }
+            }
+          }
+          for (int64_t base = e_lo; base < e_hi && !RING; base += 64) {
             const int64_t rem = e_hi - base;
             const int n = rem < 64 ? (int)rem : 64;
             uint32_t c = 0;
@@ -769,30 +834,47 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     else spmm_heavy_kernel<VEC, 1, WMODE, U, 0, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
   }
+  if constexpr (PART) f.tile_xcd = 0;
   const bool dual = f.wt2 != nullptr;
   const int strip = fuse_strip_rows(K, f.n_out, dual);  // 8, 2 or 0 (does not fit: the caller checked)
   const size_t lds = fuse_lds_bytes(K, f.n_out, dual, strip);
   const int64_t ntiles = cdiv64(a.n_rows, FUSE_ROWS);
-  const int cus = ctx->spmm_fuse_cus > 0 ? ctx->spmm_fuse_cus : ctx->num_cus;
+  int cus = ctx->spmm_fuse_cus > 0 ? ctx->spmm_fuse_cus : ctx->num_cus;
+  // a halo exchange is in flight on the communication stream (the caller said so): its kernels need CUs to land on, and a
+  // persistent workgroup of this kernel owns its CU's registers until the last tile (measured: 224 of 256 CUs cost 1.5 %)
+  if (f.overlaps_transfer && ctx->comm_reserve_cus > 0) cus = std::max(cus - ctx->comm_reserve_cus, std::min(cus, 64));
   const unsigned grid = (unsigned)std::min<int64_t>(cus, cdiv64(ntiles, FUSE_WAVES));
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, 8 * sizeof(int), ctx->stream));  // one counter per XCD
   ProfScope ps(ctx, !PART ? "spmm_gemm_fused" : (a.in2 ? "part_fused_2t" : (f.agg_in ? "part_fused_acc" : "part_fused")));
   // more than 64 KB of dynamic LDS has to be asked for
   // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
   // spill and are reloaded inside the MFMA loop)
-#define GAIB_FUSED_LAUNCH_Y(GM, STRIP, DUAL, FLAT, YACC)                                                              \
+#define GAIB_FUSED_LAUNCH_A(GM, STRIP, DUAL, FLAT, YACC, RING, AFF)                                                   \
   do {                                                                                                                \
     constexpr int UU = FLAT ? 8 : U;                                                                                  \
-    GAIB_HIP(hipFuncSetAttribute((const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART>,    \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
-    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART>                                               \
+    GAIB_HIP(hipFuncSetAttribute(                                                                                     \
+        (const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART, RING, AFF>,                  \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                                     \
+    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART, RING, AFF>                                    \
         <<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f);                                                    \
   } while (0)
+  // (row classes of a partition are rectangular graphs: their numbering is never measured as local, no affine variants)
+#define GAIB_FUSED_LAUNCH_R(GM, STRIP, DUAL, FLAT, YACC, RING)                                                        \
+  do {                                                                                                                \
+    if constexpr (!PART) {                                                                                            \
+      if (f.tile_xcd) GAIB_FUSED_LAUNCH_A(GM, STRIP, DUAL, FLAT, YACC, RING, true);                                   \
+      else GAIB_FUSED_LAUNCH_A(GM, STRIP, DUAL, FLAT, YACC, RING, false);                                             \
+    } else {                                                                                                          \
+      GAIB_FUSED_LAUNCH_A(GM, STRIP, DUAL, FLAT, YACC, RING, false);                                                  \
+    }                                                                                                                 \
+  } while (0)
+#define GAIB_FUSED_LAUNCH_Y(GM, STRIP, DUAL, FLAT, YACC) GAIB_FUSED_LAUNCH_R(GM, STRIP, DUAL, FLAT, YACC, false)
 #define GAIB_FUSED_LAUNCH(GM, STRIP, DUAL, FLAT) GAIB_FUSED_LAUNCH_Y(GM, STRIP, DUAL, FLAT, false)
   // short rows (fewer than 12 edges per row on average: halo-column halves, citation graphs): the edge-stream form
   // (scripts/ab_flat.py: -34 % at 3 edges per row, -20 % at 5, even at 12, +2 % at 30)
   const bool flat = !dual && strip == 8 && !f.y_accum &&
-                    (ctx->spmm_flat == 1 || (ctx->spmm_flat < 0 && g->ne < 12 * (int64_t)a.n_rows));
+                    (ctx->spmm_flat >= 1 || (ctx->spmm_flat < 0 && g->ne < 12 * (int64_t)a.n_rows));
+  const bool ring = flat && ctx->spmm_flat_ring != 0;  // the edge stream as a software pipeline (see RING)
   if (f.y_accum) {  // the second K-slab of a 129..256-column aggregation (VEC == 2 only; never dual or flat; not on row classes)
     if constexpr (VEC == 2 && !PART) {
       if (buf) {
@@ -806,14 +888,18 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   } else if (buf) {
     if (dual) GAIB_FUSED_LAUNCH(1, 2, true, false);
     else if (strip == 2) GAIB_FUSED_LAUNCH(1, 2, false, false);
+    else if (flat && ring) GAIB_FUSED_LAUNCH_R(1, 8, false, true, false, true);
     else if (flat) GAIB_FUSED_LAUNCH(1, 8, false, true);
     else GAIB_FUSED_LAUNCH(1, 8, false, false);
   } else {
     if (dual) GAIB_FUSED_LAUNCH(0, 2, true, false);
     else if (strip == 2) GAIB_FUSED_LAUNCH(0, 2, false, false);
+    else if (flat && ring) GAIB_FUSED_LAUNCH_R(0, 8, false, true, false, true);
     else if (flat) GAIB_FUSED_LAUNCH(0, 8, false, true);
     else GAIB_FUSED_LAUNCH(0, 8, false, false);
   }
+#undef GAIB_FUSED_LAUNCH_A
+#undef GAIB_FUSED_LAUNCH_R
 #undef GAIB_FUSED_LAUNCH
 #undef GAIB_FUSED_LAUNCH_Y
   GAIB_LAUNCH_CHECK();

@@ -643,6 +643,12 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                     "pair": [0, 1]}
         except capi.GaibError as e:
             link = {"error": str(e)[:200]}
+    # the partition-mode rule (LearningGraph::partition_mode) prices the exchange per peer pair: with the MEASURED link rate
+    # where there is one (every rank gets rank 0's figure before any partitioned graph exists), else the library's default
+    got = [link["unidirectional_gbs"] if (rank == 0 and isinstance(link, dict) and "unidirectional_gbs" in link) else None]
+    dist.broadcast_object_list(got, src=0)
+    if got[0] and "GAIB_LINK_GBS" not in os.environ:
+        os.environ["GAIB_LINK_GBS"] = f"{float(got[0]):.1f}"
     dist.barrier()
     strong = getattr(args, "scaling", "weak") == "strong"
     cut = 0.1 if args.cut_fraction is None else args.cut_fraction
@@ -726,6 +732,9 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 "parallelism": f"vertex-range x{world}",
                 # rccl_ranks: what ncclCommCount reports for the communicator that carried the halo rows (0: RCCL not used)
                 "transport": transport, "rccl_ranks": rccl_ranks,
+                # CUs the persistent fused aggregation leaves free while an exchange is in flight (gaib_comm_init: 32 under
+                # RCCL with more than one rank -- 1.5 % of that kernel, DESIGN 3.5 --, 0 on the peer-to-peer pull transport)
+                "cu_reserve_for_transport": ctx.get_option("comm_reserve_cus"),
                 # the same cut with the cut edges on a boundary band (what a METIS / breadth-first partition looks like)
                 "clustered_boundary": clustered,
                 # the other end of the partition-quality axis, same invocation (weak scaling only)

@@ -75,7 +75,7 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
       return;
     }
     g.halo_begin(len, in);
-    fused(g.class_interior(), in, flags);
+    fused(g.class_interior(), in, flags | GAIB_OVERLAPS_TRANSFER);  // (the exchange is in flight: RCCL's kernels need CUs)
     if (mode == Graph::PART_CLASSES) {
       if (gaib_graph_ne(g.class_boundary_halo()) == 0) {  // no boundary row
         g.halo_end(len);
@@ -96,7 +96,7 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
     // carry the dense product(s)
     g.halo_begin(len, in);  // every rank joins every exchange, also one without halo edges
     if (gaib_graph_ne(g.halo_graph()) == 0) {
-      fused(dev(g), in, flags);
+      fused(dev(g), in, flags | GAIB_OVERLAPS_TRANSFER);
       g.halo_end(len);
       return;
     }

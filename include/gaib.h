@@ -197,6 +197,10 @@ int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_
 #define GAIB_ACCUMULATE 1
 #define GAIB_RELU 2
 #define GAIB_AGG_SCRATCH 4 /* gaib_spmm_gemm: d_agg is scratch, its contents after the call are unspecified */
+#define GAIB_OVERLAPS_TRANSFER 8 /* gaib_spmm_gemm*: a halo exchange is in flight on the communicator's stream while this call
+                                  * runs (between gaib_halo_exchange_begin and _end).  The fused kernel is one persistent
+                                  * workgroup per CU that holds the CU's registers until its last tile; under RCCL it then leaves
+                                  * "comm_reserve_cus" CUs (32, set by gaib_comm_init; option) to the send / recv kernels */
 int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                  const float* d_in, float* d_out, int flags);
 /* multi-head attention weights: d_edge_w is [ne][heads]; column c uses head c / (len/heads).
@@ -576,6 +580,9 @@ int gaib_probe_peer_copy(int src_dev, int dst_dev, size_t bytes, int iters, int 
 
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ---- */
 int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value);
+/* what a record wants to name: "comm_reserve_cus" (CUs the fused kernel leaves to the transport, set by gaib_comm_init),
+ * "spmm_fuse_cus", "spmm_flat_ring", "num_cus" */
+int gaib_get_option(gaib_ctx* ctx, const char* key, int64_t* h_value);
 
 #ifdef __cplusplus
 }

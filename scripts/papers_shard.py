@@ -39,7 +39,7 @@ MODES = {"split": L.LGraph.PART_SPLIT, "classes": L.LGraph.PART_CLASSES, "onepas
          "onepass_all": L.LGraph.PART_ONEPASS_ALL, "auto": L.LGraph.PART_AUTO}
 
 
-def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",)):
+def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",), opts=""):
     t0 = time.time()
     # papers: the named graph is the GLOBAL one (each rank owns 1/8 of it); products: bench.py's weak-scaling
     # workload, one products-shaped range per rank
@@ -156,7 +156,7 @@ def run_mode(ctx, mode, S, steps):
     pack_ms = (time.perf_counter() - t0) / 3 * 1e3
     per_link = max(max(send_counts), max(recv_counts)) * D * 4
     out = dict(config="%s-shaped, vertex-range x8, rank %d's shard on one GPU" % (shape, rank), cut_fraction=cut,
-               boundary=boundary, band=band if boundary == "clustered" else None, mode_asked=mode,
+               boundary=boundary, band=band if boundary == "clustered" else None, mode_asked=mode, opts=S.get("opts", ""),
                mode=L.LGraph.PART_NAMES[mode_used], boundary_rows=n_bnd, boundary_row_share=n_bnd / nv,
                boundary_edges=bnd_edges, boundary_edge_share=bnd_edges / (ne_own + ne_halo) if mode_used else None,
                scale=scale, n_own=nv, ne_own_columns=ne_own, ne_halo_columns=ne_halo, n_halo_rows=n_halo,
@@ -188,14 +188,18 @@ def main():
     ap.add_argument("--band", type=float, default=0.2, help="clustered: share of a range's ids that form its boundary band")
     ap.add_argument("--mode", nargs="+", default=["split", "classes", "onepass", "onepass_all", "auto"], choices=list(MODES))
     ap.add_argument("--link-gbs", type=float, default=None, help="GAIB_LINK_GBS for the auto rule (default: the library's 100)")
+    ap.add_argument("--opts", default="", help="library options, key=value,... (gaib_set_option), e.g. spmm_flat_ring=1")
     args = ap.parse_args()
     if args.link_gbs is not None:
         import os
         os.environ["GAIB_LINK_GBS"] = str(args.link_gbs)
     ctx = L.init(0)
+    for kv in filter(None, args.opts.split(",")):
+        k, v = kv.split("=")
+        ctx.set_option(k.strip(), int(v))
     for cut in args.cut:
         for boundary in args.boundary:
-            run(ctx, args.rank, cut, args.steps, args.scale, args.shape, boundary, args.band, args.mode)
+            run(ctx, args.rank, cut, args.steps, args.scale, args.shape, boundary, args.band, args.mode, args.opts)
 
 
 if __name__ == "__main__":

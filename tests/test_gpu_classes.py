@@ -178,6 +178,47 @@ def test_class_fused_product_matches_round3_split(ctx, din, dout, kind, name, tr
         assert np.array_equal(y2.cpu().numpy().view(np.uint32), yy.view(np.uint32))
 
 
+@pytest.mark.parametrize("ring", [0, 1])
+@pytest.mark.parametrize("kind,name", KINDS)
+def test_class_halo_half_as_edge_stream(ctx, kind, name, ring):
+    """the halo-column half of the boundary rows through the fused kernel's edge-stream form (what 3-5 edges per row get),
+    in batches (ring 0) and as a software pipeline (ring 1): outputs through the row map, the same bits as the round-3 split"""
+    g_o, s = make_shard(ctx, selfloop=(kind == capi.W_GCN), seed=21)
+    din = dout = 128
+    x = feat(g_o.nv, din, 3)
+    W = dev(feat(din, dout, 4))
+    xo, xh = s.tables(x)
+    agg_r = torch.empty(s.n, din, device="cuda")
+    y_r = torch.empty(s.n, dout, device="cuda")
+    ctx.set_option("spmm_flat", 0)
+    try:
+        ctx.spmm(s.g_own, kind, xo, agg_r)
+        ctx.spmm_gemm(s.g_halo, kind, xh, agg_r, W, y_r, accumulate=True)
+    finally:
+        ctx.set_option("spmm_flat", -1)
+    c = s.cls
+    ctx.set_option("spmm_flat", 1)
+    ctx.set_option("spmm_flat_ring", ring)
+    try:
+        agg = torch.full((s.n, din), float("nan"), device="cuda")
+        y = torch.full((s.n, dout), float("nan"), device="cuda")
+        ctx.spmm_gemm(c["interior"], kind, xo, agg, W, y)
+        ctx.spmm(c["bnd_own"], kind, xo, agg)
+        ctx.spmm_gemm(c["bnd_halo"], kind, xh, agg, W, y, accumulate=True)
+        y2 = torch.full((s.n, dout), float("nan"), device="cuda")
+        agg2 = agg_r.clone()
+        ctx.spmm(s.g_own, kind, xo, agg2)
+        ctx.spmm_gemm(s.g_halo, kind, xh, agg2, W, y2, accumulate=True)  # whole-graph kernels, same form
+    finally:
+        ctx.set_option("spmm_flat", -1)
+        ctx.set_option("spmm_flat_ring", -1)
+    for a_, y_ in ((agg, y), (agg2, y2)):
+        assert np.isfinite(y_.cpu().numpy()).all()
+        assert np.array_equal(a_.cpu().numpy()[s.light].view(np.uint32), agg_r.cpu().numpy()[s.light].view(np.uint32))
+        assert np.array_equal(y_.cpu().numpy()[s.light].view(np.uint32), y_r.cpu().numpy()[s.light].view(np.uint32))
+        assert rel_err(y_.cpu().numpy(), y_r.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("din,dout", [(128, 128), (64, 64)])
 def test_class_fused_two_products_sage(ctx, din, dout):
     """the SAGE layer's self term in the same store (gaib_spmm_gemm2 on class graphs; rows2 through the row map)"""

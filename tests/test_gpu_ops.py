@@ -297,6 +297,24 @@ def test_gat_forward_fused_and_backward_from_row_stats(ctx, heads, hub):
         lg, rg = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
         assert ctx.gat_backward_fused(g_d, hd, gd, dev(out_w), dev(al), dev(ar), None, go, lg, rg, heads=heads,
                                       row_stats=stats)
+        # the two layout experiments of round 4 (off by default: both measured slower at the reddit shape) --
+        # one interleaved [h | grad | records] row per vertex, and one contiguous eighth of the chunk list per XCD -- move
+        # the same operands through the same arithmetic: bit-identical results
+        for opts in ({"gat_interleave": 1}, {"gat_chunk_xcd": 1}, {"gat_interleave": 1, "gat_chunk_xcd": 1}):
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            try:
+                out3, stats3 = torch.empty_like(out), torch.empty_like(stats)
+                assert ctx.gat_forward_fused(g_d, hd, dev(al), dev(ar), out3, stats3, heads=heads)
+                go3 = torch.full((g_o.nv, d), 7.0, device="cuda")
+                lg3, rg3 = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+                assert ctx.gat_backward_fused(g_d, hd, gd, dev(out_w), dev(al), dev(ar), None, go3, lg3, rg3, heads=heads,
+                                              row_stats=stats)
+            finally:
+                for k in opts:
+                    ctx.set_option(k, 0)
+            assert torch.equal(out3, out) and torch.equal(stats3, stats), opts
+            assert torch.equal(go3, go) and torch.equal(lg3, lg) and torch.equal(rg3, rg), opts
     finally:
         ctx.set_option("gat_fused_fwd", -1)
         ctx.set_option("gat_fused_bwd", -1)
@@ -931,11 +949,15 @@ def test_side_section_overlaps_and_orders(ctx):
 
 @pytest.fixture
 def flat_option(ctx):
-    """forces the fused kernel's row-by-row (0) / edge-stream (1) form for one test, then back to automatic"""
+    """forces the fused kernel's row-by-row (0) / edge-stream form in batches (1) / edge-stream form as a software pipeline
+    (2: option spmm_flat_ring) for one test, then back to automatic"""
     def set_flat(v):
-        ctx.set_option("spmm_flat", v)
+        ctx.set_option("spmm_flat", min(v, 1))
+        if v >= 1:
+            ctx.set_option("spmm_flat_ring", v - 1)
     yield set_flat
     ctx.set_option("spmm_flat", -1)
+    ctx.set_option("spmm_flat_ring", -1)
 
 
 @pytest.mark.parametrize("len_in,len_out,kind,transW,relu", [
@@ -957,7 +979,7 @@ def flat_option(ctx):
     (200, 96, "gcn", True, False),     # second slab narrower than 128
     (130, 40, "edge", False, True),    # second slab of 2 columns
 ])
-@pytest.mark.parametrize("flat", [0, 1])
+@pytest.mark.parametrize("flat", [0, 1, 2])
 def test_spmm_gemm_fused(ctx, flat_option, len_in, len_out, kind, transW, relu, flat):
     """gaib_spmm_gemm == aggregate then matmul (+relu) of the oracle; heavy rows, ragged row count; row by row
     (flat 0) and as one edge stream per strip of rows (flat 1, what short-row graphs get by default)"""
@@ -998,7 +1020,7 @@ def test_spmm_gemm_fused(ctx, flat_option, len_in, len_out, kind, transW, relu, 
     assert rel_err(y2.cpu().numpy(), y.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("flat", [0, 1])
+@pytest.mark.parametrize("flat", [0, 1, 2])
 @pytest.mark.parametrize("d,d_out", [(128, 128), (64, 48), (96, 32), (256, 128), (192, 256)])
 def test_spmm_gemm_accumulate_split_by_column(ctx, flat_option, d, d_out, flat):
     """the multi-GPU own/halo split through the fused kernel: gaib_spmm on the low-column edges, then
