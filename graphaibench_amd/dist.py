@@ -319,6 +319,8 @@ class DistLayerGraph:
                 self.lgraph.set_halo_plan(self.g_halo, self.ex.halo)
             else:
                 self.lgraph.set_halo(self.g_halo, self._begin, self._end)
+                # (the partition-mode rule prices the exchange by the most rows one peer pair moves: the plan form knows)
+                self.lgraph.set_halo_link_rows(max(max(part.send_counts), max(part.recv_counts)))
         self._dev = dev
 
     def _check_stream(self) -> None:

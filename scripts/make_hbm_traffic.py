@@ -46,8 +46,8 @@ out = {
     "calibration": {"known_read_bytes": known_read, "FETCH_SIZE_KB": cf, "ratio_counter_to_known": ratio,
                     "known_write_bytes": known_write, "WRITE_SIZE_KB": cw, "write_ratio": cw * 1024 / known_write},
     "fetch_correction": 2.0,
-    "sources": blob_hashes(["graphaibench_amd/csrc/spmm.hip", "graphaibench_amd/csrc/spmm_core.h", "graphaibench_amd/csrc/common.h",
-                            "graphaibench_amd/csrc/sgemm.hip"]),
+    "sources": blob_hashes(["graphaibench_amd/csrc/spmm.hip", "graphaibench_amd/csrc/spmm_kernels.h", "graphaibench_amd/csrc/spmm_core.h",
+                            "graphaibench_amd/csrc/common.h", "graphaibench_amd/csrc/sgemm.hip"]),
 }
 for name, frag in (("spmm_gemm_kernel", "spmm_gemm_kernel"), ("spmm_heavy_kernel", "spmm_heavy_kernel"),
                    ("sgemm_tn_reg_kernel_masked", "sgemm_tn_reg_kernel<true")):
