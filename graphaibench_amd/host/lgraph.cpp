@@ -58,7 +58,13 @@ int LearningGraph::partition_mode(int len) {
   if (want == PART_SPLIT) return part_mode_ = PART_SPLIT;
   // the interior class first: its size decides (auto) and every class form needs it
   gaib_graph* gi = NULL;
-  GAIB_OR_DIE(gaib_graph_split_classes(ctx, dev_, halo_dev_, &gi, NULL, NULL, NULL, &n_boundary_, &boundary_edges_, 0));
+  {
+    const int rc = gaib_graph_split_classes(ctx, dev_, halo_dev_, &gi, NULL, NULL, NULL, &n_boundary_, &boundary_edges_, 0);
+    // (a caller's halo graph without gaib_graph_set_vertex_norm -- per-edge weights only -- cannot be cut into classes: the
+    // column split of round 3 needs nothing more than the two graphs; an explicit wish for classes fails loudly instead)
+    if (rc != GAIB_OK && want < 0) return part_mode_ = PART_SPLIT;
+    GAIB_OR_DIE(rc);
+  }
   const int64_t ne_all = gaib_graph_ne(dev_) + gaib_graph_ne(halo_dev_);
   const int64_t ne_int = gaib_graph_ne(gi), ne_bhalo = gaib_graph_ne(halo_dev_);
   const bool few_interior = 10 * ne_int < ne_all;

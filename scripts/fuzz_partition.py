@@ -46,6 +46,8 @@ def run_case(comm, rank, world, cfg):
     part = L.HostPartition(rp, ci, rank, world, gat=arch == "gat")
     lo, hi = part.lo, part.hi
     lg = part.make_graph(comm)
+    if "part_mode" in cfg:  # row classes of the partition (LearningGraph::partition_mode): -1 rule, 0 split, 1 classes, 2 / 3 one pass
+        lg.set_partition_mode(cfg["part_mode"])
     kind = {"gcn": L.GCN, "sage": L.SAGE, "gat": L.GAT}[arch]
     layer = L.Layer(kind, 1, hi - lo, din, d, lg, False)
     if heads > 1:
@@ -153,10 +155,11 @@ def worker(rank, world, idfile, q, seconds, seed, transport_name):
             hub = int(rng.choice([0, 0, 900])) if n >= 3000 else 0
             gseed = int(rng.integers(1 << 30))
             arch = str(rng.choice(["gcn", "sage", "gat"]))
-            din = int(rng.choice([16, 48, 64, 128]))
-            d = int(rng.choice([16, 64, 128]))
+            din = int(rng.choice([16, 48, 64, 128, 200]))
+            d = int(rng.choice([16, 47, 64, 128]))
             heads = int(rng.choice([h for h in (1, 2, 4, 8) if d % h == 0])) if arch == "gat" else 1
-            cfg = dict(n=n, avg=avg, hub=hub, gseed=gseed, arch=arch, din=din, d=d, heads=heads, world=world)
+            cfg = dict(n=n, avg=avg, hub=hub, gseed=gseed, arch=arch, din=din, d=d, heads=heads, world=world,
+                       part_mode=int(rng.choice([-1, 0, 1, 2, 3])))
             err = ""
             try:
                 worst = max(worst, run_case(comm, rank, world, cfg))
