@@ -1610,7 +1610,7 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   // option gat_interleave: the three per-vertex tables of the sweep as one [h | grad | records] row per vertex
   const bool inter = ctx->gat_interleave == 1 && d_row_stats != nullptr;
   const int ldt = 2 * len + 4 * heads;
-  const size_t n_t = inter ? up4((size_t)g->nv * ldt) : 0;
+  const size_t n_t = inter ? up4((size_t)g->nv * ldt) + 64 : 0;  // (+ 64 floats: the table starts on a 256-B boundary)
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (7 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len + n_t)));
   f4* rec = reinterpret_cast<f4*>(ctx->ws);  // [nv][H] 16-byte records (first: alignment)
   float* rowdot = (float*)ctx->ws + 4 * n_v;
@@ -1619,7 +1619,7 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   float* out_partial = cs + n_v;
   float* rc_partial = out_partial + n_op;
   float* partial = rc_partial + n_rc;
-  float* T = partial + (size_t)nblocks * 2 * len;
+  float* T = reinterpret_cast<float*>(((uintptr_t)(partial + (size_t)nblocks * 2 * len) + 255) & ~(uintptr_t)255);
   ProfScope ps(ctx, "gat_bwd_fused");
   rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
   GAIB_LAUNCH_CHECK();

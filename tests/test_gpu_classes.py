@@ -316,3 +316,64 @@ def test_two_tables_larger_than_the_buffer_range(ctx):
         ctx.set_option("spmm_addr_mode", 0)
     assert rel_err(agg.cpu().numpy(), want) < 1e-5 and rel_err(out.cpu().numpy(), want) < 1e-5
     assert np.array_equal(agg.cpu().numpy()[s.light].view(np.uint32), out.cpu().numpy()[s.light].view(np.uint32))
+
+
+def test_partition_mode_rule_follows_the_exchange_price_and_the_interior_share(ctx, monkeypatch):
+    """LearningGraph::partition_mode (host/lgraph.cpp): one pass where the exchange is (nearly) free or hidden by the interior
+    rows' work, the column split where it would stay exposed -- over classes where a fair share of the edges is interior, over
+    all rows (round 3's form) where next to none is; an explicit wish wins; a halo graph without normalisers cannot be cut
+    into classes and keeps the column split"""
+    from graphaibench_amd import layers as L
+
+    ctx2 = L.init(0)
+
+    def lgraph(g_o, lo, hi, norms=True):
+        s = Shard(ctx2, g_o, lo, hi)
+        g_h = s.g_halo
+        if not norms:  # a halo graph the caller built without gaib_graph_set_vertex_norm
+            g_h = ctx2.graph(s.rp_halo, s.ci_halo, ncols=max(len(s.halo), 1))
+        lg = L.LGraph.adopt(s.g_own)
+        lg.set_halo(g_h, lambda n, p: None, lambda n: 0)
+        return lg, s
+
+    # a numbering with locality -- every vertex linked to its 8 nearest ids, plus a few long edges: of the rows [1000, 5000)
+    # most are interior
+    from util import csr_from_pairs
+    n0 = 6000
+    base = np.arange(n0)
+    rng = np.random.default_rng(31)
+    src = np.concatenate([base] * 4 + [rng.integers(0, n0, 300)])
+    dst = np.concatenate([(base + k) % n0 for k in (1, 2, 3, 4)] + [rng.integers(0, n0, 300)])
+    rp, ci = csr_from_pairs(n0, src, dst)
+    g_o = orc.Graph(rp, ci).add_selfloop()
+    monkeypatch.setenv("GAIB_LINK_GBS", "1e9")  # the exchange costs nothing: one pass
+    lg, s = lgraph(g_o, 1000, 5000)
+    lg.set_halo_link_rows(10_000_000)
+    mode, n_b, e_b = lg.partition_mode(128)
+    assert L.LGraph.PART_NAMES[mode] == "onepass" and n_b == int(s.is_bnd.sum()) and 0 < n_b < s.n
+    lg.close()
+    monkeypatch.setenv("GAIB_LINK_GBS", "0.001")  # the exchange dwarfs the interior work: keep it hidden -> column split of the boundary rows
+    lg, s = lgraph(g_o, 1000, 5000)
+    lg.set_halo_link_rows(10_000_000)
+    assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "classes"
+    lg.close()
+    lg, s = lgraph(g_o, 1000, 5000)  # an explicit wish wins over the rule
+    lg.set_partition_mode(L.LGraph.PART_ONEPASS)
+    assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "onepass"
+    lg.close()
+    # a thin slice of a dense graph: every row has remote neighbours, under 10 % of the edges are interior
+    rp2, ci2 = random_graph(3000, 40, seed=32, power_law=False)
+    g_d = orc.Graph(rp2, ci2).add_selfloop()
+    lg, s = lgraph(g_d, 1400, 1600)
+    lg.set_halo_link_rows(10_000_000)
+    assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "split"  # slow link: round 3's split over all rows
+    lg.close()
+    monkeypatch.setenv("GAIB_LINK_GBS", "1e9")
+    lg, s = lgraph(g_d, 1400, 1600)
+    lg.set_halo_link_rows(10_000_000)
+    mode, n_b, _ = lg.partition_mode(128)
+    assert L.LGraph.PART_NAMES[mode] == "onepass" and n_b >= 0.99 * s.n  # one pass over ALL rows (no interior launch)
+    lg.close()
+    lg, s = lgraph(g_o, 1000, 5000, norms=False)
+    assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "split"
+    lg.close()
