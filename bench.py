@@ -17,6 +17,10 @@ inputs resident in HBM when the timed region starts.
       * python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...  (the ranks given from outside).
     Ranks map to devices as LOCAL_RANK % visible devices; with fewer devices than ranks (a one-GPU box) the data path is
     the peer-to-peer pull transport, which lets several ranks share a device, and the record says so (config.transport).
+    The N > 1 record cannot be lost: the headline case runs first and rank 0 HOLDS its record (RecordGuard); every further
+    sub-case -- the N = 1 CPU baseline, the clustered-boundary generator, the random vertex order, config 5 at N = 8 -- starts
+    only if all ranks agree that it fits --budget-s (420 s; else its slot says {"skipped": "budget", ...}); on --deadline-s
+    (560 s), SIGTERM or SIGINT rank 0 prints what it holds, marked "partial", and exits 0.
     --workload gcn-papers: BASELINE config 5's layer (GCN 128 -> 128 on the ogbn-papers100M-shaped graph in vertex ranges
     of 1/8 of it: at N = 8 the whole graph); --check-oracle compares every rank's outputs with the oracle's GLOBAL run.
 
