@@ -1091,6 +1091,12 @@ int build_class(gaib_ctx* ctx, int64_t n, const uint32_t* map, int64_t n_rows_al
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
   GAIB_CHECK(ne < (int64_t)1 << 32, "gaib_graph_split_classes: a class with %lld edges (edge ids are uint32)", (long long)ne);
   GAIB_TRY(new_graph(n, ne, ctx->device, &g));
+  struct Guard {  // (every early return below goes through GAIB_HIP / GAIB_LAUNCH_CHECK: the half-built graph goes with it)
+    gaib_graph* g;
+    ~Guard() {
+      if (g) (void)gaib_graph_destroy(g);
+    }
+  } guard{g};
   g->nc = nc;
   GAIB_HIP(hipMemcpyAsync(g->rowptr, rp, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
   if (n > 0) {
@@ -1122,6 +1128,7 @@ int build_class(gaib_ctx* ctx, int64_t n, const uint32_t* map, int64_t n_rows_al
     GAIB_HIP(hipMemcpyAsync(g->col_inv_deg + off, b->col_inv_deg, sizeof(float) * b->nc, hipMemcpyDeviceToDevice, ctx->stream));
   }
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  guard.g = nullptr;
   *out = g;
   return GAIB_OK;
 }

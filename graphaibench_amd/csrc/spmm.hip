@@ -380,7 +380,8 @@ extern "C" int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const
 
 extern "C" int gaib_spmm_2t(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                             const float* d_in, const float* d_in2, int64_t n_first, float* d_out, int flags) {
-  GAIB_CHECK(d_in2 || (g && n_first >= g->nc), "gaib_spmm_2t: NULL second table with columns beyond n_first");
+  GAIB_CHECK(ctx && g, "gaib_spmm_2t: NULL ctx/graph");
+  GAIB_CHECK(d_in2 || n_first >= g->nc || g->nv == 0 || g->ne == 0, "gaib_spmm_2t: NULL second table with columns beyond n_first");
   return spmm_impl(ctx, g, weight_kind, d_edge_w, len, d_in, d_out, flags, 1, d_in2, n_first);
 }
 
@@ -581,7 +582,7 @@ extern "C" int gaib_spmm_gemm_2t(gaib_ctx* ctx, gaib_graph* g, int weight_kind, 
                                  const float* d_in, const float* d_in2, int64_t n_first, float* d_agg, const float* d_W,
                                  int transW, const float* d_rows2, const float* d_W2, int len_out, float* d_out, int flags) {
   GAIB_CHECK(ctx && g, "gaib_spmm_gemm_2t: NULL ctx/graph");
-  GAIB_CHECK(d_in2 || n_first >= g->nc, "gaib_spmm_gemm_2t: NULL second table with columns beyond n_first");
+  GAIB_CHECK(d_in2 || n_first >= g->nc || g->nv == 0 || g->ne == 0, "gaib_spmm_gemm_2t: NULL second table with columns beyond n_first");
   GAIB_CHECK(!d_in2 || (d_in2 != d_agg && d_in2 != d_out), "gaib_spmm_gemm_2t: buffers must not alias");
   return spmm_gemm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, d_W, transW, d_rows2, d_W2, len_out, d_out, flags,
                         d_in2, n_first);
