@@ -77,10 +77,7 @@ struct gaib_ctx {
                              // land on: the fused kernel holds every register of the CUs it sits on until its last tile), 0 otherwise
   int spmm_fuse_cus;         // fused kernel: persistent workgroups (= CUs it occupies); 0 = all CUs.  Fewer leave whole CUs to a kernel on another stream
   int spmm_tile_xcd;         // fused kernel's tile supply: -1 (default) = by the graph's numbering (XCD-affine chunks of 1024 tiles where the numbering has locality, else one global counter), 0 = global counter, n > 0 = XCD-affine chunks of n tiles
-  int spmm_seg;              // fused kernel on a numbering with locality: 0 = one pass, K >= 2 = K column segments per block (spmm_seg.hip), -1 = by the graph
-  int spmm_seg_block;        // rows (= columns) of a block of the segmented form (default 16 384)
-  int spmm_seg_sync;         // pacing of an XCD's waves in the segmented form: 0 none, 1 per round, 2 per phase
-  int spmm_seg_slack;        // waves of an XCD that may lag one phase behind
+  int spmm_prefetch_ids;     // fused row form on a numbering with locality (affine supply): 1 = next row's column ids requested a row ahead, 0 = per row
   int spmm_unroll;           // 0 = auto, 8 = cap gathers in flight per wave at 8
   int spmm_addr_mode;        // 0 = auto (buffer loads when the table is < 4 GB), 2 = force 64-bit global
   int spmm_gather_mode;      // 0/1 default cache policy, 2 = nt gathers, 3 = nt for cold columns only
@@ -165,12 +162,10 @@ struct gaib_graph {
   int64_t n_out_rows;
   int rows_unsorted;  // 1: a row's column ids are not ascending (gaib_graph_reorder keeps the edge ORDER of every row);
                       // the reverse-edge permutation needs sorted rows: gaib_graph_sort_rows first
-  void* seg;        // gaib_seg: the edges once more in (strip, column segment, row) order, built lazily (spmm_seg.hip)
   float near_frac;  // share of (sampled) edges whose column id lies within 32 768 of the row id: locality of the numbering; < 0 = not measured yet
 };
 
 int gaib_graph_ensure_locality(gaib_ctx* ctx, gaib_graph* g);
-void gaib_seg_free(void* seg);  // spmm_seg.hip
 
 int gaib_graph_ensure_inv_deg(gaib_ctx* ctx, gaib_graph* g);
 int gaib_graph_ensure_w_gcn(gaib_ctx* ctx, gaib_graph* g);

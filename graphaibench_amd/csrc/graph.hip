@@ -249,7 +249,6 @@ extern "C" int gaib_graph_destroy(gaib_graph* g) {
                   g->chunk_row, g->chunk_ebase, g->chunk_start, g->colidx_flagged, g->row_map};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  gaib_seg_free(g->seg);
   delete g;
   return GAIB_OK;
 }
@@ -978,8 +977,6 @@ extern "C" int gaib_graph_sort_rows(gaib_ctx* ctx, gaib_graph* g) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
-  gaib_seg_free(g->seg);
-  g->seg = nullptr;
   g->n_chunks = 0;
   g->hot_threshold = -1;
   g->near_frac = -1.f;

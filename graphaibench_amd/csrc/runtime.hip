@@ -53,10 +53,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_xcd_swizzle = 2;
   c->spmm_unroll = 0;
   c->spmm_tile_xcd = -1;
-  c->spmm_seg = 0;
-  c->spmm_seg_block = 16384;
-  c->spmm_seg_sync = 1;
-  c->spmm_seg_slack = 32;
+  c->spmm_prefetch_ids = 1;
   c->spmm_fuse_cus = 0;
   c->spmm_fuse = 1;
   c->spmm_pad = 1;
@@ -478,19 +475,9 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->spmm_fuse_cus = (int)value;
   } else if (!strcmp(key, "spmm_tile_xcd"))
     ctx->spmm_tile_xcd = (int)value;
-  else if (!strcmp(key, "spmm_seg")) {
-    GAIB_CHECK(value == 0 || value == -1 || (value >= 2 && value <= 32), "spmm_seg: 0 (one pass), -1 (by the graph) or 2..32 column segments");
-    ctx->spmm_seg = (int)value;
-  } else if (!strcmp(key, "spmm_seg_block")) {
-    GAIB_CHECK(value >= 8 && value <= (1 << 24), "spmm_seg_block: 8 .. 2^24 rows");
-    ctx->spmm_seg_block = (int)value;
-  } else if (!strcmp(key, "spmm_seg_sync")) {
-    GAIB_CHECK(value >= 0 && value <= 2, "spmm_seg_sync: 0 (none), 1 (per round), 2 (per phase)");
-    ctx->spmm_seg_sync = (int)value;
-  } else if (!strcmp(key, "spmm_seg_slack")) {
-    GAIB_CHECK(value >= 0, "spmm_seg_slack: >= 0 waves");
-    ctx->spmm_seg_slack = (int)value;
-  } else if (!strcmp(key, "spmm_unroll"))
+  else if (!strcmp(key, "spmm_prefetch_ids"))
+    ctx->spmm_prefetch_ids = value != 0;
+  else if (!strcmp(key, "spmm_unroll"))
     ctx->spmm_unroll = (int)value;
   else if (!strcmp(key, "spmm_addr_mode"))
     ctx->spmm_addr_mode = (int)value;

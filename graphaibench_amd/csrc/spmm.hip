@@ -321,9 +321,6 @@ static bool chunk_rule(gaib_ctx* ctx, gaib_graph* g, int64_t ld) {
 int gaib_spmm_part_plain(gaib_ctx* ctx, const gaib_graph* g, const void* spmm_args, int wmode, int len);
 int gaib_spmm_part_fused(gaib_ctx* ctx, const gaib_graph* g, const void* spmm_args, const void* fuse_args, float* heavy_scratch,
                          int vec, int wmode);
-// the column-segmented form for numberings with locality: spmm_seg.hip (GAIB_ERR_UNSUPPORTED: not a shape for it)
-int gaib_spmm_seg_fused(gaib_ctx* ctx, gaib_graph* g, const void* spmm_args, const void* fuse_args, float* heavy_scratch, int vec,
-                        int wmode, int segments);
 
 static int spmm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                      const float* d_in, float* d_out, int flags, int heads = 1, const float* d_in2 = nullptr,
@@ -560,10 +557,6 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
   f.heavy_rows = g->heavy_rows;
   f.n_heavy = (int)g->n_heavy;
   if (part) return gaib_spmm_part_fused(ctx, g, &a, &f, hv, len_in <= 64 ? 1 : 2, wmode);
-  if (ctx->spmm_seg >= 2) {
-    const int rc = gaib_spmm_seg_fused(ctx, g, &a, &f, hv, len_in <= 64 ? 1 : 2, wmode, ctx->spmm_seg);
-    if (rc != GAIB_ERR_UNSUPPORTED) return rc;
-  }
   if (len_in <= 64) {
     return wmode == 0 ? launch_fused<1, 0>(ctx, g, a, f, hv) : launch_fused<1, 1>(ctx, g, a, f, hv);
   }

@@ -196,11 +196,14 @@ struct RowGather {
 // voff[ct] is the lane's BYTE offset inside a feature row; lanes whose columns fall outside
 // the row are pointed at offset 0, so every gather is unconditional (a predicated load makes
 // hipcc branch on EXEC and drain vmcnt after each one); what they accumulate is never stored.
-template <int VEC, int CT, int WMODE, int U, int BUF, bool PART = false>
+// PRE: the column ids (and weights) of the row's FIRST chunk were requested by the caller ahead of time (c_first / w_first,
+// lane l = edge eb + l, 0 past the row's end) -- the fused kernel asks for row r + 1's while row r's gathers are in flight.
+template <int VEC, int CT, int WMODE, int U, int BUF, bool PART = false, bool PRE = false>
 __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int64_t eb, int64_t ee,
                                                 int64_t chunk_stride, float roww,
                                                 const uint32_t (&voff)[CT],
-                                                typename VecT<VEC>::type (&acc)[CT]) {
+                                                typename VecT<VEC>::type (&acc)[CT], uint32_t c_first = 0u,
+                                                float w_first = 0.f) {
   typedef typename VecT<VEC>::type vec_t;
   const RowGather<VEC, BUF, PART> gather(a);
   vec_t x[U][CT];  // gather destinations; the tail's piece p lives in x[p .. 2p-1]
@@ -214,7 +217,10 @@ __device__ __forceinline__ void wave_accumulate(const SpmmArgs& a, int lane, int
     const int n = rem < 64 ? (int)rem : 64;  // wave-uniform
     uint32_t c = 0;
     float w = 0.f;
-    if (lane < n) {
+    if (PRE && base == eb) {  // (wave-uniform)
+      c = c_first;
+      w = w_first;
+    } else if (lane < n) {
       c = a.col[base + lane];
       if constexpr (WMODE == 1 || WMODE == 2) w = load_edge_w<WMODE>(a, base + lane);
     }

@@ -350,7 +350,7 @@ constexpr int FUSE_WAVES = 16;
 // global-counter form -- the headline's, a random vertex order -- ran 0.5 % slower than before the affine supply existed
 // (7.597 -> 7.635 ms per launch, bisected to that change on one box: scripts/drift_ab.sh, profiles/r04/drift_*.jsonl).
 template <int VEC, int WMODE, int U, int GM, int STRIP, bool DUAL, bool FLAT = false, bool YACC = false, bool PART = false,
-          bool RING = false, bool AFFINE = false>
+          bool RING = false, bool AFFINE = false, bool PREF = false>
 __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, FuseArgs f) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int K = 64 * VEC;  // padded inner dimension; a.ncols (<= K) columns are real
@@ -468,6 +468,25 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         rwv = a.rw[rwi];
       }
     }
+    // PRE (the instantiations for numberings with locality, AFFINE): the column ids and weights of the NEXT row's first 64
+    // edges are requested while this row's gathers are in flight.  Row by row a wave waits one trip to the id stream (HBM:
+    // the ids are read once) and then one per batch of gathers; where the gathered rows come from the L2 the first is a
+    // third of a row's time (communities of 2 048 rows, 1 MB, run at the same 47 ps per edge as communities of 16 384:
+    // scripts/locality_ceiling.py).  On a random order the gathers themselves fill the fabric: not compiled in there.
+    constexpr bool PRE = PREF && !FLAT && (WMODE == 0 || WMODE == 1);
+    uint32_t c_pre = 0;
+    float w_pre = 0.f;
+    auto prefetch_ids = [&](int rr) {  // rr wave-uniform, < FUSE_ROWS
+      const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr);
+      const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane(rp_hi, rr + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, rr + 1);
+      c_pre = 0;
+      w_pre = 0.f;
+      if (e0 + lane < e1) {
+        c_pre = a.col[e0 + lane];
+        if constexpr (WMODE == 1) w_pre = load_edge_w<WMODE>(a, e0 + lane);
+      }
+    };
+    if constexpr (PRE) prefetch_ids(0);
     for (int h = 0; h < NPASS; ++h) {
       bool flat_done = false;
       if constexpr (FLAT) {
@@ -620,6 +639,11 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
         const int row = row0 + rr;
         vec_t acc[1];
         acc[0] = vzero<VEC>();
+        const uint32_t c_now = c_pre;
+        const float w_now = w_pre;
+        if constexpr (PRE) {
+          if (rr + 1 < FUSE_ROWS) prefetch_ids(rr + 1);
+        }
         if (row < a.n_rows) {
           if (f.agg_in && colok)
             acc[0] = *reinterpret_cast<const vec_t*>(f.agg_in + orow(rr) * a.ldo + lane * VEC);
@@ -644,7 +668,7 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void spmm_gemm_kernel(SpmmArgs a, 
             }
           } else {
             const float roww = (WMODE == 0) ? a.rw[row] : 0.f;
-            wave_accumulate<VEC, 1, WMODE, U, GM, PART>(a, lane, e0, e1, 64, roww, voff, acc);
+            wave_accumulate<VEC, 1, WMODE, U, GM, PART, PRE>(a, lane, e0, e1, 64, roww, voff, acc, c_now, w_now);
           }
           if (a.out && colok) store_row(reinterpret_cast<vec_t*>(a.out + orow(rr) * a.ldo + lane * VEC), acc[0]);
         }
@@ -853,14 +877,23 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   // more than 64 KB of dynamic LDS has to be asked for
   // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
   // spill and are reloaded inside the MFMA loop)
-#define GAIB_FUSED_LAUNCH_A(GM, STRIP, DUAL, FLAT, YACC, RING, AFF)                                                   \
+#define GAIB_FUSED_LAUNCH_P(GM, STRIP, DUAL, FLAT, YACC, RING, AFF, PRE)                                              \
   do {                                                                                                                \
     constexpr int UU = FLAT ? 8 : U;                                                                                  \
     GAIB_HIP(hipFuncSetAttribute(                                                                                     \
-        (const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART, RING, AFF>,                  \
+        (const void*)spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART, RING, AFF, PRE>,             \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                                     \
-    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART, RING, AFF>                                    \
+    spmm_gemm_kernel<VEC, WMODE, UU, GM, STRIP, DUAL, FLAT, YACC, PART, RING, AFF, PRE>                               \
         <<<dim3(grid), FUSE_WAVES * 64, lds, ctx->stream>>>(a, f);                                                    \
+  } while (0)
+#define GAIB_FUSED_LAUNCH_A(GM, STRIP, DUAL, FLAT, YACC, RING, AFF)                                                   \
+  do {                                                                                                                \
+    if constexpr (AFF && !FLAT) {                                                                                     \
+      if (ctx->spmm_prefetch_ids) GAIB_FUSED_LAUNCH_P(GM, STRIP, DUAL, FLAT, YACC, RING, AFF, true);                  \
+      else GAIB_FUSED_LAUNCH_P(GM, STRIP, DUAL, FLAT, YACC, RING, AFF, false);                                        \
+    } else {                                                                                                          \
+      GAIB_FUSED_LAUNCH_P(GM, STRIP, DUAL, FLAT, YACC, RING, AFF, false);                                             \
+    }                                                                                                                 \
   } while (0)
   // (row classes of a partition are rectangular graphs: their numbering is never measured as local, no affine variants)
 #define GAIB_FUSED_LAUNCH_R(GM, STRIP, DUAL, FLAT, YACC, RING)                                                        \
@@ -903,6 +936,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     else GAIB_FUSED_LAUNCH(0, 8, false, false);
   }
 #undef GAIB_FUSED_LAUNCH_A
+#undef GAIB_FUSED_LAUNCH_P
 #undef GAIB_FUSED_LAUNCH_R
 #undef GAIB_FUSED_LAUNCH
 #undef GAIB_FUSED_LAUNCH_Y

@@ -561,7 +561,8 @@ int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_to
  * workgroup-per-row kernel, and the maximum degree */
 /* locality of the vertex numbering: the share of (sampled) edges whose column id lies within 32 768 of the row id
  * (0 for rectangular graphs and graphs below 262 144 vertices).  The fused aggregation's tile supply follows it: from
- * 0.25 on, tiles are dealt XCD-affine in long chunks (option "spmm_tile_xcd" = -1), else off one global counter. */
+ * 0.25 on, tiles are dealt XCD-affine in long chunks (option "spmm_tile_xcd" = -1), else off one global counter; the
+ * affine form also requests a row's column ids one row ahead (option "spmm_prefetch_ids", default 1; same sums). */
 int gaib_graph_locality(gaib_ctx* ctx, gaib_graph* g, float* h_near_frac);
 int gaib_graph_stats(gaib_ctx* ctx, gaib_graph* g, int64_t* h_n_heavy, int64_t* h_heavy_edges,
                      int64_t* h_max_degree);

@@ -191,6 +191,20 @@ def test_tile_supply_follows_the_numbering(ctx):
         finally:
             ctx.set_option("spmm_tile_xcd", -1)
         assert torch.equal(agg, ref_agg) and torch.equal(y, ref_y), chunk
+    # the affine instantiations ask for the next row's column ids a row ahead (round 4): same sums without it
+    ctx.set_option("spmm_prefetch_ids", 0)
+    try:
+        agg, y = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+        ctx.spmm_gemm(g, capi.W_GCN, x, agg, W, y, relu=True)
+        agg_m, y_m = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+        ctx.spmm_gemm(g, capi.W_MEAN, x, agg_m, W, y_m)
+    finally:
+        ctx.set_option("spmm_prefetch_ids", 1)
+    assert torch.equal(agg, ref_agg) and torch.equal(y, ref_y)
+    agg_m2, y_m2 = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+    ctx.spmm_gemm(g, capi.W_MEAN, x, agg_m2, W, y_m2)
+    assert torch.equal(agg_m, agg_m2) and torch.equal(y_m, y_m2)
+    del agg_m, y_m, agg_m2, y_m2
     plain = torch.empty(nv, D, device="cuda")
     ctx.spmm(g, capi.W_GCN, x, plain)
     assert torch.equal(plain, ref_agg)
