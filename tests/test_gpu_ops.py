@@ -1200,6 +1200,48 @@ def test_spmm_gemm2_self_term(ctx, len_in, len_out, kind, transW, relu):
     assert_close(y.cpu().numpy(), y_w)
 
 
+@pytest.mark.parametrize("len_in,len_out,kind,transW,dual,accumulate", [
+    (128, 128, "gcn", False, False, False),
+    (128, 128, "mean", False, True, False),    # SAGE: two matrices, 2-row strips
+    (100, 47, "mean_t", True, False, False),
+    (64, 32, "gcn", False, False, True),       # continues partial sums
+    (33, 128, "mean", False, False, False),    # one float per lane
+    (256, 128, "gcn", False, False, False),    # two K-slabs (the second accumulates into y)
+    (256, 256, "mean", False, True, False),
+])
+def test_spmm_gemm_tile_supply_and_id_prefetch_change_nothing(ctx, len_in, len_out, kind, transW, dual, accumulate):
+    """the fused kernel's tile supply (one counter / XCD-affine chunks) and, in the affine form, the request of the next row's
+    column ids a row ahead (option spmm_prefetch_ids, round 4) decide WHEN a row is summed, never how: every combination
+    gives the bits of the default"""
+    rp, ci = random_graph(4099, 20, seed=len_in + 7 * len_out, power_law=True, hub_deg=1700)
+    g_o, g_d = make(ctx, rp, ci, selfloop=(kind == "gcn"))
+    n = g_o.nv
+    xd = dev(feat(n, len_in, 3))
+    shape = (len_out, len_in) if transW else (len_in, len_out)
+    W, W2 = dev(feat(*shape, 4) * 0.2), dev(feat(*shape, 5) * 0.2)
+    k = {"gcn": capi.W_GCN, "mean": capi.W_MEAN, "mean_t": capi.W_MEAN_T}[kind]
+    part = dev(feat(n, len_in, 8))
+
+    def run():
+        agg = part.clone() if accumulate else torch.full((n, len_in), 3.0, device="cuda")
+        y = torch.full((n, len_out), -5.0, device="cuda")
+        ctx.spmm_gemm(g_d, k, xd, agg, W, y, transW=transW, relu=True, accumulate=accumulate,
+                      rows2=xd if dual else None, W2=W2 if dual else None)
+        return agg, y
+
+    ref_agg, ref_y = run()
+    try:
+        for tile_xcd in (0, 1, 4):
+            for pre in (1, 0):
+                ctx.set_option("spmm_tile_xcd", tile_xcd)
+                ctx.set_option("spmm_prefetch_ids", pre)
+                agg, y = run()
+                assert torch.equal(agg, ref_agg) and torch.equal(y, ref_y), (tile_xcd, pre)
+    finally:
+        ctx.set_option("spmm_tile_xcd", -1)
+        ctx.set_option("spmm_prefetch_ids", 1)
+
+
 def test_reordered_graph_is_aggregation_only_until_its_rows_are_sorted(ctx):
     """gaib_graph_reorder keeps every row's edge ORDER, so the relabelled rows are not sorted by column id, and the
     reverse-edge permutation (GAT backward, edge_transpose) is derived from sorted rows: on such a graph it is refused with a
