@@ -31,6 +31,10 @@ def main():
         ctx.set_option("spmm_heavy_threshold", thr)
         flat = int(rng.choice([-1, 0, 1]))  # fused kernel: row by row / one edge stream per strip / by average degree
         ctx.set_option("spmm_flat", flat)
+        # tile supply: by the graph / one counter / XCD-affine chunks of 16 or 64 tiles (the affine form with and without the
+        # request of the next row's column ids a row ahead)
+        ctx.set_option("spmm_tile_xcd", int(rng.choice([-1, 0, 1, 64])))
+        ctx.set_option("spmm_prefetch_ids", int(rng.integers(2)))
         len_in = int(rng.choice([1, 7, 16, 33, 47, 64, 66, 100, 128]))
         len_out = int(rng.choice([1, 7, 16, 47, 64, 100, 128, 130, 200]))
         kind = int(rng.choice([capi.W_MEAN, capi.W_MEAN_T, capi.W_EDGE, capi.W_GCN]))
