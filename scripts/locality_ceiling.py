@@ -3,7 +3,8 @@ communities shrink from 16 384 rows (8 MB of feature rows, twice an XCD's L2) to
 LEAVE the community goes from 0.1 to 0: time per edge, with the XCD-affine chunk matched to the community.
     python scripts/locality_ceiling.py        (development aid)"""
 import json, sys, torch
-sys.path.insert(0, '/root/repo')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from graphaibench_amd import capi, synth
 def ev_ms(fn, reps=6):
     for _ in range(2): fn()
