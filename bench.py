@@ -556,6 +556,10 @@ def install_rank_guard(rank: int, deadline_s: float) -> RecordGuard:
 
 
 def main():
+    if os.environ.get("GAIB_BENCH_DUMP_STACKS_S"):  # diagnosis of a stuck rank: every process writes its Python stacks to stderr
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["GAIB_BENCH_DUMP_STACKS_S"]), repeat=True, file=sys.stderr)
     if os.environ.get("GAIB_RCCL_LIB"):  # (tests/fake_rccl's double is for call-pattern tests; a record must name the real RCCL)
         sys.exit("bench.py: GAIB_RCCL_LIB is set -- the bench measures the system's RCCL only; unset it")
     ap = argparse.ArgumentParser()

@@ -34,6 +34,10 @@
 
 #define GAIB_COMM_MAX_RANKS 16
 #define GAIB_COMM_MAX_HALOS 8
+// IPC: a send buffer is cut into separately allocated (and separately exported) chunks -- hipIpcOpenMemHandle of an
+// allocation above 2 GiB does not return on this runtime (measured: a 1.86 GB buffer opens at once, a 2.42 GB one hangs all
+// ranks; bench.py --gpus 3 --cut-fraction 0.3 on one device) -- and a receiver opens only the chunks its segment touches
+#define GAIB_IPC_MAX_CHUNKS 64
 #define GAIB_COMM_REDUCE_FLOATS (64 * 1024)  // per-rank all-reduce staging slot in the shm segment (256 KB)
 
 namespace {
@@ -111,6 +115,11 @@ struct ShmSlot {  // one rank's published send buffer of one halo plan
   int32_t pad;
   hipIpcMemHandle_t handle;
   int64_t send_off[GAIB_COMM_MAX_RANKS + 1];  // row offsets of the per-destination groups inside the buffer
+  // a send buffer above the chunk size: rows [j * chunk_rows, (j + 1) * chunk_rows) live in allocation j (handle = chunk 0)
+  int32_t n_chunks;
+  int32_t pad2;
+  int64_t chunk_rows;
+  hipIpcMemHandle_t handle_x[GAIB_IPC_MAX_CHUNKS - 1];
   // the reverse direction (gaib_halo_reduce): the rank's halo table, grouped by OWNER rank
   uint64_t gen_t;
   hipIpcMemHandle_t handle_t;
@@ -132,6 +141,31 @@ double now_s() {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+// GAIB_COMM_DEBUG=1: the steps of an exchange with time stamps on stderr (diagnosis of a stuck transport)
+bool comm_debug() {
+  static const bool on = getenv("GAIB_COMM_DEBUG") && atoi(getenv("GAIB_COMM_DEBUG")) != 0;
+  return on;
+}
+#define GAIB_COMM_DBG(c, ...)                                        \
+  do {                                                               \
+    if (comm_debug()) {                                              \
+      fprintf(stderr, "[gaib_comm r%d %.3f] ", (c)->rank, now_s()); \
+      fprintf(stderr, __VA_ARGS__);                                  \
+      fprintf(stderr, "\n");                                         \
+      fflush(stderr);                                                \
+    }                                                                \
+  } while (0)
+// size of one chunk of an IPC send buffer, and the largest allocation this transport will export at all
+size_t ipc_chunk_bytes() {
+  const char* e = getenv("GAIB_IPC_CHUNK_BYTES");  // (tests cut small buffers into many chunks)
+  const long long v = e ? atoll(e) : 0;
+  return v > 0 ? (size_t)v : (size_t)512 << 20;
+}
+size_t ipc_export_limit() {
+  const char* e = getenv("GAIB_IPC_EXPORT_LIMIT_BYTES");
+  const long long v = e ? atoll(e) : 0;
+  return v > 0 ? (size_t)v : (size_t)1536 << 20;
 }
 double timeout_s() {
   const char* e = getenv("GAIB_COMM_TIMEOUT_S");
@@ -185,6 +219,16 @@ struct gaib_halo {
   size_t send_cap;
   float* table;
   size_t table_cap;
+  // IPC, send buffers above the chunk size: chunk 0 is sendbuf, chunks 1.. live here (every chunk its own allocation)
+  float* send_x[GAIB_IPC_MAX_CHUNKS - 1];
+  size_t send_x_cap[GAIB_IPC_MAX_CHUNKS - 1];
+  uint64_t send_x_serial[GAIB_IPC_MAX_CHUNKS - 1], pub_x_serial[GAIB_IPC_MAX_CHUNKS - 1];
+  int pub_n_chunks;
+  int64_t pub_chunk_rows;
+  // gaib_halo_reduce lands what arrives here (never exported; the send buffer stays what an exchange made it)
+  float* landing;
+  size_t landing_cap;
+  uint64_t landing_serial;
   // IPC: which ALLOCATION of each buffer the peers hold a handle of.  Either entry point may reallocate either buffer
   // (an exchange reserves the table, a reduce lands its arrivals in the send buffer), so "did MY reserve() reallocate"
   // is not the question -- "is the published allocation still the current one" is.
@@ -201,6 +245,7 @@ struct gaib_halo {
   struct Peer {
     uint64_t gen;
     void* base;
+    void* base_x[GAIB_IPC_MAX_CHUNKS - 1];  // chunks 1.. of the peer's send buffer, opened when first needed
     uint64_t gen_t;  // the peer's halo table (reverse direction)
     void* base_t;
   } peer[GAIB_COMM_MAX_RANKS];
@@ -664,6 +709,8 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (c->transport == GAIB_COMM_IPC) {
     for (int r = 0; r < c->nranks; r++) {
       if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
+      for (void* q : h->peer[r].base_x)
+        if (q) (void)hipIpcCloseMemHandle(q);
       if (h->peer[r].base_t) (void)hipIpcCloseMemHandle(h->peer[r].base_t);
     }
     // nobody may still be pulling from the send buffer that is about to be freed
@@ -673,6 +720,8 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (h->d_pack_row) (void)hipFree(h->d_pack_row);
   if (h->d_pack_slot) (void)hipFree(h->d_pack_slot);
   pool_release(c, h->sendbuf);  // back into the communicator's pool (see gaib_comm::ipc_bufs)
+  for (float* q : h->send_x) pool_release(c, q);
+  pool_release(c, h->landing);
   pool_release(c, h->table);
   for (void* q : h->retired) pool_release(c, q);
   c->halo_slots &= ~(1u << h->id);  // after the barrier above: the slot row can serve the next plan
@@ -706,14 +755,35 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   GAIB_CHECK(n_send == 0 || d_rows, "gaib_halo_exchange_begin: d_rows is NULL");
   const size_t row_bytes = sizeof(float) * (size_t)len;
   gaib_halo* keep = h;  // (both transports draw from the communicator's pool; only IPC retires, see reserve)
-  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream, keep);
+  // IPC: a send buffer above the chunk size is cut into chunks of whole rows, each its own allocation (GAIB_IPC_MAX_CHUNKS)
+  const bool chunked = c->transport == GAIB_COMM_IPC && row_bytes * (size_t)n_send > ipc_chunk_bytes();
+  const int64_t chunk_rows = chunked ? std::max<int64_t>(1, (int64_t)(ipc_chunk_bytes() / row_bytes)) : n_send;
+  const int n_chunks = chunked ? (int)cdiv64(n_send, chunk_rows) : 1;
+  if (n_chunks > GAIB_IPC_MAX_CHUNKS) {
+    gaib_set_error("gaib_halo_exchange_begin(rank %d): %lld rows of %zu B need %d chunks of %zu B, at most %d (GAIB_IPC_CHUNK_BYTES)",
+                   c->rank, (long long)n_send, row_bytes, n_chunks, ipc_chunk_bytes(), GAIB_IPC_MAX_CHUNKS);
+    return fail(c, GAIB_ERR_UNSUPPORTED);
+  }
+  auto chunk_ptr = [&](int j) -> float* { return j == 0 ? h->sendbuf : h->send_x[j - 1]; };
+  auto rows_in_chunk = [&](int j) -> int64_t { return std::min<int64_t>(chunk_rows, n_send - (int64_t)j * chunk_rows); };
+  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)(chunked ? chunk_rows : n_send), ctx->stream, keep);
   if (ra < 0) return fail(c, ra);
+  for (int j = 1; j < n_chunks; ++j) {
+    int rx = reserve(&h->send_x[j - 1], &h->send_x_cap[j - 1], &h->send_x_serial[j - 1], row_bytes * (size_t)rows_in_chunk(j),
+                     ctx->stream, keep);
+    if (rx < 0) return fail(c, rx);
+  }
   int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
   if (rb < 0) return fail(c, rb);
-  if (n_send) {
+  if (n_send && !chunked) {
     int rc = h->d_pack_row ? gaib_gather_scatter_rows(ctx, n_send, h->d_pack_row, h->d_pack_slot, len, d_rows, h->sendbuf)
                            : gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
     if (rc != GAIB_OK) return fail(c, rc);
+  } else if (n_send) {  // chunk by chunk, in destination order (the source-ordered pack scatters over the whole buffer)
+    for (int j = 0; j < n_chunks; ++j) {
+      int rc = gaib_gather_rows(ctx, rows_in_chunk(j), h->d_send_idx + (int64_t)j * chunk_rows, len, d_rows, chunk_ptr(j));
+      if (rc != GAIB_OK) return fail(c, rc);
+    }
   }
   h->bytes_sent += (int64_t)row_bytes * n_send;
   h->pending_len = len;
@@ -737,36 +807,53 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   }
   // ---- IPC pull ----
   ShmSlot* mine = &c->seg->slot[h->id][c->rank];
-  if (h->pub_send_serial != h->send_serial) {  // also after a gaib_halo_reduce grew the send buffer
-    hipError_t e = pool_handle(c, h->sendbuf, &mine->handle);
-    if (e != hipSuccess) {
-      gaib_set_error("gaib_halo_exchange_begin: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
-      return fail(c, GAIB_ERR_HIP);
+  bool republish = h->pub_send_serial != h->send_serial || h->pub_n_chunks != n_chunks || h->pub_chunk_rows != chunk_rows;
+  for (int j = 1; j < n_chunks; ++j) republish = republish || h->pub_x_serial[j - 1] != h->send_x_serial[j - 1];
+  if (republish) {  // an allocation the peers hold a handle of was replaced, or the layout changed (another row length)
+    for (int j = 0; j < n_chunks; ++j) {
+      if ((j == 0 ? h->send_cap : h->send_x_cap[j - 1]) > ipc_export_limit()) {
+        gaib_set_error("gaib_halo_exchange_begin(rank %d): chunk %d of the send buffer is an allocation of %zu B, above what this "
+                       "transport exports (%zu B: hipIpcOpenMemHandle does not return for allocations above 2 GiB)", c->rank, j,
+                       j == 0 ? h->send_cap : h->send_x_cap[j - 1], ipc_export_limit());
+        return fail(c, GAIB_ERR_UNSUPPORTED);
+      }
+      hipError_t e = pool_handle(c, chunk_ptr(j), j == 0 ? &mine->handle : &mine->handle_x[j - 1]);
+      if (e != hipSuccess) {
+        gaib_set_error("gaib_halo_exchange_begin: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+        return fail(c, GAIB_ERR_HIP);
+      }
+      if (j > 0) h->pub_x_serial[j - 1] = h->send_x_serial[j - 1];
     }
     mine->capacity_bytes = h->send_cap;
     mine->device = ctx->device;
+    mine->n_chunks = n_chunks;
+    mine->chunk_rows = chunk_rows;
     for (int r = 0; r <= c->nranks; r++) mine->send_off[r] = h->send_off[r];
     mine->gen++;
     h->pub_send_serial = h->send_serial;
+    h->pub_n_chunks = n_chunks;
+    h->pub_chunk_rows = chunk_rows;
   }
+  GAIB_COMM_DBG(c, "exchange_begin: %lld rows out (%zu B), %lld rows in, handle published; waiting for the pack", (long long)n_send,
+                row_bytes * (size_t)n_send, (long long)n_recv);
   hipError_t e = hipEventSynchronize(c->ev_ready);  // the pack is done: peers may read the buffer
   if (e != hipSuccess) {
     gaib_set_error("gaib_halo_exchange_begin: %s", hipGetErrorString(e));
     return fail(c, GAIB_ERR_HIP);
   }
+  GAIB_COMM_DBG(c, "exchange_begin: packed");
   int rc = shm_barrier(c, "gaib_halo_exchange_begin (all packed)");
   if (rc != GAIB_OK) return rc;
+  GAIB_COMM_DBG(c, "exchange_begin: all ranks packed");
   for (int r = 0; r < c->nranks; r++) {
     if (!h->recv_counts[r]) continue;
     const ShmSlot* ps = &c->seg->slot[h->id][r];
-    if (h->peer[r].gen != ps->gen) {
+    if (h->peer[r].gen != ps->gen) {  // the peer's allocations (or their layout) changed: every mapping of the old ones goes
       if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
       h->peer[r].base = nullptr;
-      e = hipIpcOpenMemHandle(&h->peer[r].base, ps->handle, hipIpcMemLazyEnablePeerAccess);
-      if (e != hipSuccess) {
-        gaib_set_error("gaib_halo_exchange_begin(rank %d): hipIpcOpenMemHandle(rank %d's send buffer): %s", c->rank, r,
-                       hipGetErrorString(e));
-        return fail(c, GAIB_ERR_HIP);
+      for (void*& q : h->peer[r].base_x) {
+        if (q) (void)hipIpcCloseMemHandle(q);
+        q = nullptr;
       }
       h->peer[r].gen = ps->gen;
     }
@@ -775,12 +862,39 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
                      (long long)(ps->send_off[c->rank + 1] - ps->send_off[c->rank]), (long long)h->recv_counts[r]);
       return fail(c, GAIB_ERR_INVALID);
     }
-    const float* src = (const float*)h->peer[r].base + ps->send_off[c->rank] * len;
-    e = hipMemcpyAsync(h->table + h->recv_off[r] * len, src, row_bytes * (size_t)h->recv_counts[r], hipMemcpyDeviceToDevice,
-                       c->cstream);
-    if (e != hipSuccess) {
-      gaib_set_error("gaib_halo_exchange_begin(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
-      return fail(c, GAIB_ERR_HIP);
+    const int pk = ps->n_chunks > 0 ? ps->n_chunks : 1;
+    const int64_t pcr = ps->chunk_rows;
+    if (pk > GAIB_IPC_MAX_CHUNKS || (pk > 1 && pcr < 1)) {
+      gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d published %d chunks of %lld rows", c->rank, r, pk, (long long)pcr);
+      return fail(c, GAIB_ERR_INVALID);
+    }
+    // this rank's segment of the peer's send buffer: rows [s0, s1) of its slot space, chunk by chunk
+    const int64_t s0 = ps->send_off[c->rank], s1 = s0 + h->recv_counts[r];
+    for (int64_t a = s0; a < s1;) {
+      const int j = pk > 1 ? (int)(a / pcr) : 0;
+      const int64_t in_chunk = pk > 1 ? a - (int64_t)j * pcr : a;
+      const int64_t b = pk > 1 ? std::min<int64_t>(s1, (int64_t)(j + 1) * pcr) : s1;
+      void*& base = j == 0 ? h->peer[r].base : h->peer[r].base_x[j - 1];
+      if (!base) {
+        GAIB_COMM_DBG(c, "exchange_begin: opening chunk %d of %d of rank %d's send buffer", j, pk, r);
+        e = hipIpcOpenMemHandle(&base, j == 0 ? ps->handle : ps->handle_x[j - 1], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+          base = nullptr;
+          gaib_set_error("gaib_halo_exchange_begin(rank %d): hipIpcOpenMemHandle(rank %d's send buffer, chunk %d): %s", c->rank, r, j,
+                         hipGetErrorString(e));
+          return fail(c, GAIB_ERR_HIP);
+        }
+      }
+      const float* src = (const float*)base + in_chunk * len;
+      GAIB_COMM_DBG(c, "exchange_begin: pulling %zu B from rank %d (chunk %d, row %lld)", row_bytes * (size_t)(b - a), r, j,
+                    (long long)in_chunk);
+      e = hipMemcpyAsync(h->table + (h->recv_off[r] + (a - s0)) * len, src, row_bytes * (size_t)(b - a), hipMemcpyDeviceToDevice,
+                         c->cstream);
+      if (e != hipSuccess) {
+        gaib_set_error("gaib_halo_exchange_begin(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
+        return fail(c, GAIB_ERR_HIP);
+      }
+      a = b;
     }
   }
   GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
@@ -796,11 +910,13 @@ extern "C" int gaib_halo_exchange_end(gaib_halo* h, const float** d_table) {
   GAIB_HIP(hipSetDevice(c->ctx->device));
   h->pending_len = 0;
   if (c->transport == GAIB_COMM_IPC) {
+    GAIB_COMM_DBG(c, "exchange_end: waiting for the pulls");
     hipError_t e = hipEventSynchronize(c->ev_done);
     if (e != hipSuccess) {
       gaib_set_error("gaib_halo_exchange_end: %s", hipGetErrorString(e));
       return fail(c, GAIB_ERR_HIP);
     }
+    GAIB_COMM_DBG(c, "exchange_end: pulled");
     int rc = shm_barrier(c, "gaib_halo_exchange_end (all pulled)");  // send buffers may be overwritten from here on
     if (rc != GAIB_OK) return rc;
   }
@@ -835,7 +951,8 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   GAIB_CHECK((n_recv == 0 || d_halo_rows) && (n_send == 0 || d_rows), "gaib_halo_reduce: NULL rows");
   const size_t row_bytes = sizeof(float) * (size_t)len;
   gaib_halo* keep = h;  // (both transports draw from the communicator's pool; only IPC retires, see reserve)
-  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)n_send, ctx->stream, keep);  // arrivals land here
+  // arrivals land in a buffer of their own: the send buffer stays what the exchanges made it (on IPC possibly chunks)
+  int ra = reserve(&h->landing, &h->landing_cap, &h->landing_serial, row_bytes * (size_t)n_send, ctx->stream, keep);
   if (ra < 0) return fail(c, ra);
   if (c->transport == GAIB_COMM_RCCL) {
     GAIB_HIP(hipEventRecord(c->ev_ready, ctx->stream));
@@ -847,7 +964,7 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
           GAIB_NCCL(g_rccl.Send(d_halo_rows + h->recv_off[r] * len, (size_t)(h->recv_counts[r] * len), ncclFloat32, r, c->nccl,
                                 c->cstream));
         if (h->send_counts[r])
-          GAIB_NCCL(g_rccl.Recv(h->sendbuf + h->send_off[r] * len, (size_t)(h->send_counts[r] * len), ncclFloat32, r, c->nccl,
+          GAIB_NCCL(g_rccl.Recv(h->landing + h->send_off[r] * len, (size_t)(h->send_counts[r] * len), ncclFloat32, r, c->nccl,
                                 c->cstream));
       }
       GAIB_NCCL(g_rccl.GroupEnd());
@@ -859,6 +976,12 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
     // and let the owners pull their segments
     int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
     if (rb < 0) return fail(c, rb);
+    if (h->table_cap > ipc_export_limit()) {  // (the table is ONE allocation by contract: the aggregation reads it as a matrix)
+      gaib_set_error("gaib_halo_reduce(rank %d): the halo table is an allocation of %zu B, above what the IPC transport exports "
+                     "(%zu B: hipIpcOpenMemHandle does not return for allocations above 2 GiB) -- use the RCCL transport or more "
+                     "ranks", c->rank, h->table_cap, ipc_export_limit());
+      return fail(c, GAIB_ERR_UNSUPPORTED);
+    }
     hipError_t e = hipSuccess;
     const char* step = "staging copy";
     if (n_recv && d_halo_rows != h->table)
@@ -902,7 +1025,7 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
         return fail(c, GAIB_ERR_INVALID);
       }
       const float* src = (const float*)h->peer[r].base_t + ps->recv_off[c->rank] * len;
-      e = hipMemcpyAsync(h->sendbuf + h->send_off[r] * len, src, row_bytes * (size_t)h->send_counts[r],
+      e = hipMemcpyAsync(h->landing + h->send_off[r] * len, src, row_bytes * (size_t)h->send_counts[r],
                          hipMemcpyDeviceToDevice, ctx->stream);
       if (e != hipSuccess) {
         gaib_set_error("gaib_halo_reduce(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
@@ -920,7 +1043,7 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
   for (int r = 0; r < c->nranks; r++) {
     if (!h->send_counts[r]) continue;
     scatter_add_rows_kernel<<<(unsigned)cdiv64(h->send_counts[r], 4), 256, 0, ctx->stream>>>(
-        h->send_counts[r], h->d_send_idx + h->send_off[r], len, h->sendbuf + h->send_off[r] * len, d_rows);
+        h->send_counts[r], h->d_send_idx + h->send_off[r], len, h->landing + h->send_off[r] * len, d_rows);
   }
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;

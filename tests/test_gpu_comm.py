@@ -326,13 +326,15 @@ def _gat_worker(rank, world, idfile, q, heads, mode="fused", transport_name="ipc
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def _halo_realloc_worker(rank, world, idfile, q, transport_name="ipc"):
+def _halo_realloc_worker(rank, world, idfile, q, transport_name="ipc", chunk_bytes=0):
     """raw halo plan: exchange and reverse exchange with GROWING row lengths in the order that left a stale hipIpc
     handle behind (exchange 16, reduce 16, exchange 64, reduce 64: the reduce's table was reallocated by the exchange
     before it, the exchange's send buffer by the reduce before it), and more plans over a communicator's life than it
     has slot rows (ids are released by gaib_halo_destroy)"""
     sys.path.insert(0, str(ROOT))
     os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    if chunk_bytes:  # IPC: send buffers above this size are cut into separately exported chunks (comm.hip)
+        os.environ["GAIB_IPC_CHUNK_BYTES"] = str(chunk_bytes)
     try:
         from graphaibench_amd import capi, layers as L
 
@@ -388,6 +390,11 @@ def _halo_realloc_worker(rank, world, idfile, q, transport_name="ipc"):
         for h in alive:
             h.close()
         comm.barrier()
+        if chunk_bytes:  # an allocation above the export limit is refused loudly (hipIpcOpenMemHandle hangs above 2 GiB)
+            os.environ["GAIB_IPC_EXPORT_LIMIT_BYTES"] = str(1 << 20)
+            h3 = comm.halo(send_counts, send_idx, recv_counts)
+            with pytest.raises(capi.GaibError, match="above what this transport exports"):
+                h3.begin(torch.zeros(n_own, 100, device="cuda"), 100)
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -444,6 +451,17 @@ def test_ipc_gat_layer_on_partition_matches_global_oracle(tmp_path, heads, world
 @pytest.mark.parametrize("world", [2, 3])
 def test_ipc_halo_buffers_regrow_between_exchange_and_reduce(tmp_path, world):
     res = _spawn(world, _halo_realloc_worker, (str(tmp_path / "id"),))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("world,chunk_bytes", [(2, 50000), (3, 50000), (3, 24000)])
+def test_ipc_send_buffer_in_chunks(tmp_path, world, chunk_bytes):
+    """hipIpcOpenMemHandle of an allocation above 2 GiB does not return (bench.py --gpus 3 --cut-fraction 0.3 on one device:
+    2.4 GB send buffers), so the IPC transport cuts a send buffer into separately exported chunks of whole rows and a receiver
+    opens the chunks its segment touches.  Here with chunks of 50 / 24 kB: the exchanges and reverse exchanges of the regrow
+    test (1 to 55 chunks as the row length goes 16, 16, 64, 8, 200, ...; a layout that shrinks again) deliver the same rows,
+    and an allocation above the export limit is an error on every rank, not a hang"""
+    res = _spawn(world, _halo_realloc_worker, (str(tmp_path / "id"), "ipc", chunk_bytes))
     assert all(r[1] == "ok" for r in res), res
 
 
