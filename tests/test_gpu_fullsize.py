@@ -217,6 +217,68 @@ def test_tile_supply_follows_the_numbering(ctx):
     g2.close()
 
 
+@pytest.mark.parametrize("n_big,first_hi", [(9_000_000, 8_000_000), (6_800_000, 5_000_000)])
+def test_feature_tables_above_4_gib_and_above_2_gib(ctx, n_big, first_hi):
+    """a rank of BASELINE config 5 holds 13.9 M rows x 512 B = 7.1 GB of feature rows (and 12.8 GB of halo rows on the
+    uniform generator): byte offsets beyond 2^32, which the gather kernels address with 64-bit global loads instead of
+    buffer descriptors.  A 4.6 GB table whose gathered rows sit above the 4-GiB mark (and a few at its start) gives, bit for
+    bit, what the same rows give as a compact table -- plain aggregation, heavy rows, the fused aggregation + product, the
+    edge-stream form of short rows, and the two-table form with the big table as the SECOND table.  The second case: a
+    3.5 GB table gathered above its 2-GiB mark stays on buffer descriptors (below 4 GiB), whose 32-bit row offsets then have
+    their top bit set -- the halo table of a products-shaped rank on the uniform generator is 3.3 GB"""
+    n = 150_000
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x_big = torch.empty(n_big, D, device="cuda")
+    x_big[:4096].normal_(generator=gen)
+    x_big[first_hi:].normal_(generator=gen)  # (only the rows that are gathered need values)
+    deg = torch.randint(0, 40, (n,), device="cuda", generator=gen)
+    deg[7] = 2500  # a heavy row
+    deg[11] = 0
+    rp = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(deg, 0, out=rp[1:])
+    ne = int(rp[-1])
+    hi = torch.randint(first_hi, n_big, (ne,), device="cuda", generator=gen)  # byte offsets 4.1 .. 4.6 GB (2.6 .. 3.5 GB)
+    lo = torch.randint(0, 4096, (ne,), device="cuda", generator=gen)
+    col = torch.where(torch.rand(ne, device="cuda", generator=gen) < 0.9, hi, lo)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    col = torch.sort(rows * n_big + col).values % n_big  # rows sorted by column
+    uniq, inv = torch.unique(col, return_inverse=True)
+    x_small = x_big[uniq].contiguous()
+    assert (x_big.numel() * 4 > (1 << 32)) == (n_big == 9_000_000) and first_hi * D * 4 > (1 << 31) and x_small.numel() * 4 < (1 << 31)
+    g_big = ctx.graph(rp, col.to(torch.int32), ncols=n_big)
+    g_small = ctx.graph(rp, inv.to(torch.int32), ncols=int(uniq.numel()))
+    W = torch.randn(D, D, device="cuda", generator=gen) * 0.1
+    for flat in (0, 1):
+        ctx.set_option("spmm_flat", flat)
+        try:
+            a_s, y_s = torch.empty(n, D, device="cuda"), torch.empty(n, D, device="cuda")
+            a_b, y_b = torch.empty(n, D, device="cuda"), torch.empty(n, D, device="cuda")
+            ctx.spmm_gemm(g_small, capi.W_MEAN, x_small, a_s, W, y_s, relu=True)
+            ctx.spmm_gemm(g_big, capi.W_MEAN, x_big, a_b, W, y_b, relu=True)
+            assert torch.equal(a_s, a_b) and torch.equal(y_s, y_b), flat
+        finally:
+            ctx.set_option("spmm_flat", -1)
+    p_s, p_b = torch.empty(n, D, device="cuda"), torch.empty(n, D, device="cuda")
+    ctx.spmm(g_small, capi.W_MEAN, x_small, p_s)
+    ctx.spmm(g_big, capi.W_MEAN, x_big, p_b)
+    assert torch.equal(p_s, p_b) and torch.equal(p_s, a_s)
+    # two tables: columns below n_first from a small first table, the others from the big one (ids shifted by n_first)
+    n_first = 1000
+    first = torch.randn(n_first, D, device="cuda", generator=gen)
+    col2 = torch.where(col < 4096, col % n_first, col + n_first)
+    col2 = torch.sort(rows * (n_big + n_first) + col2).values % (n_big + n_first)
+    g2 = ctx.graph(rp, col2.to(torch.int32), ncols=n_big + n_first)
+    uniq2, inv2 = torch.unique(col2, return_inverse=True)
+    both_small = torch.where((uniq2 < n_first).unsqueeze(1), first[uniq2.clamp(max=n_first - 1)],
+                             x_big[(uniq2 - n_first).clamp(min=0)])
+    g2s = ctx.graph(rp, inv2.to(torch.int32), ncols=int(uniq2.numel()))
+    ctx.spmm_gemm(g2s, capi.W_MEAN, both_small.contiguous(), a_s, W, y_s, relu=True)
+    ctx.spmm_gemm_2t(g2, capi.W_MEAN, first, x_big, n_first, a_b, W, y_b, relu=True)
+    assert torch.equal(a_s, a_b) and torch.equal(y_s, y_b)
+    ctx.spmm_2t(g2, capi.W_MEAN, first, x_big, n_first, p_b)
+    assert torch.equal(p_b, a_s)
+
+
 def test_gat_properties_reddit_size(ctx):
     sg = synth.make("reddit", seed=7, device="cuda")
     g = ctx.graph(sg.rowptr, sg.colidx).add_selfloop()
