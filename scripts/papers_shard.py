@@ -72,8 +72,9 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform
     setup_s = time.time() - t0
     x_in = torch.randn(nv, D, device="cuda")
     g_in = torch.randn(nv, D, device="cuda")
+    shard = dict(locals())  # (one dict for all modes: the first mode leaves its output sample in it)
     for mode in modes:
-        run_mode(ctx, mode, locals(), steps)
+        run_mode(ctx, mode, shard, steps)
 
 
 def run_mode(ctx, mode, S, steps):
@@ -149,6 +150,13 @@ def run_mode(ctx, mode, S, steps):
         if n:
             br[k] = round(t / steps, 3)
     ctx.prof_reset()
+    # the modes sum a row's terms in different orders, nothing else: a sample of output and input-gradient rows (every 97th row,
+    # so rows beyond the 4-GiB mark of the 7-GB matrices of a config-5 rank are among them) against the first mode's
+    step()
+    torch.cuda.synchronize()
+    sample = (fo[::97].clone(), go[::97].clone())
+    ref = S.setdefault("_mode_ref", sample)
+    agree = [float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(sample, ref)]
     t0 = time.perf_counter()
     for _ in range(3):
         begin(D, layer.ptr(L.FEAT_IN))
@@ -168,6 +176,7 @@ def run_mode(ctx, mode, S, steps):
                # per exchange: the kernel time between its begin and its end -- what the wire time can hide under
                overlappable_ms_per_exchange=[round(v, 3) for v in overlap_ms],
                gedges_per_s_compute_only=2 * (ne_own + ne_halo) / ms / 1e6, setup_s=round(setup_s, 1),
+               out_and_grad_inf_vs_first_mode=agree,
                hbm_gb_in_use=torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9)
     print(json.dumps(out), flush=True)
     layer.close()
