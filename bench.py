@@ -319,7 +319,15 @@ class DistOracleCheck:
         torch, dist, L = self.torch, self.dist, self.L
         nv = part.n_own
         x_h, gin_h = self.inputs(self.rank, nv)
-        want = self._oracle_global(nv) if self.rank == 0 else None
+        want, err = None, [None]
+        if self.rank == 0:  # (a failing oracle run -- host memory, say -- must not leave the other ranks in a collective)
+            try:
+                want = self._oracle_global(nv)
+            except Exception as e:  # noqa: BLE001
+                err[0] = f"{type(e).__name__}: {e}"[:300]
+        dist.broadcast_object_list(err, src=0)
+        if err[0]:
+            return {"error": err[0], "ok": None} if self.rank == 0 else None
         # rank 0 hands every rank its rows of the oracle's outputs (control plane: gloo / the launcher's group)
         def scatter(key):
             mine = torch.empty(nv, D)
@@ -669,8 +677,13 @@ def main():
             torch.cuda.empty_cache()
             return rec
 
+        def parity_at(shape, cut, comm, scale):  # the budgeted parity sub-case of a default N > 1 run, at a bounded global size
+            a2 = argparse.Namespace(**{**vars(args), "scale": scale})
+            return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, a2, rank, world, shape, cut)
+
         result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
-                                       cpu_leg=None if args.no_cpu_baseline else cpu_leg)
+                                       cpu_leg=None if args.no_cpu_baseline else cpu_leg,
+                                       parity_check=None if (args.no_parity or args.check_oracle) else parity_at)
         dist.barrier()
         rc = 0
         if rank == 0:
@@ -680,7 +693,7 @@ def main():
             if cfg["transport"].startswith("gaib_comm/rccl") and cfg["rccl_ranks"] != world:
                 log(f"[bench] transport {cfg['transport']} but rccl_ranks = {cfg['rccl_ranks']} != {world}")
                 rc = 4
-            if result.get("parity") is not None and not result["parity"]["ok"]:
+            if result.get("parity") is not None and result["parity"].get("ok") is False:
                 log("[bench] PARITY FAILED (> 1e-4)")
                 rc = 3
             if guard is not None:

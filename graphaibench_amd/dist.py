@@ -603,7 +603,8 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None):
     return res
 
 
-def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=None, t_start=None, hold=None, cpu_leg=None):
+def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=None, t_start=None, hold=None, cpu_leg=None,
+                    parity_check=None):
     """bench.py's N > 1 leg.  GCN hidden layer D -> D forward + backward per step, halo exchange before each of the 2
     SpMM, one all-reduce of dW per step.
 
@@ -619,7 +620,10 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     The record cannot be lost: the HEADLINE case runs first and rank 0 hands the record to hold() as soon as it is measured
     (bench.py prints it if anything ends the run early); every further sub-case -- the N = 1 CPU baseline (cpu_leg), the
     clustered-boundary generator, the random vertex order, config 5 -- starts only if all ranks agree that its estimated
-    time fits args.budget_s counted from t_start (Budget), else its slot says {"skipped": "budget", ...}."""
+    time fits args.budget_s counted from t_start (Budget), else its slot says {"skipped": "budget", ...}.
+    parity_check(shape, cut, comm, scale) -> bench.py's oracle comparison at another scale: the record's `parity` block of a
+    default run -- the same partitioned layer over the same transport on a graph whose GLOBAL size the oracle runs in seconds
+    (two products-shaped ranges in all), every rank's rows element-wise against the oracle's global run."""
     import os
 
     from . import capi, synth
@@ -654,7 +658,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     dist.barrier()
     strong = getattr(args, "scaling", "weak") == "strong"
     cut = 0.1 if args.cut_fraction is None else args.cut_fraction
-    extra = clustered = config5 = cpu_rec = None
+    extra = clustered = config5 = cpu_rec = parity_scaled = None
     t_case = time.time()
     if strong:
         sg = synth.make("ogbn-products", seed=42, device="cuda", scale=args.scale)
@@ -700,7 +704,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     def assemble():
         achieved = main["alg_bytes"] / (main["avg_ms"] * 1e-3) / 1e9 if main["avg_ms"] > 0 else 0.0
         rccl_ranks = comm.size if (comm is not None and transport.startswith("gaib_comm/rccl")) else 0
-        parity = main["parity"]
+        parity = main["parity"] if main["parity"] is not None else parity_scaled
         if isinstance(extra, dict) and "value" in extra:
             rp = extra.get("parity")
             if parity is not None and rp is not None:
@@ -772,6 +776,27 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         if hold is not None and rank == 0:
             hold(assemble())
     weak_default = not strong and args.cut_fraction is None and world > 1
+    if parity_check is not None and not strong and world > 1 and main["parity"] is None:
+        # element-wise against the oracle's GLOBAL run, at a global size the oracle finishes in seconds: 4.9 M vertices in all
+        import argparse
+
+        scale_p = min(args.scale, 4.9e6 * args.scale / max(world * main["nv"], 1))
+        need = 75.0
+        if budget.agree(need):
+            a2 = argparse.Namespace(**{**vars(args), "scale": scale_p, "steps": 2, "warmup": 1})
+            rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=scale_p, selfloops=True)
+            r = _bench_case(ctx, comm, a2, rank, world, D, log, rows, f"parity leg, scale {scale_p:.3f}, cut {cut:.3f}",
+                            check=parity_check(shape, cut, comm, scale_p))
+            if rank == 0:
+                parity_scaled = {**(r["parity"] or {"error": "no record", "ok": None}), "scale": scale_p,
+                                 "of": f"the partitioned layer of this run ({world} ranks, {transport}) on the same generator at scale "
+                                       f"{scale_p:.3f} ({r['nv']} vertices per rank), not part of `value`"}
+            del rows
+            torch.cuda.empty_cache()
+        elif rank == 0:
+            parity_scaled = budget.skipped(need)
+        if hold is not None and rank == 0:
+            hold(assemble())
     if weak_default and os.environ.get("GAIB_BENCH_CLUSTERED", "1") != "0":
         need = 1.2 * headline_s + 10
         if budget.agree(need):

@@ -185,6 +185,11 @@ def test_bench_plain_two_gpus_default_workload():
     assert cl["value"] > 0 and 0 < cl["halo_rows_total"] < res["config"]["halo_rows_total"]
     assert cl["partition_mode_rank0"]["boundary_row_share"] < res["config"]["partition_mode_rank0"]["boundary_row_share"]
     assert res["cpu_baseline"]["value"] > 0 and "N = 1 workload" in res["cpu_baseline"]["of"]
+    # round 4: the default N > 1 record carries a parity block -- every rank's rows against the oracle's GLOBAL run on a leg of
+    # bounded size over the same transport
+    par = res["parity"]
+    assert par["ok"] is True and par["forward"]["elem"] <= 1e-4 and par["grad_out"]["elem"] <= 1e-4 and par["W_grad"]["inf"] <= 1e-4
+    assert par["scale"] <= 0.02 and "GLOBAL graph" in par["against"] and "2 ranks" in par["of"]
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["transport"].startswith("gaib_comm/")
     if torch.cuda.device_count() < 2:
         assert res["config"]["transport"].startswith("gaib_comm/ipc") and res["config"]["rccl_ranks"] == 0
@@ -209,7 +214,7 @@ def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
     assert len(out) == 1
     res = json.loads(out[0])
     assert res["value"] > 0 and res["ms_per_step"] > 0
-    for slot in (res["cpu_baseline"], res["config"]["clustered_boundary"], res["config"]["random_order"],
+    for slot in (res["cpu_baseline"], res["parity"], res["config"]["clustered_boundary"], res["config"]["random_order"],
                  res["config"]["config5_papers100M"]):
         assert slot["skipped"] == "budget" and slot["elapsed_s"] > 1 and slot["needed_s_estimate"] > 0, slot
 
