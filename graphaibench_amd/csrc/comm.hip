@@ -124,6 +124,11 @@ struct ShmSlot {  // one rank's published send buffer of one halo plan
   uint64_t gen_t;
   hipIpcMemHandle_t handle_t;
   int64_t recv_off[GAIB_COMM_MAX_RANKS + 1];
+  // ... staged in chunks when it is above the chunk size (handle_t = chunk 0)
+  int32_t n_chunks_t;
+  int32_t pad3;
+  int64_t chunk_rows_t;
+  hipIpcMemHandle_t handle_tx[GAIB_IPC_MAX_CHUNKS - 1];
 };
 struct ShmSeg {
   std::atomic<uint32_t> magic;
@@ -229,6 +234,13 @@ struct gaib_halo {
   float* landing;
   size_t landing_cap;
   uint64_t landing_serial;
+  // IPC, reverse direction with a halo table above the chunk size: the partial rows are staged in chunks of their own
+  // (the table itself is one allocation by contract and would be exported whole)
+  float* stage_x[GAIB_IPC_MAX_CHUNKS];
+  size_t stage_x_cap[GAIB_IPC_MAX_CHUNKS];
+  uint64_t stage_x_serial[GAIB_IPC_MAX_CHUNKS], pub_stage_serial[GAIB_IPC_MAX_CHUNKS];
+  int pub_n_chunks_t;
+  int64_t pub_chunk_rows_t;
   // IPC: which ALLOCATION of each buffer the peers hold a handle of.  Either entry point may reallocate either buffer
   // (an exchange reserves the table, a reduce lands its arrivals in the send buffer), so "did MY reserve() reallocate"
   // is not the question -- "is the published allocation still the current one" is.
@@ -248,6 +260,7 @@ struct gaib_halo {
     void* base_x[GAIB_IPC_MAX_CHUNKS - 1];  // chunks 1.. of the peer's send buffer, opened when first needed
     uint64_t gen_t;  // the peer's halo table (reverse direction)
     void* base_t;
+    void* base_tx[GAIB_IPC_MAX_CHUNKS - 1];
   } peer[GAIB_COMM_MAX_RANKS];
   int64_t bytes_sent;
 };
@@ -712,6 +725,8 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
       for (void* q : h->peer[r].base_x)
         if (q) (void)hipIpcCloseMemHandle(q);
       if (h->peer[r].base_t) (void)hipIpcCloseMemHandle(h->peer[r].base_t);
+      for (void* q : h->peer[r].base_tx)
+        if (q) (void)hipIpcCloseMemHandle(q);
     }
     // nobody may still be pulling from the send buffer that is about to be freed
     if (c->seg && !c->seg->error.load()) (void)shm_barrier(c, "gaib_halo_destroy");
@@ -722,6 +737,7 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   pool_release(c, h->sendbuf);  // back into the communicator's pool (see gaib_comm::ipc_bufs)
   for (float* q : h->send_x) pool_release(c, q);
   pool_release(c, h->landing);
+  for (float* q : h->stage_x) pool_release(c, q);
   pool_release(c, h->table);
   for (void* q : h->retired) pool_release(c, q);
   c->halo_slots &= ~(1u << h->id);  // after the barrier above: the slot row can serve the next plan
@@ -972,27 +988,60 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
     GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
     GAIB_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
   } else {
-    // IPC: stage the partial rows in this plan's own table allocation (a whole allocation can be exported), publish it,
-    // and let the owners pull their segments
-    int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
-    if (rb < 0) return fail(c, rb);
-    if (h->table_cap > ipc_export_limit()) {  // (the table is ONE allocation by contract: the aggregation reads it as a matrix)
-      gaib_set_error("gaib_halo_reduce(rank %d): the halo table is an allocation of %zu B, above what the IPC transport exports "
-                     "(%zu B: hipIpcOpenMemHandle does not return for allocations above 2 GiB) -- use the RCCL transport or more "
-                     "ranks", c->rank, h->table_cap, ipc_export_limit());
+    // IPC: stage the partial rows in allocations of this plan (a whole allocation can be exported) -- the table itself
+    // while it is below the chunk size, else chunks of whole rows, each its own allocation --, publish them, and let the
+    // owners pull their segments
+    // (also when the rows are few but the table an earlier, longer exchange left behind is too large to export)
+    const bool many = row_bytes * (size_t)n_recv > ipc_chunk_bytes();
+    const bool chunked = many || (h->table && h->table_cap > ipc_export_limit());
+    const int64_t chunk_rows = many ? std::max<int64_t>(1, (int64_t)(ipc_chunk_bytes() / row_bytes)) : n_recv;
+    const int n_chunks = many ? (int)cdiv64(n_recv, chunk_rows) : 1;
+    if (n_chunks > GAIB_IPC_MAX_CHUNKS) {
+      gaib_set_error("gaib_halo_reduce(rank %d): %lld halo rows of %zu B need %d chunks of %zu B, at most %d (GAIB_IPC_CHUNK_BYTES)",
+                     c->rank, (long long)n_recv, row_bytes, n_chunks, ipc_chunk_bytes(), GAIB_IPC_MAX_CHUNKS);
       return fail(c, GAIB_ERR_UNSUPPORTED);
     }
     hipError_t e = hipSuccess;
     const char* step = "staging copy";
-    if (n_recv && d_halo_rows != h->table)
-      e = hipMemcpyAsync(h->table, d_halo_rows, row_bytes * (size_t)n_recv, hipMemcpyDeviceToDevice, ctx->stream);
     ShmSlot* mine = &c->seg->slot[h->id][c->rank];
-    if (e == hipSuccess && h->pub_table_serial != h->table_serial) {  // also after an exchange grew the table
-      step = "hipIpcGetMemHandle(halo table)";
-      e = pool_handle(c, h->table, &mine->handle_t);
+    bool republish = h->pub_n_chunks_t != (chunked ? n_chunks : -1) || h->pub_chunk_rows_t != chunk_rows;
+    if (!chunked) {
+      int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
+      if (rb < 0) return fail(c, rb);
+      if (n_recv && d_halo_rows != h->table)
+        e = hipMemcpyAsync(h->table, d_halo_rows, row_bytes * (size_t)n_recv, hipMemcpyDeviceToDevice, ctx->stream);
+      republish = republish || h->pub_table_serial != h->table_serial;  // also after an exchange grew the table
+    } else {
+      for (int j = 0; j < n_chunks && e == hipSuccess; ++j) {
+        const int64_t rows_j = std::max<int64_t>(0, std::min<int64_t>(chunk_rows, n_recv - (int64_t)j * chunk_rows));
+        int rx = reserve(&h->stage_x[j], &h->stage_x_cap[j], &h->stage_x_serial[j], row_bytes * (size_t)rows_j, ctx->stream, keep);
+        if (rx < 0) return fail(c, rx);
+        if (rows_j)
+          e = hipMemcpyAsync(h->stage_x[j], d_halo_rows + (int64_t)j * chunk_rows * len, row_bytes * (size_t)rows_j,
+                             hipMemcpyDeviceToDevice, ctx->stream);
+        republish = republish || h->pub_stage_serial[j] != h->stage_x_serial[j];
+      }
+    }
+    if (e == hipSuccess && republish) {
+      step = "hipIpcGetMemHandle(halo rows)";
+      for (int j = 0; j < n_chunks && e == hipSuccess; ++j) {
+        void* q = chunked ? (void*)h->stage_x[j] : (void*)h->table;
+        const size_t cap = chunked ? h->stage_x_cap[j] : h->table_cap;
+        if (cap > ipc_export_limit()) {
+          gaib_set_error("gaib_halo_reduce(rank %d): an allocation of %zu B holds the halo rows, above what the IPC transport exports "
+                         "(%zu B: hipIpcOpenMemHandle does not return for allocations above 2 GiB)", c->rank, cap, ipc_export_limit());
+          return fail(c, GAIB_ERR_UNSUPPORTED);
+        }
+        e = pool_handle(c, q, j == 0 ? &mine->handle_t : &mine->handle_tx[j - 1]);
+        if (chunked) h->pub_stage_serial[j] = h->stage_x_serial[j];
+      }
       for (int r = 0; r <= c->nranks; r++) mine->recv_off[r] = h->recv_off[r];
+      mine->n_chunks_t = n_chunks;
+      mine->chunk_rows_t = chunk_rows;
       mine->gen_t++;
-      h->pub_table_serial = h->table_serial;
+      h->pub_table_serial = chunked ? 0 : h->table_serial;
+      h->pub_n_chunks_t = chunked ? n_chunks : -1;  // (-1: the table itself is what the peers hold a handle of)
+      h->pub_chunk_rows_t = chunk_rows;
     }
     if (e == hipSuccess) {
       step = "stream sync after staging";
@@ -1011,11 +1060,9 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
       if (h->peer[r].gen_t != ps->gen_t) {
         if (h->peer[r].base_t) (void)hipIpcCloseMemHandle(h->peer[r].base_t);
         h->peer[r].base_t = nullptr;
-        e = hipIpcOpenMemHandle(&h->peer[r].base_t, ps->handle_t, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) {
-          gaib_set_error("gaib_halo_reduce(rank %d): hipIpcOpenMemHandle(rank %d's halo table): %s", c->rank, r,
-                         hipGetErrorString(e));
-          return fail(c, GAIB_ERR_HIP);
+        for (void*& q : h->peer[r].base_tx) {
+          if (q) (void)hipIpcCloseMemHandle(q);
+          q = nullptr;
         }
         h->peer[r].gen_t = ps->gen_t;
       }
@@ -1024,12 +1071,34 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
                        (long long)(ps->recv_off[c->rank + 1] - ps->recv_off[c->rank]), (long long)h->send_counts[r]);
         return fail(c, GAIB_ERR_INVALID);
       }
-      const float* src = (const float*)h->peer[r].base_t + ps->recv_off[c->rank] * len;
-      e = hipMemcpyAsync(h->landing + h->send_off[r] * len, src, row_bytes * (size_t)h->send_counts[r],
-                         hipMemcpyDeviceToDevice, ctx->stream);
-      if (e != hipSuccess) {
-        gaib_set_error("gaib_halo_reduce(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
-        return fail(c, GAIB_ERR_HIP);
+      const int pk = ps->n_chunks_t > 0 ? ps->n_chunks_t : 1;
+      const int64_t pcr = ps->chunk_rows_t;
+      if (pk > GAIB_IPC_MAX_CHUNKS || (pk > 1 && pcr < 1)) {
+        gaib_set_error("gaib_halo_reduce(rank %d): rank %d published %d chunks of %lld rows", c->rank, r, pk, (long long)pcr);
+        return fail(c, GAIB_ERR_INVALID);
+      }
+      const int64_t s0 = ps->recv_off[c->rank], s1 = s0 + h->send_counts[r];  // this rank's rows in the peer's halo order
+      for (int64_t a = s0; a < s1;) {
+        const int j = pk > 1 ? (int)(a / pcr) : 0;
+        const int64_t in_chunk = pk > 1 ? a - (int64_t)j * pcr : a;
+        const int64_t b = pk > 1 ? std::min<int64_t>(s1, (int64_t)(j + 1) * pcr) : s1;
+        void*& base = j == 0 ? h->peer[r].base_t : h->peer[r].base_tx[j - 1];
+        if (!base) {
+          e = hipIpcOpenMemHandle(&base, j == 0 ? ps->handle_t : ps->handle_tx[j - 1], hipIpcMemLazyEnablePeerAccess);
+          if (e != hipSuccess) {
+            base = nullptr;
+            gaib_set_error("gaib_halo_reduce(rank %d): hipIpcOpenMemHandle(rank %d's halo rows, chunk %d): %s", c->rank, r, j,
+                           hipGetErrorString(e));
+            return fail(c, GAIB_ERR_HIP);
+          }
+        }
+        e = hipMemcpyAsync(h->landing + (h->send_off[r] + (a - s0)) * len, (const float*)base + in_chunk * len,
+                           row_bytes * (size_t)(b - a), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) {
+          gaib_set_error("gaib_halo_reduce(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
+          return fail(c, GAIB_ERR_HIP);
+        }
+        a = b;
       }
     }
     e = hipStreamSynchronize(ctx->stream);

@@ -502,7 +502,7 @@ int gaib_gather_scatter_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_src_
  *                   A send buffer above GAIB_IPC_CHUNK_BYTES (default 512 MiB) is cut into separately exported chunks
  *                   of whole rows (at most 64): hipIpcOpenMemHandle does not return for allocations above 2 GiB.  No
  *                   allocation above GAIB_IPC_EXPORT_LIMIT_BYTES (1.5 GiB) is exported: GAIB_ERR_UNSUPPORTED instead
- *                   (gaib_halo_reduce's halo table is one allocation by contract).  GAIB_COMM_DEBUG=1 prints the steps
+ *                   (gaib_halo_reduce stages its partial rows in chunks the same way).  GAIB_COMM_DEBUG=1 prints the steps
  *                   of every exchange with time stamps on stderr.
  * gaib_comm_unique_id is called by ONE rank; the caller carries the GAIB_COMM_ID_BYTES to the other ranks (a file,
  * MPI, torch.distributed's store ...).  gaib_comm_init is collective.  Every collective below must be called by
