@@ -683,7 +683,8 @@ def main():
 
         result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
                                        cpu_leg=None if args.no_cpu_baseline else cpu_leg,
-                                       parity_check=None if (args.no_parity or args.check_oracle) else parity_at)
+                                       parity_check=None if (args.no_parity or args.check_oracle) else parity_at,
+                                       traffic_of=traffic_from_profile)
         dist.barrier()
         rc = 0
         if rank == 0:

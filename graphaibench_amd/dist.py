@@ -604,7 +604,7 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None):
 
 
 def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=None, t_start=None, hold=None, cpu_leg=None,
-                    parity_check=None):
+                    parity_check=None, traffic_of=None):
     """bench.py's N > 1 leg.  GCN hidden layer D -> D forward + backward per step, halo exchange before each of the 2
     SpMM, one all-reduce of dW per step.
 
@@ -710,6 +710,13 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             if parity is not None and rp is not None:
                 parity = {**parity, "random_order": rp, "ok": bool(parity["ok"] and rp["ok"])}
         rec = {"parity": parity} if parity is not None else {}
+        # L2 -> fabric bytes per launch of the dominant kernel, where a PMC pass of exactly this kernel on exactly this shard
+        # exists (bench.py: profiles/hbm_traffic.json, verified by source hashes): the owned-column pass of the split on the
+        # products-shaped range at cut 0.1, uniform generator -- the same 113.6 M own-column edges at every N
+        traffic, traffic_src = None, "no PMC pass of this kernel on this shard"
+        if (traffic_of is not None and not strong and not papers and args.scale == 1.0 and abs(cut_main - 0.1) < 1e-9
+                and main["partition_mode"]["mode"] == "split" and main["kernel_name"].startswith("spmm_w64_kernel")):
+            traffic, traffic_src = traffic_of("spmm_w64_kernel_owned_pass_bytes_per_launch", "partitioned_products_uniform")
         rec.update({
             "metric": "GCN-layer fwd+bwd aggregated edges/sec",
             "value": main["value"],
@@ -751,7 +758,8 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             },
             "roofline": {
                 "bound": "hbm", "kernel": main["kernel_name"],
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": main["alg_bytes"], "avg_launch_ms": main["avg_ms"], "launches": main["launches"],
             },
             # the N = 1 workload's CPU baseline (named as such), timed on rank 0's host cores in this run

@@ -1,6 +1,6 @@
 """profiles/hbm_traffic.json from the PMC summaries of scripts/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes).
 
-    python scripts/make_hbm_traffic.py gpurun_out/prof_r02 <commit the profile was taken at>
+    python scripts/make_hbm_traffic.py gpurun_out/prof_r02 <commit the profile was taken at> [gpurun_out/prof_shard_r04]
 
 Counters are in KB (1024 B).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
 coalesced read -- re-calibrated for THIS access pattern (64 lanes x 8 B gathers of 512-B rows) with
@@ -80,6 +80,19 @@ if lp.exists():
         out["planted_locality"] = {"workload": "scripts/locality_study.py --kernel fused, natural order (= synth.planted_locality)",
                                    "commit": commit, "sources": out["sources"], "spmm_gemm_kernel": {"FETCH_SIZE_KB": fkb},
                                    "spmm_gemm_kernel_bytes_per_launch": fkb * 1024 * 2.0 + 2 * NV * 4 * D}
+# the N > 1 bench record's dominant kernel on the uniform generator: the owned-column pass of the split (spmm_w64_kernel over
+# rank 0's own rows; the same 113.6 M own-column edges at every N), from scripts/profile_shard.sh's PMC passes
+sp = Path(sys.argv[3]) / "shard_products_uniform_pmc_summary.json" if len(sys.argv) > 3 else None
+if sp is not None and sp.exists():
+    sh = json.loads(sp.read_text())
+    f, w = find(sh, "FETCH_SIZE", "spmm_w64_kernel"), find(sh, "WRITE_SIZE", "spmm_w64_kernel")
+    out["partitioned_products_uniform"] = {
+        "workload": "scripts/papers_shard.py --shape ogbn-products --cut 0.1 --boundary uniform --mode auto: rank 0 of 8, split mode",
+        "commit": commit,
+        "sources": blob_hashes(["graphaibench_amd/csrc/spmm.hip", "graphaibench_amd/csrc/spmm_kernels.h", "graphaibench_amd/csrc/spmm_core.h",
+                                "graphaibench_amd/csrc/spmm_part.hip", "graphaibench_amd/csrc/common.h"]),
+        "spmm_w64_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w},
+        "spmm_w64_kernel_owned_pass_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
 out["note"] = ("FETCH_SIZE counts L2 -> fabric requests; Infinity-Cache hits are included (MI355X_MICROARCH.md), so "
                "these are upper bounds on the HBM bytes.")
 Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -15,6 +15,16 @@ for shape in ogbn-products ogbn-papers100M; do
       --shape $shape --cut 0.1 --boundary $boundary --mode auto --steps 3 > "$OUT/${name}.jsonl" 2> "$OUT/${name}.err"
     ( cd "$ROOT" && python3 scripts/summarize_rocprof.py stats "$OUT/${name}" "$OUT/${name}_kernel_stats.csv" ) > "$OUT/${name}_top.txt" 2>&1
     rm -rf "$OUT/${name}"
+    if [ $shape = ogbn-products ] && [ $boundary = uniform ]; then
+      # the N > 1 headline case's dominant kernel (the owned-column pass of the split): its L2 -> fabric bytes, counters in
+      # their own passes (never with a trace domain) -> profiles/hbm_traffic.json "partitioned_products_uniform"
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        timeout 500 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${name}_$ctr" -- python3 "$ROOT/scripts/papers_shard.py" \
+          --shape $shape --cut 0.1 --boundary $boundary --mode auto --steps 3 > /dev/null 2> "$OUT/${name}_$ctr.err"
+      done
+      ( cd "$ROOT" && python3 scripts/summarize_rocprof.py pmc "$OUT/${name}_pmc_summary.json" fetch="$OUT/${name}_FETCH_SIZE" write="$OUT/${name}_WRITE_SIZE" ) > /dev/null 2>&1
+      rm -rf "$OUT/${name}_FETCH_SIZE" "$OUT/${name}_WRITE_SIZE"
+    fi
   done
 done
 ls -la "$OUT"
