@@ -34,6 +34,9 @@
 
 #define GAIB_COMM_MAX_RANKS 16
 #define GAIB_COMM_MAX_HALOS 8
+// elementwise.hip: the source-ordered pack into destination row ADDRESSES (a send buffer that is several allocations)
+int gaib_gather_rows_to_addresses(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_src_idx, const int64_t* d_dst_addr, int len,
+                                  const float* d_in);
 // IPC: a send buffer is cut into separately allocated (and separately exported) chunks -- hipIpcOpenMemHandle of an
 // allocation above 2 GiB does not return on this runtime (measured: a 1.86 GB buffer opens at once, a 2.42 GB one hangs all
 // ranks; bench.py --gpus 3 --cut-fraction 0.3 on one device) -- and a receiver opens only the chunks its segment touches
@@ -220,6 +223,7 @@ struct gaib_halo {
   // (2.9 x on average at 8 ranks, 6.6 x on a random vertex order) is then read from HBM once, its repeats hit the cache:
   // 1.26 -> 0.83 ms and 3.11 -> 1.79 ms for the two ends of the bench's partition axis (scripts/ab_pack.py)
   int64_t *d_pack_row, *d_pack_slot;
+  int64_t* d_pack_addr;  // chunked send buffer: the address of every pair's destination row (rebuilt per exchange: 20 us)
   float* sendbuf;
   size_t send_cap;
   float* table;
@@ -295,6 +299,18 @@ int shm_barrier(gaib_comm* c, const char* what) {
     }
   }
   return GAIB_OK;
+}
+
+// addr[k] = address of row slot[k] of a send buffer cut into chunks of chunk_rows rows
+struct ChunkBases {
+  float* p[GAIB_IPC_MAX_CHUNKS];
+};
+__global__ void chunk_row_address_kernel(int64_t n, const int64_t* slot, ChunkBases b, int64_t chunk_rows, int64_t row_floats,
+                                         int64_t* addr) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int64_t s = slot[k], j = s / chunk_rows;
+  addr[k] = (int64_t)(uintptr_t)(b.p[j] + (s - j * chunk_rows) * row_floats);
 }
 
 __global__ void iota_i64_kernel(int64_t n, int64_t* x) {
@@ -734,6 +750,7 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (h->d_send_idx) (void)hipFree(h->d_send_idx);
   if (h->d_pack_row) (void)hipFree(h->d_pack_row);
   if (h->d_pack_slot) (void)hipFree(h->d_pack_slot);
+  if (h->d_pack_addr) (void)hipFree(h->d_pack_addr);
   pool_release(c, h->sendbuf);  // back into the communicator's pool (see gaib_comm::ipc_bufs)
   for (float* q : h->send_x) pool_release(c, q);
   pool_release(c, h->landing);
@@ -795,10 +812,28 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
     int rc = h->d_pack_row ? gaib_gather_scatter_rows(ctx, n_send, h->d_pack_row, h->d_pack_slot, len, d_rows, h->sendbuf)
                            : gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
     if (rc != GAIB_OK) return fail(c, rc);
-  } else if (n_send) {  // chunk by chunk, in destination order (the source-ordered pack scatters over the whole buffer)
-    for (int j = 0; j < n_chunks; ++j) {
-      int rc = gaib_gather_rows(ctx, rows_in_chunk(j), h->d_send_idx + (int64_t)j * chunk_rows, len, d_rows, chunk_ptr(j));
-      if (rc != GAIB_OK) return fail(c, rc);
+  } else if (n_send) {
+    // the source-ordered pack into the chunks: every (row, slot) pair's destination as an address; where that form does
+    // not apply (odd row lengths, no sorted pairs) chunk by chunk in destination order
+    int rc = GAIB_ERR_UNSUPPORTED;
+    if (h->d_pack_row) {
+      if (!h->d_pack_addr && hipMalloc((void**)&h->d_pack_addr, sizeof(int64_t) * (size_t)n_send) != hipSuccess) {
+        (void)hipGetLastError();
+        h->d_pack_addr = nullptr;
+      }
+      if (h->d_pack_addr) {
+        ChunkBases b;
+        for (int j = 0; j < GAIB_IPC_MAX_CHUNKS; ++j) b.p[j] = j < n_chunks ? chunk_ptr(j) : nullptr;
+        chunk_row_address_kernel<<<(unsigned)cdiv64(n_send, 256), 256, 0, ctx->stream>>>(n_send, h->d_pack_slot, b, chunk_rows, len,
+                                                                                        h->d_pack_addr);
+        GAIB_LAUNCH_CHECK();
+        rc = gaib_gather_rows_to_addresses(ctx, n_send, h->d_pack_row, h->d_pack_addr, len, d_rows);
+        if (rc != GAIB_OK && rc != GAIB_ERR_UNSUPPORTED) return fail(c, rc);
+      }
+    }
+    for (int j = 0; j < n_chunks && rc == GAIB_ERR_UNSUPPORTED; ++j) {
+      int r2 = gaib_gather_rows(ctx, rows_in_chunk(j), h->d_send_idx + (int64_t)j * chunk_rows, len, d_rows, chunk_ptr(j));
+      if (r2 != GAIB_OK) return fail(c, r2);
     }
   }
   h->bytes_sent += (int64_t)row_bytes * n_send;

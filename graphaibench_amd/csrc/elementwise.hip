@@ -336,7 +336,8 @@ constexpr int GR_U = 8;
 // once per peer back to back): a row that goes to several peers is read from HBM once and found in the cache by its
 // repeats, where the destination-ordered pack read it once per peer (2.6 x at 8 ranks); the 512-B row pieces land in
 // their (scattered) slots of the send buffer.
-template <bool SCATTER>
+// SCATTER == 2: didx[k] is the ADDRESS of destination row k (a send buffer cut into separately allocated chunks: comm.hip)
+template <int SCATTER>
 __global__ __launch_bounds__(256) void gather_rows_vec_kernel(int64_t n_idx, const int64_t* idx, const int64_t* didx, int n4,
                                                               int shift, const f4* in, f4* out) {
   const int lane = threadIdx.x & 63;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void gather_rows_vec_kernel(int64_t n_idx, con
   const int64_t mine = idx[k0 + (lane < rows ? lane : rows - 1)];
   const int mine_lo = (int)(uint32_t)(mine & 0xffffffffll), mine_hi = (int)(mine >> 32);
   int dst_lo = 0, dst_hi = 0;
-  if constexpr (SCATTER) {
+  if constexpr (SCATTER != 0) {
     const int64_t d = didx[k0 + (lane < rows ? lane : rows - 1)];
     dst_lo = (int)(uint32_t)(d & 0xffffffffll);
     dst_hi = (int)(d >> 32);
@@ -367,12 +368,16 @@ __global__ __launch_bounds__(256) void gather_rows_vec_kernel(int64_t n_idx, con
 #pragma unroll
     for (int u = 0; u < GR_U; ++u) {
       const int t = t0 + u * 64 + lane;
-      if constexpr (SCATTER) {
+      if constexpr (SCATTER != 0) {
         const int tc = t < items ? t : items - 1;
         const int r = shift >= 0 ? (tc >> shift) : (tc / n4);
         const int c = tc - r * n4;
         const int64_t drow = ((int64_t)__shfl(dst_hi, r) << 32) | (uint32_t)__shfl(dst_lo, r);
-        if (t < items) out[drow * n4 + c] = v[u];
+        if constexpr (SCATTER == 2) {
+          if (t < items) reinterpret_cast<f4*>(drow)[c] = v[u];
+        } else {
+          if (t < items) out[drow * n4 + c] = v[u];
+        }
       } else {
         if (t < items) dst[t] = v[u];
       }
@@ -748,7 +753,7 @@ extern "C" int gaib_gather_rows(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_i
     int shift = -1;
     for (int b = 0; b < 31; ++b)
       if ((1 << b) == n4) shift = b;
-    gather_rows_vec_kernel<false><<<(unsigned)cdiv64(n_idx, 4 * GR_ROWS), 256, 0, ctx->stream>>>(
+    gather_rows_vec_kernel<0><<<(unsigned)cdiv64(n_idx, 4 * GR_ROWS), 256, 0, ctx->stream>>>(
         n_idx, d_idx, nullptr, n4, shift, reinterpret_cast<const f4*>(d_in), reinterpret_cast<f4*>(d_out));
   } else {
     gather_rows_kernel<<<(unsigned)cdiv64(n_idx, 4), 256, 0, ctx->stream>>>(n_idx, d_idx, len, d_in, d_out);
@@ -769,11 +774,28 @@ extern "C" int gaib_gather_scatter_rows(gaib_ctx* ctx, int64_t n_idx, const int6
     int shift = -1;
     for (int b = 0; b < 31; ++b)
       if ((1 << b) == n4) shift = b;
-    gather_rows_vec_kernel<true><<<(unsigned)cdiv64(n_idx, 4 * GR_ROWS), 256, 0, ctx->stream>>>(
+    gather_rows_vec_kernel<1><<<(unsigned)cdiv64(n_idx, 4 * GR_ROWS), 256, 0, ctx->stream>>>(
         n_idx, d_src_idx, d_dst_idx, n4, shift, reinterpret_cast<const f4*>(d_in), reinterpret_cast<f4*>(d_out));
   } else {
     scatter_rows_kernel<<<(unsigned)cdiv64(n_idx, 4), 256, 0, ctx->stream>>>(n_idx, d_src_idx, d_dst_idx, len, d_in, d_out);
   }
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+// *(float[len]*)d_dst_addr[k] = in[src_idx[k], :]: the source-ordered pack into a send buffer that is several allocations
+// (internal: comm.hip).  GAIB_ERR_UNSUPPORTED where the 16-byte path does not apply -- the caller packs chunk by chunk then.
+int gaib_gather_rows_to_addresses(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_src_idx, const int64_t* d_dst_addr, int len,
+                                  const float* d_in) {
+  if (n_idx <= 0 || len <= 0) return GAIB_OK;
+  if (len % 4 != 0 || (((uintptr_t)d_in) & 15) != 0) return GAIB_ERR_UNSUPPORTED;  // (chunk bases are 2-MiB aligned, rows 16 B)
+  ProfScope prof(ctx, "gather_rows");
+  const int n4 = len / 4;
+  int shift = -1;
+  for (int b = 0; b < 31; ++b)
+    if ((1 << b) == n4) shift = b;
+  gather_rows_vec_kernel<2><<<(unsigned)cdiv64(n_idx, 4 * GR_ROWS), 256, 0, ctx->stream>>>(
+      n_idx, d_src_idx, d_dst_addr, n4, shift, reinterpret_cast<const f4*>(d_in), nullptr);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
