@@ -398,10 +398,31 @@ def make_comm(ctx, rank: int, world: int, log):
         if uid[0] is None:
             ok = 0
         if ok:
-            try:
-                comm = capi.Comm(ctx, rank, world, uid[0], transport)
-            except capi.GaibError as e:
-                ok, err = 0, str(e)
+            # ncclCommInitRank is collective and has no deadline of its own: if a peer fails before it (or inside it), this
+            # rank would wait there for good and take the record with it.  The communicator is therefore created in a helper
+            # thread with a deadline (GAIB_COMM_INIT_TIMEOUT_S, 90 s); a rank that runs into it reports failure -- the call is
+            # left behind in its daemon thread -- and all ranks move on to the next transport together.  (The same path
+            # creates the peer-to-peer communicator, so every N > 1 run exercises it.)
+            import threading
+
+            box = {}
+
+            def create():
+                try:
+                    box["comm"] = capi.Comm(ctx, rank, world, uid[0], transport)
+                except Exception as e:  # noqa: BLE001
+                    box["err"] = str(e)
+
+            limit = float(os.environ.get("GAIB_COMM_INIT_TIMEOUT_S", "90"))
+            th = threading.Thread(target=create, daemon=True, name="gaib-comm-init")
+            th.start()
+            th.join(limit)
+            if th.is_alive():
+                ok, err = 0, f"communicator set-up did not return within {limit:.0f} s (left behind in its thread)"
+            elif "comm" in box:
+                comm = box["comm"]
+            else:
+                ok, err = 0, box.get("err", "communicator set-up failed")
         flag = torch.tensor([ok], dtype=torch.int32)
         if dist.get_backend() == "nccl":
             flag = flag.cuda()
