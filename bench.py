@@ -467,6 +467,7 @@ def launch_ranks(args, argv, entry=None) -> int:
     signal.signal(signal.SIGINT, on_signal)
     deadline = time.time() + args.deadline_s
     rc, why = 0, ""
+    rank0_done_at, stragglers = None, False
     while True:
         codes = [p.poll() for p in procs]
         bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
@@ -475,13 +476,22 @@ def launch_ranks(args, argv, entry=None) -> int:
             break
         if all(c == 0 for c in codes):
             break
+        # rank 0 has left with status 0 -- its record is out (in full, or the one it held when something failed on it) -- and
+        # the others are still there, e.g. inside a collective rank 0 will never join: they get 20 s, not the whole deadline
+        if codes[0] == 0:
+            rank0_done_at = rank0_done_at or time.time()
+            if time.time() - rank0_done_at > 20.0:
+                stragglers = True
+                log(f"[bench launcher] rank 0 exited 0 more than 20 s ago, stopping ranks {[r for r, c in enumerate(codes) if c is None]}")
+                break
         if time.time() > deadline:
             rc, why = 124, f"deadline of {args.deadline_s:.0f} s passed (ranks still running: " \
                            f"{[r for r, c in enumerate(codes) if c is None]})"
             break
         time.sleep(0.1)
-    if rc:
-        log(f"[bench launcher] {why}: stopping the other ranks")
+    if rc or stragglers:
+        if rc:
+            log(f"[bench launcher] {why}: stopping the other ranks")
         stop_all(signal.SIGTERM)
         t_end = time.time() + 10
         while time.time() < t_end and any(p.poll() is None for p in procs):
@@ -681,11 +691,19 @@ def main():
             a2 = argparse.Namespace(**{**vars(args), "scale": scale})
             return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, a2, rank, world, shape, cut)
 
-        result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
-                                       cpu_leg=None if args.no_cpu_baseline else cpu_leg,
-                                       parity_check=None if (args.no_parity or args.check_oracle) else parity_at,
-                                       traffic_of=traffic_from_profile)
-        dist.barrier()
+        try:
+            result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
+                                           cpu_leg=None if args.no_cpu_baseline else cpu_leg,
+                                           parity_check=None if (args.no_parity or args.check_oracle) else parity_at,
+                                           traffic_of=traffic_from_profile)
+            dist.barrier()
+        except Exception as e:  # noqa: BLE001 -- a sub-case that fails (out of memory, a transport error) after the headline case
+            import traceback
+
+            log(f"[bench r{rank}] {type(e).__name__} in the N > 1 leg:\n{traceback.format_exc()}")
+            if guard is not None:  # rank 0: print the record it holds (exit 0); the others: leave, the launcher ends the job
+                guard.bail(f"{type(e).__name__}: {e}"[:300])
+            raise
         rc = 0
         if rank == 0:
             cfg = result["config"]

@@ -151,6 +151,33 @@ def test_rank_guard_prints_the_held_record_on_sigterm(tmp_path):
         assert not _alive(int(f.read_text()))
 
 
+def test_rank0_failing_in_a_sub_case_prints_the_held_record_and_the_job_ends_soon(tmp_path):
+    """an exception on rank 0 after the headline case (bench.py catches it and calls bail from the main thread): the held record
+    goes out marked partial, rank 0 exits 0, and the launcher does not wait the whole deadline for the ranks that sit in a
+    collective rank 0 will never join -- 20 s after rank 0 left they are stopped, the line is relayed, status 0"""
+    body = f"""
+        import ctypes, os, sys, time
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{{r}}"), "w").write(str(os.getpid()))
+        g = bench.install_rank_guard(r, 500.0)
+        if r == 0:
+            g.hold({{"value": 9.0, "n_gpus": 2, "config": {{}}}})
+            try:
+                raise MemoryError("config 5 did not fit")
+            except Exception as e:
+                g.bail(f"{{type(e).__name__}}: {{e}}")
+        ctypes.CDLL(None).sleep(300)  # rank 1: the collective that never completes
+    """
+    r, took = _run_launcher(tmp_path, body, 2, deadline=400.0)
+    assert r.returncode == 0 and took < 60, (r.returncode, took, r.stderr)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 9.0 and "MemoryError" in rec["partial"]["reason"]
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text()))
+
+
 def test_rank_guard_emits_exactly_one_line(tmp_path):
     """final() after hold(): one line, not marked partial; a bail() that races with it prints nothing more"""
     prog = tmp_path / "one.py"
