@@ -805,6 +805,8 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         if hold is not None and rank == 0:
             hold(assemble())
     weak_default = not strong and args.cut_fraction is None and world > 1
+    if os.environ.get("GAIB_BENCH_FAIL_AFTER_HEADLINE") == str(rank):  # test hook: this rank fails in a sub-case (tests/test_gpu_dist.py)
+        raise RuntimeError("GAIB_BENCH_FAIL_AFTER_HEADLINE: injected failure after the headline case")
     if parity_check is not None and not strong and world > 1 and main["parity"] is None:
         # element-wise against the oracle's GLOBAL run, at a global size the oracle finishes in seconds: 4.9 M vertices in all
         import argparse

@@ -200,6 +200,30 @@ def test_bench_plain_two_gpus_default_workload():
     assert c5["nv_per_gpu"] == int(13_882_495 * 0.02)
 
 
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_bench_keeps_the_headline_when_a_rank_fails_in_a_sub_case(failing_rank):
+    """a rank raises after the headline case (injected: GAIB_BENCH_FAIL_AFTER_HEADLINE = its rank) while its peer goes on into
+    the next sub-case's collectives: rank 0 prints the record it holds, marked partial (its own exception, or the SIGTERM the
+    launcher sends when rank 1 exits non-zero), the launcher ends the stragglers, one JSON line, status 0, well inside a minute"""
+    import json
+    import subprocess
+    import time
+
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=dict(_clean_env(), GAIB_BENCH_FAIL_AFTER_HEADLINE=str(failing_rank)))
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and wall < 120, (len(out), wall)
+    res = json.loads(out[0])
+    assert res["value"] > 0 and res["n_gpus"] == 2 and "partial" in res
+    # rank 0's own failure is named; a peer's shows up as the signal from the launcher or as the control plane's broken connection
+    assert ("injected failure" in res["partial"]["reason"]) == (failing_rank == 0) and res["partial"]["reason"]
+    assert res["config"]["clustered_boundary"] is None  # (never started)
+
+
 def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
     """--budget-s smaller than any sub-case: the headline case runs, every further slot says {"skipped": "budget", ...},
     exit 0, one line"""
