@@ -246,7 +246,7 @@ struct gaib_halo {
   int pub_n_chunks_t;
   int64_t pub_chunk_rows_t;
   // IPC: which ALLOCATION of each buffer the peers hold a handle of.  Either entry point may reallocate either buffer
-  // (an exchange reserves the table, a reduce lands its arrivals in the send buffer), so "did MY reserve() reallocate"
+  // (an exchange reserves the table, a reduce may stage in it; chunks come and go with the row length), so "did MY reserve() reallocate"
   // is not the question -- "is the published allocation still the current one" is.
   uint64_t send_serial, table_serial;          // bumped by every (re)allocation
   uint64_t pub_send_serial, pub_table_serial;  // allocation the handle in the segment belongs to (0 = none)
