@@ -541,6 +541,16 @@ class RecordGuard:
                 return
             self.done = True
             held = self.held
+        if self.rank == 0 and held is None:
+            # the headline case may just have ended: between its last collective and hold() rank 0 still assembles the record
+            # (milliseconds) -- a peer that fails exactly then makes the launcher's SIGTERM arrive first.  Give the main thread
+            # a moment to hand the record over before giving up (it never comes if the main thread sits in a collective).
+            for _ in range(50):
+                time.sleep(0.1)
+                with self.lock:
+                    held = self.held
+                if held is not None:
+                    break
         if self.rank == 0 and held is not None:
             held = dict(held)
             held["partial"] = {"reason": reason, "note": "the headline case was measured in full; sub-cases that had not "

@@ -178,6 +178,29 @@ def test_rank0_failing_in_a_sub_case_prints_the_held_record_and_the_job_ends_soo
         assert not _alive(int(f.read_text()))
 
 
+def test_rank_guard_waits_a_moment_for_a_record_that_is_about_to_be_held(tmp_path):
+    """a peer fails in the instant between the headline case's last collective and rank 0's hold(): the launcher's SIGTERM
+    reaches rank 0 first.  bail() gives the main thread up to 5 s to hand the record over (found by the GPU test with an
+    injected failure on rank 1: one run in three ended without a line)"""
+    body = f"""
+        import os, sys, time
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{{r}}"), "w").write(str(os.getpid()))
+        g = bench.install_rank_guard(r, 500.0)
+        if r == 1:
+            sys.exit(124)      # the failing peer: the launcher now stops rank 0
+        time.sleep(1.5)        # rank 0 is still assembling its record when the signal arrives ...
+        g.hold({{"value": 5.0, "n_gpus": 2, "config": {{}}}})
+        time.sleep(300)
+    """
+    r, took = _run_launcher(tmp_path, body, 2, deadline=400.0)
+    assert r.returncode == 0 and took < 60, (r.returncode, took, r.stderr)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 5.0 and "signal" in rec["partial"]["reason"]
+
+
 def test_rank_guard_emits_exactly_one_line(tmp_path):
     """final() after hold(): one line, not marked partial; a bail() that races with it prints nothing more"""
     prog = tmp_path / "one.py"
