@@ -457,10 +457,18 @@ def launch_ranks(args, argv, entry=None) -> int:
                     pass
 
     def on_signal(signum, frame):
+        # the driver (or a user) ends the run from outside: the ranks get SIGTERM, rank 0 prints the record it holds (RecordGuard,
+        # which may wait up to 5 s for a record that is about to be held), and THAT line is relayed before this process leaves
         log(f"[bench launcher] signal {signum}: stopping the ranks")
         stop_all(signal.SIGTERM)
-        time.sleep(2)
+        t_end = time.time() + 9
+        while time.time() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(0.1)
         stop_all(signal.SIGKILL)
+        th.join(timeout=3)
+        out = [l for l in lines if l.startswith("{")]
+        if out and procs[0].poll() == 0:
+            print(out[-1], flush=True)
         os._exit(128 + signum)
 
     signal.signal(signal.SIGTERM, on_signal)

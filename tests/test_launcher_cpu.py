@@ -201,6 +201,44 @@ def test_rank_guard_waits_a_moment_for_a_record_that_is_about_to_be_held(tmp_pat
     assert rec["value"] == 5.0 and "signal" in rec["partial"]["reason"]
 
 
+def test_launcher_relays_the_held_record_when_it_is_signalled_itself(tmp_path):
+    """the driver's timeout ends `python bench.py --gpus N` with SIGTERM: the launcher stops its ranks, rank 0 prints the record
+    it holds, and the launcher puts that line on its own stdout before it leaves (it used to exit with the line still in its pipe)"""
+    import signal
+
+    rank_prog = tmp_path / "rank.py"
+    rank_prog.write_text(textwrap.dedent(f"""
+        import ctypes, os, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{{r}}"), "w").write(str(os.getpid()))
+        g = bench.install_rank_guard(r, 500.0)
+        if r == 0:
+            g.hold({{"value": 11.0, "n_gpus": 2, "config": {{}}}})
+        ctypes.CDLL(None).sleep(300)
+    """))
+    driver = tmp_path / "drive.py"
+    driver.write_text(textwrap.dedent(f"""
+        import argparse, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        sys.exit(bench.launch_ranks(argparse.Namespace(gpus=2, deadline_s=400.0), [{str(tmp_path)!r}], entry={str(rank_prog)!r}))
+    """))
+    p = subprocess.Popen([sys.executable, str(driver)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while time.time() - t0 < 30 and len(list(tmp_path.glob("pid*"))) < 2:
+        time.sleep(0.1)
+    time.sleep(1.0)  # (rank 0 has held its record by now)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err)
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["value"] == 11.0 and "signal" in rec["partial"]["reason"]
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text()))
+
+
 def test_rank_guard_emits_exactly_one_line(tmp_path):
     """final() after hold(): one line, not marked partial; a bail() that races with it prints nothing more"""
     prog = tmp_path / "one.py"
