@@ -901,24 +901,38 @@ def main():
     # same kernel on a graph of the same shape whose numbering carries locality (planted communities of 16 384 consecutive
     # ids, 10 % of a vertex's edges leave its community): what the XCD-affine tile supply and the L2s are worth when the
     # numbering offers something.  Not part of `value`.
-    if args.scale == 1.0 and not args.no_locality and os.environ.get("GAIB_BENCH_LOCALITY", "1") != "0":
-        try:
-            result["roofline"]["planted_locality"] = locality_leg(torch, ctx, capi, synth)
-        except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline record
-            result["roofline"]["planted_locality"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    # The GPU measurement is complete.  What follows -- the locality leg, the CPU baseline, the comparison with the oracle -- only
+    # adds to the record: it is HELD from here on (RecordGuard, as in the N > 1 leg) and printed, marked partial, if a signal, the
+    # deadline or an exception in one of those legs ends the run first.
+    guard1 = install_rank_guard(0, max(5.0, args.deadline_s - (time.time() - T_START)))  # (the deadline counts from the process's start)
+    guard1.hold(result)
     rc = 0
-    if not args.no_cpu_baseline:
-        t1 = time.time()
-        xs = (x_h, gin_h) if want_parity else host_inputs(nv)
-        result["cpu_baseline"], want = cpu_baseline(sg.rowptr, sg.colidx, nv, *xs, want_outputs=want_parity)
-        log(f"[bench] cpu baseline took {time.time()-t1:.1f}s")
-        if want_parity:
-            result["parity"] = parity_record(torch, L, layer, feat_out, grad_out, gin_h, want)
-            log(f"[bench] parity vs the oracle's full-graph run: {result['parity']}")
-            if not result["parity"]["ok"]:
-                log("[bench] PARITY FAILED (> 1e-4)")
-                rc = 3
-    emit(result)
+    try:
+        if args.scale == 1.0 and not args.no_locality and os.environ.get("GAIB_BENCH_LOCALITY", "1") != "0":
+            try:
+                result["roofline"]["planted_locality"] = locality_leg(torch, ctx, capi, synth)
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline record
+                result["roofline"]["planted_locality"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if os.environ.get("GAIB_BENCH_FAIL_AFTER_HEADLINE") == "0":  # test hook (tests/test_gpu_dist.py)
+            raise RuntimeError("GAIB_BENCH_FAIL_AFTER_HEADLINE: injected failure after the GPU measurement")
+        if not args.no_cpu_baseline:
+            t1 = time.time()
+            xs = (x_h, gin_h) if want_parity else host_inputs(nv)
+            result["cpu_baseline"], want = cpu_baseline(sg.rowptr, sg.colidx, nv, *xs, want_outputs=want_parity)
+            log(f"[bench] cpu baseline took {time.time()-t1:.1f}s")
+            if want_parity:
+                result["parity"] = parity_record(torch, L, layer, feat_out, grad_out, gin_h, want)
+                log(f"[bench] parity vs the oracle's full-graph run: {result['parity']}")
+                if not result["parity"]["ok"]:
+                    log("[bench] PARITY FAILED (> 1e-4)")
+                    rc = 3
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        log(f"[bench] {type(e).__name__} after the GPU measurement:\n{traceback.format_exc()}")
+        guard1.bail(f"{type(e).__name__}: {e}"[:300])  # prints the held record (exit 0)
+        raise
+    guard1.final(result)
     if rc:
         sys.exit(rc)
 

@@ -224,6 +224,22 @@ def test_bench_keeps_the_headline_when_a_rank_fails_in_a_sub_case(failing_rank):
     assert res["config"]["clustered_boundary"] is None  # (never started)
 
 
+def test_bench_n1_keeps_its_record_when_a_later_leg_fails():
+    """N = 1: the record is held once the GPU measurement is complete; an exception in what follows (the CPU baseline, the
+    comparison with the oracle -- injected here) prints it marked partial, status 0, one line"""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scale", "0.02", "--steps", "2", "--warmup", "1", "--sustain-s", "0"],
+                       capture_output=True, text=True, timeout=600, env=dict(_clean_env(), GAIB_BENCH_FAIL_AFTER_HEADLINE="0"))
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1
+    res = json.loads(out[0])
+    assert res["value"] > 0 and res["n_gpus"] == 1 and "injected failure" in res["partial"]["reason"]
+    assert res["roofline"]["avg_launch_ms"] > 0 and "cpu_baseline" not in res
+
+
 def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
     """--budget-s smaller than any sub-case: the headline case runs, every further slot says {"skipped": "budget", ...},
     exit 0, one line"""
