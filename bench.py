@@ -376,6 +376,7 @@ class DistOracleCheck:
         return rec
 
 
+_N1_GUARD = None  # the GAT line's RecordGuard once its GPU measurement is complete
 _REAL_STDOUT = None  # the process's original fd 1, once quiet_stdout() has pointed fd 1 at stderr
 
 
@@ -743,7 +744,15 @@ def main():
         return
 
     if args.workload == "gat-reddit":
-        rc = bench_gat_reddit(args, torch, ctx, L, synth)
+        try:
+            rc = bench_gat_reddit(args, torch, ctx, L, synth)
+        except Exception as e:  # noqa: BLE001 -- after the GPU measurement the record is held: print it
+            import traceback
+
+            log(f"[bench] {type(e).__name__} in the GAT line:\n{traceback.format_exc()}")
+            if _N1_GUARD is not None:
+                _N1_GUARD.bail(f"{type(e).__name__}: {e}"[:300])
+            raise
         if rc:
             sys.exit(rc)
         return
@@ -1088,6 +1097,10 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
     }
     if sustained:
         result["sustained_ms_per_step"] = sustained
+    # the GPU measurement is complete: the record is held from here on (as in the GCN line; main() bails on an exception)
+    global _N1_GUARD
+    _N1_GUARD = install_rank_guard(0, max(5.0, args.deadline_s - (time.time() - T_START)))
+    _N1_GUARD.hold(result)
     rc = 0
     if not args.no_cpu_baseline:
         from oracle import binding as orc
@@ -1179,7 +1192,7 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         if not par["ok"]:
             log("[bench] PARITY FAILED (> 1e-4)")
             rc = 3
-    emit(result)
+    _N1_GUARD.final(result)
     return rc
 
 
