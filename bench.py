@@ -275,6 +275,7 @@ class DistOracleCheck:
     LONG_SUM_FLOOR), the weight gradient's floor from the oracle's own distance to fp64 as in parity_record."""
 
     TOL, FLOOR = 1e-4, 1e-5
+    exchanger = None  # set by dist._bench_case: the layer's own halo exchanger (diagnostics)
 
     def __init__(self, torch, dist, synth, L, gdist, ctx, comm, args, rank, world, shape, cut):
         self.torch, self.dist, self.synth, self.L, self.gdist = torch, dist, synth, L, gdist
@@ -344,6 +345,24 @@ class DistOracleCheck:
         torch.cuda.synchronize()
         e_f = _errs(torch, feat_out, fwd_o, self.TOL, self.FLOOR)
         flips = int(((feat_out > 0) != (fwd_o > 0)).sum().item())
+        if os.environ.get("GAIB_BENCH_PARITY_DEBUG") and (e_f["elem"] > self.TOL or e_f["inf"] > self.TOL):
+            d = (feat_out - fwd_o).abs().amax(1) / fwd_o.abs().max().clamp_min(1e-30)
+            bad = torch.nonzero(d > 1e-4).flatten()
+            log(f"[bench r{self.rank}] PARITY DEBUG forward: {bad.numel()} of {nv} rows off by > 1e-4 of max; first {bad[:12].tolist()} "
+                f"last {bad[-6:].tolist()}; worst row {int(d.argmax())} ({float(d.max()):.3e}); rows with halo edges among the bad: "
+                f"{int((part.rowptr_halo[1:] - part.rowptr_halo[:-1])[bad].gt(0).sum())}")
+        if os.environ.get("GAIB_BENCH_PARITY_DEBUG") and self.exchanger is not None:
+            # the halo table itself: one exchange of x through the layer's plan against the rows the peers hold (collective)
+            import numpy as np
+
+            x_all = np.concatenate([self.inputs(q, nv)[0] for q in range(self.world)])
+            got = self.exchanger.exchange(torch.from_numpy(x_h).cuda(), D)
+            want_t = torch.from_numpy(x_all[part.halo_gids.cpu().numpy()]).cuda()
+            badr = torch.nonzero((got != want_t).any(1)).flatten()
+            offs = np.cumsum([0] + list(part.recv_counts))
+            log(f"[bench r{self.rank}] PARITY DEBUG halo table: {badr.numel()} of {part.n_halo} rows differ; first {badr[:16].tolist()} "
+                f"last {badr[-8:].tolist()}; segment offsets {offs.tolist()}; send offsets {np.cumsum([0] + list(part.send_counts)).tolist()}")
+            del x_all, got, want_t
         layer.write(L.GRAD_IN, torch.from_numpy(gin_h).cuda())
         layer.backward(fwd_o, grad_out)  # the oracle's forward output: identical relu masks
         self.gdist.allreduce_layer_grads(self.ctx, layer, [L.W_NEIGH_GRAD], (D, D), comm=self.comm)

@@ -170,6 +170,15 @@ size_t ipc_chunk_bytes() {
   const long long v = e ? atoll(e) : 0;
   return v > 0 ? (size_t)v : (size_t)512 << 20;
 }
+size_t ipc_export_limit();
+// chunk size for `total` bytes: the configured one, larger where GAIB_IPC_MAX_CHUNKS of them would not hold the buffer (config 5 in a
+// random vertex order sends 41 GB per rank) -- up to the export limit
+size_t ipc_chunk_bytes_for(size_t total) {
+  size_t c = ipc_chunk_bytes();
+  const size_t need = (total + GAIB_IPC_MAX_CHUNKS - 1) / GAIB_IPC_MAX_CHUNKS;
+  if (need > c) c = std::min(ipc_export_limit(), (need + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
+  return c;
+}
 size_t ipc_export_limit() {
   const char* e = getenv("GAIB_IPC_EXPORT_LIMIT_BYTES");
   const long long v = e ? atoll(e) : 0;
@@ -349,7 +358,9 @@ hipError_t pool_handle(gaib_comm* c, void* p, hipIpcMemHandle_t* out) {
   return e;
 }
 
-int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t s, gaib_halo* keep = nullptr) {
+// max_cap: never hand out a pooled buffer larger than this (buffers that will be exported: the IPC export limit)
+int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t s, gaib_halo* keep = nullptr,
+            size_t max_cap = ~(size_t)0) {
   if (bytes <= *cap && *p) return 0;
   if (*p) {
     GAIB_HIP(hipStreamSynchronize(s));
@@ -371,7 +382,7 @@ int reserve(float** p, size_t* cap, uint64_t* serial, size_t bytes, hipStream_t 
     gaib_comm* c = keep->c;
     gaib_comm::IpcBuf* best = nullptr;
     for (gaib_comm::IpcBuf& b : *c->ipc_bufs)
-      if (!b.in_use && b.cap >= want && (!best || b.cap < best->cap)) best = &b;
+      if (!b.in_use && b.cap >= want && b.cap <= max_cap && (!best || b.cap < best->cap)) best = &b;
     if (best && best->cap <= 2 * want) {  // (not a buffer far larger than asked for: the next large plan wants it)
       best->in_use = true;
       *p = (float*)best->p;
@@ -789,21 +800,24 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   const size_t row_bytes = sizeof(float) * (size_t)len;
   gaib_halo* keep = h;  // (both transports draw from the communicator's pool; only IPC retires, see reserve)
   // IPC: a send buffer above the chunk size is cut into chunks of whole rows, each its own allocation (GAIB_IPC_MAX_CHUNKS)
-  const bool chunked = c->transport == GAIB_COMM_IPC && row_bytes * (size_t)n_send > ipc_chunk_bytes();
-  const int64_t chunk_rows = chunked ? std::max<int64_t>(1, (int64_t)(ipc_chunk_bytes() / row_bytes)) : n_send;
+  const size_t chunk_bytes = ipc_chunk_bytes_for(row_bytes * (size_t)n_send);
+  const bool chunked = c->transport == GAIB_COMM_IPC && row_bytes * (size_t)n_send > chunk_bytes;
+  const int64_t chunk_rows = chunked ? std::max<int64_t>(1, (int64_t)(chunk_bytes / row_bytes)) : n_send;
   const int n_chunks = chunked ? (int)cdiv64(n_send, chunk_rows) : 1;
   if (n_chunks > GAIB_IPC_MAX_CHUNKS) {
     gaib_set_error("gaib_halo_exchange_begin(rank %d): %lld rows of %zu B need %d chunks of %zu B, at most %d (GAIB_IPC_CHUNK_BYTES)",
-                   c->rank, (long long)n_send, row_bytes, n_chunks, ipc_chunk_bytes(), GAIB_IPC_MAX_CHUNKS);
+                   c->rank, (long long)n_send, row_bytes, n_chunks, chunk_bytes, GAIB_IPC_MAX_CHUNKS);
     return fail(c, GAIB_ERR_UNSUPPORTED);
   }
   auto chunk_ptr = [&](int j) -> float* { return j == 0 ? h->sendbuf : h->send_x[j - 1]; };
   auto rows_in_chunk = [&](int j) -> int64_t { return std::min<int64_t>(chunk_rows, n_send - (int64_t)j * chunk_rows); };
-  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)(chunked ? chunk_rows : n_send), ctx->stream, keep);
+  const size_t exp_cap = c->transport == GAIB_COMM_IPC ? ipc_export_limit() : ~(size_t)0;  // (IPC exports every send allocation)
+  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)(chunked ? chunk_rows : n_send), ctx->stream, keep,
+                   exp_cap);
   if (ra < 0) return fail(c, ra);
   for (int j = 1; j < n_chunks; ++j) {
     int rx = reserve(&h->send_x[j - 1], &h->send_x_cap[j - 1], &h->send_x_serial[j - 1], row_bytes * (size_t)rows_in_chunk(j),
-                     ctx->stream, keep);
+                     ctx->stream, keep, exp_cap);
     if (rx < 0) return fail(c, rx);
   }
   int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
@@ -1027,13 +1041,14 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
     // while it is below the chunk size, else chunks of whole rows, each its own allocation --, publish them, and let the
     // owners pull their segments
     // (also when the rows are few but the table an earlier, longer exchange left behind is too large to export)
-    const bool many = row_bytes * (size_t)n_recv > ipc_chunk_bytes();
+    const size_t chunk_bytes = ipc_chunk_bytes_for(row_bytes * (size_t)n_recv);
+    const bool many = row_bytes * (size_t)n_recv > chunk_bytes;
     const bool chunked = many || (h->table && h->table_cap > ipc_export_limit());
-    const int64_t chunk_rows = many ? std::max<int64_t>(1, (int64_t)(ipc_chunk_bytes() / row_bytes)) : n_recv;
+    const int64_t chunk_rows = many ? std::max<int64_t>(1, (int64_t)(chunk_bytes / row_bytes)) : n_recv;
     const int n_chunks = many ? (int)cdiv64(n_recv, chunk_rows) : 1;
     if (n_chunks > GAIB_IPC_MAX_CHUNKS) {
       gaib_set_error("gaib_halo_reduce(rank %d): %lld halo rows of %zu B need %d chunks of %zu B, at most %d (GAIB_IPC_CHUNK_BYTES)",
-                     c->rank, (long long)n_recv, row_bytes, n_chunks, ipc_chunk_bytes(), GAIB_IPC_MAX_CHUNKS);
+                     c->rank, (long long)n_recv, row_bytes, n_chunks, chunk_bytes, GAIB_IPC_MAX_CHUNKS);
       return fail(c, GAIB_ERR_UNSUPPORTED);
     }
     hipError_t e = hipSuccess;
@@ -1049,7 +1064,8 @@ extern "C" int gaib_halo_reduce(gaib_halo* h, int len, const float* d_halo_rows,
     } else {
       for (int j = 0; j < n_chunks && e == hipSuccess; ++j) {
         const int64_t rows_j = std::max<int64_t>(0, std::min<int64_t>(chunk_rows, n_recv - (int64_t)j * chunk_rows));
-        int rx = reserve(&h->stage_x[j], &h->stage_x_cap[j], &h->stage_x_serial[j], row_bytes * (size_t)rows_j, ctx->stream, keep);
+        int rx = reserve(&h->stage_x[j], &h->stage_x_cap[j], &h->stage_x_serial[j], row_bytes * (size_t)rows_j, ctx->stream, keep,
+                         ipc_export_limit());
         if (rx < 0) return fail(c, rx);
         if (rows_j)
           e = hipMemcpyAsync(h->stage_x[j], d_halo_rows + (int64_t)j * chunk_rows * len, row_bytes * (size_t)rows_j,

@@ -546,6 +546,8 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None):
     part_ms = {k: ctx.prof_get(k)[1] / args.steps for k in ("part_fused", "part_fused_acc", "part_fused_2t", "part_light",
                                                             "part_light_acc", "part_light_2t")}
     ctx.prof_reset()
+    if check is not None and hasattr(check, "exchanger"):
+        check.exchanger = dg.ex  # (diagnostics of a failing comparison: the plan the layer itself uses)
     parity = check(part, layer, feat_out, grad_out) if check is not None else None
     # diagnostics outside the timed region (collective: every rank runs them): one halo exchange of a [nv x D]
     # matrix on its own (pack + all-to-all + wait) and the pack alone -- what the owned-edge SpMM has to hide

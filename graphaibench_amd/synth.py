@@ -39,6 +39,17 @@ class SynthGraph:
         return int(self.colidx.numel())
 
 
+def _cumsum_f64(w: torch.Tensor) -> torch.Tensor:
+    """running sum of float64 weights, THE SAME BITS on every call: a device scan (decoupled look-back) associates the partial sums
+    by the timing of its tiles, so two generations of the same range -- a rank's own and the one rank 0 makes for the oracle's
+    global run, or the two owners of a cross block -- could differ in the last place of the cdf and with it in a handful of
+    sampled edges (found by the N > 1 parity leg at 4 busy ranks on one device: 1 to 41 rows per rank off by up to 3 % of the
+    largest value, in some runs only).  Sequential on the host: 14 M entries take 40 ms."""
+    import numpy as np
+
+    return torch.from_numpy(np.cumsum(w.detach().cpu().numpy().astype(np.float64, copy=False))).to(w.device)
+
+
 def _weights(nv: int, mean_deg: float, max_deg: float, device) -> torch.Tensor:
     """w_r = (r + r0)^-alpha with (alpha fixed, r0 solved) so that max/mean expected degree matches."""
     alpha = 0.72
@@ -65,7 +76,7 @@ def chung_lu(name: str, nv: int, nnz: int, max_deg: int, seed: int = 42, device=
     m = int(nnz // 2 * oversample)
     w = _weights(nv, nnz / nv, max_deg, device)
     perm = torch.randperm(nv, generator=gen, device=device)
-    cdf = torch.cumsum(w, 0)
+    cdf = _cumsum_f64(w)
     cdf = cdf / cdf[-1]
     chunks = []
     step = 1 << 24
@@ -118,7 +129,7 @@ def planted_locality(name: str = "ogbn-products", block: int = 16384, cut: float
     gen.manual_seed(seed)
     w = _weights(nv, nnz / nv, max_deg, device)
     w = w[torch.randperm(nv, generator=gen, device=device)]
-    cdf = torch.cumsum(w, 0)
+    cdf = _cumsum_f64(w)
     cdf = cdf / cdf[-1]
     m = nnz // 2
     keys = []
@@ -168,7 +179,7 @@ def _part_sampler(nv_p: int, nnz_p: int, max_deg: int, seed: int, p: int, device
     gen.manual_seed(seed * 1009 + p)
     w = _weights(nv_p, nnz_p / nv_p, max_deg, device)
     perm = torch.randperm(nv_p, generator=gen, device=device)
-    cdf = torch.cumsum(w, 0)
+    cdf = _cumsum_f64(w)
     return cdf / cdf[-1], perm
 
 
@@ -188,7 +199,7 @@ def _band_sampler(cdf, perm, lo: int, hi: int):
     w[1:] = cdf[1:] - cdf[:-1]
     by_id = torch.empty_like(w)
     by_id[perm] = w  # perm[r] = the id that carries the r-th largest weight
-    c = torch.cumsum(by_id[lo:hi], 0)
+    c = _cumsum_f64(by_id[lo:hi])
     return c / c[-1], lo
 
 

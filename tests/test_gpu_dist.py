@@ -200,6 +200,30 @@ def test_bench_plain_two_gpus_default_workload():
     assert c5["nv_per_gpu"] == int(13_882_495 * 0.02)
 
 
+@pytest.mark.parametrize("boundary", ["uniform", "clustered"])
+def test_block_generator_gives_the_same_edges_on_every_call_and_a_symmetric_global_graph(boundary):
+    """synth.block_rows: a range generated twice (a rank's own copy, and the one rank 0 makes for the oracle's global run) must
+    be the same edges bit for bit, and the cross block (p, q) must be the same seen from p and from q.  Its cdf used to come from
+    a device scan whose floating-point association depends on tile timing: with four busy ranks on one device a handful of
+    sampled edges differed between two generations in some runs (found by the N > 1 parity leg, round 4)"""
+    from graphaibench_amd import synth
+
+    world, scale = 4, 0.25
+    gens = [[synth.block_rows("ogbn-products", q, world, seed=42, cut_fraction=0.1, device="cuda", scale=scale, selfloops=True,
+                              boundary=boundary) for q in range(world)] for _ in range(2)]
+    for a, b in zip(*gens):
+        assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.colidx_global, b.colidx_global)
+    nv = gens[0][0].n_local
+    n = nv * world
+    keys = []
+    for q, r in enumerate(gens[0]):
+        rows = torch.repeat_interleave(torch.arange(nv, device="cuda"), r.rowptr[1:] - r.rowptr[:-1]) + q * nv
+        keys.append(rows * n + r.colidx_global)
+    key = torch.cat(keys)
+    key_t = (key % n) * n + key // n
+    assert torch.equal(torch.sort(key).values, torch.sort(key_t).values)  # the global graph is symmetric
+
+
 @pytest.mark.parametrize("failing_rank", [0, 1])
 def test_bench_keeps_the_headline_when_a_rank_fails_in_a_sub_case(failing_rank):
     """a rank raises after the headline case (injected: GAIB_BENCH_FAIL_AFTER_HEADLINE = its rank) while its peer goes on into
