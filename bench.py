@@ -277,9 +277,10 @@ class DistOracleCheck:
     TOL, FLOOR = 1e-4, 1e-5
     exchanger = None  # set by dist._bench_case: the layer's own halo exchanger (diagnostics)
 
-    def __init__(self, torch, dist, synth, L, gdist, ctx, comm, args, rank, world, shape, cut):
+    def __init__(self, torch, dist, synth, L, gdist, ctx, comm, args, rank, world, shape, cut, boundary="uniform"):
         self.torch, self.dist, self.synth, self.L, self.gdist = torch, dist, synth, L, gdist
         self.ctx, self.comm, self.args, self.rank, self.world, self.shape, self.cut = ctx, comm, args, rank, world, shape, cut
+        self.boundary = boundary  # the generator of the case under test (synth.block_rows)
 
     @staticmethod
     def inputs(rank: int, nv: int):
@@ -296,7 +297,7 @@ class DistOracleCheck:
         rps, cis, off = [np.zeros(1, np.int64)], [], 0
         for q in range(self.world):
             rows = synth.block_rows(self.shape, q, self.world, seed=42, cut_fraction=self.cut, device="cuda",
-                                    scale=self.args.scale, selfloops=True)
+                                    scale=self.args.scale, selfloops=True, boundary=self.boundary, band=0.2)
             assert rows.n_local == nv
             rps.append(rows.rowptr[1:].cpu().numpy() + off)
             cis.append(rows.colidx_global.cpu().numpy().astype(np.uint32))
@@ -725,9 +726,9 @@ def main():
             torch.cuda.empty_cache()
             return rec
 
-        def parity_at(shape, cut, comm, scale):  # the budgeted parity sub-case of a default N > 1 run, at a bounded global size
+        def parity_at(shape, cut, comm, scale, boundary="uniform"):  # the budgeted parity legs of a default N > 1 run
             a2 = argparse.Namespace(**{**vars(args), "scale": scale})
-            return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, a2, rank, world, shape, cut)
+            return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, a2, rank, world, shape, cut, boundary=boundary)
 
         try:
             result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,

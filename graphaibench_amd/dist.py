@@ -822,10 +822,26 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                             check=parity_check(shape, cut, comm, scale_p))
             if rank == 0:
                 parity_scaled = {**(r["parity"] or {"error": "no record", "ok": None}), "scale": scale_p,
+                                 "partition_mode_rank0": r["partition_mode"]["mode"],
                                  "of": f"the partitioned layer of this run ({world} ranks, {transport}) on the same generator at scale "
                                        f"{scale_p:.3f} ({r['nv']} vertices per rank), not part of `value`"}
             del rows
             torch.cuda.empty_cache()
+            # ... and on the clustered-boundary generator, where the rule takes the row classes (one pass over [owned | halo])
+            if weak_default and budget.agree(need):
+                rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=scale_p, selfloops=True,
+                                        boundary="clustered", band=0.2)
+                r = _bench_case(ctx, comm, a2, rank, world, D, log, rows, f"parity leg (clustered boundary), scale {scale_p:.3f}",
+                                check=parity_check(shape, cut, comm, scale_p, "clustered"))
+                if rank == 0:
+                    pc = {**(r["parity"] or {"error": "no record", "ok": None}), "partition_mode_rank0": r["partition_mode"]["mode"]}
+                    parity_scaled["clustered_boundary"] = pc
+                    if pc.get("ok") is False:
+                        parity_scaled["ok"] = False
+                del rows
+                torch.cuda.empty_cache()
+            elif weak_default and rank == 0:
+                parity_scaled["clustered_boundary"] = budget.skipped(need)
         elif rank == 0:
             parity_scaled = budget.skipped(need)
         if hold is not None and rank == 0:

@@ -190,6 +190,8 @@ def test_bench_plain_two_gpus_default_workload():
     par = res["parity"]
     assert par["ok"] is True and par["forward"]["elem"] <= 1e-4 and par["grad_out"]["elem"] <= 1e-4 and par["W_grad"]["inf"] <= 1e-4
     assert par["scale"] <= 0.02 and "GLOBAL graph" in par["against"] and "2 ranks" in par["of"]
+    pc = par["clustered_boundary"]  # ... and on the clustered generator, through the row classes
+    assert pc["ok"] is True and pc["forward"]["elem"] <= 1e-4 and pc["partition_mode_rank0"] in ("classes", "onepass")
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["transport"].startswith("gaib_comm/")
     if torch.cuda.device_count() < 2:
         assert res["config"]["transport"].startswith("gaib_comm/ipc") and res["config"]["rccl_ranks"] == 0
