@@ -621,7 +621,16 @@ def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None):
                partition_mode=dict(mode=L.LGraph.PART_NAMES[mode_used], boundary_rows=n_bnd, boundary_row_share=n_bnd / max(nv, 1),
                                    boundary_edges=bnd_edges, link_gbs_assumed=float(os.environ.get("GAIB_LINK_GBS", "100"))),
                value=2 * float(e[0]) * args.steps / float(t[0]), ms_per_step=float(t[0]) / args.steps * 1e3)
+    # the case's objects go now, in an order: the layer, the graph (which points at the plan), then the plan -- collectively (every
+    # rank is here): its send buffer and halo table return to the communicator's pool for the next case, and a default run never
+    # comes near the communicator's limit of plans alive at once
+    plan = getattr(dg.ex, "halo", None)
+    layer.close()
+    dg.lgraph.close()
     del layer, feat_out, grad_out, dg
+    torch.cuda.synchronize()
+    if plan is not None:
+        plan.close()
     torch.cuda.empty_cache()
     return res
 
