@@ -20,7 +20,11 @@ inputs resident in HBM when the timed region starts.
     The N > 1 record cannot be lost: the headline case runs first and rank 0 HOLDS its record (RecordGuard); every further
     sub-case -- the N = 1 CPU baseline, the clustered-boundary generator, the random vertex order, config 5 at N = 8 -- starts
     only if all ranks agree that it fits --budget-s (420 s; else its slot says {"skipped": "budget", ...}); on --deadline-s
-    (560 s), SIGTERM or SIGINT rank 0 prints what it holds, marked "partial", and exits 0.
+    (560 s), SIGTERM or SIGINT -- or an exception on any rank after the headline case -- rank 0 prints what it holds, marked
+    "partial", and exits 0.  A default N > 1 record also carries `parity`: two budgeted legs of bounded global size (uniform and
+    clustered-boundary generator), every rank's rows against the oracle's run on the GLOBAL graph over the run's own transport;
+    `cpu_baseline` (the N = 1 workload's, named as such); `roofline.traffic` where a PMC pass of the dominant kernel on that
+    shard exists.  The N = 1 and GAT records are held the same way once their GPU measurement is complete.
     --workload gcn-papers: BASELINE config 5's layer (GCN 128 -> 128 on the ogbn-papers100M-shaped graph in vertex ranges
     of 1/8 of it: at N = 8 the whole graph); --check-oracle compares every rank's outputs with the oracle's GLOBAL run.
 
