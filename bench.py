@@ -281,10 +281,14 @@ class DistOracleCheck:
     TOL, FLOOR = 1e-4, 1e-5
     exchanger = None  # set by dist._bench_case: the layer's own halo exchanger (diagnostics)
 
-    def __init__(self, torch, dist, synth, L, gdist, ctx, comm, args, rank, world, shape, cut, boundary="uniform"):
+    def __init__(self, torch, dist, synth, L, gdist, ctx, comm, args, rank, world, shape, cut, boundary="uniform", bounds=None,
+                 graph_fn=None):
         self.torch, self.dist, self.synth, self.L, self.gdist = torch, dist, synth, L, gdist
         self.ctx, self.comm, self.args, self.rank, self.world, self.shape, self.cut = ctx, comm, args, rank, world, shape, cut
         self.boundary = boundary  # the generator of the case under test (synth.block_rows)
+        # the strong case: ONE given global graph (graph_fn() -> the oracle's graph, self loops in; rank 0 only) cut at `bounds`
+        # (gdist.partition_bounds: the last range may be shorter); its oracle run is also the N = 1 workload's CPU baseline
+        self.bounds, self.graph_fn = bounds, graph_fn
 
     @staticmethod
     def inputs(rank: int, nv: int):
@@ -293,33 +297,55 @@ class DistOracleCheck:
         rng = np.random.default_rng(4300 + rank)
         return rng.standard_normal((nv, D), dtype=np.float32), rng.standard_normal((nv, D), dtype=np.float32)
 
+    def _sizes(self, nv):
+        """rows per rank: the cut of the given graph, or `world` equal ranges of the block generator"""
+        if self.bounds is not None:
+            return [self.bounds[q + 1] - self.bounds[q] for q in range(self.world)]
+        return [nv] * self.world
+
     def _oracle_global(self, nv):
         import numpy as np
         from oracle import binding as orc
 
         torch, synth = self.torch, self.synth
-        rps, cis, off = [np.zeros(1, np.int64)], [], 0
-        for q in range(self.world):
-            rows = synth.block_rows(self.shape, q, self.world, seed=42, cut_fraction=self.cut, device="cuda",
-                                    scale=self.args.scale, selfloops=True, boundary=self.boundary, band=0.2)
-            assert rows.n_local == nv
-            rps.append(rows.rowptr[1:].cpu().numpy() + off)
-            cis.append(rows.colidx_global.cpu().numpy().astype(np.uint32))
-            off += int(rows.rowptr[-1])
-            del rows
-        torch.cuda.empty_cache()
-        g = orc.Graph(np.concatenate(rps), np.concatenate(cis))  # self loops are in (block_rows(selfloops=True), net.cpp:96)
-        xs = [self.inputs(q, nv) for q in range(self.world)]
+        sizes = self._sizes(nv)
+        cores = usable_cores()
+        orc.set_threads(cores)
+        if self.graph_fn is not None:
+            g = self.graph_fn()
+            assert g.nv == sum(sizes), (g.nv, sizes)
+        else:
+            rps, cis, off = [np.zeros(1, np.int64)], [], 0
+            for q in range(self.world):
+                rows = synth.block_rows(self.shape, q, self.world, seed=42, cut_fraction=self.cut, device="cuda",
+                                        scale=self.args.scale, selfloops=True, boundary=self.boundary, band=0.2)
+                assert rows.n_local == nv
+                rps.append(rows.rowptr[1:].cpu().numpy() + off)
+                cis.append(rows.colidx_global.cpu().numpy().astype(np.uint32))
+                off += int(rows.rowptr[-1])
+                del rows
+            torch.cuda.empty_cache()
+            g = orc.Graph(np.concatenate(rps), np.concatenate(cis))  # self loops are in (block_rows(selfloops=True), net.cpp:96)
+        xs = [self.inputs(q, sizes[q]) for q in range(self.world)]
         x, gin = np.concatenate([a for a, _ in xs]), np.concatenate([b for _, b in xs])
         del xs
-        orc.set_threads(usable_cores())
+        if self.graph_fn is not None:  # its time is reported as a CPU baseline: thread spin-up out of the way first (BASELINE.md)
+            R = max(min(g.nv // 64, 50000), 1)
+            gs = orc.Graph.__new__(orc.Graph)
+            gs.rowptr, gs.colidx, gs.nv, gs.ne, gs.vd = g.rowptr[:R + 1], g.colidx, R, int(g.rowptr[R]), g.vertex_data()
+            s_, p_ = gs._struct(), orc._p
+            import ctypes as C
+
+            t1, t2, o_ = np.zeros((R, D), np.float32), np.zeros((R, D), np.float32), np.empty((R, D), np.float32)
+            orc.lib().orc_gcn_layer_forward(C.byref(s_), C.c_int(D), C.c_int(D), C.c_int(1), p_(x), p_(orc.init_glorot(D, D, 1)),
+                                            p_(t1), p_(t2), p_(o_))
         lay = orc.GCNLayer(1, g, D, D, True)
         t0 = time.perf_counter()
         fwd = lay.forward(x)
         go = lay.backward(gin)  # gin is masked in place (Q9)
         t = time.perf_counter() - t0
         return dict(forward=fwd, grad_out=go, W_grad=lay.W_grad, agg_x=lay.in_temp1, masked_grad=gin, seconds=t,
-                    edges=g.ne, nv=g.nv)
+                    edges=g.ne, nv=g.nv, cores=cores)
 
     def __call__(self, part, layer, feat_out, grad_out):
         torch, dist, L = self.torch, self.dist, self.L
@@ -335,14 +361,25 @@ class DistOracleCheck:
         if err[0]:
             return {"error": err[0], "ok": None} if self.rank == 0 else None
         # rank 0 hands every rank its rows of the oracle's outputs (control plane: gloo / the launcher's group)
-        def scatter(key):
-            mine = torch.empty(nv, D)
-            parts = [torch.from_numpy(want[key][q * nv:(q + 1) * nv]) for q in range(self.world)] if self.rank == 0 else None
+        sizes = self._sizes(nv)
+        offs = [sum(sizes[:q]) for q in range(self.world + 1)]
+        nmax = max(sizes)
+
+        def scatter(key):  # (scatter wants equal shapes: a shorter last range is padded)
+            mine = torch.empty(nmax, D)
+            parts = None
+            if self.rank == 0:
+                parts = []
+                for q in range(self.world):
+                    t_ = torch.from_numpy(want[key][offs[q]:offs[q + 1]])
+                    if sizes[q] < nmax:
+                        t_ = torch.cat([t_, torch.zeros(nmax - sizes[q], D)])
+                    parts.append(t_.contiguous())
             if dist.get_backend() == "nccl":
                 mine = mine.cuda()
                 parts = [p_.cuda() for p_ in parts] if parts else None
             dist.scatter(mine, parts, src=0)
-            return mine.cuda()
+            return mine[:nv].cuda().contiguous()
 
         fwd_o, go_o = scatter("forward"), scatter("grad_out")
         layer.write(L.FEAT_IN, torch.from_numpy(x_h).cuda())
@@ -395,12 +432,21 @@ class DistOracleCheck:
                    "W_grad": {**e_w, "elem_floor": w_floor}, "W_grad_vs_fp64_inf": {"gpu": gpu64, "oracle": orc64}}
             rec["ok"] = bool(max(float(v) for v in t[:4]) <= self.TOL and e_w["elem"] <= self.TOL and e_w["inf"] <= self.TOL
                              and gpu64 <= 2e-5)
+            if self.graph_fn is not None:
+                # the oracle's run on the N = 1 bench graph, whole, on the run's inputs: the N = 1 workload's CPU baseline
+                # (gdist.bench_gcn_layer moves it to the record's cpu_baseline)
+                rec["cpu_baseline"] = dict(
+                    value=2 * want["edges"] / want["seconds"], unit="edges/s", cores=want["cores"], cores_available=os.cpu_count(),
+                    kind="port",
+                    sample=f"the whole N = 1 bench graph ({want['nv']} vertices, {want['edges']} edges incl. self loops), 1 GCN layer "
+                           f"fwd+bwd, {want['seconds']:.2f} s on rank 0's host cores while the other ranks wait, gcc -O3 -fopenmp no "
+                           f"-march=native (reference Makefile flags); the same run the strong case's parity is checked against",
+                    of="the N = 1 workload (ogbn-products shape, seed 42): the graph this run partitions")
             log(f"[bench] parity vs the oracle's GLOBAL run (cut {self.cut:.3f}): {rec}")
         dist.barrier()
         return rec
 
 
-_N1_GUARD = None  # the GAT line's RecordGuard once its GPU measurement is complete
 _REAL_STDOUT = None  # the process's original fd 1, once quiet_stdout() has pointed fd 1 at stderr
 
 
@@ -538,9 +584,10 @@ def launch_ranks(args, argv, entry=None) -> int:
     if rc == 0 and not out:
         log("[bench launcher] rank 0 printed no JSON line")
         rc = 1
-    # a record rank 0 DID emit is relayed whatever ended the run (exit 3 / 4: its own verdict on the record; exit 0 after
+    # a record rank 0 DID emit is relayed whatever ended the run (exit 3 / 4: its own verdict on the record; 5: a leg after the
+    # headline case crashed, the held record is out; exit 0 after
     # the deadline or a signal: the record it held, marked partial -- RecordGuard)
-    if out and (rc == 0 or procs[0].poll() in (0, 3, 4)):
+    if out and (rc == 0 or procs[0].poll() in (0, 3, 4, 5)):
         print(out[-1], flush=True)
         if rc == 124 and procs[0].poll() == 0:  # the deadline cut the sub-cases short, the headline record is out
             rc = 0
@@ -556,6 +603,7 @@ class RecordGuard:
 
     def __init__(self, rank: int):
         self.rank, self.lock, self.held, self.done = rank, threading.Lock(), None, False
+        self.want_parity = False  # the run was asked for a comparison with the oracle: a record cut short must SAY it has none
 
     def hold(self, record: dict) -> None:
         with self.lock:
@@ -567,8 +615,12 @@ class RecordGuard:
                 self.done = True
                 emit(record)
 
-    def bail(self, reason: str) -> None:
-        """from a watcher thread: print what is held (rank 0) and leave"""
+    def bail(self, reason: str, status: int = 0) -> None:
+        """from a watcher thread (deadline, signal) or from an exception handler (a leg after the measurement crashed): print
+        what is held (rank 0) and leave with `status`.  A held record that was to carry `parity` and does not gets
+        parity = {"ok": null, "reason": ...}, next to `partial`: UNCHECKED, never silently the same as checked (the
+        exit status stays 0 so that whoever collects the line keeps the measured headline -- the marker is what says the run
+        did not end the way a passing run does)."""
         with self.lock:
             if self.done:  # the record is out already: let the process end by itself
                 return
@@ -588,9 +640,11 @@ class RecordGuard:
             held = dict(held)
             held["partial"] = {"reason": reason, "note": "the headline case was measured in full; sub-cases that had not "
                                                           "finished are null or say why"}
-            log(f"[bench r0] {reason}: printing the record held so far")
+            if self.want_parity and not isinstance(held.get("parity"), dict):
+                held["parity"] = {"ok": None, "reason": f"the comparison with the oracle did not complete: {reason}"}
+            log(f"[bench r0] {reason}: printing the record held so far (exit {status})")
             emit(held)
-            os._exit(0)
+            os._exit(status)
         log(f"[bench r{self.rank}] {reason}: exiting 124")
         os._exit(124)
 
@@ -603,7 +657,11 @@ def install_rank_guard(rank: int, deadline_s: float) -> RecordGuard:
 
     guard = RecordGuard(rank)
     sigs = {signal.SIGTERM, signal.SIGINT}
-    signal.pthread_sigmask(signal.SIG_BLOCK, sigs)  # (threads started from here on inherit the mask)
+    # main() has blocked both already, as its FIRST act in a rank / N = 1 process -- before `import torch` and any HIP call, so
+    # that every native thread created later (HSA's event thread, the OpenMP pool) inherits the mask; a thread that predates
+    # the mask would take a process-directed SIGTERM at SIG_DFL and the record would die with it.  Again here for
+    # callers that come without main() (the tests' stand-in rank programs).
+    signal.pthread_sigmask(signal.SIG_BLOCK, sigs)
 
     def wait_signal():
         s = signal.sigwait(sigs)
@@ -648,22 +706,35 @@ def main():
                          "gradient element-wise with the oracle's run on the GLOBAL graph (sizes the host finishes in "
                          "seconds: use --scale); exit code 3 above 1e-4")
     ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("GAIB_BENCH_DEADLINE_S", "560")),
-                    help="wall-clock limit of an N>1 run (under the 600 s the driver grants a bench run): the launcher stops "
-                         "all ranks, a rank ends itself; rank 0 prints the record it holds first")
+                    help="wall-clock limit of the run, any N (under the 600 s the driver grants a bench run), counted from the "
+                         "process's start: N>1 -- the launcher stops all ranks, a rank ends itself; N=1 (GCN and GAT lines) -- the "
+                         "legs after the GPU measurement (CPU baseline, parity) are cut.  Rank 0 prints the record it holds first, "
+                         "marked `partial`, with parity = {ok: null, reason} if the comparison had not completed; exit 0 (the same "
+                         "when a leg after the measurement raises)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("GAIB_BENCH_BUDGET_S", "420")),
                     help="N>1: wall-clock budget of the whole run, counted from the rank's start.  The headline case always runs; "
                          "every further sub-case (CPU baseline, random vertex order, config 5) starts only if all ranks agree that "
                          "its estimated time still fits, else the record says {\"skipped\": \"budget\", ...}")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N>1: weak = one products-shaped vertex range per GPU; strong = the single-GPU bench graph "
-                         "partitioned N ways")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N>1, which case is `value`: strong (default) = the single-GPU bench graph partitioned N ways (north_star's "
+                         "\"edges/sec at 1/2/4/8\" on ogbn-products: total work fixed); weak = one products-shaped vertex range per "
+                         "GPU at --cut-fraction.  A default run measures BOTH: the other one is config.weak_products_range / "
+                         "config.strong_products.  gcn-papers (config 5) is weak by construction")
     args = ap.parse_args()
     if args.workload == "gat-reddit" and args.gpus > 1:
         ap.error("--workload gat-reddit is a one-GPU workload (config 4); N > 1 runs gcn-products or gcn-papers")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))  # no torch, no GPU API in this process
 
+    # A rank / N = 1 process from here on.  FIRST: SIGTERM / SIGINT are blocked and the watcher threads started (sigwait + the
+    # deadline timer), before torch is imported and before any HIP call -- every thread created after this line inherits the
+    # mask, so a process-directed signal can only be taken by the sigwait thread, which prints the held record.
+    import signal
+
+    signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGINT})
     quiet_stdout()
+    guard = install_rank_guard(int(os.environ.get("RANK", "0")), max(5.0, args.deadline_s - (time.time() - T_START)))
+    guard.want_parity = not (args.no_parity or args.no_cpu_baseline) or args.check_oracle
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -676,9 +747,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     ndev = torch.cuda.device_count()
     device = local_rank % ndev
-    guard = None
     if world > 1:
-        guard = install_rank_guard(rank, args.deadline_s)
         if world > ndev and "GAIB_DIST_BACKEND" not in os.environ:
             # ranks share devices (a one-GPU box): RCCL refuses that by design, the peer-to-peer pull transport does not
             os.environ["GAIB_DIST_BACKEND"] = "ipc"
@@ -716,7 +785,7 @@ def main():
                     if os.environ.get("GAIB_LAUNCH_NONCE") else "ranks given from outside (torch.distributed.run)")
 
         def hold(record):  # (rank 0) the headline case is measured: from here on the record cannot be lost
-            if guard is not None and rank == 0:
+            if rank == 0:
                 record["config"]["launcher"] = launcher
                 guard.hold(record)
 
@@ -730,6 +799,20 @@ def main():
             torch.cuda.empty_cache()
             return rec
 
+        def strong_check(comm, bounds):  # the strong case against the oracle's run on the bench graph (the N = 1 bench's own run)
+            def graph_fn():
+                import numpy as np
+                from oracle import binding as orc
+
+                sg = synth.make("ogbn-products", seed=42, device="cuda", scale=args.scale)
+                rp, ci = sg.rowptr.cpu().numpy(), sg.colidx.cpu().numpy().view(np.uint32)
+                del sg
+                torch.cuda.empty_cache()
+                return orc.Graph(rp, ci).add_selfloop()  # net.cpp:96
+
+            return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, args, rank, world, "ogbn-products", (world - 1) / world,
+                                   bounds=bounds, graph_fn=graph_fn)
+
         def parity_at(shape, cut, comm, scale, boundary="uniform"):  # the budgeted parity legs of a default N > 1 run
             a2 = argparse.Namespace(**{**vars(args), "scale": scale})
             return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, a2, rank, world, shape, cut, boundary=boundary)
@@ -738,14 +821,16 @@ def main():
             result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
                                            cpu_leg=None if args.no_cpu_baseline else cpu_leg,
                                            parity_check=None if (args.no_parity or args.check_oracle) else parity_at,
-                                           traffic_of=traffic_from_profile)
+                                           traffic_of=traffic_from_profile,
+                                           strong_check=None if args.no_parity else strong_check)
             dist.barrier()
         except Exception as e:  # noqa: BLE001 -- a sub-case that fails (out of memory, a transport error) after the headline case
             import traceback
 
             log(f"[bench r{rank}] {type(e).__name__} in the N > 1 leg:\n{traceback.format_exc()}")
-            if guard is not None:  # rank 0: print the record it holds (exit 0); the others: leave, the launcher ends the job
-                guard.bail(f"{type(e).__name__}: {e}"[:300])
+            # rank 0: print the record it holds (marked partial; parity = {ok: null, reason} if the comparison had not completed);
+            # the others: leave, the launcher ends the job
+            guard.bail(f"{type(e).__name__}: {e}"[:300])
             raise
         rc = 0
         if rank == 0:
@@ -758,10 +843,7 @@ def main():
             if result.get("parity") is not None and result["parity"].get("ok") is False:
                 log("[bench] PARITY FAILED (> 1e-4)")
                 rc = 3
-            if guard is not None:
-                guard.final(result)
-            else:
-                emit(result)
+            guard.final(result)
         dist.destroy_process_group()
         if rc:
             sys.exit(rc)
@@ -769,13 +851,13 @@ def main():
 
     if args.workload == "gat-reddit":
         try:
-            rc = bench_gat_reddit(args, torch, ctx, L, synth)
+            rc = bench_gat_reddit(args, torch, ctx, L, synth, guard)
         except Exception as e:  # noqa: BLE001 -- after the GPU measurement the record is held: print it
             import traceback
 
             log(f"[bench] {type(e).__name__} in the GAT line:\n{traceback.format_exc()}")
-            if _N1_GUARD is not None:
-                _N1_GUARD.bail(f"{type(e).__name__}: {e}"[:300])
+            if guard.held is not None:
+                guard.bail(f"{type(e).__name__}: {e}"[:300])
             raise
         if rc:
             sys.exit(rc)
@@ -888,7 +970,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        # the N > 1 runs partition THIS graph N ways (north_star's curve): total work fixed as N grows
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -937,7 +1020,7 @@ def main():
     # The GPU measurement is complete.  What follows -- the locality leg, the CPU baseline, the comparison with the oracle -- only
     # adds to the record: it is HELD from here on (RecordGuard, as in the N > 1 leg) and printed, marked partial, if a signal, the
     # deadline or an exception in one of those legs ends the run first.
-    guard1 = install_rank_guard(0, max(5.0, args.deadline_s - (time.time() - T_START)))  # (the deadline counts from the process's start)
+    guard1 = guard  # (installed first thing in main(); its deadline counts from the process's start)
     guard1.hold(result)
     rc = 0
     try:
@@ -963,7 +1046,7 @@ def main():
         import traceback
 
         log(f"[bench] {type(e).__name__} after the GPU measurement:\n{traceback.format_exc()}")
-        guard1.bail(f"{type(e).__name__}: {e}"[:300])  # prints the held record (exit 0)
+        guard1.bail(f"{type(e).__name__}: {e}"[:300])  # prints the held record, marked partial, parity = {ok: null, reason}
         raise
     guard1.final(result)
     if rc:
@@ -1005,7 +1088,7 @@ def locality_leg(torch, ctx, capi, synth, reps: int = 6) -> dict:
             "traffic_over_b_min": (traffic / b_min) if traffic else None}
 
 
-def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
+def bench_gat_reddit(args, torch, ctx, L, synth, guard) -> int:
     """BASELINE config 4 ("reddit GAT 2-layer 8-head", SDDMM + edge-softmax kernel path): the hidden GAT layer 64 -> 64
     with 8 heads (8 x 8 columns), forward + backward per step, on the reddit-shaped graph with self loops (net.cpp:96).
     `value` = aggregated edges per second (2 attention-weighted aggregations per step).  The table (60 MB) lives in the
@@ -1122,9 +1205,7 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
     if sustained:
         result["sustained_ms_per_step"] = sustained
     # the GPU measurement is complete: the record is held from here on (as in the GCN line; main() bails on an exception)
-    global _N1_GUARD
-    _N1_GUARD = install_rank_guard(0, max(5.0, args.deadline_s - (time.time() - T_START)))
-    _N1_GUARD.hold(result)
+    guard.hold(result)
     rc = 0
     if not args.no_cpu_baseline:
         from oracle import binding as orc
@@ -1216,7 +1297,7 @@ def bench_gat_reddit(args, torch, ctx, L, synth) -> int:
         if not par["ok"]:
             log("[bench] PARITY FAILED (> 1e-4)")
             rc = 3
-    _N1_GUARD.final(result)
+    guard.final(result)
     return rc
 
 

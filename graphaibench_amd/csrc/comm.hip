@@ -439,6 +439,20 @@ extern "C" int gaib_comm_unique_id(int transport, void* h_id) {
   return GAIB_OK;
 }
 
+// GAIB_COMM_RESERVE_CUS: the caller's choice from the environment (validated: a whole number >= 0; anything else is ignored
+// with a line on stderr); an option set before gaib_comm_init wins
+static void reserve_from_env(gaib_ctx* ctx) {
+  const char* e = getenv("GAIB_COMM_RESERVE_CUS");
+  if (!e || ctx->comm_reserve_cus >= 0) return;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  if (end == e || *end != '\0' || v < 0 || v > 4096) {
+    fprintf(stderr, "[gaib] GAIB_COMM_RESERVE_CUS='%s' ignored (want a whole number >= 0)\n", e);
+    return;
+  }
+  ctx->comm_reserve_cus = (int)v;  // (clamped where it is used: gaib_comm_reserve)
+}
+
 extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h_id, int transport, gaib_comm** out) {
   GAIB_CHECK(ctx && h_id && out, "gaib_comm_init: NULL argument");
   GAIB_CHECK(nranks >= 1 && nranks <= GAIB_COMM_MAX_RANKS && rank >= 0 && rank < nranks,
@@ -490,13 +504,13 @@ extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h
     c->nranks = cnt;
     // RCCL's send / recv kernels need CUs to land on while the persistent fused aggregation runs (GAIB_OVERLAPS_TRANSFER):
     // one eighth of the chip, measured to cost that kernel 1.5 %; GAIB_COMM_RESERVE_CUS / the option override
-    if (cnt > 1 && ctx->comm_reserve_cus == 0) {
-      const char* e = getenv("GAIB_COMM_RESERVE_CUS");
-      ctx->comm_reserve_cus = e ? atoi(e) : 32;
-    }
+    ctx->comm_reserve_default = cnt > 1 ? 32 : 0;
+    reserve_from_env(ctx);
     *out = c;
     return GAIB_OK;
   }
+  ctx->comm_reserve_default = 0;  // the peer-to-peer pull runs on copy engines: nothing to leave free
+  reserve_from_env(ctx);
   // ---- IPC: map (rank 0: create) the segment named after the id ----
   const unsigned char* b = (const unsigned char*)h_id;
   snprintf(c->shm_name, sizeof(c->shm_name), "/gaib_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", b[0], b[1], b[2],
@@ -565,6 +579,7 @@ extern "C" int gaib_comm_destroy(gaib_comm* c) {
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->cstream);
   if (c->transport == GAIB_COMM_RCCL && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->transport == GAIB_COMM_RCCL) c->ctx->comm_reserve_default = 0;  // its send / recv kernels are gone with it
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (gaib_comm::IpcBuf& b : *c->ipc_bufs) (void)hipFree(b.p);  // (every plan is gone: gaib_halo_destroy comes first)
   if (c->seg) munmap(c->seg, sizeof(ShmSeg));

@@ -73,8 +73,11 @@ struct gaib_ctx {
   int spmm_flat;             // fused kernel, edge-stream form for short rows: -1 = by average degree, 0 = never, 1 = always
   int spmm_flat_ring;        // edge-stream form: 1 (default) = software-pipelined gathers (U always in flight), 0 = batches of U
   int comm_reserve_cus;      // CUs the persistent fused kernel leaves free while a halo exchange is in flight (GAIB_OVERLAPS_TRANSFER):
-                             // set by gaib_comm_init -- 32 under RCCL with more than one rank (its send / recv kernels need CUs to
-                             // land on: the fused kernel holds every register of the CUs it sits on until its last tile), 0 otherwise
+                             // -1 = unset (the communicator's default applies), >= 0 = the caller's choice (option / GAIB_COMM_RESERVE_CUS),
+                             // an explicit 0 included; clamped so that the fused kernel keeps at least 64 CUs
+  int comm_reserve_default;  // what gaib_comm_init found right for its transport: 32 under RCCL with more than one rank (its send /
+                             // recv kernels need CUs to land on: the fused kernel holds every register of the CUs it sits on until
+                             // its last tile), 0 on the peer-to-peer pull (copy engines) and before any communicator exists
   int spmm_fuse_cus;         // fused kernel: persistent workgroups (= CUs it occupies); 0 = all CUs.  Fewer leave whole CUs to a kernel on another stream
   int spmm_tile_xcd;         // fused kernel's tile supply: -1 (default) = by the graph's numbering (XCD-affine chunks of 1024 tiles where the numbering has locality, else one global counter), 0 = global counter, n > 0 = XCD-affine chunks of n tiles
   int spmm_prefetch_ids;     // fused row form on a numbering with locality (affine supply): 1 = next row's column ids requested a row ahead, 0 = per row
@@ -105,6 +108,14 @@ struct gaib_ctx {
   struct ProfRec { const char* key; hipEvent_t a, b; };
   std::vector<ProfRec> prof;
 };
+
+// CUs the fused aggregation leaves to the transport while an exchange is in flight: the caller's choice where there is one
+// (explicit 0 included), else the default of the communicator that was created on this context
+static inline int gaib_comm_reserve(const gaib_ctx* ctx) {
+  const int r = ctx->comm_reserve_cus >= 0 ? ctx->comm_reserve_cus : ctx->comm_reserve_default;
+  const int cap = ctx->num_cus > 64 ? ctx->num_cus - 64 : 0;
+  return r < 0 ? 0 : (r > cap ? cap : r);
+}
 
 // RAII: event pair around a kernel launch when profiling is on
 struct ProfScope {

@@ -72,7 +72,8 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->gat_fused_fwd = -1;
   c->gat_fused_unroll = 4;
   c->spmm_flat_ring = GAIB_FLAT_RING_DEFAULT;
-  c->comm_reserve_cus = 0;
+  c->comm_reserve_cus = -1;  // unset: the communicator's default applies (an explicit 0 stays 0)
+  c->comm_reserve_default = 0;
   c->gat_interleave = 0;
   c->gat_chunk_xcd = 0;
   c->prof_on = 0;
@@ -442,7 +443,8 @@ extern "C" int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, d
 
 extern "C" int gaib_get_option(gaib_ctx* ctx, const char* key, int64_t* h_value) {
   GAIB_CHECK(ctx && key && h_value, "gaib_get_option: NULL argument");
-  if (!strcmp(key, "comm_reserve_cus")) *h_value = ctx->comm_reserve_cus;
+  if (!strcmp(key, "comm_reserve_cus")) *h_value = gaib_comm_reserve(ctx);  // the EFFECTIVE figure
+  else if (!strcmp(key, "comm_reserve_cus_raw")) *h_value = ctx->comm_reserve_cus;  // what the caller set (-1: unset)
   else if (!strcmp(key, "spmm_fuse_cus")) *h_value = ctx->spmm_fuse_cus;
   else if (!strcmp(key, "spmm_flat_ring")) *h_value = ctx->spmm_flat_ring;
   else if (!strcmp(key, "num_cus")) *h_value = ctx->num_cus;
@@ -497,8 +499,8 @@ extern "C" int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value) {
     ctx->gat_fused_fwd = (int)value;
   else if (!strcmp(key, "gat_fused_unroll"))
     ctx->gat_fused_unroll = (int)value;
-  else if (!strcmp(key, "comm_reserve_cus"))
-    ctx->comm_reserve_cus = (int)value;
+  else if (!strcmp(key, "comm_reserve_cus"))  // -1: back to "unset"; else clamped so that the fused kernel keeps >= 64 CUs
+    ctx->comm_reserve_cus = value < 0 ? -1 : (int)std::min<int64_t>(value, std::max(0, ctx->num_cus - 64));
   else if (!strcmp(key, "spmm_flat_ring"))
     ctx->spmm_flat_ring = value < 0 ? GAIB_FLAT_RING_DEFAULT : (int)value;  // (-1: back to the default)
   else if (!strcmp(key, "gat_interleave"))

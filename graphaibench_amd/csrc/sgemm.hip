@@ -815,6 +815,7 @@ extern "C" int gaib_sgemm(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
 // bytes A[row i][k0 + 4h .. k0 + 4h + 3] and pairs them, step by step, with B rows k0 + 4h + s from LDS (the two lane
 // halves of v_mfma_f32_32x32x2_f32 may carry any two k's as long as both operands agree).  One float4 load feeds 16
 // MFMAs; no barrier after the slab is staged.
+namespace {
 constexpr int NNP_WAVES = 8;
 constexpr int NNP_LDB = 128 + 4;
 template <int NT, bool BT>  // NT = 32-column MFMA tiles per wave (N slab = 32 * NT <= 128); BT: B is [N][K] (op = transpose)
@@ -923,6 +924,8 @@ __global__ __launch_bounds__(NNP_WAVES * 64) void sgemm_stream_kernel(GemmArgs g
     }
   }
 }
+
+}  // namespace
 
 template <bool BT>
 int launch_stream(gaib_ctx* ctx, const GemmArgs& g) {

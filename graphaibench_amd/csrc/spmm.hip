@@ -434,7 +434,9 @@ static int spmm_gemm_impl(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const f
                          weight_kind == GAIB_W_MEAN_T || weight_kind == GAIB_W_EDGE);
   // two products whose matrices do not fit LDS together (SAGE's 100 -> 256 input layer): the neighbour product still
   // rides on the aggregation, the self term follows as an accumulating GEMM that also applies the activation
-  if (shape_ok && dual && fuse_strip_rows(kpad, len_out, true) == 0 && fuse_strip_rows(kpad, len_out, false) != 0) {
+  // (whole graphs only: a row class of a partition -- row map, second feature table -- cannot take this route, the
+  // accumulating GEMM below runs over rows [0, nv) of rows2 / out; it gets GAIB_ERR_UNSUPPORTED further down)
+  if (!part && shape_ok && dual && fuse_strip_rows(kpad, len_out, true) == 0 && fuse_strip_rows(kpad, len_out, false) != 0) {
     GAIB_TRY(spmm_gemm_impl(ctx, g, weight_kind, d_edge_w, len_in, d_in, d_agg, d_W, transW, nullptr, nullptr, len_out, d_out,
                             flags & ~GAIB_RELU));
     return gaib_sgemm_ex(ctx, 0, transW, g->nv, len_out, len_in, d_rows2, d_W2,

@@ -870,7 +870,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   int cus = ctx->spmm_fuse_cus > 0 ? ctx->spmm_fuse_cus : ctx->num_cus;
   // a halo exchange is in flight on the communication stream (the caller said so): its kernels need CUs to land on, and a
   // persistent workgroup of this kernel owns its CU's registers until the last tile (measured: 224 of 256 CUs cost 1.5 %)
-  if (f.overlaps_transfer && ctx->comm_reserve_cus > 0) cus = std::max(cus - ctx->comm_reserve_cus, std::min(cus, 64));
+  if (f.overlaps_transfer && gaib_comm_reserve(ctx) > 0) cus = std::max(cus - gaib_comm_reserve(ctx), std::min(cus, 64));
   const unsigned grid = (unsigned)std::min<int64_t>(cus, cdiv64(ntiles, FUSE_WAVES));
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, 8 * sizeof(int), ctx->stream));  // one counter per XCD
   ProfScope ps(ctx, !PART ? "spmm_gemm_fused" : (a.in2 ? "part_fused_2t" : (f.agg_in ? "part_fused_acc" : "part_fused")));

@@ -371,6 +371,89 @@ def allreduce_layer_grads(ctx, layer, which_list, shape, group=None, comm=None):
         capi._check(ctx.lib.gaib_memcpy_d2d(ctx.h, layer.ptr(w), buf[i * n:].data_ptr(), n * 4), "gaib_memcpy_d2d")
 
 
+# what the record must say about the communicator's set-up (config.comm_init_timed_out): a transport whose set-up ran into its
+# deadline on THIS rank is still inside a C call in a helper thread while the run goes on over the next transport -- the figure
+# is then not a clean one, and the record names it
+COMM_SETUP = {"timed_out": []}
+
+
+def comm_attempt(ctx, rank: int, world: int, transport: int):
+    """one communicator of one transport, created by all ranks together: every rank tries, the outcome is agreed on by all of
+    them (all-reduce(MIN) of the success flag) -> (capi.Comm | None, error text).  Collective."""
+    import threading
+
+    from . import capi
+
+    ok, comm, err = 1, None, ""
+    try:
+        uid = [capi.comm_unique_id(transport) if rank == 0 else None]
+    except capi.GaibError as e:
+        uid, ok, err = [None], 0, str(e)
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0] is None:
+        ok = 0
+    if ok:
+        # ncclCommInitRank is collective and has no deadline of its own: if a peer fails before it (or inside it), this
+        # rank would wait there for good and take the record with it.  The communicator is therefore created in a helper
+        # thread with a deadline (GAIB_COMM_INIT_TIMEOUT_S, 90 s); a rank that runs into it reports failure -- the call is
+        # left behind in its daemon thread, and a communicator that still comes out of it is closed at once -- and all ranks
+        # move on to the next transport together; the record names the transport (config.comm_init_timed_out).  (The same
+        # path creates the peer-to-peer communicator, so every N > 1 run exercises it.)
+        box = {}
+
+        def create():
+            try:
+                c = capi.Comm(ctx, rank, world, uid[0], transport)
+            except Exception as e:  # noqa: BLE001
+                box["err"] = str(e)
+                return
+            if box.get("abandoned"):  # the deadline passed while the call was inside: nobody will use this communicator --
+                try:                  # it goes at once instead of living on beside the one the run fell back to
+                    c.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                return
+            box["comm"] = c
+
+        limit = float(os.environ.get("GAIB_COMM_INIT_TIMEOUT_S", "90"))
+        th = threading.Thread(target=create, daemon=True, name="gaib-comm-init")
+        th.start()
+        th.join(limit)
+        if th.is_alive():
+            box["abandoned"] = True
+            ok, err = 0, f"communicator set-up did not return within {limit:.0f} s (left behind in its thread)"
+            COMM_SETUP["timed_out"].append("ipc" if transport == capi.COMM_IPC else "rccl")
+        elif "comm" in box:
+            comm = box["comm"]
+        else:
+            ok, err = 0, box.get("err", "communicator set-up failed")
+    flag = torch.tensor([ok], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None, err or "a peer failed"
+    return comm, ""
+
+
+def rccl_possible(ctx, world: int):
+    """the cheap preconditions of ncclCommInitRank, agreed by all ranks BEFORE anybody enters it (the call is collective and
+    has no deadline: a rank that cannot load RCCL, or two ranks on one device, would leave the others waiting inside it):
+    librccl loads on every rank, and every rank has a device of its own -> (bool, reason).  Collective."""
+    from . import capi
+
+    mine = [ctx.device, 1 if capi.comm_transport_available(capi.COMM_RCCL) else 0]
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    if not all(e[1] for e in every):
+        return False, "librccl.so.1 does not load on rank(s) " + str([r for r, e in enumerate(every) if not e[1]])
+    if len({e[0] for e in every}) != world:
+        return False, f"ranks share devices ({[e[0] for e in every]}): RCCL wants one GPU per rank"
+    return True, ""
+
+
 def make_comm(ctx, rank: int, world: int, log):
     """The data-path communicator of bench.py's N > 1 leg, behind the C ABI.  GAIB_DIST_BACKEND:
          rccl (default)  gaib_comm over RCCL -- one GPU per rank
@@ -378,74 +461,12 @@ def make_comm(ctx, rank: int, world: int, log):
          nccl | gloo     no gaib_comm: torch.distributed moves the halo rows (the round-1 path)
     torch.distributed (the launcher's process group) only carries the 128-byte id, barriers and the timing reductions.
     The choice is made ONCE here, by all ranks together: if any rank fails to create its communicator, every rank
-    falls back to torch.distributed (an all-reduce(MIN) of the success flag) -- never per call."""
-    import os
-
+    falls back to the next transport, last to torch.distributed (an all-reduce(MIN) of the success flag) -- never per call."""
     from . import capi
 
     backend = os.environ.get("GAIB_DIST_BACKEND", "rccl")
     if backend in ("nccl", "gloo"):
         return None, f"torch.distributed/{dist.get_backend()}"
-
-    def attempt(transport):
-        """every rank tries; the outcome is agreed on by all of them (all-reduce(MIN) of the success flag)"""
-        ok, comm, err = 1, None, ""
-        try:
-            uid = [capi.comm_unique_id(transport) if rank == 0 else None]
-        except capi.GaibError as e:
-            uid, ok, err = [None], 0, str(e)
-        dist.broadcast_object_list(uid, src=0)
-        if uid[0] is None:
-            ok = 0
-        if ok:
-            # ncclCommInitRank is collective and has no deadline of its own: if a peer fails before it (or inside it), this
-            # rank would wait there for good and take the record with it.  The communicator is therefore created in a helper
-            # thread with a deadline (GAIB_COMM_INIT_TIMEOUT_S, 90 s); a rank that runs into it reports failure -- the call is
-            # left behind in its daemon thread -- and all ranks move on to the next transport together.  (The same path
-            # creates the peer-to-peer communicator, so every N > 1 run exercises it.)
-            import threading
-
-            box = {}
-
-            def create():
-                try:
-                    box["comm"] = capi.Comm(ctx, rank, world, uid[0], transport)
-                except Exception as e:  # noqa: BLE001
-                    box["err"] = str(e)
-
-            limit = float(os.environ.get("GAIB_COMM_INIT_TIMEOUT_S", "90"))
-            th = threading.Thread(target=create, daemon=True, name="gaib-comm-init")
-            th.start()
-            th.join(limit)
-            if th.is_alive():
-                ok, err = 0, f"communicator set-up did not return within {limit:.0f} s (left behind in its thread)"
-            elif "comm" in box:
-                comm = box["comm"]
-            else:
-                ok, err = 0, box.get("err", "communicator set-up failed")
-        flag = torch.tensor([ok], dtype=torch.int32)
-        if dist.get_backend() == "nccl":
-            flag = flag.cuda()
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if comm is not None:
-                comm.close()
-            return None, err or "a peer failed"
-        return comm, ""
-
-    def rccl_possible():
-        """the cheap preconditions of ncclCommInitRank, agreed by all ranks BEFORE anybody enters it (the call is
-        collective and has no deadline: a rank that cannot load RCCL, or two ranks on one device, would leave the
-        others waiting inside it): librccl loads on every rank, and every rank has a device of its own"""
-        mine = [ctx.device, 1 if capi.comm_transport_available(capi.COMM_RCCL) else 0]
-        every = [None] * world
-        dist.all_gather_object(every, mine)
-        if not all(e[1] for e in every):
-            return False, "librccl.so.1 does not load on rank(s) " + str([r for r, e in enumerate(every) if not e[1]])
-        if len({e[0] for e in every}) != world:
-            return False, f"ranks share devices ({[e[0] for e in every]}): RCCL wants one GPU per rank"
-        return True, ""
-
     # rccl (default): if it cannot be set up on some rank, the peer-to-peer pull transport (hipIpc handles, device-to-
     # device copies over xGMI) is tried before torch.distributed carries the rows
     order = [capi.COMM_IPC] if backend == "ipc" else [capi.COMM_RCCL, capi.COMM_IPC]
@@ -453,12 +474,12 @@ def make_comm(ctx, rank: int, world: int, log):
     for transport in order:
         name = "ipc" if transport == capi.COMM_IPC else "rccl"
         if transport == capi.COMM_RCCL:
-            ok, err = rccl_possible()
+            ok, err = rccl_possible(ctx, world)
             if not ok:
                 log(f"[bench r{rank}] gaib_comm(rccl) not attempted: {err}")
                 failed.append("rccl")
                 continue
-        comm, err = attempt(transport)
+        comm, err = comm_attempt(ctx, rank, world, transport)
         if comm is not None:
             note = f" (after {', '.join(failed)} failed at set-up)" if failed else ""
             return comm, f"gaib_comm/{name}{note}"
@@ -490,178 +511,280 @@ class Budget:
                 "needed_s_estimate": round(need_s, 1)}
 
 
-def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None):
-    """one timed case: partition `rows`, build the layer, warm up, time args.steps steps.
-    check(part, layer, feat_out, grad_out, inputs): bench.py's comparison with the oracle's GLOBAL run (test
-    infrastructure stays outside this package); the layer then runs on inputs(rank, nv) -> (x, grad_in) host arrays"""
-    from . import layers as L
+class BenchCase:
+    """one partitioned GCN layer of bench.py's N > 1 leg: partition `rows`, build the graph (row classes by the rule) and the
+    layer; time steps; diagnostics (one exchange on its own, the pack alone); A/B legs on the live objects; close.
+    inputs(rank, nv) -> (x, grad_in) host arrays: what a comparison with the oracle will want the layer to run on."""
 
-    t0 = time.time()
-    part = build_partition(rows.rowptr, rows.colidx_global, rows.n_global, rank, world)
-    dg = DistLayerGraph(ctx, part, comm)
-    mode_used, n_bnd, bnd_edges = dg.lgraph.partition_mode(D)  # decided (and the class graphs built) before the timed steps
-    torch.cuda.synchronize()
-    log(f"[bench r{rank}] {label}: rows [{part.lo},{part.hi}) ne={part.ne} (own-column {part.colidx_own.numel()}) "
-        f"halo rows={part.n_halo} send rows={part.send_idx.numel()} mode {L.LGraph.PART_NAMES[mode_used]} "
-        f"boundary rows={n_bnd} setup {time.time()-t0:.1f}s")
-    nv = part.n_own
-    torch.manual_seed(43 + rank)
-    layer = L.Layer(L.GCN, 1, nv, D, D, dg.lgraph, act=True, lr=0.01)
-    if check is not None:
-        x_h, gin_h = check.inputs(rank, nv)
-        layer.write(L.FEAT_IN, torch.from_numpy(x_h).cuda())
-        layer.write(L.GRAD_IN, torch.from_numpy(gin_h).cuda())
-        del x_h, gin_h
-    else:
-        layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda"))
-        layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda"))
-    feat_out = torch.empty(nv, D, device="cuda")
-    grad_out = torch.empty(nv, D, device="cuda")
+    def __init__(self, ctx, comm, args, rank, world, D, log, rows, label, inputs=None):
+        from . import layers as L
 
-    def step():
-        layer.forward(feat_out)
-        layer.backward(feat_out, grad_out)
-        allreduce_layer_grads(ctx, layer, [L.W_NEIGH_GRAD], (D, D), comm=comm)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    dg.ex.bytes_sent = 0
-    dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    ctx.prof_enable(False)
-    n_light, ms_light = ctx.prof_get("spmm_light")
-    n_fused, ms_fused = ctx.prof_get("spmm_gemm_fused")
-    n_heavy, ms_heavy = ctx.prof_get("spmm_heavy")
-    n_gemm, ms_gemm = ctx.prof_get("sgemm")
-    n_pack, ms_pack = ctx.prof_get("gather_rows")
-    part_ms = {k: ctx.prof_get(k)[1] / args.steps for k in ("part_fused", "part_fused_acc", "part_fused_2t", "part_light",
-                                                            "part_light_acc", "part_light_2t")}
-    ctx.prof_reset()
-    if check is not None and hasattr(check, "exchanger"):
-        check.exchanger = dg.ex  # (diagnostics of a failing comparison: the plan the layer itself uses)
-    parity = check(part, layer, feat_out, grad_out) if check is not None else None
-    # diagnostics outside the timed region (collective: every rank runs them): one halo exchange of a [nv x D]
-    # matrix on its own (pack + all-to-all + wait) and the pack alone -- what the owned-edge SpMM has to hide
-    bytes_timed = dg.ex.bytes_sent
-    feat = layer.tensor(L.FEAT_IN, (nv, D))
-    reps = 3
-    dg.ex.exchange(feat, D)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        dg.ex.exchange(feat, D)
-    torch.cuda.synchronize()
-    exch_ms = (time.perf_counter() - t0) / reps * 1e3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        if isinstance(dg.ex, AbiHaloExchanger):
-            dg.ex.pack_only(feat, D)
-        elif part.send_idx.numel():
-            sendbuf, _ = dg.ex._bufs(D, torch.float32, feat.device)
-            dg.ex.gather_rows(part.send_idx, feat, D, sendbuf)
-    torch.cuda.synchronize()
-    pack_ms = (time.perf_counter() - t0) / reps * 1e3
-    # max time over ranks, total edges over ranks
-    rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([elapsed, exch_ms, pack_ms], dtype=torch.float64, device=rdev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    e = torch.tensor([float(part.ne), float(part.n_halo), float(bytes_timed)], dtype=torch.float64, device=rdev)
-    dist.all_reduce(e, op=dist.ReduceOp.SUM)
-    # dominant kernel (rank 0's view) = the pass over the owned-column edges of each aggregation: with halo
-    # edges that is spmm_w64_kernel (the halo half then carries the dense product), without them the fused
-    # kernel does everything, as in the single-GPU bench
-    st_own = ctx.graph_stats(dg.lgraph.device_graph())
-    e_light = part.colidx_own.numel() - st_own["heavy_edges"]
-    if mode_used != L.LGraph.PART_SPLIT:
-        # row classes: the dominant kernel is the fused pass over the larger class -- the interior rows (one table) or the
-        # boundary rows over [owned | halo] (two tables); bytes as in the single-GPU record, per edge of that class
-        by_int = part_ms["part_fused"] >= max(part_ms["part_fused_2t"], part_ms["part_light"])
-        e_int = part.ne - bnd_edges
-        if by_int:
-            kernel_name = "spmm_gemm_kernel<VEC=2,edge-weights,U=16,PART> over the interior rows (aggregation + MFMA product, rank 0)"
-            e_k, r_k, ms_dom = e_int, nv - n_bnd, part_ms["part_fused"] * args.steps
-        elif part_ms["part_fused_2t"] > 0:
-            kernel_name = ("spmm_gemm_kernel<VEC=2,edge-weights,U=16,PART> over the boundary rows, one pass over "
-                           "[owned | halo] (two feature tables, rank 0)")
-            e_k, r_k, ms_dom = bnd_edges, n_bnd, part_ms["part_fused_2t"] * args.steps
+        self.ctx, self.comm, self.args, self.rank, self.world, self.D, self.log, self.label = ctx, comm, args, rank, world, D, log, label
+        self.L = L
+        t0 = time.time()
+        self.part = part = build_partition(rows.rowptr, rows.colidx_global, rows.n_global, rank, world)
+        self.dg = dg = DistLayerGraph(ctx, part, comm)
+        # decided (and the class graphs built) before the timed steps
+        self.mode_used, self.n_bnd, self.bnd_edges = dg.lgraph.partition_mode(D)
+        torch.cuda.synchronize()
+        log(f"[bench r{rank}] {label}: rows [{part.lo},{part.hi}) ne={part.ne} (own-column {part.colidx_own.numel()}) "
+            f"halo rows={part.n_halo} send rows={part.send_idx.numel()} mode {L.LGraph.PART_NAMES[self.mode_used]} "
+            f"boundary rows={self.n_bnd} setup {time.time()-t0:.1f}s")
+        self.nv = nv = part.n_own
+        torch.manual_seed(43 + rank)
+        self.layer = layer = L.Layer(L.GCN, 1, nv, D, D, dg.lgraph, act=True, lr=0.01)
+        if inputs is not None:
+            x_h, gin_h = inputs(rank, nv)
+            layer.write(L.FEAT_IN, torch.from_numpy(x_h).cuda())
+            layer.write(L.GRAD_IN, torch.from_numpy(gin_h).cuda())
+            del x_h, gin_h
         else:
-            kernel_name = "spmm_w64_kernel<VEC=2,PART> over the boundary rows' owned-column edges (rank 0)"
-            e_k, r_k, ms_dom = bnd_edges - part.colidx_halo.numel(), n_bnd, part_ms["part_light"] * args.steps
-        alg_bytes = e_k * (4 * D + 8) + int(1.5 * r_k * 4 * D) + (r_k + 1) * 8
-        n_dom = 2 * args.steps
-    elif part.colidx_halo.numel() > 0:
-        kernel_name = "spmm_w64_kernel<VEC=2,CT=1,edge-weights,U=16,buffer> over the owned-column edges (rank 0)"
-        alg_bytes = e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
-        n_dom, ms_dom = n_light, ms_light
-    else:
-        kernel_name = "spmm_gemm_kernel<VEC=2,edge-weights,U=16,buffer> (aggregation + MFMA dense product, rank 0)"
-        alg_bytes = e_light * (4 * D + 8) + int(1.5 * nv * 4 * D) + (nv + 1) * 8
-        n_dom, ms_dom = n_fused, ms_fused
-    avg_ms = ms_dom / max(n_dom, 1)
-    res = dict(elapsed=float(t[0]), exch_ms=float(t[1]), pack_ms=float(t[2]), total_edges=float(e[0]),
-               halo_rows_total=int(e[1]), halo_bytes_per_step_total=float(e[2]) / args.steps, nv=nv,
-               owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
-               avg_ms=avg_ms, launches=n_dom, parity=parity,
-               # rank 0's kernels per step: the owned-column pass, the halo-column half (fused with the dense product),
-               # heavy rows, the weight gradient, the pack of the rows on the send lists
-               breakdown=dict(owned_edge_spmm_ms=ms_light / args.steps, halo_half_ms=ms_fused / args.steps,
-                              heavy_rows_ms=ms_heavy / args.steps, sgemm_ms=ms_gemm / args.steps,
-                              pack_ms=ms_pack / args.steps, **{k + "_ms": v for k, v in part_ms.items() if v}),
-               # how rank 0 aggregates on this partition (LearningGraph::partition_mode) and what decided it
-               partition_mode=dict(mode=L.LGraph.PART_NAMES[mode_used], boundary_rows=n_bnd, boundary_row_share=n_bnd / max(nv, 1),
-                                   boundary_edges=bnd_edges, link_gbs_assumed=float(os.environ.get("GAIB_LINK_GBS", "100"))),
-               value=2 * float(e[0]) * args.steps / float(t[0]), ms_per_step=float(t[0]) / args.steps * 1e3)
-    # the case's objects go now, in an order: the layer, the graph (which points at the plan), then the plan -- collectively (every
-    # rank is here): its send buffer and halo table return to the communicator's pool for the next case, and a default run never
-    # comes near the communicator's limit of plans alive at once
-    plan = getattr(dg.ex, "halo", None)
-    layer.close()
-    dg.lgraph.close()
-    del layer, feat_out, grad_out, dg
-    torch.cuda.synchronize()
-    if plan is not None:
-        plan.close()
-    torch.cuda.empty_cache()
+            layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda"))
+            layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda"))
+        self.feat_out = torch.empty(nv, D, device="cuda")
+        self.grad_out = torch.empty(nv, D, device="cuda")
+        self.rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def step(self):
+        L = self.L
+        self.layer.forward(self.feat_out)
+        self.layer.backward(self.feat_out, self.grad_out)
+        allreduce_layer_grads(self.ctx, self.layer, [L.W_NEIGH_GRAD], (self.D, self.D), comm=self.comm)
+
+    def time_steps(self, steps: int, warmup: int) -> float:
+        """seconds of `steps` steps between barriers (this rank's clock; the caller takes the MAX over ranks).  Collective."""
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter() - t0
+
+    def max_over_ranks(self, *vals):
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=self.rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def exchange_standalone_ms(self, ex=None, reps: int = 3) -> float:
+        """one halo exchange of the layer's [nv x D] input on its own (pack + transfer + wait), this rank's clock.  Collective."""
+        ex = ex or self.dg.ex
+        feat = self.layer.tensor(self.L.FEAT_IN, (self.nv, self.D))
+        ex.exchange(feat, self.D)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ex.exchange(feat, self.D)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def measure(self) -> dict:
+        ctx, args, part, dg, L, D, nv = self.ctx, self.args, self.part, self.dg, self.L, self.D, self.nv
+        for _ in range(args.warmup):
+            self.step()
+        torch.cuda.synchronize()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        dg.ex.bytes_sent = 0
+        elapsed = self.time_steps(args.steps, 0)
+        ctx.prof_enable(False)
+        n_light, ms_light = ctx.prof_get("spmm_light")
+        n_fused, ms_fused = ctx.prof_get("spmm_gemm_fused")
+        n_heavy, ms_heavy = ctx.prof_get("spmm_heavy")
+        n_gemm, ms_gemm = ctx.prof_get("sgemm")
+        n_pack, ms_pack = ctx.prof_get("gather_rows")
+        part_ms = {k: ctx.prof_get(k)[1] / args.steps for k in ("part_fused", "part_fused_acc", "part_fused_2t", "part_light",
+                                                                "part_light_acc", "part_light_2t")}
+        ctx.prof_reset()
+        # diagnostics outside the timed region (collective: every rank runs them): one halo exchange of a [nv x D]
+        # matrix on its own (pack + all-to-all + wait) and the pack alone -- what the owned-edge SpMM has to hide
+        bytes_timed = dg.ex.bytes_sent
+        exch_ms = self.exchange_standalone_ms()
+        feat = self.layer.tensor(L.FEAT_IN, (nv, D))
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if isinstance(dg.ex, AbiHaloExchanger):
+                dg.ex.pack_only(feat, D)
+            elif part.send_idx.numel():
+                sendbuf, _ = dg.ex._bufs(D, torch.float32, feat.device)
+                dg.ex.gather_rows(part.send_idx, feat, D, sendbuf)
+        torch.cuda.synchronize()
+        pack_ms = (time.perf_counter() - t0) / reps * 1e3
+        # max time over ranks, total edges over ranks
+        t = self.max_over_ranks(elapsed, exch_ms, pack_ms)
+        e = torch.tensor([float(part.ne), float(part.n_halo), float(bytes_timed), float(part.colidx_halo.numel())],
+                         dtype=torch.float64, device=self.rdev)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        # dominant kernel (rank 0's view) = the pass over the owned-column edges of each aggregation: with halo
+        # edges that is spmm_w64_kernel (the halo half then carries the dense product), without them the fused
+        # kernel does everything, as in the single-GPU bench
+        mode_used, n_bnd, bnd_edges = self.mode_used, self.n_bnd, self.bnd_edges
+        st_own = ctx.graph_stats(dg.lgraph.device_graph())
+        e_light = part.colidx_own.numel() - st_own["heavy_edges"]
+        if mode_used != L.LGraph.PART_SPLIT:
+            # row classes: the dominant kernel is the fused pass over the larger class -- the interior rows (one table) or the
+            # boundary rows over [owned | halo] (two tables); bytes as in the single-GPU record, per edge of that class
+            by_int = part_ms["part_fused"] >= max(part_ms["part_fused_2t"], part_ms["part_light"])
+            e_int = part.ne - bnd_edges
+            if by_int:
+                kernel_name = "spmm_gemm_kernel<VEC=2,edge-weights,U=16,PART> over the interior rows (aggregation + MFMA product, rank 0)"
+                e_k, r_k, ms_dom = e_int, nv - n_bnd, part_ms["part_fused"] * args.steps
+            elif part_ms["part_fused_2t"] > 0:
+                kernel_name = ("spmm_gemm_kernel<VEC=2,edge-weights,U=16,PART> over the boundary rows, one pass over "
+                               "[owned | halo] (two feature tables, rank 0)")
+                e_k, r_k, ms_dom = bnd_edges, n_bnd, part_ms["part_fused_2t"] * args.steps
+            else:
+                kernel_name = "spmm_w64_kernel<VEC=2,PART> over the boundary rows' owned-column edges (rank 0)"
+                e_k, r_k, ms_dom = bnd_edges - part.colidx_halo.numel(), n_bnd, part_ms["part_light"] * args.steps
+            alg_bytes = e_k * (4 * D + 8) + int(1.5 * r_k * 4 * D) + (r_k + 1) * 8
+            n_dom = 2 * args.steps
+        elif part.colidx_halo.numel() > 0:
+            kernel_name = "spmm_w64_kernel<VEC=2,CT=1,edge-weights,U=16,buffer> over the owned-column edges (rank 0)"
+            alg_bytes = e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
+            n_dom, ms_dom = n_light, ms_light
+        else:
+            kernel_name = "spmm_gemm_kernel<VEC=2,edge-weights,U=16,buffer> (aggregation + MFMA dense product, rank 0)"
+            alg_bytes = e_light * (4 * D + 8) + int(1.5 * nv * 4 * D) + (nv + 1) * 8
+            n_dom, ms_dom = n_fused, ms_fused
+        avg_ms = ms_dom / max(n_dom, 1)
+        link_env = os.environ.get("GAIB_LINK_GBS")
+        return dict(elapsed=t[0], exch_ms=t[1], pack_ms=t[2], total_edges=float(e[0]),
+                    halo_rows_total=int(e[1]), halo_bytes_per_step_total=float(e[2]) / args.steps, nv=nv,
+                    cut_fraction_measured=float(e[3]) / max(float(e[0]), 1.0),
+                    owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
+                    avg_ms=avg_ms, launches=n_dom, parity=None,
+                    # rank 0's kernels per step: the owned-column pass, the halo-column half (fused with the dense product),
+                    # heavy rows, the weight gradient, the pack of the rows on the send lists
+                    breakdown=dict(owned_edge_spmm_ms=ms_light / args.steps, halo_half_ms=ms_fused / args.steps,
+                                   heavy_rows_ms=ms_heavy / args.steps, sgemm_ms=ms_gemm / args.steps,
+                                   pack_ms=ms_pack / args.steps, **{k + "_ms": v for k, v in part_ms.items() if v}),
+                    # how rank 0 aggregates on this partition (LearningGraph::partition_mode) and what decided it
+                    partition_mode=dict(mode=L.LGraph.PART_NAMES[mode_used], boundary_rows=n_bnd, boundary_row_share=n_bnd / max(nv, 1),
+                                        boundary_edges=bnd_edges, link_gbs_assumed=float(link_env or "100"),
+                                        link_gbs_source=LINK_GBS_SOURCE.get("source", "the library's default (100 GB/s per peer pair)")),
+                    value=2 * float(e[0]) * args.steps / t[0], ms_per_step=t[0] / args.steps * 1e3)
+
+    def cu_reserve_ab(self, reserves=(0, 32, 64), steps: int = 6) -> dict:
+        """the step with the persistent fused aggregation leaving 0 / 32 / 64 CUs to the transport while an exchange is in
+        flight (option comm_reserve_cus; GAIB_OVERLAPS_TRANSFER).  The option only reaches launches of the fused kernel that
+        overlap an exchange: the interior pass of the class modes -- in the column split the overlapping pass is the
+        non-persistent spmm_w64_kernel, whose workgroups retire and leave room by themselves (the record says which mode ran).
+        Collective; max over ranks; the option returns to what it was."""
+        ctx = self.ctx
+        raw = ctx.get_option("comm_reserve_cus_raw")
+        out = {"mode": self.L.LGraph.PART_NAMES[self.mode_used], "steps_each": steps, "ms_per_step": {},
+               "fused_launches_overlap_an_exchange": self.mode_used != self.L.LGraph.PART_SPLIT}
+        try:
+            for r in reserves:
+                ctx.set_option("comm_reserve_cus", r)
+                el = self.time_steps(steps, 1)
+                out["ms_per_step"][str(r)] = self.max_over_ranks(el)[0] / steps * 1e3
+        finally:
+            ctx.set_option("comm_reserve_cus", raw)
+        out["in_effect_for_the_timed_steps"] = ctx.get_option("comm_reserve_cus")
+        return out
+
+    def transport_ab(self, transports) -> dict:
+        """the SAME exchange plan (this case's send / receive lists) timed on its own over every transport in `transports`:
+        {name: capi.Comm | (None, reason)} -> {name: ms (max over ranks) | {"skipped": reason}}.  Collective."""
+        out = {}
+        for name, c in transports.items():
+            if not hasattr(c, "halo"):
+                out[name] = {"skipped": c[1]}
+                continue
+            plan_ex = None
+            try:
+                if c is self.comm:
+                    ms = self.exchange_standalone_ms()
+                else:
+                    plan_ex = AbiHaloExchanger(self.ctx, c, self.part)
+                    ms = self.exchange_standalone_ms(plan_ex)
+                out[name] = {"exchange_standalone_ms": self.max_over_ranks(ms)[0]}
+            finally:
+                if plan_ex is not None:
+                    torch.cuda.synchronize()
+                    plan_ex.halo.close()
+        return out
+
+    def close(self):
+        # the case's objects go in an order: the layer, the graph (which points at the plan), then the plan -- collectively (every
+        # rank is here): its send buffer and halo table return to the communicator's pool for the next case, and a default run
+        # never comes near the communicator's limit of plans alive at once
+        plan = getattr(self.dg.ex, "halo", None)
+        self.layer.close()
+        self.dg.lgraph.close()
+        self.layer = self.feat_out = self.grad_out = self.dg = None
+        torch.cuda.synchronize()
+        if plan is not None:
+            plan.close()
+        torch.cuda.empty_cache()
+
+
+# where the link rate of the partition-mode rule came from (set once per run by bench_gcn_layer; the record names it)
+LINK_GBS_SOURCE = {}
+
+
+def _bench_case(ctx, comm, args, rank, world, D, log, rows, label, check=None, on_measured=None, extras=None):
+    """one timed case.  check(part, layer, feat_out, grad_out): bench.py's comparison with the oracle's GLOBAL run (test
+    infrastructure stays outside this package); the layer then runs on check.inputs(rank, nv) -> (x, grad_in) host arrays.
+    on_measured(res): called as soon as the timed steps and the diagnostics are in -- BEFORE the comparison and the A/B legs
+    (the caller holds the record from there on).  extras(case, res): further legs on the live objects (A/B), before close."""
+    case = BenchCase(ctx, comm, args, rank, world, D, log, rows, label, inputs=check.inputs if check is not None else None)
+    res = case.measure()
+    if on_measured is not None:
+        on_measured(res)
+    if check is not None:
+        if hasattr(check, "exchanger"):
+            check.exchanger = case.dg.ex  # (diagnostics of a failing comparison: the plan the layer itself uses)
+        res["parity"] = check(case.part, case.layer, case.feat_out, case.grad_out)
+    if extras is not None:
+        extras(case, res)
+    case.close()
     return res
 
 
 def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=None, t_start=None, hold=None, cpu_leg=None,
-                    parity_check=None, traffic_of=None):
+                    parity_check=None, traffic_of=None, strong_check=None):
     """bench.py's N > 1 leg.  GCN hidden layer D -> D forward + backward per step, halo exchange before each of the 2
     SpMM, one all-reduce of dW per step.
 
-    --scaling weak (default): every rank owns a products-shaped vertex range of one global block Chung-Lu graph
-    (synth.block_rows).  The share of a range's edges that cross ranges stands for the partitioner's quality, so BOTH
-    ends are measured in one invocation: `value` at --cut-fraction (default 0.1, a locality-preserving order) and
-    `config.random_order` at (N-1)/N (a random vertex order: the adversarial end).
-    --scaling strong: the SAME 2.45 M-vertex products-shaped graph of the single-GPU bench, partitioned N ways by
-    vertex range (its vertex order is random, so the cut is (N-1)/N).
+    --scaling strong (default since round 5): north_star's curve -- the SAME 2.45 M-vertex products-shaped graph of the
+    single-GPU bench, partitioned N ways by vertex range (its vertex order is random, so the cut is (N-1)/N), the reference's
+    scheme for one fixed graph on N devices (src/partitioner/graph_partition.cc:128-178, src/triangle/multigpu_induced.cu:31-84).
+    That case is `value`; its sub-record `config.strong_products` adds the one-rank timing of the same graph taken in the run
+    (`speedup_vs_n1`).  The weak case -- every rank owns a products-shaped vertex range of one global block Chung-Lu graph
+    (synth.block_rows), cut 0.1 -- runs second as `config.weak_products_range`; the share of a range's edges that cross ranges
+    stands for the partitioner's quality, so the other end, (N-1)/N, is `config.random_order`, and the clustered-boundary
+    generator `config.clustered_boundary`.
+    --scaling weak: the two swap places (`value` = the weak case at --cut-fraction, `config.strong_products` second).
     --workload gcn-papers (BASELINE config 5): the same layer on the ogbn-papers100M-shaped graph, one vertex range of
-    1/8 of it per rank -- at N = 8 the whole 111 M-vertex / 3.2 G-edge graph -- again at both ends of the partition-quality
-    axis.  make_check(shape, cut) -> bench.py's oracle comparison for one case (--check-oracle), or None.
+    1/8 of it per rank -- at N = 8 the whole 111 M-vertex / 3.2 G-edge graph -- at both ends of the partition-quality
+    axis (weak by construction).  make_check(shape, cut) -> bench.py's oracle comparison for one case (--check-oracle), or None.
     The record cannot be lost: the HEADLINE case runs first and rank 0 hands the record to hold() as soon as it is measured
-    (bench.py prints it if anything ends the run early); every further sub-case -- the N = 1 CPU baseline (cpu_leg), the
-    clustered-boundary generator, the random vertex order, config 5 -- starts only if all ranks agree that its estimated
-    time fits args.budget_s counted from t_start (Budget), else its slot says {"skipped": "budget", ...}.
-    parity_check(shape, cut, comm, scale) -> bench.py's oracle comparison at another scale: the record's `parity` block of a
-    default run -- the same partitioned layer over the same transport on a graph whose GLOBAL size the oracle runs in seconds
-    (two products-shaped ranges in all), every rank's rows element-wise against the oracle's global run."""
-    import os
+    (bench.py prints it if anything ends the run early); every further leg -- the comparison with the oracle, the other
+    scaling mode, the A/B legs of the run's own constants (config.cu_reserve_ab, config.transport_ab), the clustered-boundary
+    generator, the random vertex order, config 5 -- starts only if all ranks agree that its estimated time fits args.budget_s
+    counted from t_start (Budget), else its slot says {"skipped": "budget", ...}.
+    strong_check(comm, bounds) -> bench.py's comparison of the strong case with the oracle's run on the bench graph (the run
+    the N = 1 bench makes: also the record's cpu_baseline).  parity_check(shape, cut, comm, scale) -> the comparison at another
+    scale for the weak generator: the same partitioned layer over the same transport on a graph whose GLOBAL size the oracle
+    runs in seconds, every rank's rows element-wise against the oracle's global run."""
+    import socket
 
-    from . import capi, synth
+    from . import capi, layers as L, synth
 
     comm, transport = make_comm(ctx, rank, world, log)
     rdev0 = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    every = [None] * world
+    dist.all_gather_object(every, [list(COMM_SETUP["timed_out"]), socket.gethostname(), ctx.device])
+    comm_timed_out = sorted({t for e in every for t in e[0]})
+    share = len({(e[1], e[2]) for e in every}) < world  # two ranks on one device: timings are not evidence of anything
 
     def reduce_min(flag: int) -> int:
         t = torch.tensor([flag], dtype=torch.int32, device=rdev0)
@@ -672,83 +795,191 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     papers = getattr(args, "workload", "gcn-products") == "gcn-papers"
     shape = "ogbn-papers100M/8" if papers else "ogbn-products"
     mk = (lambda c: make_check(shape, c, comm)) if make_check is not None else (lambda c: None)
-    # the xGMI link, measured (rank 0 while the others wait): replaces the 153 GB/s spec constant in the record
-    link = None
-    if rank == 0 and torch.cuda.device_count() >= 2:
+    # ---- the xGMI link, measured FIRST (rank 0 while the others wait): the figure replaces the spec constant in the record and
+    # -- before any partitioned graph exists -- the constant in the partition-mode rule (LearningGraph::partition_mode prices the
+    # exchange per peer pair: GAIB_LINK_GBS, read when a graph's mode is decided)
+    ndev = torch.cuda.device_count()
+    link = {"skipped": f"{ndev} visible device(s): no peer to copy to"}
+    if world > 1 and share:
+        link = {"skipped": "ranks share a device: a peer copy would not cross a link"}
+    elif rank == 0 and ndev >= 2:
         try:
+            t0 = time.time()
             link = {"unidirectional_gbs": capi.probe_peer_copy(0, 1, 1 << 28, 10, False),
                     "bidirectional_gbs_per_direction": capi.probe_peer_copy(0, 1, 1 << 28, 10, True), "bytes": 1 << 28,
                     "pair": [0, 1]}
+            # every peer of device 0, one direction (the 7 links of a node are not promised to be alike), bounded to ~10 s
+            per_peer = {}
+            for d in range(2, min(ndev, 8)):
+                if time.time() - t0 > 10.0:
+                    break
+                per_peer[str(d)] = capi.probe_peer_copy(0, d, 1 << 27, 5, False)
+            if per_peer:
+                link["unidirectional_gbs_from_0_to"] = {"1": link["unidirectional_gbs"], **per_peer}
+            link["seconds"] = round(time.time() - t0, 2)
         except capi.GaibError as e:
             link = {"error": str(e)[:200]}
-    # the partition-mode rule (LearningGraph::partition_mode) prices the exchange per peer pair: with the MEASURED link rate
-    # where there is one (every rank gets rank 0's figure before any partitioned graph exists), else the library's default
-    got = [link["unidirectional_gbs"] if (rank == 0 and isinstance(link, dict) and "unidirectional_gbs" in link) else None]
+    got = [link.get("unidirectional_gbs") if rank == 0 else None]
     dist.broadcast_object_list(got, src=0)
-    if got[0] and "GAIB_LINK_GBS" not in os.environ:
-        os.environ["GAIB_LINK_GBS"] = f"{float(got[0]):.1f}"
-    dist.barrier()
-    strong = getattr(args, "scaling", "weak") == "strong"
-    cut = 0.1 if args.cut_fraction is None else args.cut_fraction
-    extra = clustered = config5 = cpu_rec = parity_scaled = None
-    t_case = time.time()
-    if strong:
-        sg = synth.make("ogbn-products", seed=42, device="cuda", scale=args.scale)
-        g0 = ctx.graph(sg.rowptr, sg.colidx)
-        g1 = g0.add_selfloop()  # GCN aggregates over A + I (net.cpp:96)
-        g0.close()
-        rp_all, ci_all = g1.rowptr(), g1.colidx().to(torch.int64)
-        n_global = g1.nv
-        g1.close()
-        b = partition_bounds(n_global, world)
-        lo, hi = b[rank], b[rank + 1]
-        e0, e1 = int(rp_all[lo]), int(rp_all[hi])
-        rows = synth.BlockRows((rp_all[lo:hi + 1] - e0).contiguous(), ci_all[e0:e1].contiguous(), n_global, hi - lo)
-        del rp_all, ci_all, sg
-        torch.cuda.empty_cache()
-        assert not papers, "--scaling strong partitions the single-GPU products graph; gcn-papers is defined per range"
-        main = _bench_case(ctx, comm, args, rank, world, D, log, rows, "strong scaling, products graph")
-        workload = (f"the single-GPU bench's ogbn-products-shaped graph (seed 42, random vertex order) partitioned into "
-                    f"{world} vertex ranges, GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
-        cut_main = (world - 1) / world
+    if "GAIB_LINK_GBS" in os.environ:
+        LINK_GBS_SOURCE["source"] = "GAIB_LINK_GBS from the environment"
+    elif got[0]:
+        # (the slowest link seen decides: the rule prices the pair that moves the most rows)
+        slow = min([got[0]] + (list(link.get("unidirectional_gbs_from_0_to", {}).values()) if rank == 0 else []))
+        slow_b = [slow]
+        dist.broadcast_object_list(slow_b, src=0)
+        os.environ["GAIB_LINK_GBS"] = f"{float(slow_b[0]):.1f}"
+        LINK_GBS_SOURCE["source"] = "config.xgmi_link_probe of this run (slowest link from device 0, one direction), set before the first partition was built"
     else:
-        rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
-                                selfloops=True)  # GCN aggregates over A + I (net.cpp:96)
-        main = _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}", check=mk(cut))
-        del rows
-        torch.cuda.empty_cache()
-        cut_main = cut
-        if papers:
-            workload = (f"BASELINE config 5: block Chung-Lu graph of {world} vertex range(s), each 1/8 of the ogbn-papers100M "
-                        f"shape (seed 42; N = 8: 111 M vertices, 3.2 G edges), GCN hidden layer 128->128 fwd+bwd, halo "
-                        f"exchange before each SpMM + dW all-reduce")
-        else:
-            workload = ("block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
-                        "GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
-    headline_s = time.time() - t_case  # set-up + warm-up + timed steps + diagnostics of one case of this size
+        LINK_GBS_SOURCE["source"] = "the library's default (100 GB/s per peer pair): no link was probed in this run"
+    dist.barrier()
+    strong = getattr(args, "scaling", "strong") == "strong" and not papers
+    cut = 0.1 if args.cut_fraction is None else args.cut_fraction
+    default_run = args.cut_fraction is None and world > 1 and not papers
+    extra = clustered = config5 = cpu_rec = parity_scaled = None
+    other = None          # the sub-record of the scaling mode that is not the headline
+    strong_extra = {}     # one-rank timing of the same graph, speedup (strong case)
+    ab = {"cu_reserve_ab": None, "transport_ab": None}
+    state = {"main": None, "headline_s": 0.0}
 
     def sub_record(r, **more):
         return {"value": r["value"], "ms_per_step": r["ms_per_step"], "halo_rows_total": r["halo_rows_total"],
                 "halo_bytes_per_step_total": r["halo_bytes_per_step_total"], "halo_exchange_standalone_ms": r["exch_ms"],
                 "halo_pack_ms": r["pack_ms"], "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"],
+                "cut_fraction_measured": r["cut_fraction_measured"],
                 "breakdown_ms_per_step_rank0": r["breakdown"], "partition_mode_rank0": r["partition_mode"], **more}
 
+    strong_workload = (f"the single-GPU bench's ogbn-products-shaped graph (seed 42, random vertex order) partitioned into "
+                       f"{world} vertex ranges, GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
+    if papers:
+        weak_workload = (f"BASELINE config 5: block Chung-Lu graph of {world} vertex range(s), each 1/8 of the ogbn-papers100M "
+                         f"shape (seed 42; N = 8: 111 M vertices, 3.2 G edges), GCN hidden layer 128->128 fwd+bwd, halo "
+                         f"exchange before each SpMM + dW all-reduce")
+    else:
+        weak_workload = ("block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
+                         "GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
+
+    def strong_rows():
+        """this rank's rows of the single-GPU bench graph (every rank generates the whole graph: seeded, identical) and, on
+        rank 0, the one-rank timing of the same layer on the whole graph (the denominator of speedup_vs_n1) while the full
+        CSR is on the device anyway"""
+        sg = synth.make("ogbn-products", seed=42, device="cuda", scale=args.scale)
+        g0 = ctx.graph(sg.rowptr, sg.colidx)
+        g1 = g0.add_selfloop()  # GCN aggregates over A + I (net.cpp:96)
+        g0.close()
+        del sg
+        rp_all, ci_all = g1.rowptr(), g1.colidx()  # (copies)
+        n_global = g1.nv
+        b = partition_bounds(n_global, world)
+        lo, hi = b[rank], b[rank + 1]
+        e0, e1 = int(rp_all[lo]), int(rp_all[hi])
+        rows = synth.BlockRows((rp_all[lo:hi + 1] - e0).contiguous(), ci_all[e0:e1].to(torch.int64).contiguous(), n_global, hi - lo)
+        del rp_all, ci_all
+        torch.cuda.empty_cache()
+        one = None
+        if rank == 0 and os.environ.get("GAIB_BENCH_ONE_RANK", "1") != "0":
+            try:
+                one = _one_rank_timing(ctx, g1, args, D)  # (takes the graph over and closes it)
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline record
+                one = {"error": f"{type(e).__name__}: {e}"[:200]}
+            torch.cuda.empty_cache()
+        else:
+            g1.close()
+        dist.barrier()  # (the others wait here for rank 0's one-rank timing: the cases start together)
+        return rows, b, one
+
+    def ab_legs(case, res):
+        """the run measures its own constants on the live headline case: each leg budgeted, each
+        {"skipped": reason} where it would not measure anything"""
+        force = os.environ.get("GAIB_BENCH_AB", "") == "force"  # rehearsals / tests: run the bookkeeping on a shared device too
+        if os.environ.get("GAIB_BENCH_AB", "1") == "0" or not default_run:
+            return
+        step_s = max(res["ms_per_step"] * 1e-3, 1e-3)
+        # (b) CUs left to the transport
+        need = min(20.0, 3 * 8 * step_s + 3)
+        if share and not force:
+            ab["cu_reserve_ab"] = {"skipped": "ranks share a device: the transport and the fused kernel would compete for the same CUs whatever is reserved"}
+        elif comm is None:
+            ab["cu_reserve_ab"] = {"skipped": "torch.distributed carries the rows: no GAIB_OVERLAPS_TRANSFER launches"}
+        elif not budget.agree(need):
+            ab["cu_reserve_ab"] = budget.skipped(need)
+        else:
+            ab["cu_reserve_ab"] = case.cu_reserve_ab(steps=max(3, min(8, int(5.0 / step_s))))
+            if share:
+                ab["cu_reserve_ab"]["ranks_share_device"] = True
+        # (c) the same plan over RCCL and over the peer-to-peer pull
+        need = 20.0
+        if comm is None:
+            ab["transport_ab"] = {"skipped": "torch.distributed carries the rows: no gaib_comm plan to re-time"}
+        elif not budget.agree(need):
+            ab["transport_ab"] = budget.skipped(need)
+        else:
+            mine = "rccl" if transport.startswith("gaib_comm/rccl") else "ipc"
+            tr = {mine: comm}
+            made = None
+            other_t, other_name = (capi.COMM_IPC, "ipc") if mine == "rccl" else (capi.COMM_RCCL, "rccl")
+            if other_name == "rccl":
+                ok, why = rccl_possible(ctx, world)
+                if not ok:
+                    tr["rccl"] = (None, why)
+                elif "rccl" in transport:  # "gaib_comm/ipc (after rccl failed at set-up)": do not walk into the same failure twice
+                    tr["rccl"] = (None, "RCCL failed at set-up in this run")
+            if other_name not in tr:
+                made, err = comm_attempt(ctx, rank, world, other_t)
+                tr[other_name] = made if made is not None else (None, f"set-up failed: {err}"[:200])
+            try:
+                ab["transport_ab"] = {"plan": "the headline case's send / receive lists, [nv x 128] fp32, pack + transfer + wait",
+                                      "carried_the_run": mine, **case.transport_ab(tr)}
+                if share:
+                    ab["transport_ab"]["ranks_share_device"] = True
+            finally:
+                if made is not None:
+                    torch.cuda.synchronize()
+                    made.close()
+        if hold is not None and rank == 0:
+            hold(assemble())
+
+    def run_strong(on_measured, check, extras=None):
+        rows, bounds, one = strong_rows()
+        r = _bench_case(ctx, comm, args, rank, world, D, log, rows, "strong scaling, products graph",
+                        check=check(bounds) if check is not None else None, on_measured=on_measured, extras=extras)
+        if one is not None:
+            strong_extra["one_rank_same_graph"] = one
+            if "value" in one:
+                strong_extra["speedup_vs_n1"] = r["value"] / one["value"]
+                strong_extra["speedup_vs_n1_of"] = ("this case's value over the one-rank timing of the same layer on the whole graph, "
+                                                    "taken on rank 0's device in this run before the graph was partitioned")
+        return r
+
+    def run_weak(on_measured, check):
+        rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
+                                selfloops=True)  # GCN aggregates over A + I (net.cpp:96)
+        return _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}", check=check, on_measured=on_measured)
+
     def assemble():
+        main = state["main"]
         achieved = main["alg_bytes"] / (main["avg_ms"] * 1e-3) / 1e9 if main["avg_ms"] > 0 else 0.0
         rccl_ranks = comm.size if (comm is not None and transport.startswith("gaib_comm/rccl")) else 0
-        parity = main["parity"] if main["parity"] is not None else parity_scaled
+        parity = main["parity"] if main["parity"] is not None else (None if strong else parity_scaled)
+        if strong and parity_scaled is not None:
+            parity = {**(parity or {"ok": None, "reason": "the comparison of the strong case did not run"}),
+                      "weak_generator_scaled": parity_scaled}
+            if parity_scaled.get("ok") is False:
+                parity["ok"] = False
         if isinstance(extra, dict) and "value" in extra:
             rp = extra.get("parity")
             if parity is not None and rp is not None:
-                parity = {**parity, "random_order": rp, "ok": bool(parity["ok"] and rp["ok"])}
+                parity = {**parity, "random_order": rp, "ok": (None if parity.get("ok") is None else bool(parity["ok"] and rp.get("ok")))}
         rec = {"parity": parity} if parity is not None else {}
         # L2 -> fabric bytes per launch of the dominant kernel, where a PMC pass of exactly this kernel on exactly this shard
         # exists (bench.py: profiles/hbm_traffic.json, verified by source hashes): the owned-column pass of the split on the
         # products-shaped range at cut 0.1, uniform generator -- the same 113.6 M own-column edges at every N
         traffic, traffic_src = None, "no PMC pass of this kernel on this shard"
-        if (traffic_of is not None and not strong and not papers and args.scale == 1.0 and abs(cut_main - 0.1) < 1e-9
+        if (traffic_of is not None and not strong and not papers and args.scale == 1.0 and abs(cut - 0.1) < 1e-9
                 and main["partition_mode"]["mode"] == "split" and main["kernel_name"].startswith("spmm_w64_kernel")):
             traffic, traffic_src = traffic_of("spmm_w64_kernel_owned_pass_bytes_per_launch", "partitioned_products_uniform")
+        strong_rec = ({**sub_record(main, workload=strong_workload), **strong_extra} if strong else other)
+        weak_rec = (other if strong else sub_record(main, workload=weak_workload, cut_fraction=cut))
         rec.update({
             "metric": "GCN-layer fwd+bwd aggregated edges/sec",
             "value": main["value"],
@@ -758,14 +989,18 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             "warmup": args.warmup,
             "ms_per_step": main["ms_per_step"],
             "higher_is_better": True,
+            # strong: ONE graph (the N = 1 bench's), partitioned N ways -- north_star's "edges/sec reported at 1/2/4/8 MI355X" on
+            # ogbn-products; total work fixed as N grows.  weak (--scaling weak, and config 5): a new products-shaped range per GPU
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": workload,
+                "workload": strong_workload if strong else weak_workload,
                 "nv_per_gpu": main["nv"], "ne_total_with_selfloops": int(main["total_edges"]), "D": D, "scale": args.scale,
-                "cut_fraction": cut_main, "boundary": "uniform (a cut edge may end at any vertex of the two ranges)",
+                "cut_fraction": (world - 1) / world if strong else cut,
+                "cut_fraction_measured": main["cut_fraction_measured"],
+                "boundary": "uniform (a cut edge may end at any vertex of the two ranges)",
                 "halo_rows_total": main["halo_rows_total"],
                 "halo_bytes_per_step_total": main["halo_bytes_per_step_total"],
                 # slowest rank, measured after the timed region: one exchange on its own (pack + all-to-all + wait), the
@@ -777,32 +1012,83 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 "parallelism": f"vertex-range x{world}",
                 # rccl_ranks: what ncclCommCount reports for the communicator that carried the halo rows (0: RCCL not used)
                 "transport": transport, "rccl_ranks": rccl_ranks,
-                # CUs the persistent fused aggregation leaves free while an exchange is in flight (gaib_comm_init: 32 under
-                # RCCL with more than one rank -- 1.5 % of that kernel, DESIGN 3.5 --, 0 on the peer-to-peer pull transport)
+                # transports whose set-up hit its deadline on some rank (the call is then left behind in a helper thread and the
+                # run continued over the next transport: not a clean figure); [] in a clean run
+                "comm_init_timed_out": comm_timed_out,
+                # several ranks on one device (a one-GPU box rehearsing the N-rank code): every timing of this record is then
+                # ranks taking turns on one chip -- NOT evidence of scaling, of a roofline fraction or of anything else
+                "ranks_share_device": share,
+                # CUs the persistent fused aggregation leaves free while an exchange is in flight (the effective figure: option,
+                # GAIB_COMM_RESERVE_CUS or the communicator's default -- 32 under RCCL with more than one rank, 0 on the peer-to-peer pull)
                 "cu_reserve_for_transport": ctx.get_option("comm_reserve_cus"),
-                # the same cut with the cut edges on a boundary band (what a METIS / breadth-first partition looks like)
+                # north_star's curve: the N = 1 bench graph partitioned N ways (the headline itself under --scaling strong)
+                "strong_products": strong_rec,
+                # one products-shaped vertex range per GPU at cut 0.1 (the headline itself under --scaling weak)
+                "weak_products_range": weak_rec,
+                # the run's own constants, measured on the live headline case
+                "cu_reserve_ab": ab["cu_reserve_ab"], "transport_ab": ab["transport_ab"],
+                # the weak case's cut with the cut edges on a boundary band (what a METIS / breadth-first partition looks like)
                 "clustered_boundary": clustered,
-                # the other end of the partition-quality axis, same invocation (weak scaling only)
+                # the other end of the weak case's partition-quality axis, same invocation
                 "random_order": {k: v for k, v in extra.items() if k != "parity"} if isinstance(extra, dict) else extra,
                 "config5_papers100M": config5,
                 "xgmi_link_probe": link,
-                "budget": {"budget_s": budget.total_s, "elapsed_s": round(budget.elapsed(), 1), "headline_case_s": round(headline_s, 1)},
+                "budget": {"budget_s": budget.total_s, "elapsed_s": round(budget.elapsed(), 1), "headline_case_s": round(state["headline_s"], 1)},
             },
             "roofline": {
                 "bound": "hbm", "kernel": main["kernel_name"],
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": main["alg_bytes"], "avg_launch_ms": main["avg_ms"], "launches": main["launches"],
+                **({"ranks_share_device": True, "note": "ranks took turns on ONE device: this launch time includes waiting for the "
+                    "other ranks' kernels and is not a roofline measurement"} if share else {}),
             },
             # the N = 1 workload's CPU baseline (named as such), timed on rank 0's host cores in this run
-            "cpu_baseline": cpu_rec,
+            "cpu_baseline": cpu_rec if cpu_rec is not None else ({"skipped": "--no-cpu-baseline"} if cpu_leg is None else None),
         })
         return rec
 
+    def on_headline(res):
+        state["main"] = res
+        state["headline_s"] = time.time() - t_case
+        if hold is not None and rank == 0:
+            hold(assemble())  # from here on the headline value cannot be lost
+
+    # the comparison of the strong case with the oracle's run on the bench graph: budgeted like every other leg (rank 0 spends
+    # ~30 s of host time at full size: inputs of all ranks, the oracle's layer, the scatter of its rows), and its timing of the
+    # oracle IS the N = 1 workload's CPU baseline
+    def strong_check_budgeted(bounds):
+        if strong_check is None:
+            return None
+        chk = strong_check(comm, bounds)
+        need = 25.0 + 60.0 * min(args.scale, 1.0)
+
+        class Budgeted:
+            inputs = staticmethod(chk.inputs)
+            exchanger = None
+
+            def __call__(self_, part, layer, feat_out, grad_out):
+                if not budget.agree(need):
+                    return budget.skipped(need) if rank == 0 else None
+                chk.exchanger = self_.exchanger
+                return chk(part, layer, feat_out, grad_out)
+
+        return Budgeted()
+
+    t_case = time.time()
+    if strong:
+        main = run_strong(on_headline, strong_check_budgeted if strong_check is not None else None, extras=ab_legs)
+        if rank == 0 and isinstance(main.get("parity"), dict) and main["parity"].get("cpu_baseline"):
+            cpu_rec = main["parity"].pop("cpu_baseline")
+    else:
+        main = run_weak(on_headline, mk(cut))
+        torch.cuda.empty_cache()
+    state["main"] = main
+    headline_s = state["headline_s"]
     if hold is not None and rank == 0:
-        hold(assemble())  # from here on the headline value cannot be lost
+        hold(assemble())
     # ---- what follows only adds to the record; every sub-case is budgeted --------------------------------------------
-    if cpu_leg is not None:
+    if cpu_leg is not None and cpu_rec is None:
         need = 45.0
         if budget.agree(need):
             if rank == 0:
@@ -815,14 +1101,36 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             cpu_rec = budget.skipped(need)
         if hold is not None and rank == 0:
             hold(assemble())
-    weak_default = not strong and args.cut_fraction is None and world > 1
     if os.environ.get("GAIB_BENCH_FAIL_AFTER_HEADLINE") == str(rank):  # test hook: this rank fails in a sub-case (tests/test_gpu_dist.py)
         raise RuntimeError("GAIB_BENCH_FAIL_AFTER_HEADLINE: injected failure after the headline case")
-    if parity_check is not None and not strong and world > 1 and main["parity"] is None:
+    # ---- second: the other scaling mode (a default run) --------------------------------------------------
+    if default_run and os.environ.get("GAIB_BENCH_OTHER_SCALING", "1") != "0":
+        need = 1.3 * headline_s + 15
+        if budget.agree(need):
+            if strong:
+                r = run_weak(None, None)
+                other = sub_record(r, workload=weak_workload, cut_fraction=cut, nv_per_gpu=r["nv"],
+                                   ne_total_with_selfloops=int(r["total_edges"]))
+                weak_headline_s = time.time() - t_case - headline_s
+            else:
+                r = run_strong(None, None)
+                other = {**sub_record(r, workload=strong_workload, cut_fraction=(world - 1) / world, nv_per_gpu=r["nv"],
+                                      ne_total_with_selfloops=int(r["total_edges"])), **strong_extra}
+            torch.cuda.empty_cache()
+        else:
+            other = budget.skipped(need)
+        if hold is not None and rank == 0:
+            hold(assemble())
+    # what the weak sub-cases below cost: a case of the weak generator's size (the headline's under --scaling weak)
+    weak_s = headline_s if not strong else (weak_headline_s if (isinstance(other, dict) and "value" in other) else 2.0 * headline_s + 5)
+    weak_default = args.cut_fraction is None and world > 1  # (config 5's workload included: it has the same sub-cases)
+    weak_parity = parity_check is not None and world > 1 and (strong or main["parity"] is None)
+    if weak_parity:
         # element-wise against the oracle's GLOBAL run, at a global size the oracle finishes in seconds: 4.9 M vertices in all
         import argparse
 
-        scale_p = min(args.scale, 4.9e6 * args.scale / max(world * main["nv"], 1))
+        nv_weak = max(int(synth.SHAPES[shape][0] * args.scale), 16)
+        scale_p = min(args.scale, 4.9e6 * args.scale / max(world * nv_weak, 1))
         need = 75.0
         if budget.agree(need):
             a2 = argparse.Namespace(**{**vars(args), "scale": scale_p, "steps": 2, "warmup": 1})
@@ -832,7 +1140,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             if rank == 0:
                 parity_scaled = {**(r["parity"] or {"error": "no record", "ok": None}), "scale": scale_p,
                                  "partition_mode_rank0": r["partition_mode"]["mode"],
-                                 "of": f"the partitioned layer of this run ({world} ranks, {transport}) on the same generator at scale "
+                                 "of": f"the partitioned layer of this run ({world} ranks, {transport}) on the weak generator at scale "
                                        f"{scale_p:.3f} ({r['nv']} vertices per rank), not part of `value`"}
             del rows
             torch.cuda.empty_cache()
@@ -856,7 +1164,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         if hold is not None and rank == 0:
             hold(assemble())
     if weak_default and os.environ.get("GAIB_BENCH_CLUSTERED", "1") != "0":
-        need = 1.2 * headline_s + 10
+        need = 1.2 * weak_s + 10
         if budget.agree(need):
             rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
                                     selfloops=True, boundary="clustered", band=0.2)
@@ -871,7 +1179,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             hold(assemble())
     if weak_default and os.environ.get("GAIB_BENCH_RANDOM_ORDER", "1") != "0":
         rcut = (world - 1) / world
-        need = 1.6 * headline_s + 10  # (the halo of a random order is several times the headline's: longer set-up and exchanges)
+        need = 1.6 * weak_s + 10  # (the halo of a random order is several times the headline's: longer set-up and exchanges)
         if budget.agree(need):
             rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=rcut, device="cuda",
                                     scale=args.scale, selfloops=True)
@@ -887,8 +1195,8 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     # the papers100M-shaped graph, so the scaling run that measures the metric's "1/2/4/8" half also yields config 5's number
     # (locality-preserving end of the partition axis; `--workload gcn-papers` gives both ends).  GAIB_BENCH_CONFIG5=0 skips.
     c5 = os.environ.get("GAIB_BENCH_CONFIG5", "1")  # "force": also at other N / scales (the one-GPU test of this branch)
-    if not papers and not strong and args.cut_fraction is None and ((world == 8 and args.scale == 1.0 and c5 != "0") or c5 == "force"):
-        need = 4.5 * headline_s + 20  # 5.7 x the rows, 3.3 x the edges of a products-shaped range
+    if not papers and args.cut_fraction is None and ((world == 8 and args.scale == 1.0 and c5 != "0") or c5 == "force"):
+        need = 4.5 * weak_s + 20  # 5.7 x the rows, 3.3 x the edges of a products-shaped range
         if not budget.agree(need):
             config5 = budget.skipped(need)
         else:
@@ -913,3 +1221,34 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     if comm is not None:
         comm.barrier()
     return assemble()
+
+
+def _one_rank_timing(ctx, g1, args, D) -> dict:
+    """the single-GPU layer (the N = 1 bench's step) on the whole graph `g1`, args.steps steps after args.warmup: what
+    `speedup_vs_n1` of the strong case divides by.  The graph moves into the layer's LearningGraph and goes with it."""
+    from . import layers as L
+
+    nv, ne = g1.nv, g1.ne
+    lg = L.LGraph.adopt(g1)
+    layer = L.Layer(L.GCN, 1, nv, D, D, lg, act=True, lr=0.01)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(43)
+    layer.write(L.FEAT_IN, torch.randn(nv, D, device="cuda", generator=gen))
+    layer.write(L.GRAD_IN, torch.randn(nv, D, device="cuda", generator=gen))
+    fo, go = torch.empty(nv, D, device="cuda"), torch.empty(nv, D, device="cuda")
+    for _ in range(args.warmup):
+        layer.forward(fo)
+        layer.backward(fo, go)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        layer.forward(fo)
+        layer.backward(fo, go)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    layer.close()
+    lg.close()
+    del fo, go
+    torch.cuda.empty_cache()
+    return {"value": 2 * ne * args.steps / el, "ms_per_step": el / args.steps * 1e3, "steps": args.steps,
+            "of": "the single-GPU GCN layer step on the whole graph, rank 0's device, while the other ranks wait"}

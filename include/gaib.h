@@ -200,7 +200,9 @@ int gaib_spmm_acc(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_
 #define GAIB_OVERLAPS_TRANSFER 8 /* gaib_spmm_gemm*: a halo exchange is in flight on the communicator's stream while this call
                                   * runs (between gaib_halo_exchange_begin and _end).  The fused kernel is one persistent
                                   * workgroup per CU that holds the CU's registers until its last tile; under RCCL it then leaves
-                                  * "comm_reserve_cus" CUs (32, set by gaib_comm_init; option) to the send / recv kernels */
+                                  * "comm_reserve_cus" CUs to the send / recv kernels: the option (or GAIB_COMM_RESERVE_CUS) where one is set
+                                  * -- an explicit 0 included, -1 = unset --, else gaib_comm_init's default for its transport (32
+                                  * under RCCL with > 1 rank, 0 on the peer-to-peer pull); at most num_cus - 64 */
 int gaib_spmm_ex(gaib_ctx* ctx, gaib_graph* g, int weight_kind, const float* d_edge_w, int len,
                  const float* d_in, float* d_out, int flags);
 /* multi-head attention weights: d_edge_w is [ne][heads]; column c uses head c / (len/heads).
@@ -586,7 +588,8 @@ int gaib_probe_peer_copy(int src_dev, int dst_dev, size_t bytes, int iters, int 
 
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ---- */
 int gaib_set_option(gaib_ctx* ctx, const char* key, int64_t value);
-/* what a record wants to name: "comm_reserve_cus" (CUs the fused kernel leaves to the transport, set by gaib_comm_init),
+/* what a record wants to name: "comm_reserve_cus" (CUs the fused kernel leaves to the transport: the EFFECTIVE figure -- option,
+ * environment or the communicator's default, clamped; "comm_reserve_cus_raw": what the caller set, -1 = unset),
  * "spmm_fuse_cus", "spmm_flat_ring", "num_cus" */
 int gaib_get_option(gaib_ctx* ctx, const char* key, int64_t* h_value);
 

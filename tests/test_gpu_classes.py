@@ -292,6 +292,21 @@ def test_class_graph_refusals(ctx):
         ctx.spmm_gemm(c["interior"], capi.W_GCN, xo, out, W, y)
     with pytest.raises(capi.GaibError):  # class graphs are not split again
         ctx.split_classes(c["interior"], c["bnd_halo"])
+    # two products whose matrices do not fit LDS together (SAGE 100 -> 256): on a WHOLE graph the self term follows as an
+    # accumulating GEMM over rows [0, nv); a row class (row map / second table) must be refused, not computed over the wrong
+    # rows (the split used to run before the class check)
+    assert ctx.spmm_gemm_fusable(capi.W_MEAN, 100, 256) and not ctx.spmm_gemm_fusable(capi.W_MEAN, 100, 256, dual=True)
+    x1 = feat(g_o.nv, 100, 3)
+    xo1, xh1 = s.tables(x1)
+    W1, W2 = dev(feat(100, 256, 4)), dev(feat(100, 256, 5))
+    agg1 = torch.empty(s.n, 100, device="cuda")
+    y1 = torch.full((s.n, 256), 7.0, device="cuda")
+    with pytest.raises(capi.GaibError, match="fusable"):
+        ctx.spmm_gemm(c["interior"], capi.W_MEAN, xo1, agg1, W1, y1, rows2=xo1, W2=W2)
+    with pytest.raises(capi.GaibError, match="fusable"):
+        ctx.spmm_gemm_2t(c["bnd_full"], capi.W_MEAN, xo1, xh1, s.n, agg1, W1, y1, rows2=xo1, W2=W2)
+    ctx.sync()
+    assert bool((y1 == 7.0).all())  # nothing was written on the way to the refusal
 
 
 def test_two_tables_larger_than_the_buffer_range(ctx):

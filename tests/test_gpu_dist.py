@@ -111,12 +111,24 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
     assert cfg["transport"].startswith(want), cfg["transport"]
     assert cfg["rccl_ranks"] == 0 and "xgmi_link_probe" in cfg  # one GPU here: no RCCL ranks, no link to probe
     assert cfg["halo_exchange_standalone_ms"] > 0 and cfg["halo_bytes_per_step_total"] > 0
+    # round 5: whichever mode is `value`, the other is a sub-record of the same invocation, and north_star's curve (the N = 1
+    # bench graph partitioned N ways) is under config.strong_products either way
+    sp, wk = cfg["strong_products"], cfg["weak_products_range"]
+    for rec in (sp, wk):
+        assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["halo_bytes_per_step_total"] > 0
+        assert rec["halo_exchange_standalone_ms"] > 0 and rec["partition_mode_rank0"]["mode"] in ("split", "classes", "onepass")
+    assert sp["one_rank_same_graph"]["value"] > 0 and sp["speedup_vs_n1"] == pytest.approx(sp["value"] / sp["one_rank_same_graph"]["value"])
+    assert 0.4 < sp["cut_fraction_measured"] < 0.6 and 0.05 < wk["cut_fraction_measured"] < 0.15
+    assert cfg["ranks_share_device"] is True and res["roofline"]["ranks_share_device"] is True
+    assert "skipped" in cfg["xgmi_link_probe"] and cfg["comm_init_timed_out"] == []
+    # both ends of the weak case's partition-quality axis in the same invocation
+    assert cfg["random_order"]["cut_fraction"] == 0.5 and cfg["random_order"]["value"] > 0
+    assert cfg["random_order"]["halo_rows_total"] > wk["halo_rows_total"]
     if scaling == "weak":
-        # both ends of the partition-quality axis in one invocation
-        assert cfg["cut_fraction"] == 0.1 and cfg["random_order"]["cut_fraction"] == 0.5
-        assert cfg["random_order"]["value"] > 0 and cfg["random_order"]["halo_rows_total"] > cfg["halo_rows_total"]
+        assert cfg["cut_fraction"] == 0.1 and res["value"] == wk["value"]
     else:
-        assert cfg["cut_fraction"] == 0.5 and cfg["random_order"] is None
+        assert cfg["cut_fraction"] == 0.5 and res["value"] == sp["value"]
+    assert res["cpu_baseline"] == {"skipped": "--no-cpu-baseline"}
 
 
 def _clean_env():
@@ -181,18 +193,36 @@ def test_bench_plain_two_gpus_default_workload():
     bud = res["config"]["budget"]
     assert wall < bud["budget_s"] and bud["elapsed_s"] < bud["budget_s"] and "partial" not in res
     # the sub-records of the default run: the clustered-boundary generator next to the uniform one, the N = 1 CPU baseline
-    cl = res["config"]["clustered_boundary"]
-    assert cl["value"] > 0 and 0 < cl["halo_rows_total"] < res["config"]["halo_rows_total"]
-    assert cl["partition_mode_rank0"]["boundary_row_share"] < res["config"]["partition_mode_rank0"]["boundary_row_share"]
-    assert res["cpu_baseline"]["value"] > 0 and "N = 1 workload" in res["cpu_baseline"]["of"]
-    # round 4: the default N > 1 record carries a parity block -- every rank's rows against the oracle's GLOBAL run on a leg of
-    # bounded size over the same transport
+    cfg = res["config"]
+    # round 5: `value` is north_star's curve -- the N = 1 bench graph partitioned N ways -- and the record says so;
+    # config.strong_products names it with the one-rank timing of the same graph taken in the run; the weak case runs second
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and cfg["transport"].startswith("gaib_comm/")
+    sp, wk = cfg["strong_products"], cfg["weak_products_range"]
+    assert sp["value"] == res["value"] and sp["ms_per_step"] == res["ms_per_step"] and "partitioned into 2 vertex ranges" in sp["workload"]
+    assert sp["halo_bytes_per_step_total"] > 0 and sp["halo_exchange_standalone_ms"] > 0 and sp["partition_mode_rank0"]["mode"]
+    assert sp["one_rank_same_graph"]["ms_per_step"] > 0 and sp["speedup_vs_n1"] > 0
+    assert wk["value"] > 0 and wk["cut_fraction"] == 0.1 and 0 < wk["halo_rows_total"]
+    cl = cfg["clustered_boundary"]
+    assert cl["value"] > 0 and 0 < cl["halo_rows_total"] < wk["halo_rows_total"]
+    assert cl["partition_mode_rank0"]["boundary_row_share"] < wk["partition_mode_rank0"]["boundary_row_share"]
+    # the strong case's comparison is the oracle's run on the WHOLE bench graph: its timing is the N = 1 workload's CPU baseline
+    assert res["cpu_baseline"]["value"] > 0 and "N = 1 workload" in res["cpu_baseline"]["of"] and "whole" in res["cpu_baseline"]["sample"]
     par = res["parity"]
     assert par["ok"] is True and par["forward"]["elem"] <= 1e-4 and par["grad_out"]["elem"] <= 1e-4 and par["W_grad"]["inf"] <= 1e-4
-    assert par["scale"] <= 0.02 and "GLOBAL graph" in par["against"] and "2 ranks" in par["of"]
-    pc = par["clustered_boundary"]  # ... and on the clustered generator, through the row classes
+    assert "GLOBAL graph" in par["against"] and "cpu_baseline" not in par
+    # round 4's legs on the weak generator stay: every rank's rows against the oracle's GLOBAL run on a leg of bounded size
+    pw = par["weak_generator_scaled"]
+    assert pw["ok"] is True and pw["forward"]["elem"] <= 1e-4 and pw["scale"] <= 0.02 and "2 ranks" in pw["of"]
+    pc = pw["clustered_boundary"]  # ... and on the clustered generator, through the row classes
     assert pc["ok"] is True and pc["forward"]["elem"] <= 1e-4 and pc["partition_mode_rank0"] in ("classes", "onepass")
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["transport"].startswith("gaib_comm/")
+    # the run measures its own constants -- on a one-device box each slot says why it did not
+    if torch.cuda.device_count() < 2:
+        assert "skipped" in cfg["xgmi_link_probe"] and "skipped" in cfg["cu_reserve_ab"]
+        assert cfg["transport_ab"]["carried_the_run"] == "ipc" and cfg["transport_ab"]["ipc"]["exchange_standalone_ms"] > 0
+        assert "share devices" in cfg["transport_ab"]["rccl"]["skipped"]
+        assert cfg["ranks_share_device"] is True and res["roofline"]["ranks_share_device"] is True
+        assert "library's default" in cfg["partition_mode_rank0"]["link_gbs_source"]
+    assert cfg["comm_init_timed_out"] == []
     if torch.cuda.device_count() < 2:
         assert res["config"]["transport"].startswith("gaib_comm/ipc") and res["config"]["rccl_ranks"] == 0
     else:
@@ -200,6 +230,28 @@ def test_bench_plain_two_gpus_default_workload():
     c5 = res["config"]["config5_papers100M"]
     assert c5["value"] > 0 and c5["halo_rows_total"] > 0 and "config 5" in c5["workload"]
     assert c5["nv_per_gpu"] == int(13_882_495 * 0.02)
+
+
+def test_bench_ab_legs_bookkeeping_on_a_shared_device():
+    """the A/B legs of the run's own constants (config.cu_reserve_ab, config.transport_ab) with their bookkeeping forced on a
+    one-device box (GAIB_BENCH_AB=force; 3 ranks): three timings of the headline step at 0 / 32 / 64 reserved CUs, the option back
+    where it was, the plan re-timed over the transport that carried the run, both stamped as taken on a shared device"""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-parity"], capture_output=True, text=True, timeout=900,
+                       env=dict(_clean_env(), GAIB_BENCH_AB="force", GAIB_BENCH_CLUSTERED="0", GAIB_BENCH_RANDOM_ORDER="0"))
+    assert r.returncode == 0, r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    cfg = res["config"]
+    ab = cfg["cu_reserve_ab"]
+    assert sorted(ab["ms_per_step"]) == ["0", "32", "64"] and all(v > 0 for v in ab["ms_per_step"].values())
+    assert ab["ranks_share_device"] is True and ab["in_effect_for_the_timed_steps"] == cfg["cu_reserve_for_transport"] == 0
+    assert ab["mode"] == cfg["partition_mode_rank0"]["mode"]
+    tb = cfg["transport_ab"]
+    assert tb["ipc"]["exchange_standalone_ms"] > 0 and "skipped" in tb["rccl"] and tb["ranks_share_device"] is True
+    assert res["n_gpus"] == 3 and cfg["strong_products"]["value"] == res["value"]
 
 
 @pytest.mark.parametrize("boundary", ["uniform", "clustered"])
@@ -264,6 +316,7 @@ def test_bench_n1_keeps_its_record_when_a_later_leg_fails():
     res = json.loads(out[0])
     assert res["value"] > 0 and res["n_gpus"] == 1 and "injected failure" in res["partial"]["reason"]
     assert res["roofline"]["avg_launch_ms"] > 0 and "cpu_baseline" not in res
+    assert res["parity"]["ok"] is None and "did not complete" in res["parity"]["reason"]  # unchecked is SAID
 
 
 def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
@@ -280,8 +333,8 @@ def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
     assert len(out) == 1
     res = json.loads(out[0])
     assert res["value"] > 0 and res["ms_per_step"] > 0
-    for slot in (res["cpu_baseline"], res["parity"], res["config"]["clustered_boundary"], res["config"]["random_order"],
-                 res["config"]["config5_papers100M"]):
+    for slot in (res["cpu_baseline"], res["parity"], res["config"]["weak_products_range"], res["config"]["clustered_boundary"],
+                 res["config"]["random_order"], res["config"]["config5_papers100M"]):
         assert slot["skipped"] == "budget" and slot["elapsed_s"] > 1 and slot["needed_s_estimate"] > 0, slot
 
 

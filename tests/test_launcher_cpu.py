@@ -239,6 +239,82 @@ def test_launcher_relays_the_held_record_when_it_is_signalled_itself(tmp_path):
         assert not _alive(int(f.read_text()))
 
 
+def test_record_survives_sigterm_when_native_threads_exist_before_the_guard(tmp_path):
+    """threads created BEFORE the signal mask (torch's OpenMP pool, HSA's event thread) keep SIGTERM unblocked at
+    SIG_DFL, the kernel hands a process-directed SIGTERM to one of them and the process dies without a record.  bench.main()
+    therefore blocks the signals as its first act in a rank process, before `import torch`; this program keeps that order
+    (mask -> torch + a matmul that spins up the pool -> guard -> hold -> C sleep) and must print the held record"""
+    import signal
+
+    prog = tmp_path / "rank.py"
+    prog.write_text(textwrap.dedent(f"""
+        import ctypes, os, signal, sys
+        signal.pthread_sigmask(signal.SIG_BLOCK, {{signal.SIGTERM, signal.SIGINT}})   # what bench.main() does first
+        sys.path.insert(0, {str(ROOT)!r})
+        import torch
+        torch.set_num_threads(8)
+        a = torch.randn(1024, 1024)
+        (a @ a).sum().item()                      # native worker threads exist from here on
+        import threading
+        n_native = len(os.listdir("/proc/self/task"))
+        import bench
+        g = bench.install_rank_guard(0, 500.0)
+        g.want_parity = True
+        g.hold({{"value": 13.0, "n_gpus": 1, "config": {{}}, "threads_before_guard": n_native}})
+        open(os.path.join(sys.argv[1], "ready"), "w").write(str(os.getpid()))
+        ctypes.CDLL(None).sleep(300)
+    """))
+    p = subprocess.Popen([sys.executable, str(prog), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while time.time() - t0 < 120 and not (tmp_path / "ready").exists():
+        time.sleep(0.1)
+    assert (tmp_path / "ready").exists(), p.stderr.read() if p.poll() is not None else "rank program did not get ready"
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)  # process-directed, like the launcher's / the driver's
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 0, (p.returncode, err)
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["value"] == 13.0 and "signal" in rec["partial"]["reason"]
+    assert rec["threads_before_guard"] > 1  # the situation the finding describes was really there
+    assert rec["parity"]["ok"] is None and "did not complete" in rec["parity"]["reason"]
+
+
+def test_bench_main_blocks_the_signals_before_it_imports_torch():
+    """the order in bench.main() itself (it cannot run here without a GPU): pthread_sigmask + the guard come before `import torch`"""
+    import inspect
+
+    import bench
+
+    src = inspect.getsource(bench.main)
+    i_mask, i_guard, i_torch = src.index("signal.pthread_sigmask(signal.SIG_BLOCK"), src.index("install_rank_guard("), src.index("import torch")
+    assert i_mask < i_guard < i_torch
+    assert src.index("launch_ranks(args") < i_mask  # the launcher parent keeps its signal HANDLERS: it never blocks
+
+
+def test_a_crashing_leg_after_the_headline_prints_the_record_and_exits_5(tmp_path):
+    """a leg that crashes after the measurement must not look like a passing run by exit status -- the held record
+    goes out (relayed by the launcher), the status is 5"""
+    body = f"""
+        import ctypes, os, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid{{r}}"), "w").write(str(os.getpid()))
+        g = bench.install_rank_guard(r, 500.0)
+        g.want_parity = True
+        if r == 0:
+            g.hold({{"value": 9.5, "n_gpus": 2, "config": {{}}}})
+            g.bail("RuntimeError: the parity leg crashed", status=5)
+        ctypes.CDLL(None).sleep(300)
+    """
+    r, took = _run_launcher(tmp_path, body, 2, deadline=400.0)
+    assert r.returncode == 5 and took < 60, (r.returncode, took, r.stderr)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 9.5 and rec["parity"]["ok"] is None and "crashed" in rec["partial"]["reason"]
+    for f in tmp_path.glob("pid*"):
+        assert not _alive(int(f.read_text()))
+
+
 def test_rank_guard_emits_exactly_one_line(tmp_path):
     """final() after hold(): one line, not marked partial; a bail() that races with it prints nothing more"""
     prog = tmp_path / "one.py"
