@@ -60,6 +60,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def start_heartbeat(who: str, every_s: float = 60.0) -> None:
+    """a line on stderr every minute: a harness that watches a run's output takes minutes of silence for a hang and kills the
+    run (the pool's limit is 7 minutes -- shorter than --deadline-s), and the oracle's legs on the host are silent for that long
+    at full size on few cores"""
+    def beat():
+        while True:
+            time.sleep(every_s)
+            log(f"[bench {who}] alive, {time.time() - T_START:.0f} s since start")
+
+    threading.Thread(target=beat, daemon=True, name="bench-heartbeat").start()
+
+
 def usable_cores() -> int:
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -735,6 +747,8 @@ def main():
     quiet_stdout()
     guard = install_rank_guard(int(os.environ.get("RANK", "0")), max(5.0, args.deadline_s - (time.time() - T_START)))
     guard.want_parity = not (args.no_parity or args.no_cpu_baseline) or args.check_oracle
+    if int(os.environ.get("RANK", "0")) == 0:
+        start_heartbeat("r0")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))

@@ -807,6 +807,53 @@ __global__ void gat_rec_kernel(int64_t n, const float* rowdot, const float2* sta
   }
 }
 
+// ---- lane layout of the one-sweep kernels, by row width (round 5: len = 32, 64 and 128) -------------------------------
+// A lane owns 4 columns of a row, so a row takes G = len / 4 lanes (8, 16, 32) and a wave works on NG = 64 / G edges at a
+// time, G steps per 64-edge chunk.  The chunk's column ids are fetched ONCE, one or two per lane, laid out so that "the
+// column of (my group, step t)" is a row-share DPP inside the lane's 16-lane row (no LDS, no bpermute):
+//   G = 16: 4 groups = the 4 DPP rows.  Lane (row r, position p) holds edge p*4 + r; (group r, step t) = edge t*4 + r.
+//   G =  8: 8 groups, two per DPP row (half hg = 0, 1).  Same holding; (group (r, hg), step t) = edge (2t + hg)*4 + r:
+//           two row-shares with constant lane numbers and a select on hg.
+//   G = 32: 2 groups of two DPP rows.  (group g, step t) = edge t*2 + g; every lane of the group's two rows holds TWO ids,
+//           edges p*2 + g and (p + 16)*2 + g (both rows load the same lines), so steps 0..15 come from the first, 16..31
+//           from the second.
+// In every layout the edges of step t are t*NG .. t*NG + NG - 1: a chunk of n edges takes ceil(n / NG) steps.
+template <int G>
+struct ChunkLanes {
+  static_assert(G == 8 || G == 16 || G == 32, "len = 32, 64 or 128");
+  static constexpr int NG = 64 / G;
+  // the edge whose id this lane holds (which = 1: the second one, G = 32 only)
+  static __device__ __forceinline__ int held_edge(int lane, int which) {
+    const int r = lane >> 4, p = lane & 15;
+    if constexpr (G == 32) return (p + 16 * which) * 2 + (r >> 1);
+    else return p * 4 + r;
+  }
+  // the edge of (this lane's group, step t)
+  static __device__ __forceinline__ int step_edge(int lane, int t) {
+    if constexpr (G == 32) return t * 2 + (lane >> 5);
+    else if constexpr (G == 16) return t * 4 + (lane >> 4);
+    else return (2 * t + ((lane >> 3) & 1)) * 4 + (lane >> 4);
+  }
+  // its held value (a column id, a reverse-edge id): t is a compile-time constant after unrolling
+  static __device__ __forceinline__ int step_value(int v0, int v1, int lane, int t) {
+    if constexpr (G == 32) return t < 16 ? row_lane(v0, t) : row_lane(v1, t - 16);
+    else if constexpr (G == 16) return row_lane(v0, t);
+    else {
+      const int a = row_lane(v0, 2 * t), b = row_lane(v0, 2 * t + 1);
+      return ((lane >> 3) & 1) ? b : a;
+    }
+  }
+};
+// lanes_sum over an aligned group of up to 32 lanes (LH = 32: one head over a 128-wide row)
+template <int LH>
+__device__ __forceinline__ float lanes_sum_w(float v) {
+  if constexpr (LH <= 16) return lanes_sum<LH>(v);
+  else {
+    v = lanes_sum<16>(v);
+    return v + __shfl_xor(v, 16, 64);
+  }
+}
+
 // ---- the whole edge side of GAT backward in ONE pass over the ordered 64-edge chunk list ---------------------------
 // GAT_Aggregator::d_aggregate (gat_aggregator.cpp:99-200) is four sweeps over the edges: SDDMM dp_e = <grad_i, h_c>;
 // softmax backward + leaky-relu' -> g_e, with the row sums rs and the column sums cs of g for the alpha gradients;
@@ -862,6 +909,8 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   // [x per_xcd, (x + 1) per_xcd) of the column-block-ordered chunk list, so each L2 sees its own eighth of the columns
   // instead of all eight L2s caching the same window.
   constexpr int LH = G / H;  // lanes per head
+  using CL = ChunkLanes<G>;
+  constexpr int NG = CL::NG;
   int64_t blk = blockIdx.x;
   if (per_xcd > 0) blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t c = blk * 4 + (threadIdx.x >> 6);
@@ -874,19 +923,27 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
 
-  // edge t * 4 + g of the chunk is step t of lane group g: a chunk of n edges takes ceil(n / 4) steps whatever n is (with
-  // group g on edges 16 g .. 16 g + 15, the 17-edge tail of a row took all 16).
-  // Lane (g, t) fetches that edge's column id, so "step t of my group" is lane t of my 16-lane row (DPP).
-  const int grp = lane >> 4;
-  const int my_e = sl * 4 + grp;
+  // step t of lane group g is edge t * NG + g (ChunkLanes): a chunk of n edges takes ceil(n / NG) steps whatever n is (with
+  // group g on edges 16 g .. 16 g + 15, the 17-edge tail of a row took all 16).  The lanes fetch the chunk's column ids
+  // once, laid out so that "the column of my group's step t" is a DPP row-share.
+  const int my_e = CL::held_edge(lane, 0), my_e1 = CL::held_edge(lane, 1);
   const int64_t el = eb + (my_e < n ? my_e : 0);
   const uint32_t cl = col[el];
+  uint32_t cl1 = 0;
+  int64_t el1 = eb;
+  if constexpr (G == 32) {
+    el1 = eb + (my_e1 < n ? my_e1 : 0);
+    cl1 = col[el1];
+  }
   // a rank's rows over [owned | halo] columns (a row keeps the global edge order, so halo ids sit on both sides of the
   // owned ones): phase 0 sweeps the chunks that touch owned columns only -- while the halo rows are still on the wire --,
   // phase 1 the others; -1: all
-  if (phase >= 0 && ((__ballot(my_e < n && cl >= own_cols) == 0) != (phase == 0))) return;
-  uint32_t rl = 0;
-  if constexpr (!RECOMP) rl = rev[el];
+  if (phase >= 0 && ((__ballot((my_e < n && cl >= own_cols) || (G == 32 && my_e1 < n && cl1 >= own_cols)) == 0) != (phase == 0))) return;
+  uint32_t rl = 0, rl1 = 0;
+  if constexpr (!RECOMP) {
+    rl = rev[el];
+    if constexpr (G == 32) rl1 = rev[el1];
+  }
   const int coff = sl * 4;  // len == 4 * G
   const int head = sl / LH;
   const f4 gi = *reinterpret_cast<const f4*>(grad + row * (int64_t)ld + coff);
@@ -902,8 +959,8 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   auto d4 = [](const f4& a, const f4& b) {
     return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
   };
-  const float sl_i = lanes_sum<LH>(d4(al4, hi));
-  const float sr_i = lanes_sum<LH>(d4(ar4, hi));
+  const float sl_i = lanes_sum_w<LH>(d4(al4, hi));
+  const float sr_i = lanes_sum_w<LH>(d4(ar4, hi));
   float rd_i;
   float2 st_i = {0.f, 0.f};
   if constexpr (RECOMP) {
@@ -917,14 +974,14 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   float s_e = 0.f, s_r = 0.f;
 #pragma unroll
   for (int j = 0; j < G; j += U) {
-    if (j * 4 >= n) break;  // (wave-uniform: no edge of the chunk is left for any group)
+    if (j * NG >= n) break;  // (wave-uniform: no edge of the chunk is left for any group)
     f4 xg[U], xh[U];
     float pe[U], pr[U], rd[U];
     float2 stc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int ei = (j + u) * 4 + grp;
-      const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
+      const int ei = CL::step_edge(lane, j + u);
+      const uint32_t cj = (uint32_t)CL::step_value((int)cl, (int)cl1, lane, j + u);
       xg[u] = *reinterpret_cast<const f4*>(grad + (int64_t)cj * ld + coff);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * ld + coff);
       if constexpr (RECOMP) {
@@ -933,7 +990,7 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
         stc[u] = float2{rc[1], rc[2]};
       } else {
         rd[u] = rowdot[(int64_t)cj * H + head];
-        const uint32_t rj = (uint32_t)row_lane((int)rl, j + u);
+        const uint32_t rj = (uint32_t)CL::step_value((int)rl, (int)rl1, lane, j + u);
         pe[u] = p[(eb + (ei < n ? ei : 0)) * H + head];
         pr[u] = p[(int64_t)rj * H + head];
       }
@@ -941,11 +998,11 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
     __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first one is consumed
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool live = (j + u) * 4 + grp < n;
-      const float dpe = lanes_sum<LH>(d4(gi, xh[u]));
-      const float dpr = lanes_sum<LH>(d4(xg[u], hi));
-      const float sl_c = lanes_sum<LH>(d4(al4, xh[u]));
-      const float sr_c = lanes_sum<LH>(d4(ar4, xh[u]));
+      const bool live = CL::step_edge(lane, j + u) < n;
+      const float dpe = lanes_sum_w<LH>(d4(gi, xh[u]));
+      const float dpr = lanes_sum_w<LH>(d4(xg[u], hi));
+      const float sl_c = lanes_sum_w<LH>(d4(al4, xh[u]));
+      const float sr_c = lanes_sum_w<LH>(d4(ar4, xh[u]));
       const float t_e = sl_i + sr_c, t_r = sl_c + sr_i;  // pre-activation scores of (i -> c) and (c -> i)
       float a, b;
       if constexpr (RECOMP) {
@@ -1001,6 +1058,8 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
     const int64_t* rowptr, const uint32_t* col, int len, const float* feat, const float* alpha_l, const float* alpha_r,
     float eps, float* out_partial, float2* ms_partial, int phase, uint32_t own_cols, int per_xcd) {
   constexpr int LH = G / H;
+  using CL = ChunkLanes<G>;
+  constexpr int NG = CL::NG;
   int64_t blk = blockIdx.x;  // (per_xcd: see gat_bwd_fused_chunk_kernel)
   if (per_xcd > 0) blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int64_t c = blk * 4 + (threadIdx.x >> 6);
@@ -1013,10 +1072,12 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
 
-  const int grp = lane >> 4;  // edge t * 4 + g = step t of lane group g (see the backward kernel)
-  const int my_e = sl * 4 + grp;
+  // step t of lane group g = edge t * NG + g; the column ids once, in DPP reach (ChunkLanes, see the backward kernel)
+  const int my_e = CL::held_edge(lane, 0), my_e1 = CL::held_edge(lane, 1);
   const uint32_t cl = col[eb + (my_e < n ? my_e : 0)];
-  if (phase >= 0 && ((__ballot(my_e < n && cl >= own_cols) == 0) != (phase == 0))) return;  // (see the backward kernel)
+  uint32_t cl1 = 0;
+  if constexpr (G == 32) cl1 = col[eb + (my_e1 < n ? my_e1 : 0)];
+  if (phase >= 0 && ((__ballot((my_e < n && cl >= own_cols) || (G == 32 && my_e1 < n && cl1 >= own_cols)) == 0) != (phase == 0))) return;
   const int coff = sl * 4;
   const int head = sl / LH;
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
@@ -1025,23 +1086,23 @@ __global__ __launch_bounds__(256) void gat_fwd_fused_chunk_kernel(
   auto d4 = [](const f4& a, const f4& b) {
     return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
   };
-  const float sl_i = lanes_sum<LH>(d4(al4, hi));  // (DPP sums / broadcasts, FMA chains: see the backward kernel)
+  const float sl_i = lanes_sum_w<LH>(d4(al4, hi));  // (DPP sums / broadcasts, FMA chains: see the backward kernel)
   float m = GAT_NEG, ssum = 0.f;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < G; j += U) {
-    if (j * 4 >= n) break;  // (wave-uniform)
+    if (j * NG >= n) break;  // (wave-uniform)
     f4 xh[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t cj = (uint32_t)row_lane((int)cl, j + u);
+      const uint32_t cj = (uint32_t)CL::step_value((int)cl, (int)cl1, lane, j + u);
       xh[u] = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float sr_c = lanes_sum<LH>(d4(ar4, xh[u]));
-      if ((j + u) * 4 + grp < n) {  // uniform per group; lanes past the end of a short chunk add nothing
+      const float sr_c = lanes_sum_w<LH>(d4(ar4, xh[u]));
+      if (CL::step_edge(lane, j + u) < n) {  // uniform per group; lanes past the end of a short chunk add nothing
         const float t0 = sl_i + sr_c;
         const float t = t0 > 0.0f ? t0 : eps * t0;
         // online softmax: one of exp(m - max), exp(t - max) is exp(0) -- ONE exponential per edge
@@ -1083,6 +1144,7 @@ __global__ __launch_bounds__(256) void gat_score_sign_kernel(int64_t n_chunks, c
                                                              const int64_t* rowptr, const uint32_t* col, int len, const float* feat,
                                                              const float* alpha_l, const float* alpha_r, uint8_t* sign_out) {
   constexpr int LH = G / H;
+  using CL = ChunkLanes<G>;
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_chunks) return;
   const int lane = threadIdx.x & 63;
@@ -1091,9 +1153,10 @@ __global__ __launch_bounds__(256) void gat_score_sign_kernel(int64_t n_chunks, c
   const int64_t eb = chunk_ebase[c];
   const int64_t rem = rowptr[row + 1] - eb;
   const int n = rem < 64 ? (int)rem : 64;
-  const int grp = lane >> 4;
-  const int my_e = sl * 4 + grp;
+  const int my_e = CL::held_edge(lane, 0), my_e1 = CL::held_edge(lane, 1);
   const uint32_t cl = col[eb + (my_e < n ? my_e : 0)];
+  uint32_t cl1 = 0;
+  if constexpr (G == 32) cl1 = col[eb + (my_e1 < n ? my_e1 : 0)];
   const int coff = sl * 4;
   const int head = sl / LH;
   const f4 hi = *reinterpret_cast<const f4*>(feat + row * (int64_t)len + coff);
@@ -1102,44 +1165,46 @@ __global__ __launch_bounds__(256) void gat_score_sign_kernel(int64_t n_chunks, c
   auto d4 = [](const f4& a, const f4& b) {
     return __builtin_fmaf(a[3], b[3], __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])));
   };
-  const float sl_i = lanes_sum<LH>(d4(al4, hi));
+  const float sl_i = lanes_sum_w<LH>(d4(al4, hi));
 #pragma unroll
   for (int j = 0; j < G; ++j) {
-    if (j * 4 >= n) break;
-    const uint32_t cj = (uint32_t)row_lane((int)cl, j);
+    if (j * CL::NG >= n) break;
+    const uint32_t cj = (uint32_t)CL::step_value((int)cl, (int)cl1, lane, j);
     const f4 xh = *reinterpret_cast<const f4*>(feat + (int64_t)cj * len + coff);
-    const float sr_c = lanes_sum<LH>(d4(ar4, xh));
+    const float sr_c = lanes_sum_w<LH>(d4(ar4, xh));
     const float t_e = sl_i + sr_c;
-    const int ei = j * 4 + grp;
+    const int ei = CL::step_edge(lane, j);
     if (ei < n && (sl & (LH - 1)) == 0) sign_out[(eb + ei) * H + head] = t_e > 0.0f ? 1 : 0;
   }
 }
 
 // per row: combine the chunks' (m, s, acc) in chunk order; out = act(sum / S); stats[row][h] = (M, 1/S)
-// (len == 64: a row is 16 lanes of 4 columns, so the wave's four 16-lane groups take the row's chunks k, k + 1, k + 2,
-// k + 3, ... and meet at the end -- a row with 330 chunks is 83 steps deep instead of 330, and no lane idles)
+// (a row is G = len / 4 lanes of 4 columns, so the wave's NG = 64 / G lane groups take the row's chunks k, k + 1, ...,
+// k + NG - 1, ... and meet at the end -- at len 64 a row with 330 chunks is 83 steps deep instead of 330, and no lane idles)
+template <int G>
 __global__ __launch_bounds__(256) void gat_fwd_reduce_kernel(int64_t nv, int len, int H, const uint32_t* chunk_start,
                                                              const float* out_partial, const float2* ms_partial, int relu,
                                                              float* out, float2* stats) {
+  constexpr int NG = 64 / G;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
-  const int sl = lane & 15, grp = lane >> 4;
+  const int sl = lane & (G - 1), grp = lane / G;
   const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
   const int dh = len / H, head = (sl * 4) / dh;
   float M = GAT_NEG;
-  for (int64_t k = c0 + grp; k < c1; k += 4) {
+  for (int64_t k = c0 + grp; k < c1; k += NG) {
     const float mk = ms_partial[k * H + head].x;
     M = mk > M ? mk : M;
   }
 #pragma unroll
-  for (int o = 16; o < 64; o <<= 1) {
+  for (int o = G; o < 64; o <<= 1) {
     const float mo = __shfl_xor(M, o, 64);
     M = mo > M ? mo : M;
   }
   float S = 0.f;
   f4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t k = c0 + grp; k < c1; k += 4) {
+  for (int64_t k = c0 + grp; k < c1; k += NG) {
     const float2 ms = ms_partial[k * H + head];
     const float w = __expf(ms.x - M);
     S += ms.y * w;
@@ -1148,7 +1213,7 @@ __global__ __launch_bounds__(256) void gat_fwd_reduce_kernel(int64_t nv, int len
     for (int q = 0; q < 4; ++q) s[q] += t[q] * w;
   }
 #pragma unroll
-  for (int o = 16; o < 64; o <<= 1) {  // fixed order: deterministic
+  for (int o = G; o < 64; o <<= 1) {  // fixed order: deterministic
     S += __shfl_xor(S, o, 64);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], o, 64);
@@ -1165,39 +1230,44 @@ __global__ __launch_bounds__(256) void gat_fwd_reduce_kernel(int64_t nv, int len
 }
 
 // out[row] = sum of the row's chunk partials in chunk order; rs / cs [row][H] the same for the g sums
+template <int G>
 __global__ __launch_bounds__(256) void gat_fused_reduce_kernel(int64_t nv, int len, int H, const uint32_t* chunk_start,
                                                                const float* out_partial, const float* rc_partial,
                                                                float* out, float* rs, float* cs) {
+  constexpr int NG = 64 / G;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nv) return;
   const int lane = threadIdx.x & 63;
-  const int sl = lane & 15, grp = lane >> 4;  // len == 64: four lane groups share the row's chunks (see the forward's)
+  const int sl = lane & (G - 1), grp = lane / G;  // NG lane groups share the row's chunks (see the forward's)
   const int64_t c0 = chunk_start[row], c1 = chunk_start[row + 1];
   f4 s = {0.f, 0.f, 0.f, 0.f};
-  float r = 0.f, r2 = 0.f;  // this lane's share of the 2 H row / column sums: entries sl and sl + 16
+  // this lane's share of the 2 H row / column sums: entries sl, sl + G, sl + 2 G, sl + 3 G (2 H <= 32, G >= 8)
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
   const float* pp = out_partial + sl * 4;
-  for (int64_t k = c0 + grp; k < c1; k += 4) {
+  for (int64_t k = c0 + grp; k < c1; k += NG) {
     const f4 t = *reinterpret_cast<const f4*>(pp + k * len);
-    if (sl < 2 * H) r += rc_partial[k * 2 * H + sl];
-    if (sl + 16 < 2 * H) r2 += rc_partial[k * 2 * H + sl + 16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (sl + q * G < 2 * H) r[q] += rc_partial[k * 2 * H + sl + q * G];
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[q] += t[q];
   }
 #pragma unroll
-  for (int o = 16; o < 64; o <<= 1) {  // fixed order: deterministic
-    r += __shfl_xor(r, o, 64);
-    r2 += __shfl_xor(r2, o, 64);
+  for (int o = G; o < 64; o <<= 1) {  // fixed order: deterministic
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] += __shfl_xor(r[q], o, 64);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], o, 64);
   }
   if (grp != 0) return;
   *reinterpret_cast<f4*>(out + row * (int64_t)len + sl * 4) = s;
   // entries 0..H-1: rs, H..2H-1: cs
-  if (sl < 2 * H) {
-    if (sl < H) rs[row * H + sl] = r;
-    else cs[row * H + sl - H] = r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = sl + q * G;
+    if (e < H) rs[row * H + e] = r[q];
+    else if (e < 2 * H) cs[row * H + e - H] = r[q];
   }
-  if (sl + 16 < 2 * H) cs[row * H + sl + 16 - H] = r2;  // (16 heads: entries 16..31 are all column sums)
 }
 
 inline unsigned rowgrid(int64_t nv) { return (unsigned)cdiv64(nv > 0 ? nv : 1, 4); }
@@ -1462,8 +1532,32 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   return GAIB_OK;
 }
 
-// The fused edge side of backward (gat_bwd_fused_chunk_kernel).  Shapes: len == 64 (16 lanes x 4 columns per edge) and
-// 1, 2, 4, 8 or 16 heads; otherwise, or where the auto rule says the ordered-chunk sweep does not pay (option
+// the one-sweep kernels' shapes (round 5): len = 32, 64 or 128 (8, 16 or 32 lanes x 4 columns per edge) and 1, 2, 4, 8 or 16
+// heads with at least 4 columns per head -- every head width the reference's GAT runs up to its limit of 128 columns
+// (gat_aggregator.cpp:57-200, global.h:58) as long as a head is a whole number of 4-column lanes
+static bool gat_fused_shape(int len, int heads) {
+  if (!(len == 32 || len == 64 || len == 128)) return false;
+  if (!(heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16)) return false;
+  return heads * 4 <= len;
+}
+// M(G, H) for the kernel instance of a shape gat_fused_shape() admits
+#define GAIB_GAT_BY_HEADS(G, M, WITH16) \
+  switch (heads) {                      \
+    case 1: M(G, 1); break;             \
+    case 2: M(G, 2); break;             \
+    case 4: M(G, 4); break;             \
+    case 8: M(G, 8); break;             \
+    default: WITH16; break;             \
+  }
+#define GAIB_GAT_DISPATCH(M)                                    \
+  do {                                                          \
+    if (len == 32) { GAIB_GAT_BY_HEADS(8, M, (void)0) }         \
+    else if (len == 64) { GAIB_GAT_BY_HEADS(16, M, M(16, 16)) } \
+    else { GAIB_GAT_BY_HEADS(32, M, M(32, 16)) }                \
+  } while (0)
+
+// The fused edge side of backward (gat_bwd_fused_chunk_kernel).  Shapes: gat_fused_shape(); otherwise, or where the auto
+// rule says the ordered-chunk sweep does not pay (option
 // gat_fused_bwd: -1 = graphs with >= 1/4 of their edges in heavy rows and a feature table of <= 512 MB -- the
 // dense-graph rule of the aggregation; 0 = never; 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and
 // nothing was touched: the caller runs the staged entry points.
@@ -1474,7 +1568,7 @@ static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, 
   // the one-sweep and the staged path run different collectives in backward, so a rank that has rows but no edges (an
   // empty sweep is a valid sweep) or a misaligned buffer must not take another path than its peers (the latter is an
   // error, not a reason to fall back).
-  const bool heads_ok = len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16);
+  const bool heads_ok = gat_fused_shape(len, heads);
   if (rect) {
     if (heads_ok && knob != 0 && (align_or & 15) != 0) {
       gaib_set_error("one-sweep GAT on a partition: buffers must be 16-byte aligned");
@@ -1508,8 +1602,7 @@ static int gat_forward_fused_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   if (g->nv == 0) {
     // a rank without rows (fewer vertices than ranks): nothing to write, its buffers may be NULL -- but WHICH path "ran" must be
     // what the ranks with rows decide, from the shape and the option alone: the two paths differ in their exchanges
-    if (rect && len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) && ctx->gat_fused_fwd != 0)
-      return GAIB_OK;
+    if (rect && gat_fused_shape(len, heads) && ctx->gat_fused_fwd != 0) return GAIB_OK;
     gaib_set_error("%s: not applicable to this shape / graph (len %d, heads %d)", who, len, heads);
     return GAIB_ERR_UNSUPPORTED;
   }
@@ -1538,23 +1631,22 @@ static int gat_forward_fused_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
     per_xcd = (int)cdiv64(grid, 8);
     grid = (unsigned)per_xcd * 8u;
   }
-#define GAIB_FF(HH)                                                                                                       \
-  if (grid > 0) gat_fwd_fused_chunk_kernel<16, HH, 8><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,          \
+#define GAIB_FF(GG, HH)                                                                                                   \
+  if (grid > 0) gat_fwd_fused_chunk_kernel<GG, HH, 8><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase,          \
                                                                        g->chunk_start, g->rowptr, g->colidx, len, d_h,     \
                                                                        d_alpha_l, d_alpha_r, epsilon, out_partial, ms_partial, \
                                                                        phase, (uint32_t)g->nv, per_xcd)
-  switch (heads) {
-    case 1: GAIB_FF(1); break;
-    case 2: GAIB_FF(2); break;
-    case 4: GAIB_FF(4); break;
-    case 8: GAIB_FF(8); break;
-    default: GAIB_FF(16); break;
-  }
+  GAIB_GAT_DISPATCH(GAIB_FF);
 #undef GAIB_FF
   GAIB_LAUNCH_CHECK();
   if (phase == 0) return GAIB_OK;
-  gat_fwd_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial, ms_partial,
-                                                                 relu ? 1 : 0, d_out, reinterpret_cast<float2*>(d_row_stats));
+#define GAIB_FR(GG)                                                                                                        \
+  gat_fwd_reduce_kernel<GG><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial, ms_partial, \
+                                                                     relu ? 1 : 0, d_out, reinterpret_cast<float2*>(d_row_stats))
+  if (len == 32) GAIB_FR(8);
+  else if (len == 64) GAIB_FR(16);
+  else GAIB_FR(32);
+#undef GAIB_FR
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -1651,33 +1743,32 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
     grid = (unsigned)per_xcd * 8u;
   }
   // edges in flight per group: 8 or 4 (option gat_fused_unroll)
-#define GAIB_FB_U(HH, UU, RC)                                                                                              \
-  gat_bwd_fused_chunk_kernel<16, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
+#define GAIB_FB_U(GG, HH, UU, RC)                                                                                          \
+  gat_bwd_fused_chunk_kernel<GG, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
       g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, g->rev, len, k_feat, k_grad,        \
       d_norm_scores, reinterpret_cast<const float2*>(d_row_stats), rowdot, d_alpha_l, d_alpha_r, epsilon, out_partial,     \
       rc_partial, k_rec, -1, 0u, k_ld, k_rec_ld, per_xcd)
-#define GAIB_FB(HH)                                          \
-  do {                                                       \
-    if (d_row_stats) {                                       \
-      if (ctx->gat_fused_unroll == 8) GAIB_FB_U(HH, 8, true); \
-      else GAIB_FB_U(HH, 4, true);                           \
-    } else {                                                 \
-      if (ctx->gat_fused_unroll == 8) GAIB_FB_U(HH, 8, false); \
-      else GAIB_FB_U(HH, 4, false);                          \
-    }                                                        \
+  // (8 edges in flight per group is an option of the 64-wide form only, where it was measured)
+#define GAIB_FB(GG, HH)                                                      \
+  do {                                                                       \
+    if (d_row_stats) {                                                       \
+      if (GG == 16 && ctx->gat_fused_unroll == 8) GAIB_FB_U(16, HH, 8, true); \
+      else GAIB_FB_U(GG, HH, 4, true);                                       \
+    } else {                                                                 \
+      if (GG == 16 && ctx->gat_fused_unroll == 8) GAIB_FB_U(16, HH, 8, false); \
+      else GAIB_FB_U(GG, HH, 4, false);                                      \
+    }                                                                        \
   } while (0)
-  switch (heads) {
-    case 1: GAIB_FB(1); break;
-    case 2: GAIB_FB(2); break;
-    case 4: GAIB_FB(4); break;
-    case 8: GAIB_FB(8); break;
-    default: GAIB_FB(16); break;
-  }
+  GAIB_GAT_DISPATCH(GAIB_FB);
 #undef GAIB_FB
 #undef GAIB_FB_U
   GAIB_LAUNCH_CHECK();
-  gat_fused_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial,
-                                                                   rc_partial, d_grad_out, rs, cs);
+#define GAIB_FRD(GG)                                                                                                   \
+  gat_fused_reduce_kernel<GG><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial, \
+                                                                       rc_partial, d_grad_out, rs, cs)
+  if (len == 32) GAIB_FRD(8);
+  else if (len == 64) GAIB_FRD(16);
+  else GAIB_FRD(32);
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat, rs, cs,
                                                                          rows_per_block, partial);
@@ -1692,22 +1783,16 @@ extern "C" int gaib_gat_score_signs(gaib_ctx* ctx, gaib_graph* g, int len, int h
                                     const float* d_alpha_r, uint8_t* d_sign_out) {
   GAIB_CHECK(ctx && g && d_h && d_alpha_l && d_alpha_r && d_sign_out, "gaib_gat_score_signs: NULL argument");
   GAIB_TRY(check_heads("gaib_gat_score_signs", len, heads));
-  GAIB_CHECK(len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16),
-             "gaib_gat_score_signs: the one-sweep kernels' shapes only (len 64; 1, 2, 4, 8 or 16 heads)");
+  GAIB_CHECK(gat_fused_shape(len, heads),
+             "gaib_gat_score_signs: the one-sweep kernels' shapes only (len 32, 64 or 128; 1, 2, 4, 8 or 16 heads of >= 4 columns)");
   GAIB_HIP(hipSetDevice(ctx->device));
   if (g->ne == 0) return GAIB_OK;
   GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
-#define GAIB_SS(HH)                                                                                                     \
-  gat_score_sign_kernel<16, HH><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->rowptr,     \
+#define GAIB_SS(GG, HH)                                                                                                 \
+  gat_score_sign_kernel<GG, HH><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->rowptr,     \
                                                                g->colidx, len, d_h, d_alpha_l, d_alpha_r, d_sign_out)
-  switch (heads) {
-    case 1: GAIB_SS(1); break;
-    case 2: GAIB_SS(2); break;
-    case 4: GAIB_SS(4); break;
-    case 8: GAIB_SS(8); break;
-    default: GAIB_SS(16); break;
-  }
+  GAIB_GAT_DISPATCH(GAIB_SS);
 #undef GAIB_SS
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
@@ -1750,7 +1835,7 @@ extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int le
   GAIB_TRY(check_heads("gaib_gat_backward_fused_rect", len, heads));
   if (g->nv == 0) {  // a rank without rows: zero alpha gradients (they are summed over the ranks afterwards), nothing else
     GAIB_CHECK(phase >= -1 && phase <= 1, "gaib_gat_backward_fused_rect: phase is -1, 0 or 1");
-    if (!(len == 64 && (heads == 1 || heads == 2 || heads == 4 || heads == 8 || heads == 16) && ctx->gat_fused_bwd != 0)) {
+    if (!(gat_fused_shape(len, heads) && ctx->gat_fused_bwd != 0)) {
       gaib_set_error("gaib_gat_backward_fused_rect: not applicable to this shape / graph (len %d, heads %d)", len, heads);
       return GAIB_ERR_UNSUPPORTED;  // (the decision of the ranks WITH rows: shape and option alone, see the forward)
     }
@@ -1789,23 +1874,18 @@ extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int le
   float* partial = rc_partial + n_rc;
   ProfScope ps(ctx, "gat_bwd_fused");
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
-#define GAIB_FBR(HH)                                                                                                       \
-  if (grid > 0) gat_bwd_fused_chunk_kernel<16, HH, 4, true><<<grid, 256, 0, ctx->stream>>>(                                              \
+#define GAIB_FBR(GG, HH)                                                                                                   \
+  if (grid > 0) gat_bwd_fused_chunk_kernel<GG, HH, 4, true><<<grid, 256, 0, ctx->stream>>>(                                              \
       g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, nullptr, len, d_feat_tab, d_grad_tab, \
       nullptr, nullptr, nullptr, d_alpha_l, d_alpha_r, epsilon, out_partial, rc_partial,                                   \
       reinterpret_cast<const f4*>(d_rec_tab), phase, (uint32_t)g->nv, len, HH, 0)
-  switch (heads) {
-    case 1: GAIB_FBR(1); break;
-    case 2: GAIB_FBR(2); break;
-    case 4: GAIB_FBR(4); break;
-    case 8: GAIB_FBR(8); break;
-    default: GAIB_FBR(16); break;
-  }
+  GAIB_GAT_DISPATCH(GAIB_FBR);
 #undef GAIB_FBR
   GAIB_LAUNCH_CHECK();
   if (phase == 0) return GAIB_OK;
-  gat_fused_reduce_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial,
-                                                                   rc_partial, d_grad_out, rs, cs);
+  if (len == 32) GAIB_FRD(8);
+  else if (len == 64) GAIB_FRD(16);
+  else GAIB_FRD(32);
   GAIB_LAUNCH_CHECK();
   alpha_partial_kernel<<<nblocks, 256, sizeof(float) * 512, ctx->stream>>>(g->nv, len, heads, d_feat_tab, rs, cs,
                                                                          rows_per_block, partial);

@@ -1078,8 +1078,16 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     t_case = time.time()
     if strong:
         main = run_strong(on_headline, strong_check_budgeted if strong_check is not None else None, extras=ab_legs)
+        # the comparison's run of the oracle on the whole bench graph IS the N = 1 workload's CPU baseline (rank 0 has it; every
+        # rank must know whether it exists: the bounded-sample leg below is collective)
         if rank == 0 and isinstance(main.get("parity"), dict) and main["parity"].get("cpu_baseline"):
-            cpu_rec = main["parity"].pop("cpu_baseline")
+            cb = main["parity"].pop("cpu_baseline")
+            if cpu_leg is not None:  # (--no-cpu-baseline: the slot says skipped)
+                cpu_rec = cb
+        have = [cpu_rec is not None]
+        dist.broadcast_object_list(have, src=0)
+        if have[0] and rank != 0:
+            cpu_rec = {"on": "rank 0"}
     else:
         main = run_weak(on_headline, mk(cut))
         torch.cuda.empty_cache()

@@ -42,8 +42,10 @@ def ev_time(fn, iters=8, warm=3, rounds=2):
     return best
 
 
-def layer_step(kind, graph_name, din, dout, selfloop, heads=1, steps=6):
+def layer_step(kind, graph_name, din, dout, selfloop, heads=1, steps=6, options=None):
     ctx = L.init(0)
+    for k, v in (options or {}).items():
+        ctx.set_option(k, v)
     sg = synth.make(graph_name, device="cuda")
     g = ctx.graph(sg.rowptr, sg.colidx)
     if selfloop:
@@ -72,9 +74,30 @@ def layer_step(kind, graph_name, din, dout, selfloop, heads=1, steps=6):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    layer.close()
+    lg.close()
     del layer, out, gout, lg
     torch.cuda.empty_cache()
+    for k in (options or {}):  # (back to the library's rule)
+        ctx.set_option(k, -1)
     return ms
+
+
+def gat_fused_vs_staged(res):
+    """the one-sweep GAT kernels outside the config-4 shape, next to the staged kernels on the same layer step:
+    a products-shaped graph at 1 head x 64 (sparse: one short chunk per row), the reddit shape at 8 heads x 128 and at 8 x 32"""
+    one = {"gat_fused_fwd": 1, "gat_fused_bwd": 1}
+    staged = {"gat_fused_fwd": 0, "gat_fused_bwd": 0}
+    for name, graph, d, heads in (("GAT 64->64 1 head layer step, products shape", "ogbn-products", 64, 1),
+                                  ("GAT 128->128 8 heads layer step, reddit shape", "reddit", 128, 8),
+                                  ("GAT 32->32 8 heads layer step, reddit shape", "reddit", 32, 8)):
+        f = layer_step(L.GAT, graph, d, d, True, heads=heads, options=one)
+        st = layer_step(L.GAT, graph, d, d, True, heads=heads, options=staged)
+        auto = layer_step(L.GAT, graph, d, d, True, heads=heads)
+        res[name + " (one sweep)"] = f
+        res[name + " (staged)"] = st
+        res[name + " (the library's rule)"] = auto
+        print(f"    {name}: one sweep {f:.2f} ms, staged {st:.2f} ms (ratio {f / st:.2f}), rule {auto:.2f} ms", flush=True)
 
 
 def dominant_kernel_normalised(steps=10):
@@ -171,6 +194,7 @@ def main():
     res["SAGE 256->256 layer step, products shape"] = layer_step(L.SAGE, "ogbn-products", 256, 256, False)
     res["GCN 128->47 layer step, products shape"] = layer_step(L.GCN, "ogbn-products", 128, 47, True)
     res["GAT 64->64 8 heads layer step, reddit shape"] = layer_step(L.GAT, "reddit", 64, 64, True, heads=8)
+    gat_fused_vs_staged(res)
     res["cora GCN 2-layer epoch (trainer, recorded epochs)"] = cora_epoch_ms()
     k_ms, copy_gbs, norm = dominant_kernel_normalised()
     for k, v in res.items():

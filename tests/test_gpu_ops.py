@@ -323,6 +323,81 @@ def test_gat_forward_fused_and_backward_from_row_stats(ctx, heads, hub):
     assert_close(rg.cpu().numpy(), want_rg, "alpha_r grad", floor=LONG_SUM_FLOOR)
 
 
+@pytest.mark.parametrize("d,heads,hub", [(32, 1, 0), (32, 8, 900), (32, 4, 0), (64, 1, 900), (64, 8, 0), (128, 1, 0), (128, 8, 1400),
+                                         (128, 16, 0), (128, 2, 700)])
+def test_gat_one_sweep_at_every_row_width(ctx, d, heads, hub):
+    """round 5: the one-sweep forward and backward at len 32 / 64 / 128 -- 8, 16 or 32 lanes per edge, the
+    chunk's column ids in DPP reach (ChunkLanes) -- against the oracle's aggregate / d_aggregate head by head
+    (gat_aggregator.cpp:57-200; its len limit of 128: global.h:58): forward + row statistics, backward from the statistics AND
+    from the attention array (the p[rev e] form), deterministic, and the score signs the alpha-gradient analysis imposes.
+    The graph has rows of 1..9 edges, and with `hub` rows of many chunks whose last chunk is short."""
+    rp, ci = random_graph(1300, 7, seed=3 * d + heads, power_law=True, hub_deg=hub)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    h = feat(g_o.nv, d, 1)
+    gin = feat(g_o.nv, d, 4)
+    al = feat(1, d, 2).ravel() * 0.2
+    ar = feat(1, d, 3).ravel() * 0.2
+    out_w, temp, _, norm = orc.gat_aggregate_mh(g_o, h, al, ar, heads)
+    want_go, _, _, want_lg, want_rg = orc.gat_d_aggregate_mh(g_o, h, gin, norm, temp, heads)
+    hd, gd, pd = dev(h), dev(gin), dev(np.ascontiguousarray(norm))
+    fl = LONG_SUM_FLOOR if hub else 1e-6
+    ctx.set_option("gat_fused_fwd", 1)
+    ctx.set_option("gat_fused_bwd", 1)
+    try:
+        runs = []
+        for _ in range(2):
+            out = torch.full((g_o.nv, d), 7.0, device="cuda")
+            stats = torch.empty(g_o.nv, heads, 2, device="cuda")
+            assert ctx.gat_forward_fused(g_d, hd, dev(al), dev(ar), out, stats, heads=heads)
+            go = torch.full((g_o.nv, d), 7.0, device="cuda")
+            lg, rg = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+            assert ctx.gat_backward_fused(g_d, hd, gd, dev(out_w), dev(al), dev(ar), None, go, lg, rg, heads=heads, row_stats=stats)
+            go_p = torch.full((g_o.nv, d), 7.0, device="cuda")
+            lg_p, rg_p = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+            assert ctx.gat_backward_fused(g_d, hd, gd, dev(out_w), dev(al), dev(ar), pd, go_p, lg_p, rg_p, heads=heads)
+            runs.append((out, stats, go, lg, rg, go_p, lg_p, rg_p))
+        signs = ctx.gat_score_signs(g_d, hd, dev(al), dev(ar), heads=heads)
+    finally:
+        ctx.set_option("gat_fused_fwd", -1)
+        ctx.set_option("gat_fused_bwd", -1)
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)  # fixed summation order
+    out, stats, go, lg, rg, go_p, lg_p, rg_p = runs[0]
+    assert_close(out.cpu().numpy(), out_w, "forward", floor=fl)
+    rows = np.repeat(np.arange(g_o.nv), np.diff(g_o.rowptr))
+    t = np.asarray(temp).reshape(g_o.ne, heads).astype(np.float64)
+    st = stats.cpu().numpy().astype(np.float64)
+    p_re = np.exp(np.where(t > 0, t, 0.2 * t) - st[rows, :, 0]) * st[rows, :, 1]
+    assert_close(p_re, np.asarray(norm).reshape(g_o.ne, heads), "attention from the row statistics", floor=LONG_SUM_FLOOR)
+    for got_go, got_lg, got_rg, what in ((go, lg, rg, "from the statistics"), (go_p, lg_p, rg_p, "from the attention array")):
+        assert_close(got_go.cpu().numpy(), want_go, f"grad_out {what}", floor=fl)
+        assert_close(got_lg.cpu().numpy(), want_lg, f"alpha_l grad {what}", floor=LONG_SUM_FLOOR)
+        assert_close(got_rg.cpu().numpy(), want_rg, f"alpha_r grad {what}", floor=LONG_SUM_FLOOR)
+    # the signs of the pre-activation scores as the kernels form them: the oracle's, except within rounding of zero
+    sg = signs.cpu().numpy().reshape(g_o.ne, heads).astype(bool)
+    diff = sg != (t > 0)
+    assert np.abs(t[diff]).max(initial=0.0) < 1e-5 * max(np.abs(t).max(), 1e-30)
+
+
+def test_gat_one_sweep_refuses_shapes_outside_its_cover(ctx):
+    """len not in {32, 64, 128}, a head narrower than one 4-column lane, a head count that is no power of two: refused,
+    nothing touched (the layers then run the staged entry points)"""
+    rp, ci = random_graph(600, 6, seed=2, power_law=True)
+    g_o, g_d = make(ctx, rp, ci, selfloop=True)
+    ctx.set_option("gat_fused_fwd", 1)
+    try:
+        for d, heads in ((48, 1), (96, 8), (32, 16), (64, 32), (128, 3), (256, 8)):
+            if d % heads:
+                continue
+            out = torch.full((g_o.nv, d), 7.0, device="cuda")
+            stats = torch.full((g_o.nv, heads, 2), 7.0, device="cuda")
+            assert not ctx.gat_forward_fused(g_d, dev(feat(g_o.nv, d, 1)), dev(feat(1, d, 2).ravel()), dev(feat(1, d, 3).ravel()),
+                                             out, stats, heads=heads)
+            assert torch.all(out == 7.0) and torch.all(stats == 7.0)
+    finally:
+        ctx.set_option("gat_fused_fwd", -1)
+
+
 def test_spmm_chunked_short_chunk_does_not_touch_missing_edges(ctx):
     """a 70-edge row = one full 64-edge chunk + a 6-edge chunk whose idle lanes point at the chunk's first column.
     With an Inf in that column's feature row the sum must come out +Inf (the real edge carries it), not NaN
