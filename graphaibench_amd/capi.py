@@ -120,6 +120,9 @@ SIGNATURES = {
     "gaib_prof_enable": (_i, [_vp, _i]),
     "gaib_prof_reset": (_i, [_vp]),
     "gaib_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gaib_prof_get_work": (_i, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gaib_prof_table": (_i, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gaib_gat_score_signs": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "gaib_gat_forward_fused_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _i]),
     "gaib_gat_backward_rec": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
@@ -162,6 +165,16 @@ class GaibError(RuntimeError):
 COMM_RCCL, COMM_IPC = 0, 1
 ORDER_DEGREE, ORDER_BFS, ORDER_CM = 1, 2, 3
 COMM_ID_BYTES = 128
+
+
+def parse_prof_table(text: str) -> dict:
+    """lines "key count total_ms alg_bytes flops roof_ms" (gaib_prof_table; the trainer prints them after "[gaib prof]")"""
+    out = {}
+    for line in text.splitlines():
+        f = line.split()
+        if len(f) == 6:
+            out[f[0]] = dict(count=int(f[1]), ms=float(f[2]), bytes=float(f[3]), flops=float(f[4]), roof_ms=float(f[5]))
+    return out
 
 
 def comm_transport_available(transport: int = COMM_RCCL) -> bool:
@@ -396,6 +409,14 @@ class Context:
         n, ms = _i64(), C.c_double()
         _check(self.lib.gaib_prof_get(self.h, key.encode(), C.byref(n), C.byref(ms)), "gaib_prof_get")
         return n.value, ms.value
+
+    def prof_table(self) -> dict:
+        """{key: dict(count, ms, bytes, flops, roof_ms)} of every key that has records (gaib_prof_table)"""
+        need = C.c_size_t(0)
+        _check(self.lib.gaib_prof_table(self.h, None, 0, C.byref(need)), "gaib_prof_table")
+        buf = C.create_string_buffer(need.value + 16)
+        _check(self.lib.gaib_prof_table(self.h, buf, len(buf), C.byref(need)), "gaib_prof_table")
+        return parse_prof_table(buf.value.decode())
 
     def probe_stream_copy(self, nbytes: int = 1 << 30, iters: int = 20) -> float:
         """GB/s (read + written bytes) of a 16-B-per-lane copy kernel on this context's stream"""

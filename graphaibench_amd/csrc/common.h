@@ -105,7 +105,8 @@ struct gaib_ctx {
   std::vector<void*> retired;
   // in-stream kernel timing (gaib_prof_*)
   int prof_on;
-  struct ProfRec { const char* key; hipEvent_t a, b; };
+  // bytes / flops: the ALGORITHMIC work of the launch as SURVEY.md 8(d) prices it (0: not stated by the site)
+  struct ProfRec { const char* key; hipEvent_t a, b; double bytes, flops; };
   std::vector<ProfRec> prof;
 };
 
@@ -118,13 +119,25 @@ static inline int gaib_comm_reserve(const gaib_ctx* ctx) {
 }
 
 // RAII: event pair around a kernel launch when profiling is on
+// the roofs an epoch record prices a launch against (MI355X_MICROARCH.md: HBM3E 8.0 TB/s; fp32 MFMA 157.3 TFLOP/s dense)
+constexpr double GAIB_HBM_PEAK_BPS = 8.0e12;
+constexpr double GAIB_MFMA_F32_PEAK_FLOPS = 157.3e12;
+// algorithmic bytes of one aggregation launch over `edges` edges into `rows` rows of `cols` columns --
+// every gathered row counted (4 cols), the column id (4) and the per-edge weight where there is one, `stored` [rows x cols]
+// matrices written (or read back), the row pointers (8 B here: rowptr is int64)
+static inline double gaib_alg_spmm_bytes(double edges, double rows, double cols, double w_bytes_per_edge, double stored) {
+  return edges * (4.0 * cols + 4.0 + w_bytes_per_edge) + stored * rows * 4.0 * cols + (rows + 1.0) * 8.0;
+}
+
 struct ProfScope {
   gaib_ctx* c;
   size_t idx;
-  ProfScope(gaib_ctx* ctx, const char* key) : c(ctx), idx((size_t)-1) {
+  ProfScope(gaib_ctx* ctx, const char* key, double bytes = 0.0, double flops = 0.0) : c(ctx), idx((size_t)-1) {
     if (!c->prof_on || c->capturing) return;
     gaib_ctx::ProfRec r;
     r.key = key;
+    r.bytes = bytes;
+    r.flops = flops;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, c->stream);
     c->prof.push_back(r);

@@ -510,7 +510,7 @@ extern "C" int gaib_relu(gaib_ctx* ctx, int64_t n, const float* d_in, float* d_o
   GAIB_CHECK(ctx && ((d_in && d_out) || n == 0), "gaib_relu: NULL argument");
   if (n <= 0) return GAIB_OK;
   const int vec_ok = ((((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0);
-  ProfScope ps(ctx, "relu");
+  ProfScope ps(ctx, "relu", 8.0 * (double)n);
   relu_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, ctx->stream>>>(n, d_in, d_out, vec_ok);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
@@ -521,7 +521,7 @@ extern "C" int gaib_d_relu(gaib_ctx* ctx, int64_t n, const float* d_in_diff, con
   GAIB_CHECK(ctx && ((d_in_diff && d_data && d_out_diff) || n == 0), "gaib_d_relu: NULL argument");
   if (n <= 0) return GAIB_OK;
   const int vec_ok = ((((uintptr_t)d_in_diff | (uintptr_t)d_data | (uintptr_t)d_out_diff) & 15) == 0);
-  ProfScope ps(ctx, "d_relu");
+  ProfScope ps(ctx, "d_relu", 12.0 * (double)n);
   d_relu_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, ctx->stream>>>(n, d_in_diff, d_data,
                                                                      d_out_diff, vec_ok);
   GAIB_LAUNCH_CHECK();

@@ -1357,12 +1357,12 @@ extern "C" int gaib_gat_scores_mh(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   float* sl = (float*)ctx->ws;
   float* sr = sl + nt * heads;
   {
-    ProfScope ps(ctx, "gat_vertex_dots");
+    ProfScope ps(ctx, "gat_vertex_dots", (double)nt * (4.0 * len + 8.0 * heads), 4.0 * (double)nt * len);
     vertex_dots_kernel<<<rowgrid(nt), 256, 0, ctx->stream>>>(nt, len, heads, d_h, d_alpha_l, d_alpha_r, sl, sr);
   }
   GAIB_LAUNCH_CHECK();
   {
-    ProfScope ps(ctx, "gat_edge_softmax");
+    ProfScope ps(ctx, "gat_edge_softmax", (double)g->ne * (4.0 + 4.0 * heads + 2 * 4.0 * heads) + (double)g->nv * 8.0 * heads);
     const bool al16 = (((uintptr_t)d_temp_scores | (uintptr_t)d_scores | (uintptr_t)d_norm_scores) & 15) == 0;
     int rc = GAIB_OK;
     if (heads == 1) rc = launch_edge_softmax<1>(ctx, g, sl, sr, epsilon, d_temp_scores, d_scores, d_norm_scores);
@@ -1401,7 +1401,7 @@ extern "C" int gaib_sddmm_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, c
                       ctx->gat_fast && (heads == 1 || (dh % 4 == 0 && (lh & (lh - 1)) == 0));
   if (vec_ok) {
     GAIB_TRY(gaib_graph_ensure_chunks(ctx, g));
-    ProfScope ps(ctx, "gat_sddmm");
+    ProfScope ps(ctx, "gat_sddmm", (double)g->ne * (4.0 + 4.0 * len + 4.0 * heads) + (double)g->nv * 4.0 * len, 2.0 * (double)g->ne * len);
     const unsigned grid = (unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4);
 #define GAIB_SDDMM(G, U, LH)                                                                            \
   sddmm_chunk_kernel<G, U, LH><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, \
@@ -1435,7 +1435,7 @@ extern "C" int gaib_sddmm_mh(gaib_ctx* ctx, gaib_graph* g, int len, int heads, c
     GAIB_LAUNCH_CHECK();
     return GAIB_OK;
   }
-  ProfScope ps(ctx, "gat_sddmm");
+  ProfScope ps(ctx, "gat_sddmm", (double)g->ne * (4.0 + 4.0 * len + 4.0 * heads) + (double)g->nv * 4.0 * len, 2.0 * (double)g->ne * len);
   sddmm_generic_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, heads, g->rowptr, g->colidx, len,
                                                                d_grad, d_feat, d_out_e);
   GAIB_LAUNCH_CHECK();
@@ -1486,7 +1486,7 @@ static int softmax_bwd_alpha_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   float* sr = sl + n_v;
   float* cs_partial = sr + n_v;
   float* partial = cs_partial + n_p;
-  ProfScope ps(ctx, "gat_softmax_bwd_alpha");
+  ProfScope ps(ctx, "gat_softmax_bwd_alpha", (double)g->ne * (4.0 + 4.0 + 3 * 4.0 * heads) + (double)g->nv * (2 * 4.0 * len));
   if (!d_temp_scores) {
     vertex_dots_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_feat, d_alpha_l, d_alpha_r, sl, sr);
     GAIB_LAUNCH_CHECK();
@@ -1624,7 +1624,8 @@ static int gat_forward_fused_impl(gaib_ctx* ctx, gaib_graph* g, int len, int hea
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (n_op + n_ms)));
   float* out_partial = (float*)ctx->ws;
   float2* ms_partial = reinterpret_cast<float2*>(out_partial + n_op);
-  ProfScope ps(ctx, "gat_fwd_fused");
+  ProfScope ps(ctx, "gat_fwd_fused", (double)g->ne * (4.0 + 4.0 * len) + (double)g->n_chunks * (4.0 * len + 8.0 * heads) * 2 + (double)g->nv * (4.0 * len + 8.0 * heads),
+               4.0 * (double)g->ne * len);
   unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);  // (0 on a rank whose rows have no edges: nothing to sweep)
   int per_xcd = 0;
   if (ctx->gat_chunk_xcd == 1 && grid >= 64) {
@@ -1712,7 +1713,8 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   float* rc_partial = out_partial + n_op;
   float* partial = rc_partial + n_rc;
   float* T = reinterpret_cast<float*>(((uintptr_t)(partial + (size_t)nblocks * 2 * len) + 255) & ~(uintptr_t)255);
-  ProfScope ps(ctx, "gat_bwd_fused");
+  ProfScope ps(ctx, "gat_bwd_fused", (double)g->ne * (4.0 + 2 * 4.0 * len + 12.0 * heads) + (double)g->n_chunks * (4.0 * len + 8.0 * heads) * 2 + (double)g->nv * 3 * 4.0 * len,
+               8.0 * (double)g->ne * len);
   rowdot_kernel<<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, d_grad, d_fwd_out, rowdot);
   GAIB_LAUNCH_CHECK();
   if (d_row_stats) {
@@ -1872,7 +1874,8 @@ extern "C" int gaib_gat_backward_fused_rect(gaib_ctx* ctx, gaib_graph* g, int le
   float* out_partial = cs + n_v;
   float* rc_partial = out_partial + n_op;
   float* partial = rc_partial + n_rc;
-  ProfScope ps(ctx, "gat_bwd_fused");
+  ProfScope ps(ctx, "gat_bwd_fused", (double)g->ne * (4.0 + 2 * 4.0 * len + 12.0 * heads) + (double)g->n_chunks * (4.0 * len + 8.0 * heads) * 2 + (double)g->nv * 3 * 4.0 * len,
+               8.0 * (double)g->ne * len);
   const unsigned grid = (unsigned)cdiv64(g->n_chunks, 4);
 #define GAIB_FBR(GG, HH)                                                                                                   \
   if (grid > 0) gat_bwd_fused_chunk_kernel<GG, HH, 4, true><<<grid, 256, 0, ctx->stream>>>(                                              \
@@ -1915,7 +1918,7 @@ extern "C" int gaib_gat_softmax_bwd_rows(gaib_ctx* ctx, gaib_graph* g, int heads
   GAIB_HIP(hipSetDevice(ctx->device));
   const bool al16 = (((uintptr_t)d_norm_scores | (uintptr_t)d_norm_scores_grad | (uintptr_t)d_temp_scores |
                       (uintptr_t)d_g_out | (uintptr_t)d_rs_out) & 15) == 0;
-  ProfScope ps(ctx, "gat_softmax_bwd_alpha");
+  ProfScope ps(ctx, "gat_softmax_bwd_alpha", (double)g->ne * (4.0 + 4.0 + 3 * 4.0 * heads));
   GAIB_TRY(gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold));
   const uint32_t* rl = g->heavy_rows;
   const uint32_t* ro = g->heavy_rows ? g->heavy_rows + g->n_heavy : nullptr;

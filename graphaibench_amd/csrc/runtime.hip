@@ -2,6 +2,7 @@
 // Replaces the reference's gpu_context statics (include/gnn/gpu_context.h:4-16,
 // src/utilities/random.cpp:62-80) and the malloc/copy helpers
 // (include/utils/math_functions.hh:161-173, include/utils/cutils.h:193-202).
+#include <algorithm>
 #include <stdarg.h>
 #include <string.h>
 #include <utility>
@@ -438,6 +439,62 @@ extern "C" int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, d
   }
   *h_count = n;
   *h_total_ms = ms;
+  return GAIB_OK;
+}
+
+// the same with the launches' algorithmic work (the figures the sites state: SURVEY.md 8(d)) and the time the launches would
+// take at the chip's roofs -- per launch max(bytes / 8 TB/s, flops / 157.3 TFLOP/s), summed
+extern "C" int gaib_prof_get_work(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_total_ms, double* h_bytes,
+                                  double* h_flops, double* h_roof_ms) {
+  GAIB_CHECK(ctx && key && h_count && h_total_ms && h_bytes && h_flops && h_roof_ms, "gaib_prof_get_work: NULL argument");
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t n = 0;
+  double ms = 0.0, by = 0.0, fl = 0.0, roof = 0.0;
+  for (auto& r : ctx->prof) {
+    if (strcmp(r.key, key) != 0) continue;
+    float t = 0.f;
+    GAIB_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    by += r.bytes;
+    fl += r.flops;
+    roof += 1e3 * std::max(r.bytes / GAIB_HBM_PEAK_BPS, r.flops / GAIB_MFMA_F32_PEAK_FLOPS);
+    n++;
+  }
+  *h_count = n;
+  *h_total_ms = ms;
+  *h_bytes = by;
+  *h_flops = fl;
+  *h_roof_ms = roof;
+  return GAIB_OK;
+}
+
+// every key that has records, as text: one line "key count total_ms alg_bytes flops roof_ms" per key, in order of first
+// appearance.  Returns the number of bytes the whole table needs (incl. the terminating 0) through *h_needed; writes at most
+// `cap` bytes.  (The trainer prints it on GAIB_PROF_TABLE=1; bench.py's epoch workloads parse it.)
+extern "C" int gaib_prof_table(gaib_ctx* ctx, char* h_buf, size_t cap, size_t* h_needed) {
+  GAIB_CHECK(ctx && h_needed && (h_buf || cap == 0), "gaib_prof_table: NULL argument");
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<const char*> keys;
+  for (auto& r : ctx->prof) {
+    bool seen = false;
+    for (const char* k : keys) seen = seen || strcmp(k, r.key) == 0;
+    if (!seen) keys.push_back(r.key);
+  }
+  std::string out;
+  char line[256];
+  for (const char* k : keys) {
+    int64_t n = 0;
+    double ms = 0, by = 0, fl = 0, roof = 0;
+    GAIB_TRY(gaib_prof_get_work(ctx, k, &n, &ms, &by, &fl, &roof));
+    snprintf(line, sizeof(line), "%s %lld %.6f %.0f %.0f %.6f\n", k, (long long)n, ms, by, fl, roof);
+    out += line;
+  }
+  *h_needed = out.size() + 1;
+  if (cap > 0) {
+    const size_t w = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(h_buf, out.data(), w);
+    h_buf[w] = 0;
+  }
   return GAIB_OK;
 }
 

@@ -153,7 +153,10 @@ int launch_chunked(gaib_ctx* ctx, gaib_graph* g, const SpmmArgs& a) {
   const unsigned grid = (unsigned)cdiv64(g->n_chunks > 0 ? g->n_chunks : 1, 4);
   const int lanes = (a.ncols + 3) / 4;
   {
-    ProfScope ps(ctx, "spmm_chunk");
+    // col + gathered row + the edge's weights; a partial row per chunk written (and read again by the reduction)
+    const double wb = WMODE == 0 ? 0.0 : (WMODE >= 3 ? 4.0 * a.heads : 4.0);
+    ProfScope ps(ctx, "spmm_chunk", (double)g->ne * (4.0 * a.ncols + 4.0 + wb) + (double)g->n_chunks * 4.0 * a.ncols,
+                 2.0 * (double)g->ne * a.ncols);
 #define GAIB_CHUNK(GG) \
   spmm_chunk_kernel<GG, WMODE><<<grid, 256, 0, ctx->stream>>>(g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, a, partial)
 #define GAIB_CHUNK_H(GG, HH) \
@@ -175,7 +178,7 @@ int launch_chunked(gaib_ctx* ctx, gaib_graph* g, const SpmmArgs& a) {
 #undef GAIB_CHUNK_H
     GAIB_LAUNCH_CHECK();
   }
-  ProfScope ps(ctx, "spmm_chunk_reduce");
+  ProfScope ps(ctx, "spmm_chunk_reduce", ((double)g->n_chunks + (double)a.n_rows * (a.accumulate ? 2 : 1)) * 4.0 * a.ncols);
   spmm_chunk_reduce_kernel<<<(unsigned)cdiv64(a.n_rows, 4), 256, 0, ctx->stream>>>(a, g->chunk_start, partial);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;

@@ -136,7 +136,8 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     h.row_list = g->heavy_rows;
     h.row_order = g->heavy_rows + g->n_heavy;
     size_t lds = sizeof(float) * HEAVY_WAVES * CT * 64 * VEC;
-    ProfScope ps(ctx, "spmm_heavy");
+    ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4,
+                                                         a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols);
     spmm_heavy_kernel<VEC, CT, WMODE, U, BUF, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                      ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -153,7 +154,9 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   }
   if (grid > 0) {
     // (row classes of a partition are timed under keys of their own: interior / owned-column pass, halo-column pass, one pass)
-    ProfScope ps(ctx, !PART ? "spmm_light" : (a.in2 ? "part_light_2t" : (a.accumulate ? "part_light_acc" : "part_light")));
+    const double e_l = (double)g->ne - (g->n_heavy > 0 ? (double)g->heavy_edges : 0.0), r_l = (double)a.n_rows - (double)g->n_heavy;
+    ProfScope ps(ctx, !PART ? "spmm_light" : (a.in2 ? "part_light_2t" : (a.accumulate ? "part_light_acc" : "part_light")),
+                 gaib_alg_spmm_bytes(e_l, r_l, a.ncols, WMODE == 0 ? 0 : 4, a.accumulate ? 2 : 1), 2.0 * e_l * a.ncols);
     spmm_w64_kernel<VEC, CT, WMODE, U, BUF, PART><<<dim3(grid), 256, 0, ctx->stream>>>(a);
     GAIB_LAUNCH_CHECK();
   }
@@ -186,7 +189,8 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     h.row_list = g->heavy_rows;
     h.row_order = g->heavy_rows + g->n_heavy;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
-    ProfScope ps(ctx, "spmm_heavy");
+    ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4,
+                                                         a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols);
     spmm_heavy_kernel<VEC, 1, WMODE, 8, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                  ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -199,7 +203,8 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     grid = (unsigned)a.per_xcd * 8u;
   }
   if (grid > 0) {
-    ProfScope ps(ctx, "spmm_sub");
+    const double e_l = (double)g->ne - (g->n_heavy > 0 ? (double)g->heavy_edges : 0.0), r_l = (double)a.n_rows - (double)g->n_heavy;
+    ProfScope ps(ctx, "spmm_sub", gaib_alg_spmm_bytes(e_l, r_l, a.ncols, WMODE == 0 ? 0 : 4, a.accumulate ? 2 : 1), 2.0 * e_l * a.ncols);
     spmm_sub_kernel<VEC, G, WMODE><<<dim3(grid), 256, 0, ctx->stream>>>(a);
     GAIB_LAUNCH_CHECK();
   }
@@ -857,7 +862,8 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     h.relu = 0;
     h.accumulate = 0;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
-    ProfScope ps(ctx, "spmm_heavy");
+    ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4, 1),
+                 2.0 * g->heavy_edges * a.ncols);
     if (buf) spmm_heavy_kernel<VEC, 1, WMODE, U, 1, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     else spmm_heavy_kernel<VEC, 1, WMODE, U, 0, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -873,7 +879,14 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
   if (f.overlaps_transfer && gaib_comm_reserve(ctx) > 0) cus = std::max(cus - gaib_comm_reserve(ctx), std::min(cus, 64));
   const unsigned grid = (unsigned)std::min<int64_t>(cus, cdiv64(ntiles, FUSE_WAVES));
   GAIB_HIP(hipMemsetAsync(f.tile_counter, 0, 8 * sizeof(int), ctx->stream));  // one counter per XCD
-  ProfScope ps(ctx, !PART ? "spmm_gemm_fused" : (a.in2 ? "part_fused_2t" : (f.agg_in ? "part_fused_acc" : "part_fused")));
+  // SURVEY 8(d) for the aggregation part (the heavy rows' edges are the heavy kernel's) + what the riding product moves: the
+  // aggregate rows stored (unless scratch) or continued (agg_in), y written (read too on a later K-slab), the second row operand
+  const double e_l = (double)g->ne - (g->n_heavy > 0 ? (double)g->heavy_edges : 0.0), r_all = (double)a.n_rows;
+  const double fused_bytes = gaib_alg_spmm_bytes(e_l, r_all, a.ncols, WMODE == 0 ? 0 : 4, (a.out ? 1 : 0) + (f.agg_in ? 1 : 0) + (dual ? 1 : 0)) +
+                             r_all * 4.0 * f.n_out * (f.y_accum ? 2 : 1);
+  const double fused_flops = 2.0 * e_l * a.ncols + 2.0 * r_all * a.ncols * f.n_out * (dual ? 2 : 1);
+  ProfScope ps(ctx, !PART ? "spmm_gemm_fused" : (a.in2 ? "part_fused_2t" : (f.agg_in ? "part_fused_acc" : "part_fused")), fused_bytes,
+               fused_flops);
   // more than 64 KB of dynamic LDS has to be asked for
   // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
   // spill and are reloaded inside the MFMA loop)
