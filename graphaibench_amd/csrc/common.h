@@ -106,7 +106,9 @@ struct gaib_ctx {
   // in-stream kernel timing (gaib_prof_*)
   int prof_on;
   // bytes / flops: the ALGORITHMIC work of the launch as SURVEY.md 8(d) prices it (0: not stated by the site)
-  struct ProfRec { const char* key; hipEvent_t a, b; double bytes, flops; };
+  // cols: the row width of a gather kernel's launch (0: not a gather kernel) -- the table lists them per width ("key@cols"),
+  // because a row that is no whole number of 128-B lines costs more than its bytes
+  struct ProfRec { const char* key; hipEvent_t a, b; double bytes, flops; int cols; };
   std::vector<ProfRec> prof;
 };
 
@@ -132,12 +134,13 @@ static inline double gaib_alg_spmm_bytes(double edges, double rows, double cols,
 struct ProfScope {
   gaib_ctx* c;
   size_t idx;
-  ProfScope(gaib_ctx* ctx, const char* key, double bytes = 0.0, double flops = 0.0) : c(ctx), idx((size_t)-1) {
+  ProfScope(gaib_ctx* ctx, const char* key, double bytes = 0.0, double flops = 0.0, int cols = 0) : c(ctx), idx((size_t)-1) {
     if (!c->prof_on || c->capturing) return;
     gaib_ctx::ProfRec r;
     r.key = key;
     r.bytes = bytes;
     r.flops = flops;
+    r.cols = cols;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, c->stream);
     c->prof.push_back(r);

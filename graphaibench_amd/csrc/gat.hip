@@ -1556,11 +1556,9 @@ static bool gat_fused_shape(int len, int heads) {
     else { GAIB_GAT_BY_HEADS(32, M, M(32, 16)) }                \
   } while (0)
 
-// The fused edge side of backward (gat_bwd_fused_chunk_kernel).  Shapes: gat_fused_shape(); otherwise, or where the auto
-// rule says the ordered-chunk sweep does not pay (option
-// gat_fused_bwd: -1 = graphs with >= 1/4 of their edges in heavy rows and a feature table of <= 512 MB -- the
-// dense-graph rule of the aggregation; 0 = never; 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and
-// nothing was touched: the caller runs the staged entry points.
+// The fused edge side of backward (gat_bwd_fused_chunk_kernel).  Shapes: gat_fused_shape(); otherwise, or with the option off (option
+// gat_fused_bwd: 0 = never; -1 / 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and nothing was touched: the
+// caller runs the staged entry points.
 static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, int knob, uintptr_t align_or, int* rc,
                               bool rect = false) {
   *rc = GAIB_OK;
@@ -1577,14 +1575,14 @@ static bool gat_fused_applies(gaib_ctx* ctx, gaib_graph* g, int len, int heads, 
     }
     return heads_ok && knob != 0;
   }
+  // Round 5: the rule is the SHAPE.  Until round 4 the automatic choice (knob < 0) also asked for a dense graph (a quarter of
+  // the edges in heavy rows) over a table of <= 512 MB -- the rule of the ordered-chunk aggregation.  Measured with the kernels
+  // at every width (scripts/perf_guard.py, profiles/r05/perf_guard.log): the one sweep wins wherever it applies -- reddit shape
+  // 8 heads x 32: 5.06 vs 15.95 ms per layer step, x 64: 8.8 vs 17.8, x 128: 18.4 vs 26.0; products shape (sparse: one short
+  // chunk per row, a 627 MB table) 1 head x 64: 19.7 vs 21.2 -- so nothing is left for the staged kernels but the widths
+  // outside gat_fused_shape(), attention dropout and the explicit option.
   const bool shape_ok = heads_ok && g->nc == g->nv && g->ne > 0 && (align_or & 15) == 0;
-  bool use = shape_ok && knob != 0;
-  if (use && knob < 0) {  // (not on a rank's share of a partition: the staged pieces there cost two permuted [ne][H] copies more)
-    *rc = gaib_graph_ensure_heavy(ctx, g, ctx->spmm_heavy_threshold);
-    if (*rc != GAIB_OK) return false;
-    use = g->n_heavy > 0 && 4 * g->heavy_edges >= g->ne && (int64_t)g->nv * len * 4 <= ((int64_t)512 << 20);
-  }
-  return use;
+  return shape_ok && knob != 0;
 }
 
 // Forward in one sweep (gat_fwd_fused_chunk_kernel): d_out = act(P h) and d_row_stats [nv][heads][2] = (row maximum of

@@ -468,25 +468,36 @@ extern "C" int gaib_prof_get_work(gaib_ctx* ctx, const char* key, int64_t* h_cou
   return GAIB_OK;
 }
 
-// every key that has records, as text: one line "key count total_ms alg_bytes flops roof_ms" per key, in order of first
-// appearance.  Returns the number of bytes the whole table needs (incl. the terminating 0) through *h_needed; writes at most
-// `cap` bytes.  (The trainer prints it on GAIB_PROF_TABLE=1; bench.py's epoch workloads parse it.)
+// every key that has records, as text: one line "key[@cols] count total_ms alg_bytes flops roof_ms" per (key, row width of a
+// gather kernel), in order of first appearance.  Returns the number of bytes the whole table needs (incl. the terminating
+// 0) through *h_needed; writes at most `cap` bytes.  (The trainer prints it on GAIB_PROF_TABLE; bench.py's epoch workloads
+// parse it.)
 extern "C" int gaib_prof_table(gaib_ctx* ctx, char* h_buf, size_t cap, size_t* h_needed) {
   GAIB_CHECK(ctx && h_needed && (h_buf || cap == 0), "gaib_prof_table: NULL argument");
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
-  std::vector<const char*> keys;
+  struct Row { const char* key; int cols; int64_t n; double ms, by, fl, roof; };
+  std::vector<Row> rows;
   for (auto& r : ctx->prof) {
-    bool seen = false;
-    for (const char* k : keys) seen = seen || strcmp(k, r.key) == 0;
-    if (!seen) keys.push_back(r.key);
+    Row* at = nullptr;
+    for (auto& q : rows)
+      if (q.cols == r.cols && strcmp(q.key, r.key) == 0) at = &q;
+    if (!at) {
+      rows.push_back(Row{r.key, r.cols, 0, 0, 0, 0, 0});
+      at = &rows.back();
+    }
+    float t = 0.f;
+    GAIB_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    at->n++;
+    at->ms += t;
+    at->by += r.bytes;
+    at->fl += r.flops;
+    at->roof += 1e3 * std::max(r.bytes / GAIB_HBM_PEAK_BPS, r.flops / GAIB_MFMA_F32_PEAK_FLOPS);
   }
   std::string out;
-  char line[256];
-  for (const char* k : keys) {
-    int64_t n = 0;
-    double ms = 0, by = 0, fl = 0, roof = 0;
-    GAIB_TRY(gaib_prof_get_work(ctx, k, &n, &ms, &by, &fl, &roof));
-    snprintf(line, sizeof(line), "%s %lld %.6f %.0f %.0f %.6f\n", k, (long long)n, ms, by, fl, roof);
+  char line[320];
+  for (auto& q : rows) {
+    if (q.cols > 0) snprintf(line, sizeof(line), "%s@%d %lld %.6f %.0f %.0f %.6f\n", q.key, q.cols, (long long)q.n, q.ms, q.by, q.fl, q.roof);
+    else snprintf(line, sizeof(line), "%s %lld %.6f %.0f %.0f %.6f\n", q.key, (long long)q.n, q.ms, q.by, q.fl, q.roof);
     out += line;
   }
   *h_needed = out.size() + 1;

@@ -137,7 +137,7 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     h.row_order = g->heavy_rows + g->n_heavy;
     size_t lds = sizeof(float) * HEAVY_WAVES * CT * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4,
-                                                         a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols);
+                                                         a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols, a.ncols);
     spmm_heavy_kernel<VEC, CT, WMODE, U, BUF, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                      ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -156,7 +156,7 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     // (row classes of a partition are timed under keys of their own: interior / owned-column pass, halo-column pass, one pass)
     const double e_l = (double)g->ne - (g->n_heavy > 0 ? (double)g->heavy_edges : 0.0), r_l = (double)a.n_rows - (double)g->n_heavy;
     ProfScope ps(ctx, !PART ? "spmm_light" : (a.in2 ? "part_light_2t" : (a.accumulate ? "part_light_acc" : "part_light")),
-                 gaib_alg_spmm_bytes(e_l, r_l, a.ncols, WMODE == 0 ? 0 : 4, a.accumulate ? 2 : 1), 2.0 * e_l * a.ncols);
+                 gaib_alg_spmm_bytes(e_l, r_l, a.ncols, WMODE == 0 ? 0 : 4, a.accumulate ? 2 : 1), 2.0 * e_l * a.ncols, a.ncols);
     spmm_w64_kernel<VEC, CT, WMODE, U, BUF, PART><<<dim3(grid), 256, 0, ctx->stream>>>(a);
     GAIB_LAUNCH_CHECK();
   }
@@ -190,7 +190,7 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     h.row_order = g->heavy_rows + g->n_heavy;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4,
-                                                         a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols);
+                                                         a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols, a.ncols);
     spmm_heavy_kernel<VEC, 1, WMODE, 8, 0><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
                                                  ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -204,7 +204,7 @@ int launch_sub(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
   }
   if (grid > 0) {
     const double e_l = (double)g->ne - (g->n_heavy > 0 ? (double)g->heavy_edges : 0.0), r_l = (double)a.n_rows - (double)g->n_heavy;
-    ProfScope ps(ctx, "spmm_sub", gaib_alg_spmm_bytes(e_l, r_l, a.ncols, WMODE == 0 ? 0 : 4, a.accumulate ? 2 : 1), 2.0 * e_l * a.ncols);
+    ProfScope ps(ctx, "spmm_sub", gaib_alg_spmm_bytes(e_l, r_l, a.ncols, WMODE == 0 ? 0 : 4, a.accumulate ? 2 : 1), 2.0 * e_l * a.ncols, a.ncols);
     spmm_sub_kernel<VEC, G, WMODE><<<dim3(grid), 256, 0, ctx->stream>>>(a);
     GAIB_LAUNCH_CHECK();
   }
@@ -863,7 +863,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
     h.accumulate = 0;
     size_t lds = sizeof(float) * HEAVY_WAVES * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4, 1),
-                 2.0 * g->heavy_edges * a.ncols);
+                 2.0 * g->heavy_edges * a.ncols, a.ncols);
     if (buf) spmm_heavy_kernel<VEC, 1, WMODE, U, 1, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     else spmm_heavy_kernel<VEC, 1, WMODE, U, 0, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds, ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
@@ -886,7 +886,7 @@ int launch_fused(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a, FuseArgs f, flo
                              r_all * 4.0 * f.n_out * (f.y_accum ? 2 : 1);
   const double fused_flops = 2.0 * e_l * a.ncols + 2.0 * r_all * a.ncols * f.n_out * (dual ? 2 : 1);
   ProfScope ps(ctx, !PART ? "spmm_gemm_fused" : (a.in2 ? "part_fused_2t" : (f.agg_in ? "part_fused_acc" : "part_fused")), fused_bytes,
-               fused_flops);
+               fused_flops, a.ncols);
   // more than 64 KB of dynamic LDS has to be asked for
   // (the edge-stream form keeps 8 gathers in flight, not 16: with 16 the operand fragments of the dense product
   // spill and are reloaded inside the MFMA loop)

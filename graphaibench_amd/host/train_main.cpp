@@ -26,6 +26,8 @@
 // others and exits non-zero -- one entry point drives all devices, as the reference's multi-GPU programs do from one
 // main (src/triangle/multigpu_induced.cu:31-84); RCCL itself has no deadline for a peer that died.
 #include <omp.h>
+#include <algorithm>
+#include <string>
 #include <fcntl.h>
 #include <signal.h>
 #include <sys/stat.h>
@@ -620,7 +622,18 @@ struct Trainer {
     double total = 0.0;
     int num_subg_remain = 0;
     unsigned long long edges_epoch = 0;  // edges aggregated by a steady-state epoch (the aggregators count per call)
+    // GAIB_PROF_TABLE=k: in-stream timing of every library launch from epoch k on (default 1: epoch 0 allocates and builds
+    // the graph's lazily made tables), printed after the run as "[gaib prof] key count total_ms alg_bytes flops roof_ms" --
+    // what bench.py's epoch workloads build their roofline record from.  Not with recorded epochs (nothing is launched call by call).
+    const char* pt = getenv("GAIB_PROF_TABLE");
+    const int prof_from = (pt && *pt && !graph_mode) ? std::max(0, atoi(pt)) : -1;
+    int prof_epochs = 0;
     for (int itr = 0; itr < num_epochs; itr++) {
+      if (itr == prof_from) {
+        GAIB_OR_DIE(gaib_prof_reset(gpu_context::get()));
+        GAIB_OR_DIE(gaib_prof_enable(gpu_context::get(), 1));
+      }
+      if (prof_from >= 0 && itr >= prof_from) prof_epochs++;
       const unsigned long long edges_before = gpu_context::aggregated_edges();
       if (subg_size > 0) subgraph_sampling(num_subg_remain);
       std::cout << "Epoch " << std::setw(3) << itr << " ";
@@ -675,6 +688,26 @@ struct Trainer {
       } else {
         std::cout << "train_time " << std::fixed << epoch_time << " s (fw " << fw << ", bw " << bw << ")\n";
       }
+    }
+    if (prof_from >= 0 && prof_epochs > 0) {
+      gaib_ctx* c = gpu_context::get();
+      GAIB_OR_DIE(gaib_prof_enable(c, 0));
+      size_t need = 0;
+      GAIB_OR_DIE(gaib_prof_table(c, NULL, 0, &need));
+      std::string tab(need + 1, '\0');
+      GAIB_OR_DIE(gaib_prof_table(c, &tab[0], tab.size(), &need));
+      if (root()) {
+        std::cout << "[gaib prof] epochs " << prof_epochs << "\n";
+        size_t a = 0;
+        const std::string text(tab.c_str());
+        while (a < text.size()) {
+          size_t b = text.find('\n', a);
+          if (b == std::string::npos) b = text.size();
+          if (b > a) std::cout << "[gaib prof] " << text.substr(a, b - a) << "\n";
+          a = b + 1;
+        }
+      }
+      GAIB_OR_DIE(gaib_prof_reset(c));
     }
     std::cout << "Average training time per epoch: " << total / (double)num_epochs << " seconds. Throughput "
               << (double)num_epochs / total << " epoch/s\n";

@@ -296,3 +296,37 @@ def block_rows(name: str, rank: int, world: int, seed: int = 42, cut_fraction: f
     rowptr = torch.zeros(nv_p + 1, dtype=torch.int64, device=device)
     torch.cumsum(counts, 0, out=rowptr[1:])
     return BlockRows(rowptr, cols, n_global, nv_p)
+
+
+def write_dataset(name: str, root, scale: float = 1.0, device="cuda", seed: int = 42):
+    """The named shape as a dataset directory in the reference's binary format (src/gnn/reader.cpp:414-457):
+    root/name/graph.{meta.txt,vertex.bin,edge.bin,vlabel.bin,feats.bin} -- what the trainer CLI reads.  Topology: make();
+    features: class mean + noise (training has something to learn), seed 43; labels uniform, seed 44; masks = the contiguous
+    8 % / 2 % / 90 % ranges of the meta file.  Returns dict(nv, ne, F, C, train_begin, train_end, dir)."""
+    from pathlib import Path
+
+    import numpy as np
+
+    nv0, nnz0, maxdeg, F, C = SHAPES[name]
+    sg = make(name, seed=seed, device=device, scale=scale)
+    d = Path(root) / name
+    d.mkdir(parents=True, exist_ok=True)
+    sg.rowptr.cpu().numpy().astype(np.int64).tofile(d / "graph.vertex.bin")
+    sg.colidx.cpu().numpy().view(np.uint32).tofile(d / "graph.edge.bin")
+    nv, ne = sg.nv, sg.ne
+    g = torch.Generator(device="cpu").manual_seed(44)
+    labels = torch.randint(0, C, (nv,), generator=g, dtype=torch.int64)
+    labels.numpy().astype(np.uint8).tofile(d / "graph.vlabel.bin")
+    gen = torch.Generator(device=device).manual_seed(43)
+    centers = torch.randn(C, F, device=device, generator=gen)
+    with open(d / "graph.feats.bin", "wb") as f:
+        step = 1 << 18
+        for s in range(0, nv, step):
+            lab = labels[s:s + step].to(device)
+            x = centers[lab] * 0.5 + torch.randn(lab.numel(), F, device=device, generator=gen)
+            f.write(x.float().cpu().numpy().tobytes())
+    max_degree = int((sg.rowptr[1:] - sg.rowptr[:-1]).max())
+    tr, va = int(0.08 * nv), int(0.10 * nv)
+    meta = [nv, ne, 4, 8, 1, 2, max_degree, F, C, 0, 0, tr, tr, tr, va, va - tr, va, nv, nv - va]
+    (d / "graph.meta.txt").write_text("\n".join(str(v) for v in meta) + "\n")
+    return dict(nv=nv, ne=ne, F=F, C=C, train_begin=0, train_end=tr, max_degree=max_degree, dir=str(d))

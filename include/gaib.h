@@ -269,8 +269,9 @@ int gaib_gat_softmax_bwd_alpha_re(gaib_ctx* ctx, gaib_graph* g, int len, int hea
  * alpha gradients, transpose, gradient aggregation) in ONE sweep over the edges.  d_fwd_out is the aggregation's forward
  * output (sum_e p_e dp_e of a row == <grad_i, out_i>); d_grad_out [nv x len] must not alias an input.  Nothing per edge is
  * written: the per-edge arrays dp / ds / p^T of the staged entry points do not exist on this path.  The attention comes
- * from d_norm_scores [ne][heads], or -- when d_row_stats (gaib_gat_forward_fused) is given -- is formed again.  Applies to len == 64
- * with 1, 2, 4, 8 or 16 heads on dense graphs (option "gat_fused_bwd": -1 auto, 0 never, 1 whenever the shape fits);
+ * from d_norm_scores [ne][heads], or -- when d_row_stats (gaib_gat_forward_fused) is given -- is formed again.  Applies to
+ * len == 32, 64 or 128 (8, 16 or 32 lanes x 4 columns per edge; the reference's GAT covers len <= 128, global.h:58) with 1, 2, 4,
+ * 8 or 16 heads of at least 4 columns, on any graph (option "gat_fused_bwd": -1 or 1 = whenever the shape fits, 0 = never);
  * otherwise returns GAIB_ERR_UNSUPPORTED without touching anything and the caller uses the staged entry points. */
 int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const float* d_feat, const float* d_grad,
                             const float* d_fwd_out, const float* d_alpha_l, const float* d_alpha_r,
@@ -297,8 +298,8 @@ int gaib_gat_score_signs(gaib_ctx* ctx, gaib_graph* g, int len, int heads, const
  * structure, no reverse exchange.  phase: -1 = everything; 0 = only the chunks over owned columns (may run while the halo
  * rows are still arriving: it reads owned rows only); 1 = the remaining chunks + the per-row combination (phase 0's
  * partial results wait in the context's workspace: no other call on the context in between).  The alpha gradients cover
- * the owned rows; the caller sums them over the ranks.  Same shape cover as gaib_gat_backward_fused (len == 64; 1, 2, 4,
- * 8 or 16 heads; options gat_fused_fwd / gat_fused_bwd = 0 switch them off), else GAIB_ERR_UNSUPPORTED.
+ * the owned rows; the caller sums them over the ranks.  Same shape cover as gaib_gat_backward_fused (len 32 / 64 / 128; 1, 2,
+ * 4, 8 or 16 heads of >= 4 columns; options gat_fused_fwd / gat_fused_bwd = 0 switch them off), else GAIB_ERR_UNSUPPORTED.
  * A graph WITHOUT rows (a rank of a partition with fewer vertices than ranks) is accepted with NULL buffers: the answer --
  * GAIB_OK or GAIB_ERR_UNSUPPORTED -- then follows from len, heads and the option alone, i.e. it is what the ranks that do have
  * rows get (the two paths differ in their halo exchanges: all ranks must take the same one), nothing is written except zero

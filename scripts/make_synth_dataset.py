@@ -49,31 +49,8 @@ def main():
     args = ap.parse_args()
     if args.name == "cora":
         return cora(Path(args.root))
-    nv0, nnz0, maxdeg, F, C = synth.SHAPES[args.name]
-    sg = synth.make(args.name, seed=42, device=args.device, scale=args.scale)
-    d = Path(args.root) / args.name
-    d.mkdir(parents=True, exist_ok=True)
-    rp = sg.rowptr.cpu().numpy().astype(np.int64)
-    ci = sg.colidx.cpu().numpy().view(np.uint32)
-    rp.tofile(d / "graph.vertex.bin")
-    ci.tofile(d / "graph.edge.bin")
-    nv, ne = sg.nv, sg.ne
-    g = torch.Generator(device="cpu").manual_seed(44)
-    labels = torch.randint(0, C, (nv,), generator=g, dtype=torch.int64)
-    labels.numpy().astype(np.uint8).tofile(d / "graph.vlabel.bin")
-    gen = torch.Generator(device=args.device).manual_seed(43)
-    centers = torch.randn(C, F, device=args.device, generator=gen)
-    with open(d / "graph.feats.bin", "wb") as f:
-        step = 1 << 18
-        for s in range(0, nv, step):
-            lab = labels[s:s + step].to(args.device)
-            x = centers[lab] * 0.5 + torch.randn(lab.numel(), F, device=args.device, generator=gen)
-            f.write(x.float().cpu().numpy().tobytes())
-    max_degree = int((sg.rowptr[1:] - sg.rowptr[:-1]).max())
-    tr, va = int(0.08 * nv), int(0.10 * nv)
-    meta = [nv, ne, 4, 8, 1, 2, max_degree, F, C, 0, 0, tr, tr, tr, va, va - tr, va, nv, nv - va]
-    (d / "graph.meta.txt").write_text("\n".join(str(v) for v in meta) + "\n")
-    print(f"wrote {d}: nv={nv} ne={ne} F={F} C={C} max_degree={max_degree}")
+    info = synth.write_dataset(args.name, args.root, scale=args.scale, device=args.device)
+    print(f"wrote {info['dir']}: nv={info['nv']} ne={info['ne']} F={info['F']} C={info['C']} max_degree={info['max_degree']}")
 
 
 if __name__ == "__main__":

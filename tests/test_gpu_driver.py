@@ -35,58 +35,7 @@ def make_dataset(tmp_path, feat_len=96, seed=0):
     return str(tmp_path / "data") + "/", x, labels, [int(v) for v in meta[10:19]]
 
 
-class OracleModel:
-    def __init__(self, arch, rp, ci, F, H, C, L, lr):
-        self.arch, self.lr, self.L = arch, lr, L
-        g = orc.Graph(rp, ci)
-        self.g = g if arch == "sage" else g.add_selfloop()
-        last = H if arch == "gat" else C
-        dims = [(F if l == 0 else H, H if l < L - 1 else last) for l in range(L)]
-        mk = {"gcn": orc.GCNLayer, "sage": orc.SAGELayer, "gat": lambda *a: orc.GATLayer(*a, fast=True)}[arch]
-        self.layers = [mk(l, self.g, di, do, l < L - 1) for l, (di, do) in enumerate(dims)]
-        self.opt = orc.Adam(lr)                      # shared by GCN / GAT gconv weights (Q6)
-        self.optm = [orc.Adam(lr) for _ in range(L)]  # SAGE: per layer
-        self.alpha_opt = [orc.Adam(lr) for _ in range(L)]
-        if arch == "gat":
-            self.Wd = orc.init_glorot(H, C, 1)
-            self.dense_opt = orc.Adam(lr)
-
-    def epoch(self, x, labels, begin, end, masks, sigmoid=False):
-        acts = [x]
-        for l in self.layers:
-            acts.append(l.forward(acts[-1]))
-        if self.arch == "gat":
-            z = orc.l2norm(acts[-1])
-            logits = orc.matmul(z, self.Wd)
-        else:
-            logits = acts[-1]
-        if sigmoid:  # labels: [n x C] multi-hot rows
-            probs, lv = orc.sigmoid_xent_fwd(logits, labels, begin, end, masks)
-            acc = orc.masked_f1_micro(probs, labels, begin, end, masks)
-            g = orc.sigmoid_xent_bwd(probs, labels, begin, end, masks)
-        else:
-            probs, lv = orc.softmax_xent_fwd(logits, labels, begin, end, masks)
-            acc = orc.masked_accuracy_single(logits, labels, begin, end, masks)
-            g = orc.softmax_xent_bwd(probs, labels, begin, end, masks)
-        loss = orc.masked_avg_loss(lv, begin, end, masks)
-        if self.arch == "gat":
-            dWd = orc.matmul(z, g, True, False)
-            gz = orc.matmul(g, self.Wd, False, True)
-            self.dense_opt.update("wd", dWd, self.Wd)  # dense_layer::backward updates its own weights
-            g = orc.d_l2norm(acts[-1], gz)
-        for l in reversed(self.layers):
-            g = l.backward(np.ascontiguousarray(g))
-        for i, l in enumerate(self.layers):
-            if self.arch == "gcn":
-                self.opt.update(("w", i), l.W_grad, l.W)
-            elif self.arch == "sage":
-                self.optm[i].update(("wn", i), l.W_neigh_grad, l.W_neigh)
-                self.optm[i].update(("ws", i), l.W_self_grad, l.W_self)
-            else:
-                self.opt.update(("w", i), l.W_grad, l.W)
-                self.alpha_opt[i].update(("al", i), l.alpha_lgrad, l.alpha_l)
-                self.alpha_opt[i].update(("ar", i), l.alpha_rgrad, l.alpha_r)
-        return loss, acc
+from oracle.model import OracleModel  # noqa: E402  (the reference's Model composed from the oracle's layers)
 
 
 @pytest.mark.parametrize("arch,layers", [("gcn", 2), ("sage", 2), ("gat", 2), ("gcn", 3)])
