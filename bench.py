@@ -16,17 +16,29 @@ inputs resident in HBM when the timed region starts.
         (one entry point drives all devices, like the reference's multi-GPU programs: src/triangle/multigpu_induced.cu:31-84);
       * python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...  (the ranks given from outside).
     Ranks map to devices as LOCAL_RANK % visible devices; with fewer devices than ranks (a one-GPU box) the data path is
-    the peer-to-peer pull transport, which lets several ranks share a device, and the record says so (config.transport).
-    The N > 1 record cannot be lost: the headline case runs first and rank 0 HOLDS its record (RecordGuard); every further
-    sub-case -- the N = 1 CPU baseline, the clustered-boundary generator, the random vertex order, config 5 at N = 8 -- starts
+    the peer-to-peer pull transport, which lets several ranks share a device, and the record says so (config.transport,
+    config.ranks_share_device, roofline.ranks_share_device: such timings are evidence of nothing).
+
+    What an N > 1 run measures (round 5; DESIGN.md 5 "which figure is value"):
+      `value`  north_star's curve -- the N = 1 bench graph (products shape, seed 42, random vertex order) partitioned N ways by
+               vertex range (graph_partition.cc:128-178), "scaling": "strong"; config.strong_products repeats it with the
+               one-rank timing of the same graph taken in the run (speedup_vs_n1).  Its parity is element-wise against the
+               oracle's run on the WHOLE graph (the run the N = 1 bench makes), whose timing is also the record's cpu_baseline.
+      second   config.weak_products_range: a products-shaped vertex range per GPU of one block graph at cut 0.1 (--scaling weak
+               swaps the two), then config.cu_reserve_ab and config.transport_ab -- the run measures its own constants on the
+               live headline case -- config.xgmi_link_probe (measured FIRST and fed to the partition-mode rule before any
+               partition exists), the weak generator's parity legs at bounded size, config.clustered_boundary,
+               config.random_order, and at N = 8 config.config5_papers100M.
+    The N > 1 record cannot be lost: the headline case runs first and rank 0 HOLDS its record (RecordGuard: SIGTERM / SIGINT
+    blocked as main()'s first act, before torch is imported, so no native thread can take them); every further leg starts
     only if all ranks agree that it fits --budget-s (420 s; else its slot says {"skipped": "budget", ...}); on --deadline-s
-    (560 s), SIGTERM or SIGINT -- or an exception on any rank after the headline case -- rank 0 prints what it holds, marked
-    "partial", and exits 0.  A default N > 1 record also carries `parity`: two budgeted legs of bounded global size (uniform and
-    clustered-boundary generator), every rank's rows against the oracle's run on the GLOBAL graph over the run's own transport;
-    `cpu_baseline` (the N = 1 workload's, named as such); `roofline.traffic` where a PMC pass of the dominant kernel on that
-    shard exists.  The N = 1 and GAT records are held the same way once their GPU measurement is complete.
+    (560 s), a signal, or an exception on any rank after the headline case rank 0 prints what it holds, marked "partial",
+    with parity = {"ok": null, "reason"} if the comparison had not completed, and exits 0.  A heartbeat line goes to stderr
+    every minute.  The N = 1, GAT and epoch records are held the same way once their GPU measurement is complete.
     --workload gcn-papers: BASELINE config 5's layer (GCN 128 -> 128 on the ogbn-papers100M-shaped graph in vertex ranges
     of 1/8 of it: at N = 8 the whole graph); --check-oracle compares every rank's outputs with the oracle's GLOBAL run.
+    --workload gat-reddit: config 4's layer.  --workload epoch-sage-products | epoch-gcn-products | epoch-gat-reddit: one
+    training EPOCH of the model configs through the trainer CLI per step (bench_epoch).
 
 One JSON line on rank 0.  `roofline` prices the dominant kernel (spmm_gemm_kernel: the one-wave-per-row
 aggregation with the dense product riding on it) by ALGORITHMIC bytes per launch / mean launch time measured

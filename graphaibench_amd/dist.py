@@ -859,7 +859,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         weak_workload = ("block Chung-Lu graph, one ogbn-products-shaped vertex range per GPU (seed 42), "
                          "GCN hidden layer 128->128 fwd+bwd, halo exchange before each SpMM + dW all-reduce")
 
-    def strong_rows():
+    def strong_rows(one_rank=True):
         """this rank's rows of the single-GPU bench graph (every rank generates the whole graph: seeded, identical) and, on
         rank 0, the one-rank timing of the same layer on the whole graph (the denominator of speedup_vs_n1) while the full
         CSR is on the device anyway"""
@@ -877,7 +877,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         del rp_all, ci_all
         torch.cuda.empty_cache()
         one = None
-        if rank == 0 and os.environ.get("GAIB_BENCH_ONE_RANK", "1") != "0":
+        if one_rank and rank == 0 and os.environ.get("GAIB_BENCH_ONE_RANK", "1") != "0":
             try:
                 one = _one_rank_timing(ctx, g1, args, D)  # (takes the graph over and closes it)
             except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline record
@@ -888,16 +888,17 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         dist.barrier()  # (the others wait here for rank 0's one-rank timing: the cases start together)
         return rows, b, one
 
-    def ab_legs(case, res):
-        """the run measures its own constants on the live headline case: each leg budgeted, each
-        {"skipped": reason} where it would not measure anything"""
-        force = os.environ.get("GAIB_BENCH_AB", "") == "force"  # rehearsals / tests: run the bookkeeping on a shared device too
-        if os.environ.get("GAIB_BENCH_AB", "1") == "0" or not default_run:
+    ab_on = os.environ.get("GAIB_BENCH_AB", "1") != "0" and default_run
+    ab_force = os.environ.get("GAIB_BENCH_AB", "") == "force"  # rehearsals / tests: run the bookkeeping on a shared device too
+
+    def cu_reserve_leg(case, res):
+        """the run measures its own constants, (b): the CUs left to the transport, on the LIVE headline case --
+        the same communicator and plan, only the option changes -- budgeted, {"skipped": reason} where it would not measure anything"""
+        if not ab_on:
             return
         step_s = max(res["ms_per_step"] * 1e-3, 1e-3)
-        # (b) CUs left to the transport
         need = min(20.0, 3 * 8 * step_s + 3)
-        if share and not force:
+        if share and not ab_force:
             ab["cu_reserve_ab"] = {"skipped": "ranks share a device: the transport and the fused kernel would compete for the same CUs whatever is reserved"}
         elif comm is None:
             ab["cu_reserve_ab"] = {"skipped": "torch.distributed carries the rows: no GAIB_OVERLAPS_TRANSFER launches"}
@@ -907,37 +908,49 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
             ab["cu_reserve_ab"] = case.cu_reserve_ab(steps=max(3, min(8, int(5.0 / step_s))))
             if share:
                 ab["cu_reserve_ab"]["ranks_share_device"] = True
-        # (c) the same plan over RCCL and over the peer-to-peer pull
-        need = 20.0
-        if comm is None:
-            ab["transport_ab"] = {"skipped": "torch.distributed carries the rows: no gaib_comm plan to re-time"}
-        elif not budget.agree(need):
-            ab["transport_ab"] = budget.skipped(need)
-        else:
-            mine = "rccl" if transport.startswith("gaib_comm/rccl") else "ipc"
-            tr = {mine: comm}
-            made = None
-            other_t, other_name = (capi.COMM_IPC, "ipc") if mine == "rccl" else (capi.COMM_RCCL, "rccl")
-            if other_name == "rccl":
-                ok, why = rccl_possible(ctx, world)
-                if not ok:
-                    tr["rccl"] = (None, why)
-                elif "rccl" in transport:  # "gaib_comm/ipc (after rccl failed at set-up)": do not walk into the same failure twice
-                    tr["rccl"] = (None, "RCCL failed at set-up in this run")
-            if other_name not in tr:
-                made, err = comm_attempt(ctx, rank, world, other_t)
-                tr[other_name] = made if made is not None else (None, f"set-up failed: {err}"[:200])
-            try:
-                ab["transport_ab"] = {"plan": "the headline case's send / receive lists, [nv x 128] fp32, pack + transfer + wait",
-                                      "carried_the_run": mine, **case.transport_ab(tr)}
-                if share:
-                    ab["transport_ab"]["ranks_share_device"] = True
-            finally:
-                if made is not None:
-                    torch.cuda.synchronize()
-                    made.close()
         if hold is not None and rank == 0:
             hold(assemble())
+
+    def transport_leg():
+        """(c): the strong case's exchange plan timed on its own over RCCL and over the peer-to-peer pull.  The LAST leg of the
+        run: it creates a second communicator, the one step of this file that has never met real hardware with N > 1 -- if
+        it fails on some rank only, the ranks part ways and the deadline ends the run; every other figure is held by then."""
+        if not ab_on:
+            return
+        need = 25.0
+        if comm is None:
+            ab["transport_ab"] = {"skipped": "torch.distributed carries the rows: no gaib_comm plan to re-time"}
+            return
+        if not budget.agree(need):
+            ab["transport_ab"] = budget.skipped(need)
+            return
+        mine = "rccl" if transport.startswith("gaib_comm/rccl") else "ipc"
+        tr = {mine: comm}
+        made = None
+        other_t, other_name = (capi.COMM_IPC, "ipc") if mine == "rccl" else (capi.COMM_RCCL, "rccl")
+        if other_name == "rccl":
+            ok, why = rccl_possible(ctx, world)
+            if not ok:
+                tr["rccl"] = (None, why)
+            elif "rccl" in transport:  # "gaib_comm/ipc (after rccl failed at set-up)": do not walk into the same failure twice
+                tr["rccl"] = (None, "RCCL failed at set-up in this run")
+        if other_name not in tr:
+            made, err = comm_attempt(ctx, rank, world, other_t)
+            tr[other_name] = made if made is not None else (None, f"set-up failed: {err}"[:200])
+        rows, _, _ = strong_rows(one_rank=False)
+        a2 = type(args)(**{**vars(args), "steps": 1, "warmup": 0})
+        case = BenchCase(ctx, comm, a2, rank, world, D, log, rows, "transport A/B: the strong case's plan")
+        del rows
+        try:
+            ab["transport_ab"] = {"plan": "the strong case's send / receive lists, [nv x 128] fp32, pack + transfer + wait",
+                                  "carried_the_run": mine, **case.transport_ab(tr)}
+            if share:
+                ab["transport_ab"]["ranks_share_device"] = True
+        finally:
+            case.close()
+            if made is not None:
+                torch.cuda.synchronize()
+                made.close()
 
     def run_strong(on_measured, check, extras=None):
         rows, bounds, one = strong_rows()
@@ -951,10 +964,11 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                                                     "taken on rank 0's device in this run before the graph was partitioned")
         return r
 
-    def run_weak(on_measured, check):
+    def run_weak(on_measured, check, extras=None):
         rows = synth.block_rows(shape, rank, world, seed=42, cut_fraction=cut, device="cuda", scale=args.scale,
                                 selfloops=True)  # GCN aggregates over A + I (net.cpp:96)
-        return _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}", check=check, on_measured=on_measured)
+        return _bench_case(ctx, comm, args, rank, world, D, log, rows, f"cut {cut:.3f}", check=check, on_measured=on_measured,
+                           extras=extras)
 
     def assemble():
         main = state["main"]
@@ -1077,7 +1091,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
 
     t_case = time.time()
     if strong:
-        main = run_strong(on_headline, strong_check_budgeted if strong_check is not None else None, extras=ab_legs)
+        main = run_strong(on_headline, strong_check_budgeted if strong_check is not None else None, extras=cu_reserve_leg)
         # the comparison's run of the oracle on the whole bench graph IS the N = 1 workload's CPU baseline (rank 0 has it; every
         # rank must know whether it exists: the bounded-sample leg below is collective)
         if rank == 0 and isinstance(main.get("parity"), dict) and main["parity"].get("cpu_baseline"):
@@ -1089,7 +1103,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         if have[0] and rank != 0:
             cpu_rec = {"on": "rank 0"}
     else:
-        main = run_weak(on_headline, mk(cut))
+        main = run_weak(on_headline, mk(cut), extras=cu_reserve_leg)
         torch.cuda.empty_cache()
     state["main"] = main
     headline_s = state["headline_s"]
@@ -1226,6 +1240,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 config5 = {"error": "graph generation failed on some rank (see stderr)"}
             del rows
             torch.cuda.empty_cache()
+    transport_leg()
     if comm is not None:
         comm.barrier()
     return assemble()

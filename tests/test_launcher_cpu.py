@@ -395,3 +395,16 @@ def test_trainer_launcher_stops_all_ranks_when_one_fails():
     r = subprocess.run([str(exe), "cora", "1", "1", "softmax"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0
     assert "[launcher] rank" in r.stderr and "stopping the other ranks" in r.stderr
+
+
+def test_epoch_record_helpers():
+    """bench.py's epoch workloads: the 128-B lines a gathered row touches (the physical floor next to SURVEY 8(d)'s algorithmic
+    bytes) and the parser of the trainer's "[gaib prof]" table"""
+    import bench
+    from graphaibench_amd import capi
+
+    assert bench._lines_per_row(47) == 2.0 and bench._lines_per_row(128) == 4.0 and bench._lines_per_row(32) == 1.0
+    assert bench._lines_per_row(100) == 4.0 and bench._lines_per_row(16) == 1.0 and bench._lines_per_row(256) == 8.0
+    tab = capi.parse_prof_table("spmm_gemm_fused@128 4 30.5 2.3e11 1.2e11 28.75\nsgemm 6 7.25 1e10 9e11 5.7\n\nnot a line\n")
+    assert tab["spmm_gemm_fused@128"] == dict(count=4, ms=30.5, bytes=2.3e11, flops=1.2e11, roof_ms=28.75) and tab["sgemm"]["count"] == 6
+    assert set(bench.EPOCH_WORKLOADS) == {"epoch-sage-products", "epoch-gcn-products", "epoch-gat-reddit"}
