@@ -106,9 +106,10 @@ struct gaib_ctx {
   // in-stream kernel timing (gaib_prof_*)
   int prof_on;
   // bytes / flops: the ALGORITHMIC work of the launch as SURVEY.md 8(d) prices it (0: not stated by the site)
-  // cols: the row width of a gather kernel's launch (0: not a gather kernel) -- the table lists them per width ("key@cols"),
-  // because a row that is no whole number of 128-B lines costs more than its bytes
-  struct ProfRec { const char* key; hipEvent_t a, b; double bytes, flops; int cols; };
+  // tag: the shape of the launch where the price depends on it -- the row width of a gather kernel ("47": a row that is no
+  // whole number of 128-B lines costs more than its bytes), M x N x K of a dense product -- the table lists launches per
+  // "key@tag"; empty: one line per key
+  struct ProfRec { const char* key; hipEvent_t a, b; double bytes, flops; char tag[28]; };
   std::vector<ProfRec> prof;
 };
 
@@ -134,13 +135,16 @@ static inline double gaib_alg_spmm_bytes(double edges, double rows, double cols,
 struct ProfScope {
   gaib_ctx* c;
   size_t idx;
-  ProfScope(gaib_ctx* ctx, const char* key, double bytes = 0.0, double flops = 0.0, int cols = 0) : c(ctx), idx((size_t)-1) {
+  ProfScope(gaib_ctx* ctx, const char* key, double bytes = 0.0, double flops = 0.0, int cols = 0, const char* tag = nullptr)
+      : c(ctx), idx((size_t)-1) {
     if (!c->prof_on || c->capturing) return;
     gaib_ctx::ProfRec r;
     r.key = key;
     r.bytes = bytes;
     r.flops = flops;
-    r.cols = cols;
+    r.tag[0] = 0;
+    if (tag) snprintf(r.tag, sizeof(r.tag), "%s", tag);
+    else if (cols > 0) snprintf(r.tag, sizeof(r.tag), "%d", cols);
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, c->stream);
     c->prof.push_back(r);

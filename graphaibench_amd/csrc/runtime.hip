@@ -468,21 +468,21 @@ extern "C" int gaib_prof_get_work(gaib_ctx* ctx, const char* key, int64_t* h_cou
   return GAIB_OK;
 }
 
-// every key that has records, as text: one line "key[@cols] count total_ms alg_bytes flops roof_ms" per (key, row width of a
-// gather kernel), in order of first appearance.  Returns the number of bytes the whole table needs (incl. the terminating
+// every key that has records, as text: one line "key[@tag] count total_ms alg_bytes flops roof_ms" per (key, shape tag: the row
+// width of a gather kernel, M x N x K of a dense product), in order of first appearance.  Returns the number of bytes the whole table needs (incl. the terminating
 // 0) through *h_needed; writes at most `cap` bytes.  (The trainer prints it on GAIB_PROF_TABLE; bench.py's epoch workloads
 // parse it.)
 extern "C" int gaib_prof_table(gaib_ctx* ctx, char* h_buf, size_t cap, size_t* h_needed) {
   GAIB_CHECK(ctx && h_needed && (h_buf || cap == 0), "gaib_prof_table: NULL argument");
   GAIB_HIP(hipStreamSynchronize(ctx->stream));
-  struct Row { const char* key; int cols; int64_t n; double ms, by, fl, roof; };
+  struct Row { const char* key; const char* tag; int64_t n; double ms, by, fl, roof; };
   std::vector<Row> rows;
   for (auto& r : ctx->prof) {
     Row* at = nullptr;
     for (auto& q : rows)
-      if (q.cols == r.cols && strcmp(q.key, r.key) == 0) at = &q;
+      if (strcmp(q.tag, r.tag) == 0 && strcmp(q.key, r.key) == 0) at = &q;
     if (!at) {
-      rows.push_back(Row{r.key, r.cols, 0, 0, 0, 0, 0});
+      rows.push_back(Row{r.key, r.tag, 0, 0, 0, 0, 0});
       at = &rows.back();
     }
     float t = 0.f;
@@ -496,8 +496,8 @@ extern "C" int gaib_prof_table(gaib_ctx* ctx, char* h_buf, size_t cap, size_t* h
   std::string out;
   char line[320];
   for (auto& q : rows) {
-    if (q.cols > 0) snprintf(line, sizeof(line), "%s@%d %lld %.6f %.0f %.0f %.6f\n", q.key, q.cols, (long long)q.n, q.ms, q.by, q.fl, q.roof);
-    else snprintf(line, sizeof(line), "%s %lld %.6f %.0f %.0f %.6f\n", q.key, (long long)q.n, q.ms, q.by, q.fl, q.roof);
+    if (q.tag[0]) snprintf(line, sizeof(line), "%s@%s %lld %.6f %.0f %.0f %.9f\n", q.key, q.tag, (long long)q.n, q.ms, q.by, q.fl, q.roof);
+    else snprintf(line, sizeof(line), "%s %lld %.6f %.0f %.0f %.9f\n", q.key, (long long)q.n, q.ms, q.by, q.fl, q.roof);
     out += line;
   }
   *h_needed = out.size() + 1;

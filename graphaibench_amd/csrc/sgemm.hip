@@ -49,6 +49,10 @@ struct GemmArgs {
 // a dense product's work -- flops 2 M N K; bytes: both operands once, C written (and read when C +=),
 // the mask read and the masked operand written back by the d_relu form
 inline double gemm_flops(const GemmArgs& g) { return 2.0 * (double)g.M * (double)g.N * (double)g.K; }
+struct GemmTag {  // "M x N x K" for the work table (the price of a product depends on its shape: a 47-wide output is no MFMA-bound job)
+  char s[28];
+  explicit GemmTag(const GemmArgs& g) { snprintf(s, sizeof(s), "%lldx%lldx%lld", (long long)g.M, (long long)g.N, (long long)g.K); }
+};
 inline double gemm_bytes(const GemmArgs& g, int accum) {
   return 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * (accum ? 2.0 : 1.0) +
                 (g.bmask ? 2.0 * (double)g.K * g.N : 0.0));
@@ -654,7 +658,7 @@ int launch_tn_glds(gaib_ctx* ctx, GemmArgs g) {
   g.slab = g.M * g.N;
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)blocks * g.slab));
   g.C = (float*)ctx->ws;
-  ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g));
+  ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g), 0, GemmTag(g).s);
 #define GAIB_TG(MASK_)                                                                                                 \
   do {                                                                                                                 \
     const size_t lds = sizeof(float) * (size_t)TgCfg<MASK_>::STAGES * TgCfg<MASK_>::STAGE_F;                           \
@@ -697,7 +701,7 @@ int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)n_slabs * g.slab));
   g.C = (float*)ctx->ws;
   {
-    ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g));
+    ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g), 0, GemmTag(g).s);
 #define GAIB_TN(QM_, QN_)                                                                          \
   do {                                                                                             \
     if (g.bmask) sgemm_tn_reg_kernel<true, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);          \
@@ -749,7 +753,7 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
     g.slab = 0;
   }
   dim3 grid((unsigned)tiles, (unsigned)splits);
-  ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g));
+  ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g), 0, GemmTag(g).s);
   // OCC = workgroups per CU the register allocation is held to (__launch_bounds__ 2nd argument):
   // more resident blocks hide the staging / epilogue phases of one block under another's MFMAs.
 #define GAIB_GEMM_LAUNCH(AV, BV, OCC)                                                    \
@@ -943,7 +947,7 @@ int launch_stream(gaib_ctx* ctx, const GemmArgs& g) {
   const int64_t ntiles = cdiv64(g.M, 32);
   unsigned gx = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus / slabs > 0 ? ctx->num_cus / slabs : 1, cdiv64(ntiles, NNP_WAVES));
   if (slabs == 1) gx = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(ntiles, NNP_WAVES));
-  ProfScope ps(ctx, "sgemm", gemm_bytes(g, g.accum), gemm_flops(g));
+  ProfScope ps(ctx, "sgemm", gemm_bytes(g, g.accum), gemm_flops(g), 0, GemmTag(g).s);
 #define GAIB_STREAM(NTT)                                                                                        \
   do {                                                                                                          \
     GAIB_HIP(hipFuncSetAttribute((const void*)sgemm_stream_kernel<NTT, BT>,                                     \

@@ -568,8 +568,9 @@ int gaib_prof_get(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_to
 /* the same plus the launches' ALGORITHMIC work as the call sites state it (bytes of the aggregation /
  * edge kernels, flops and operand bytes of the dense products; 0 where a site states none) and h_roof_ms = the time those
  * launches would take at the chip's roofs, per launch max(bytes / 8 TB/s, flops / 157.3 TFLOP/s).  gaib_prof_table: one text
- * line "key count total_ms alg_bytes flops roof_ms" per key that has records (at most cap bytes incl. the terminating 0 are
- * written; *h_needed = what the whole table takes) -- the epoch records of bench.py are built from it */
+ * line "key[@shape] count total_ms alg_bytes flops roof_ms" per key and launch shape that has records -- shape = the row width
+ * of a gather kernel ("spmm_light@47"), M x N x K of a dense product ("sgemm@2449029x128x100") -- (at most cap bytes incl. the
+ * terminating 0 are written; *h_needed = what the whole table takes); the epoch records of bench.py are built from it */
 int gaib_prof_get_work(gaib_ctx* ctx, const char* key, int64_t* h_count, double* h_total_ms, double* h_bytes, double* h_flops,
                        double* h_roof_ms);
 int gaib_prof_table(gaib_ctx* ctx, char* h_buf, size_t cap, size_t* h_needed);

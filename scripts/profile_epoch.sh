@@ -1,9 +1,10 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of whole training epochs through the trainer CLI (BASELINE configs 3 and 4 on the
 # synthetic datasets of scripts/make_synth_dataset.py): where an epoch goes beyond the layer kernels.
-# Run on the GPU box: gpurun -- bash scripts/profile_epoch.sh ; summaries land in gpurun_out/prof_epoch/.
+# Run on the GPU box: gpurun -- bash scripts/profile_epoch.sh r05 ; summaries land in gpurun_out/prof_epoch_<round>/.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/prof_epoch
+ROUND=${1:-r05}
+OUT=$ROOT/gpurun_out/prof_epoch_$ROUND
 mkdir -p $OUT
 DATA=/tmp/gaib_data_pe
 mkdir -p $DATA
