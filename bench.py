@@ -1386,6 +1386,9 @@ def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: i
     env.pop("GAIB_RANKS", None)
     if prof_from is not None:
         env["GAIB_PROF_TABLE"] = str(prof_from)
+        # (launch-bound datasets -- <= 4 M edges: scaled-down development runs -- would be replayed as recorded HIP graphs, where
+        # nothing is launched call by call and no launch can be timed; the full-size configs run call by call anyway)
+        env["GAIB_EPOCH_GRAPH"] = "0"
     # <dataset> <epochs> <threads> <loss> <hidden> <score_drop> <feat_drop> <lr> <layers> <subgraph> <val_interval> <inductive>
     cmd = [str(exe), dataset, str(epochs), "32", "softmax", str(hidden), "0", "0", "0.01", str(layers), "0", str(epochs + 100), "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
