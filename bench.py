@@ -1439,8 +1439,9 @@ def bench_epoch(args, torch, synth, guard) -> int:
             e = {"launches_per_epoch": v["count"] / steps, "ms_per_epoch": v["ms"] / steps, "roof_ms_per_epoch": v["roof_ms"] / steps,
                  "alg_bytes_per_epoch": v["bytes"] / steps, "flops_per_epoch": v["flops"] / steps,
                  "frac": (v["roof_ms"] / v["ms"]) if v["ms"] > 0 else None}
-            if "@" in k:
-                cols = int(k.split("@")[1])
+            tag = k.split("@")[1] if "@" in k else ""
+            if tag.isdigit():  # a gather kernel's row width (dense products carry "MxNxK")
+                cols = int(tag)
                 if (cols * 4) % 128 != 0 and v["bytes"] > 0:
                     # a gathered row that is no whole number of 128-B lines: the lines it touches are the physical floor
                     lines = _lines_per_row(cols)

@@ -408,3 +408,56 @@ def test_epoch_record_helpers():
     tab = capi.parse_prof_table("spmm_gemm_fused@128 4 30.5 2.3e11 1.2e11 28.75\nsgemm 6 7.25 1e10 9e11 5.7\n\nnot a line\n")
     assert tab["spmm_gemm_fused@128"] == dict(count=4, ms=30.5, bytes=2.3e11, flops=1.2e11, roof_ms=28.75) and tab["sgemm"]["count"] == 6
     assert set(bench.EPOCH_WORKLOADS) == {"epoch-sage-products", "epoch-gcn-products", "epoch-gat-reddit"}
+
+
+def test_epoch_record_is_assembled_from_the_trainer_output(monkeypatch, tmp_path):
+    """bench_epoch with the trainer and the dataset writer replaced by canned outputs (no GPU here): the record's arithmetic --
+    value from the trainer's own epoch times and edge count, the fraction = the launches' roof time over the epoch, the
+    line floor only next to gather kernels whose rows are no whole number of lines, dense products listed per shape"""
+    import argparse
+
+    import bench
+
+    class FakeTorch:
+        class cuda:
+            @staticmethod
+            def empty_cache():
+                pass
+
+    class FakeSynth:
+        @staticmethod
+        def write_dataset(name, root, scale=1.0, device="cuda"):
+            return dict(nv=1000, ne=50000, F=100, C=47, train_begin=0, train_end=80, max_degree=99, dir=str(tmp_path / name))
+
+    table = ("spmm_gemm_fused@128 4 20.0 1.2e11 4e10 16.0\nspmm_light@47 2 6.0 3.0e10 1e9 4.0\nsgemm@1000x128x100 6 3.0 6e9 1.2e11 1.5\n"
+             "d_relu 2 0.1 1e8 0 0.0125\n")
+
+    def fake_trainer(arch, data_root, dataset, epochs, hidden, layers, heads, prof_from, timeout_s):
+        ep = [dict(loss=3.8 - 0.1 * i, acc=0.02 * i, seconds=0.020 if i else 0.5) for i in range(epochs)]
+        return "", ep, bench.__dict__["capi_parse"](table) if prof_from is not None else {}, 250000
+
+    from graphaibench_amd import capi
+    monkeypatch.setitem(bench.__dict__, "capi_parse", capi.parse_prof_table)
+    monkeypatch.setattr(bench, "_run_trainer", fake_trainer)
+    held = {}
+
+    class Guard:
+        held = None
+
+        def hold(self, r):
+            held["r"] = r
+
+        def final(self, r):
+            held["final"] = r
+
+    args = argparse.Namespace(workload="epoch-gcn-products", steps=2, warmup=1, scale=1.0, no_cpu_baseline=True)
+    assert bench.bench_epoch(args, FakeTorch, FakeSynth, Guard()) == 0
+    r = held["final"]
+    assert r["ms_per_step"] == pytest.approx(20.0) and r["value"] == pytest.approx(250000 * 2 / 0.040) and r["steps"] == 2
+    roof = r["roofline"]
+    assert roof["roof_ms_per_epoch"] == pytest.approx((16.0 + 4.0 + 1.5 + 0.0125) / 2) and roof["frac"] == pytest.approx(roof["roof_ms_per_epoch"] / 20.0)
+    assert roof["untimed_ms_per_epoch"] == pytest.approx(20.0 - 29.1 / 2)
+    pk = roof["per_key"]
+    assert "line_floor" in pk["spmm_light@47"] and pk["spmm_light@47"]["line_floor"]["lines_per_row"] == 2.0
+    assert "line_floor" not in pk["spmm_gemm_fused@128"] and "line_floor" not in pk["sgemm@1000x128x100"] and "line_floor" not in pk["d_relu"]
+    assert pk["sgemm@1000x128x100"]["frac"] == pytest.approx(0.5) and r["config"]["train_loss_timed_epochs"] == [pytest.approx(3.7), pytest.approx(3.6)]
