@@ -172,7 +172,7 @@ def parse_prof_table(text: str) -> dict:
     out = {}
     for line in text.splitlines():
         f = line.split()
-        if len(f) == 6:
+        if len(f) == 6 and f[0] not in ("epochs", "epoch_seconds") and f[1].isdigit():
             out[f[0]] = dict(count=int(f[1]), ms=float(f[2]), bytes=float(f[3]), flops=float(f[4]), roof_ms=float(f[5]))
     return out
 

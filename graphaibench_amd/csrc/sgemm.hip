@@ -25,6 +25,9 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+// a float4 whose address is only 4-byte aligned (rows of an odd width: 47 floats = 188 B): global loads of 16 B need dword
+// alignment only
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int BK = 32;
 constexpr int THREADS = 256;
@@ -348,8 +351,16 @@ template <bool BMASK> struct TnDepth { static constexpr int PD = BMASK ? 4 : 8; 
 // second reader sits on the same CU (L1) or at worst behind the same XCD's L2 -- the LDS kernel's 128-row tiles re-read
 // every A and B / mask line from HBM twice at 256 x 256 (17.6 GB of traffic for 10 GB).  The masked
 // B is written back by the waves of the first quadrant row only.  <1, 1> is the M, N <= 128 kernel unchanged.
-template <bool BMASK, int QM, int QN>
+// NUNAL (round 5: the weight gradient of a 47-wide output layer, 128 x 47 and 256 x 47 with K = 2.45 M, ran through the LDS-tiled
+// kernel with 4-byte loads at 0.26 of its roof): N is no multiple of 4, so B's rows are not 16-B aligned and the last lane of a
+// row would read past its end.  Rows are still 4-B aligned, which is all a 16-byte global load needs; the one lane whose four
+// columns straddle the end of the row takes the four columns that END at the row's end instead (never past the matrix): which
+// columns a lane carries is free in this kernel as long as the epilogue stores them where they belong, so that lane and its
+// neighbour both produce the overlapping columns -- the same sums in the same order, stored twice.  Plain form only (an output
+// layer has no activation, hence no mask).
+template <bool BMASK, int QM, int QN, bool NUNAL = false>
 __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
+  static_assert(!(BMASK && NUNAL), "the masked form writes float4s back: N must be a multiple of 4 there");
   constexpr int TN_PD = TnDepth<BMASK>::PD;
   constexpr int TS = QM * QN;  // waves per team (1, 2 or 4); 4 / TS teams per workgroup
   static_assert(TS == 1 || TS == 2 || TS == 4, "a team is 1, 2 or 4 waves of one workgroup");
@@ -384,8 +395,10 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int mcol = 128 * qm + 4 * i, ncol = 128 * qn + 4 * i;
-  const bool mok = mcol < g.M, nok = ncol < g.N;  // (M, N are multiples of 4: a lane's float4 is all in or all out)
-  const int mo = mok ? mcol : 0, no = nok ? ncol : 0;
+  const bool mok = mcol < g.M, nok = ncol < g.N;  // (M, N multiples of 4 -- N unless NUNAL --: a lane's float4 is all in or all out)
+  // NUNAL: columns ncol .. ncol + 3 with only 4 - nsh of them inside the row: the lane carries the columns nsh further left
+  const int nsh = (NUNAL && nok && ncol + 4 > g.N) ? (int)(ncol + 4 - g.N) : 0;
+  const int mo = mok ? mcol : 0, no = nok ? ncol - nsh : 0;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f4 sa[2][TN_PD], sb[2][TN_PD];
   f4 sm[BMASK ? 2 : 1][BMASK ? TN_PD : 1];  // BMASK: the mask rows travel with the set and are applied when it is consumed
@@ -400,7 +413,9 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
       const bool kok = full || k < kend;
       const int64_t kr = kok ? phys(kp) + 2 * s + h : 0;
       f4 va = *reinterpret_cast<const f4*>(g.A + kr * g.M + mo);
-      f4 vb = *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
+      f4 vb;
+      if constexpr (NUNAL) vb = *reinterpret_cast<const f4u*>(g.B + kr * g.N + no);
+      else vb = *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
       if constexpr (BMASK) {
         f4 mk = *reinterpret_cast<const f4*>(g.bmask + kr * g.N + no);
         if (!full) mk = kok ? mk : zero4;  // (a zero mask also keeps the row out of the write-back below)
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int64_t nn = 128 * qn + 4 * i + b;
+      const int64_t nn = 128 * qn + 4 * i - nsh + b;  // (nsh: the columns this lane carries, see above; 0 unless NUNAL)
       if (nn < g.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -705,6 +720,7 @@ int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
 #define GAIB_TN(QM_, QN_)                                                                          \
   do {                                                                                             \
     if (g.bmask) sgemm_tn_reg_kernel<true, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);          \
+    else if (g.N % 4 != 0) sgemm_tn_reg_kernel<false, QM_, QN_, true><<<blocks, 256, 0, ctx->stream>>>(g); \
     else sgemm_tn_reg_kernel<false, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);                 \
   } while (0)
     if (qm == 1 && qn == 1) GAIB_TN(1, 1);
@@ -1004,7 +1020,10 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // weight gradients of the layer widths: register-resident split-K (sgemm_variant 30 keeps the LDS kernel)
   // (M, N <= 128: one wave per output; up to 256: teams of quadrant waves; sgemm_variant 32: only up to 128, the round-2 rule)
   const int64_t tn_max = ctx->sgemm_variant == 32 ? 128 : 256;
-  if (transA && !transB && M <= tn_max && N <= tn_max && M % 4 == 0 && N % 4 == 0 && avec && bvec && K >= 32768 &&
+  // (N no multiple of 4 -- the 47-wide output layer: B's rows are 4-byte aligned only, the NUNAL form; sgemm_variant 36 keeps
+  // the LDS-tiled kernel there)
+  const bool b_rows_ok = (N % 4 == 0 && bvec) || (N % 4 != 0 && N >= 4 && (((uintptr_t)d_B & 3) == 0) && ctx->sgemm_variant != 36);
+  if (transA && !transB && M <= tn_max && N <= tn_max && M % 4 == 0 && avec && b_rows_ok && K >= 32768 &&
       ctx->sgemm_variant != 30)
     return launch_tn_reg(ctx, g);
   // streaming products (rows in the millions, 128 < K <= 256): persistent workgroups with the op(B) slab in LDS
@@ -1023,7 +1042,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 35);  // (30 .. 34 concern the weight gradient only)
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 36);  // (30 .. 36 concern the weight gradient only)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);

@@ -28,6 +28,7 @@
 #include <omp.h>
 #include <algorithm>
 #include <string>
+#include <vector>
 #include <fcntl.h>
 #include <signal.h>
 #include <sys/stat.h>
@@ -628,6 +629,7 @@ struct Trainer {
     const char* pt = getenv("GAIB_PROF_TABLE");
     const int prof_from = (pt && *pt && !graph_mode) ? std::max(0, atoi(pt)) : -1;
     int prof_epochs = 0;
+    std::vector<double> prof_epoch_s;  // the profiled epochs' train_time at full precision (the log line keeps the reference's 3 decimals)
     for (int itr = 0; itr < num_epochs; itr++) {
       if (itr == prof_from) {
         GAIB_OR_DIE(gaib_prof_reset(gpu_context::get()));
@@ -675,6 +677,7 @@ struct Trainer {
       }
       const double fw = t1 - t0, bw = t2 - t1, epoch_time = fw + bw;
       total += epoch_time;
+      if (prof_from >= 0 && itr >= prof_from) prof_epoch_s.push_back(epoch_time);
       std::cout << "train_loss " << std::setprecision(3) << std::fixed << train_loss << " train_acc " << train_acc << " ";
       if (itr % val_interval == 0 && itr != 0) {
         double tv0 = omp_get_wtime();
@@ -697,7 +700,9 @@ struct Trainer {
       std::string tab(need + 1, '\0');
       GAIB_OR_DIE(gaib_prof_table(c, &tab[0], tab.size(), &need));
       if (root()) {
-        std::cout << "[gaib prof] epochs " << prof_epochs << "\n";
+        std::cout << "[gaib prof] epochs " << prof_epochs << "\n[gaib prof] epoch_seconds";
+        for (double t : prof_epoch_s) std::cout << " " << std::setprecision(7) << std::fixed << t;
+        std::cout << std::setprecision(3) << "\n";
         size_t a = 0;
         const std::string text(tab.c_str());
         while (a < text.size()) {

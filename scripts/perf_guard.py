@@ -182,6 +182,14 @@ def main():
         res[f"sgemm NT 2.45M x {d} x {d}"] = ev_time(lambda: ctx.sgemm(x, W, y, False, True))
         res[f"sgemm TN {d} x {d}, K = 2.45M"] = ev_time(lambda: ctx.sgemm(x, g, dW, True, False))
         del x, g, W, y, dW
+    # the output layer's weight gradients (47 classes): N % 4 != 0 (round 5: the register-resident kernel's NUNAL form)
+    g47 = torch.randn(nv, 47, device="cuda")
+    for d in (128, 256):
+        x = torch.randn(nv, d, device="cuda")
+        dW = torch.empty(d, 47, device="cuda")
+        res[f"sgemm TN {d} x 47, K = 2.45M"] = ev_time(lambda: ctx.sgemm(x, g47, dW, True, False))
+        del x, dW
+    del g47
     x100 = torch.randn(nv, 100, device="cuda")
     W100 = torch.randn(100, 128, device="cuda")
     y128 = torch.empty(nv, 128, device="cuda")

@@ -596,7 +596,13 @@ GEMM_SHAPES = [
     (5000, 100, 128, 0, 1, 1),
     (100, 128, 20011, 1, 0, 1),  # split-K + accum, ragged K
     (128, 128, 40001, 1, 0, 0),  # long K, M, N <= 128: register-resident split-K kernel (odd K)
-    (100, 47, 33000, 1, 0, 1),   # ... ragged M / N, accumulate
+    (100, 47, 33000, 1, 0, 1),   # ... ragged M / N, accumulate (round 5: N % 4 != 0 takes the register kernel too -- rows of B
+    (128, 47, 40003, 1, 0, 0),   #     are 4-byte aligned only, the lane at the row's end carries the columns that END there)
+    (256, 47, 36001, 1, 0, 0),   # the output layer's weight gradient at hidden 256: quadrant teams, N = 47
+    (128, 6, 33001, 1, 0, 1),    # citeseer's / cora's class counts
+    (256, 7, 32768, 1, 0, 0),
+    (64, 5, 32769, 1, 0, 0),
+    (200, 129, 33000, 1, 0, 0),  # N = 129: the straddling lane sits in the second column quadrant
     (7, 16, 70000, 1, 0, 0),
     (128, 96, 32768, 1, 0, 0),
     (1, 1, 1, 0, 0, 0),
@@ -1195,6 +1201,31 @@ def test_sgemm_streaming_kernel(ctx, x, y, z, tB, accum, relu):
         ctx.set_option("sgemm_variant", 0)
     for got in res:
         assert rel_err(got, want) < 2e-5
+
+
+def test_sgemm_tn_odd_width_matches_the_tiled_kernel_and_reads_nothing_past_the_matrix(ctx):
+    """the NUNAL form of the register-resident weight gradient against the LDS-tiled kernel it replaces (option sgemm_variant
+    36) and fp64, with B placed at the very END of its allocation and followed by NaNs in a guard allocation: a lane reading
+    past the last row would poison the sums"""
+    K, M, N = 50001, 128, 47
+    rng = np.random.default_rng(7)
+    A = dev(rng.standard_normal((K, M)).astype(np.float32))
+    flat = torch.full((K * N + 64,), float("nan"), device="cuda")
+    B = flat[:K * N].view(K, N)
+    B.copy_(dev(rng.standard_normal((K, N)).astype(np.float32)))
+    C1, C2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ctx.sgemm(A, B, C1, True, False)
+    ctx.set_option("sgemm_variant", 36)
+    try:
+        ctx.sgemm(A, B, C2, True, False)
+    finally:
+        ctx.set_option("sgemm_variant", 0)
+    ref = A.double().t() @ B.double()
+    assert torch.isfinite(C1).all()
+    assert rel_err(C1.cpu().numpy(), ref.cpu().numpy()) < 2e-5 and rel_err(C2.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    again = torch.empty_like(C1)
+    ctx.sgemm(A, B, again, True, False)
+    assert torch.equal(again, C1)  # fixed summation order
 
 
 @pytest.mark.parametrize("variant", [10, 11, 12, 13, 20, 21, 30, 32, 33, 34, 35])
