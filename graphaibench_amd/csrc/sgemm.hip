@@ -78,7 +78,9 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t
     if (gr < R) {
       const float* p = src + gr * ld + gc;
       if (VEC4 && gc + 3 < Cc) {
-        v = *reinterpret_cast<const f4*>(p);
+        // (f4u: 4-byte alignment is all a 16-byte global load needs -- rows of an odd width, 47 or 1433 floats, are loaded
+        // with the same instruction as aligned ones; round 5: they used to take four 4-byte loads each)
+        v = *reinterpret_cast<const f4u*>(p);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -104,7 +106,7 @@ __device__ __forceinline__ void tile_store_global(float* __restrict__ dst, int64
     if (gr < R) {
       float* p = dst + gr * ld + gc;
       if (VEC4 && gc + 3 < Cc) {
-        *reinterpret_cast<f4*>(p) = regs[s];
+        *reinterpret_cast<f4u*>(p) = regs[s];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1042,12 +1044,16 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 36);  // (30 .. 36 concern the weight gradient only)
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37);  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
-  if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, avec, bvec);
-  if (!transA && transB) return dispatch_shape<false, false>(ctx, g, avec, bvec);
-  return dispatch_shape<true, true>(ctx, g, avec, bvec);
+  // the LDS-tiled kernel loads its tiles with 16-byte instructions whenever the operand is 4-byte aligned (tile_load: f4u) --
+  // also rows of an odd width (sgemm_variant 37: only 16-byte aligned rows, the rule until round 4)
+  const bool av4 = ctx->sgemm_variant == 37 ? avec : (((uintptr_t)d_A & 3) == 0);
+  const bool bv4 = ctx->sgemm_variant == 37 ? bvec : (((uintptr_t)d_B & 3) == 0);
+  if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, av4, bv4);
+  if (!transA && transB) return dispatch_shape<false, false>(ctx, g, av4, bv4);
+  return dispatch_shape<true, true>(ctx, g, av4, bv4);
 }
 
 // weight gradient with the layer's d_relu folded in (graph_conv_layer backward: d_relu_gpu on grad_in, then

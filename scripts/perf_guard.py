@@ -189,7 +189,11 @@ def main():
         dW = torch.empty(d, 47, device="cuda")
         res[f"sgemm TN {d} x 47, K = 2.45M"] = ev_time(lambda: ctx.sgemm(x, g47, dW, True, False))
         del x, dW
-    del g47
+    # the output layer's input gradient dX = G [N x 47] . W^T: rows of 188 B (round 5: 16-byte loads at 4-byte alignment)
+    W47 = torch.randn(256, 47, device="cuda")
+    dx = torch.empty(nv, 256, device="cuda")
+    res["sgemm NT 2.45M x 256 x 47"] = ev_time(lambda: ctx.sgemm(g47, W47, dx, False, True))
+    del g47, W47, dx
     x100 = torch.randn(nv, 100, device="cuda")
     W100 = torch.randn(100, 128, device="cuda")
     y128 = torch.empty(nv, 128, device="cuda")
