@@ -1024,7 +1024,10 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   const int64_t tn_max = ctx->sgemm_variant == 32 ? 128 : 256;
   // (N no multiple of 4 -- the 47-wide output layer: B's rows are 4-byte aligned only, the NUNAL form; sgemm_variant 36 keeps
   // the LDS-tiled kernel there)
-  const bool b_rows_ok = (N % 4 == 0 && bvec) || (N % 4 != 0 && N >= 4 && (((uintptr_t)d_B & 3) == 0) && ctx->sgemm_variant != 36);
+  // measured (scripts/gemm_odd_width.py, K = 2.45 M): 128 x 47 0.82 -> 0.69-0.72 ms, 100 x 47 0.65; at 256 x 47 the quadrant
+  // teams compute two 128 x 128 tiles for 47 columns and lose to the tiled kernel (1.22 vs 0.80 ms): M <= 128 only
+  const bool b_rows_ok = (N % 4 == 0 && bvec) ||
+                         (N % 4 != 0 && N >= 4 && M <= 128 && (((uintptr_t)d_B & 3) == 0) && ctx->sgemm_variant != 36);
   if (transA && !transB && M <= tn_max && N <= tn_max && M % 4 == 0 && avec && b_rows_ok && K >= 32768 &&
       ctx->sgemm_variant != 30)
     return launch_tn_reg(ctx, g);
@@ -1047,10 +1050,12 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37);  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
-  // the LDS-tiled kernel loads its tiles with 16-byte instructions whenever the operand is 4-byte aligned (tile_load: f4u) --
-  // also rows of an odd width (sgemm_variant 37: only 16-byte aligned rows, the rule until round 4)
-  const bool av4 = ctx->sgemm_variant == 37 ? avec : (((uintptr_t)d_A & 3) == 0);
-  const bool bv4 = ctx->sgemm_variant == 37 ? bvec : (((uintptr_t)d_B & 3) == 0);
+  // The LDS-tiled kernel loads a ROW-MAJOR A ([M][K], K odd: dX = G [N x 47] . W^T of the output layer) with 16-byte
+  // instructions at 4-byte alignment (tile_load: f4u): 2.45 M x 256 x 47 1.21 -> 1.04 ms, x 128 x 47 0.63 -> 0.55
+  // (scripts/gemm_odd_width.py; sgemm_variant 37: 4-byte loads, the rule until round 4).  NOT the k-major operands of a weight
+  // gradient: the same loads on B [K][47] made the tiled 128 x 47 product 2.18 ms against 0.82 with 4-byte loads.
+  const bool av4 = (transA || ctx->sgemm_variant == 37) ? avec : (((uintptr_t)d_A & 3) == 0);
+  const bool bv4 = bvec;
   if (!transA && !transB) return dispatch_shape<false, true>(ctx, g, av4, bv4);
   if (!transA && transB) return dispatch_shape<false, false>(ctx, g, av4, bv4);
   return dispatch_shape<true, true>(ctx, g, av4, bv4);

@@ -598,11 +598,11 @@ GEMM_SHAPES = [
     (128, 128, 40001, 1, 0, 0),  # long K, M, N <= 128: register-resident split-K kernel (odd K)
     (100, 47, 33000, 1, 0, 1),   # ... ragged M / N, accumulate (round 5: N % 4 != 0 takes the register kernel too -- rows of B
     (128, 47, 40003, 1, 0, 0),   #     are 4-byte aligned only, the lane at the row's end carries the columns that END there)
-    (256, 47, 36001, 1, 0, 0),   # the output layer's weight gradient at hidden 256: quadrant teams, N = 47
+    (256, 47, 36001, 1, 0, 0),   # the output layer's weight gradient at hidden 256 (the tiled kernel: M > 128)
     (128, 6, 33001, 1, 0, 1),    # citeseer's / cora's class counts
     (256, 7, 32768, 1, 0, 0),
     (64, 5, 32769, 1, 0, 0),
-    (200, 129, 33000, 1, 0, 0),  # N = 129: the straddling lane sits in the second column quadrant
+    (100, 129, 33000, 1, 0, 0),  # N = 129: the straddling lane sits in the second column quadrant
     (7, 16, 70000, 1, 0, 0),
     (128, 96, 32768, 1, 0, 0),
     (1, 1, 1, 0, 0, 0),
