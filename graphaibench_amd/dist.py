@@ -644,6 +644,16 @@ class BenchCase:
                 e_k, r_k, ms_dom = bnd_edges - part.colidx_halo.numel(), n_bnd, part_ms["part_light"] * args.steps
             alg_bytes = e_k * (4 * D + 8) + int(1.5 * r_k * 4 * D) + (r_k + 1) * 8
             n_dom = 2 * args.steps
+        elif part.colidx_halo.numel() > 0 and ms_fused > ms_light and dg.g_halo is not None:
+            # the column split on a partition whose edges mostly cross ranges (the strong case on a random order at N >= 4):
+            # the halo-column half -- the fused kernel continuing the owned-column partial sums, the dense product riding on
+            # it -- is the larger launch.  Bytes: its gathers, the partial sums read, the rows it stores (A.X forward; 1.5 on average)
+            st_h = ctx.graph_stats(dg.g_halo)
+            e_h = part.colidx_halo.numel() - st_h["heavy_edges"]
+            kernel_name = ("spmm_gemm_kernel<VEC=2,edge-weights,U=16,buffer> over the halo-column edges (continues the owned-column "
+                           "sums, aggregation + MFMA dense product, rank 0)")
+            alg_bytes = e_h * (4 * D + 8) + nv * 4 * D + int(1.5 * nv * 4 * D) + (nv + 1) * 8
+            n_dom, ms_dom = n_fused, ms_fused
         elif part.colidx_halo.numel() > 0:
             kernel_name = "spmm_w64_kernel<VEC=2,CT=1,edge-weights,U=16,buffer> over the owned-column edges (rank 0)"
             alg_bytes = e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
@@ -992,6 +1002,10 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         if (traffic_of is not None and not strong and not papers and args.scale == 1.0 and abs(cut - 0.1) < 1e-9
                 and main["partition_mode"]["mode"] == "split" and main["kernel_name"].startswith("spmm_w64_kernel")):
             traffic, traffic_src = traffic_of("spmm_w64_kernel_owned_pass_bytes_per_launch", "partitioned_products_uniform")
+        # ... and of the strong headline's dominant kernel at N = 8 (the halo-column half on rank 0's eighth of the bench graph)
+        if (traffic_of is not None and strong and world == 8 and args.scale == 1.0 and main["partition_mode"]["mode"] == "split"
+                and "halo-column edges" in main["kernel_name"]):
+            traffic, traffic_src = traffic_of("spmm_gemm_kernel_halo_half_bytes_per_launch", "partitioned_products_strong")
         strong_rec = ({**sub_record(main, workload=strong_workload), **strong_extra} if strong else other)
         weak_rec = (other if strong else sub_record(main, workload=weak_workload, cut_fraction=cut))
         rec.update({

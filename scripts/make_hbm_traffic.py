@@ -93,6 +93,20 @@ if sp is not None and sp.exists():
                                 "graphaibench_amd/csrc/spmm_part.hip", "graphaibench_amd/csrc/common.h"]),
         "spmm_w64_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w},
         "spmm_w64_kernel_owned_pass_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
+# round 5: the N > 1 HEADLINE's shard (the N = 1 bench graph in 8 vertex ranges): its dominant kernel is the halo-column half --
+# spmm_gemm_kernel with the accumulate form (it continues the owned-column partial sums); the launches of that kernel in the run
+# are the two halves of a step, so the mean over launches is the per-launch figure
+sp2 = Path(sys.argv[3]) / "shard_products_strong_pmc_summary.json" if len(sys.argv) > 3 else None
+if sp2 is not None and sp2.exists():
+    sh = json.loads(sp2.read_text())
+    f, w = find(sh, "FETCH_SIZE", "spmm_gemm_kernel"), find(sh, "WRITE_SIZE", "spmm_gemm_kernel")
+    out["partitioned_products_strong"] = {
+        "workload": "scripts/papers_shard.py --strong --mode auto: rank 0 of 8 of the N = 1 bench graph (random order), split mode",
+        "commit": commit,
+        "sources": blob_hashes(["graphaibench_amd/csrc/spmm.hip", "graphaibench_amd/csrc/spmm_kernels.h", "graphaibench_amd/csrc/spmm_core.h",
+                                "graphaibench_amd/csrc/spmm_part.hip", "graphaibench_amd/csrc/common.h"]),
+        "spmm_gemm_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w},
+        "spmm_gemm_kernel_halo_half_bytes_per_launch": f * 1024 * 2.0 + w * 1024}
 out["note"] = ("FETCH_SIZE counts L2 -> fabric requests; Infinity-Cache hits are included (MI355X_MICROARCH.md), so "
                "these are upper bounds on the HBM bytes.")
 Path("profiles/hbm_traffic.json").write_text(json.dumps(out, indent=1) + "\n")

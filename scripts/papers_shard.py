@@ -39,27 +39,51 @@ MODES = {"split": L.LGraph.PART_SPLIT, "classes": L.LGraph.PART_CLASSES, "onepas
          "onepass_all": L.LGraph.PART_ONEPASS_ALL, "auto": L.LGraph.PART_AUTO}
 
 
-def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",), opts=""):
+def strong_rows(ctx, rank, scale):
+    """rank's rows of bench.py's N = 1 graph (products shape, seed 42, random vertex order) cut into WORLD vertex ranges: the
+    HEADLINE case of `bench.py --gpus 8` since round 5 (north_star's curve).  Ranges are ceil(n / WORLD) rows (the last one
+    shorter), as gd.partition_bounds cuts them."""
+    sg = synth.make("ogbn-products", seed=42, device="cuda", scale=scale)
+    g0 = ctx.graph(sg.rowptr, sg.colidx)
+    g1 = g0.add_selfloop()
+    g0.close()
+    del sg
+    rp_all, ci_all, n = g1.rowptr(), g1.colidx(), g1.nv
+    g1.close()
+    per = -(-n // WORLD)
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    e0, e1 = int(rp_all[lo]), int(rp_all[hi])
+    rows = synth.BlockRows((rp_all[lo:hi + 1] - e0).contiguous(), ci_all[e0:e1].to(torch.int64).contiguous(), n, hi - lo)
+    return rows, per
+
+
+def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",), opts="", strong=False):
     t0 = time.time()
     # papers: the named graph is the GLOBAL one (each rank owns 1/8 of it); products: bench.py's weak-scaling
-    # workload, one products-shaped range per rank
+    # workload, one products-shaped range per rank; strong: the N = 1 bench graph itself in WORLD ranges
     per_rank = scale / WORLD if shape == "ogbn-papers100M" else scale
-    rows = synth.block_rows(shape, rank, WORLD, seed=42, cut_fraction=cut, device="cuda", scale=per_rank,
-                            selfloops=True, boundary=boundary, band=band)
-    nv = rows.n_local
-    lo, hi = rank * nv, (rank + 1) * nv
+    if strong:
+        rows, nv = strong_rows(ctx, rank, scale)  # (nv: the range length that maps a global id to its owner)
+        cut, boundary = (WORLD - 1) / WORLD, "strong: the bench graph's random order"
+    else:
+        rows = synth.block_rows(shape, rank, WORLD, seed=42, cut_fraction=cut, device="cuda", scale=per_rank,
+                                selfloops=True, boundary=boundary, band=band)
+        nv = rows.n_local
+    lo, hi = rank * nv, rank * nv + rows.n_local
     rp_own, ci_own, rp_halo, ci_halo, halo, deg = gd.split_by_owner(rows.rowptr, rows.colidx_global, lo, hi)
     del rows
     n_halo = int(halo.numel())
     # exact send lists by symmetry: (peer, own row) pairs over the halo-column edges
+    per = nv          # rows per range (owner of global id v = v // per)
+    nv = hi - lo      # this rank's rows
     deg_h = rp_halo[1:] - rp_halo[:-1]
     rows_h = torch.repeat_interleave(torch.arange(nv, device="cuda"), deg_h)
-    peer = halo[ci_halo.to(torch.int64)] // nv
-    send_key = torch.unique(peer * nv + rows_h)
+    peer = halo[ci_halo.to(torch.int64)] // per
+    send_key = torch.unique(peer * per + rows_h)
     del rows_h, peer
-    send_idx = (send_key % nv).contiguous()
-    send_counts = torch.bincount(send_key // nv, minlength=WORLD).tolist()
-    recv_counts = torch.bincount(halo // nv, minlength=WORLD).tolist()
+    send_idx = (send_key % per).contiguous()
+    send_counts = torch.bincount(send_key // per, minlength=WORLD).tolist()
+    recv_counts = torch.bincount(halo // per, minlength=WORLD).tolist()
     del send_key
     # normalisers: own rows from their full degrees; halo columns from a stand-in of the same distribution (their
     # owners would send them once at setup; values do not change the timing)
@@ -196,6 +220,8 @@ def main():
     ap.add_argument("--boundary", nargs="+", default=["uniform"], choices=["uniform", "clustered"])
     ap.add_argument("--band", type=float, default=0.2, help="clustered: share of a range's ids that form its boundary band")
     ap.add_argument("--mode", nargs="+", default=["split", "classes", "onepass", "onepass_all", "auto"], choices=list(MODES))
+    ap.add_argument("--strong", action="store_true",
+                    help="the N = 1 bench graph (products shape, random order) cut into 8 vertex ranges: rank's share of the N > 1 headline")
     ap.add_argument("--link-gbs", type=float, default=None, help="GAIB_LINK_GBS for the auto rule (default: the library's 100)")
     ap.add_argument("--opts", default="", help="library options, key=value,... (gaib_set_option), e.g. spmm_flat_ring=1")
     args = ap.parse_args()
@@ -206,6 +232,9 @@ def main():
     for kv in filter(None, args.opts.split(",")):
         k, v = kv.split("=")
         ctx.set_option(k.strip(), int(v))
+    if args.strong:
+        run(ctx, args.rank, 0.875, args.steps, args.scale, "ogbn-products", "uniform", args.band, args.mode, args.opts, strong=True)
+        return
     for cut in args.cut:
         for boundary in args.boundary:
             run(ctx, args.rank, cut, args.steps, args.scale, args.shape, boundary, args.band, args.mode, args.opts)

@@ -27,4 +27,18 @@ for shape in ogbn-products ogbn-papers100M; do
     fi
   done
 done
+# round 5: rank 0's share of the N > 1 HEADLINE -- the N = 1 bench graph in 8 vertex ranges (random order, cut 7/8): kernel
+# statistics, and the L2 -> fabric bytes of its dominant kernel (the halo-column half: the fused kernel continuing the owned-column
+# sums) -> profiles/hbm_traffic.json "partitioned_products_strong"
+name=shard_products_strong
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${name}" -- python3 "$ROOT/scripts/papers_shard.py" \
+  --strong --mode auto --steps 3 > "$OUT/${name}.jsonl" 2> "$OUT/${name}.err"
+( cd "$ROOT" && python3 scripts/summarize_rocprof.py stats "$OUT/${name}" "$OUT/${name}_kernel_stats.csv" ) > "$OUT/${name}_top.txt" 2>&1
+rm -rf "$OUT/${name}"
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 500 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${name}_$ctr" -- python3 "$ROOT/scripts/papers_shard.py" \
+    --strong --mode auto --steps 3 > /dev/null 2> "$OUT/${name}_$ctr.err"
+done
+( cd "$ROOT" && python3 scripts/summarize_rocprof.py pmc "$OUT/${name}_pmc_summary.json" fetch="$OUT/${name}_FETCH_SIZE" write="$OUT/${name}_WRITE_SIZE" ) > /dev/null 2>&1
+rm -rf "$OUT/${name}_FETCH_SIZE" "$OUT/${name}_WRITE_SIZE"
 ls -la "$OUT"
