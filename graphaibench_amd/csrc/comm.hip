@@ -30,6 +30,8 @@
 #include <new>
 #include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 #define GAIB_COMM_MAX_RANKS 16
@@ -439,6 +441,22 @@ extern "C" int gaib_comm_unique_id(int transport, void* h_id) {
   return GAIB_OK;
 }
 
+// RCCL communicators of more than one rank alive per context: while there is one, the fused aggregation leaves CUs to RCCL's
+// kernels by default (ctx->comm_reserve_default = 32); a peer-to-peer pull communicator created NEXT to it (bench.py's transport
+// A/B) does not change that, and the default returns to 0 when the last of them is destroyed.  (Kept here, not in gaib_ctx.)
+static int rccl_alive(gaib_ctx* ctx, int delta) {
+  static std::mutex mu;
+  static std::vector<std::pair<gaib_ctx*, int>> alive;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& e : alive)
+    if (e.first == ctx) {
+      e.second = e.second + delta > 0 ? e.second + delta : 0;
+      return e.second;
+    }
+  alive.push_back({ctx, delta > 0 ? delta : 0});
+  return alive.back().second;
+}
+
 // GAIB_COMM_RESERVE_CUS: the caller's choice from the environment (validated: a whole number >= 0; anything else is ignored
 // with a line on stderr); an option set before gaib_comm_init wins
 static void reserve_from_env(gaib_ctx* ctx) {
@@ -504,13 +522,15 @@ extern "C" int gaib_comm_init(gaib_ctx* ctx, int rank, int nranks, const void* h
     c->nranks = cnt;
     // RCCL's send / recv kernels need CUs to land on while the persistent fused aggregation runs (GAIB_OVERLAPS_TRANSFER):
     // one eighth of the chip, measured to cost that kernel 1.5 %; GAIB_COMM_RESERVE_CUS / the option override
-    ctx->comm_reserve_default = cnt > 1 ? 32 : 0;
+    if (cnt > 1) {
+      rccl_alive(ctx, +1);
+      ctx->comm_reserve_default = 32;
+    }
     reserve_from_env(ctx);
     *out = c;
     return GAIB_OK;
   }
-  ctx->comm_reserve_default = 0;  // the peer-to-peer pull runs on copy engines: nothing to leave free
-  reserve_from_env(ctx);
+  reserve_from_env(ctx);  // (the peer-to-peer pull runs on copy engines: it asks for no CUs and leaves the default alone)
   // ---- IPC: map (rank 0: create) the segment named after the id ----
   const unsigned char* b = (const unsigned char*)h_id;
   snprintf(c->shm_name, sizeof(c->shm_name), "/gaib_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", b[0], b[1], b[2],
@@ -579,7 +599,8 @@ extern "C" int gaib_comm_destroy(gaib_comm* c) {
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->cstream);
   if (c->transport == GAIB_COMM_RCCL && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
-  if (c->transport == GAIB_COMM_RCCL) c->ctx->comm_reserve_default = 0;  // its send / recv kernels are gone with it
+  if (c->transport == GAIB_COMM_RCCL && c->nranks > 1 && c->nccl && rccl_alive(c->ctx, -1) == 0)
+    c->ctx->comm_reserve_default = 0;  // its send / recv kernels are gone with the last such communicator
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (gaib_comm::IpcBuf& b : *c->ipc_bufs) (void)hipFree(b.p);  // (every plan is gone: gaib_halo_destroy comes first)
   if (c->seg) munmap(c->seg, sizeof(ShmSeg));

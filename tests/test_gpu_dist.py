@@ -131,6 +131,76 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
     assert res["cpu_baseline"] == {"skipped": "--no-cpu-baseline"}
 
 
+def _ab_worker(rank, world, port, q):
+    """the A/B legs of the N > 1 bench (dist.BenchCase.cu_reserve_ab / transport_ab) with the RCCL BRANCH of comm.hip carrying the
+    case -- bound to tests/fake_rccl's strict double, this box has one GPU -- and the peer-to-peer pull as the other transport"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GAIB_RCCL_LIB"] = str(ROOT / "tests" / "fake_rccl" / "librccl_fake.so")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import argparse
+
+        from graphaibench_amd import capi, dist as gd, layers as L, synth
+
+        ctx = L.init(0)
+        rccl, err = gd.comm_attempt(ctx, rank, world, capi.COMM_RCCL)
+        assert rccl is not None, err
+        ipc, err = gd.comm_attempt(ctx, rank, world, capi.COMM_IPC)
+        assert ipc is not None, err
+        # the communicator's default: 32 CUs left to RCCL's kernels with more than one rank; an explicit 0 stays 0
+        assert ctx.get_option("comm_reserve_cus") == 32 and ctx.get_option("comm_reserve_cus_raw") == -1
+        args = argparse.Namespace(steps=2, warmup=1, scale=0.02)
+        rows = synth.block_rows("ogbn-products", rank, world, seed=42, cut_fraction=0.1, device="cuda", scale=0.02, selfloops=True,
+                                boundary="clustered", band=0.2)  # (interior rows: the class modes, whose fused pass overlaps the exchange)
+        case = gd.BenchCase(ctx, rccl, args, rank, world, 128, lambda *a: None, rows, "ab test")
+        res = case.measure()
+        ab = case.cu_reserve_ab(steps=2)
+        tb = case.transport_ab({"rccl": rccl, "ipc": ipc, "absent": (None, "not built")})
+        after = (ctx.get_option("comm_reserve_cus"), ctx.get_option("comm_reserve_cus_raw"))
+        ctx.set_option("comm_reserve_cus", 0)
+        zero = ctx.get_option("comm_reserve_cus")
+        ctx.set_option("comm_reserve_cus", 100000)
+        clamped = ctx.get_option("comm_reserve_cus")
+        ctx.set_option("comm_reserve_cus", -1)
+        case.close()
+        ipc.close()
+        rccl.close()
+        q.put((rank, "ok", dict(mode=res["partition_mode"]["mode"], ab=ab, tb=tb, after=after, zero=zero, clamped=clamped,
+                                num_cus=ctx.get_option("num_cus"), reserve_after_close=ctx.get_option("comm_reserve_cus"))))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ab_legs_through_the_rccl_branch():
+    """VERDICT r4 #2 "done" line: the CU-reserve A/B and the transport A/B with the RCCL branch (strict double) carrying the plan"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_ab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    for _, _, d in res:
+        assert d["mode"] in ("classes", "onepass")  # the fused interior pass overlaps the exchange: the option reaches it
+        assert sorted(d["ab"]["ms_per_step"]) == ["0", "32", "64"] and all(v > 0 for v in d["ab"]["ms_per_step"].values())
+        assert d["ab"]["fused_launches_overlap_an_exchange"] is True and d["ab"]["in_effect_for_the_timed_steps"] == 32
+        assert d["after"] == (32, -1)  # the option went back to "unset": the communicator's default applies again
+        assert d["tb"]["rccl"]["exchange_standalone_ms"] > 0 and d["tb"]["ipc"]["exchange_standalone_ms"] > 0
+        assert d["tb"]["absent"] == {"skipped": "not built"}
+        assert d["zero"] == 0 and d["clamped"] == d["num_cus"] - 64  # an explicit 0 is 0; the fused kernel keeps >= 64 CUs
+        assert d["reserve_after_close"] == 0  # RCCL's kernels are gone with its communicator
+
+
 def _clean_env():
     return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
                                                               "MASTER_PORT", "GAIB_DIST_BACKEND", "GAIB_FORCE_DIST")}
