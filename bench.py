@@ -761,7 +761,8 @@ def main():
     signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGINT})
     quiet_stdout()
     guard = install_rank_guard(int(os.environ.get("RANK", "0")), max(5.0, args.deadline_s - (time.time() - T_START)))
-    guard.want_parity = not (args.no_parity or args.no_cpu_baseline) or args.check_oracle
+    # (N = 1: the comparison needs the CPU baseline's run; N > 1: the strong case's comparison is its own leg)
+    guard.want_parity = (not args.no_parity and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or not args.no_cpu_baseline)) or args.check_oracle
     if int(os.environ.get("RANK", "0")) == 0:
         start_heartbeat("r0")
     import torch

@@ -8,7 +8,8 @@ nv / 2^k vertices -- at k = 5 a 7 K-vertex window, 4 MB of [h | grad | records],
 the kernel's instruction issue (~2 000 VALU / LDS instructions per 64-edge chunk) and the linear streams.  If that
 time is not well below 6.1 ms, no chunk order, table layout or XCD mapping can reach the 5.5 ms asked for.
 
-    python scripts/gat_l2_ceiling.py            # one JSON line per k
+    python scripts/gat_l2_ceiling.py [k ...]    # one JSON line per k (default 0 2 3 4 5 6 8)
+    bash scripts/profile_gat_ceiling.sh         # TCC_HIT / TCC_MISS of the backward sweep at k = 0 and k = 5
 """
 import json
 import sys
@@ -39,7 +40,8 @@ def main():
     ar = torch.randn(D, device="cuda", generator=gen) * 0.2
     ctx.set_option("gat_fused_fwd", 1)
     ctx.set_option("gat_fused_bwd", 1)
-    for k in (0, 2, 3, 4, 5, 6, 8):
+    shifts = [int(v) for v in sys.argv[1:]] or [0, 2, 3, 4, 5, 6, 8]  # (a counter pass names the two shifts it wants: 0 5)
+    for k in shifts:
         cols = (ci.to(torch.int64) >> k).to(torch.int32)  # rows stay sorted; duplicates are fine for a timing
         g = ctx.graph(rp, cols)
         out = torch.empty(nv, D, device="cuda")
