@@ -223,6 +223,10 @@ def test_bench_plain_invocation_config5_shape_matches_global_oracle():
     res = json.loads(line)
     cfg, par = res["config"], res["parity"]
     assert res["n_gpus"] == 4 and res["value"] > 0 and "config 5" in cfg["workload"]
+    # (the kept 4-rank records of round 4 had cpu_baseline null -- they were taken with --no-cpu-baseline, which
+    # now says {"skipped": ...}; a 4-rank run without the flag carries the baseline)
+    assert res["cpu_baseline"] is not None and res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["kind"] == "port"
+    assert cfg["ranks_share_device"] is (torch.cuda.device_count() < 4) and res["scaling"] == "weak"
     assert cfg["launcher"].startswith("bench.py itself")
     assert cfg["nv_per_gpu"] * 4 == pytest.approx(111_059_956 / 50, rel=0.01)
     assert cfg["transport"].startswith("gaib_comm/ipc") and cfg["rccl_ranks"] == 0  # 4 ranks on one device

@@ -388,10 +388,13 @@ def test_sage_layer_products_vs_oracle(products, width):
     assert_close_dev(ld.tensor(L.W_SELF_GRAD, (Dw, Dw)), lo.W_self_grad, "W_self_grad", floor=LONG_SUM_FLOOR)
 
 
-def test_gat_layer_8_heads_reddit_vs_oracle():
+@pytest.mark.parametrize("d", [64, 128])
+def test_gat_layer_8_heads_reddit_vs_oracle(d):
     """GAT_layer 64 -> 64 with 8 heads (BASELINE config 4: hidden 64 = 8 x 8) forward + backward on the reddit-shaped
     graph (112 M edges) against 8 single-head oracles on the column slices (gat_aggregator.cpp:57-200, the
-    `fast` d_softmax branch = the reference's AVX-512 form; the O(deg^2) fallback is the same function)."""
+    `fast` d_softmax branch = the reference's AVX-512 form; the O(deg^2) fallback is the same function).
+    Round 5: also 128 -> 128 (8 x 16), the widest layer the reference's GAT runs (global.h:58) -- the one-sweep kernels'
+    32-lane form at full size."""
     L.init(0)
     sg = synth.make("reddit", seed=7, device="cuda")
     rp = sg.rowptr.cpu().numpy()
@@ -400,7 +403,7 @@ def test_gat_layer_8_heads_reddit_vs_oracle():
     orc.set_threads(usable_cores())
     g_o = orc.Graph(rp, ci).add_selfloop()
     del sg
-    n, ne, d, H = g_o.nv, g_o.ne, 64, 8
+    n, ne, H = g_o.nv, g_o.ne, 8
     dh = d // H
     x, gin = _host_feat(n, d, 3), _host_feat(n, d, 4)
     ld = L.Layer(L.GAT, 1, n, d, d, g_d, True)
