@@ -187,7 +187,7 @@ def run_mode(ctx, mode, S, steps):
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t0) / 3 * 1e3
     per_link = max(max(send_counts), max(recv_counts)) * D * 4
-    out = dict(config="%s-shaped, vertex-range x8, rank %d's shard on one GPU" % (shape, rank), cut_fraction=cut,
+    out = dict(config="%s-shaped, vertex-range x%d, rank %d's shard on one GPU" % (shape, WORLD, rank), cut_fraction=cut,
                boundary=boundary, band=band if boundary == "clustered" else None, mode_asked=mode, opts=S.get("opts", ""),
                mode=L.LGraph.PART_NAMES[mode_used], boundary_rows=n_bnd, boundary_row_share=n_bnd / nv,
                boundary_edges=bnd_edges, boundary_edge_share=bnd_edges / (ne_own + ne_halo) if mode_used else None,
@@ -195,7 +195,7 @@ def run_mode(ctx, mode, S, steps):
                send_rows=int(send_idx.numel()), halo_table_gb=n_halo * D * 4 / 1e9,
                exchanges_per_step=exchanges,
                send_gb_per_exchange=send_idx.numel() * D * 4 / 1e9, recv_gb_per_exchange=n_halo * D * 4 / 1e9,
-               xgmi_ms_per_exchange_at_153GBs_per_link=per_link / (XGMI_LINK_GBS * 1e9) * 1e3,
+               xgmi_ms_per_exchange_at_153GBs_per_link=per_link / (XGMI_LINK_GBS * 1e9) * 1e3, world=WORLD,
                compute_ms_per_step=ms, pack_ms_per_exchange=pack_ms, breakdown_ms_per_step=br,
                # per exchange: the kernel time between its begin and its end -- what the wire time can hide under
                overlappable_ms_per_exchange=[round(v, 3) for v in overlap_ms],
@@ -220,11 +220,14 @@ def main():
     ap.add_argument("--boundary", nargs="+", default=["uniform"], choices=["uniform", "clustered"])
     ap.add_argument("--band", type=float, default=0.2, help="clustered: share of a range's ids that form its boundary band")
     ap.add_argument("--mode", nargs="+", default=["split", "classes", "onepass", "onepass_all", "auto"], choices=list(MODES))
+    ap.add_argument("--world", type=int, default=8, help="number of vertex ranges (default 8: the node)")
     ap.add_argument("--strong", action="store_true",
                     help="the N = 1 bench graph (products shape, random order) cut into 8 vertex ranges: rank's share of the N > 1 headline")
     ap.add_argument("--link-gbs", type=float, default=None, help="GAIB_LINK_GBS for the auto rule (default: the library's 100)")
     ap.add_argument("--opts", default="", help="library options, key=value,... (gaib_set_option), e.g. spmm_flat_ring=1")
     args = ap.parse_args()
+    global WORLD
+    WORLD = args.world
     if args.link_gbs is not None:
         import os
         os.environ["GAIB_LINK_GBS"] = str(args.link_gbs)
