@@ -149,6 +149,7 @@ SIGNATURES = {
     "gaib_halo_rows": (_i64, [_vp]),
     "gaib_halo_send_rows": (_i64, [_vp]),
     "gaib_halo_bytes_sent": (_i64, [_vp]),
+    "gaib_halo_send_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
     "gaib_halo_link_rows": (_i64, [_vp]),
     "gaib_halo_exchange_begin": (_i, [_vp, _i, _vp]),
     "gaib_halo_exchange_end": (_i, [_vp, _pp]),
@@ -261,6 +262,12 @@ class Halo:
     @property
     def bytes_sent(self) -> int:
         return int(self.lib.gaib_halo_bytes_sent(self.h))
+
+    def send_stats(self) -> dict:
+        """dict(packs, direct_sends, direct_peers): gaib_halo_send_stats"""
+        a, b, n = _i64(), _i64(), _i()
+        _check(self.lib.gaib_halo_send_stats(self.h, C.byref(a), C.byref(b), C.byref(n)), "gaib_halo_send_stats")
+        return dict(packs=a.value, direct_sends=b.value, direct_peers=n.value)
 
     def close(self):
         if getattr(self, "h", None):

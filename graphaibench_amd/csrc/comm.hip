@@ -278,6 +278,13 @@ struct gaib_halo {
     void* base_tx[GAIB_IPC_MAX_CHUNKS - 1];
   } peer[GAIB_COMM_MAX_RANKS];
   int64_t bytes_sent;
+  // RCCL, round 5: a peer whose send list is one run of consecutive rows (first, first + 1, ...) -- every peer of a partition
+  // whose ranges need (nearly) all of each other's rows, the N-way cut of a graph on a random numbering: dist.py then asks for
+  // the whole range -- is sent straight from the caller's matrix; if EVERY peer is, the plan never packs and needs no send
+  // buffer (the pack was 0.43 of the 3.6 ms of rank 0's step at N = 8, profiles/r05/shard/).  -1: packed as before.
+  int64_t direct_first[GAIB_COMM_MAX_RANKS];
+  int all_direct;  // every peer with rows to send is direct (and there is one)
+  int64_t packs, direct_sends;  // exchanges that ran the pack kernel / sends that went straight from the caller's matrix
 };
 
 namespace {
@@ -728,6 +735,7 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
     h->recv_off[r + 1] = h->recv_off[r] + h_recv_counts[r];
   }
   const int64_t n_send = h->send_off[c->nranks];
+  for (int r = 0; r < GAIB_COMM_MAX_RANKS; r++) h->direct_first[r] = -1;
   GAIB_CHECK(n_send == 0 || send_idx, "gaib_halo_create: send_idx is NULL");
   if (n_send) {
     hipError_t e = hipMalloc((void**)&h->d_send_idx, sizeof(int64_t) * n_send);
@@ -740,6 +748,30 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
       if (h->d_send_idx) (void)hipFree(h->d_send_idx);
       delete h;
       return GAIB_ERR_HIP;
+    }
+    // which peers' lists are one run of consecutive rows (checked on the host, once)
+    {
+      std::vector<int64_t> hidx((size_t)n_send);
+      e = hipMemcpy(hidx.data(), h->d_send_idx, sizeof(int64_t) * n_send, hipMemcpyDeviceToHost);
+      int any = 0, all = 1;
+      for (int r = 0; r < c->nranks; r++) {
+        h->direct_first[r] = -1;
+        const int64_t n_r = h->send_counts[r], o = h->send_off[r];
+        if (e != hipSuccess || n_r == 0 || c->transport != GAIB_COMM_RCCL || getenv("GAIB_NO_DIRECT_SEND")) {
+          if (n_r) all = 0;
+          continue;
+        }
+        bool run = true;
+        for (int64_t k = 1; k < n_r && run; ++k) run = hidx[o + k] == hidx[o] + k;
+        if (run && hidx[o] >= 0) {
+          h->direct_first[r] = hidx[o];
+          any = 1;
+        } else {
+          all = 0;
+        }
+      }
+      h->all_direct = any && all;
+      (void)hipGetLastError();
     }
     // (row, slot) pairs sorted by row (stable radix sort of the row ids with the slot numbers as values); if anything
     // here fails the plan packs in destination order, as before
@@ -822,6 +854,16 @@ extern "C" int64_t gaib_halo_link_rows(const gaib_halo* h) {
 }
 extern "C" int64_t gaib_halo_bytes_sent(const gaib_halo* h) { return h ? h->bytes_sent : 0; }
 
+extern "C" int gaib_halo_send_stats(const gaib_halo* h, int64_t* h_packs, int64_t* h_direct_sends, int* h_direct_peers) {
+  GAIB_CHECK(h && h_packs && h_direct_sends && h_direct_peers, "gaib_halo_send_stats: NULL argument");
+  *h_packs = h->packs;
+  *h_direct_sends = h->direct_sends;
+  int n = 0;
+  for (int r = 0; r < h->c->nranks; r++) n += h->direct_first[r] >= 0 ? 1 : 0;
+  *h_direct_peers = n;
+  return GAIB_OK;
+}
+
 // 1. pack the owned rows the peers asked for (compute stream), 2. start moving them.  Every rank calls it for every
 // exchange (also one that neither sends nor receives).  Returns at once on RCCL; on IPC after the peers' packs are
 // done and this rank's pulls are enqueued.
@@ -848,8 +890,9 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   auto chunk_ptr = [&](int j) -> float* { return j == 0 ? h->sendbuf : h->send_x[j - 1]; };
   auto rows_in_chunk = [&](int j) -> int64_t { return std::min<int64_t>(chunk_rows, n_send - (int64_t)j * chunk_rows); };
   const size_t exp_cap = c->transport == GAIB_COMM_IPC ? ipc_export_limit() : ~(size_t)0;  // (IPC exports every send allocation)
-  int ra = reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)(chunked ? chunk_rows : n_send), ctx->stream, keep,
-                   exp_cap);
+  const bool no_pack = c->transport == GAIB_COMM_RCCL && h->all_direct;  // every peer reads the caller's matrix itself
+  int ra = no_pack ? 0 : reserve(&h->sendbuf, &h->send_cap, &h->send_serial, row_bytes * (size_t)(chunked ? chunk_rows : n_send),
+                                 ctx->stream, keep, exp_cap);
   if (ra < 0) return fail(c, ra);
   for (int j = 1; j < n_chunks; ++j) {
     int rx = reserve(&h->send_x[j - 1], &h->send_x_cap[j - 1], &h->send_x_serial[j - 1], row_bytes * (size_t)rows_in_chunk(j),
@@ -858,10 +901,13 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   }
   int rb = reserve(&h->table, &h->table_cap, &h->table_serial, row_bytes * (size_t)n_recv, ctx->stream, keep);
   if (rb < 0) return fail(c, rb);
-  if (n_send && !chunked) {
+  if (n_send && no_pack) {
+    // nothing to pack
+  } else if (n_send && !chunked) {
     int rc = h->d_pack_row ? gaib_gather_scatter_rows(ctx, n_send, h->d_pack_row, h->d_pack_slot, len, d_rows, h->sendbuf)
                            : gaib_gather_rows(ctx, n_send, h->d_send_idx, len, d_rows, h->sendbuf);
     if (rc != GAIB_OK) return fail(c, rc);
+    h->packs++;
   } else if (n_send) {
     // the source-ordered pack into the chunks: every (row, slot) pair's destination as an address; where that form does
     // not apply (odd row lengths, no sorted pairs) chunk by chunk in destination order
@@ -894,9 +940,14 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
     if (c->nranks > 1) {
       GAIB_NCCL(g_rccl.GroupStart());
       for (int r = 0; r < c->nranks; r++) {
-        if (h->send_counts[r])
-          GAIB_NCCL(g_rccl.Send(h->sendbuf + h->send_off[r] * len, (size_t)(h->send_counts[r] * len), ncclFloat32, r,
-                                c->nccl, c->cstream));
+        if (h->send_counts[r]) {
+          // a run of consecutive rows goes straight from the caller's matrix (it stays untouched until gaib_halo_exchange_end:
+          // the aggregation in between only reads it); otherwise from the packed send buffer
+          const bool direct = h->direct_first[r] >= 0;
+          const float* src = direct ? d_rows + h->direct_first[r] * len : h->sendbuf + h->send_off[r] * len;
+          if (direct) h->direct_sends++;
+          GAIB_NCCL(g_rccl.Send(src, (size_t)(h->send_counts[r] * len), ncclFloat32, r, c->nccl, c->cstream));
+        }
         if (h->recv_counts[r])
           GAIB_NCCL(g_rccl.Recv(h->table + h->recv_off[r] * len, (size_t)(h->recv_counts[r] * len), ncclFloat32, r,
                                 c->nccl, c->cstream));

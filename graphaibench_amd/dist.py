@@ -124,11 +124,15 @@ class Partition:
         return int(self.colidx_own.numel() + self.colidx_halo.numel())
 
 
-def split_by_owner(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, lo: int, hi: int):
+def split_by_owner(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, lo: int, hi: int, bounds=None, complete: float = 0.0):
     """the local (no communication) half of the partition: rows [lo, hi) of the global CSR -> an owned-column CSR
     (column ids relative to lo), a halo-column CSR (column ids index `halo`), the sorted global ids of the halo
     vertices and the rows' full degrees.  owned + halo == the vertex set of the reference's induced subgraph
-    (graph_partition.cc:150-166), pinned against it in tests/test_dist_cpu.py."""
+    (graph_partition.cc:150-166), pinned against it in tests/test_dist_cpu.py.
+    bounds + complete > 0 (round 5): a peer range of which this rank needs at least that share of the rows is taken WHOLE --
+    the halo grows by the few rows nobody here reads, and the peer's send list becomes its full row range, one run of
+    consecutive rows, which the RCCL transport sends straight from the peer's matrix without packing (the N-way cut of a
+    graph on a random numbering needs 99.9 % of every peer's rows at N = 8)."""
     device = colidx_global.device
     n_own = hi - lo
     assert rowptr_local.numel() == n_own + 1
@@ -138,6 +142,22 @@ def split_by_owner(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, lo: 
     rows = torch.repeat_interleave(torch.arange(n_own, device=device), deg)
     own = (cols >= lo) & (cols < hi)
     halo = torch.unique(cols[~own])  # sorted
+    if bounds is not None and complete > 0.0 and halo.numel():
+        bt = torch.tensor(bounds, dtype=torch.int64, device=device)
+        owner = torch.searchsorted(bt, halo, right=True) - 1
+        cnt = torch.bincount(owner, minlength=len(bounds) - 1).tolist()
+        segs, grew = [], False
+        for q in range(len(bounds) - 1):
+            size_q = bounds[q + 1] - bounds[q]
+            if bounds[q] == lo and bounds[q + 1] == hi:
+                continue  # this rank's own range
+            if size_q > 0 and cnt[q] >= complete * size_q and cnt[q] < size_q:
+                segs.append(torch.arange(bounds[q], bounds[q + 1], dtype=torch.int64, device=device))
+                grew = True
+            elif cnt[q]:
+                segs.append(halo[owner == q])
+        if grew:
+            halo = torch.cat(segs)  # (still ascending: the ranges are)
 
     def csr_of(mask, ids):
         cnt = torch.bincount(rows[mask], minlength=n_own)
@@ -158,7 +178,9 @@ def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_g
     bounds = partition_bounds(n_global, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     n_own = hi - lo
-    rp_own, ci_own, rp_halo, ci_halo, halo, deg = split_by_owner(rowptr_local, colidx_global, lo, hi)
+    # GAIB_COMPLETE_HALO (default 0.9; 0 = never): see split_by_owner
+    complete = float(os.environ.get("GAIB_COMPLETE_HALO", "0.9"))
+    rp_own, ci_own, rp_halo, ci_halo, halo, deg = split_by_owner(rowptr_local, colidx_global, lo, hi, bounds, complete)
     # owner of each halo vertex -> how many rows we receive from each rank
     bt = torch.tensor(bounds, dtype=torch.int64, device=device)
     owner = torch.searchsorted(bt, halo, right=True) - 1

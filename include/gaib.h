@@ -546,6 +546,10 @@ int64_t gaib_halo_send_rows(const gaib_halo* halo); /* rows this rank packs per 
 int64_t gaib_halo_link_rows(const gaib_halo* halo); /* the most rows one peer pair moves per exchange, either direction:
                                                       * what one xGMI link carries (every pair has its own) */
 int64_t gaib_halo_bytes_sent(const gaib_halo* halo);
+/* how the plan's rows left so far: exchanges that ran the pack kernel, sends that went STRAIGHT from the caller's matrix, and the
+ * number of peers whose send list is one run of consecutive rows (RCCL transport: such a peer is sent from d_rows itself; if
+ * every peer is, the plan never packs -- the N-way cut of a graph whose ranges need all of each other's rows) */
+int gaib_halo_send_stats(const gaib_halo* halo, int64_t* h_packs, int64_t* h_direct_sends, int* h_direct_peers);
 /* one exchange = begin (pack the requested rows of d_rows [n_own x len] on the compute stream, start moving them)
  * ... independent work on the compute stream (the owned-column edges of the aggregation) ... end (the compute stream
  * continues only after the halo rows have arrived; *d_table stays valid until the next begin on this plan). */

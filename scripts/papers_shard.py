@@ -57,7 +57,8 @@ def strong_rows(ctx, rank, scale):
     return rows, per
 
 
-def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",), opts="", strong=False):
+def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform", band=0.2, modes=("split",), opts="", strong=False,
+        direct_send=False):
     t0 = time.time()
     # papers: the named graph is the GLOBAL one (each rank owns 1/8 of it); products: bench.py's weak-scaling
     # workload, one products-shaped range per rank; strong: the N = 1 bench graph itself in WORLD ranges
@@ -121,7 +122,9 @@ def run_mode(ctx, mode, S, steps):
     pack_slot = pack_slot.contiguous()
 
     def begin(length, src_ptr):  # pack the rows the 7 peers need (the all-to-all would start here)
-        if send_idx.numel():
+        # --direct-send: complete halos over RCCL -- every peer's list is this rank's whole row range and is sent straight from
+        # the matrix (comm.hip, round 5): no pack
+        if send_idx.numel() and not S.get("direct_send"):
             capi._check(ctx.lib.gaib_gather_scatter_rows(ctx.h, send_idx.numel(), pack_row.data_ptr(), pack_slot.data_ptr(),
                                                          length, src_ptr, sendbuf.data_ptr()), "gaib_gather_scatter_rows")
             pack_calls[0] += 1
@@ -196,7 +199,7 @@ def run_mode(ctx, mode, S, steps):
                exchanges_per_step=exchanges,
                send_gb_per_exchange=send_idx.numel() * D * 4 / 1e9, recv_gb_per_exchange=n_halo * D * 4 / 1e9,
                xgmi_ms_per_exchange_at_153GBs_per_link=per_link / (XGMI_LINK_GBS * 1e9) * 1e3, world=WORLD,
-               compute_ms_per_step=ms, pack_ms_per_exchange=pack_ms, breakdown_ms_per_step=br,
+               compute_ms_per_step=ms, pack_ms_per_exchange=pack_ms, breakdown_ms_per_step=br, direct_send=bool(S.get("direct_send")),
                # per exchange: the kernel time between its begin and its end -- what the wire time can hide under
                overlappable_ms_per_exchange=[round(v, 3) for v in overlap_ms],
                gedges_per_s_compute_only=2 * (ne_own + ne_halo) / ms / 1e6, setup_s=round(setup_s, 1),
@@ -223,6 +226,9 @@ def main():
     ap.add_argument("--world", type=int, default=8, help="number of vertex ranges (default 8: the node)")
     ap.add_argument("--strong", action="store_true",
                     help="the N = 1 bench graph (products shape, random order) cut into 8 vertex ranges: rank's share of the N > 1 headline")
+    ap.add_argument("--direct-send", action="store_true",
+                    help="no pack: what a rank computes when every peer takes its whole row range straight from the matrix (complete "
+                         "halos over the RCCL transport)")
     ap.add_argument("--link-gbs", type=float, default=None, help="GAIB_LINK_GBS for the auto rule (default: the library's 100)")
     ap.add_argument("--opts", default="", help="library options, key=value,... (gaib_set_option), e.g. spmm_flat_ring=1")
     args = ap.parse_args()
@@ -236,7 +242,8 @@ def main():
         k, v = kv.split("=")
         ctx.set_option(k.strip(), int(v))
     if args.strong:
-        run(ctx, args.rank, 0.875, args.steps, args.scale, "ogbn-products", "uniform", args.band, args.mode, args.opts, strong=True)
+        run(ctx, args.rank, 0.875, args.steps, args.scale, "ogbn-products", "uniform", args.band, args.mode, args.opts, strong=True,
+            direct_send=args.direct_send)
         return
     for cut in args.cut:
         for boundary in args.boundary:

@@ -103,6 +103,72 @@ def test_partition_and_halo_exchange_gloo(world):
     assert all(r[1] == "ok" for r in res), res
 
 
+def _complete_worker(rank, world, port, q):
+    """a DENSE random graph (every range needs nearly all rows of every other): the halo of a peer above the threshold is taken
+    whole (dist.split_by_owner, round 5), so that peer's send list is its full row range -- one run of consecutive rows"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphaibench_amd import dist as gd
+        from oracle import binding as orc
+        from util import random_graph
+
+        rp, ci = random_graph(600, 60, seed=5, power_law=False)
+        g = orc.Graph(rp, ci).add_selfloop()
+        n, D = g.nv, 8
+        b = gd.partition_bounds(n, world)
+        lo, hi = b[rank], b[rank + 1]
+        e0, e1 = g.rowptr[lo], g.rowptr[hi]
+        rp_l = torch.from_numpy((g.rowptr[lo:hi + 1] - e0).astype(np.int64))
+        ci_g = torch.from_numpy(g.colidx[e0:e1].astype(np.int64))
+        needed = torch.unique(ci_g[(ci_g < lo) | (ci_g >= hi)])
+        part = gd.build_partition(rp_l, ci_g, n, rank, world)
+        # every peer range is complete: the halo is ALL remote vertices (a superset of what the rows read), ascending
+        assert part.n_halo == n - (hi - lo) and part.n_halo >= needed.numel() > 0.9 * part.n_halo
+        assert torch.equal(part.halo_gids, torch.cat([torch.arange(0, lo), torch.arange(hi, n)]))
+        off = 0
+        for qk in range(world):  # the list for every peer: my rows 0 .. n_own - 1 in order
+            cnt = part.send_counts[qk]
+            assert cnt == (0 if qk == rank else hi - lo)
+            assert torch.equal(part.send_idx[off:off + cnt], torch.arange(cnt))
+            off += cnt
+        x = torch.from_numpy(np.random.default_rng(5).standard_normal((n, D)).astype(np.float32))
+        halo_rows = gd.HaloExchanger(part).exchange(x[lo:hi].contiguous(), D)
+        assert torch.equal(halo_rows, x[part.halo_gids])
+        # the column split still holds every edge
+        own_g = part.colidx_own.long() + lo
+        halo_g = part.halo_gids[part.colidx_halo.long()]
+        assert torch.equal(torch.sort(torch.cat([own_g, halo_g])).values, torch.sort(ci_g).values)
+        # ... and with the upgrade off the halo is exactly what the rows read
+        os.environ["GAIB_COMPLETE_HALO"] = "0"
+        part0 = gd.build_partition(rp_l, ci_g, n, rank, world)
+        assert torch.equal(part0.halo_gids, needed)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_complete_halo_makes_send_lists_one_run_of_rows(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + world + (os.getpid() % 500)
+    procs = [ctx.Process(target=_complete_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def test_block_rows_are_globally_symmetric():
     """the multi-GPU bench generator: every rank's rows of one symmetric global graph"""
     from graphaibench_amd import synth

@@ -201,6 +201,85 @@ def test_ab_legs_through_the_rccl_branch():
         assert d["reserve_after_close"] == 0  # RCCL's kernels are gone with its communicator
 
 
+def _direct_worker(rank, world, port, q):
+    """round 5: a partition whose ranges need all of each other's rows (dense graph -> complete halos, send lists = the peers' whole
+    row ranges): over the RCCL branch (strict double) the rows leave STRAIGHT from the layer's matrix -- no pack, no send buffer --
+    and the layer's results are bit-identical to the same partition over the peer-to-peer pull (which packs)"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GAIB_RCCL_LIB"] = str(ROOT / "tests" / "fake_rccl" / "librccl_fake.so")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphaibench_amd import capi, dist as gd, layers as L
+        from oracle import binding as orc
+        from util import random_graph, rel_err
+
+        ctx = L.init(0)
+        rp, ci = random_graph(2400, 70, seed=21, power_law=True, hub_deg=1500)
+        g = orc.Graph(rp, ci).add_selfloop()
+        n, D = g.nv, 128
+        x = np.random.default_rng(5).standard_normal((n, D)).astype(np.float32)
+        gin = np.random.default_rng(6).standard_normal((n, D)).astype(np.float32)
+        lo_ = orc.GCNLayer(1, g, D, D, True)
+        want = lo_.forward(x)
+        want_go = lo_.backward(gin.copy())
+        b = gd.partition_bounds(n, world)
+        lo, hi = b[rank], b[rank + 1]
+        e0, e1 = g.rowptr[lo], g.rowptr[hi]
+        rp_l = torch.from_numpy((g.rowptr[lo:hi + 1] - e0).astype(np.int64)).cuda()
+        ci_g = torch.from_numpy(g.colidx[e0:e1].astype(np.int64)).cuda()
+        outs = {}
+        for name, tr in (("rccl", capi.COMM_RCCL), ("ipc", capi.COMM_IPC)):
+            comm, err = gd.comm_attempt(ctx, rank, world, tr)
+            assert comm is not None, err
+            part = gd.build_partition(rp_l, ci_g, n, rank, world)
+            assert part.n_halo == n - (hi - lo)  # complete halos
+            dg = gd.DistLayerGraph(ctx, part, comm)
+            layer = L.Layer(L.GCN, 1, hi - lo, D, D, dg.lgraph, True)
+            layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+            out = torch.empty(hi - lo, D, device="cuda")
+            layer.forward(out)
+            layer.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
+            go = torch.empty(hi - lo, D, device="cuda")
+            layer.backward(out, go)
+            torch.cuda.synchronize()
+            st = dg.ex.halo.send_stats()
+            outs[name] = (out.clone(), go.clone(), st)
+            plan = dg.ex.halo
+            layer.close()
+            dg.lgraph.close()
+            plan.close()
+            comm.close()
+        (o_r, g_r, st_r), (o_i, g_i, st_i) = outs["rccl"], outs["ipc"]
+        assert st_r["direct_peers"] == world - 1 and st_r["packs"] == 0 and st_r["direct_sends"] >= 2 * (world - 1), st_r
+        assert st_i["direct_peers"] == 0 and st_i["packs"] >= 2 and st_i["direct_sends"] == 0, st_i
+        assert torch.equal(o_r, o_i) and torch.equal(g_r, g_i)
+        assert rel_err(o_r.cpu().numpy(), want[lo:hi]) < 1e-4 and rel_err(g_r.cpu().numpy(), want_go[lo:hi]) < 1e-4
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_complete_halo_rows_leave_straight_from_the_matrix_over_rccl(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29150 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def _clean_env():
     return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
                                                               "MASTER_PORT", "GAIB_DIST_BACKEND", "GAIB_FORCE_DIST")}
