@@ -124,6 +124,22 @@ class Partition:
         return int(self.colidx_own.numel() + self.colidx_halo.numel())
 
 
+def complete_halo_threshold(world: int) -> float:
+    """From which share of a peer's rows on the halo is taken whole (split_by_owner; the C++ builder computes the same figure,
+    host/partition.cpp).  Taking a range whole puts the (1 - share) rows nobody reads on the wire, spread over world - 1 links,
+    and saves the sender the pack of the share that is read (a read and a write of every row at ~5 TB/s of HBM): it pays while
+    (1 - share) / ((world - 1) * link) < 2 * share / 5 TB/s, i.e. share > 1 - 2 (world - 1) link / 5000 GB/s, with the link rate
+    the partition rule uses (GAIB_LINK_GBS: measured by the run where it can be, else 100).  N = 2: 0.96, N = 4: 0.88, N = 8:
+    0.72 at 100 GB/s; never below 0.5.  GAIB_COMPLETE_HALO overrides (0 = never)."""
+    ov = os.environ.get("GAIB_COMPLETE_HALO")
+    if ov is not None and ov != "":
+        return float(ov)
+    if world < 2:
+        return 0.0
+    link = float(os.environ.get("GAIB_LINK_GBS", "100") or "100")
+    return max(0.5, 1.0 - 2.0 * (world - 1) * link / 5000.0)
+
+
 def split_by_owner(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, lo: int, hi: int, bounds=None, complete: float = 0.0):
     """the local (no communication) half of the partition: rows [lo, hi) of the global CSR -> an owned-column CSR
     (column ids relative to lo), a halo-column CSR (column ids index `halo`), the sorted global ids of the halo
@@ -178,8 +194,7 @@ def build_partition(rowptr_local: torch.Tensor, colidx_global: torch.Tensor, n_g
     bounds = partition_bounds(n_global, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     n_own = hi - lo
-    # GAIB_COMPLETE_HALO (default 0.9; 0 = never): see split_by_owner
-    complete = float(os.environ.get("GAIB_COMPLETE_HALO", "0.9"))
+    complete = complete_halo_threshold(world)  # see split_by_owner
     rp_own, ci_own, rp_halo, ci_halo, halo, deg = split_by_owner(rowptr_local, colidx_global, lo, hi, bounds, complete)
     # owner of each halo vertex -> how many rows we receive from each rank
     bt = torch.tensor(bounds, dtype=torch.int64, device=device)

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <math.h>
 #include "partition.h"
+#include <stdlib.h>
 #include "host_util.h"
 
 std::vector<int64_t> vertex_range_bounds(int64_t n, int world) {
@@ -27,6 +28,24 @@ VertexRangePartition build_vertex_range_partition(int64_t n, const index_t* rowp
     for (index_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
       const index_t c = colidx[e];
       if ((int64_t)c < P.lo || (int64_t)c >= P.hi) mark[c] = 1;
+    }
+  // Round 5: a peer range of which this rank needs at least a share `complete` of the rows is taken WHOLE -- its
+  // send list then is its full row range, one run of consecutive rows, which the RCCL transport sends straight from the
+  // matrix without packing (comm.hip; the same rule as dist.py's split_by_owner, so both builders give the same partition)
+  // The share from which that pays (dist.py: complete_halo_threshold): the rows nobody reads cross world - 1 links, the pack
+  // they save is a read and a write at ~5 TB/s: share > 1 - 2 (world - 1) link / 5000 GB/s, link = GAIB_LINK_GBS (100), >= 0.5
+  const char* ch = getenv("GAIB_COMPLETE_HALO");
+  const char* lk = getenv("GAIB_LINK_GBS");
+  const double link_gbs = lk && *lk ? atof(lk) : 100.0;
+  const double complete = ch && *ch ? atof(ch) : (world < 2 ? 0.0 : std::max(0.5, 1.0 - 2.0 * (world - 1) * link_gbs / 5000.0));
+  if (complete > 0.0)
+    for (int q = 0; q < world; q++) {
+      if (q == rank) continue;
+      const int64_t size_q = bounds[q + 1] - bounds[q];
+      int64_t cnt = 0;
+      for (int64_t v = bounds[q]; v < bounds[q + 1]; v++) cnt += mark[v];
+      if (size_q > 0 && (double)cnt >= complete * (double)size_q && cnt < size_q)
+        for (int64_t v = bounds[q]; v < bounds[q + 1]; v++) mark[v] = 1;
     }
   std::vector<int64_t> halo_slot((size_t)n, -1);  // global id -> position in halo_gids
   for (int64_t v = 0; v < n; v++)
@@ -83,6 +102,11 @@ VertexRangePartition build_vertex_range_partition(int64_t n, const index_t* rowp
         const index_t c = colidx[e];
         if ((int64_t)c >= P.lo && (int64_t)c < P.hi) want[c - P.lo] = 1;
       }
+    if (complete > 0.0) {  // (the peer applies the rule above to THIS rank's range: same count, same decision)
+      int64_t cnt = 0;
+      for (int64_t i = 0; i < n_own; i++) cnt += want[i];
+      if (n_own > 0 && (double)cnt >= complete * (double)n_own && cnt < n_own) std::fill(want.begin(), want.end(), 1);
+    }
     for (int64_t i = 0; i < n_own; i++)
       if (want[i]) {
         P.send_idx.push_back(i);

@@ -247,14 +247,22 @@ def test_partition_matches_live_reference(nv, parts):
 
 
 # ---- the host C++ partition builder of the multi-rank trainer (include/gnn/partition.h) --------------------------
+@pytest.mark.parametrize("complete", [0.0, 0.9, None])
 @pytest.mark.parametrize("nv,world", [(1000, 2), (777, 3), (4096, 8), (50, 8)])
-def test_cpp_partition_equals_dist_py(nv, world):
+def test_cpp_partition_equals_dist_py(nv, world, complete, monkeypatch):
     """build_vertex_range_partition (host C++, no communication: every rank derives its share from the global CSR)
     == dist.py's split (pinned against the reference partitioner above), and the ranks' send / receive lists mirror
-    each other."""
+    each other.  complete = 0.9 (the default, round 5): a peer range needed to at least 90 % is taken whole, by both builders
+    alike; 0: the plain induced halo; None: the threshold from the link rate and the number of ranks."""
     from graphaibench_amd import dist as gd, layers as L
     from util import random_graph
 
+    if complete is None:  # the rule: 1 - 2 (world - 1) link / 5000, the same figure in both builders
+        monkeypatch.delenv("GAIB_COMPLETE_HALO", raising=False)
+        monkeypatch.setenv("GAIB_LINK_GBS", "120")
+        assert gd.complete_halo_threshold(world) == pytest.approx(max(0.5, 1 - 2 * (world - 1) * 120 / 5000))
+    else:
+        monkeypatch.setenv("GAIB_COMPLETE_HALO", str(complete))
     rp, ci = random_graph(nv, 7, seed=nv + world, power_law=True)
     bounds = gd.partition_bounds(nv, world)
     parts = [L.HostPartition(rp, ci, r, world) for r in range(world)]
@@ -263,7 +271,9 @@ def test_cpp_partition_equals_dist_py(nv, world):
         assert (P.lo, P.hi) == (lo, hi)
         rpl = torch.from_numpy((rp[lo:hi + 1] - rp[lo]).astype(np.int64))
         cg = torch.from_numpy(ci[rp[lo]:rp[hi]].astype(np.int64))
-        rp_own, ci_own, rp_halo, ci_halo, halo, deg = gd.split_by_owner(rpl, cg, lo, hi)
+        rp_own, ci_own, rp_halo, ci_halo, halo, deg = gd.split_by_owner(rpl, cg, lo, hi, bounds, gd.complete_halo_threshold(world))
+        if complete == 0.0:  # exactly the columns the rows read
+            assert np.array_equal(halo.numpy(), np.unique(cg.numpy()[(cg.numpy() < lo) | (cg.numpy() >= hi)]))
         assert np.array_equal(P.rowptr_own, rp_own.numpy()) and np.array_equal(P.rowptr_halo, rp_halo.numpy())
         assert np.array_equal(P.colidx_own, ci_own.numpy().view(np.uint32))
         assert np.array_equal(P.colidx_halo, ci_halo.numpy().view(np.uint32))

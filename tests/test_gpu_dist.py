@@ -123,7 +123,7 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, backend, scaling):
     assert "skipped" in cfg["xgmi_link_probe"] and cfg["comm_init_timed_out"] == []
     # both ends of the weak case's partition-quality axis in the same invocation
     assert cfg["random_order"]["cut_fraction"] == 0.5 and cfg["random_order"]["value"] > 0
-    assert cfg["random_order"]["halo_rows_total"] > wk["halo_rows_total"]
+    assert cfg["random_order"]["halo_rows_total"] >= wk["halo_rows_total"]  # (equal if both halos are complete at this scale)
     if scaling == "weak":
         assert cfg["cut_fraction"] == 0.1 and res["value"] == wk["value"]
     else:
