@@ -701,10 +701,15 @@ class BenchCase:
             n_dom, ms_dom = n_fused, ms_fused
         avg_ms = ms_dom / max(n_dom, 1)
         link_env = os.environ.get("GAIB_LINK_GBS")
+        # how rank 0's rows left: exchanges that packed, sends straight from the matrix (complete halos over RCCL), and the share
+        # of a peer's rows from which its range is taken whole on this run
+        send_stats = dict(dg.ex.halo.send_stats(), complete_halo_from_share=round(complete_halo_threshold(self.world), 3)) \
+            if isinstance(dg.ex, AbiHaloExchanger) else None
         return dict(elapsed=t[0], exch_ms=t[1], pack_ms=t[2], total_edges=float(e[0]),
                     halo_rows_total=int(e[1]), halo_bytes_per_step_total=float(e[2]) / args.steps, nv=nv,
                     cut_fraction_measured=float(e[3]) / max(float(e[0]), 1.0),
                     owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
+                    halo_send_stats=send_stats,
                     avg_ms=avg_ms, launches=n_dom, parity=None,
                     # rank 0's kernels per step: the owned-column pass, the halo-column half (fused with the dense product),
                     # heavy rows, the weight gradient, the pack of the rows on the send lists
@@ -893,7 +898,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         return {"value": r["value"], "ms_per_step": r["ms_per_step"], "halo_rows_total": r["halo_rows_total"],
                 "halo_bytes_per_step_total": r["halo_bytes_per_step_total"], "halo_exchange_standalone_ms": r["exch_ms"],
                 "halo_pack_ms": r["pack_ms"], "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"],
-                "cut_fraction_measured": r["cut_fraction_measured"],
+                "cut_fraction_measured": r["cut_fraction_measured"], "halo_send_stats_rank0": r["halo_send_stats"],
                 "breakdown_ms_per_step_rank0": r["breakdown"], "partition_mode_rank0": r["partition_mode"], **more}
 
     strong_workload = (f"the single-GPU bench's ogbn-products-shaped graph (seed 42, random vertex order) partitioned into "
@@ -1074,6 +1079,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 "owned_edge_spmm_ms_per_step": main["owned_edge_spmm_ms_per_step"],
                 "breakdown_ms_per_step_rank0": main["breakdown"],
                 "partition_mode_rank0": main["partition_mode"],
+                "halo_send_stats_rank0": main["halo_send_stats"],
                 "parallelism": f"vertex-range x{world}",
                 # rccl_ranks: what ncclCommCount reports for the communicator that carried the halo rows (0: RCCL not used)
                 "transport": transport, "rccl_ranks": rccl_ranks,
