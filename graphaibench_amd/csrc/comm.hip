@@ -931,6 +931,7 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
       int r2 = gaib_gather_rows(ctx, rows_in_chunk(j), h->d_send_idx + (int64_t)j * chunk_rows, len, d_rows, chunk_ptr(j));
       if (r2 != GAIB_OK) return fail(c, r2);
     }
+    h->packs++;
   }
   h->bytes_sent += (int64_t)row_bytes * n_send;
   h->pending_len = len;
