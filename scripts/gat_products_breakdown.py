@@ -20,9 +20,11 @@ def main():
     del sg
     nv, ne, d = g.nv, g.ne, 64
     lg = L.LGraph.adopt(g)
-    for name, opt in (("one_sweep", 1), ("staged", 0)):
+    forms = [("one_sweep", 1, 4), ("one_sweep_8_in_flight", 1, 8), ("staged", 0, 4)]
+    for name, opt, unroll in forms:
         ctx.set_option("gat_fused_fwd", opt)
         ctx.set_option("gat_fused_bwd", opt)
+        ctx.set_option("gat_fused_unroll", unroll)
         layer = L.Layer(L.GAT, 1, nv, d, d, lg, act=True)
         layer.write(L.FEAT_IN, torch.randn(nv, d, device="cuda"))
         layer.write(L.GRAD_IN, torch.randn(nv, d, device="cuda"))
