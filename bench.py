@@ -236,7 +236,40 @@ def _errs(torch, a, b, tol, floor):
     return {"elem": elem, "inf": inf}
 
 
-def parity_record(torch, L, layer, feat_out, grad_out, gin_h, want: dict, tol=1e-4, floor=1e-6):
+def flips_against_fp64(torch, layer, L, graph, feat_in, feat_out, fwd_o, flips, D_):
+    """The outputs whose relu mask differs between the GPU and the oracle, evaluated in fp64 from the layer's inputs: a flipped
+    mask bit is two CORRECT roundings of the same number only if that number is within the fp32 rounding of its own sum of
+    zero -- |y64| <= bound, bound = (terms of the sum) * 2^-24 * sum|terms| of the row (aggregation) and of the dot product.
+    Anchors the "backward on the oracle's mask" criterion in the exact value instead of in the two implementations.
+    graph: the layer's device graph (A + I, rows sorted); weights as the aggregation forms them: vd[i] * vd[c] in fp32."""
+    idx = torch.nonzero(flips)
+    if idx.numel() == 0:
+        return {"count": 0}
+    idx = idx[:256]  # (a handful in practice)
+    rp, ci, vd = graph.rowptr(), graph.colidx().to(torch.int64), graph.vertex_data()
+    W = layer.tensor(L.W_NEIGH, (D_, D_)).double()
+    worst = worst_ratio = 0.0
+    for i, j in idx.tolist():
+        e0, e1 = int(rp[i]), int(rp[i + 1])
+        cols = ci[e0:e1]
+        w = (vd[i] * vd[cols]).double()                      # (the fp32 product of the kernel, then exact)
+        rows = feat_in[cols].double()
+        a = (w[:, None] * rows).sum(0)                        # aggregated row, fp64
+        a_abs = (w[:, None].abs() * rows.abs()).sum(0)
+        y = float((a * W[:, j]).sum())
+        y_abs = float((a_abs * W[:, j].abs()).sum())
+        bound = ((e1 - e0) + D_) * 2.0 ** -24 * y_abs         # first-order bound of an fp32 evaluation in any order
+        worst = max(worst, abs(y))
+        worst_ratio = max(worst_ratio, abs(y) / max(bound, 1e-300))
+    scale = float(fwd_o.abs().max())
+    return {"count": int(flips.sum().item()), "checked": int(idx.shape[0]), "max_abs_fp64_value_over_scale": worst / scale,
+            "max_abs_fp64_value_over_fp32_rounding_bound": worst_ratio,
+            "ok": bool(worst_ratio <= 1.0),
+            "note": "every output whose mask bit differs is, evaluated in fp64 from the inputs, within the first-order fp32 rounding "
+                    "bound of its own sum around zero: both signs are correct fp32 roundings"}
+
+
+def parity_record(torch, L, layer, feat_out, grad_out, gin_h, want: dict, tol=1e-4, floor=1e-6, graph=None, feat_in=None):
     """Element-wise parity of the GPU layer against the oracle's full-graph run on the same inputs.
 
     Per tensor: `elem` = max_i |a_i-b_i| / (|b_i| + (floor/tol) max|b|)  (<= tol  <=>  |a-b| <= tol|b| + floor max|b|
@@ -259,6 +292,11 @@ def parity_record(torch, L, layer, feat_out, grad_out, gin_h, want: dict, tol=1e
     scale = fwd_o.abs().max().item()
     worst = max(feat_out[flips].abs().max().item(), fwd_o[flips].abs().max().item()) / scale if n_flips else 0.0
     rec["relu_mask_flips"] = {"count": n_flips, "of": int(fwd_o.numel()), "max_abs_output_over_scale": worst}
+    if graph is not None and feat_in is not None:
+        try:
+            rec["relu_mask_flips"]["fp64"] = flips_against_fp64(torch, layer, L, graph, feat_in, feat_out, fwd_o, flips, D_)
+        except Exception as e:  # noqa: BLE001 -- an extra check must not cost the record
+            rec["relu_mask_flips"]["fp64"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     del flips
     go_o = torch.from_numpy(want["grad_out"]).cuda()
     wg_o = torch.from_numpy(want["W_grad"]).cuda()
@@ -1081,7 +1119,10 @@ def main():
             result["cpu_baseline"], want = cpu_baseline(sg.rowptr, sg.colidx, nv, *xs, want_outputs=want_parity)
             log(f"[bench] cpu baseline took {time.time()-t1:.1f}s")
             if want_parity:
-                result["parity"] = parity_record(torch, L, layer, feat_out, grad_out, gin_h, want)
+                gview = lg.device_graph()  # (non-owning view of the layer's graph; the copies of its arrays need the context)
+                gview.ctx = ctx
+                result["parity"] = parity_record(torch, L, layer, feat_out, grad_out, gin_h, want, graph=gview,
+                                                 feat_in=layer.tensor(L.FEAT_IN, (nv, D)))
                 log(f"[bench] parity vs the oracle's full-graph run: {result['parity']}")
                 if not result["parity"]["ok"]:
                     log("[bench] PARITY FAILED (> 1e-4)")
