@@ -327,7 +327,8 @@ def parity_record(torch, L, layer, feat_out, grad_out, gin_h, want: dict, tol=1e
     rec["ok"] = bool(rec["forward"]["elem"] <= tol and rec["forward"]["inf"] <= tol
                      and rec["grad_out"]["elem"] <= tol and rec["grad_out"]["inf"] <= tol
                      and rec["W_grad"]["inf"] <= tol and rec["W_grad"]["elem_at_floor"] <= tol
-                     and gpu64 <= 2e-5 and worst <= 1e-5)
+                     and gpu64 <= 2e-5 and worst <= 1e-5
+                     and rec["relu_mask_flips"].get("fp64", {}).get("ok", True) is not False)
     return rec
 
 

@@ -472,6 +472,29 @@ def test_bench_n1_keeps_its_record_when_a_later_leg_fails():
     assert res["parity"]["ok"] is None and "did not complete" in res["parity"]["reason"]  # unchecked is SAID
 
 
+def test_bench_n1_record_at_small_scale():
+    """`python bench.py --scale 0.05`: the N = 1 record with every block the contract names, element-wise parity, and -- round 5 --
+    the outputs whose relu mask differs from the oracle's checked against an fp64 evaluation (inside the fp32 rounding bound of
+    their sums: both signs are correct roundings)"""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scale", "0.05", "--steps", "3", "--warmup", "1", "--sustain-s", "0"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1
+    res = json.loads(out[0])
+    assert res["n_gpus"] == 1 and res["scaling"] == "strong" and res["unit"] == "edges/s" and res["dtype"] == "f32" and res["vs_baseline"] is None
+    assert res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] > 0 and res["cpu_baseline"]["value"] > 0
+    par = res["parity"]
+    assert par["ok"] is True and par["forward"]["elem"] <= 1e-4 and par["grad_out"]["elem"] <= 1e-4
+    fl = par["relu_mask_flips"]
+    assert "fp64" in fl and fl["fp64"].get("ok", True) is True
+    if fl["count"]:
+        assert fl["fp64"]["checked"] >= 1 and fl["fp64"]["max_abs_fp64_value_over_fp32_rounding_bound"] <= 1.0
+
+
 def test_bench_budget_skips_sub_cases_and_keeps_the_headline():
     """--budget-s smaller than any sub-case: the headline case runs, every further slot says {"skipped": "budget", ...},
     exit 0, one line"""
