@@ -1395,6 +1395,11 @@ EPOCH_WORKLOADS = {
                                      "shape (scripts/run-sage-products.sh)"),
     "epoch-gcn-products": dict(arch="gcn", dataset="ogbn-products", hidden=128, layers=3, heads=1, parity_scale=0.04,
                                what="3-layer GCN 100 -> 128 -> 128 -> 47 on the ogbn-products shape (north_star's D = 128 as a model)"),
+    # BASELINE config 2: "cora GCN 2-layer D=16 fp32 on 1 MI355X" -- the reference's own topology (tests/golden/cora), seeded features
+    "epoch-gcn-cora": dict(arch="gcn", dataset="cora", hidden=16, layers=2, heads=1, parity_scale=1.0,
+                           what="BASELINE config 2: 2-layer GCN 1433 -> 16 -> 7 on the cora topology the reference ships (launch-bound: "
+                                "the timed epochs are replayed as recorded HIP graphs; the work table comes from a second, "
+                                "call-by-call run)"),
     "epoch-gat-reddit": dict(arch="gat", dataset="reddit", hidden=64, layers=2, heads=8, parity_scale=0.1,
                              what="BASELINE config 4: 2-layer 8-head GAT 602 -> 64 -> 64 (+ l2norm + dense 64 -> 41, net.cpp:69-71) "
                                   "on the reddit shape"),
@@ -1414,7 +1419,7 @@ def _lines_per_row(cols: int) -> float:
 
 
 def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: int, layers: int, heads: int, prof_from: int | None,
-                 timeout_s: float):
+                 timeout_s: float, times_from: int | None = None):
     """bin/gpu_train_<arch> with the reference's argument list (train.cpp:9-14; net.cpp:40-64) as a CHILD process ->
     (stdout text, per-epoch dicts (loss, acc, seconds), work table or {}, aggregated edges per epoch)"""
     import re
@@ -1427,10 +1432,13 @@ def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: i
         raise RuntimeError(f"{exe} is missing: python -m graphaibench_amd.build")
     env = dict(os.environ, DATASET_PATH=data_root if data_root.endswith("/") else data_root + "/", GAIB_GAT_HEADS=str(heads))
     env.pop("GAIB_RANKS", None)
+    if times_from is not None:  # epoch times at full precision without timing launches (recorded epochs included)
+        env["GAIB_EPOCH_TIMES"] = str(times_from)
     if prof_from is not None:
         env["GAIB_PROF_TABLE"] = str(prof_from)
-        # (launch-bound datasets -- <= 4 M edges: scaled-down development runs -- would be replayed as recorded HIP graphs, where
-        # nothing is launched call by call and no launch can be timed; the full-size configs run call by call anyway)
+        # (launch-bound datasets -- <= 4 M edges: cora, scaled-down development runs -- are replayed as recorded HIP graphs, where
+        # nothing is launched call by call and no launch can be timed: the table needs a call-by-call run; the full-size
+        # configs run call by call anyway)
         env["GAIB_EPOCH_GRAPH"] = "0"
     # <dataset> <epochs> <threads> <loss> <hidden> <score_drop> <feat_drop> <lr> <layers> <subgraph> <val_interval> <inductive>
     cmd = [str(exe), dataset, str(epochs), "32", "softmax", str(hidden), "0", "0", "0.01", str(layers), "0", str(epochs + 100), "0"]
@@ -1473,10 +1481,27 @@ def bench_epoch(args, torch, synth, guard) -> int:
     tmp = tempfile.mkdtemp(prefix="gaib_epoch_")
     try:
         t0 = time.time()
-        info = synth.write_dataset(name, tmp, scale=args.scale, device="cuda")
+
+        def write(scale):
+            if name == "cora":  # the reference's own topology (data fixture), not a generator
+                return synth.write_cora_dataset(tmp, ROOT / "tests" / "golden" / "cora")
+            return synth.write_dataset(name, tmp, scale=scale, device="cuda")
+
+        info = write(args.scale)
         torch.cuda.empty_cache()
         log(f"[bench] {name}-shaped dataset written in {time.time()-t0:.1f}s: nv={info['nv']} ne={info['ne']} F={info['F']} C={info['C']}")
         out, ep, table, edges_epoch = _run_trainer(arch, tmp, name, warm + steps, hid, nl, heads, warm, 500.0)
+        recorded = None
+        if info["ne"] <= (1 << 22):
+            # launch bound: what the trainer does by default there is replay the epoch as two recorded HIP graphs -- THAT is the
+            # timed figure; the call-by-call run above only supplies the work table (its epochs are several times longer)
+            warm_r = max(warm, 2)  # (epoch 0 runs call by call and is followed by the recording)
+            out_r, ep_r, _, edges_r = _run_trainer(arch, tmp, name, warm_r + steps, hid, nl, heads, None, 500.0, times_from=warm_r)
+            recorded = dict(call_by_call_ms_per_epoch=sum(e["seconds"] for e in ep[warm:]) / steps * 1e3,
+                            note="timed epochs = the trainer's default on a launch-bound dataset: two recorded HIP-graph launches per "
+                                 "epoch; roofline.per_key comes from the call-by-call run (same kernels, launched one by one)")
+            ep, warm = ep_r, warm_r
+            edges_epoch = edges_r or edges_epoch
         shutil.rmtree(os.path.join(tmp, name), ignore_errors=True)
         if len(ep) != warm + steps or not table:
             raise RuntimeError(f"trainer output not understood ({len(ep)} epoch lines, {len(table)} table lines):\n{out[-1500:]}")
@@ -1512,7 +1537,7 @@ def bench_epoch(args, torch, synth, guard) -> int:
                                              f"(bin/gpu_train_{arch} {name} {warm + steps} 32 softmax {hid} 0 0 0.01 {nl} 0 - 0"
                                              + (f", GAIB_GAT_HEADS={heads})" if heads > 1 else ")"),
                        "nv": info["nv"], "ne": info["ne"], "F": info["F"], "C": info["C"], "hidden": hid, "layers": nl, "heads": heads,
-                       "scale": args.scale, "aggregated_edges_per_epoch": edges_epoch, "parallelism": "1 GPU",
+                       "scale": args.scale, "aggregated_edges_per_epoch": edges_epoch, "parallelism": "1 GPU", "recorded_epochs": recorded,
                        "train_loss_timed_epochs": [e["loss"] for e in timed]},
             "roofline": {"bound": "hbm (aggregations, edge kernels) + mfma (dense products), per launch", "kernel": f"all launches of an epoch; largest: {dom}",
                          # bytes-at-the-HBM-roof view of the whole epoch, and the judge's definition of the fraction
@@ -1540,7 +1565,7 @@ def bench_epoch(args, torch, synth, guard) -> int:
             from oracle.model import OracleModel
 
             sc = min(w["parity_scale"], args.scale)
-            info_s = synth.write_dataset(name, tmp, scale=sc, device="cuda")
+            info_s = write(sc)
             torch.cuda.empty_cache()
             n_cmp = 5
             _, ep_s, _, edges_s = _run_trainer(arch, tmp, name, n_cmp, hid, nl, heads, None, 300.0)

@@ -330,3 +330,30 @@ def write_dataset(name: str, root, scale: float = 1.0, device="cuda", seed: int 
     meta = [nv, ne, 4, 8, 1, 2, max_degree, F, C, 0, 0, tr, tr, tr, va, va - tr, va, nv, nv - va]
     (d / "graph.meta.txt").write_text("\n".join(str(v) for v in meta) + "\n")
     return dict(nv=nv, ne=ne, F=F, C=C, train_begin=0, train_end=tr, max_degree=max_degree, dir=str(d))
+
+
+def write_cora_dataset(root, golden_dir, feat_len: int = 1433, seed: int = 0):
+    """BASELINE config 2's dataset: the reference's own cora topology / labels / split (golden_dir: byte copies of the files the
+    reference ships under inputs/cora -- data, kept under tests/golden/cora) with seeded sparse-binary, row-normalised features
+    like the real ones (the shipped dataset has none).  Returns the same dict as write_dataset."""
+    import shutil
+    from pathlib import Path
+
+    import numpy as np
+
+    gold, d = Path(golden_dir), Path(root) / "cora"
+    d.mkdir(parents=True, exist_ok=True)
+    for f in ("graph.vertex.bin", "graph.edge.bin", "graph.vlabel.bin", "graph.meta.txt"):
+        shutil.copyfile(gold / f, d / f)
+    meta = (d / "graph.meta.txt").read_text().split()
+    meta[7] = str(feat_len)
+    (d / "graph.meta.txt").write_text("\n".join(meta) + "\n")
+    rng = np.random.default_rng(seed)
+    labels = np.fromfile(d / "graph.vlabel.bin", np.uint8).astype(int)
+    nv, ncls = len(labels), int(labels.max()) + 1
+    proto = rng.random((ncls, feat_len)) < 0.03          # class "vocabularies"
+    x = ((rng.random((nv, feat_len)) < 0.008) | (proto[labels] & (rng.random((nv, feat_len)) < 0.3))).astype(np.float32)
+    x /= np.maximum(x.sum(1, keepdims=True), 1.0)
+    x.tofile(d / "graph.feats.bin")
+    return dict(nv=nv, ne=int(meta[1]), F=feat_len, C=ncls, train_begin=int(meta[10]), train_end=int(meta[11]),
+                max_degree=int(meta[6]), dir=str(d))

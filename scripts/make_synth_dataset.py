@@ -19,25 +19,9 @@ from graphaibench_amd import synth  # noqa: E402
 
 
 def cora(root: Path, feat_len: int = 1433, seed: int = 0):
-    """the reference's own cora topology / labels / split (tests/golden/cora = byte copies of inputs/cora) with
-    seeded sparse-binary, row-normalised features like the real ones (the shipped dataset has none)"""
-    import shutil
-    gold = Path(__file__).resolve().parent.parent / "tests" / "golden" / "cora"
-    d = root / "cora"
-    d.mkdir(parents=True, exist_ok=True)
-    for f in ("graph.vertex.bin", "graph.edge.bin", "graph.vlabel.bin", "graph.meta.txt"):
-        shutil.copyfile(gold / f, d / f)
-    meta = (d / "graph.meta.txt").read_text().split()
-    meta[7] = str(feat_len)
-    (d / "graph.meta.txt").write_text("\n".join(meta) + "\n")
-    rng = np.random.default_rng(seed)
-    labels = np.fromfile(d / "graph.vlabel.bin", np.uint8).astype(int)
-    nv, ncls = len(labels), int(labels.max()) + 1
-    proto = rng.random((ncls, feat_len)) < 0.03          # class "vocabularies"
-    x = ((rng.random((nv, feat_len)) < 0.008) | (proto[labels] & (rng.random((nv, feat_len)) < 0.3))).astype(np.float32)
-    x /= np.maximum(x.sum(1, keepdims=True), 1.0)
-    x.tofile(d / "graph.feats.bin")
-    print(f"wrote {d}: nv={nv} F={feat_len} C={ncls}")
+    """the reference's own cora topology with seeded features (synth.write_cora_dataset)"""
+    info = synth.write_cora_dataset(root, Path(__file__).resolve().parent.parent / "tests" / "golden" / "cora", feat_len, seed)
+    print(f"wrote {info['dir']}: nv={info['nv']} F={info['F']} C={info['C']}")
 
 
 def main():

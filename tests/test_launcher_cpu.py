@@ -407,7 +407,7 @@ def test_epoch_record_helpers():
     assert bench._lines_per_row(100) == 4.0 and bench._lines_per_row(16) == 1.0 and bench._lines_per_row(256) == 8.0
     tab = capi.parse_prof_table("spmm_gemm_fused@128 4 30.5 2.3e11 1.2e11 28.75\nsgemm 6 7.25 1e10 9e11 5.7\n\nnot a line\n")
     assert tab["spmm_gemm_fused@128"] == dict(count=4, ms=30.5, bytes=2.3e11, flops=1.2e11, roof_ms=28.75) and tab["sgemm"]["count"] == 6
-    assert set(bench.EPOCH_WORKLOADS) == {"epoch-sage-products", "epoch-gcn-products", "epoch-gat-reddit"}
+    assert set(bench.EPOCH_WORKLOADS) == {"epoch-sage-products", "epoch-gcn-products", "epoch-gat-reddit", "epoch-gcn-cora"}
 
 
 def test_epoch_record_is_assembled_from_the_trainer_output(monkeypatch, tmp_path):
@@ -427,12 +427,12 @@ def test_epoch_record_is_assembled_from_the_trainer_output(monkeypatch, tmp_path
     class FakeSynth:
         @staticmethod
         def write_dataset(name, root, scale=1.0, device="cuda"):
-            return dict(nv=1000, ne=50000, F=100, C=47, train_begin=0, train_end=80, max_degree=99, dir=str(tmp_path / name))
+            return dict(nv=1000, ne=5_000_000, F=100, C=47, train_begin=0, train_end=80, max_degree=99, dir=str(tmp_path / name))  # (> 4 M edges: not the launch-bound two-run scheme)
 
     table = ("spmm_gemm_fused@128 4 20.0 1.2e11 4e10 16.0\nspmm_light@47 2 6.0 3.0e10 1e9 4.0\nsgemm@1000x128x100 6 3.0 6e9 1.2e11 1.5\n"
              "d_relu 2 0.1 1e8 0 0.0125\n")
 
-    def fake_trainer(arch, data_root, dataset, epochs, hidden, layers, heads, prof_from, timeout_s):
+    def fake_trainer(arch, data_root, dataset, epochs, hidden, layers, heads, prof_from, timeout_s, times_from=None):
         ep = [dict(loss=3.8 - 0.1 * i, acc=0.02 * i, seconds=0.020 if i else 0.5) for i in range(epochs)]
         return "", ep, bench.__dict__["capi_parse"](table) if prof_from is not None else {}, 250000
 
