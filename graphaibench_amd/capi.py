@@ -74,6 +74,7 @@ SIGNATURES = {
     "gaib_spmm_gemm2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i]),
     "gaib_spmm_mh": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i]),
     "gaib_graph_split_classes": (_i, [_vp, _vp, _vp, _pp, _pp, _pp, _pp, C.POINTER(_i64), C.POINTER(_i64), _i]),
+    "gaib_graph_split_pieces": (_i, [_vp, _vp, _i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i), _pp]),
     "gaib_graph_set_row_map": (_i, [_vp, _vp, _vp, _i64]),
     "gaib_graph_row_map": (_vp, [_vp]),
     "gaib_spmm_2t": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _i]),
@@ -153,6 +154,12 @@ SIGNATURES = {
     "gaib_halo_link_rows": (_i64, [_vp]),
     "gaib_halo_exchange_begin": (_i, [_vp, _i, _vp]),
     "gaib_halo_exchange_end": (_i, [_vp, _pp]),
+    "gaib_halo_set_pieces": (_i, [_vp, _i]),
+    "gaib_halo_pieces": (_i, [_vp]),
+    "gaib_halo_default_pieces": (_i, [_i64, _i]),
+    "gaib_halo_piece_slice": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "gaib_halo_piece_ranges": (_i, [_vp, _i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
+    "gaib_halo_exchange_wait_piece": (_i, [_vp, _i, _pp]),
     "gaib_halo_reduce": (_i, [_vp, _i, _vp, _vp]),
     "gaib_probe_stream_copy": (_i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
     "gaib_probe_peer_copy": (_i, [_i, _i, C.c_size_t, _i, _i, C.POINTER(C.c_double)]),
@@ -253,6 +260,26 @@ class Halo:
     def end(self) -> int:
         p = C.c_void_p()
         _check(self.lib.gaib_halo_exchange_end(self.h, C.byref(p)), "gaib_halo_exchange_end")
+        return p.value or 0
+
+    def set_pieces(self, n_pieces: int):
+        """the exchange in n_pieces time slices (gaib_halo_set_pieces; the same on every rank)"""
+        _check(self.lib.gaib_halo_set_pieces(self.h, int(n_pieces)), "gaib_halo_set_pieces")
+
+    @property
+    def pieces(self) -> int:
+        return int(self.lib.gaib_halo_pieces(self.h))
+
+    def piece_ranges(self, piece: int):
+        """[(begin, end), ...] rows of the halo table that slice `piece` fills (gaib_halo_piece_ranges)"""
+        cap = self.comm.nranks
+        b, e, n = (C.c_int64 * cap)(), (C.c_int64 * cap)(), _i()
+        _check(self.lib.gaib_halo_piece_ranges(self.h, piece, cap, b, e, C.byref(n)), "gaib_halo_piece_ranges")
+        return [(int(b[j]), int(e[j])) for j in range(n.value)]
+
+    def wait_piece(self, piece: int) -> int:
+        p = C.c_void_p()
+        _check(self.lib.gaib_halo_exchange_wait_piece(self.h, piece, C.byref(p)), "gaib_halo_exchange_wait_piece")
         return p.value or 0
 
     def reduce(self, halo_rows, rows, length: int):
@@ -503,6 +530,16 @@ class Context:
         out["n_boundary"], out["boundary_edges"] = nb.value, be.value
         return out
 
+    def split_pieces(self, g: "Graph", n_pieces: int, ranges):
+        """gaib_graph_split_pieces: ranges = [(begin, end, piece), ...] over g's column space -> [Graph] * n_pieces"""
+        nr = len(ranges)
+        b = (C.c_int64 * max(nr, 1))(*[int(r[0]) for r in ranges])
+        e = (C.c_int64 * max(nr, 1))(*[int(r[1]) for r in ranges])
+        pc = (C.c_int * max(nr, 1))(*[int(r[2]) for r in ranges])
+        hs = (C.c_void_p * n_pieces)()
+        _check(self.lib.gaib_graph_split_pieces(self.h, g.h, n_pieces, nr, b, e, pc, hs), "gaib_graph_split_pieces")
+        return [Graph(self, _handle=C.c_void_p(hs[k])) for k in range(n_pieces)]
+
     def gat_scores(self, g, h, alpha_l, alpha_r, temp, scores, norm, eps: float = 0.2, heads: int = 1):
         _check(self.lib.gaib_gat_scores_mh(self.h, g.h, h.shape[1], heads, _ptr(h), _ptr(alpha_l), _ptr(alpha_r),
                                            eps, _ptr(temp), _ptr(scores), _ptr(norm)), "gaib_gat_scores")
@@ -724,6 +761,10 @@ class Graph:
     @property
     def ne(self) -> int:
         return self.lib.gaib_graph_ne(self.h)
+
+    @property
+    def nc(self) -> int:
+        return self.lib.gaib_graph_nc(self.h)
 
     def add_selfloop(self) -> "Graph":
         h = C.c_void_p()

@@ -36,6 +36,7 @@
 
 #define GAIB_COMM_MAX_RANKS 16
 #define GAIB_COMM_MAX_HALOS 8
+#define GAIB_HALO_MAX_PIECES 16  // time slices of one exchange (gaib_halo_set_pieces)
 // elementwise.hip: the source-ordered pack into destination row ADDRESSES (a send buffer that is several allocations)
 int gaib_gather_rows_to_addresses(gaib_ctx* ctx, int64_t n_idx, const int64_t* d_src_idx, const int64_t* d_dst_addr, int len,
                                   const float* d_in);
@@ -117,7 +118,7 @@ struct ShmSlot {  // one rank's published send buffer of one halo plan
   uint64_t gen;   // bumped whenever the buffer was (re)allocated: peers re-open the handle
   uint64_t capacity_bytes;
   int32_t device;
-  int32_t pad;
+  int32_t n_pieces;  // time slices the owner cuts an exchange into (gaib_halo_set_pieces): the puller's must be the same
   hipIpcMemHandle_t handle;
   int64_t send_off[GAIB_COMM_MAX_RANKS + 1];  // row offsets of the per-destination groups inside the buffer
   // a send buffer above the chunk size: rows [j * chunk_rows, (j + 1) * chunk_rows) live in allocation j (handle = chunk 0)
@@ -285,7 +286,22 @@ struct gaib_halo {
   int64_t direct_first[GAIB_COMM_MAX_RANKS];
   int all_direct;  // every peer with rows to send is direct (and there is one)
   int64_t packs, direct_sends;  // exchanges that ran the pack kernel / sends that went straight from the caller's matrix
+  // round 6: an exchange in K time slices ("pieces").  Slice k of a peer pair's R rows is rows [R k / K, R (k + 1) / K) of that
+  // pair's segment -- sender and receiver cut the same R the same way -- and slice k of EVERY pair travels together (one
+  // ncclGroup / one round of pulls), so every link is busy all the time and piece k has landed after ~ (k + 1) / K of the
+  // exchange.  ev_piece[k] is recorded on the communication stream behind slice k: the caller's halo-column pass over piece
+  // k's columns (gaib_halo_exchange_wait_piece) runs while slices k + 1 ... are still on the wire.  The table's layout does
+  // not change (grouped by source rank): a piece is up to nranks - 1 column ranges of it (gaib_halo_piece_ranges).
+  int n_pieces;
+  hipEvent_t ev_piece[GAIB_HALO_MAX_PIECES];
+  int64_t piece_waits;
 };
+
+// rows [lo, hi) of a peer pair's R-row segment that travel in slice k of K
+static inline void piece_slice(int64_t rows, int n_pieces, int piece, int64_t* lo, int64_t* hi) {
+  *lo = rows * piece / n_pieces;
+  *hi = rows * (piece + 1) / n_pieces;
+}
 
 namespace {
 
@@ -721,6 +737,7 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
   gaib_halo* h = new (std::nothrow) gaib_halo();
   GAIB_CHECK(h, "gaib_halo_create: out of memory");  // (value-initialised: every plain member is zero, `retired` is empty)
   h->c = c;
+  h->n_pieces = 1;
   h->id = slot;  // taken (bit set) only once every argument check has passed
   h->send_off[0] = h->recv_off[0] = 0;
   for (int r = 0; r < c->nranks; r++) {
@@ -830,6 +847,8 @@ extern "C" int gaib_halo_destroy(gaib_halo* h) {
   if (h->d_pack_row) (void)hipFree(h->d_pack_row);
   if (h->d_pack_slot) (void)hipFree(h->d_pack_slot);
   if (h->d_pack_addr) (void)hipFree(h->d_pack_addr);
+  for (hipEvent_t ev : h->ev_piece)
+    if (ev) (void)hipEventDestroy(ev);
   pool_release(c, h->sendbuf);  // back into the communicator's pool (see gaib_comm::ipc_bufs)
   for (float* q : h->send_x) pool_release(c, q);
   pool_release(c, h->landing);
@@ -861,6 +880,63 @@ extern "C" int gaib_halo_send_stats(const gaib_halo* h, int64_t* h_packs, int64_
   int n = 0;
   for (int r = 0; r < h->c->nranks; r++) n += h->direct_first[r] >= 0 ? 1 : 0;
   *h_direct_peers = n;
+  return GAIB_OK;
+}
+
+// ---- an exchange in time slices ("pieces", round 6) ----
+extern "C" int gaib_halo_piece_slice(int64_t rows, int n_pieces, int piece, int64_t* h_lo, int64_t* h_hi) {
+  GAIB_CHECK(h_lo && h_hi, "gaib_halo_piece_slice: NULL argument");
+  GAIB_CHECK(rows >= 0 && n_pieces >= 1 && n_pieces <= GAIB_HALO_MAX_PIECES && piece >= 0 && piece < n_pieces,
+             "gaib_halo_piece_slice: piece %d of %d over %lld rows (at most %d pieces)", piece, n_pieces, (long long)rows,
+             GAIB_HALO_MAX_PIECES);
+  piece_slice(rows, n_pieces, piece, h_lo, h_hi);
+  return GAIB_OK;
+}
+
+// how many slices a partition of n_global vertices over `world` ranges cuts its exchanges into -- a function of figures every
+// rank holds (so all ranks agree without a collective): GAIB_HALO_PIECES if set; else by the rows one peer pair can move at
+// most (a whole range): from 131 072 rows (64 MB of 512-B rows) 4 slices, from 32 768 two, below that one -- a slice should
+// stay far above the latency of its group launch, and every further piece costs one more read + write of the rows' partial sums
+extern "C" int gaib_halo_default_pieces(int64_t n_global, int world) {
+  const char* e = getenv("GAIB_HALO_PIECES");
+  if (e && *e) {
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end != e && *end == '\0' && v >= 1 && v <= GAIB_HALO_MAX_PIECES) return (int)v;
+    fprintf(stderr, "[gaib] GAIB_HALO_PIECES='%s' ignored (want 1 .. %d)\n", e, GAIB_HALO_MAX_PIECES);
+  }
+  if (world < 2 || n_global <= 0) return 1;
+  const int64_t rows = n_global / world;
+  return rows >= 131072 ? 4 : (rows >= 32768 ? 2 : 1);
+}
+
+extern "C" int gaib_halo_set_pieces(gaib_halo* h, int n_pieces) {
+  GAIB_CHECK(h, "gaib_halo_set_pieces: halo is NULL");
+  GAIB_CHECK(n_pieces >= 1 && n_pieces <= GAIB_HALO_MAX_PIECES, "gaib_halo_set_pieces: %d pieces (1 .. %d)", n_pieces,
+             GAIB_HALO_MAX_PIECES);
+  GAIB_CHECK(h->pending_len == 0, "gaib_halo_set_pieces: an exchange is in flight on this plan");
+  GAIB_HIP(hipSetDevice(h->c->ctx->device));
+  for (int k = 0; k < n_pieces; ++k)
+    if (!h->ev_piece[k]) GAIB_HIP(hipEventCreateWithFlags(&h->ev_piece[k], hipEventDisableTiming));
+  h->n_pieces = n_pieces;
+  return GAIB_OK;
+}
+extern "C" int gaib_halo_pieces(const gaib_halo* h) { return h ? h->n_pieces : 0; }
+
+extern "C" int gaib_halo_piece_ranges(const gaib_halo* h, int piece, int cap, int64_t* h_begin, int64_t* h_end, int* h_n) {
+  GAIB_CHECK(h && h_begin && h_end && h_n, "gaib_halo_piece_ranges: NULL argument");
+  GAIB_CHECK(piece >= 0 && piece < h->n_pieces, "gaib_halo_piece_ranges: piece %d of %d", piece, h->n_pieces);
+  int n = 0;
+  for (int r = 0; r < h->c->nranks; ++r) {
+    int64_t lo, hi;
+    piece_slice(h->recv_counts[r], h->n_pieces, piece, &lo, &hi);
+    if (hi <= lo) continue;
+    GAIB_CHECK(n < cap, "gaib_halo_piece_ranges: more than %d ranges", cap);
+    h_begin[n] = h->recv_off[r] + lo;
+    h_end[n] = h->recv_off[r] + hi;
+    ++n;
+  }
+  *h_n = n;
   return GAIB_OK;
 }
 
@@ -939,21 +1015,33 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   if (c->transport == GAIB_COMM_RCCL) {
     GAIB_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
     if (c->nranks > 1) {
-      GAIB_NCCL(g_rccl.GroupStart());
-      for (int r = 0; r < c->nranks; r++) {
-        if (h->send_counts[r]) {
-          // a run of consecutive rows goes straight from the caller's matrix (it stays untouched until gaib_halo_exchange_end:
-          // the aggregation in between only reads it); otherwise from the packed send buffer
-          const bool direct = h->direct_first[r] >= 0;
-          const float* src = direct ? d_rows + h->direct_first[r] * len : h->sendbuf + h->send_off[r] * len;
-          if (direct) h->direct_sends++;
-          GAIB_NCCL(g_rccl.Send(src, (size_t)(h->send_counts[r] * len), ncclFloat32, r, c->nccl, c->cstream));
+      // one group per time slice (K = 1: the whole exchange): slice k of every peer pair travels together, and the event
+      // behind it tells the compute stream that piece k's columns of the table are there
+      const int K = h->n_pieces;
+      for (int r = 0; r < c->nranks; r++)
+        if (h->send_counts[r] && h->direct_first[r] >= 0) h->direct_sends++;
+      for (int k = 0; k < K; ++k) {
+        GAIB_NCCL(g_rccl.GroupStart());
+        for (int r = 0; r < c->nranks; r++) {
+          int64_t lo, hi;
+          piece_slice(h->send_counts[r], K, k, &lo, &hi);
+          if (hi > lo) {
+            // a run of consecutive rows goes straight from the caller's matrix (it stays untouched until gaib_halo_exchange_end:
+            // the aggregation in between only reads it); otherwise from the packed send buffer
+            const bool direct = h->direct_first[r] >= 0;
+            const float* src = direct ? d_rows + (h->direct_first[r] + lo) * len : h->sendbuf + (h->send_off[r] + lo) * len;
+            GAIB_NCCL(g_rccl.Send(src, (size_t)((hi - lo) * len), ncclFloat32, r, c->nccl, c->cstream));
+          }
+          piece_slice(h->recv_counts[r], K, k, &lo, &hi);
+          if (hi > lo)
+            GAIB_NCCL(g_rccl.Recv(h->table + (h->recv_off[r] + lo) * len, (size_t)((hi - lo) * len), ncclFloat32, r, c->nccl,
+                                  c->cstream));
         }
-        if (h->recv_counts[r])
-          GAIB_NCCL(g_rccl.Recv(h->table + h->recv_off[r] * len, (size_t)(h->recv_counts[r] * len), ncclFloat32, r,
-                                c->nccl, c->cstream));
+        GAIB_NCCL(g_rccl.GroupEnd());
+        if (K > 1) GAIB_HIP(hipEventRecord(h->ev_piece[k], c->cstream));
       }
-      GAIB_NCCL(g_rccl.GroupEnd());
+    } else {
+      for (int k = 0; k < h->n_pieces && h->n_pieces > 1; ++k) GAIB_HIP(hipEventRecord(h->ev_piece[k], c->cstream));
     }
     GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
     return GAIB_OK;
@@ -987,6 +1075,7 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
     h->pub_n_chunks = n_chunks;
     h->pub_chunk_rows = chunk_rows;
   }
+  mine->n_pieces = h->n_pieces;  // (read by the peers after the barrier below)
   GAIB_COMM_DBG(c, "exchange_begin: %lld rows out (%zu B), %lld rows in, handle published; waiting for the pack", (long long)n_send,
                 row_bytes * (size_t)n_send, (long long)n_recv);
   hipError_t e = hipEventSynchronize(c->ev_ready);  // the pack is done: peers may read the buffer
@@ -998,59 +1087,86 @@ extern "C" int gaib_halo_exchange_begin(gaib_halo* h, int len, const float* d_ro
   int rc = shm_barrier(c, "gaib_halo_exchange_begin (all packed)");
   if (rc != GAIB_OK) return rc;
   GAIB_COMM_DBG(c, "exchange_begin: all ranks packed");
-  for (int r = 0; r < c->nranks; r++) {
-    if (!h->recv_counts[r]) continue;
-    const ShmSlot* ps = &c->seg->slot[h->id][r];
-    if (h->peer[r].gen != ps->gen) {  // the peer's allocations (or their layout) changed: every mapping of the old ones goes
-      if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
-      h->peer[r].base = nullptr;
-      for (void*& q : h->peer[r].base_x) {
-        if (q) (void)hipIpcCloseMemHandle(q);
-        q = nullptr;
+  const int K = h->n_pieces;
+  for (int k = 0; k < K; ++k) {
+    for (int r = 0; r < c->nranks; r++) {
+      if (!h->recv_counts[r]) continue;
+      const ShmSlot* ps = &c->seg->slot[h->id][r];
+      if (ps->n_pieces != K) {
+        gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d cuts this exchange into %d pieces, this rank into %d "
+                       "(gaib_halo_set_pieces: the same on every rank)", c->rank, r, ps->n_pieces, K);
+        return fail(c, GAIB_ERR_INVALID);
       }
-      h->peer[r].gen = ps->gen;
-    }
-    if (ps->send_off[c->rank + 1] - ps->send_off[c->rank] != h->recv_counts[r]) {
-      gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d sends %lld rows, this rank expects %lld", c->rank, r,
-                     (long long)(ps->send_off[c->rank + 1] - ps->send_off[c->rank]), (long long)h->recv_counts[r]);
-      return fail(c, GAIB_ERR_INVALID);
-    }
-    const int pk = ps->n_chunks > 0 ? ps->n_chunks : 1;
-    const int64_t pcr = ps->chunk_rows;
-    if (pk > GAIB_IPC_MAX_CHUNKS || (pk > 1 && pcr < 1)) {
-      gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d published %d chunks of %lld rows", c->rank, r, pk, (long long)pcr);
-      return fail(c, GAIB_ERR_INVALID);
-    }
-    // this rank's segment of the peer's send buffer: rows [s0, s1) of its slot space, chunk by chunk
-    const int64_t s0 = ps->send_off[c->rank], s1 = s0 + h->recv_counts[r];
-    for (int64_t a = s0; a < s1;) {
-      const int j = pk > 1 ? (int)(a / pcr) : 0;
-      const int64_t in_chunk = pk > 1 ? a - (int64_t)j * pcr : a;
-      const int64_t b = pk > 1 ? std::min<int64_t>(s1, (int64_t)(j + 1) * pcr) : s1;
-      void*& base = j == 0 ? h->peer[r].base : h->peer[r].base_x[j - 1];
-      if (!base) {
-        GAIB_COMM_DBG(c, "exchange_begin: opening chunk %d of %d of rank %d's send buffer", j, pk, r);
-        e = hipIpcOpenMemHandle(&base, j == 0 ? ps->handle : ps->handle_x[j - 1], hipIpcMemLazyEnablePeerAccess);
+      if (h->peer[r].gen != ps->gen) {  // the peer's allocations (or their layout) changed: every mapping of the old ones goes
+        if (h->peer[r].base) (void)hipIpcCloseMemHandle(h->peer[r].base);
+        h->peer[r].base = nullptr;
+        for (void*& q : h->peer[r].base_x) {
+          if (q) (void)hipIpcCloseMemHandle(q);
+          q = nullptr;
+        }
+        h->peer[r].gen = ps->gen;
+      }
+      if (ps->send_off[c->rank + 1] - ps->send_off[c->rank] != h->recv_counts[r]) {
+        gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d sends %lld rows, this rank expects %lld", c->rank, r,
+                       (long long)(ps->send_off[c->rank + 1] - ps->send_off[c->rank]), (long long)h->recv_counts[r]);
+        return fail(c, GAIB_ERR_INVALID);
+      }
+      const int pk = ps->n_chunks > 0 ? ps->n_chunks : 1;
+      const int64_t pcr = ps->chunk_rows;
+      if (pk > GAIB_IPC_MAX_CHUNKS || (pk > 1 && pcr < 1)) {
+        gaib_set_error("gaib_halo_exchange_begin(rank %d): rank %d published %d chunks of %lld rows", c->rank, r, pk, (long long)pcr);
+        return fail(c, GAIB_ERR_INVALID);
+      }
+      // this rank's segment of the peer's send buffer: rows [s0, s0 + recv_counts) of its slot space; slice k of it, chunk by chunk
+      const int64_t s0 = ps->send_off[c->rank];
+      int64_t k_lo, k_hi;
+      piece_slice(h->recv_counts[r], K, k, &k_lo, &k_hi);
+      const int64_t s1 = s0 + k_hi;
+      for (int64_t a = s0 + k_lo; a < s1;) {
+        const int j = pk > 1 ? (int)(a / pcr) : 0;
+        const int64_t in_chunk = pk > 1 ? a - (int64_t)j * pcr : a;
+        const int64_t b = pk > 1 ? std::min<int64_t>(s1, (int64_t)(j + 1) * pcr) : s1;
+        void*& base = j == 0 ? h->peer[r].base : h->peer[r].base_x[j - 1];
+        if (!base) {
+          GAIB_COMM_DBG(c, "exchange_begin: opening chunk %d of %d of rank %d's send buffer", j, pk, r);
+          e = hipIpcOpenMemHandle(&base, j == 0 ? ps->handle : ps->handle_x[j - 1], hipIpcMemLazyEnablePeerAccess);
+          if (e != hipSuccess) {
+            base = nullptr;
+            gaib_set_error("gaib_halo_exchange_begin(rank %d): hipIpcOpenMemHandle(rank %d's send buffer, chunk %d): %s", c->rank, r, j,
+                           hipGetErrorString(e));
+            return fail(c, GAIB_ERR_HIP);
+          }
+        }
+        const float* src = (const float*)base + in_chunk * len;
+        GAIB_COMM_DBG(c, "exchange_begin: pulling %zu B from rank %d (chunk %d, row %lld)", row_bytes * (size_t)(b - a), r, j,
+                      (long long)in_chunk);
+        e = hipMemcpyAsync(h->table + (h->recv_off[r] + (a - s0)) * len, src, row_bytes * (size_t)(b - a), hipMemcpyDeviceToDevice,
+                           c->cstream);
         if (e != hipSuccess) {
-          base = nullptr;
-          gaib_set_error("gaib_halo_exchange_begin(rank %d): hipIpcOpenMemHandle(rank %d's send buffer, chunk %d): %s", c->rank, r, j,
-                         hipGetErrorString(e));
+          gaib_set_error("gaib_halo_exchange_begin(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
           return fail(c, GAIB_ERR_HIP);
         }
+        a = b;
       }
-      const float* src = (const float*)base + in_chunk * len;
-      GAIB_COMM_DBG(c, "exchange_begin: pulling %zu B from rank %d (chunk %d, row %lld)", row_bytes * (size_t)(b - a), r, j,
-                    (long long)in_chunk);
-      e = hipMemcpyAsync(h->table + (h->recv_off[r] + (a - s0)) * len, src, row_bytes * (size_t)(b - a), hipMemcpyDeviceToDevice,
-                         c->cstream);
-      if (e != hipSuccess) {
-        gaib_set_error("gaib_halo_exchange_begin(rank %d): peer copy from rank %d: %s", c->rank, r, hipGetErrorString(e));
-        return fail(c, GAIB_ERR_HIP);
-      }
-      a = b;
     }
+    if (K > 1) GAIB_HIP(hipEventRecord(h->ev_piece[k], c->cstream));
   }
   GAIB_HIP(hipEventRecord(c->ev_done, c->cstream));
+  return GAIB_OK;
+}
+
+// between begin and end: the compute stream continues only after slice `piece` of every peer pair has landed -- the columns
+// gaib_halo_piece_ranges names are then valid in *d_table (the others are still on the wire).  Stream-ordered on both
+// transports (the host does not wait); gaib_halo_exchange_end is still due after the last piece.
+extern "C" int gaib_halo_exchange_wait_piece(gaib_halo* h, int piece, const float** d_table) {
+  GAIB_CHECK(h && d_table, "gaib_halo_exchange_wait_piece: NULL argument");
+  GAIB_CHECK(h->pending_len > 0, "gaib_halo_exchange_wait_piece: no exchange in flight");
+  GAIB_CHECK(piece >= 0 && piece < h->n_pieces, "gaib_halo_exchange_wait_piece: piece %d of %d", piece, h->n_pieces);
+  gaib_comm* c = h->c;
+  GAIB_HIP(hipSetDevice(c->ctx->device));
+  GAIB_HIP(hipStreamWaitEvent(c->ctx->stream, h->n_pieces > 1 ? h->ev_piece[piece] : c->ev_done, 0));
+  h->piece_waits++;
+  *d_table = h->table;
   return GAIB_OK;
 }
 

@@ -1240,6 +1240,210 @@ extern "C" int gaib_graph_split_classes(gaib_ctx* ctx, const gaib_graph* g_own, 
   return GAIB_OK;
 }
 
+// ---- pieces of a halo-column graph (round 6: the exchange in time slices, gaib_halo_set_pieces) ----
+// Piece k of a rank's halo-column graph = the edges whose column (a row of the halo table) travels in slice k of the exchange:
+// the same rows, the same column space, every row's edges in the row's order.  Aggregating piece 0, 1, ... in accumulate mode
+// adds a row's terms piece by piece and inside a piece in column order -- for ONE peer (the slices are then consecutive column
+// ranges) exactly the order of the uncut graph, for several peers the piece-major order of the same terms.
+namespace {
+
+struct PiecePtrs {
+  int64_t* rp[GAIB_GRAPH_MAX_PIECES];
+  uint32_t* col[GAIB_GRAPH_MAX_PIECES];
+};
+
+// piece of column c: the range [rb[j], re[j]) it lies in (ranges ascending, disjoint), -1 if none
+__device__ __forceinline__ int piece_of(uint32_t c, int n_ranges, const uint32_t* rb, const uint32_t* re, const int* rpiece) {
+  int lo = 0, hi = n_ranges;  // last range whose begin is <= c
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rb[mid] <= c) lo = mid;
+    else hi = mid;
+  }
+  return (n_ranges > 0 && c >= rb[lo] && c < re[lo]) ? rpiece[lo] : -1;
+}
+
+// one wave per row: cnt[k * (nv + 1) + row] = the row's edges in piece k; *n_lost counts edges in no piece
+__global__ __launch_bounds__(256) void piece_count_kernel(int64_t nv, const int64_t* rowptr, const uint32_t* col, int n_pieces,
+                                                          int n_ranges, const uint32_t* rb, const uint32_t* re, const int* rpiece,
+                                                          int64_t* cnt, unsigned long long* n_lost) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row > nv) return;
+  const int lane = threadIdx.x & 63;
+  if (row == nv) {  // closes every piece's exclusive scan
+    if (lane < n_pieces) cnt[(int64_t)lane * (nv + 1) + nv] = 0;
+    return;
+  }
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  int64_t mine = 0;  // lane k < n_pieces carries piece k's count
+  unsigned lost = 0;
+  for (int64_t base = e0; base < e1; base += 64) {
+    const int64_t e = base + lane;
+    const int pc = e < e1 ? piece_of(col[e], n_ranges, rb, re, rpiece) : -2;
+    lost += pc == -1 ? 1u : 0u;
+    for (int k = 0; k < n_pieces; ++k) {
+      const int c = __popcll(__ballot(pc == k));
+      if (lane == k) mine += c;
+    }
+  }
+  if (lane < n_pieces) cnt[(int64_t)lane * (nv + 1) + row] = mine;
+  lost = wave_sum_u32(lost);
+  if (lane == 0 && lost) atomicAdd(n_lost, (unsigned long long)lost);
+}
+
+__global__ __launch_bounds__(256) void piece_fill_kernel(int64_t nv, const int64_t* rowptr, const uint32_t* col, int n_pieces,
+                                                         int n_ranges, const uint32_t* rb, const uint32_t* re, const int* rpiece,
+                                                         PiecePtrs out) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  int64_t off = lane < n_pieces ? out.rp[lane][row] : 0;  // lane k: where piece k's next edge of this row goes
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int64_t base = e0; base < e1; base += 64) {
+    const int64_t e = base + lane;
+    const uint32_t c = e < e1 ? col[e] : 0u;
+    const int pc = e < e1 ? piece_of(c, n_ranges, rb, re, rpiece) : -2;
+    for (int k = 0; k < n_pieces; ++k) {
+      const unsigned long long m = __ballot(pc == k);
+      const int64_t o = __shfl(off, k, 64);  // (int64 shuffle: two 32-bit halves)
+      if (pc == k) out.col[k][o + __popcll(m & below)] = c;
+      if (lane == k) off += __popcll(m);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gaib_graph_split_pieces(gaib_ctx* ctx, const gaib_graph* g, int n_pieces, int n_ranges, const int64_t* h_range_begin,
+                                       const int64_t* h_range_end, const int* h_range_piece, gaib_graph** out) {
+  GAIB_CHECK(ctx && g && out && (n_ranges == 0 || (h_range_begin && h_range_end && h_range_piece)),
+             "gaib_graph_split_pieces: NULL argument");
+  GAIB_NOT_WHILE_CAPTURING(ctx, "gaib_graph_split_pieces");
+  GAIB_CHECK(n_pieces >= 1 && n_pieces <= GAIB_GRAPH_MAX_PIECES, "gaib_graph_split_pieces: %d pieces (1 .. %d)", n_pieces,
+             GAIB_GRAPH_MAX_PIECES);
+  GAIB_CHECK(n_ranges >= 0 && n_ranges <= 4096, "gaib_graph_split_pieces: %d column ranges (at most 4096)", n_ranges);
+  GAIB_CHECK(g->col_vdata && g->vdata && g->inv_deg,
+             "gaib_graph_split_pieces: call gaib_graph_set_vertex_norm (rows and columns) on the graph first");
+  // ranges sorted by their first column, disjoint, inside the column space
+  std::vector<int> order((size_t)n_ranges);
+  for (int j = 0; j < n_ranges; ++j) order[(size_t)j] = j;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return h_range_begin[a] < h_range_begin[b]; });
+  std::vector<uint32_t> rb, re;
+  std::vector<int> rpc;
+  int64_t last_end = 0;
+  for (int j : order) {
+    const int64_t b = h_range_begin[j], e = h_range_end[j];
+    if (e <= b) continue;
+    GAIB_CHECK(b >= last_end && e <= g->nc, "gaib_graph_split_pieces: column range [%lld, %lld) overlaps another or leaves the %lld "
+               "columns", (long long)b, (long long)e, (long long)g->nc);
+    GAIB_CHECK(h_range_piece[j] >= 0 && h_range_piece[j] < n_pieces, "gaib_graph_split_pieces: range of piece %d (of %d)",
+               h_range_piece[j], n_pieces);
+    rb.push_back((uint32_t)b);
+    re.push_back((uint32_t)e);
+    rpc.push_back(h_range_piece[j]);
+    last_end = e;
+  }
+  const int nr = (int)rb.size();
+  GAIB_HIP(hipSetDevice(ctx->device));
+  const int64_t nv = g->nv;
+  struct Release {
+    std::vector<void*> p;
+    ~Release() {
+      for (void* q : p)
+        if (q) (void)hipFree(q);
+    }
+  } rel;
+  auto dmalloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes > 0 ? bytes : 16) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    rel.p.push_back(q);
+    return q;
+  };
+  uint32_t* d_rb = (uint32_t*)dmalloc(sizeof(uint32_t) * (size_t)nr);
+  uint32_t* d_re = (uint32_t*)dmalloc(sizeof(uint32_t) * (size_t)nr);
+  int* d_rpc = (int*)dmalloc(sizeof(int) * (size_t)nr);
+  int64_t* cnt = (int64_t*)dmalloc(sizeof(int64_t) * (size_t)n_pieces * (size_t)(nv + 1));
+  int64_t* rp = (int64_t*)dmalloc(sizeof(int64_t) * (size_t)n_pieces * (size_t)(nv + 1));
+  unsigned long long* d_lost = (unsigned long long*)dmalloc(sizeof(unsigned long long));
+  if (!d_rb || !d_re || !d_rpc || !cnt || !rp || !d_lost) {
+    gaib_set_error("gaib_graph_split_pieces: out of device memory");
+    return GAIB_ERR_NOMEM;
+  }
+  if (nr) {
+    GAIB_HIP(hipMemcpyAsync(d_rb, rb.data(), sizeof(uint32_t) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+    GAIB_HIP(hipMemcpyAsync(d_re, re.data(), sizeof(uint32_t) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+    GAIB_HIP(hipMemcpyAsync(d_rpc, rpc.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+  }
+  GAIB_HIP(hipMemsetAsync(d_lost, 0, sizeof(unsigned long long), ctx->stream));
+  piece_count_kernel<<<grid1d(nv + 1, 4), 256, 0, ctx->stream>>>(nv, g->rowptr, g->colidx, n_pieces, nr, d_rb, d_re, d_rpc, cnt, d_lost);
+  GAIB_LAUNCH_CHECK();
+  size_t tmp_bytes = 0;
+  GAIB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, rp, (int)(nv + 1), ctx->stream));
+  void* tmp = dmalloc(tmp_bytes);
+  GAIB_CHECK(tmp, "gaib_graph_split_pieces: out of device memory");
+  for (int k = 0; k < n_pieces; ++k)
+    GAIB_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt + (int64_t)k * (nv + 1), rp + (int64_t)k * (nv + 1), (int)(nv + 1),
+                                              ctx->stream));
+  unsigned long long lost = 0;
+  int64_t ne_k[GAIB_GRAPH_MAX_PIECES];
+  GAIB_HIP(hipMemcpyAsync(&lost, d_lost, sizeof(lost), hipMemcpyDeviceToHost, ctx->stream));
+  for (int k = 0; k < n_pieces; ++k)
+    GAIB_HIP(hipMemcpyAsync(&ne_k[k], rp + (int64_t)k * (nv + 1) + nv, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  GAIB_CHECK(lost == 0, "gaib_graph_split_pieces: %llu edges point at columns outside every piece's ranges", lost);
+  gaib_graph* made[GAIB_GRAPH_MAX_PIECES] = {};
+  struct Guard {
+    gaib_graph** m;
+    int n;
+    bool armed;
+    ~Guard() {
+      for (int k = 0; armed && k < n; ++k) gaib_graph_destroy(m[k]);
+    }
+  } guard{made, n_pieces, true};
+  PiecePtrs ptrs;
+  memset(&ptrs, 0, sizeof(ptrs));
+  const size_t n1 = (size_t)(nv > 0 ? nv : 1), nc1 = (size_t)(g->nc > 0 ? g->nc : 1);
+  for (int k = 0; k < n_pieces; ++k) {
+    GAIB_TRY(new_graph(nv, ne_k[k], ctx->device, &made[k]));
+    gaib_graph* q = made[k];
+    q->nc = g->nc;
+    GAIB_HIP(hipMemcpyAsync(q->rowptr, rp + (int64_t)k * (nv + 1), sizeof(int64_t) * (size_t)(nv + 1), hipMemcpyDeviceToDevice,
+                            ctx->stream));
+    ptrs.rp[k] = q->rowptr;
+    ptrs.col[k] = q->colidx;
+    // the rows' and columns' normalisers: the source graph's
+    GAIB_HIP(hipMalloc(&q->vdata, sizeof(float) * n1));
+    GAIB_HIP(hipMalloc(&q->inv_deg, sizeof(float) * n1));
+    GAIB_HIP(hipMalloc(&q->col_vdata, sizeof(float) * nc1));
+    GAIB_HIP(hipMalloc(&q->col_inv_deg, sizeof(float) * nc1));
+    q->dev_bytes += sizeof(float) * (2 * nv + 2 * g->nc);
+    GAIB_HIP(hipMemcpyAsync(q->vdata, g->vdata, sizeof(float) * (size_t)nv, hipMemcpyDeviceToDevice, ctx->stream));
+    GAIB_HIP(hipMemcpyAsync(q->inv_deg, g->inv_deg, sizeof(float) * (size_t)nv, hipMemcpyDeviceToDevice, ctx->stream));
+    GAIB_HIP(hipMemcpyAsync(q->col_vdata, g->col_vdata, sizeof(float) * (size_t)g->nc, hipMemcpyDeviceToDevice, ctx->stream));
+    GAIB_HIP(hipMemcpyAsync(q->col_inv_deg, g->col_inv_deg ? g->col_inv_deg : g->col_vdata, sizeof(float) * (size_t)g->nc,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    if (g->row_map) {  // a piece of a row class keeps the class's map
+      GAIB_HIP(hipMalloc(&q->row_map, sizeof(uint32_t) * n1));
+      GAIB_HIP(hipMemcpyAsync(q->row_map, g->row_map, sizeof(uint32_t) * (size_t)nv, hipMemcpyDeviceToDevice, ctx->stream));
+      q->n_out_rows = g->n_out_rows;
+      q->dev_bytes += sizeof(uint32_t) * nv;
+    }
+    q->rows_unsorted = g->rows_unsorted;
+  }
+  if (nv > 0 && g->ne > 0) {
+    piece_fill_kernel<<<grid1d(nv, 4), 256, 0, ctx->stream>>>(nv, g->rowptr, g->colidx, n_pieces, nr, d_rb, d_re, d_rpc, ptrs);
+    GAIB_LAUNCH_CHECK();
+  }
+  GAIB_HIP(hipStreamSynchronize(ctx->stream));
+  guard.armed = false;
+  for (int k = 0; k < n_pieces; ++k) out[k] = made[k];
+  return GAIB_OK;
+}
+
 // ---- csr2csc (math_functions.hh:45; cusparseCsr2cscEx2, math_functions.cu:345-358): the transpose of a general CSR matrix
 // with 32-bit offsets, everything in device memory.  A stable radix sort of the edges by column id: inside a column the
 // rows come out ascending (the order of cuSPARSE's ALG1).

@@ -272,6 +272,8 @@ class AbiHaloExchanger:
         self.ctx, self.comm, self.p = ctx, comm, part
         self.halo = comm.halo(part.send_counts, part.send_idx, part.recv_counts)
         assert self.halo.rows == part.n_halo
+        # the exchange in time slices where the ranges are large enough (gaib_halo_default_pieces: the same on every rank)
+        self.halo.set_pieces(ctx.lib.gaib_halo_default_pieces(part.n_global, part.world))
         self._base = 0
 
     @property

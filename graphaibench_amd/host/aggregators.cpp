@@ -14,6 +14,25 @@ static gaib_graph* dev(Graph& g) {
   return g.device_graph();
 }
 
+// The halo-column half of a partitioned aggregation over `whole` (the mode's halo-column graph): in one pass after the whole
+// exchange -- last(whole, table) --, or, where the exchange travels in K > 1 time slices (gaib_halo_set_pieces), piece by piece
+// as the slices land: plain(piece k, table) in accumulate mode for every piece but the last non-empty one, which takes last()
+// (the pass that carries the activation / the dense product).  Same terms per row, added piece by piece.  Ends the exchange.
+template <class Plain, class Last>
+static void halo_half(Graph& g, gaib_graph* whole, int len, Plain plain, Last last) {
+  const int K = g.halo_pieces();
+  if (K <= 1) {
+    last(whole, g.halo_end(len));
+    return;
+  }
+  int last_k = 0;
+  for (int k = 0; k < K; k++)
+    if (gaib_graph_ne(g.halo_piece_graph(k)) > 0) last_k = k;
+  for (int k = 0; k < last_k; k++)
+    if (gaib_graph_ne(g.halo_piece_graph(k)) > 0) plain(g.halo_piece_graph(k), g.halo_wait_piece(k));
+  last(g.halo_piece_graph(last_k), g.halo_end(len));  // (pieces behind last_k are empty: waiting for all of them costs nothing)
+}
+
 // One aggregation.  On a vertex-range partition the work that needs no halo row runs while the halo rows are in flight
 // (separate RCCL stream), the rest after they have arrived -- by row class (LearningGraph::partition_mode):
 //   PART_SPLIT    owned-column edges of all rows meanwhile, halo-column edges added to the same rows after
@@ -27,15 +46,20 @@ static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* 
     return;
   }
   const int mode = g.partition_mode(len);
+  auto acc = [&](gaib_graph* gh, const float* halo) {
+    GAIB_OR_DIE(gaib_spmm_ex(C(), gh, kind, NULL, len, halo, out, GAIB_ACCUMULATE));
+  };
+  auto acc_act = [&](gaib_graph* gh, const float* halo) {
+    GAIB_OR_DIE(gaib_spmm_ex(C(), gh, kind, NULL, len, halo, out, GAIB_ACCUMULATE | act));
+  };
   if (mode != Graph::PART_SPLIT) {
     g.halo_begin(len, in);
     GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_interior(), kind, NULL, len, in, out, act));
     if (mode == Graph::PART_CLASSES) {
       const bool have_halo_edges = gaib_graph_ne(g.class_boundary_halo()) > 0;  // (else: no boundary row either)
       GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_boundary_own(), kind, NULL, len, in, out, have_halo_edges ? 0 : act));
-      const float* halo = g.halo_end(len);
-      if (have_halo_edges)
-        GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_boundary_halo(), kind, NULL, len, halo, out, GAIB_ACCUMULATE | act));
+      if (have_halo_edges) halo_half(g, g.class_boundary_halo(), len, acc, acc_act);
+      else g.halo_end(len);
     } else {
       const float* halo = g.halo_end(len);
       GAIB_OR_DIE(gaib_spmm_2t(C(), g.class_boundary_full(), kind, NULL, len, in, halo, (int64_t)g.size(), out, act));
@@ -45,9 +69,11 @@ static void aggregate_rows(Graph& g, int kind, int len, const float* in, float* 
   g.halo_begin(len, in);
   const bool have_halo_edges = gaib_graph_ne(g.halo_graph()) > 0;
   GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, out, have_halo_edges ? 0 : act));
-  const float* halo = g.halo_end(len);
-  if (have_halo_edges)
-    GAIB_OR_DIE(gaib_spmm_ex(C(), g.halo_graph(), kind, NULL, len, halo, out, GAIB_ACCUMULATE | act));
+  if (!have_halo_edges) {
+    g.halo_end(len);
+    return;
+  }
+  halo_half(g, g.halo_graph(), len, acc, acc_act);
 }
 
 void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float* in, float* agg, bool keep_agg,
@@ -61,6 +87,10 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
       GAIB_OR_DIE(gaib_spmm_gemm2(C(), dg, kind, NULL, len, src, agg, W, transW ? 1 : 0, rows2, W2, len_out, out, fl));
     else
       GAIB_OR_DIE(gaib_spmm_gemm(C(), dg, kind, NULL, len, src, agg, W, transW ? 1 : 0, len_out, out, fl));
+  };
+  // a piece of the halo-column half that is not the last: the partial sums continue in agg, no product yet
+  auto plain_acc = [&](gaib_graph* gh, const float* halo) {
+    GAIB_OR_DIE(gaib_spmm_ex(C(), gh, kind, NULL, len, halo, agg, GAIB_ACCUMULATE));
   };
   const int mode = g.has_halo() ? g.partition_mode(len) : Graph::PART_SPLIT;
   if (mode != Graph::PART_SPLIT) {
@@ -82,8 +112,8 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
         return;
       }
       GAIB_OR_DIE(gaib_spmm_ex(C(), g.class_boundary_own(), kind, NULL, len, in, agg, 0));
-      const float* halo = g.halo_end(len);
-      fused(g.class_boundary_halo(), halo, flags | GAIB_ACCUMULATE);
+      halo_half(g, g.class_boundary_halo(), len, plain_acc,
+                [&](gaib_graph* gh, const float* halo) { fused(gh, halo, flags | GAIB_ACCUMULATE); });
     } else {
       const float* halo = g.halo_end(len);
       GAIB_OR_DIE(gaib_spmm_gemm_2t(C(), g.class_boundary_full(), kind, NULL, len, in, halo, (int64_t)g.size(), agg, W,
@@ -101,8 +131,8 @@ void aggregator::aggregate_then_matmul(int kind, int len, Graph& g, const float*
       return;
     }
     GAIB_OR_DIE(gaib_spmm_ex(C(), dev(g), kind, NULL, len, in, agg, 0));
-    const float* halo = g.halo_end(len);
-    fused(g.halo_graph(), halo, flags | GAIB_ACCUMULATE);
+    halo_half(g, g.halo_graph(), len, plain_acc,
+              [&](gaib_graph* gh, const float* halo) { fused(gh, halo, flags | GAIB_ACCUMULATE); });
     return;
   }
   fused(dev(g), in, flags);

@@ -227,6 +227,11 @@ void gaibl_graph_set_halo_plan(void* graph, void* halo_graph, void* plan) {
 void* gaibl_graph_halo_plan(void* graph) { return static_cast<Graph*>(graph)->halo_plan(); }
 void gaibl_graph_set_partition_mode(void* graph, int mode) { static_cast<Graph*>(graph)->set_partition_mode(mode); }
 void gaibl_graph_set_halo_link_rows(void* graph, int64_t rows) { static_cast<Graph*>(graph)->set_halo_link_rows(rows); }
+void gaibl_graph_set_halo_pieces(void* graph, int n_pieces, int n_ranges, const int64_t* begin, const int64_t* end,
+                                 const int* piece, gaibl_halo_wait_piece_fn wait_piece) {
+  static_cast<Graph*>(graph)->set_halo_pieces(n_pieces, n_ranges, begin, end, piece, wait_piece);
+}
+int gaibl_graph_halo_pieces(void* graph) { return static_cast<Graph*>(graph)->halo_pieces(); }
 int gaibl_graph_partition_mode(void* graph, int len, int64_t* n_boundary, int64_t* boundary_edges) {
   Graph* g = static_cast<Graph*>(graph);
   const int mode = g->partition_mode(len);

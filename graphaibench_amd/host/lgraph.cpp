@@ -25,6 +25,51 @@ const float* LearningGraph::halo_end(int len) {
   return table;
 }
 
+const float* LearningGraph::halo_wait_piece(int k) {
+  if (!halo_plan_) return halo_wait_piece_(halo_user_, k);
+  const float* table = NULL;
+  GAIB_OR_DIE(gaib_halo_exchange_wait_piece(halo_plan_, k, &table));
+  return table;
+}
+
+void LearningGraph::drop_pieces() {
+  for (gaib_graph*& p : pieces_) {
+    if (p) gaib_graph_destroy(p);
+    p = NULL;
+  }
+  pieces_built_ = 0;
+}
+
+int LearningGraph::halo_pieces() {
+  const int K = halo_plan_ ? gaib_halo_pieces(halo_plan_) : (halo_wait_piece_ ? cb_pieces_ : 1);
+  if (K <= 1 || part_mode_ < 0) return 1;
+  gaib_graph* half = part_mode_ == PART_SPLIT ? halo_dev_ : (part_mode_ == PART_CLASSES ? cls_bhalo_ : NULL);
+  if (!half || gaib_graph_ne(half) == 0) return 1;  // (the one-pass forms wait for the whole exchange)
+  if (pieces_built_ == K) return K;
+  drop_pieces();
+  std::vector<int64_t> rb, re;
+  std::vector<int> rp;
+  if (halo_plan_) {
+    int64_t b[64], e[64];
+    for (int k = 0; k < K; k++) {
+      int n = 0;
+      GAIB_OR_DIE(gaib_halo_piece_ranges(halo_plan_, k, 64, b, e, &n));
+      for (int j = 0; j < n; j++) {
+        rb.push_back(b[j]);
+        re.push_back(e[j]);
+        rp.push_back(k);
+      }
+    }
+  } else {
+    rb = cb_range_begin_;
+    re = cb_range_end_;
+    rp = cb_range_piece_;
+  }
+  GAIB_OR_DIE(gaib_graph_split_pieces(gpu_context::get(), half, K, (int)rb.size(), rb.data(), re.data(), rp.data(), pieces_));
+  pieces_built_ = K;
+  return K;
+}
+
 // The mode of a partitioned graph's aggregations.  GAIB_PART_MODE = split | classes | onepass | onepass_all | auto (default), or
 // set_partition_mode.  The rule (auto) prices what each form leaves exposed, per aggregation:
 //   one pass    : the exchange minus what hides it -- the interior rows' work (the boundary rows wait for the halo rows)
@@ -247,6 +292,7 @@ void LearningGraph::dealloc() {
   for (gaib_graph* c : cls)
     if (c) gaib_graph_destroy(c);
   cls_int_ = cls_bown_ = cls_bhalo_ = cls_bfull_ = NULL;
+  drop_pieces();
   part_mode_ = -1;
   if (owns_partition_) {
     if (halo_plan_) gaib_halo_destroy(halo_plan_);

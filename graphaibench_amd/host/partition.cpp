@@ -206,6 +206,8 @@ LearningGraph* make_partitioned_graph(const VertexRangePartition& P, gaib_comm* 
     GAIB_OR_DIE(gaib_graph_set_vertex_norm(ctx, g_halo, d_vd, d_inv, d_vd_h, d_inv_h));
     gaib_halo* plan = nullptr;
     GAIB_OR_DIE(gaib_halo_create(comm, P.send_counts.data(), P.send_idx.data(), 0, P.recv_counts.data(), &plan));
+    // the exchange in time slices where the ranges are large enough to pay for it (the same figure on every rank)
+    GAIB_OR_DIE(gaib_halo_set_pieces(plan, gaib_halo_default_pieces(P.n_global, P.world)));
     lg->set_halo_plan(g_halo, plan);
   }
   if (!P.rowptr_full.empty()) {

@@ -51,6 +51,8 @@ SIGNATURES = {
     "gaibl_graph_set_halo_plan": (None, [_vp, _vp, _vp]),
     "gaibl_graph_set_partition_mode": (None, [_vp, _i]),
     "gaibl_graph_set_halo_link_rows": (None, [_vp, C.c_int64]),
+    "gaibl_graph_set_halo_pieces": (None, [_vp, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_i), _vp]),
+    "gaibl_graph_halo_pieces": (_i, [_vp]),
     "gaibl_graph_partition_mode": (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
@@ -168,6 +170,21 @@ class LGraph:
         nb, be = C.c_int64(), C.c_int64()
         m = load().gaibl_graph_partition_mode(self.h, int(length), C.byref(nb), C.byref(be))
         return m, nb.value, be.value
+
+    def set_halo_pieces(self, n_pieces: int, ranges, wait_piece):
+        """callback transports: the exchange lands in n_pieces slices; ranges = [(begin, end, piece), ...] rows of the halo table;
+        wait_piece(k:int) -> int (device pointer of the table once slice k is there).  After set_halo."""
+        WAIT = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int)
+        self._cb_wait = WAIT(lambda _u, k: wait_piece(int(k)))
+        nr = len(ranges)
+        b = (C.c_int64 * max(nr, 1))(*[int(r[0]) for r in ranges])
+        e = (C.c_int64 * max(nr, 1))(*[int(r[1]) for r in ranges])
+        pc = (C.c_int * max(nr, 1))(*[int(r[2]) for r in ranges])
+        load().gaibl_graph_set_halo_pieces(self.h, int(n_pieces), nr, b, e, pc, C.cast(self._cb_wait, C.c_void_p))
+
+    def halo_pieces(self) -> int:
+        """slices the halo-column half is consumed in right now (1 = whole; after partition_mode)"""
+        return int(load().gaibl_graph_halo_pieces(self.h))
 
     def set_halo_plan(self, halo_graph: capi.Graph, plan: "capi.Halo"):
         """the exchange runs behind the C ABI (gaib_halo_exchange_begin/end inside the C++ aggregators)"""

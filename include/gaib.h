@@ -356,6 +356,19 @@ int gaib_edge_transpose(gaib_ctx* ctx, gaib_graph* g, const float* d_in_e, float
 int gaib_graph_split_classes(gaib_ctx* ctx, const gaib_graph* g_own, const gaib_graph* g_halo, gaib_graph** interior,
                              gaib_graph** bnd_own, gaib_graph** bnd_halo, gaib_graph** bnd_full, int64_t* h_n_boundary,
                              int64_t* h_boundary_edges, int flags);
+/* ---- pieces of a halo-column graph (round 6; the exchange in time slices: gaib_halo_set_pieces below) ------------------
+ * Cuts a rank's halo-column graph (gaib_graph_create_rect + gaib_graph_set_vertex_norm; also a *bnd_halo row class) into
+ * n_pieces graphs over the SAME rows, column space and normalisers: piece k holds, row by row and in the row's edge order,
+ * the edges whose column lies in one of piece k's column ranges -- range j = [h_range_begin[j], h_range_end[j]) of the
+ * column space belongs to piece h_range_piece[j]; ranges are disjoint and every edge's column lies in one (else
+ * GAIB_ERR_INVALID).  With the ranges of gaib_halo_piece_ranges, piece k reads exactly the rows of the halo table that have
+ * landed after gaib_halo_exchange_wait_piece(k): aggregate piece 0, 1, ... in GAIB_ACCUMULATE mode as they arrive (the last
+ * one may carry the dense product) -- a row's terms are then added piece by piece, inside a piece in column order: with ONE
+ * peer the order of the uncut graph (same bits on rows below the heavy threshold), with several the piece-major order of
+ * the same terms.  out: n_pieces graphs (the caller destroys each). */
+#define GAIB_GRAPH_MAX_PIECES 16
+int gaib_graph_split_pieces(gaib_ctx* ctx, const gaib_graph* g, int n_pieces, int n_ranges, const int64_t* h_range_begin,
+                            const int64_t* h_range_end, const int* h_range_piece, gaib_graph** out);
 /* the row map by hand (uint32 [nv] device array, copied; n_out_rows = rows of the matrices it indexes; NULL removes it) */
 int gaib_graph_set_row_map(gaib_ctx* ctx, gaib_graph* g, const uint32_t* d_row_map, int64_t n_out_rows);
 const uint32_t* gaib_graph_row_map(const gaib_graph* g); /* device, uint32[nv], or NULL */
@@ -552,9 +565,31 @@ int64_t gaib_halo_bytes_sent(const gaib_halo* halo);
 int gaib_halo_send_stats(const gaib_halo* halo, int64_t* h_packs, int64_t* h_direct_sends, int* h_direct_peers);
 /* one exchange = begin (pack the requested rows of d_rows [n_own x len] on the compute stream, start moving them)
  * ... independent work on the compute stream (the owned-column edges of the aggregation) ... end (the compute stream
- * continues only after the halo rows have arrived; *d_table stays valid until the next begin on this plan). */
+ * continues only after the halo rows have arrived; *d_table stays valid until the next begin on this plan).
+ * d_rows must stay valid and UNMODIFIED until gaib_halo_exchange_end: over RCCL a peer whose send list is one run of
+ * consecutive rows is sent straight from d_rows on the communication stream (gaib_halo_send_stats), not from a packed
+ * copy.  (A plan that mixes direct and packed peers still packs -- and reserves buffer space for -- all of its rows.) */
 int gaib_halo_exchange_begin(gaib_halo* halo, int len, const float* d_rows);
 int gaib_halo_exchange_end(gaib_halo* halo, const float** d_table);
+/* An exchange in K time slices ("pieces", round 6): slice k of a peer pair's R rows is rows [R k / K, R (k + 1) / K) of
+ * that pair's segment (gaib_halo_piece_slice: sender and receiver cut the same R the same way), slice k of EVERY pair
+ * travels together (one ncclGroup / one round of peer pulls), so every link is busy throughout and piece k has landed after
+ * ~(k + 1) / K of the exchange.  Between begin and end, gaib_halo_exchange_wait_piece(k) makes the compute stream wait for
+ * piece k only (stream-ordered, the host does not wait): the caller's halo-column pass over piece k's columns
+ * (gaib_graph_split_pieces with gaib_halo_piece_ranges) then runs while the later slices are still on the wire.
+ * gaib_halo_exchange_end stays due after the last piece.  The table's layout does not change with K.
+ * gaib_halo_set_pieces: 1 <= n_pieces <= 16, THE SAME ON EVERY RANK (the peer-to-peer transport checks it, RCCL would
+ * mismatch its counts), not while an exchange is in flight; default 1.  gaib_halo_piece_ranges: the column ranges
+ * [begin, end) of the table that piece k fills (at most one per peer; h_n = how many, at most cap). */
+int gaib_halo_set_pieces(gaib_halo* halo, int n_pieces);
+/* the library's choice for a partition of n_global vertices into `world` ranges, a function of figures every rank holds (so
+ * the ranks agree without a collective): GAIB_HALO_PIECES if set (1 .. 16), else 4 from 131 072 rows per range, 2 from
+ * 32 768, else 1.  make_partitioned_graph and dist.py set it on their plans. */
+int gaib_halo_default_pieces(int64_t n_global, int world);
+int gaib_halo_pieces(const gaib_halo* halo);
+int gaib_halo_piece_slice(int64_t rows, int n_pieces, int piece, int64_t* h_lo, int64_t* h_hi); /* pure arithmetic, no device */
+int gaib_halo_piece_ranges(const gaib_halo* halo, int piece, int cap, int64_t* h_begin, int64_t* h_end, int* h_n);
+int gaib_halo_exchange_wait_piece(gaib_halo* halo, int piece, const float** d_table);
 
 /* the reverse of an exchange: d_halo_rows [halo rows x len] (the table's layout) holds this rank's partial sums for its
  * HALO vertices; they travel back to the owners, which add them to their own rows: d_rows[send_idx[k], :] += arrived[k, :],

@@ -7,6 +7,7 @@
 // is commented out there), print_test.
 #pragma once
 #include <algorithm>
+#include <vector>
 #include "global.h"
 #include "gaib.h"
 
@@ -48,6 +49,19 @@ class LearningGraph {
   int part_mode_;         // PART_*, -1 = not decided yet
   int part_mode_wanted_;  // set_partition_mode / GAIB_PART_MODE; -1 = by the rule
   int64_t n_boundary_, boundary_edges_, link_rows_;
+  // Round 6: the exchange in time slices (gaib_halo_set_pieces).  Where the plan cuts an exchange into K > 1 pieces and the
+  // mode keeps a halo-column half (PART_SPLIT: halo_dev_, PART_CLASSES: cls_bhalo_), that half is cut into K piece graphs
+  // (gaib_graph_split_pieces over the plan's column ranges) and aggregated piece by piece in accumulate mode as the slices
+  // land (host/aggregators.cpp halo_half): the wire hides under the halo-column work too, not only under the owned-column
+  // pass.  Built lazily for the plan's current K; a plan set back to 1 piece takes the uncut half again (bench A/B).
+  gaib_graph* pieces_[GAIB_GRAPH_MAX_PIECES];
+  int pieces_built_;  // K the piece graphs were cut for (0 = none)
+  // callback transports (set_halo) bring the piece structure themselves: set_halo_pieces
+  int cb_pieces_;
+  std::vector<int64_t> cb_range_begin_, cb_range_end_;
+  std::vector<int> cb_range_piece_;
+  const float* (*halo_wait_piece_)(void* user, int piece);
+  void drop_pieces();
 
  public:
   typedef size_t iterator;
@@ -56,7 +70,10 @@ class LearningGraph {
         colidx_(NULL), vertex_data_(NULL), edge_data_(NULL), dev_(NULL), halo_dev_(NULL),
         halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL), gat_full_(NULL), gat_t_(NULL),
         gat_tperm_(NULL), gat_n_halo_(0), owns_partition_(false), cls_int_(NULL), cls_bown_(NULL), cls_bhalo_(NULL),
-        cls_bfull_(NULL), part_mode_(-1), part_mode_wanted_(-1), n_boundary_(0), boundary_edges_(0), link_rows_(-1) {}
+        cls_bfull_(NULL), part_mode_(-1), part_mode_wanted_(-1), n_boundary_(0), boundary_edges_(0), link_rows_(-1),
+        pieces_built_(0), cb_pieces_(1), halo_wait_piece_(NULL) {
+    for (gaib_graph*& p : pieces_) p = NULL;
+  }
   LearningGraph() : LearningGraph(true) {}
   // wrap a graph that already lives in HBM (synthetic / partitioned graphs built on device)
   static LearningGraph* adopt_device(gaib_graph* g);
@@ -137,7 +154,11 @@ class LearningGraph {
          PART_ONEPASS_ALL = 3  // (a wish only; partition_mode reports PART_ONEPASS) every row counts as a boundary row:
                                // one pass over all rows of one [owned | halo] graph after arrival
   };
-  void set_partition_mode(int mode) { part_mode_wanted_ = mode; part_mode_ = -1; }  // -1: by the rule
+  void set_partition_mode(int mode) {  // -1: by the rule
+    part_mode_wanted_ = mode;
+    part_mode_ = -1;
+    drop_pieces();  // (cut from the former mode's halo-column half)
+  }
   // callback transports (set_halo): the most rows one peer pair moves per exchange (the plan form knows: gaib_halo_link_rows)
   void set_halo_link_rows(int64_t rows) { link_rows_ = rows; }
   // the mode of this graph's aggregations of `len` columns; the first call decides and builds the class graphs
@@ -152,6 +173,23 @@ class LearningGraph {
   gaib_graph* halo_graph() { return halo_dev_; }
   void halo_begin(int len, const float* d_in);
   const float* halo_end(int len);
+  // ---- the halo-column half piece by piece (see pieces_ above) ----
+  // callback transports: the exchange lands in n_pieces slices; range j = [begin[j], end[j]) of the halo table belongs to slice
+  // piece[j]; wait_piece(user, k) returns the table once slice k is there (stream-ordered).  Plans: gaib_halo_set_pieces.
+  void set_halo_pieces(int n_pieces, int n_ranges, const int64_t* begin, const int64_t* end, const int* piece,
+                       const float* (*wait_piece)(void*, int)) {
+    drop_pieces();
+    cb_pieces_ = n_pieces;
+    cb_range_begin_.assign(begin, begin + n_ranges);
+    cb_range_end_.assign(end, end + n_ranges);
+    cb_range_piece_.assign(piece, piece + n_ranges);
+    halo_wait_piece_ = wait_piece;
+  }
+  // slices the halo-column half is consumed in RIGHT NOW: the plan's (or the callbacks') K where the mode has such a half and
+  // K > 1 -- the piece graphs are (re)built here if need be --, else 1 = the whole half after gaib_halo_exchange_end
+  int halo_pieces();
+  gaib_graph* halo_piece_graph(int k) { return pieces_[k]; }
+  const float* halo_wait_piece(int k);
   // device pointers, as the reference's ENABLE_GPU accessors return them.  Row pointers are
   // int64 in HBM (the reference's uint32 offsets overflow past 2^32 edges*features).
   const int64_t* row_start_ptr() const { return gaib_graph_rowptr(dev_); }

@@ -495,6 +495,234 @@ def test_rccl_branch_exchange_and_reduce_with_growing_rows(tmp_path, world):
     assert all(r[1] == "ok" for r in res), res
 
 
+def _slices(rows, K):
+    """slice k of a peer pair's `rows` rows (gaib_halo_piece_slice's arithmetic, restated)"""
+    return [(rows * k // K, rows * (k + 1) // K) for k in range(K)]
+
+
+def _pieces_raw_worker(rank, world, idfile, q, transport_name, chunk_bytes=0):
+    """a raw halo plan whose exchanges travel in K time slices (gaib_halo_set_pieces): after wait_piece(k) the table's rows of
+    slices 0..k are the peers' rows (a snapshot enqueued behind every wait proves the ordering the stream sees), the table
+    after end() is the whole exchange, K changes between exchanges (1 -> 4 -> 3 -> 16 -> 1), the reverse exchange is untouched,
+    and ranks that disagree on K get an error, not wrong rows (the peer-to-peer transport checks)"""
+    sys.path.insert(0, str(ROOT))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    if chunk_bytes:
+        os.environ["GAIB_IPC_CHUNK_BYTES"] = str(chunk_bytes)
+    try:
+        from graphaibench_amd import capi, layers as L
+
+        ctx = L.init(0)
+        transport = _transport(transport_name, capi)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
+        n_own = 4000
+        rng = np.random.default_rng(100)
+        need = [[np.sort(rng.choice(n_own, 600 + 37 * (r + 2 * q), replace=False)) if q != r else np.empty(0, np.int64)
+                 for q in range(world)] for r in range(world)]
+        if world > 2:  # one pair moves fewer rows than there are slices, one peer's list is a run of consecutive rows (direct send)
+            need[0][1] = np.array([5, 9, 11], np.int64)
+            need[1][2] = np.arange(100, 900, dtype=np.int64)
+        send_idx = np.concatenate([need[q][rank] for q in range(world)]).astype(np.int64)
+        send_counts = [len(need[q][rank]) for q in range(world)]
+        recv_counts = [len(need[rank][q]) for q in range(world)]
+        recv_off = np.concatenate([[0], np.cumsum(recv_counts)])
+
+        def rows_of(r, length, salt):
+            return np.random.default_rng(1000 * r + length + salt).standard_normal((n_own, length)).astype(np.float32)
+
+        halo = comm.halo(send_counts, send_idx, recv_counts)
+        assert halo.pieces == 1
+        for salt, (K, length) in enumerate([(1, 16), (4, 16), (4, 128), (3, 40), (16, 8), (1, 64), (2, 200)]):
+            halo.set_pieces(K)
+            assert halo.pieces == K
+            want = np.concatenate([rows_of(q_, length, salt)[need[rank][q_]] for q_ in range(world)]) if halo.rows else \
+                np.zeros((0, length), np.float32)
+            # the library's column ranges == the restated arithmetic
+            for k in range(K):
+                mine = [(int(recv_off[q_] + lo), int(recv_off[q_] + hi)) for q_ in range(world)
+                        for lo, hi in [_slices(recv_counts[q_], K)[k]] if hi > lo]
+                assert halo.piece_ranges(k) == mine, (k, halo.piece_ranges(k), mine)
+            src = torch.from_numpy(rows_of(rank, length, salt)).cuda()
+            snaps = []
+            halo.begin(src, length)
+            for k in range(K):
+                ptr = halo.wait_piece(k)
+                snap = torch.full((max(halo.rows, 1), length), float("nan"), device="cuda")
+                if halo.rows:  # on the compute stream, behind the wait
+                    capi._check(ctx.lib.gaib_memcpy_d2d(ctx.h, snap.data_ptr(), ptr, halo.rows * length * 4), "d2d")
+                snaps.append(snap)
+            ptr = halo.end()
+            got = torch.empty(max(halo.rows, 1), length, device="cuda")
+            capi._check(ctx.lib.gaib_memcpy_d2d(ctx.h, got.data_ptr(), ptr, halo.rows * length * 4), "d2d")
+            ctx.sync()
+            assert np.array_equal(got[:halo.rows].cpu().numpy(), want), f"exchange K {K} len {length}"
+            for k, snap in enumerate(snaps):
+                sn = snap.cpu().numpy()
+                for j in range(k + 1):
+                    for b, e in halo.piece_ranges(j):
+                        assert np.array_equal(sn[b:e], want[b:e]), f"K {K} len {length}: piece {j} not there after wait_piece({k})"
+            # the reverse exchange does not care about K
+            partial = got[:halo.rows] * float(rank + 1)
+            acc = torch.zeros(n_own, length, device="cuda")
+            halo.reduce(partial, acc, length)
+            ctx.sync()
+            want_acc = np.zeros((n_own, length), np.float32)
+            for q_ in range(world):
+                if q_ != rank:
+                    want_acc[need[q_][rank]] += rows_of(rank, length, salt)[need[q_][rank]] * np.float32(q_ + 1)
+            assert np.array_equal(acc.cpu().numpy(), want_acc), f"reduce K {K} len {length}"
+        # misuse
+        with pytest.raises(capi.GaibError):
+            halo.set_pieces(0)
+        with pytest.raises(capi.GaibError):
+            halo.set_pieces(17)
+        with pytest.raises(capi.GaibError, match="no exchange in flight"):
+            halo.wait_piece(0)
+        halo.set_pieces(2)
+        halo.begin(torch.zeros(n_own, 8, device="cuda"), 8)
+        with pytest.raises(capi.GaibError, match="in flight"):
+            halo.set_pieces(3)
+        with pytest.raises(capi.GaibError, match="piece 2 of 2"):
+            halo.wait_piece(2)
+        halo.end()
+        comm.barrier()
+        if transport_name == "ipc":  # ranks that disagree on K: an error on the ranks that pull from the odd one out
+            halo.set_pieces(3 if rank == 0 else 2)
+            try:
+                halo.begin(torch.zeros(n_own, 8, device="cuda"), 8)
+                halo.end()
+                failed = False
+            except capi.GaibError:
+                failed = True
+            assert failed or rank == 0, "a peer cut the exchange differently and nobody noticed"
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def _pieces_layer_worker(rank, world, idfile, q, arch, mode, K, transport_name):
+    """a GCN / SAGE layer on a vertex-range partition whose exchanges travel in K slices: the library cuts the halo-column half
+    into K piece graphs and aggregates them as the slices land.  Against (a) the oracle's run on the GLOBAL graph and (b) the
+    UNPIPED exchange -- the same partition with a plan of one piece and the halo graph's rows in piece-major order (the order
+    the pieces add a row's terms in; with one peer the column order itself): bit for bit on rows below the heavy threshold"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
+    os.environ["GAIB_PART_MODE"] = mode
+    os.environ["GAIB_HALO_PIECES"] = str(K)
+    try:
+        from graphaibench_amd import capi, layers as L
+        from oracle import binding as orc
+        from util import LONG_SUM_FLOOR, assert_close, random_graph, rel_err
+
+        transport = _transport(transport_name, capi)
+        ctx = L.init(0)
+        comm = capi.Comm(ctx, rank, world, _id_via_file(idfile, rank, transport, capi), transport)
+        L.set_comm(comm)
+        rp, ci = random_graph(3000, 12, seed=19, power_law=True, hub_deg=700)
+        g = orc.Graph(rp, ci)
+        if arch == "gcn":
+            g = g.add_selfloop()
+        n, D = g.nv, 128
+        x = np.random.default_rng(5).standard_normal((n, D)).astype(np.float32)
+        gin = np.random.default_rng(6).standard_normal((n, D)).astype(np.float32)
+        lo_ = (orc.GCNLayer if arch == "gcn" else orc.SAGELayer)(1, g, D, D, True)
+        want = lo_.forward(x)
+        want_go = lo_.backward(gin.copy())
+        part = L.HostPartition(g.rowptr, g.colidx, rank, world)
+        lo, hi = part.lo, part.hi
+
+        def run(lg, pieces):
+            used, _, _ = lg.partition_mode(D)
+            assert L.LGraph.PART_NAMES[used] == mode
+            assert lg.halo_pieces() == pieces, (lg.halo_pieces(), pieces)
+            layer = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, hi - lo, D, D, lg, True)
+            layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
+            out = torch.full((hi - lo, D), float("nan"), device="cuda")
+            layer.forward(out)
+            L.sync()
+            fwd = out.cpu().numpy().copy()
+            out.copy_(torch.from_numpy(want[lo:hi]).cuda())  # identical relu masks
+            layer.write(L.GRAD_IN, torch.from_numpy(gin[lo:hi]).cuda())
+            grad_out = torch.full((hi - lo, D), float("nan"), device="cuda")
+            layer.backward(out, grad_out)
+            L.sync()
+            go = grad_out.cpu().numpy().copy()
+            layer.update_weight(L.adam(0.01))  # (sums the gradient over the ranks first)
+            wg = layer.tensor(L.W_NEIGH_GRAD, (D, D)).cpu().numpy().copy()
+            comm.barrier()
+            layer.close()
+            return fwd, go, wg
+
+        lg = part.make_graph(comm)  # (GAIB_HALO_PIECES: the plan travels in K slices)
+        fwd, go, wg = run(lg, K)
+        assert_close(fwd, want[lo:hi], "forward", floor=LONG_SUM_FLOOR)
+        assert_close(go, want_go[lo:hi], "grad_out", floor=LONG_SUM_FLOOR)
+        assert_close(wg, lo_.W_grad if arch == "gcn" else lo_.W_neigh_grad, "W_grad", floor=LONG_SUM_FLOOR)
+        lg.close()
+        # (b) the unpiped exchange over the piece-major halo graph
+        n_own, nh = hi - lo, len(part.halo_gids)
+        recv_off = np.concatenate([[0], np.cumsum(part.recv_counts)])
+        piece = np.zeros(max(nh, 1), np.int64)
+        for q_ in range(world):
+            for k, (a, b) in enumerate(_slices(int(part.recv_counts[q_]), K)):
+                piece[recv_off[q_] + a:recv_off[q_] + b] = k
+        cih = part.colidx_halo.astype(np.int64)
+        rows = np.repeat(np.arange(n_own), np.diff(part.rowptr_halo))
+        order = np.lexsort((cih, piece[cih], rows))
+        if world == 2:
+            assert np.array_equal(order, np.arange(len(cih)))  # one peer: piece-major is the column order
+        def norms(deg):
+            t = np.sqrt(deg.astype(np.float32))
+            vd = np.where(t == 0, 0.0, 1.0 / np.maximum(t, 1e-30).astype(np.float64)).astype(np.float32)
+            inv = (1.0 / deg.astype(np.float32).astype(np.float64)).astype(np.float32)
+            return torch.from_numpy(vd).cuda(), torch.from_numpy(inv).cuda()
+        vd, inv = norms(part.degree)
+        vd_h, inv_h = norms(part.halo_degree if nh else np.ones(1, np.int64))
+        g_own = ctx.graph(part.rowptr_own, part.colidx_own.view(np.int32))
+        g_own.set_vertex_norm(vd, vd, inv, row_inv_deg=inv)
+        g_halo = ctx.graph(part.rowptr_halo, cih[order].astype(np.int32), ncols=max(nh, 1))
+        g_halo.set_vertex_norm(vd, vd_h, inv_h, row_inv_deg=inv)
+        plan = comm.halo(part.send_counts, part.send_idx, part.recv_counts)  # one piece
+        lg2 = L.LGraph.adopt(g_own)
+        lg2.set_halo_plan(g_halo, plan)
+        fwd2, go2, wg2 = run(lg2, 1)
+        light = (np.diff(part.rowptr_own) <= 1024) & (np.diff(part.rowptr_halo) <= 1024)
+        assert light.sum() >= n_own - 2
+        for a, b, what in ((fwd, fwd2, "forward"), (go, go2, "grad_out")):
+            assert np.isfinite(a).all() and np.isfinite(b).all()
+            assert np.array_equal(a[light].view(np.uint32), b[light].view(np.uint32)), f"{what}: piped != unpiped"
+            assert rel_err(a, b) < 1e-5
+        assert rel_err(wg, wg2) < 1e-5
+        comm.barrier()
+        lg2.close()
+        plan.close()
+        g_halo.close()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("transport_name,world,chunk_bytes", [("ipc", 2, 0), ("ipc", 3, 0), ("ipc", 3, 30000), ("fake-rccl", 2, 0),
+                                                             ("fake-rccl", 3, 0)])
+def test_halo_exchange_in_time_slices(tmp_path, transport_name, world, chunk_bytes):
+    res = _spawn(world, _pieces_raw_worker, (str(tmp_path / "id"), transport_name, chunk_bytes))
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("arch,mode,K,world,transport_name", [
+    ("gcn", "split", 4, 2, "ipc"), ("gcn", "split", 2, 3, "ipc"), ("sage", "split", 3, 3, "ipc"), ("gcn", "classes", 4, 2, "ipc"),
+    ("gcn", "classes", 2, 3, "ipc"), ("gcn", "split", 4, 2, "fake-rccl"), ("gcn", "split", 3, 3, "fake-rccl"),
+    ("sage", "classes", 2, 3, "fake-rccl")])
+def test_layers_consume_the_halo_piece_by_piece(tmp_path, arch, mode, K, world, transport_name):
+    res = _spawn(world, _pieces_layer_worker, (str(tmp_path / "id"), arch, mode, K, transport_name))
+    assert all(r[1] == "ok" for r in res), res
+
+
 def _fewer_vertices_than_ranks(rank, world, idfile, q, transport_name):
     """ranks WITHOUT rows (2 vertices on 3 ranks, 1 vertex on 3 ranks) take part in every exchange, reverse exchange and
     all-reduce with empty buffers, take the SAME path (one sweep / staged) as the ranks with rows -- the choice follows
