@@ -712,6 +712,8 @@ class BenchCase:
                     cut_fraction_measured=float(e[3]) / max(float(e[0]), 1.0),
                     owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
                     halo_send_stats=send_stats,
+                    # time slices the exchanges of the timed steps travelled in / the halo-column half was consumed in
+                    halo_pieces=dict(plan=dg.ex.halo.pieces, consumed=dg.lgraph.halo_pieces(D)) if isinstance(dg.ex, AbiHaloExchanger) else None,
                     avg_ms=avg_ms, launches=n_dom, parity=None,
                     # rank 0's kernels per step: the owned-column pass, the halo-column half (fused with the dense product),
                     # heavy rows, the weight gradient, the pack of the rows on the send lists
@@ -742,6 +744,41 @@ class BenchCase:
         finally:
             ctx.set_option("comm_reserve_cus", raw)
         out["in_effect_for_the_timed_steps"] = ctx.get_option("comm_reserve_cus")
+        return out
+
+    def halo_pipeline_ab(self, pieces=(1, 2, 4, 8), steps: int = 6) -> dict:
+        """the step with the exchange travelling in 1 / 2 / 4 / 8 time slices (gaib_halo_set_pieces on the live plan, the same
+        on every rank): one slice = the whole exchange awaited before the halo-column half, K slices = that half aggregated
+        piece by piece as they land.  Per K: ms per step (max over ranks) and the outputs' distance from
+        the one-slice run's (inf norm over this rank's rows, max over ranks: the same terms added piece-major -- 0 on rows
+        below the heavy threshold where every rank has ONE peer).  Collective; the plan returns to what it was."""
+        L, plan = self.L, getattr(self.dg.ex, "halo", None)
+        out = {"mode": L.LGraph.PART_NAMES[self.mode_used], "steps_each": steps, "ms_per_step": {}, "inf_vs_one_slice": {},
+               "slices_consumed": {}}
+        if plan is None:
+            return {"skipped": "torch.distributed carries the rows: no plan to cut into slices"}
+        if self.mode_used not in (L.LGraph.PART_SPLIT, L.LGraph.PART_CLASSES):
+            return {"skipped": f"mode {out['mode']}: no halo-column half to consume piece by piece", "mode": out["mode"]}
+        k0 = plan.pieces
+        ref = None
+        try:
+            for k in pieces:
+                plan.set_pieces(k)
+                self.dg.lgraph.set_halo_consumption(k)  # (forced: k slices on the wire, consumed in k pieces)
+                el = self.time_steps(steps, 2)  # (the first step after a change cuts the piece graphs)
+                out["ms_per_step"][str(k)] = self.max_over_ranks(el)[0] / steps * 1e3
+                out["slices_consumed"][str(k)] = self.dg.lgraph.halo_pieces(self.D)
+                cur = (self.feat_out.clone(), self.grad_out.clone())
+                if ref is None:
+                    ref = cur
+                else:
+                    d = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(cur, ref))
+                    out["inf_vs_one_slice"][str(k)] = self.max_over_ranks(d)[0]
+        finally:
+            plan.set_pieces(k0)
+            self.dg.lgraph.set_halo_consumption(-1)  # back to the rule
+        # what the timed steps of the record ran with: k0 slices on the wire, consumed in as many pieces as this rank's rule chose
+        out["in_effect_for_the_timed_steps"] = {"plan": k0, "consumed_rank0": self.dg.lgraph.halo_pieces(self.D)}
         return out
 
     def transport_ab(self, transports) -> dict:
@@ -893,7 +930,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
     extra = clustered = config5 = cpu_rec = parity_scaled = None
     other = None          # the sub-record of the scaling mode that is not the headline
     strong_extra = {}     # one-rank timing of the same graph, speedup (strong case)
-    ab = {"cu_reserve_ab": None, "transport_ab": None}
+    ab = {"cu_reserve_ab": None, "transport_ab": None, "halo_pipeline_ab": None}
     state = {"main": None, "headline_s": 0.0}
 
     def sub_record(r, **more):
@@ -901,6 +938,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 "halo_bytes_per_step_total": r["halo_bytes_per_step_total"], "halo_exchange_standalone_ms": r["exch_ms"],
                 "halo_pack_ms": r["pack_ms"], "owned_edge_spmm_ms_per_step": r["owned_edge_spmm_ms_per_step"],
                 "cut_fraction_measured": r["cut_fraction_measured"], "halo_send_stats_rank0": r["halo_send_stats"],
+                "halo_pieces_rank0": r["halo_pieces"],
                 "breakdown_ms_per_step_rank0": r["breakdown"], "partition_mode_rank0": r["partition_mode"], **more}
 
     strong_workload = (f"the single-GPU bench's ogbn-products-shaped graph (seed 42, random vertex order) partitioned into "
@@ -964,6 +1002,31 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 ab["cu_reserve_ab"]["ranks_share_device"] = True
         if hold is not None and rank == 0:
             hold(assemble())
+
+    def halo_pipeline_leg(case, res):
+        """(a'): the exchange in 1 / 2 / 4 / 8 time slices on the LIVE headline case (round 6): whether consuming the halo-column
+        half piece by piece hides the wire, measured where there is a wire"""
+        if not ab_on:
+            return
+        step_s = max(res["ms_per_step"] * 1e-3, 1e-3)
+        n_steps = max(3, min(8, int(4.0 / step_s)))
+        need = min(30.0, 4 * (n_steps + 2) * step_s * 1.5 + 4)
+        if share and not ab_force:
+            ab["halo_pipeline_ab"] = {"skipped": "ranks share a device: no wire to hide, the slices' kernels only take turns"}
+        elif comm is None:
+            ab["halo_pipeline_ab"] = {"skipped": "torch.distributed carries the rows: no plan to cut into slices"}
+        elif not budget.agree(need):
+            ab["halo_pipeline_ab"] = budget.skipped(need)
+        else:
+            ab["halo_pipeline_ab"] = case.halo_pipeline_ab(steps=n_steps)
+            if share:
+                ab["halo_pipeline_ab"]["ranks_share_device"] = True
+        if hold is not None and rank == 0:
+            hold(assemble())
+
+    def headline_legs(case, res):
+        halo_pipeline_leg(case, res)
+        cu_reserve_leg(case, res)
 
     def transport_leg():
         """(c): the strong case's exchange plan timed on its own over RCCL and over the peer-to-peer pull.  The LAST leg of the
@@ -1100,6 +1163,8 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
                 "weak_products_range": weak_rec,
                 # the run's own constants, measured on the live headline case
                 "cu_reserve_ab": ab["cu_reserve_ab"], "transport_ab": ab["transport_ab"],
+                # the exchange in 1 / 2 / 4 / 8 time slices, the halo-column half consumed piece by piece (round 6)
+                "halo_pipeline_ab": ab["halo_pipeline_ab"], "halo_pieces_rank0": main["halo_pieces"],
                 # the weak case's cut with the cut edges on a boundary band (what a METIS / breadth-first partition looks like)
                 "clustered_boundary": clustered,
                 # the other end of the weak case's partition-quality axis, same invocation
@@ -1150,7 +1215,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
 
     t_case = time.time()
     if strong:
-        main = run_strong(on_headline, strong_check_budgeted if strong_check is not None else None, extras=cu_reserve_leg)
+        main = run_strong(on_headline, strong_check_budgeted if strong_check is not None else None, extras=headline_legs)
         # the comparison's run of the oracle on the whole bench graph IS the N = 1 workload's CPU baseline (rank 0 has it; every
         # rank must know whether it exists: the bounded-sample leg below is collective)
         if rank == 0 and isinstance(main.get("parity"), dict) and main["parity"].get("cpu_baseline"):
@@ -1162,7 +1227,7 @@ def bench_gcn_layer(ctx, args, rank: int, world: int, D: int, log, make_check=No
         if have[0] and rank != 0:
             cpu_rec = {"on": "rank 0"}
     else:
-        main = run_weak(on_headline, mk(cut), extras=cu_reserve_leg)
+        main = run_weak(on_headline, mk(cut), extras=headline_legs)
         torch.cuda.empty_cache()
     state["main"] = main
     headline_s = state["headline_s"]

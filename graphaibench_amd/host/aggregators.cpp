@@ -20,7 +20,7 @@ static gaib_graph* dev(Graph& g) {
 // (the pass that carries the activation / the dense product).  Same terms per row, added piece by piece.  Ends the exchange.
 template <class Plain, class Last>
 static void halo_half(Graph& g, gaib_graph* whole, int len, Plain plain, Last last) {
-  const int K = g.halo_pieces();
+  const int K = g.halo_pieces(len);
   if (K <= 1) {
     last(whole, g.halo_end(len));
     return;

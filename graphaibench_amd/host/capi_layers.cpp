@@ -231,7 +231,8 @@ void gaibl_graph_set_halo_pieces(void* graph, int n_pieces, int n_ranges, const 
                                  const int* piece, gaibl_halo_wait_piece_fn wait_piece) {
   static_cast<Graph*>(graph)->set_halo_pieces(n_pieces, n_ranges, begin, end, piece, wait_piece);
 }
-int gaibl_graph_halo_pieces(void* graph) { return static_cast<Graph*>(graph)->halo_pieces(); }
+int gaibl_graph_halo_pieces(void* graph, int len) { return static_cast<Graph*>(graph)->halo_pieces(len); }
+void gaibl_graph_set_halo_consumption(void* graph, int pieces) { static_cast<Graph*>(graph)->set_halo_consumption(pieces); }
 int gaibl_graph_partition_mode(void* graph, int len, int64_t* n_boundary, int64_t* boundary_edges) {
   Graph* g = static_cast<Graph*>(graph);
   const int mode = g->partition_mode(len);

@@ -25,7 +25,8 @@ const float* LearningGraph::halo_end(int len) {
   return table;
 }
 
-const float* LearningGraph::halo_wait_piece(int k) {
+const float* LearningGraph::halo_wait_piece(int j) {
+  const int k = (j + 1) * (pieces_slices_ / pieces_built_) - 1;  // the last slice of piece j
   if (!halo_plan_) return halo_wait_piece_(halo_user_, k);
   const float* table = NULL;
   GAIB_OR_DIE(gaib_halo_exchange_wait_piece(halo_plan_, k, &table));
@@ -37,18 +38,71 @@ void LearningGraph::drop_pieces() {
     if (p) gaib_graph_destroy(p);
     p = NULL;
   }
-  pieces_built_ = 0;
+  pieces_built_ = pieces_slices_ = 0;
 }
 
-int LearningGraph::halo_pieces() {
-  const int K = halo_plan_ ? gaib_halo_pieces(halo_plan_) : (halo_wait_piece_ ? cb_pieces_ : 1);
+// How many pieces this rank consumes an exchange of K slices in, for rows of `len` columns: the K' | K with the shortest
+// modelled aggregation.  The owned-column work runs first; piece j can start once slice (j + 1) K / K' - 1 has landed, at
+// (j + 1) / K' of the exchange (priced like partition_mode prices it: the most rows one peer pair moves, at GAIB_LINK_GBS);
+// the halo-column half moves its gathers plus -- once per piece -- the rows' partial sums, at the rates the two forms reach
+// (one fused pass 7.7 TB/s, accumulate passes over row segments 6.0 TB/s: profiles/r06/shard/strong_world*_slices_*.jsonl).
+int LearningGraph::consumption_rule(int K, int len) {
+  gaib_graph* half = part_mode_ == PART_SPLIT ? halo_dev_ : cls_bhalo_;
+  const double row_bytes = 4.0 * len;
+  const double link_gbs = getenv("GAIB_LINK_GBS") ? atof(getenv("GAIB_LINK_GBS")) : 100.0;
+  int64_t link_rows = link_rows_;
+  if (link_rows < 0 && halo_plan_) link_rows = gaib_halo_link_rows(halo_plan_);
+  if (link_rows < 0) link_rows = gaib_graph_nc(half) / 7 + 1;
+  const double t_wire = link_rows * row_bytes / (link_gbs * 1e9);
+  const double t_own = gaib_graph_ne(dev_) * (row_bytes + 8) / 7.5e12;  // (classes: interior + boundary rows' owned columns = all of dev_)
+  const double b_halo = gaib_graph_ne(half) * (row_bytes + 8), b_rows = 2.0 * gaib_graph_nv(half) * row_bytes;
+  int best = 1;
+  double best_t = 0.0;
+  for (int kc = 1; kc <= K; kc++) {
+    if (K % kc) continue;
+    const double t_piece = (b_halo + kc * b_rows) / (kc > 1 ? 6.0e12 : 7.7e12) / kc;
+    double t = t_own;
+    for (int j = 0; j < kc; j++) {
+      const double arrive = t_wire * (j + 1) / kc;
+      t = (t > arrive ? t : arrive) + t_piece;
+    }
+    if (kc == 1 || t < best_t * 0.98) {  // (a further piece must buy 2 %: the model is not better than that)
+      best = kc;
+      best_t = t;
+    }
+  }
+  if (getenv("GAIB_PART_VERBOSE"))
+    fprintf(stderr, "[gaib] halo consumption: %d piece(s) of %d slice(s) (exchange %.2f ms per link, owned-column work %.2f ms, "
+            "halo-column half %.2f ms in one pass)\n", best, K, t_wire * 1e3, t_own * 1e3, (b_halo + b_rows) / 7.7e12 * 1e3);
+  return best;
+}
+
+int LearningGraph::halo_pieces(int len) {
+  const int K = halo_slices();
   if (K <= 1 || part_mode_ < 0) return 1;
   gaib_graph* half = part_mode_ == PART_SPLIT ? halo_dev_ : (part_mode_ == PART_CLASSES ? cls_bhalo_ : NULL);
   if (!half || gaib_graph_ne(half) == 0) return 1;  // (the one-pass forms wait for the whole exchange)
-  if (pieces_built_ == K) return K;
+  int want = pieces_want_;
+  if (want < 0) {
+    const char* e = getenv("GAIB_HALO_CONSUME");
+    if (e && *e) want = atoi(e);
+  }
+  if (want < 0) {
+    if (pieces_rule_k_ != K || pieces_rule_len_ != len) {
+      pieces_rule_ = consumption_rule(K, len);
+      pieces_rule_k_ = K;
+      pieces_rule_len_ = len;
+    }
+    want = pieces_rule_;
+  }
+  if (want > K) want = K;
+  while (want > 1 && K % want) want--;  // K' | K
+  if (want <= 1) return 1;
+  if (pieces_built_ == want && pieces_slices_ == K) return want;
   drop_pieces();
   std::vector<int64_t> rb, re;
   std::vector<int> rp;
+  const int m = K / want;  // slices per piece
   if (halo_plan_) {
     int64_t b[64], e[64];
     for (int k = 0; k < K; k++) {
@@ -57,17 +111,18 @@ int LearningGraph::halo_pieces() {
       for (int j = 0; j < n; j++) {
         rb.push_back(b[j]);
         re.push_back(e[j]);
-        rp.push_back(k);
+        rp.push_back(k / m);
       }
     }
   } else {
     rb = cb_range_begin_;
     re = cb_range_end_;
-    rp = cb_range_piece_;
+    for (int s : cb_range_piece_) rp.push_back(s / m);
   }
-  GAIB_OR_DIE(gaib_graph_split_pieces(gpu_context::get(), half, K, (int)rb.size(), rb.data(), re.data(), rp.data(), pieces_));
-  pieces_built_ = K;
-  return K;
+  GAIB_OR_DIE(gaib_graph_split_pieces(gpu_context::get(), half, want, (int)rb.size(), rb.data(), re.data(), rp.data(), pieces_));
+  pieces_built_ = want;
+  pieces_slices_ = K;
+  return want;
 }
 
 // The mode of a partitioned graph's aggregations.  GAIB_PART_MODE = split | classes | onepass | onepass_all | auto (default), or
@@ -128,16 +183,34 @@ int LearningGraph::partition_mode(int len) {
     // the split's extra cost: the boundary rows' partial sums written and read again (6 TB/s), and the halo-column half
     // at 5.2 TB/s of its 1 + 12.6 M edges x 520 B instead of the gather rate
     const int64_t split_rows = few_interior ? (int64_t)size() : n_boundary_;
-    const double split_cost = 2.0 * split_rows * row_bytes / 6.0e12 + ne_bhalo * (row_bytes + 8) * (1.0 / 5.2e12 - 1.0 / gather_rate);
-    const bool onepass = exposed_onepass <= split_cost;
+    // round 6: an exchange that travels in K slices (gaib_halo_set_pieces) costs the split one more read + write of the partial
+    // sums per further piece -- and leaves it exposed only where the compute stream reaches a slice before it has landed:
+    // slice k lands at (k + 1) / K of the exchange, the owned-column work runs first, then the pieces of the halo-column half
+    const int K = halo_slices();
+    const double rmw = 2.0 * split_rows * row_bytes / 6.0e12;
+    const double t_halo_half = ne_bhalo * (row_bytes + 8) / 5.2e12;
+    const double split_cost = rmw * (K > 1 ? K : 1) + ne_bhalo * (row_bytes + 8) * (1.0 / 5.2e12 - 1.0 / gather_rate);
+    double exposed_split = 0.0;
+    {
+      double t = gaib_graph_ne(dev_) * (row_bytes + 8) / gather_rate;  // owned-column edges of all rows: before the first wait
+      for (int k = 0; k < (K > 1 ? K : 1); k++) {
+        const double arrive = t_exchange * (k + 1) / (K > 1 ? K : 1);
+        if (arrive > t) {
+          exposed_split += arrive - t;
+          t = arrive;
+        }
+        t += t_halo_half / (K > 1 ? K : 1) + (k > 0 ? rmw : 0.0);
+      }
+    }
+    const bool onepass = exposed_onepass <= split_cost + exposed_split;
     mode = onepass ? PART_ONEPASS : (few_interior ? PART_SPLIT : PART_CLASSES);
     all_boundary = onepass && few_interior;
     if (getenv("GAIB_PART_VERBOSE"))
       fprintf(stderr, "[gaib] partition mode %s%s: %lld of %lld rows on the boundary (%.1f %% of the edges in interior rows), "
-              "exchange %.2f ms per link, interior work %.2f ms, split cost %.2f ms\n",
+              "exchange %.2f ms per link in %d slice(s), interior work %.2f ms, split cost %.2f ms + %.2f ms exposed\n",
               mode == PART_ONEPASS ? "onepass" : (mode == PART_CLASSES ? "classes" : "split"), all_boundary ? " (all rows)" : "",
-              (long long)n_boundary_, (long long)size(), 100.0 * ne_int / (ne_all > 0 ? ne_all : 1), t_exchange * 1e3,
-              t_interior * 1e3, split_cost * 1e3);
+              (long long)n_boundary_, (long long)size(), 100.0 * ne_int / (ne_all > 0 ? ne_all : 1), t_exchange * 1e3, K,
+              t_interior * 1e3, split_cost * 1e3, exposed_split * 1e3);
   }
   if (mode == PART_SPLIT) {
     gaib_graph_destroy(gi);

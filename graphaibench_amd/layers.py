@@ -52,7 +52,8 @@ SIGNATURES = {
     "gaibl_graph_set_partition_mode": (None, [_vp, _i]),
     "gaibl_graph_set_halo_link_rows": (None, [_vp, C.c_int64]),
     "gaibl_graph_set_halo_pieces": (None, [_vp, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_i), _vp]),
-    "gaibl_graph_halo_pieces": (_i, [_vp]),
+    "gaibl_graph_halo_pieces": (_i, [_vp, _i]),
+    "gaibl_graph_set_halo_consumption": (None, [_vp, _i]),
     "gaibl_graph_partition_mode": (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gaibl_adam_create": (_vp, [_f]),
     "gaibl_adam_free": (None, [_vp]),
@@ -182,9 +183,14 @@ class LGraph:
         pc = (C.c_int * max(nr, 1))(*[int(r[2]) for r in ranges])
         load().gaibl_graph_set_halo_pieces(self.h, int(n_pieces), nr, b, e, pc, C.cast(self._cb_wait, C.c_void_p))
 
-    def halo_pieces(self) -> int:
-        """slices the halo-column half is consumed in right now (1 = whole; after partition_mode)"""
-        return int(load().gaibl_graph_halo_pieces(self.h))
+    def set_halo_consumption(self, pieces: int):
+        """consume the exchange's K slices in `pieces` | K pieces (LearningGraph::set_halo_consumption); -1 = by the rule"""
+        load().gaibl_graph_set_halo_consumption(self.h, int(pieces))
+
+    def halo_pieces(self, length: int) -> int:
+        """pieces the halo-column half of an aggregation of `length` columns is consumed in right now (1 = whole; after
+        partition_mode)"""
+        return int(load().gaibl_graph_halo_pieces(self.h, int(length)))
 
     def set_halo_plan(self, halo_graph: capi.Graph, plan: "capi.Halo"):
         """the exchange runs behind the C ABI (gaib_halo_exchange_begin/end inside the C++ aggregators)"""

@@ -93,15 +93,17 @@ void gaibl_graph_set_partition_mode(void* graph, int mode);
 void gaibl_graph_set_halo_link_rows(void* graph, int64_t rows); /* callback transports: rows one peer pair moves per exchange */
 int gaibl_graph_partition_mode(void* graph, int len, int64_t* n_boundary, int64_t* boundary_edges);
 
-/* the halo-column half in pieces (LearningGraph::set_halo_pieces / halo_pieces, round 6).  Plans bring their slices
- * themselves (gaib_halo_set_pieces); a callback transport names them here: range j = [begin[j], end[j]) of the halo table
- * arrives in slice piece[j], wait_piece(user, k) returns the table once slice k is there (stream-ordered; `user` is
- * gaibl_graph_set_halo's).  gaibl_graph_halo_pieces: the slices the graph's halo-column half is consumed in right now
- * (1 = whole; decided after gaibl_graph_partition_mode). */
+/* the halo-column half in pieces (LearningGraph::set_halo_pieces / halo_pieces, round 6).  A plan puts K slices on the wire
+ * (gaib_halo_set_pieces); a callback transport names its slices here: range j = [begin[j], end[j]) of the halo table arrives in
+ * slice piece[j], wait_piece(user, k) returns the table once slice k is there (stream-ordered; `user` is gaibl_graph_set_halo's).
+ * A rank consumes the K slices in K' | K pieces: gaibl_graph_set_halo_consumption(K') forces it (GAIB_HALO_CONSUME too), -1 =
+ * by the library's rule.  gaibl_graph_halo_pieces: K' for aggregations of `len` columns right now (1 = the whole half after the
+ * exchange; decided after gaibl_graph_partition_mode). */
 typedef const float* (*gaibl_halo_wait_piece_fn)(void* user, int piece);
 void gaibl_graph_set_halo_pieces(void* graph, int n_pieces, int n_ranges, const int64_t* begin, const int64_t* end,
                                  const int* piece, gaibl_halo_wait_piece_fn wait_piece);
-int gaibl_graph_halo_pieces(void* graph);
+void gaibl_graph_set_halo_consumption(void* graph, int pieces);
+int gaibl_graph_halo_pieces(void* graph, int len);
 
 void* gaibl_adam_create(float lr);
 void gaibl_adam_free(void* opt);

@@ -49,19 +49,28 @@ class LearningGraph {
   int part_mode_;         // PART_*, -1 = not decided yet
   int part_mode_wanted_;  // set_partition_mode / GAIB_PART_MODE; -1 = by the rule
   int64_t n_boundary_, boundary_edges_, link_rows_;
-  // Round 6: the exchange in time slices (gaib_halo_set_pieces).  Where the plan cuts an exchange into K > 1 pieces and the
-  // mode keeps a halo-column half (PART_SPLIT: halo_dev_, PART_CLASSES: cls_bhalo_), that half is cut into K piece graphs
-  // (gaib_graph_split_pieces over the plan's column ranges) and aggregated piece by piece in accumulate mode as the slices
-  // land (host/aggregators.cpp halo_half): the wire hides under the halo-column work too, not only under the owned-column
-  // pass.  Built lazily for the plan's current K; a plan set back to 1 piece takes the uncut half again (bench A/B).
+  // Round 6: the exchange in time slices (gaib_halo_set_pieces).  The plan puts K slices on the wire (the same K on every
+  // rank); each rank CONSUMES them in K' pieces of K / K' consecutive slices, K' | K, its own choice: where the mode keeps a
+  // halo-column half (PART_SPLIT: halo_dev_, PART_CLASSES: cls_bhalo_) that half is cut into K' piece graphs
+  // (gaib_graph_split_pieces over the plan's column ranges) and aggregated piece by piece in accumulate mode as the slices land
+  // (host/aggregators.cpp halo_half), so the wire hides under the halo-column work too, not only under the owned-column pass.
+  // Every further piece costs one more read + write of the rows' partial sums and shorter row segments per pass (measured:
+  // + 6 % of a step at K' = 2, + 25 % at 4, profiles/r06/shard/), so K' comes from a rule that prices both (halo_pieces):
+  // a rank whose owned-column work already covers the exchange keeps K' = 1 and pays nothing.
   gaib_graph* pieces_[GAIB_GRAPH_MAX_PIECES];
-  int pieces_built_;  // K the piece graphs were cut for (0 = none)
-  // callback transports (set_halo) bring the piece structure themselves: set_halo_pieces
+  int pieces_built_;   // K' the piece graphs were cut for (0 = none) ...
+  int pieces_slices_;  // ... out of this many slices on the wire
+  int pieces_want_;    // set_halo_consumption / GAIB_HALO_CONSUME; -1 = by the rule
+  int pieces_rule_;    // what the rule chose (cached with the K and row length it chose for)
+  int pieces_rule_k_, pieces_rule_len_;
+  // callback transports (set_halo) bring the slice structure themselves: set_halo_pieces
   int cb_pieces_;
   std::vector<int64_t> cb_range_begin_, cb_range_end_;
   std::vector<int> cb_range_piece_;
   const float* (*halo_wait_piece_)(void* user, int piece);
   void drop_pieces();
+  int halo_slices() const { return halo_plan_ ? gaib_halo_pieces(halo_plan_) : (halo_wait_piece_ ? cb_pieces_ : 1); }
+  int consumption_rule(int K, int len);
 
  public:
   typedef size_t iterator;
@@ -71,7 +80,8 @@ class LearningGraph {
         halo_begin_(NULL), halo_end_(NULL), halo_user_(NULL), halo_plan_(NULL), gat_full_(NULL), gat_t_(NULL),
         gat_tperm_(NULL), gat_n_halo_(0), owns_partition_(false), cls_int_(NULL), cls_bown_(NULL), cls_bhalo_(NULL),
         cls_bfull_(NULL), part_mode_(-1), part_mode_wanted_(-1), n_boundary_(0), boundary_edges_(0), link_rows_(-1),
-        pieces_built_(0), cb_pieces_(1), halo_wait_piece_(NULL) {
+        pieces_built_(0), pieces_slices_(0), pieces_want_(-1), pieces_rule_(0), pieces_rule_k_(0), pieces_rule_len_(0), cb_pieces_(1),
+        halo_wait_piece_(NULL) {
     for (gaib_graph*& p : pieces_) p = NULL;
   }
   LearningGraph() : LearningGraph(true) {}
@@ -160,7 +170,10 @@ class LearningGraph {
     drop_pieces();  // (cut from the former mode's halo-column half)
   }
   // callback transports (set_halo): the most rows one peer pair moves per exchange (the plan form knows: gaib_halo_link_rows)
-  void set_halo_link_rows(int64_t rows) { link_rows_ = rows; }
+  void set_halo_link_rows(int64_t rows) {
+    link_rows_ = rows;
+    pieces_rule_k_ = 0;  // (the consumption rule prices the exchange by it: decide again)
+  }
   // the mode of this graph's aggregations of `len` columns; the first call decides and builds the class graphs
   int partition_mode(int len);
   gaib_graph* class_interior() { return cls_int_; }
@@ -185,11 +198,14 @@ class LearningGraph {
     cb_range_piece_.assign(piece, piece + n_ranges);
     halo_wait_piece_ = wait_piece;
   }
-  // slices the halo-column half is consumed in RIGHT NOW: the plan's (or the callbacks') K where the mode has such a half and
-  // K > 1 -- the piece graphs are (re)built here if need be --, else 1 = the whole half after gaib_halo_exchange_end
-  int halo_pieces();
-  gaib_graph* halo_piece_graph(int k) { return pieces_[k]; }
-  const float* halo_wait_piece(int k);
+  // pieces the halo-column half of an aggregation of `len` columns is consumed in RIGHT NOW: K' | K (the plan's / the callbacks'
+  // slices), forced (set_halo_consumption, GAIB_HALO_CONSUME) or by the rule; 1 = the whole half after gaib_halo_exchange_end
+  // (also wherever the mode has no such half).  The piece graphs are (re)built here if need be.
+  int halo_pieces(int len);
+  void set_halo_consumption(int pieces) { pieces_want_ = pieces; }  // -1: by the rule
+  gaib_graph* halo_piece_graph(int j) { return pieces_[j]; }
+  // the compute stream continues once piece j -- slices j K / K' ... (j + 1) K / K' - 1 -- has landed
+  const float* halo_wait_piece(int j);
   // device pointers, as the reference's ENABLE_GPU accessors return them.  Row pointers are
   // int64 in HBM (the reference's uint32 offsets overflow past 2^32 edges*features).
   const int64_t* row_start_ptr() const { return gaib_graph_rowptr(dev_); }

@@ -32,6 +32,8 @@ sys.path.insert(0, str(ROOT))
 from graphaibench_amd import capi, dist as gd, layers as L, synth  # noqa: E402
 
 WORLD, D = 8, 128
+S_PIECES = [1]  # --pieces
+S_CONSUME = "same"  # --consume
 XGMI_LINK_GBS = 153.0
 
 
@@ -99,11 +101,42 @@ def run(ctx, rank, cut, steps, scale, shape="ogbn-papers100M", boundary="uniform
     g_in = torch.randn(nv, D, device="cuda")
     shard = dict(locals())  # (one dict for all modes: the first mode leaves its output sample in it)
     for mode in modes:
-        run_mode(ctx, mode, shard, steps)
+        for k in (S_PIECES or [1]):
+            run_mode(ctx, mode, shard, steps, pieces=k)
 
 
-def run_mode(ctx, mode, S, steps):
-    """one mode on the shard held in S (run()'s locals)"""
+def piece_ranges(ctx, recv_counts, K):
+    """[(begin, end, piece)] rows of the halo table (grouped by owner rank) that travel in slice k: the library's arithmetic"""
+    import ctypes as C
+
+    out, off = [], 0
+    for rows in recv_counts:
+        for k in range(K):
+            lo, hi = C.c_int64(), C.c_int64()
+            capi._check(ctx.lib.gaib_halo_piece_slice(int(rows), K, k, C.byref(lo), C.byref(hi)), "gaib_halo_piece_slice")
+            if hi.value > lo.value:
+                out.append((off + lo.value, off + hi.value, k))
+        off += int(rows)
+    return out
+
+
+def modelled_stall_ms(marks, wire_ms):
+    """one exchange whose K slices land at (k + 1) / K of wire_ms, against the kernel time between the marks (begin, wait 0,
+    ..., end): the compute stream stalls where it reaches a wait before that slice is there.  marks = ms between consecutive
+    callbacks: [owned-column pass, piece 0, ..., piece K - 2]; the last piece starts behind end()."""
+    K = len(marks)
+    t = stall = 0.0
+    for k in range(K):
+        t += marks[k]          # the work enqueued before wait k (k = K - 1: before end)
+        arrive = wire_ms * (k + 1) / K
+        if arrive > t:
+            stall += arrive - t
+            t = arrive
+    return stall
+
+
+def run_mode(ctx, mode, S, steps, pieces=1):
+    """one mode on the shard held in S (run()'s locals); pieces: time slices of the exchange (gaib_halo_set_pieces)"""
     (rank, cut, scale, shape, boundary, band, nv, n_halo, ne_own, ne_halo, halo_table, send_idx, send_counts, recv_counts, vd, inv,
      pick, setup_s) = (S[k] for k in ("rank", "cut", "scale", "shape", "boundary", "band", "nv", "n_halo", "ne_own", "ne_halo",
                                       "halo_table", "send_idx", "send_counts", "recv_counts", "vd", "inv", "pick", "setup_s"))
@@ -129,19 +162,32 @@ def run_mode(ctx, mode, S, steps):
                                                          length, src_ptr, sendbuf.data_ptr()), "gaib_gather_scatter_rows")
             pack_calls[0] += 1
         if timing[0]:  # what runs between here and end() is what the exchange can hide under
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-            windows.append(ev)
+            windows.append([mark()])
+
+    def mark():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def wait_piece(k):  # slice k has landed (the table is resident: nothing to wait for)
+        if timing[0] and windows:
+            windows[-1].append(mark())
+        return halo_table.data_ptr()
 
     def end(length):  # (and finish here: the table is resident instead)
         if timing[0] and windows:
-            windows[-1][1].record()
+            windows[-1].append(mark())
         return halo_table.data_ptr()
 
     timing, windows = [False], []
 
     lg.set_halo(g_halo, begin, end)
+    if pieces > 1:
+        lg.set_halo_pieces(pieces, piece_ranges(ctx, recv_counts, pieces), wait_piece)
+        if S_CONSUME != "rule":  # the K slices consumed in K pieces (--consume same) or in a given number; rule: the library's choice
+            lg.set_halo_consumption(pieces if S_CONSUME == "same" else int(S_CONSUME))
     mode_used, n_bnd, bnd_edges = lg.partition_mode(D)
+    pieces_used = lg.halo_pieces(D)
     layer = L.Layer(L.GCN, 1, nv, D, D, lg, act=True)
     layer.write(L.FEAT_IN, S["x_in"])
     layer.write(L.GRAD_IN, S["g_in"])
@@ -168,7 +214,8 @@ def run_mode(ctx, mode, S, steps):
     step()
     torch.cuda.synchronize()
     timing[0] = False
-    overlap_ms = [a.elapsed_time(b) for a, b in windows]
+    overlap_ms = [w[0].elapsed_time(w[-1]) for w in windows]
+    marks = [[a.elapsed_time(b) for a, b in zip(w[:-1], w[1:])] for w in windows]  # per exchange: owned pass, piece 0, ...
     exchanges = (pack_calls[0] * steps) // (steps + 2) // steps if send_idx.numel() else 2
     br = {}
     for k in ("spmm_gemm_fused", "spmm_light", "spmm_heavy", "sgemm", "gather_rows", "part_fused", "part_fused_acc", "part_fused_2t",
@@ -202,6 +249,16 @@ def run_mode(ctx, mode, S, steps):
                compute_ms_per_step=ms, pack_ms_per_exchange=pack_ms, breakdown_ms_per_step=br, direct_send=bool(S.get("direct_send")),
                # per exchange: the kernel time between its begin and its end -- what the wire time can hide under
                overlappable_ms_per_exchange=[round(v, 3) for v in overlap_ms],
+               # round 6: the exchange in time slices -- kernel time between the callbacks (owned-column pass, piece 0, ...; the
+               # last piece runs behind end()), and the step with the wire modelled at a link rate: compute + the stalls of a
+               # compute stream that reaches a wait before its slice has landed (slice k lands at (k + 1) / K of the exchange)
+               halo_pieces=pieces_used, halo_slices=pieces, consume=S_CONSUME,
+               link_gbs_of_the_rules=float(__import__("os").environ.get("GAIB_LINK_GBS", "100")),
+               ms_between_waits_per_exchange=[[round(v, 3) for v in m] for m in marks],
+               modelled_ms_per_step={str(g): round(ms + sum(modelled_stall_ms(m, per_link / (g * 1e9) * 1e3) for m in marks), 3)
+                                     for g in (153.0, 100.0, 75.0)},
+               modelled_stall_ms_per_exchange={str(g): [round(modelled_stall_ms(m, per_link / (g * 1e9) * 1e3), 3) for m in marks]
+                                               for g in (153.0, 100.0, 75.0)},
                gedges_per_s_compute_only=2 * (ne_own + ne_halo) / ms / 1e6, setup_s=round(setup_s, 1),
                out_and_grad_inf_vs_first_mode=agree,
                hbm_gb_in_use=torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9)
@@ -229,11 +286,18 @@ def main():
     ap.add_argument("--direct-send", action="store_true",
                     help="no pack: what a rank computes when every peer takes its whole row range straight from the matrix (complete "
                          "halos over the RCCL transport)")
+    ap.add_argument("--pieces", type=int, nargs="+", default=[1],
+                    help="time slices of the exchange (gaib_halo_set_pieces): the halo-column half is aggregated piece by piece; "
+                         "several values = one record each")
+    ap.add_argument("--consume", default="same",
+                    help="pieces the rank consumes the slices in: same (= --pieces), rule (the library's choice at --link-gbs), or a number")
     ap.add_argument("--link-gbs", type=float, default=None, help="GAIB_LINK_GBS for the auto rule (default: the library's 100)")
     ap.add_argument("--opts", default="", help="library options, key=value,... (gaib_set_option), e.g. spmm_flat_ring=1")
     args = ap.parse_args()
-    global WORLD
+    global WORLD, S_PIECES, S_CONSUME
     WORLD = args.world
+    S_PIECES = args.pieces
+    S_CONSUME = args.consume
     if args.link_gbs is not None:
         import os
         os.environ["GAIB_LINK_GBS"] = str(args.link_gbs)

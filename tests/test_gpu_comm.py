@@ -611,7 +611,8 @@ def _pieces_layer_worker(rank, world, idfile, q, arch, mode, K, transport_name):
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["GAIB_COMM_TIMEOUT_S"] = "60"
     os.environ["GAIB_PART_MODE"] = mode
-    os.environ["GAIB_HALO_PIECES"] = str(K)
+    os.environ["GAIB_HALO_PIECES"] = str(K)   # slices on the wire ...
+    os.environ["GAIB_HALO_CONSUME"] = str(K)  # ... consumed one to one (the rule would take one piece on a graph this small)
     try:
         from graphaibench_amd import capi, layers as L
         from oracle import binding as orc
@@ -637,7 +638,7 @@ def _pieces_layer_worker(rank, world, idfile, q, arch, mode, K, transport_name):
         def run(lg, pieces):
             used, _, _ = lg.partition_mode(D)
             assert L.LGraph.PART_NAMES[used] == mode
-            assert lg.halo_pieces() == pieces, (lg.halo_pieces(), pieces)
+            assert lg.halo_pieces(D) == pieces, (lg.halo_pieces(D), pieces)
             layer = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, hi - lo, D, D, lg, True)
             layer.write(L.FEAT_IN, torch.from_numpy(x[lo:hi]).cuda())
             out = torch.full((hi - lo, D), float("nan"), device="cuda")

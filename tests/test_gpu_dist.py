@@ -158,6 +158,8 @@ def _ab_worker(rank, world, port, q):
         case = gd.BenchCase(ctx, rccl, args, rank, world, 128, lambda *a: None, rows, "ab test")
         res = case.measure()
         ab = case.cu_reserve_ab(steps=2)
+        hp = case.halo_pipeline_ab(pieces=(1, 3), steps=2)  # (over the RCCL branch: one group per slice)
+        assert "skipped" in hp or (hp["slices_consumed"] == {"1": 1, "3": 3} and hp["inf_vs_one_slice"]["3"] <= 1e-5), hp
         tb = case.transport_ab({"rccl": rccl, "ipc": ipc, "absent": (None, "not built")})
         after = (ctx.get_option("comm_reserve_cus"), ctx.get_option("comm_reserve_cus_raw"))
         ctx.set_option("comm_reserve_cus", 0)
@@ -370,7 +372,7 @@ def test_bench_plain_two_gpus_default_workload():
     assert pc["ok"] is True and pc["forward"]["elem"] <= 1e-4 and pc["partition_mode_rank0"] in ("classes", "onepass")
     # the run measures its own constants -- on a one-device box each slot says why it did not
     if torch.cuda.device_count() < 2:
-        assert "skipped" in cfg["xgmi_link_probe"] and "skipped" in cfg["cu_reserve_ab"]
+        assert "skipped" in cfg["xgmi_link_probe"] and "skipped" in cfg["cu_reserve_ab"] and "skipped" in cfg["halo_pipeline_ab"]
         assert cfg["transport_ab"]["carried_the_run"] == "ipc" and cfg["transport_ab"]["ipc"]["exchange_standalone_ms"] > 0
         assert "share devices" in cfg["transport_ab"]["rccl"]["skipped"]
         assert cfg["ranks_share_device"] is True and res["roofline"]["ranks_share_device"] is True
@@ -394,7 +396,8 @@ def test_bench_ab_legs_bookkeeping_on_a_shared_device():
 
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--scale", "0.02", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--no-parity"], capture_output=True, text=True, timeout=900,
-                       env=dict(_clean_env(), GAIB_BENCH_AB="force", GAIB_BENCH_CLUSTERED="0", GAIB_BENCH_RANDOM_ORDER="0"))
+                       env=dict(_clean_env(), GAIB_BENCH_AB="force", GAIB_BENCH_CLUSTERED="0", GAIB_BENCH_RANDOM_ORDER="0",
+                                GAIB_PART_MODE="split"))  # (a mode with a halo-column half: what the slices are consumed by)
     assert r.returncode == 0, r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     cfg = res["config"]
@@ -402,6 +405,13 @@ def test_bench_ab_legs_bookkeeping_on_a_shared_device():
     assert sorted(ab["ms_per_step"]) == ["0", "32", "64"] and all(v > 0 for v in ab["ms_per_step"].values())
     assert ab["ranks_share_device"] is True and ab["in_effect_for_the_timed_steps"] == cfg["cu_reserve_for_transport"] == 0
     assert ab["mode"] == cfg["partition_mode_rank0"]["mode"]
+    # round 6: the exchange in 1 / 2 / 4 / 8 time slices on the live headline case; the plan back where it was; the same sums
+    hp = cfg["halo_pipeline_ab"]
+    assert sorted(hp["ms_per_step"], key=int) == ["1", "2", "4", "8"] and all(v > 0 for v in hp["ms_per_step"].values())
+    assert hp["slices_consumed"] == {"1": 1, "2": 2, "4": 4, "8": 8} and hp["ranks_share_device"] is True
+    assert all(v <= 1e-5 for v in hp["inf_vs_one_slice"].values()) and sorted(hp["inf_vs_one_slice"], key=int) == ["2", "4", "8"]
+    assert hp["in_effect_for_the_timed_steps"] == {"plan": 1, "consumed_rank0": 1} and cfg["halo_pieces_rank0"] == {"plan": 1, "consumed": 1}
+    assert hp["mode"] == cfg["partition_mode_rank0"]["mode"]
     tb = cfg["transport_ab"]
     assert tb["ipc"]["exchange_standalone_ms"] > 0 and "skipped" in tb["rccl"] and tb["ranks_share_device"] is True
     assert res["n_gpus"] == 3 and cfg["strong_products"]["value"] == res["value"]

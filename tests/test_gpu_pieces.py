@@ -165,9 +165,10 @@ def _layer_run(lctx, s, g_halo, arch, mode, din, dout, x, gin, want_fwd, tab_fwd
     lg.set_partition_mode({"split": L.LGraph.PART_SPLIT, "classes": L.LGraph.PART_CLASSES}[mode])
     if pieces:
         lg.set_halo_pieces(pieces[0], pieces[1], tr.wait)
+        lg.set_halo_consumption(pieces[0])  # (the rule would take one piece on a graph this small)
     used, _, _ = lg.partition_mode(din)
     assert L.LGraph.PART_NAMES[used] == mode
-    assert lg.halo_pieces() == (pieces[0] if pieces else 1)
+    assert lg.halo_pieces(din) == (pieces[0] if pieces else 1)
     layer = L.Layer(L.GCN if arch == "gcn" else L.SAGE, 1, s.n, din, dout, lg, True)
     layer.write(L.FEAT_IN, dev(x[s.lo:s.hi]))
     out = torch.full((s.n, dout), float("nan"), device="cuda")
@@ -238,4 +239,69 @@ def test_layer_piece_by_piece_equals_the_piece_major_pass(arch, din, dout, mode,
         assert rel_err(a, b) < 1e-5, key
     assert rel_err(piped["W_grad"], whole["W_grad"]) < 1e-5
     g_m.close()
+    g_h.close()
+
+
+def test_consumption_follows_the_rule_and_divides_the_slices():
+    """K slices on the wire are consumed in K' | K pieces: forced, or by the rule -- an exchange priced far above the rank's
+    owned-column work is consumed slice by slice, one that the owned-column work covers in one piece (no further pass over the
+    partial sums); a forced K' that does not divide K falls to the next divisor"""
+    lctx = L.init(0)
+    g_o, s = make_shard(lctx, hub=900)
+    vd = g_o.vertex_data()
+    inv = (1.0 / np.diff(g_o.rowptr).astype(np.float64)).astype(np.float32)
+    nh = len(s.halo)
+    g_own = lctx.graph(s.rp_own, s.ci_own)
+    g_own.set_vertex_norm(dev(vd[s.lo:s.hi]), dev(vd[s.lo:s.hi]), dev(inv[s.lo:s.hi]), row_inv_deg=dev(inv[s.lo:s.hi]))
+    g_h = lctx.graph(s.rp_halo, s.ci_halo, ncols=nh)
+    g_h.set_vertex_norm(dev(vd[s.lo:s.hi]), dev(vd[s.halo]), dev(inv[s.halo]), row_inv_deg=dev(inv[s.lo:s.hi]))
+    lg = L.LGraph.adopt(g_own)
+    tr = ResidentHalo(dev(feat(nh, 128, 3)))
+    lg.set_halo(g_h, tr.begin, tr.end)
+    lg.set_partition_mode(L.LGraph.PART_SPLIT)
+    lg.set_halo_pieces(8, piece_ranges(nh, 3, 8, lctx.lib), tr.wait)
+    lg.partition_mode(128)
+
+    def rule(link_rows, K=8, length=128, link_gbs=100.0):
+        """LearningGraph::consumption_rule, restated: the K' | K with the shortest modelled aggregation (2 % per further piece)"""
+        row_bytes = 4.0 * length
+        t_wire = link_rows * row_bytes / (link_gbs * 1e9)
+        t_own = len(s.ci_own) * (row_bytes + 8) / 7.5e12
+        b_halo, b_rows = len(s.ci_halo) * (row_bytes + 8), 2.0 * s.n * row_bytes
+        best, best_t = 1, None
+        for kc in (k for k in range(1, K + 1) if K % k == 0):
+            t_piece = (b_halo + kc * b_rows) / (6.0e12 if kc > 1 else 7.7e12) / kc
+            t = t_own
+            for j in range(kc):
+                t = max(t, t_wire * (j + 1) / kc) + t_piece
+            if best_t is None or t < best_t * 0.98:
+                best, best_t = kc, t
+        return best
+
+    seen = set()
+    for link_rows in (0, 50, 200, 400, 1000, 5000, 10**9):
+        lg.set_halo_link_rows(link_rows)
+        assert lg.halo_pieces(128) == rule(link_rows), link_rows
+        seen.add(rule(link_rows))
+    # nothing to hide -> one piece; a wire a few times the halo-column half -> slice by slice; hours of wire -> one piece again
+    # (the pieces would shave the last pass off a wait that is a million times longer)
+    assert rule(0) == 1 and rule(10**9) == 1 and 8 in seen, seen
+    for want, got in ((8, 8), (4, 4), (3, 2), (5, 4), (7, 4), (1, 1), (100, 8)):
+        lg.set_halo_consumption(want)
+        assert lg.halo_pieces(128) == got, (want, got)
+    # an aggregation over the pieces of a forced K' = 2 out of 8 slices waits for slices 3 and (behind end) 7
+    x = feat(g_o.nv, 128, 11)
+    tr.table = dev(x[s.halo])
+    lg.set_halo_consumption(2)
+    layer = L.Layer(L.GCN, 1, s.n, 128, 128, lg, True)
+    layer.write(L.FEAT_IN, dev(x[s.lo:s.hi]))
+    out = torch.empty(s.n, 128, device="cuda")
+    tr.calls.clear()
+    layer.forward(out)
+    L.sync()
+    assert tr.calls == ["begin", "wait3", "end"], tr.calls
+    lo_ = orc.GCNLayer(1, g_o, 128, 128, True)
+    assert_close(out.cpu().numpy(), lo_.forward(x)[s.lo:s.hi], "forward", floor=LONG_SUM_FLOOR)
+    layer.close()
+    lg.close()
     g_h.close()
