@@ -657,6 +657,64 @@ def launch_ranks(args, argv, entry=None) -> int:
     return rc
 
 
+# ---- child programs (the trainer CLI of the epoch workloads) ---------------------------------------------------------------
+# main() blocks SIGTERM / SIGINT first thing and a signal mask survives fork + exec: a child started plainly would run with both
+# blocked, and RecordGuard.bail() -- deadline or signal -- leaves through os._exit without a look at it: an orphan on the GPU
+# that ignores SIGTERM, under the next GPU step.  So: every child starts in a session of its own through a
+# two-line wrapper that restores the mask BEFORE it becomes the program (an exec in a fresh interpreter that has touched no GPU),
+# its handle is kept here, and bail() kills and reaps the whole group before it leaves.
+_CHILDREN = []
+_CHILDREN_LOCK = threading.Lock()
+_UNMASK = ("import os, signal, sys; signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM, signal.SIGINT}); "
+           "os.execv(sys.argv[1], sys.argv[1:])")
+
+
+def kill_children(grace_s: float = 0.0) -> int:
+    """SIGTERM (if grace_s > 0), then SIGKILL, to the process group of every child still alive, and reap them -> how many"""
+    import signal
+    import subprocess
+
+    with _CHILDREN_LOCK:
+        alive = [p for p in _CHILDREN if p.poll() is None]
+    for sig, wait_s in ((signal.SIGTERM, grace_s), (signal.SIGKILL, 5.0)):
+        if sig == signal.SIGTERM and grace_s <= 0:
+            continue
+        for p in alive:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        t_end = time.time() + wait_s
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                pass
+    return len(alive)
+
+
+def run_child(cmd, env=None, timeout_s: float = 600.0, unmask=_UNMASK):
+    """cmd as a supervised child (see above) -> (returncode, stdout, stderr).  On timeout the group is killed and
+    subprocess.TimeoutExpired raised."""
+    import subprocess
+
+    p = subprocess.Popen([sys.executable, "-c", unmask, *[str(c) for c in cmd]], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, start_new_session=True)
+    with _CHILDREN_LOCK:
+        _CHILDREN.append(p)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        kill_children()
+        raise
+    finally:
+        with _CHILDREN_LOCK:
+            if p.poll() is not None and p in _CHILDREN:
+                _CHILDREN.remove(p)
+    return p.returncode, out, err
+
+
 class RecordGuard:
     """The N > 1 record cannot be lost: rank 0 HOLDS the record as soon as the headline case is measured (hold), the
     sub-cases that follow only add to it, and whatever ends the run early -- the deadline, SIGTERM from the launcher or the
@@ -666,6 +724,7 @@ class RecordGuard:
 
     def __init__(self, rank: int):
         self.rank, self.lock, self.held, self.done = rank, threading.Lock(), None, False
+        self.leaving = threading.Event()  # set once a bail() owns the exit: a second caller waits for it instead of racing it out
         self.want_parity = False  # the run was asked for a comparison with the oracle: a record cut short must SAY it has none
 
     def hold(self, record: dict) -> None:
@@ -685,10 +744,18 @@ class RecordGuard:
         exit status stays 0 so that whoever collects the line keeps the measured headline -- the marker is what says the run
         did not end the way a passing run does)."""
         with self.lock:
-            if self.done:  # the record is out already: let the process end by itself
+            if self.done:
+                # the record is out already (final), or another thread's bail() is on its way out -- it killed the child program
+                # this thread was waiting for, which is why this thread is here: let IT print and leave, do not outrun it
+                if self.leaving.is_set():
+                    time.sleep(30)
                 return
             self.done = True
+            self.leaving.set()
             held = self.held
+        n_killed = kill_children()  # (a trainer child of an epoch leg: never left behind on the GPU)
+        if n_killed:
+            log(f"[bench r{self.rank}] {reason}: killed {n_killed} child program(s)")
         if self.rank == 0 and held is None:
             # the headline case may just have ended: between its last collective and hold() rank 0 still assembles the record
             # (milliseconds) -- a peer that fails exactly then makes the launcher's SIGTERM arrive first.  Give the main thread
@@ -764,6 +831,13 @@ def main():
                          "configs 2-4 are MODELS -- one training epoch of the 3-layer GraphSAGE (hidden 256, "
                          "scripts/run-sage-products.sh) / 3-layer GCN (hidden 128) on the products shape, of the 2-layer 8-head GAT "
                          "on the reddit shape, through the trainer CLI (a step = one epoch; same JSON schema; one GPU)")
+    ap.add_argument("--hidden", type=int, default=None,
+                    help="epoch-* workloads: the hidden width (default the workload's own; epoch-sage-products: 256 as "
+                         "scripts/run-sage-products.sh passes it, `--hidden 128` = BASELINE config 3's literal \"3-layer D=128\")")
+    ap.add_argument("--other-configs-s", type=float, default=float(os.environ.get("GAIB_BENCH_OTHER_CONFIGS_S", "100")),
+                    help="N = 1 default run: wall-clock budget of the `other_configs` block -- BASELINE configs 2-4 as short legs "
+                         "after the headline record is held (SAGE layer steps at 128 / 256, the 8-head GAT layer, the epoch "
+                         "workloads); 0 = skip")
     ap.add_argument("--no-locality", action="store_true",
                     help="skip the planted-locality leg of the N = 1 record (profiling runs: its launches of the dominant kernel "
                          "on ANOTHER graph would be averaged into the per-kernel statistics)")
@@ -1128,6 +1202,21 @@ def main():
                 if not result["parity"]["ok"]:
                     log("[bench] PARITY FAILED (> 1e-4)")
                     rc = 3
+        # ---- BASELINE configs 2-4 in front of whoever runs the default command: after everything the headline
+        # record needs -- its value, roofline, CPU baseline and parity are complete and held; this block only adds a slot
+        if args.other_configs_s > 0 and os.environ.get("GAIB_BENCH_OTHER_CONFIGS", "1") != "0":
+            layer.close()
+            lg.close()
+            del feat_out, grad_out
+            torch.cuda.empty_cache()
+            # (the block's own budget, and never past the run's deadline: 25 s are left for the last leg to be cut and the record to leave)
+            t_end = min(time.time() + args.other_configs_s, T_START + args.deadline_s - 25.0)
+
+            def upd(o):
+                result["other_configs"] = o
+                guard1.hold(result)
+
+            other_configs(args, torch, ctx, L, synth, sg, t_end, upd)
     except Exception as e:  # noqa: BLE001
         import traceback
 
@@ -1383,8 +1472,154 @@ def bench_gat_reddit(args, torch, ctx, L, synth, guard) -> int:
         if not par["ok"]:
             log("[bench] PARITY FAILED (> 1e-4)")
             rc = 3
+    layer.close()
+    lg.close()
+    del feat_out, grad_out, gin_d
+    torch.cuda.empty_cache()
     guard.final(result)
     return rc
+
+
+# ---- the other BASELINE configs inside the default N = 1 run ------------------------------------------------
+class _Capture:
+    """stands in for the RecordGuard where a leg's record goes into a slot of the default run's record instead of out"""
+    held = None
+
+    def hold(self, r):
+        self.held = r
+
+    final = hold
+
+
+def sage_layer_step(torch, ctx, L, sg, width: int, steps: int, warmup: int) -> dict:
+    """BASELINE config 3's layer: one GraphSAGE hidden layer width -> width forward + backward on the products-shaped graph
+    (A without self loops, net.cpp:96) -- two mean aggregations with the neighbour product riding on them, the self products,
+    the two weight gradients -- with the per-launch work table priced at the chip's roofs (as the epoch records do)"""
+    g = ctx.graph(sg.rowptr, sg.colidx)
+    nv, ne = g.nv, g.ne
+    lg = L.LGraph.adopt(g)
+    layer = L.Layer(L.SAGE, 1, nv, width, width, lg, act=True, lr=0.01)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(43)
+    layer.write(L.FEAT_IN, torch.randn(nv, width, device="cuda", generator=gen))
+    layer.write(L.GRAD_IN, torch.randn(nv, width, device="cuda", generator=gen))
+    fo, go = torch.empty(nv, width, device="cuda"), torch.empty(nv, width, device="cuda")
+
+    def step():
+        layer.forward(fo)
+        layer.backward(fo, go)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    table = ctx.prof_table()
+    ctx.prof_reset()
+    layer.close()
+    lg.close()
+    del fo, go
+    torch.cuda.empty_cache()
+    ms = el / steps * 1e3
+    roof = sum(v["roof_ms"] for v in table.values()) / steps
+    dom = max(table, key=lambda k: table[k]["ms"]) if table else None
+    return {"workload": f"GraphSAGE hidden layer {width} -> {width} fwd+bwd on the ogbn-products-shaped graph (seed 42, no self loops)",
+            "value": 2 * ne * steps / el, "unit": "edges/s", "ms_per_step": ms, "steps": steps, "warmup": warmup, "nv": nv, "ne": ne,
+            "roofline": {"frac": roof / ms, "frac_definition": "sum over the step's launches of max(algorithmic bytes / 8 TB/s, flops / 157.3 TFLOP/s), "
+                         "over the measured step time", "roof_ms_per_step": roof,
+                         "largest": dom, "per_key": {k: {"ms_per_step": v["ms"] / steps, "frac": (v["roof_ms"] / v["ms"]) if v["ms"] > 0 else None}
+                                                     for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])[:6]}}}
+
+
+def _brief_epoch(r: dict) -> dict:
+    """an epoch record cut down to what a slot of other_configs carries (the full one: `bench.py --workload epoch-*`)"""
+    pk = r["roofline"]["per_key"]
+    top = sorted(pk, key=lambda k: -pk[k]["ms_per_epoch"])[:8]
+    return {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_epoch": r["ms_per_step"], "steps": r["steps"],
+            "warmup": r["warmup"], "nv": r["config"]["nv"], "ne": r["config"]["ne"], "hidden": r["config"]["hidden"],
+            "aggregated_edges_per_epoch": r["config"]["aggregated_edges_per_epoch"], "recorded_epochs": bool(r["config"]["recorded_epochs"]),
+            "train_loss_timed_epochs": r["config"]["train_loss_timed_epochs"],
+            "roofline": {"frac": r["roofline"]["frac"], "frac_definition": r["roofline"]["frac_definition"],
+                         "roof_ms_per_epoch": r["roofline"]["roof_ms_per_epoch"], "untimed_ms_per_epoch": r["roofline"]["untimed_ms_per_epoch"],
+                         "frac_note": r["roofline"].get("frac_note"),
+                         "per_key": {k: {"ms_per_epoch": pk[k]["ms_per_epoch"], "frac": pk[k]["frac"],
+                                         **({"frac_of_line_floor": pk[k]["line_floor"]["frac_of_line_floor"]} if "line_floor" in pk[k] else {})}
+                                     for k in top}}}
+
+
+def other_configs(args, torch, ctx, L, synth, sg, t_budget_end: float, on_update) -> dict:
+    """BASELINE configs 2-4 as short legs of the DEFAULT run, after the headline record is held -- so that the driver's own
+    `bench.py --gpus 1` witnesses them (round 5: everything but the headline was builder-run): the SAGE layer step at 128 and
+    256, the 8-head GAT layer on the reddit shape, and the epoch workloads through the trainer CLI (10 timed epochs each; the
+    products dataset written once for the three models on it).  Every leg is budgeted -- it starts only if its estimated time
+    fits what is left of --other-configs-s -- and failure-proof: a slot says {"skipped": ...} or {"error": ...}, the headline
+    `value` and its timed region are long done.  GPU timings only (no CPU baseline, no parity: the per-workload commands have them)."""
+    import argparse
+    import shutil
+    import tempfile
+
+    out = {"budget_s": args.other_configs_s}
+    t_block = time.time()
+
+    def leg(name, need_s, fn):
+        left = t_budget_end - time.time()
+        if left < need_s:
+            out[name] = {"skipped": "budget", "needed_s_estimate": need_s, "left_s": round(left, 1)}
+        else:
+            t0 = time.time()
+            try:
+                out[name] = fn()
+                out[name]["leg_seconds"] = round(time.time() - t0, 1)
+            except Exception as e:  # noqa: BLE001 -- a side leg must not cost the record
+                import traceback
+
+                log(f"[bench] other_configs.{name}: {type(e).__name__}:\n{traceback.format_exc()}")
+                out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+        out["elapsed_s"] = round(time.time() - t_block, 1)
+        on_update(out)
+
+    full = args.scale == 1.0
+    st = 10
+    leg("sage_layer_128", 6 if full else 3, lambda: sage_layer_step(torch, ctx, L, sg, 128, st, 3))
+    leg("sage_layer_256", 8 if full else 3, lambda: sage_layer_step(torch, ctx, L, sg, 256, st, 3))
+
+    def gat_layer():
+        cap = _Capture()
+        a2 = argparse.Namespace(**{**vars(args), "steps": st, "warmup": 3, "sustain_s": 0.0, "no_cpu_baseline": True})
+        bench_gat_reddit(a2, torch, ctx, L, synth, cap)
+        r = cap.held
+        return {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": st,
+                "nv": r["config"]["nv"], "ne": r["config"]["ne_with_selfloops"], "heads": r["config"]["heads"], "roofline": r["roofline"],
+                "breakdown_ms_per_step": r["breakdown_ms_per_step"]}
+
+    leg("gat_layer_reddit_8x8", 12 if full else 4, gat_layer)
+    why = profiler_preload()
+    if why:
+        for k in ("epoch_sage_products_hidden256", "epoch_sage_products_hidden128", "epoch_gcn_products", "epoch_gat_reddit", "epoch_gcn_cora"):
+            out[k] = {"skipped": f"{why}: the epoch legs start the trainer as a child program (profile bin/gpu_train_* directly)"}
+        return out
+    ea = argparse.Namespace(**{**vars(args), "steps": st, "warmup": 2, "no_cpu_baseline": True})
+    data = tempfile.mkdtemp(prefix="gaib_other_")
+    try:
+        ep = lambda w, **kw: (lambda: _brief_epoch(epoch_record(ea, torch, synth, wname=w, data_root=data, keep_data=True, **kw)[0]))
+        leg("epoch_sage_products_hidden256", 40 if full else 8, ep("epoch-sage-products", hidden=256))
+        leg("epoch_sage_products_hidden128", 18 if full else 6, ep("epoch-sage-products", hidden=128))
+        leg("epoch_gcn_products", 15 if full else 6, ep("epoch-gcn-products"))
+        shutil.rmtree(os.path.join(data, "ogbn-products"), ignore_errors=True)
+        leg("epoch_gat_reddit", 30 if full else 8, ep("epoch-gat-reddit"))
+        shutil.rmtree(os.path.join(data, "reddit"), ignore_errors=True)
+        leg("epoch_gcn_cora", 12, ep("epoch-gcn-cora"))
+    finally:
+        shutil.rmtree(data, ignore_errors=True)
+    return out
 
 
 # ---- epoch-level records (BASELINE configs 2-4 are models, not layers; VERDICT r4 #4) ------------------------------------
@@ -1423,15 +1658,19 @@ def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: i
     """bin/gpu_train_<arch> with the reference's argument list (train.cpp:9-14; net.cpp:40-64) as a CHILD process ->
     (stdout text, per-epoch dicts (loss, acc, seconds), work table or {}, aggregated edges per epoch)"""
     import re
-    import subprocess
 
     from graphaibench_amd import capi
 
+    why = profiler_preload()
+    if why:  # (as launch_ranks: the tool library has initialised the GPU in THIS process, and the child would be profiled into it)
+        raise RuntimeError(f"{why}: the epoch workloads start the trainer as a child program, which a process under a profiler must "
+                           "not do on this pool -- profile bin/gpu_train_* directly after `--` (scripts/profile_epoch.sh)")
     exe = ROOT / "bin" / f"gpu_train_{arch}"
     if not exe.exists():
         raise RuntimeError(f"{exe} is missing: python -m graphaibench_amd.build")
     env = dict(os.environ, DATASET_PATH=data_root if data_root.endswith("/") else data_root + "/", GAIB_GAT_HEADS=str(heads))
     env.pop("GAIB_RANKS", None)
+    env["GAIB_EPOCH_LOSSES"] = "1"  # train_loss / train_acc once more with 9 digits (the log line keeps the reference's three decimals)
     if times_from is not None:  # epoch times at full precision without timing launches (recorded epochs included)
         env["GAIB_EPOCH_TIMES"] = str(times_from)
     if prof_from is not None:
@@ -1442,11 +1681,20 @@ def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: i
         env["GAIB_EPOCH_GRAPH"] = "0"
     # <dataset> <epochs> <threads> <loss> <hidden> <score_drop> <feat_drop> <lr> <layers> <subgraph> <val_interval> <inductive>
     cmd = [str(exe), dataset, str(epochs), "32", "softmax", str(hidden), "0", "0", "0.01", str(layers), "0", str(epochs + 100), "0"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
+    rcode, r_out, r_err = run_child(cmd, env=env, timeout_s=timeout_s)
+
+    class r:  # (the fields the code below reads)
+        returncode, stdout, stderr = rcode, r_out, r_err
+
     if r.returncode != 0:
         raise RuntimeError(f"{' '.join(cmd)} exited with {r.returncode}: {r.stderr[-600:]}")
     ep = [dict(loss=float(a), acc=float(b), seconds=float(c))
           for a, b, c in re.findall(r"train_loss ([0-9.]+) train_acc ([0-9.]+) train_time ([0-9.]+) s", r.stdout)]
+    for key, field in (("epoch_losses", "loss"), ("epoch_accs", "acc")):  # full precision where the trainer gave it
+        mm = re.search(rf"^\[gaib prof\] {key}((?: [0-9.eE+-]+)+)$", r.stdout, re.M)
+        if mm and len(mm.group(1).split()) == len(ep):
+            for e, v in zip(ep, mm.group(1).split()):
+                e[field] = float(v)
     table = capi.parse_prof_table("\n".join(l[len("[gaib prof] "):] for l in r.stdout.splitlines() if l.startswith("[gaib prof] ")))
     m = re.search(r"Aggregated edges per epoch: (\d+)", r.stdout)
     # the profiled epochs' times at full precision (the log line keeps the reference's three decimals: 1 ms)
@@ -1459,7 +1707,14 @@ def _run_trainer(arch: str, data_root: str, dataset: str, epochs: int, hidden: i
 
 
 def bench_epoch(args, torch, synth, guard) -> int:
-    """One training EPOCH of a BASELINE model config per step, through the trainer CLI the reference's scripts call
+    """`--workload epoch-*`: the record of epoch_record, held as soon as the GPU measurement is in, then printed"""
+    result, rc = epoch_record(args, torch, synth, hold=guard.hold, hidden=getattr(args, "hidden", None))
+    guard.final(result)
+    return rc
+
+
+def epoch_record(args, torch, synth, hold=None, wname=None, hidden=None, data_root=None, keep_data=False):
+    """-> (record, rc).  One training EPOCH of a BASELINE model config per step, through the trainer CLI the reference's scripts call
     (bin/gpu_train_*: reader -> Model -> forward_prop / backward_prop / update, src/gnn/net.cpp:361-419) on a seeded synthetic
     dataset of the config's shape in the reference's on-disk format.  --warmup epochs run first (epoch 0 allocates and builds
     the graph's lazily made tables), then --steps epochs are timed -- the trainer's own per-epoch train_time, each bracketed
@@ -1469,40 +1724,53 @@ def bench_epoch(args, torch, synth, guard) -> int:
     epoch time; per kernel and row width in `per_key`, with the 128-B-line floor of the gathers whose rows are no whole
     number of lines (D = 47, 100) next to their algorithmic bytes.
     cpu_baseline + parity: the oracle's Model (oracle/model.py) on the same generator at `parity_scale` -- its epoch timed, and the
-    first 5 train_loss / train_acc of the trainer on that dataset against it (the trainer prints 3 decimals)."""
+    first 5 train_loss / train_acc of the trainer on that dataset against it (GAIB_EPOCH_LOSSES: 9 digits, held to 1e-4 relative).
+    wname / hidden: the workload (default args.workload) and its hidden width (default the workload's: `--hidden 128` is BASELINE
+    config 3's literal "3-layer D=128", 256 what scripts/run-sage-products.sh passes).  data_root + keep_data: a directory that
+    already holds (or will keep) the full-size dataset -- the default run's other_configs block writes the products dataset once
+    for its three epoch records."""
     import shutil
     import tempfile
 
     import numpy as np
 
-    w = EPOCH_WORKLOADS[args.workload]
-    arch, name, hid, nl, heads = w["arch"], w["dataset"], w["hidden"], w["layers"], w["heads"]
+    w = EPOCH_WORKLOADS[wname or args.workload]
+    arch, name, hid, nl, heads = w["arch"], w["dataset"], hidden or w["hidden"], w["layers"], w["heads"]
     steps, warm = args.steps, max(args.warmup, 1)
     tmp = tempfile.mkdtemp(prefix="gaib_epoch_")
+    root_full = data_root or tmp
     try:
         t0 = time.time()
 
-        def write(scale):
+        def write(scale, where=None):
             if name == "cora":  # the reference's own topology (data fixture), not a generator
-                return synth.write_cora_dataset(tmp, ROOT / "tests" / "golden" / "cora")
-            return synth.write_dataset(name, tmp, scale=scale, device="cuda")
+                return synth.write_cora_dataset(where or tmp, ROOT / "tests" / "golden" / "cora")
+            return synth.write_dataset(name, where or tmp, scale=scale, device="cuda")
 
-        info = write(args.scale)
+        meta = Path(root_full) / name / "gaib_info.json"
+        if data_root and meta.exists():
+            info = json.loads(meta.read_text())
+        else:
+            info = write(args.scale, root_full)
+            if keep_data:
+                meta.write_text(json.dumps({k: (str(v) if isinstance(v, Path) else v) for k, v in info.items()}))
         torch.cuda.empty_cache()
-        log(f"[bench] {name}-shaped dataset written in {time.time()-t0:.1f}s: nv={info['nv']} ne={info['ne']} F={info['F']} C={info['C']}")
-        out, ep, table, edges_epoch = _run_trainer(arch, tmp, name, warm + steps, hid, nl, heads, warm, 500.0)
+        log(f"[bench] {name}-shaped dataset ready in {time.time()-t0:.1f}s: nv={info['nv']} ne={info['ne']} F={info['F']} C={info['C']}")
+        tmp_full = root_full
+        out, ep, table, edges_epoch = _run_trainer(arch, tmp_full, name, warm + steps, hid, nl, heads, warm, 500.0)
         recorded = None
         if info["ne"] <= (1 << 22):
             # launch bound: what the trainer does by default there is replay the epoch as two recorded HIP graphs -- THAT is the
             # timed figure; the call-by-call run above only supplies the work table (its epochs are several times longer)
             warm_r = max(warm, 2)  # (epoch 0 runs call by call and is followed by the recording)
-            out_r, ep_r, _, edges_r = _run_trainer(arch, tmp, name, warm_r + steps, hid, nl, heads, None, 500.0, times_from=warm_r)
+            out_r, ep_r, _, edges_r = _run_trainer(arch, tmp_full, name, warm_r + steps, hid, nl, heads, None, 500.0, times_from=warm_r)
             recorded = dict(call_by_call_ms_per_epoch=sum(e["seconds"] for e in ep[warm:]) / steps * 1e3,
                             note="timed epochs = the trainer's default on a launch-bound dataset: two recorded HIP-graph launches per "
                                  "epoch; roofline.per_key comes from the call-by-call run (same kernels, launched one by one)")
             ep, warm = ep_r, warm_r
             edges_epoch = edges_r or edges_epoch
-        shutil.rmtree(os.path.join(tmp, name), ignore_errors=True)
+        if not keep_data:
+            shutil.rmtree(os.path.join(tmp_full, name), ignore_errors=True)
         if len(ep) != warm + steps or not table:
             raise RuntimeError(f"trainer output not understood ({len(ep)} epoch lines, {len(table)} table lines):\n{out[-1500:]}")
         timed = ep[warm:]
@@ -1558,7 +1826,8 @@ def bench_epoch(args, torch, synth, guard) -> int:
                 "Cache and partly in the L2s, so the algorithmic bytes of its gather kernels (every gathered row counted) are a WORK "
                 "rate, not HBM traffic; the layer record (--workload gat-reddit) prices the dominant kernel's measured L2 -> fabric "
                 "bytes against the cache-resident gather rate instead")
-        guard.hold(result)
+        if hold is not None:
+            hold(result)
         rc = 0
         if not args.no_cpu_baseline:
             from oracle import binding as orc
@@ -1592,21 +1861,23 @@ def bench_epoch(args, torch, synth, guard) -> int:
                        f"{edges_s} aggregated edges per epoch), one epoch of the oracle's Model (oracle/model.py: the restatement's "
                        f"layers, loss, Adam), best of epochs 2-{n_cmp}: {t_cpu:.2f} s")
             dl = [abs(g["loss"] - wl) for g, (wl, _) in zip(ep_s, want)]
+            dr = [abs(g["loss"] - wl) / max(abs(wl), 1e-30) for g, (wl, _) in zip(ep_s, want)]
             da = [abs(g["acc"] - wa) for g, (_, wa) in zip(ep_s, want)]
-            # the trainer prints three decimals: half a unit of the last place + the fp32 distance of two correct evaluations
-            par = {"against": f"oracle Model, first {n_cmp} epochs, scale {sc}", "tol_loss": 2e-3, "tol_acc": 0.02,
-                   "train_loss_gpu": [g["loss"] for g in ep_s], "train_loss_oracle": [round(float(wl), 6) for wl, _ in want],
+            # round 6: the trainer hands its losses over with 9 digits (GAIB_EPOCH_LOSSES), so the curve is held to north_star's
+            # 1e-4 RELATIVE instead of the printed three decimals; accuracy = a count of argmax hits over the training range: a
+            # logit pair within rounding of a tie may fall either way -- 2e-3 of the range
+            par = {"against": f"oracle Model, first {n_cmp} epochs, scale {sc}", "tol_loss_rel": 1e-4, "tol_acc": 2e-3,
+                   "train_loss_gpu": [g["loss"] for g in ep_s], "train_loss_oracle": [float(wl) for wl, _ in want],
                    "train_acc_gpu": [g["acc"] for g in ep_s], "train_acc_oracle": [round(float(wa), 6) for _, wa in want],
-                   "max_abs_loss_diff": max(dl), "max_abs_acc_diff": max(da),
+                   "max_abs_loss_diff": max(dl), "max_rel_loss_diff": max(dr), "max_abs_acc_diff": max(da),
                    "learns": bool(want[-1][0] < want[0][0])}
-            par["ok"] = bool(len(ep_s) == n_cmp and max(dl) <= par["tol_loss"] and max(da) <= par["tol_acc"])
+            par["ok"] = bool(len(ep_s) == n_cmp and max(dr) <= par["tol_loss_rel"] and max(da) <= par["tol_acc"])
             result["parity"] = par
             log(f"[bench] loss-curve parity vs the oracle's Model: {par}")
             if not par["ok"]:
                 log("[bench] PARITY FAILED (loss curve)")
                 rc = 3
-        guard.final(result)
-        return rc
+        return result, rc
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -41,39 +41,66 @@ void LearningGraph::drop_pieces() {
   pieces_built_ = pieces_slices_ = 0;
 }
 
-// How many pieces this rank consumes an exchange of K slices in, for rows of `len` columns: the K' | K with the shortest
-// modelled aggregation.  The owned-column work runs first; piece j can start once slice (j + 1) K / K' - 1 has landed, at
-// (j + 1) / K' of the exchange (priced like partition_mode prices it: the most rows one peer pair moves, at GAIB_LINK_GBS);
-// the halo-column half moves its gathers plus -- once per piece -- the rows' partial sums, at the rates the two forms reach
-// (one fused pass 7.7 TB/s, accumulate passes over row segments 6.0 TB/s: profiles/r06/shard/strong_world*_slices_*.jsonl).
-int LearningGraph::consumption_rule(int K, int len) {
-  gaib_graph* half = part_mode_ == PART_SPLIT ? halo_dev_ : cls_bhalo_;
-  const double row_bytes = 4.0 * len;
+// ---- the model the two rules share (partition_mode: which form; consumption_rule: how many pieces) ----------------------
+// One aggregation of a rank whose rows keep a halo-column half, on rows of `len` columns, with the exchange priced at the
+// most rows one peer pair moves x row bytes / GAIB_LINK_GBS (default 100 GB/s per pair; bench.py --gpus N puts the link rate
+// it measured there).  Rates are the ones measured on the shard benchmarks (scripts/papers_shard.py; profiles/r04/shard_*,
+// profiles/r06/shard/): the row kernels gather 512-B rows at 7.5 TB/s; a pass that continues partial sums reaches
+// 4.8 TB/s on row segments of <= 3 edges, 7.7 TB/s from 12 edges on, and 8 % less where it is one of several pieces.
+namespace {
+struct SplitShape {
+  double row_bytes, t_wire;
+  int64_t ne_own, ne_halo, rows_half;  // owned-column edges of ALL rows; halo-column edges; rows of the halo-column half
+};
+double wire_seconds(int64_t link_rows, int len) {
   const double link_gbs = getenv("GAIB_LINK_GBS") ? atof(getenv("GAIB_LINK_GBS")) : 100.0;
-  int64_t link_rows = link_rows_;
-  if (link_rows < 0 && halo_plan_) link_rows = gaib_halo_link_rows(halo_plan_);
-  if (link_rows < 0) link_rows = gaib_graph_nc(half) / 7 + 1;
-  const double t_wire = link_rows * row_bytes / (link_gbs * 1e9);
-  const double t_own = gaib_graph_ne(dev_) * (row_bytes + 8) / 7.5e12;  // (classes: interior + boundary rows' owned columns = all of dev_)
-  const double b_halo = gaib_graph_ne(half) * (row_bytes + 8), b_rows = 2.0 * gaib_graph_nv(half) * row_bytes;
+  return link_rows * 4.0 * len / ((link_gbs > 0 ? link_gbs : 100.0) * 1e9);
+}
+// the column split with the K slices consumed in kc pieces: owned-column work first, piece j once slice (j + 1) K / kc - 1 has
+// landed -- at (j + 1) / kc of the exchange --, every piece a read + write of the half's partial sums on top of its gathers
+double model_split(const SplitShape& s, int kc) {
+  const double e = s.rows_half > 0 ? (double)s.ne_halo / ((double)s.rows_half * kc) : 0.0;  // edges per row segment
+  double rate = 4.8e12 + (e - 3.0) / 9.0 * 2.9e12;
+  rate = rate < 4.8e12 ? 4.8e12 : (rate > 7.7e12 ? 7.7e12 : rate);
+  if (kc > 1) rate *= 0.92;
+  const double t_piece = (s.ne_halo * (s.row_bytes + 8) + kc * 2.0 * s.rows_half * s.row_bytes) / rate / kc;
+  double t = s.ne_own * (s.row_bytes + 8) / 7.5e12;
+  for (int j = 0; j < kc; j++) {
+    const double arrive = s.t_wire * (j + 1) / kc;
+    t = (t > arrive ? t : arrive) + t_piece;
+  }
+  return t;
+}
+// the K' | K with the shortest modelled aggregation; a further piece must buy 2 % (the model is not better than that)
+int best_consumption(const SplitShape& s, int K, double* t_best) {
   int best = 1;
   double best_t = 0.0;
   for (int kc = 1; kc <= K; kc++) {
     if (K % kc) continue;
-    const double t_piece = (b_halo + kc * b_rows) / (kc > 1 ? 6.0e12 : 7.7e12) / kc;
-    double t = t_own;
-    for (int j = 0; j < kc; j++) {
-      const double arrive = t_wire * (j + 1) / kc;
-      t = (t > arrive ? t : arrive) + t_piece;
-    }
-    if (kc == 1 || t < best_t * 0.98) {  // (a further piece must buy 2 %: the model is not better than that)
+    const double t = model_split(s, kc);
+    if (kc == 1 || t < best_t * 0.98) {
       best = kc;
       best_t = t;
     }
   }
+  if (t_best) *t_best = best_t;
+  return best;
+}
+}  // namespace
+
+// How many pieces this rank consumes an exchange of K slices in, for rows of `len` columns (see lgraph.h)
+int LearningGraph::consumption_rule(int K, int len) {
+  gaib_graph* half = part_mode_ == PART_SPLIT ? halo_dev_ : cls_bhalo_;
+  int64_t link_rows = link_rows_;
+  if (link_rows < 0 && halo_plan_) link_rows = gaib_halo_link_rows(halo_plan_);
+  if (link_rows < 0) link_rows = gaib_graph_nc(half) / 7 + 1;
+  // (classes: interior rows + the boundary rows' owned columns run before the first wait = all of dev_'s edges)
+  const SplitShape s{4.0 * len, wire_seconds(link_rows, len), gaib_graph_ne(dev_), gaib_graph_ne(half), gaib_graph_nv(half)};
+  double t = 0.0;
+  const int best = best_consumption(s, K, &t);
   if (getenv("GAIB_PART_VERBOSE"))
-    fprintf(stderr, "[gaib] halo consumption: %d piece(s) of %d slice(s) (exchange %.2f ms per link, owned-column work %.2f ms, "
-            "halo-column half %.2f ms in one pass)\n", best, K, t_wire * 1e3, t_own * 1e3, (b_halo + b_rows) / 7.7e12 * 1e3);
+    fprintf(stderr, "[gaib] halo consumption: %d piece(s) of %d slice(s): modelled aggregation %.3f ms (in one piece %.3f ms; "
+            "exchange %.3f ms per link)\n", best, K, t * 1e3, model_split(s, 1) * 1e3, s.t_wire * 1e3);
   return best;
 }
 
@@ -126,17 +153,17 @@ int LearningGraph::halo_pieces(int len) {
 }
 
 // The mode of a partitioned graph's aggregations.  GAIB_PART_MODE = split | classes | onepass | onepass_all | auto (default), or
-// set_partition_mode.  The rule (auto) prices what each form leaves exposed, per aggregation:
-//   one pass    : the exchange minus what hides it -- the interior rows' work (the boundary rows wait for the halo rows)
-//   column split: everything overlaps, but the boundary rows' partial sums are written and read once more and the
-//                 halo-column half runs below the gather rate
-// with the exchange priced at GAIB_LINK_GBS per peer pair (default 100: the guide's 153 GB/s per xGMI link at the share
-// RCCL send/recv pairs are expected to reach; unmeasured on this pool's one-GPU boxes) and the kernels at the rates
-// measured on the shard benchmarks (scripts/papers_shard.py, profiles/r04/shard_*.jsonl: DESIGN.md 6).  Where next to no
-// row is interior (a random vertex order, or cut edges spread over every vertex: under 10 % of the edges in interior
-// rows) the classes are not worth their second launch: the column split then runs over all rows as in round 3, the one
-// pass over all rows of one [owned | halo] graph.  A rank decides for itself: every form runs the same exchange, so
-// ranks need not agree.
+// set_partition_mode.  The rule (auto) models one aggregation in each form and takes the shorter (model_split above):
+//   one pass    : max(exchange, the interior rows' work) + the boundary rows over [owned | halo] after the last row has landed
+//   column split: the owned-column work of all rows, then the halo-column half -- one more read + write of the boundary rows'
+//                 partial sums, below the gather rate on short row segments -- piece by piece where the exchange travels in
+//                 slices, each piece as soon as its slices have landed (round 6; in as many pieces as the model likes best)
+// with the exchange priced at GAIB_LINK_GBS per peer pair (default 100; unmeasured on this pool's one-GPU boxes: bench.py
+// --gpus N measures the link first and puts the figure there) and the kernels at the rates measured on the shard benchmarks
+// (scripts/papers_shard.py).  Where next to no row is interior (a random vertex order, or cut edges spread over
+// every vertex: under 10 % of the edges in interior rows) the classes are not worth their second launch: the column split then
+// runs over all rows as in round 3, the one pass over all rows of one [owned | halo] graph.  A rank decides for itself:
+// every form runs the same exchange, so ranks need not agree.
 int LearningGraph::partition_mode(int len) {
   if (part_mode_ >= 0) return part_mode_;
   if (!has_halo()) return part_mode_ = PART_SPLIT;
@@ -171,46 +198,31 @@ int LearningGraph::partition_mode(int len) {
   bool all_boundary = want == PART_ONEPASS_ALL;
   int mode = all_boundary ? (int)PART_ONEPASS : want;
   if (mode < 0) {
-    const double link_gbs = getenv("GAIB_LINK_GBS") ? atof(getenv("GAIB_LINK_GBS")) : 100.0;
     int64_t link_rows = link_rows_;
     if (link_rows < 0 && halo_plan_) link_rows = gaib_halo_link_rows(halo_plan_);
     if (link_rows < 0) link_rows = (ne_bhalo ? gaib_graph_nc(halo_dev_) : 0) / 7 + 1;  // (a callback transport that gave no figure: 8 ranks)
     const double row_bytes = 4.0 * len;
-    const double t_exchange = link_rows * row_bytes / (link_gbs * 1e9);
-    const double gather_rate = 7.5e12;  // bytes/s the aggregation kernels reach on 512-B rows
-    const double t_interior = few_interior ? 0.0 : ne_int * (row_bytes + 8) / gather_rate;
-    const double exposed_onepass = t_exchange > t_interior ? t_exchange - t_interior : 0.0;
-    // the split's extra cost: the boundary rows' partial sums written and read again (6 TB/s), and the halo-column half
-    // at 5.2 TB/s of its 1 + 12.6 M edges x 520 B instead of the gather rate
-    const int64_t split_rows = few_interior ? (int64_t)size() : n_boundary_;
-    // round 6: an exchange that travels in K slices (gaib_halo_set_pieces) costs the split one more read + write of the partial
-    // sums per further piece -- and leaves it exposed only where the compute stream reaches a slice before it has landed:
-    // slice k lands at (k + 1) / K of the exchange, the owned-column work runs first, then the pieces of the halo-column half
+    const double t_exchange = wire_seconds(link_rows, len);
+    // one pass: the interior rows' work hides the exchange (where a fair share of the edges is interior), the boundary rows --
+    // all rows where next to none is interior -- run over [owned | halo] after the last row has landed
+    const double t_interior = few_interior ? 0.0 : ne_int * (row_bytes + 8) / 7.5e12;
+    const double t_onepass = (t_exchange > t_interior ? t_exchange : t_interior) + (ne_all - (few_interior ? 0 : ne_int)) * (row_bytes + 8) / 7.5e12;
+    // the column split (of the boundary rows; of all rows where next to none is interior): the owned-column work of ALL rows
+    // hides the exchange, the halo-column half follows -- piece by piece where the exchange travels in slices (round 6), in as
+    // many pieces as serve it best
+    const SplitShape shape{row_bytes, t_exchange, gaib_graph_ne(dev_), ne_bhalo, few_interior ? (int64_t)size() : n_boundary_};
     const int K = halo_slices();
-    const double rmw = 2.0 * split_rows * row_bytes / 6.0e12;
-    const double t_halo_half = ne_bhalo * (row_bytes + 8) / 5.2e12;
-    const double split_cost = rmw * (K > 1 ? K : 1) + ne_bhalo * (row_bytes + 8) * (1.0 / 5.2e12 - 1.0 / gather_rate);
-    double exposed_split = 0.0;
-    {
-      double t = gaib_graph_ne(dev_) * (row_bytes + 8) / gather_rate;  // owned-column edges of all rows: before the first wait
-      for (int k = 0; k < (K > 1 ? K : 1); k++) {
-        const double arrive = t_exchange * (k + 1) / (K > 1 ? K : 1);
-        if (arrive > t) {
-          exposed_split += arrive - t;
-          t = arrive;
-        }
-        t += t_halo_half / (K > 1 ? K : 1) + (k > 0 ? rmw : 0.0);
-      }
-    }
-    const bool onepass = exposed_onepass <= split_cost + exposed_split;
+    double t_split = 0.0;
+    const int kc = best_consumption(shape, K > 1 ? K : 1, &t_split);
+    const bool onepass = t_onepass <= t_split;
     mode = onepass ? PART_ONEPASS : (few_interior ? PART_SPLIT : PART_CLASSES);
     all_boundary = onepass && few_interior;
     if (getenv("GAIB_PART_VERBOSE"))
       fprintf(stderr, "[gaib] partition mode %s%s: %lld of %lld rows on the boundary (%.1f %% of the edges in interior rows), "
-              "exchange %.2f ms per link in %d slice(s), interior work %.2f ms, split cost %.2f ms + %.2f ms exposed\n",
+              "exchange %.3f ms per link in %d slice(s); modelled aggregation: one pass %.3f ms, column split %.3f ms in %d piece(s)\n",
               mode == PART_ONEPASS ? "onepass" : (mode == PART_CLASSES ? "classes" : "split"), all_boundary ? " (all rows)" : "",
               (long long)n_boundary_, (long long)size(), 100.0 * ne_int / (ne_all > 0 ? ne_all : 1), t_exchange * 1e3, K,
-              t_interior * 1e3, split_cost * 1e3, exposed_split * 1e3);
+              t_onepass * 1e3, t_split * 1e3, kc);
   }
   if (mode == PART_SPLIT) {
     gaib_graph_destroy(gi);

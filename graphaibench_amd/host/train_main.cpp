@@ -634,6 +634,11 @@ struct Trainer {
     const int times_from = prof_from >= 0 ? prof_from : ((et && *et) ? std::max(0, atoi(et)) : -1);
     int prof_epochs = 0;
     std::vector<double> prof_epoch_s;  // the profiled epochs' train_time at full precision (the log line keeps the reference's 3 decimals)
+    // GAIB_EPOCH_LOSSES=1: every epoch's train_loss / train_acc once more after the run with 9 significant digits
+    // ("[gaib prof] epoch_losses ..." / "epoch_accs ..."): the log line keeps the reference's three decimals, which is all a
+    // comparison of loss curves would otherwise see (bench.py's epoch parity holds the curve to 1e-4 relative)
+    const bool exact_losses = getenv("GAIB_EPOCH_LOSSES") && atoi(getenv("GAIB_EPOCH_LOSSES")) != 0;
+    std::vector<double> all_loss, all_acc;
     for (int itr = 0; itr < num_epochs; itr++) {
       if (itr == prof_from) {
         GAIB_OR_DIE(gaib_prof_reset(gpu_context::get()));
@@ -682,6 +687,10 @@ struct Trainer {
       const double fw = t1 - t0, bw = t2 - t1, epoch_time = fw + bw;
       total += epoch_time;
       if (times_from >= 0 && itr >= times_from) prof_epoch_s.push_back(epoch_time);
+      if (exact_losses) {
+        all_loss.push_back((double)train_loss);
+        all_acc.push_back((double)train_acc);
+      }
       std::cout << "train_loss " << std::setprecision(3) << std::fixed << train_loss << " train_acc " << train_acc << " ";
       if (itr % val_interval == 0 && itr != 0) {
         double tv0 = omp_get_wtime();
@@ -695,6 +704,13 @@ struct Trainer {
       } else {
         std::cout << "train_time " << std::fixed << epoch_time << " s (fw " << fw << ", bw " << bw << ")\n";
       }
+    }
+    if (exact_losses && root()) {
+      std::cout << "[gaib prof] epoch_losses" << std::scientific << std::setprecision(8);
+      for (double v : all_loss) std::cout << " " << v;
+      std::cout << "\n[gaib prof] epoch_accs";
+      for (double v : all_acc) std::cout << " " << v;
+      std::cout << std::fixed << std::setprecision(3) << "\n";
     }
     if (prof_from < 0 && !prof_epoch_s.empty() && root()) {
       std::cout << "[gaib prof] epoch_seconds";

@@ -367,11 +367,27 @@ def test_partition_mode_rule_follows_the_exchange_price_and_the_interior_share(c
     mode, n_b, e_b = lg.partition_mode(128)
     assert L.LGraph.PART_NAMES[mode] == "onepass" and n_b == int(s.is_bnd.sum()) and 0 < n_b < s.n
     lg.close()
-    monkeypatch.setenv("GAIB_LINK_GBS", "0.001")  # the exchange dwarfs the interior work: keep it hidden -> column split of the boundary rows
-    lg, s = lgraph(g_o, 1000, 5000)
-    lg.set_halo_link_rows(10_000_000)
-    assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "classes"
-    lg.close()
+
+    from util import partition_rule
+
+    def rule(s, link_rows, link_gbs):
+        """LearningGraph::partition_mode's rule, restated in tests/util.py (round 6: one model of an aggregation for both forms --
+        the column split is priced with what IT leaves exposed too, not as if it hid everything)"""
+        return partition_rule(s.n, np.diff(s.rp_own), np.diff(s.rp_halo), link_rows, link_gbs)
+
+    # the exchange priced from free to far beyond the rank's work: one pass where it is hidden by the interior rows anyway (or so
+    # long that the split's owned-column pass hides next to nothing more), the column split of the boundary rows in between --
+    # where it hides what one pass would leave exposed
+    seen = set()
+    for link_rows in (0, 1000, 3000, 4000, 5000, 5500, 6000, 8000, 20000, 10_000_000):
+        monkeypatch.setenv("GAIB_LINK_GBS", "100")
+        lg, s = lgraph(g_o, 1000, 5000)
+        lg.set_halo_link_rows(link_rows)
+        got = L.LGraph.PART_NAMES[lg.partition_mode(128)[0]]
+        assert got == rule(s, link_rows, 100.0), (link_rows, got)
+        seen.add(got)
+        lg.close()
+    assert seen == {"onepass", "classes"}, seen
     lg, s = lgraph(g_o, 1000, 5000)  # an explicit wish wins over the rule
     lg.set_partition_mode(L.LGraph.PART_ONEPASS)
     assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "onepass"
@@ -379,10 +395,16 @@ def test_partition_mode_rule_follows_the_exchange_price_and_the_interior_share(c
     # a thin slice of a dense graph: every row has remote neighbours, under 10 % of the edges are interior
     rp2, ci2 = random_graph(3000, 40, seed=32, power_law=False)
     g_d = orc.Graph(rp2, ci2).add_selfloop()
-    lg, s = lgraph(g_d, 1400, 1600)
-    lg.set_halo_link_rows(10_000_000)
-    assert L.LGraph.PART_NAMES[lg.partition_mode(128)[0]] == "split"  # slow link: round 3's split over all rows
-    lg.close()
+    seen = set()
+    for link_rows in (0, 100, 300, 400, 500, 600, 800, 2000, 10_000_000):
+        monkeypatch.setenv("GAIB_LINK_GBS", "100")
+        lg, s = lgraph(g_d, 1400, 1600)
+        lg.set_halo_link_rows(link_rows)
+        got = L.LGraph.PART_NAMES[lg.partition_mode(128)[0]]
+        assert got == rule(s, link_rows, 100.0), (link_rows, got)
+        seen.add(got)
+        lg.close()
+    assert seen == {"onepass", "split"}, seen  # no interior rows to speak of: round 3's split over all rows, or one pass over all rows
     monkeypatch.setenv("GAIB_LINK_GBS", "1e9")
     lg, s = lgraph(g_d, 1400, 1600)
     lg.set_halo_link_rows(10_000_000)

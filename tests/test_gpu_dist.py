@@ -503,6 +503,17 @@ def test_bench_n1_record_at_small_scale():
     assert "fp64" in fl and fl["fp64"].get("ok", True) is True
     if fl["count"]:
         assert fl["fp64"]["checked"] >= 1 and fl["fp64"]["max_abs_fp64_value_over_fp32_rounding_bound"] <= 1.0
+    # round 6: BASELINE configs 2-4 as short legs of the default run, after the headline record is complete
+    oc = res["other_configs"]
+    for k in ("sage_layer_128", "sage_layer_256", "gat_layer_reddit_8x8"):
+        assert oc[k]["value"] > 0 and oc[k]["ms_per_step"] > 0 and oc[k]["steps"] == 10, (k, oc[k])
+    assert 0 < oc["sage_layer_256"]["roofline"]["frac"] < 1.5 and oc["sage_layer_256"]["roofline"]["per_key"]
+    for k, hid in (("epoch_sage_products_hidden256", 256), ("epoch_sage_products_hidden128", 128), ("epoch_gcn_products", 128),
+                   ("epoch_gat_reddit", 64), ("epoch_gcn_cora", 16)):
+        e = oc[k]
+        assert e["value"] > 0 and e["ms_per_epoch"] > 0 and e["hidden"] == hid and e["steps"] == 10 and e["roofline"]["frac"] > 0, (k, e)
+        assert len(e["train_loss_timed_epochs"]) == 10 and e["train_loss_timed_epochs"][-1] < e["train_loss_timed_epochs"][0]
+    assert oc["epoch_gcn_cora"]["recorded_epochs"] is True and oc["elapsed_s"] < oc["budget_s"] + 60
 
 
 def test_bench_budget_skips_sub_cases_and_keeps_the_headline():

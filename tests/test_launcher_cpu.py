@@ -461,3 +461,126 @@ def test_epoch_record_is_assembled_from_the_trainer_output(monkeypatch, tmp_path
     assert "line_floor" in pk["spmm_light@47"] and pk["spmm_light@47"]["line_floor"]["lines_per_row"] == 2.0
     assert "line_floor" not in pk["spmm_gemm_fused@128"] and "line_floor" not in pk["sgemm@1000x128x100"] and "line_floor" not in pk["d_relu"]
     assert pk["sgemm@1000x128x100"]["frac"] == pytest.approx(0.5) and r["config"]["train_loss_timed_epochs"] == [pytest.approx(3.7), pytest.approx(3.6)]
+
+
+def test_child_programs_run_unmasked_and_do_not_outlive_a_bailing_guard(tmp_path):
+    """bench.py blocks SIGTERM / SIGINT first thing and the mask survives fork + exec -- the trainer child of
+    an epoch leg must start with the mask RESTORED (it has to die on the pool's SIGTERM) and must not be left on the GPU when
+    RecordGuard.bail() leaves through os._exit: run_child starts it in its own session through the unmasking wrapper, bail()
+    kills and reaps the group first"""
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent(f"""
+        import os, signal, sys, time
+        blocked = signal.pthread_sigmask(signal.SIG_BLOCK, [])
+        open({str(tmp_path / "child_info")!r}, "w").write(f"{{os.getpid()}} {{int(signal.SIGTERM in blocked)}} {{int(signal.SIGINT in blocked)}}")
+        time.sleep(300)
+    """))
+    parent = tmp_path / "parent.py"
+    parent.write_text(textwrap.dedent(f"""
+        import signal, sys, threading
+        signal.pthread_sigmask(signal.SIG_BLOCK, {{signal.SIGTERM, signal.SIGINT}})  # bench.main()'s first act
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        g = bench.install_rank_guard(0, 3.0)
+        g.hold({{"value": 7.0, "config": {{}}}})
+        try:
+            rc, _, _ = bench.run_child([sys.executable, {str(child)!r}], timeout_s=120)  # "the epoch leg": never returns by itself
+            raise RuntimeError(f"the trainer exited with {{rc}}")  # (what _run_trainer makes of a killed child)
+        except Exception as e:
+            g.bail(str(e))  # main()'s handler: must not outrun the watcher thread that is printing the record
+            raise
+    """))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(parent)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and time.time() - t0 < 30, (r.returncode, r.stderr[-2000:])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 7.0 and "deadline" in rec["partial"]["reason"]
+    pid, term_blocked, int_blocked = (int(v) for v in (tmp_path / "child_info").read_text().split())
+    assert term_blocked == 0 and int_blocked == 0, "the child inherited the blocked signals"
+    assert not _alive(pid), "the child program outlived the bailing guard"
+    assert "killed 1 child program" in r.stderr
+
+
+def test_run_child_returns_output_and_kills_on_timeout(tmp_path):
+    import bench
+
+    ok = tmp_path / "ok.py"
+    ok.write_text("import sys; print('out'); print('err', file=sys.stderr); sys.exit(3)")
+    rc, out, err = bench.run_child([sys.executable, str(ok)], timeout_s=30)
+    assert (rc, out.strip(), err.strip()) == (3, "out", "err") and not bench._CHILDREN
+    slow = tmp_path / "slow.py"
+    slow.write_text(f"import os, time; open({str(tmp_path / 'slow_pid')!r}, 'w').write(str(os.getpid())); time.sleep(300)")
+    with pytest.raises(subprocess.TimeoutExpired):
+        bench.run_child([sys.executable, str(slow)], timeout_s=2)
+    assert not _alive(int((tmp_path / "slow_pid").read_text()))
+
+
+def test_other_configs_block_is_budgeted_and_failure_proof(monkeypatch, tmp_path):
+    """the default N = 1 run's `other_configs` slot: every leg present when the budget allows, {"skipped": "budget"}
+    when it does not, {"error": ...} when a leg raises -- the block never raises; the epoch legs' records are cut down to the
+    slot's fields; the products dataset is written once for the three models on it"""
+    import argparse
+
+    import bench
+    from graphaibench_amd import capi
+
+    class FakeTorch:
+        class cuda:
+            @staticmethod
+            def empty_cache():
+                pass
+
+    writes = []
+
+    class FakeSynth:
+        @staticmethod
+        def write_dataset(name, root, scale=1.0, device="cuda"):
+            writes.append(name)
+            d = Path(root) / name
+            d.mkdir(parents=True, exist_ok=True)
+            return dict(nv=1000, ne=5_000_000, F=100, C=47, train_begin=0, train_end=80, max_degree=99, dir=str(d))
+
+        @staticmethod
+        def write_cora_dataset(root, golden):
+            writes.append("cora")
+            d = Path(root) / "cora"
+            d.mkdir(parents=True, exist_ok=True)
+            return dict(nv=2708, ne=13264, F=1433, C=7, train_begin=0, train_end=140, max_degree=168, dir=str(d))
+
+    table = "spmm_gemm_fused@128 4 20.0 1.2e11 4e10 16.0\nspmm_light@47 2 6.0 3.0e10 1e9 4.0\nsgemm@1000x128x100 6 3.0 6e9 1.2e11 1.5\n"
+    hiddens = []
+
+    def fake_trainer(arch, data_root, dataset, epochs, hidden, layers, heads, prof_from, timeout_s, times_from=None):
+        hiddens.append((arch, dataset, hidden))
+        ep = [dict(loss=3.8 - 0.1 * i, acc=0.02 * i, seconds=0.020 if i else 0.5) for i in range(epochs)]
+        return "", ep, capi.parse_prof_table(table) if prof_from is not None else {}, 250000
+
+    monkeypatch.setattr(bench, "_run_trainer", fake_trainer)
+    monkeypatch.setattr(bench, "sage_layer_step", lambda torch, ctx, L, sg, width, steps, warmup: {"ms_per_step": float(width), "value": 1.0})
+
+    def fake_gat(a2, torch, ctx, L, synth, cap):
+        if a2.scale == 0.5:
+            raise RuntimeError("boom")
+        cap.hold({"config": {"workload": "gat", "nv": 1, "ne_with_selfloops": 2, "heads": 8}, "value": 3.0, "unit": "edges/s", "ms_per_step": 8.6,
+                  "roofline": None, "breakdown_ms_per_step": {}})
+
+    monkeypatch.setattr(bench, "bench_gat_reddit", fake_gat)
+    updates = []
+    args = argparse.Namespace(scale=1.0, steps=20, warmup=3, other_configs_s=100.0, no_cpu_baseline=False, workload="gcn-products")
+    out = bench.other_configs(args, FakeTorch, None, None, FakeSynth, None, time.time() + 1000, lambda o: updates.append(dict(o)))
+    legs = ["sage_layer_128", "sage_layer_256", "gat_layer_reddit_8x8", "epoch_sage_products_hidden256", "epoch_sage_products_hidden128",
+            "epoch_gcn_products", "epoch_gat_reddit", "epoch_gcn_cora"]
+    assert all(k in out for k in legs) and len(updates) == len(legs)
+    assert out["sage_layer_256"]["ms_per_step"] == 256.0 and out["gat_layer_reddit_8x8"]["ms_per_step"] == 8.6
+    e = out["epoch_sage_products_hidden128"]
+    assert e["hidden"] == 128 and e["ms_per_epoch"] == pytest.approx(20.0) and e["steps"] == 10 and 0 < e["roofline"]["frac"] < 1
+    assert set(e["roofline"]["per_key"]) == {"spmm_gemm_fused@128", "spmm_light@47", "sgemm@1000x128x100"}
+    assert "frac_of_line_floor" in e["roofline"]["per_key"]["spmm_light@47"]
+    assert ("sage", "ogbn-products", 256) in hiddens and ("sage", "ogbn-products", 128) in hiddens and ("gcn", "ogbn-products", 128) in hiddens
+    assert writes.count("ogbn-products") == 1 and writes.count("reddit") == 1  # one dataset for the three products models
+    # no time left: every leg says so; a leg that raises costs only its own slot
+    out = bench.other_configs(args, FakeTorch, None, None, FakeSynth, None, time.time() - 1, lambda o: None)
+    assert all(out[k]["skipped"] == "budget" for k in legs)
+    args.scale = 0.5
+    out = bench.other_configs(args, FakeTorch, None, None, FakeSynth, None, time.time() + 1000, lambda o: None)
+    assert "boom" in out["gat_layer_reddit_8x8"]["error"] and out["epoch_gcn_cora"]["ms_per_epoch"] > 0

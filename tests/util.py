@@ -135,3 +135,44 @@ def dense_adj(rowptr, colidx, w=None):
         for e in range(rowptr[i], rowptr[i + 1]):
             A[i, colidx[e]] += 1.0 if w is None else w[e]
     return A
+
+
+# ---- the partition rules of host/lgraph.cpp, restated (tests/test_gpu_classes.py, tests/test_gpu_pieces.py pin the library to it) ----
+def model_split(row_bytes, t_wire, ne_own, ne_halo, rows_half, kc):
+    """model_split: one aggregation by the column split with the exchange's slices consumed in kc pieces (seconds)"""
+    e = ne_halo / (rows_half * kc) if rows_half > 0 else 0.0
+    rate = min(7.7e12, max(4.8e12, 4.8e12 + (e - 3.0) / 9.0 * 2.9e12))
+    if kc > 1:
+        rate *= 0.92
+    t_piece = (ne_halo * (row_bytes + 8) + kc * 2.0 * rows_half * row_bytes) / rate / kc
+    t = ne_own * (row_bytes + 8) / 7.5e12
+    for j in range(kc):
+        t = max(t, t_wire * (j + 1) / kc) + t_piece
+    return t
+
+
+def best_consumption(row_bytes, t_wire, ne_own, ne_halo, rows_half, K):
+    """(K' | K with the shortest modelled aggregation -- a further piece must buy 2 % --, that time)"""
+    best, best_t = 1, None
+    for kc in (k for k in range(1, K + 1) if K % k == 0):
+        t = model_split(row_bytes, t_wire, ne_own, ne_halo, rows_half, kc)
+        if best_t is None or t < best_t * 0.98:
+            best, best_t = kc, t
+    return best, best_t
+
+
+def partition_rule(n, own_deg, halo_deg, link_rows, link_gbs=100.0, length=128, K=1):
+    """LearningGraph::partition_mode's rule for a rank of n rows with own_deg / halo_deg edges per row -> "onepass" | "classes" | "split" """
+    import numpy as np
+
+    row_bytes = 4.0 * length
+    is_b = halo_deg > 0
+    ne_own, ne_halo, ne_int = int(own_deg.sum()), int(halo_deg.sum()), int(own_deg[~is_b].sum())
+    few = 10 * ne_int < ne_own + ne_halo
+    t_wire = link_rows * row_bytes / (link_gbs * 1e9)
+    t_int = 0.0 if few else ne_int * (row_bytes + 8) / 7.5e12
+    t_onepass = max(t_wire, t_int) + (ne_own + ne_halo - (0 if few else ne_int)) * (row_bytes + 8) / 7.5e12
+    _, t_split = best_consumption(row_bytes, t_wire, ne_own, ne_halo, n if few else int(is_b.sum()), max(K, 1))
+    if t_onepass <= t_split:
+        return "onepass"
+    return "split" if few else "classes"
