@@ -213,7 +213,27 @@ def cpu_baseline(sg_rowptr, sg_colidx, nv, x, gin, budget_s=30.0, want_outputs=T
                kind="port",
                sample=f"rows [0,{R}) of the same graph ({e // 2} edges incl. self loops), 1 layer fwd+bwd on the GPU "
                       f"leg's inputs, {t:.2f} s, gcc -O3 -fopenmp no -march=native (reference Makefile flags)")
-    nat = orc.native_lib()  # second figure with -march=native built on this host, same sample
+    # how the reference would run it (src/gnn/Makefile:50-54 links MKL or OpenBLAS; env.sh:3-6 sets OMP_NUM_THREADS=32 and
+    # KMP_AFFINITY=scatter): `value` keeps the port's own blocked sgemm -- the run the parity leg compares with is that one --
+    # and the same sample is timed once more with the three dense products through cblas_sgemm of libmkl_rt where it loads
+    res["gemm"] = "builtin (the port's blocked sgemm; value_mkl_sgemm: the same sample with the layer's products through cblas_sgemm)"
+    res["omp"] = {"threads": cores, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
+                  "OMP_PLACES": os.environ.get("OMP_PLACES"),
+                  "note": "reference env.sh: OMP_NUM_THREADS=32, KMP_AFFINITY=scatter (Intel runtime); libgomp's equivalent is "
+                          "OMP_PROC_BIND=spread, set by bench.py before the runtime starts unless the caller set it"}
+    try:
+        if orc.use_blas(True):
+            run(min(probe_R, nv))  # (MKL's first call builds its thread pool)
+            tb, eb, _ = run(R)
+            res["value_mkl_sgemm"] = eb / tb
+        else:
+            res["value_mkl_sgemm"] = None
+            res["gemm"] += "; no cblas library could be loaded on this host"
+    except Exception as ex:  # noqa: BLE001 -- a second figure must not cost the first
+        res["value_mkl_sgemm"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+    finally:
+        orc.use_blas(False)
+    nat = orc.native_lib()  # another figure with -march=native built on this host, same sample
     if nat is not None:
         libs["lib"] = nat
         run(min(probe_R, nv))
@@ -872,6 +892,7 @@ def main():
     import signal
 
     signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGINT})
+    os.environ.setdefault("OMP_PROC_BIND", "spread")  # (the CPU baseline's threads like the reference's KMP_AFFINITY=scatter; before any OpenMP runtime starts)
     quiet_stdout()
     guard = install_rank_guard(int(os.environ.get("RANK", "0")), max(5.0, args.deadline_s - (time.time() - T_START)))
     # (N = 1: the comparison needs the CPU baseline's run; N > 1: the strong case's comparison is its own leg)

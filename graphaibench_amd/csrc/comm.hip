@@ -802,12 +802,11 @@ extern "C" int gaib_halo_create(gaib_comm* c, const int64_t* h_send_counts, cons
       iota_i64_kernel<<<(unsigned)cdiv64(n_send, 256), 256, 0, c->ctx->stream>>>(n_send, iota);
       e = hipGetLastError();
     }
-    if (e == hipSuccess && n_send < ((int64_t)1 << 31))
-      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_send_idx, srow, iota, sslot, (int)n_send, 0, 48, c->ctx->stream);
-    else if (e == hipSuccess) e = hipErrorInvalidValue;
+    if (e == hipSuccess)
+      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_send_idx, srow, iota, sslot, n_send, 0, 48, c->ctx->stream);
     if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
     if (e == hipSuccess)
-      e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_send_idx, srow, iota, sslot, (int)n_send, 0, 48, c->ctx->stream);
+      e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_send_idx, srow, iota, sslot, n_send, 0, 48, c->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
     if (tmp) (void)hipFree(tmp);
     if (iota) (void)hipFree(iota);

@@ -404,12 +404,12 @@ int gaib_graph_ensure_rev(gaib_ctx* ctx, gaib_graph* g) {
     if (e == hipSuccess) e = hipMalloc(&ids, sizeof(uint32_t) * ne);
     if (e == hipSuccess) e = hipMalloc(&ids_out, sizeof(uint32_t) * ne);
     if (e == hipSuccess)
-      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, g->colidx, keys_out, ids, ids_out, (int)ne, 0, end_bit,
-                                             ctx->stream);
+      e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, g->colidx, keys_out, ids, ids_out, ne, 0, end_bit,
+                                             ctx->stream);  // (64-bit item count: graphs of 2^31 .. 2^32 - 1 edges, round 6)
     if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes);
     if (e == hipSuccess) {
       iota_u32_kernel<<<grid1d(ne, 256), 256, 0, ctx->stream>>>(ne, ids);
-      e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, g->colidx, keys_out, ids, ids_out, (int)ne, 0, end_bit,
+      e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, g->colidx, keys_out, ids, ids_out, ne, 0, end_bit,
                                              ctx->stream);  // radix sort is stable: ties keep the row order
     }
     if (e == hipSuccess) {
@@ -951,11 +951,11 @@ extern "C" int gaib_graph_sort_rows(gaib_ctx* ctx, gaib_graph* g) {
     while (end_bit < 64 && ((int64_t)1 << (end_bit - 32)) < nv) end_bit++;
     hipError_t e = hipMalloc(&key, sizeof(uint64_t) * ne);
     if (e == hipSuccess) e = hipMalloc(&key2, sizeof(uint64_t) * ne);
-    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, key, key2, (int)ne, 0, end_bit, ctx->stream);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, key, key2, ne, 0, end_bit, ctx->stream);  // (64-bit count)
     if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes);
     if (e == hipSuccess) {
       row_col_key_kernel<<<grid1d(nv, 4), 256, 0, ctx->stream>>>(nv, g->rowptr, g->colidx, key);
-      e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, key, key2, (int)ne, 0, end_bit, ctx->stream);
+      e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, key, key2, ne, 0, end_bit, ctx->stream);
     }
     if (e == hipSuccess) {
       key_low_kernel<<<grid1d(ne, 256), 256, 0, ctx->stream>>>(ne, key2, g->colidx);

@@ -439,6 +439,8 @@ def comm_attempt(ctx, rank: int, world: int, transport: int):
         # move on to the next transport together; the record names the transport (config.comm_init_timed_out).  (The same
         # path creates the peer-to-peer communicator, so every N > 1 run exercises it.)
         box = {}
+        hand_over = threading.Lock()  # the helper's "abandoned? else store" and the main thread's "abandon, close what is stored" are
+                                      # each one step: a communicator that finishes exactly at the deadline is used or closed, never lost
 
         def create():
             try:
@@ -446,20 +448,23 @@ def comm_attempt(ctx, rank: int, world: int, transport: int):
             except Exception as e:  # noqa: BLE001
                 box["err"] = str(e)
                 return
-            if box.get("abandoned"):  # the deadline passed while the call was inside: nobody will use this communicator --
-                try:                  # it goes at once instead of living on beside the one the run fell back to
-                    c.close()
-                except Exception:  # noqa: BLE001
-                    pass
-                return
-            box["comm"] = c
+            with hand_over:
+                if not box.get("abandoned"):
+                    box["comm"] = c
+                    return
+            try:  # the deadline passed while the call was inside: nobody will use this communicator -- it goes at once instead of
+                c.close()  # living on beside the one the run fell back to
+            except Exception:  # noqa: BLE001
+                pass
 
         limit = float(os.environ.get("GAIB_COMM_INIT_TIMEOUT_S", "90"))
         th = threading.Thread(target=create, daemon=True, name="gaib-comm-init")
         th.start()
         th.join(limit)
-        if th.is_alive():
-            box["abandoned"] = True
+        with hand_over:  # (a communicator stored in the instant between join() and this lock counts as in time)
+            if "comm" not in box and "err" not in box:
+                box["abandoned"] = True
+        if box.get("abandoned"):
             ok, err = 0, f"communicator set-up did not return within {limit:.0f} s (left behind in its thread)"
             COMM_SETUP["timed_out"].append("ipc" if transport == capi.COMM_IPC else "rccl")
         elif "comm" in box:
@@ -656,6 +661,11 @@ class BenchCase:
         torch.cuda.synchronize()
         pack_ms = (time.perf_counter() - t0) / reps * 1e3
         # max time over ranks, total edges over ranks
+        packed = True
+        if isinstance(dg.ex, AbiHaloExchanger) and dg.ex.halo.send_stats()["packs"] == 0:
+            # every peer of this plan is sent straight from the matrix (complete halos over RCCL): the timed steps ran no pack
+            # kernel, so the stand-alone figure above is not a part of them
+            pack_ms, packed = 0.0, False
         t = self.max_over_ranks(elapsed, exch_ms, pack_ms)
         e = torch.tensor([float(part.ne), float(part.n_halo), float(bytes_timed), float(part.colidx_halo.numel())],
                          dtype=torch.float64, device=self.rdev)
@@ -711,7 +721,7 @@ class BenchCase:
                     halo_rows_total=int(e[1]), halo_bytes_per_step_total=float(e[2]) / args.steps, nv=nv,
                     cut_fraction_measured=float(e[3]) / max(float(e[0]), 1.0),
                     owned_edge_spmm_ms_per_step=ms_light / args.steps, kernel_name=kernel_name, alg_bytes=alg_bytes,
-                    halo_send_stats=send_stats,
+                    halo_send_stats=send_stats, halo_pack_in_timed_steps=packed,
                     # time slices the exchanges of the timed steps travelled in / the halo-column half was consumed in
                     halo_pieces=dict(plan=dg.ex.halo.pieces, consumed=dg.lgraph.halo_pieces(D)) if isinstance(dg.ex, AbiHaloExchanger) else None,
                     avg_ms=avg_ms, launches=n_dom, parity=None,

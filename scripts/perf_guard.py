@@ -224,7 +224,7 @@ def main():
         out = ROOT / "gpurun_out"  # (what travels back from the GPU box)
         out.mkdir(exist_ok=True)
         (out / "perf_baseline.json").write_text(text)
-        print(f"baseline written: {BASE} (copy: gpurun_out/perf_baseline.json)")
+        print("baseline written: profiles/perf_baseline.json (copy: gpurun_out/perf_baseline.json -- on the GPU box only the copy comes back)")
         return 0
     whole = json.loads(BASE.read_text())
     base = whole["times"]

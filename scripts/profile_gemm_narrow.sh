@@ -23,7 +23,9 @@ if [ "$WHAT" = gemm ] || [ "$WHAT" = all ]; then
   pmc_pass gemm_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY" $G
   pmc_pass gemm_tcc "TCC_HIT_sum TCC_MISS_sum TCC_EA_WRREQ_sum TCC_EA_WRREQ_64B_sum" $G
   ( cd "$ROOT" && python3 scripts/summarize_rocprof.py stats "$OUT/gemm_stats" "$OUT/gemm_narrow_kernel_stats.csv" > "$OUT/gemm_stats_top.txt" 2>&1
-    python3 scripts/summarize_rocprof.py pmc "$OUT/gemm_narrow_pmc_raw.json" fetch="$OUT/gemm_fetch" write="$OUT/gemm_write" sq="$OUT/gemm_sq" tcc="$OUT/gemm_tcc" )
+    python3 scripts/summarize_rocprof.py pmc "$OUT/gemm_narrow_pmc_raw.json" fetch="$OUT/gemm_fetch" write="$OUT/gemm_write" sq="$OUT/gemm_sq" tcc="$OUT/gemm_tcc"
+    # per SHAPE: gemm_narrow.py launches 3 + 5 main kernels per shape, shape after shape (the split-K reduce and the probe dropped)
+    python3 scripts/summarize_rocprof.py pmcseq "$OUT/gemm_narrow_pmc_by_shape.json" 8 "splitk_reduce|probe|copy_kernel" fetch="$OUT/gemm_fetch" write="$OUT/gemm_write" sq="$OUT/gemm_sq" tcc="$OUT/gemm_tcc" )
   rm -rf "$OUT/gemm_stats" "$OUT/gemm_fetch" "$OUT/gemm_write" "$OUT/gemm_sq" "$OUT/gemm_tcc"
 fi
 if [ "$WHAT" = gat ] || [ "$WHAT" = all ]; then

@@ -2,6 +2,10 @@
 
     python scripts/summarize_rocprof.py stats <dir> <out.csv>        # *_kernel_stats.csv, our kernels only
     python scripts/summarize_rocprof.py pmc <out.json> NAME=<dir> ...  # mean counter per kernel per pass
+    python scripts/summarize_rocprof.py pmcseq <out.json> <group> <skip-regex> NAME=<dir> ...
+        # a driver that launches shape after shape through the SAME kernels (scripts/gemm_narrow.py): our dispatches in
+        # dispatch order, those matching <skip-regex> dropped (probes, the split-K reduce), cut into consecutive groups of
+        # <group> launches = one shape each -> per group the kernel name and the mean of every counter
 """
 import csv
 import glob
@@ -50,8 +54,35 @@ def pmc(out, pairs):
     print(f"wrote {out}: counters {sorted(res)}")
 
 
+def pmcseq(out, group, skip, pairs):
+    import re
+
+    rx = re.compile(skip)
+    res = {}
+    for pair in pairs:
+        name, d = pair.split("=", 1)
+        by_id = {}
+        for r in csv.DictReader(open(find(d, "_counter_collection.csv"))):
+            if ours(r["Kernel_Name"]) and not rx.search(r["Kernel_Name"]):
+                e = by_id.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"], "grid": r.get("Grid_Size"), "ctr": {}})
+                e["ctr"][r["Counter_Name"]] = e["ctr"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        seq = [by_id[k] for k in sorted(by_id)]
+        for gi in range(0, len(seq) // group):
+            chunk = seq[gi * group:(gi + 1) * group]
+            g = res.setdefault(str(gi), {"kernel": chunk[0]["kernel"], "grid": chunk[0]["grid"], "launches": len(chunk), "counters": {}})
+            if any(c["kernel"] != chunk[0]["kernel"] for c in chunk):
+                g["mixed_kernels"] = sorted({c["kernel"] for c in chunk})
+            for cname in chunk[0]["ctr"]:
+                vals = [c["ctr"].get(cname, 0.0) for c in chunk]
+                g["counters"][cname] = {"mean": sum(vals) / len(vals), "pass": name}
+    json.dump(res, open(out, "w"), indent=1)
+    print(f"wrote {out}: {len(res)} groups")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmcseq":
+        pmcseq(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5:])
     else:
         pmc(sys.argv[2], sys.argv[3:])

@@ -150,3 +150,55 @@ def test_edge_offsets_up_to_2_32(ctx):
     finally:
         ctx.set_option("spmm_heavy_threshold", 1024)
     g.close()
+
+
+def test_reverse_edges_and_row_sort_past_2_31_edges(ctx):
+    """gaib_graph_create_rect accepts up to 2^32 - 1 edges, and the two one-off radix sorts behind GAT backward
+    -- the reverse-edge permutation (gaib_graph_ensure_rev) and gaib_graph_sort_rows -- took the edge count as a 32-bit int:
+    negative from 2^31 on.  A symmetric circulant graph of 2.2 G edges (8.8 GB of column ids): the transpose of a per-edge array
+    through the permutation lands every sampled value on its reverse edge, and sort_rows leaves the sorted rows as they were."""
+    _need(120)
+    deg_half, n = 512, 2_150_000            # row i: i +- k * stride (mod n), k = 1 .. 512: symmetric, 1024 neighbours
+    deg = 2 * deg_half
+    stride = 1009
+    ne = n * deg
+    assert (1 << 31) < ne < (1 << 32)
+    ks = torch.arange(1, deg_half + 1, device="cuda", dtype=torch.int64) * stride
+    offs = torch.cat([-ks.flip(0), ks])     # [1024], ascending offsets
+    colidx = torch.empty(ne, device="cuda", dtype=torch.int32)
+    chunk = 1 << 15
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        c = (torch.arange(r0, r1, device="cuda", dtype=torch.int64).unsqueeze(1) + offs) % n
+        colidx[r0 * deg:r1 * deg] = c.sort(1).values.reshape(-1).to(torch.int32)
+        del c
+    rowptr = torch.arange(n + 1, device="cuda", dtype=torch.int64) * deg
+    g = ctx.graph(rowptr, colidx)
+    assert g.ne == ne
+    # p[e] = a value that names the edge (exact in fp32: 24 bits of row-mixed hash); pT = the transpose through rev
+    e_ids = torch.arange(ne, device="cuda", dtype=torch.int64)
+    p = ((e_ids * 2654435761) % (1 << 24)).to(torch.float32)
+    del e_ids
+    pT = torch.full((ne,), -1.0, device="cuda")
+    ctx.edge_transpose(g, p, pT)            # builds the permutation by the radix sort (ne >= 2^16)
+    ctx.sync()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    es = torch.cat([torch.randint(0, ne, (200_000,), generator=gen, device="cuda", dtype=torch.int64),
+                    torch.tensor([0, 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, ne - 2, ne - 1], device="cuda")])
+    rows, cols = es // deg, colidx[es].to(torch.int64)
+    # the reverse of edge e = (i -> c): the position of i in row c (rows are sorted)
+    rows_c = colidx.view(n, deg)[cols].to(torch.int64)           # [samples x 1024]
+    pos = (rows_c == rows.unsqueeze(1)).to(torch.int64).argmax(1)
+    assert bool((rows_c.gather(1, pos.unsqueeze(1)).squeeze(1) == rows).all())
+    rev = cols * deg + pos
+    assert torch.equal(pT[rev], p[es])     # d_out_e[rev(e)] = d_in_e[e]  (gaib_edge_transpose)
+    assert float(pT.min()) >= 0.0           # every slot written: rev is a permutation
+    del rows_c, p, pT
+    # sort_rows over 2.2 G (row, column) keys: the rows are sorted already, so nothing may move
+    before = colidx[es].clone()
+    g.sort_rows()
+    ctx.sync()
+    after = g.colidx()
+    assert torch.equal(after[es], before) and torch.equal(after[:4096], colidx[:4096]) and torch.equal(after[-4096:], colidx[-4096:])
+    g.close()
