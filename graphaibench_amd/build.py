@@ -32,6 +32,8 @@ HIPCC_FLAGS = [
     "-ffp-contract=off",
     "-Wall",
     "-Wno-unused-function",
+    # a kernel that misses its own __launch_bounds__ occupancy target is an error, not a remark (round 6: 21 sgemm tilings did)
+    "-Werror=pass-failed",
 ]
 
 

@@ -131,9 +131,16 @@ __device__ __forceinline__ void tile_store_lds(float* lds, const f4 (&regs)[TR *
 
 // WAVES_M x WAVES_N waves, each WM x WN tiles of 32x32.
 // A_KMAJOR: op(A) is stored [K][M] (transA);  B_KMAJOR: op(B) is stored [K][N] (no transB).
+// OCC: workgroups per CU the register allocation is held to -- an HONEST figure (round 6): the 256-row tilings (WAVES_M = 4)
+// stage 32-40 floats of A per lane next to 32-64 accumulators and cannot live in the 168 registers three workgroups per CU leave
+// a wave (hipcc either missed the target or spilled 47-61 registers trying, -Rpass-analysis=kernel-resource-usage); they are
+// held to two.  The build runs with -Werror=pass-failed: a tiling that misses its target does not compile.
+template <int WAVES_M, int OCC>
+constexpr int honest_occ() { return (WAVES_M == 4 && OCC > 2) ? 2 : OCC; }
+
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool AVEC, bool BVEC, int OCC,
           bool BMASK = false, bool DB = false>
-__global__ __launch_bounds__(THREADS, OCC) void sgemm_mfma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(THREADS, (honest_occ<WAVES_M, OCC>())) void sgemm_mfma_kernel(GemmArgs g) {
   static_assert(!BMASK || B_KMAJOR, "the B mask is implemented for row-major [K][N] B operands");
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int BM = WAVES_M * WM * 32;
@@ -776,7 +783,10 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
   // more resident blocks hide the staging / epilogue phases of one block under another's MFMAs.
 #define GAIB_GEMM_LAUNCH(AV, BV, OCC)                                                    \
   sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, AV, BV, OCC><<<grid, THREADS, 0, ctx->stream>>>(g)
-  const int occ = ctx->sgemm_variant == 2 ? 2 : ((ctx->sgemm_variant == 4 || (ctx->sgemm_variant >= 10 && ctx->sgemm_variant < 20)) ? 4 : 3);
+  // (sgemm_variant 2: two workgroups per CU; default three.  The four-per-CU and LDS-double-buffered experiments of rounds 1-2
+  // are gone: the former spilled on every 128-column tiling, the latter's 70-90 KB of LDS held every tiling to one or two
+  // workgroups per CU whatever was asked for -- 21 instantiations that missed their own occupancy target)
+  const int occ = ctx->sgemm_variant == 2 ? 2 : 3;
   if constexpr (AK && BKM) {
     if (g.bmask) {  // (the entry point only takes this path with 16-B aligned operands)
       sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 3, true><<<grid, THREADS, 0, ctx->stream>>>(g);
@@ -790,15 +800,8 @@ int launch(gaib_ctx* ctx, GemmArgs g, bool avec, bool bvec) {
       return GAIB_OK;
     }
   }
-  if (avec && bvec && (ctx->sgemm_variant == 20 || ctx->sgemm_variant == 21)) {
-    // experimental: LDS double buffering (one barrier per K-step); 20 -> 2 workgroups/CU, 21 -> 3
-    if (ctx->sgemm_variant == 21)
-      sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 3, false, true><<<grid, THREADS, 0, ctx->stream>>>(g);
-    else
-      sgemm_mfma_kernel<WAVES_M, WAVES_N, WM, WN, AK, BKM, true, true, 2, false, true><<<grid, THREADS, 0, ctx->stream>>>(g);
-  } else if (avec && bvec) {
-    if (occ == 4) GAIB_GEMM_LAUNCH(true, true, 4);
-    else if (occ == 3) GAIB_GEMM_LAUNCH(true, true, 3);
+  if (avec && bvec) {
+    if (occ == 3) GAIB_GEMM_LAUNCH(true, true, 3);
     else GAIB_GEMM_LAUNCH(true, true, 2);
   } else if (avec) GAIB_GEMM_LAUNCH(true, false, 2);
   else if (bvec) GAIB_GEMM_LAUNCH(false, true, 2);

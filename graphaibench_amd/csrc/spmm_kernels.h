@@ -138,8 +138,11 @@ int launch_w64_u(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     size_t lds = sizeof(float) * HEAVY_WAVES * CT * 64 * VEC;
     ProfScope ps(ctx, "spmm_heavy", gaib_alg_spmm_bytes((double)g->heavy_edges, (double)g->n_heavy, a.ncols, WMODE == 0 ? 0 : 4,
                                                          a.accumulate ? 2 : 1), 2.0 * g->heavy_edges * a.ncols, a.ncols);
-    spmm_heavy_kernel<VEC, CT, WMODE, U, BUF, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
-                                                     ctx->stream>>>(h);
+    // (a 1024-thread workgroup leaves a wave 128 VGPRs: the multi-head edge-weight modes -- a weight per head and edge next to
+    // the gathers -- keep half as many rows in flight there, or they spill 52-61 registers; 16 waves per row hide the rest)
+    constexpr int UH = (WMODE >= 3 && U * CT * VEC > 16) ? (U / 2 > 4 ? U / 2 : 4) : U;
+    spmm_heavy_kernel<VEC, CT, WMODE, UH, BUF, PART><<<dim3((unsigned)g->n_heavy), HEAVY_WAVES * 64, lds,
+                                                      ctx->stream>>>(h);
     GAIB_LAUNCH_CHECK();
   }
   a.nblocks = (int)cdiv64(a.n_rows, 4);
@@ -173,12 +176,24 @@ int launch_w64(gaib_ctx* ctx, const gaib_graph* g, SpmmArgs a) {
     gm = 3;
     a.col = a.col_flagged;
   }
-  const bool u8 = ctx->spmm_unroll == 8 && U > 8;
+  // option spmm_unroll = 8: eight gathers in flight where the default is sixteen.  (Only THERE is the 8-deep form instantiated:
+  // as a dead branch next to U = 4 it gave the wide-lane kernels eight 8-register gathers they never run -- and spilled
+  // 82-236 registers doing it, round 6's spill check)
+  if constexpr (U > 8) {
+    if (ctx->spmm_unroll == 8) {
+      switch (gm) {
+        case 0: return launch_w64_u<VEC, CT, WMODE, 8, 0>(ctx, g, a);
+        case 2: return launch_w64_u<VEC, CT, WMODE, 8, 2>(ctx, g, a);
+        case 3: return launch_w64_u<VEC, CT, WMODE, 8, 3>(ctx, g, a);
+        default: return launch_w64_u<VEC, CT, WMODE, 8, 1>(ctx, g, a);
+      }
+    }
+  }
   switch (gm) {
-    case 0: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 0>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 0>(ctx, g, a);
-    case 2: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 2>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 2>(ctx, g, a);
-    case 3: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 3>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 3>(ctx, g, a);
-    default: return u8 ? launch_w64_u<VEC, CT, WMODE, 8, 1>(ctx, g, a) : launch_w64_u<VEC, CT, WMODE, U, 1>(ctx, g, a);
+    case 0: return launch_w64_u<VEC, CT, WMODE, U, 0>(ctx, g, a);
+    case 2: return launch_w64_u<VEC, CT, WMODE, U, 2>(ctx, g, a);
+    case 3: return launch_w64_u<VEC, CT, WMODE, U, 3>(ctx, g, a);
+    default: return launch_w64_u<VEC, CT, WMODE, U, 1>(ctx, g, a);
   }
 }
 
@@ -215,7 +230,15 @@ template <int VEC, int WMODE>
 int dispatch_ct(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a, int lanes) {
   if (lanes <= 64) return launch_w64<VEC, 1, WMODE>(ctx, g, a);
   if (lanes <= 128) return launch_w64<VEC, 2, WMODE>(ctx, g, a);
-  return launch_w64<VEC, 4, WMODE>(ctx, g, a);
+  // 16-byte lanes never take four column tiles: 16 accumulator floats per lane next to 4 gathers of 16 floats each spilled
+  // 205-354 VGPRs in every such kernel (round 5's code-object notes); rows of 513 .. 1024 columns run as 512-column slabs
+  // of two tiles instead (dispatch_vec), each slab walking the row's edge list once more -- 8 B per edge next to 2 KB of row
+  if constexpr (VEC == 4) {
+    gaib_set_error("spmm: %d 16-byte lanes in one launch (internal: the slab width is 128 lanes at VEC = 4)", lanes);
+    return GAIB_ERR_INVALID;
+  } else {
+    return launch_w64<VEC, 4, WMODE>(ctx, g, a);
+  }
 }
 
 template <int VEC, int WMODE>
@@ -265,8 +288,8 @@ int dispatch_vec(gaib_ctx* ctx, const gaib_graph* g, const SpmmArgs& a0, int len
     if (vec == 2) return dispatch_sub<2, WMODE>(ctx, g, a, lanes);
     return dispatch_sub<1, WMODE>(ctx, g, a, lanes);
   }
-  // one launch covers up to 256 lanes' worth of columns; wider rows are done in column slabs
-  const int slab = 256 * vec;
+  // one launch covers up to 256 lanes' worth of columns (128 lanes of 16 B: see dispatch_ct); wider rows are done in column slabs
+  const int slab = (vec == 4 ? 128 : 256) * vec;
   for (int c0 = 0; c0 < len; c0 += slab) {
     SpmmArgs a = a0;
     a.in = a0.in + c0;
