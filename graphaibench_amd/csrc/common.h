@@ -93,6 +93,7 @@ struct gaib_ctx {
   int gat_fused_bwd;         // the one-pass edge side of GAT backward: -1 = dense graphs (aggregation's rule), 0 never, 1 whenever the shape fits
   int gat_fused_fwd;         // the one-sweep forward (scores + online softmax + aggregation): -1 = dense graphs, 0 never, 1 whenever the shape fits
   int gat_fused_unroll;      // gathers in flight per lane and table in the fused backward sweep: 4 (default; measured 10.7 vs 10.9 ms) or 8
+  int gat_bwd_pk;            // one-sweep GAT backward: 1 = the packed-math kernel over the element-interleaved table (round 6), 0 (default) = the round-5 kernel
   int gat_interleave;        // one-sweep GAT backward: 1 = gather from ONE interleaved [h | grad | records] row per vertex (built per call), 0 = three tables
   int gat_chunk_xcd;         // one-sweep GAT kernels: 1 = every XCD walks a contiguous eighth of the column-block-ordered chunk list, 0 = round robin
   int graph_rev_search;      // 1 = reverse-edge permutation by per-edge binary search (the reference's way) instead of the sort

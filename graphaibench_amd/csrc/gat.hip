@@ -1041,6 +1041,187 @@ __global__ __launch_bounds__(256) void gat_bwd_fused_chunk_kernel(
   }
 }
 
+// ---- the same sweep on a VALU diet (round 6) ----------------------------------------------------------------------------
+// Counters of gat_bwd_fused_chunk_kernel<16, 8, 4, true> at the reddit shape (profiles/r06/gat_bwd_sq.json): 2.48 G VALU
+// instructions per launch = 1 324 per 64-edge chunk, SQ_ACTIVE_INST_VALU = 2.53 G quad-cycles -- 4.1 ms of pure VALU issue on
+// 1 024 SIMDs at 2.4 GHz, which IS the 4.4-4.7 ms the sweep takes with every gather served by the L2 (gat_l2_ceiling.py):
+// the kernel is VALU-bound.  Its ISA shows where the instructions go: hipcc packs the e-side and the r-side chains into
+// v_pk_*_f32 pairs, and 461 of the 1 389 VALU instructions are v_mov_b32 marshalling operands into aligned register pairs;
+// the sums over a head's lanes are v_mov_b32_dpp + add (the packed add cannot take a DPP operand) behind a zero-initialising
+// move each; three 64-bit row addresses per edge cost a v_mad_u64_u32 + v_lshl_add_u64 each.  Here the data layout makes the
+// pairs natural instead:
+//   * the table row of a vertex interleaves h and grad ELEMENT by element: lane sl reads (h0 g0 h1 g1 | h2 g2 h3 g3), so
+//     (h_k, g_k) is an aligned register pair as loaded;
+//   * chain P = (dpe, dpr) = sum_k (grad_i[k], h_i[k]) * (h_c[k], grad_c[k]) and chain Q = (sr_c, sl_c) = sum_k (a_r[k], a_l[k]) *
+//     (h_c[k], h_c[k]) are four packed multiply-adds each, in d4()'s order of additions (same bits), with loop-invariant left
+//     operands; (t_e, t_r) = (sl_i, sr_i) + Q and everything downstream stays in pairs without a move;
+//   * the sums over a head's lanes are v_add_f32_dpp, one instruction per value and stage (inline: the compiler does not fold a
+//     DPP move into an add whose other operand is not the identity);
+//   * one 32-bit byte offset per edge addresses all three loads of its row (tables below 4 GB; else the kernel above);
+//   * the softmax backward in its short form g = p (dp - rowdot) -- the reference's p (1 - p) dp - (rowdot - p dp) p
+//     (math_functions.cpp:496-514) multiplied out; one rounding fewer per term, not the same bits.
+// ~41 VALU instructions per edge step instead of ~80 (898 against 1 389 in the kernel's ISA at 8 heads x 8).  RECOMP form only
+// (the attention is formed again from the row statistics), heads of at most 16 lanes.
+// MEASURED (reddit shape, 8 heads x 8, scripts/gat_l2_ceiling.py, profiles/r06/gat_pk_*): with every gather served by the L2
+// (column ids >> 8) the backward call drops from 4.31 to 3.95 ms -- and at the REAL column ids it does not move: 6.27 against
+// 6.25 ms.  There the sweep draws 43 GB per launch through the L2 -> fabric boundary at 7 TB/s (0.82 of the cache-resident gather
+// rate, L2 hit rate 0.42): the VALU work had been hiding under the gathers all along.  So the kernel is an OPTION (gat_bwd_pk = 1),
+// off by default -- it costs the table build (0.06 ms at the reddit shape, 0.45 ms at the products shape) and buys nothing where
+// the tables do not fit the L2s; tests/test_gpu_ops.py runs both.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// T2[v] = [(h0 g0 h1 g1 ...) 2 len | records 4 H]: h and grad of vertex v element by element, then its (rowdot, M, 1/S, 0) records
+__global__ __launch_bounds__(256) void gat_interleave_pairs_kernel(int64_t nv, int len4, int H, const f4* feat, const f4* grad,
+                                                                   const f4* rec, f4* T) {
+  const int ldt4 = 2 * len4 + H;
+  const int64_t total = nv * ldt4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / ldt4;
+    const int k = (int)(i - v * ldt4);
+    if (k < 2 * len4) {
+      const f4 h = feat[v * len4 + (k >> 1)], g = grad[v * len4 + (k >> 1)];
+      T[i] = (k & 1) ? f4{h[2], g[2], h[3], g[3]} : f4{h[0], g[0], h[1], g[1]};
+    } else {
+      T[i] = rec[v * H + k - 2 * len4];
+    }
+  }
+}
+
+// a, b, c, d <- their sums over the aligned group of LH lanes (LH = 1 .. 16 inside a 16-lane row); every lane gets them.
+// v_add_f32_dpp reads its permuted operand through the DPP path: a VGPR written by the VALU instruction right before needs two
+// wait states there, and the compiler's hazard recogniser does not look inside inline assembly -- hence the leading s_nop; the
+// later stages read registers written four instructions earlier.
+template <int LH>
+__device__ __forceinline__ void lanes_sum4_dpp(float& a, float& b, float& c, float& d) {
+  static_assert(LH == 1 || LH == 2 || LH == 4 || LH == 8 || LH == 16, "aligned power-of-two groups inside a 16-lane row");
+#define GAIB_DPP4(CTRL)                                                                   \
+  asm volatile("s_nop 1\n\t"                                                               \
+               "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+               "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+               "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+               "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf"              \
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+  if constexpr (LH >= 2) GAIB_DPP4("quad_perm:[1,0,3,2]");
+  if constexpr (LH >= 4) GAIB_DPP4("quad_perm:[2,3,0,1]");
+  if constexpr (LH >= 8) GAIB_DPP4("row_half_mirror");
+  if constexpr (LH >= 16) GAIB_DPP4("row_mirror");
+#undef GAIB_DPP4
+}
+
+template <int G, int H, int U>
+__global__ __launch_bounds__(256) void gat_bwd_fused_pk_kernel(int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase,
+                                                               const uint32_t* chunk_start, const int64_t* rowptr, const uint32_t* col,
+                                                               int len, const float* T, const float* alpha_l, const float* alpha_r,
+                                                               float eps, float* out_partial, float* rc_partial, int per_xcd) {
+  constexpr int LH = G / H;  // lanes per head
+  static_assert(LH <= 16, "a head's lanes sit inside one 16-lane DPP row");
+  using CL = ChunkLanes<G>;
+  constexpr int NG = CL::NG;
+  int64_t blk = blockIdx.x;
+  if (per_xcd > 0) blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t c = blk * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & (G - 1), gbase = lane & ~(G - 1);
+  const int64_t row = chunk_row[c];
+  const int64_t eb = chunk_ebase[c];
+  const int64_t rb = rowptr[row];
+  const int64_t rem = rowptr[row + 1] - eb;
+  const int n = rem < 64 ? (int)rem : 64;
+  const int my_e = CL::held_edge(lane, 0), my_e1 = CL::held_edge(lane, 1);
+  const uint32_t cl = col[eb + (my_e < n ? my_e : 0)];
+  uint32_t cl1 = 0;
+  if constexpr (G == 32) cl1 = col[eb + (my_e1 < n ? my_e1 : 0)];
+  const int head = sl / LH;
+  const uint32_t ldb = (uint32_t)(2 * len + 4 * H) * 4u;        // bytes of a table row
+  const uint32_t lane_off = (uint32_t)sl * 32u;                 // this lane's (h0 g0 h1 g1 h2 g2 h3 g3)
+  const uint32_t rec_off = (uint32_t)(2 * len) * 4u + (uint32_t)head * 16u;
+  const char* Tb = reinterpret_cast<const char*>(T);
+  auto row_at = [&](uint32_t v, uint32_t off) { return *reinterpret_cast<const f4*>(Tb + (size_t)(v * ldb + off)); };
+  const uint32_t ri = (uint32_t)row;
+  const f4 qi0 = row_at(ri, lane_off), qi1 = row_at(ri, lane_off + 16u), reci = row_at(ri, rec_off);
+  const f4 al4 = *reinterpret_cast<const f4*>(alpha_l + sl * 4);
+  const f4 ar4 = *reinterpret_cast<const f4*>(alpha_r + sl * 4);
+  // loop-invariant left operands of the two chains: (grad_i[k], h_i[k]) and (a_r[k], a_l[k])
+  const f2 GH[4] = {{qi0[1], qi0[0]}, {qi0[3], qi0[2]}, {qi1[1], qi1[0]}, {qi1[3], qi1[2]}};
+  const f2 RL[4] = {{ar4[0], al4[0]}, {ar4[1], al4[1]}, {ar4[2], al4[2]}, {ar4[3], al4[3]}};
+  // (sl_i, sr_i): the row's own dots, formed like the columns' below
+  f2 SI;
+  {
+    float a = __builtin_fmaf(al4[3], qi1[2], __builtin_fmaf(al4[2], qi1[0], __builtin_fmaf(al4[1], qi0[2], al4[0] * qi0[0])));
+    float b = __builtin_fmaf(ar4[3], qi1[2], __builtin_fmaf(ar4[2], qi1[0], __builtin_fmaf(ar4[1], qi0[2], ar4[0] * qi0[0])));
+    float z0 = 0.f, z1 = 0.f;
+    lanes_sum4_dpp<LH>(a, b, z0, z1);
+    SI = f2{a, b};
+  }
+  const float rd_i = reci[0], m_i = reci[1], is_i = reci[2];
+  const f2 eps2 = {eps, eps};
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  f2 S = {0.f, 0.f};  // (partial row sum of g, partial column sum of g)
+#pragma unroll
+  for (int j = 0; j < G; j += U) {
+    if (j * NG >= n) break;  // (wave-uniform: no edge of the chunk is left for any group)
+    f4 q0[U], q1[U], rc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t cj = (uint32_t)CL::step_value((int)cl, (int)cl1, lane, j + u);
+      const uint32_t base = cj * ldb;
+      q0[u] = *reinterpret_cast<const f4*>(Tb + (size_t)(base + lane_off));
+      q1[u] = *reinterpret_cast<const f4*>(Tb + (size_t)(base + lane_off + 16u));
+      rc[u] = *reinterpret_cast<const f4*>(Tb + (size_t)(base + rec_off));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first one is consumed
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = CL::step_edge(lane, j + u) < n;
+      const f2 e0 = {q0[u][0], q0[u][1]}, e1 = {q0[u][2], q0[u][3]}, e2 = {q1[u][0], q1[u][1]}, e3 = {q1[u][2], q1[u][3]};
+      // P = (dpe, dpr) = (<grad_i, h_c>, <h_i, grad_c>)
+      f2 P = GH[0] * e0;
+      P = __builtin_elementwise_fma(GH[1], e1, P);
+      P = __builtin_elementwise_fma(GH[2], e2, P);
+      P = __builtin_elementwise_fma(GH[3], e3, P);
+      // Q = (sr_c, sl_c) = (<a_r, h_c>, <a_l, h_c>)
+      f2 Q = RL[0] * f2{e0[0], e0[0]};
+      Q = __builtin_elementwise_fma(RL[1], f2{e1[0], e1[0]}, Q);
+      Q = __builtin_elementwise_fma(RL[2], f2{e2[0], e2[0]}, Q);
+      Q = __builtin_elementwise_fma(RL[3], f2{e3[0], e3[0]}, Q);
+      float dpe = P[0], dpr = P[1], src = Q[0], slc = Q[1];
+      lanes_sum4_dpp<LH>(dpe, dpr, src, slc);
+      const f2 Tt = SI + f2{src, slc};  // pre-activation scores of (i -> c) and (c -> i)
+      const f2 Tm = eps2 * Tt;
+      const bool pe = Tt[0] > 0.0f, pr = Tt[1] > 0.0f;
+      const float le = pe ? Tt[0] : Tm[0], lr = pr ? Tt[1] : Tm[1];
+      const float a = __expf(le - m_i) * is_i;
+      const float b = __expf(lr - rc[u][1]) * rc[u][2];
+      // g = p (dp - rowdot) * leaky-relu'
+      const f2 Gv = f2{a * (dpe - rd_i), b * (dpr - rc[u][0])} * f2{pe ? 1.0f : eps, pr ? 1.0f : eps};
+      if (live) {  // (lanes past the end of a short chunk looked at the chunk's first edge: nothing of it is added)
+        S += Gv;
+        acc[0] = __builtin_fmaf(b, e0[1], acc[0]);
+        acc[1] = __builtin_fmaf(b, e1[1], acc[1]);
+        acc[2] = __builtin_fmaf(b, e2[1], acc[2]);
+        acc[3] = __builtin_fmaf(b, e3[1], acc[3]);
+      }
+    }
+  }
+  float s_e = S[0], s_r = S[1];
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+    s_e += __shfl_xor(s_e, o, 64);
+    s_r += __shfl_xor(s_r, o, 64);
+  }
+  const int64_t slot = (int64_t)chunk_start[row] + (eb - rb) / 64;
+  if (gbase == 0) {
+    *reinterpret_cast<f4*>(out_partial + slot * len + sl * 4) = acc;
+    if ((sl & (LH - 1)) == 0) {
+      rc_partial[slot * 2 * H + head] = s_e;      // partial row sum of g    (-> alpha_l gradient)
+      rc_partial[slot * 2 * H + H + head] = s_r;  // partial column sum of g (-> alpha_r gradient)
+    }
+  }
+}
+
 // ---- forward in ONE sweep: scores, edge softmax and aggregation over the ordered chunk list ---------------------------
 // GAT_Aggregator::aggregate (gat_aggregator.cpp:57-97) staged = per-vertex dots, a row-owner pass writing p [ne][H]
 // (two sweeps over long rows), then the aggregation reading p.  Here a chunk's wave gathers the rows h_c once, forms
@@ -1561,6 +1742,17 @@ static bool gat_fused_shape(int len, int heads) {
     else { GAIB_GAT_BY_HEADS(32, M, M(32, 16)) }                \
   } while (0)
 
+// the packed-math sweep for the shapes it covers (a head of at most 16 lanes); the others never get here (see `pk` below)
+template <int G, int H>
+static void launch_bwd_pk(unsigned grid, hipStream_t st, int64_t n_chunks, const uint32_t* chunk_row, const uint32_t* chunk_ebase,
+                          const uint32_t* chunk_start, const int64_t* rowptr, const uint32_t* col, int len, const float* T,
+                          const float* alpha_l, const float* alpha_r, float eps, float* out_partial, float* rc_partial, int per_xcd) {
+  if constexpr (G / H <= 16) {
+    gat_bwd_fused_pk_kernel<G, H, 4><<<grid, 256, 0, st>>>(n_chunks, chunk_row, chunk_ebase, chunk_start, rowptr, col, len, T, alpha_l,
+                                                          alpha_r, eps, out_partial, rc_partial, per_xcd);
+  }
+}
+
 // The fused edge side of backward (gat_bwd_fused_chunk_kernel).  Shapes: gat_fused_shape(); otherwise, or with the option off (option
 // gat_fused_bwd: 0 = never; -1 / 1 = whenever the shape fits), GAIB_ERR_UNSUPPORTED is returned and nothing was touched: the
 // caller runs the staged entry points.
@@ -1704,9 +1896,14 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
   const size_t n_v = up4((size_t)g->nv * heads);
   const size_t n_op = up4((size_t)g->n_chunks * len), n_rc = up4((size_t)g->n_chunks * 2 * heads);
   // option gat_interleave: the three per-vertex tables of the sweep as one [h | grad | records] row per vertex
-  const bool inter = ctx->gat_interleave == 1 && d_row_stats != nullptr;
   const int ldt = 2 * len + 4 * heads;
-  const size_t n_t = inter ? up4((size_t)g->nv * ldt) + 64 : 0;  // (+ 64 floats: the table starts on a 256-B boundary)
+  // round 6: the packed-math sweep (gat_bwd_fused_pk_kernel) over a table whose rows interleave h and grad element by element
+  // (option gat_bwd_pk = 1; off by default, see the kernel): attention formed again from the row statistics, heads of at most
+  // 16 lanes, a table below 4 GB (32-bit byte offsets)
+  const bool pk = d_row_stats != nullptr && ctx->gat_bwd_pk == 1 && (len / 4) / heads <= 16 &&
+                  (uint64_t)g->nv * (uint64_t)ldt * 4u < ((uint64_t)1 << 32);
+  const bool inter = !pk && ctx->gat_interleave == 1 && d_row_stats != nullptr;
+  const size_t n_t = (inter || pk) ? up4((size_t)g->nv * ldt) + 64 : 0;  // (+ 64 floats: the table starts on a 256-B boundary)
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (7 * n_v + n_op + n_rc + (size_t)nblocks * 2 * len + n_t)));
   f4* rec = reinterpret_cast<f4*>(ctx->ws);  // [nv][H] 16-byte records (first: alignment)
   float* rowdot = (float*)ctx->ws + 4 * n_v;
@@ -1747,6 +1944,19 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
     per_xcd = (int)cdiv64(grid, 8);
     grid = (unsigned)per_xcd * 8u;
   }
+  if (pk) {
+    const int64_t tot4 = g->nv * (int64_t)(ldt / 4);
+    gat_interleave_pairs_kernel<<<(unsigned)std::min<int64_t>(cdiv64(tot4, 256), (int64_t)ctx->num_cus * 16), 256, 0, ctx->stream>>>(
+        g->nv, len / 4, heads, reinterpret_cast<const f4*>(d_feat), reinterpret_cast<const f4*>(d_grad), rec,
+        reinterpret_cast<f4*>(T));
+    GAIB_LAUNCH_CHECK();
+#define GAIB_FBP(GG, HH)                                                                                                        \
+  launch_bwd_pk<GG, HH>(grid, ctx->stream, g->n_chunks, g->chunk_row, g->chunk_ebase, g->chunk_start, g->rowptr, g->colidx, len, T, \
+                        d_alpha_l, d_alpha_r, epsilon, out_partial, rc_partial, per_xcd)
+    GAIB_GAT_DISPATCH(GAIB_FBP);
+#undef GAIB_FBP
+    GAIB_LAUNCH_CHECK();
+  } else {
   // edges in flight per group: 8 or 4 (option gat_fused_unroll)
 #define GAIB_FB_U(GG, HH, UU, RC)                                                                                          \
   gat_bwd_fused_chunk_kernel<GG, HH, UU, RC><<<grid, 256, 0, ctx->stream>>>(                                               \
@@ -1768,6 +1978,7 @@ extern "C" int gaib_gat_backward_fused(gaib_ctx* ctx, gaib_graph* g, int len, in
 #undef GAIB_FB
 #undef GAIB_FB_U
   GAIB_LAUNCH_CHECK();
+  }
 #define GAIB_FRD(GG)                                                                                                   \
   gat_fused_reduce_kernel<GG><<<rowgrid(g->nv), 256, 0, ctx->stream>>>(g->nv, len, heads, g->chunk_start, out_partial, \
                                                                        rc_partial, d_grad_out, rs, cs)

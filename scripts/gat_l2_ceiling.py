@@ -40,6 +40,10 @@ def main():
     ar = torch.randn(D, device="cuda", generator=gen) * 0.2
     ctx.set_option("gat_fused_fwd", 1)
     ctx.set_option("gat_fused_bwd", 1)
+    import os
+    for kv in filter(None, os.environ.get("GAIB_OPTS", "").split(",")):  # e.g. GAIB_OPTS=gat_bwd_pk=0: round 5's backward kernel
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_.strip(), int(v_))
     shifts = [int(v) for v in sys.argv[1:]] or [0, 2, 3, 4, 5, 6, 8]  # (a counter pass names the two shifts it wants: 0 5)
     for k in shifts:
         cols = (ci.to(torch.int64) >> k).to(torch.int32)  # rows stay sorted; duplicates are fine for a timing

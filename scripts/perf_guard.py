@@ -147,6 +147,35 @@ def dominant_kernel_normalised(steps=10):
     return k_ms, copy, k_ms * 1e-3 * copy
 
 
+def wide_row_aggregation(res):
+    """aggregations of rows wider than 256 columns -- the reddit input layer's 602 features (8-byte lanes,
+    four column tiles + a 90-column slab) and 1 024 columns (16-byte lanes: since round 6 two 512-column slabs of two tiles
+    each, where the four-tile kernels spilled 200-350 registers).  Each line also names its rate over SURVEY 8(d)'s bytes; the
+    guard fails a line below 0.85 of 8 TB/s x the share of the gathers the caches do not serve ... held simply to
+    `min_frac` of the algorithmic rate recorded with the baseline (the tables live in the Infinity Cache: the rate is a WORK
+    rate, as on the GAT lines)."""
+    ctx = capi.Context(0)
+    sg = synth.make("reddit", device="cuda")
+    g0 = ctx.graph(sg.rowptr, sg.colidx)
+    g = g0.add_selfloop()
+    g0.close()
+    nv, ne = g.nv, g.ne
+    out = {}
+    for d in (602, 1024):
+        x = torch.randn(nv, d, device="cuda")
+        y = torch.empty(nv, d, device="cuda")
+        ms = ev_time(lambda: ctx.spmm(g, capi.W_GCN, x, y), iters=4, warm=2)
+        alg = ne * (4.0 * d + 8) + nv * 4.0 * d + (nv + 1) * 8
+        res[f"aggregation D = {d}, reddit shape (GCN weights)"] = ms
+        out[d] = alg / (ms * 1e-3) / 1e12
+        print(f"    aggregation D = {d}: {ms:.2f} ms = {out[d]:.2f} TB/s of algorithmic bytes", flush=True)
+        del x, y
+    g.close()
+    ctx.close()
+    torch.cuda.empty_cache()
+    return out
+
+
 def cora_epoch_ms():
     data = Path("/tmp/gaib_data_pg")
     subprocess.run([sys.executable, str(ROOT / "scripts" / "make_synth_dataset.py"), "cora", str(data)], check=True,
@@ -207,6 +236,7 @@ def main():
     res["GCN 128->47 layer step, products shape"] = layer_step(L.GCN, "ogbn-products", 128, 47, True)
     res["GAT 64->64 8 heads layer step, reddit shape"] = layer_step(L.GAT, "reddit", 64, 64, True, heads=8)
     gat_fused_vs_staged(res)
+    wide_tbs = wide_row_aggregation(res)
     res["cora GCN 2-layer epoch (trainer, recorded epochs)"] = cora_epoch_ms()
     k_ms, copy_gbs, norm = dominant_kernel_normalised()
     for k, v in res.items():
@@ -217,7 +247,7 @@ def main():
               "dominant kernel x in-run stream-copy rate (GB of copy traffic per launch)": norm}
     if args.update or not BASE.exists():
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
-        text = json.dumps({"commit": commit or "?", "unit": "ms", "times": res,
+        text = json.dumps({"commit": commit or "?", "unit": "ms", "times": res, "wide_row_aggregation_tb_s_algorithmic": {str(k): v for k, v in wide_tbs.items()},
                            "strict": {"tol": args.strict_tol, "values": strict,
                                       "measured_with": {"kernel_ms": k_ms, "stream_copy_gbs": copy_gbs}}}, indent=1) + "\n"
         BASE.write_text(text)

@@ -325,12 +325,15 @@ def test_gat_forward_fused_and_backward_from_row_stats(ctx, heads, hub):
 
 @pytest.mark.parametrize("d,heads,hub", [(32, 1, 0), (32, 8, 900), (32, 4, 0), (64, 1, 900), (64, 8, 0), (128, 1, 0), (128, 8, 1400),
                                          (128, 16, 0), (128, 2, 700)])
-def test_gat_one_sweep_at_every_row_width(ctx, d, heads, hub):
+@pytest.mark.parametrize("pk", [0, 1])
+def test_gat_one_sweep_at_every_row_width(ctx, d, heads, hub, pk):
     """round 5: the one-sweep forward and backward at len 32 / 64 / 128 -- 8, 16 or 32 lanes per edge, the
     chunk's column ids in DPP reach (ChunkLanes) -- against the oracle's aggregate / d_aggregate head by head
     (gat_aggregator.cpp:57-200; its len limit of 128: global.h:58): forward + row statistics, backward from the statistics AND
     from the attention array (the p[rev e] form), deterministic, and the score signs the alpha-gradient analysis imposes.
-    The graph has rows of 1..9 edges, and with `hub` rows of many chunks whose last chunk is short."""
+    The graph has rows of 1..9 edges, and with `hub` rows of many chunks whose last chunk is short.
+    pk = 1 (round 6): the backward from the statistics through gat_bwd_fused_pk_kernel -- the packed-math sweep over the
+    element-interleaved table (option gat_bwd_pk; heads of at most 16 lanes, else the option changes nothing)."""
     rp, ci = random_graph(1300, 7, seed=3 * d + heads, power_law=True, hub_deg=hub)
     g_o, g_d = make(ctx, rp, ci, selfloop=True)
     h = feat(g_o.nv, d, 1)
@@ -343,6 +346,7 @@ def test_gat_one_sweep_at_every_row_width(ctx, d, heads, hub):
     fl = LONG_SUM_FLOOR if hub else 1e-6
     ctx.set_option("gat_fused_fwd", 1)
     ctx.set_option("gat_fused_bwd", 1)
+    ctx.set_option("gat_bwd_pk", pk)
     try:
         runs = []
         for _ in range(2):
@@ -360,6 +364,7 @@ def test_gat_one_sweep_at_every_row_width(ctx, d, heads, hub):
     finally:
         ctx.set_option("gat_fused_fwd", -1)
         ctx.set_option("gat_fused_bwd", -1)
+        ctx.set_option("gat_bwd_pk", 0)
     for a, b in zip(*runs):
         assert torch.equal(a, b)  # fixed summation order
     out, stats, go, lg, rg, go_p, lg_p, rg_p = runs[0]
