@@ -367,10 +367,16 @@ template <bool BMASK> struct TnDepth { static constexpr int PD = BMASK ? 4 : 8; 
 // columns a lane carries is free in this kernel as long as the epilogue stores them where they belong, so that lane and its
 // neighbour both produce the overlapping columns -- the same sums in the same order, stored twice.  Plain form only (an output
 // layer has no activation, hence no mask).
-template <bool BMASK, int QM, int QN, bool NUNAL = false>
-__global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
+// NB < 4 (round 6: the 47 output classes, N <= 32 NB or 64): the 4 i + t column map gives a 47-wide B twelve useful lanes of 32 in
+// every one of its four tiles -- 16 MFMAs per row pair for what two tiles hold, 0.51 ms of matrix-core time at 128 x 47 x 2.45 M
+// where the bytes need 0.29 (profiles/r06/gemm_narrow_pmc.json: 0.27 of the roof).  Here tile b of B holds the columns 32 b + i:
+// a lane reads B[k][i] and B[k][32 + i] with two 4-byte loads (coalesced: 128 + 60 bytes of the 188-byte row), the row pair
+// costs 4 x NB MFMAs, and the accumulators -- 128 registers instead of 256 -- leave room for two waves per SIMD.  Plain form.
+template <bool BMASK, int QM, int QN, bool NUNAL = false, int NB = 4>
+__global__ __launch_bounds__(256, (NB < 4 ? 2 : 1)) void sgemm_tn_reg_kernel(GemmArgs g) {
   static_assert(!(BMASK && NUNAL), "the masked form writes float4s back: N must be a multiple of 4 there");
-  constexpr int TN_PD = TnDepth<BMASK>::PD;
+  static_assert(NB == 4 || (!BMASK && !NUNAL && QN == 1), "the narrow-B form: plain, one column quadrant");
+  constexpr int TN_PD = NB < 4 ? 4 : TnDepth<BMASK>::PD;  // (narrow B: two waves per SIMD overlap each other -- half the prefetch depth, no spills)
   constexpr int TS = QM * QN;  // waves per team (1, 2 or 4); 4 / TS teams per workgroup
   static_assert(TS == 1 || TS == 2 || TS == 4, "a team is 1, 2 or 4 waves of one workgroup");
   const int lane = threadIdx.x & 63;
@@ -396,11 +402,11 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
     kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
   }
   auto phys = [&](int64_t kp) -> int64_t { return g.interleave ? ((kp / GRP) * W + wid) * GRP : kp; };
-  f16v acc[4][4];
+  f16v acc[4][NB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int mcol = 128 * qm + 4 * i, ncol = 128 * qn + 4 * i;
@@ -411,6 +417,10 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f4 sa[2][TN_PD], sb[2][TN_PD];
   f4 sm[BMASK ? 2 : 1][BMASK ? TN_PD : 1];  // BMASK: the mask rows travel with the set and are applied when it is consumed
+  // NB < 4: sb[set][s][b] = B[k][32 b + i] (columns past N: column 0 of the row -- a valid address, a tile column never stored)
+  int ncl[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) ncl[b] = (b < NB && 32 * b + i < g.N) ? 32 * b + i : 0;
 
   // load the TN_PD row pairs starting at row kp into register set `set`.  full: every row exists -> no selects on the
   // loaded values (a select makes the compiler wait for each load where it is issued).  Lanes beyond M / N read
@@ -423,7 +433,10 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
       const int64_t kr = kok ? phys(kp) + 2 * s + h : 0;
       f4 va = *reinterpret_cast<const f4*>(g.A + kr * g.M + mo);
       f4 vb;
-      if constexpr (NUNAL) vb = *reinterpret_cast<const f4u*>(g.B + kr * g.N + no);
+      if constexpr (NB < 4) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) vb[b] = g.B[kr * g.N + ncl[b]];
+      } else if constexpr (NUNAL) vb = *reinterpret_cast<const f4u*>(g.B + kr * g.N + no);
       else vb = *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
       if constexpr (BMASK) {
         f4 mk = *reinterpret_cast<const f4*>(g.bmask + kr * g.N + no);
@@ -432,7 +445,12 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
       }
       if (!full) {  // rows past the end of this wave's range must not contribute
         va = kok ? va : zero4;
-        vb = kok ? vb : zero4;
+        if constexpr (NB < 4) {  // (only the NB components that exist: the others are never read and must not cost registers)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) vb[b] = kok ? vb[b] : 0.f;
+        } else {
+          vb = kok ? vb : zero4;
+        }
       }
       sa[set][s] = va;
       sb[set][s] = vb;
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[set][s][a], sb[set][s][b], acc[a][b], 0, 0, 0);
   };
   constexpr int64_t GROUP = 2 * TN_PD;  // rows per register set
@@ -503,8 +521,9 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_reg_kernel(GemmArgs g) {
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int64_t nn = 128 * qn + 4 * i - nsh + b;  // (nsh: the columns this lane carries, see above; 0 unless NUNAL)
+    for (int b = 0; b < NB; ++b) {
+      // (nsh: the columns this lane carries, see above; 0 unless NUNAL.  NB < 4: tile b holds the columns 32 b + j)
+      const int64_t nn = NB < 4 ? (int64_t)(32 * b + i) : (int64_t)(128 * qn + 4 * i - nsh + b);
       if (nn < g.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -709,8 +728,10 @@ int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
   // the register teams / the ring for both forms).
   if (g.M > 128 && g.N > 128 && ctx->sgemm_variant != 34 && (g.bmask || ctx->sgemm_variant == 35)) return launch_tn_glds(ctx, g);
   const int qm = g.M > 128 ? 2 : 1, qn = g.N > 128 ? 2 : 1, ts = qm * qn;
-  const int64_t teams = (int64_t)ctx->num_cus * 4 / ts;
-  const int64_t group = 2 * (g.bmask ? TnDepth<true>::PD : TnDepth<false>::PD);
+  // narrow B (N <= 64, plain): two column tiles instead of four, two waves per SIMD (sgemm_variant 38: the four-tile form)
+  const bool narrow = !g.bmask && g.N <= 64 && ctx->sgemm_variant != 38;
+  const int64_t teams = (int64_t)ctx->num_cus * 4 / ts * (narrow ? 2 : 1);
+  const int64_t group = 2 * (narrow ? 4 : (g.bmask ? TnDepth<true>::PD : TnDepth<false>::PD));  // rows per register set (TN_PD of the kernel)
   int64_t chunk = cdiv64(cdiv64(g.K, teams), group) * group;  // whole register sets per team
   int64_t active = cdiv64(g.K, chunk);             // teams that own rows
   // sgemm_variant 33: contiguous K ranges per team; default: sets dealt round robin
@@ -732,7 +753,13 @@ int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
     else if (g.N % 4 != 0) sgemm_tn_reg_kernel<false, QM_, QN_, true><<<blocks, 256, 0, ctx->stream>>>(g); \
     else sgemm_tn_reg_kernel<false, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);                 \
   } while (0)
-    if (qm == 1 && qn == 1) GAIB_TN(1, 1);
+    if (narrow && g.N <= 32) {
+      if (qm == 1) sgemm_tn_reg_kernel<false, 1, 1, false, 1><<<blocks, 256, 0, ctx->stream>>>(g);
+      else sgemm_tn_reg_kernel<false, 2, 1, false, 1><<<blocks, 256, 0, ctx->stream>>>(g);
+    } else if (narrow) {
+      if (qm == 1) sgemm_tn_reg_kernel<false, 1, 1, false, 2><<<blocks, 256, 0, ctx->stream>>>(g);
+      else sgemm_tn_reg_kernel<false, 2, 1, false, 2><<<blocks, 256, 0, ctx->stream>>>(g);
+    } else if (qm == 1 && qn == 1) GAIB_TN(1, 1);
     else if (qm == 2 && qn == 2) GAIB_TN(2, 2);
     else if (qm == 1) GAIB_TN(1, 2);
     else GAIB_TN(2, 1);
@@ -1029,7 +1056,8 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // the LDS-tiled kernel there)
   // measured (scripts/gemm_odd_width.py, K = 2.45 M): 128 x 47 0.82 -> 0.69-0.72 ms, 100 x 47 0.65; at 256 x 47 the quadrant
   // teams compute two 128 x 128 tiles for 47 columns and lose to the tiled kernel (1.22 vs 0.80 ms): M <= 128 only
-  const bool b_rows_ok = (N % 4 == 0 && bvec) ||
+  // round 6: N <= 64 takes the narrow-B form (4-byte loads of B: any N, any alignment of its rows; M up to 256)
+  const bool b_rows_ok = (N % 4 == 0 && bvec) || (N <= 64 && ctx->sgemm_variant != 38 && ctx->sgemm_variant != 36) ||
                          (N % 4 != 0 && N >= 4 && M <= 128 && (((uintptr_t)d_B & 3) == 0) && ctx->sgemm_variant != 36);
   if (transA && !transB && M <= tn_max && N <= tn_max && M % 4 == 0 && avec && b_rows_ok && K >= 32768 &&
       ctx->sgemm_variant != 30)
