@@ -693,6 +693,20 @@ class BenchCase:
                 e_k, r_k, ms_dom = bnd_edges - part.colidx_halo.numel(), n_bnd, part_ms["part_light"] * args.steps
             alg_bytes = e_k * (4 * D + 8) + int(1.5 * r_k * 4 * D) + (r_k + 1) * 8
             n_dom = 2 * args.steps
+        elif part.colidx_halo.numel() > 0 and dg.g_halo is not None and dg.lgraph.halo_pieces(D) > 1 and ms_light >= ms_fused:
+            # round 6, the column split with the halo-column half consumed in K' pieces: the row kernel runs the owned-column pass
+            # AND the K' - 1 accumulate passes over the pieces that are not the last (the last one is the fused kernel with the
+            # product): K' launches per aggregation under one key.  Bytes of an average launch: the owned-column gathers and
+            # stores, the pieces' gathers ((K' - 1) / K' of the halo-column edges), one read + write of the rows per piece pass
+            kc = dg.lgraph.halo_pieces(D)
+            st_h = ctx.graph_stats(dg.g_halo)
+            e_h = part.colidx_halo.numel() - st_h["heavy_edges"]
+            kernel_name = (f"spmm_w64_kernel<VEC=2,CT=1,edge-weights,U=16,buffer>: the owned-column pass and the {kc - 1} accumulate "
+                           f"pass(es) over the halo-column pieces that are not the last (rank 0; {kc} launches per aggregation, averaged)")
+            total = (e_light * (4 * D + 8) + (nv - st_own["n_heavy"]) * 4 * D + (nv + 1) * 8
+                     + (kc - 1) / kc * e_h * (4 * D + 8) + (kc - 1) * (2 * nv * 4 * D + (nv + 1) * 8))
+            alg_bytes = int(total / kc)
+            n_dom, ms_dom = n_light, ms_light
         elif part.colidx_halo.numel() > 0 and ms_fused > ms_light and dg.g_halo is not None:
             # the column split on a partition whose edges mostly cross ranges (the strong case on a random order at N >= 4):
             # the halo-column half -- the fused kernel continuing the owned-column partial sums, the dense product riding on
