@@ -21,7 +21,7 @@ INCLUDE = ROOT / "include"
 ORACLE = ROOT / "oracle"
 REFERENCE = Path("/root/reference")
 
-HIP_SOURCES = ["runtime.hip", "graph.hip", "spmm.hip", "spmm_part.hip", "gat.hip", "sgemm.hip", "elementwise.hip", "probe.hip", "comm.hip"]
+HIP_SOURCES = ["runtime.hip", "graph.hip", "spmm.hip", "spmm_part.hip", "gat.hip", "sgemm.hip", "sgemm_skinny.hip", "elementwise.hip", "probe.hip", "comm.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

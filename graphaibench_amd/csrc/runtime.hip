@@ -7,6 +7,7 @@
 #include <string.h>
 #include <utility>
 #include "common.h"
+#include <stdlib.h>
 
 static thread_local char g_err[1024] = "";
 
@@ -64,6 +65,7 @@ extern "C" int gaib_ctx_create(int device, void* stream, gaib_ctx** out) {
   c->spmm_gather_mode = 0;
   c->spmm_hot_bytes = 3 << 20;
   c->sgemm_variant = 0;
+  if (const char* e = getenv("GAIB_SGEMM_VARIANT")) c->sgemm_variant = atoi(e);  // (A/B of a whole trainer run: 61 = without sgemm_skinny.hip)
   c->gat_fast = 1;
   c->gat_row_waves = 4;
   c->gat_chunk_sort = 1;

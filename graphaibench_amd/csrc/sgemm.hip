@@ -21,6 +21,10 @@
 // operands (the sum over k is order-free as long as A and B agree).
 #include "common.h"
 
+// sgemm_skinny.hip: *handled = 1 when the product was launched there
+int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* d_A,
+                          const float* d_B, int flags, float* d_C, int* handled);
+
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1029,6 +1033,11 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
     gaib_set_error("gaib_sgemm: transA && transB is not on the GNN path (unsupported)");
     return GAIB_ERR_UNSUPPORTED;
   }
+  {  // round 6: the products whose output or inner width is the class / input feature count (sgemm_skinny.hip)
+    int handled = 0;
+    GAIB_TRY(gaib_sgemm_skinny_try(ctx, transA, transB, M, N, K, d_A, d_B, flags, d_C, &handled));
+    if (handled) return GAIB_OK;
+  }
   GemmArgs g;
   g.A = d_A;
   g.B = d_B;
@@ -1078,7 +1087,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37);  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37) || (sv >= 60 && sv <= 63);  // (60 .. 63 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   // The LDS-tiled kernel loads a ROW-MAJOR A ([M][K], K odd: dX = G [N x 47] . W^T of the output layer) with 16-byte

@@ -1,0 +1,513 @@
+// sgemm_skinny.hip -- the dense products of a layer whose output or inner width is the class count or the input feature
+// count (47 and 100 on the products shape): matmul -> sgemm_gpu -> cublasSgemm (src/utilities/math_functions.cu:321-343; CPU:
+// matmul -> cblas_sgemm, math_functions.cpp:142-171) at   rows x 47 x {128, 256},  rows x {128, 256} x 47 (NT),
+// {128, 256} x 47 x rows (TN)  and  rows x 128 x 100.
+//
+// These are HBM-stream shapes (<= 17 flop / B): both operands leave HBM once, the output is written once, and the matrix cores
+// need 0.6-0.9 of the time the bytes need -- IF a tile wastes no columns.  Round 5 ran them through kernels built for 128-wide
+// outputs: 32 x 32 tiles (a 47-wide output pays for 64 columns: 27 % of the matrix-core time), operands requested ONE 8-column
+// step (200 ns of MFMA work) ahead of their use, i.e. a memory latency exposed at every new 128-B line -- 2.1-3.5 TB/s
+// (profiles/r06/gemm_narrow_pmc.json: traffic = 1.0-1.15 x the algorithmic bytes, SQ_WAIT_INST_ANY 35-60 % of the wave time:
+// not over-fetch, under-issue).  Here:
+//   * v_mfma_f32_16x16x4_f32: 47 columns cost 48;
+//   * the SMALL operand (W or its transpose, <= 128 x 48 / 48 x 128 ... 256 x 48) lives in REGISTERS for the life of a
+//     persistent wave, laid out as MFMA operand fragments: the inner loop reads no LDS and has no barrier;
+//   * the STREAMED operand is requested a whole row tile (16 rows x K: 3-16 KB per wave) ahead, 16-byte loads, every row's
+//     lines requested in one burst; two waves per SIMD wherever the registers allow;
+//   * row-stream kernel: the product is computed TRANSPOSED (D^T = op(B)^T . A^T), so that a lane ends up with four consecutive
+//     COLUMNS of one output row: 16-byte stores, one per 16 x 16 tile instead of four 4-byte ones.
+// f32-input MFMA is a k-ordered chain of exact fp32 fmas; which k a lane pair carries is free as long as both operands agree,
+// which is what lets a lane load 16 contiguous bytes of a row and use them in four consecutive MFMAs.
+#include "common.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at 4-byte alignment (rows of 47 floats)
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u3_t __attribute__((ext_vector_type(3)));
+
+struct SkinnyArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t M;  // row-stream: rows of A and C.  TN: rows of A and B (the long K)
+  int N, K;   // row-stream: C is [M x N], A is [M x K].  TN: C is [K x N] = A[M x K]^T . B[M x N]
+  int accum, relu;
+  float* slabs;  // TN: per-workgroup partial outputs
+};
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---- row stream:  C[M x N] (=|+=) A[M x K] . op(B),  M in the millions, N <= 16 CT, K = 16 G + 4 E ---------------------------
+// Lane (j = l & 15, q = l >> 4).  Chunk c of a row = its columns 4c .. 4c + 3; in group g lane q takes chunk 4g + q with one
+// 16-byte load, and the four MFMA steps (g, t) pair element t of it with op(B)[4 (4g + q) + t][:] -- held in registers.  E: one
+// more step whose lanes take ONE column each (k = 16 G + q; K = 100 = 6 groups + 1 step).  A chunk that would straddle the end
+// of a row (K = 47: chunk 11) starts 4 - K % 4 columns further left instead; the columns it then shares with its neighbour
+// meet zeros in the B registers.  Chunks past the row likewise re-read the row's first chunk against zeros.  No load ever
+// leaves its row.
+// MFMA operands: a = op(B) fragment (i = column 16 ct + j of the output), b = A fragment (j = row of the tile)
+//   => D[i][j] in lane (j, q), register r = C[row j][16 ct + 4 q + r].
+// Epilogue, two forms, both with a FIXED number of memory instructions per tile (a store under a branch makes the compiler wait
+// for vmcnt(0) at the top of the loop, i.e. for the previous tile's stores to be acknowledged before the next loads go out):
+//   LDSOUT (N <= 48, any N): the 16 rows of a tile are 16 N CONTIGUOUS floats of C.  The wave drops its D fragments into a
+//     compact [16][N] image in LDS (its own 16 x 48 floats, no barrier) and copies the image out -- or adds it to what is
+//     there (ACC) -- with 16-byte accesses of whole lines; the ragged column edge never reaches a global store;
+//   direct (N % 4 == 0): lane (j, q) stores C[row j][16 ct + 4 q .. + 3] from its registers, one 16-byte store per column tile.
+template <int G, int E, int CT, int RT, bool BT, int WPS, bool LDSOUT, bool ACC, int NBUF>
+__global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
+  __shared__ __attribute__((aligned(16))) float out_lds[LDSOUT ? 4 * (16 * 16 * CT + 4) : 4];  // per wave: image + scrap word
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int K = g.K, N = g.N;
+  const int K4 = (K + 3) >> 2;
+  int kb[G > 0 ? G : 1];
+  float breg[G > 0 ? G : 1][4][CT];
+  float bx[E ? CT : 1];
+#pragma unroll
+  for (int gg = 0; gg < G; ++gg) {
+    const int c = 4 * gg + q;
+    const bool valid = c < K4;
+    const int base = valid ? (4 * c + 4 <= K ? 4 * c : K - 4) : 0;
+    kb[gg] = base;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = base + t;
+      const bool live = valid && k >= 4 * c;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int n = 16 * ct + j;
+        const bool on = live && n < N;  // (unconditional load from a clamped address + select: no branch per register)
+        const int nn = on ? n : 0, kk = on ? k : 0;
+        const float v = BT ? g.B[(int64_t)nn * K + kk] : g.B[(int64_t)kk * N + nn];
+        breg[gg][t][ct] = on ? v : 0.f;
+      }
+    }
+  }
+  if constexpr (E) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int n = 16 * ct + j, k = 16 * G + q;
+      const bool on = n < N && k < K;
+      const int nn = on ? n : 0, kk = on ? k : 0;
+      const float v = BT ? g.B[(int64_t)nn * K + kk] : g.B[(int64_t)kk * N + nn];
+      bx[ct] = on ? v : 0.f;
+    }
+  }
+  const int kx = (16 * G + q < K) ? 16 * G + q : 0;  // E: this lane's single column (past the row: column 0 against a zero)
+
+  constexpr int ROWS = 16 * RT;
+  const int64_t ntiles = (g.M + ROWS - 1) / ROWS;
+  const int64_t W = (int64_t)gridDim.x * 4;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the tile loop and its bounds run on the SALU
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wv;
+  float* img = out_lds + (LDSOUT ? wv * (16 * 16 * CT + 4) : 0);  // this wave's [16][N] image
+  const int64_t cend = g.M * N;
+  const bool relu = g.relu != 0;
+  f4 buf[NBUF][RT][G > 0 ? G : 1];  // the ring: NBUF - 1 tiles in flight while one runs on the matrix cores
+  float bufx[NBUF][RT];
+
+  // The streamed operand comes through buffer loads: one descriptor per tile (its base = the tile's first row: scalar
+  // arithmetic), the lane's byte offsets inside the tile are loop invariants -- no 64-bit address is computed per load, and
+  // rows past the end of the matrix (the last, partial tile) read as zeros instead of faulting.
+  int voff[RT][G > 0 ? G : 1];
+  int voffx[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) voff[rt][gg] = 4 * ((16 * rt + j) * K + kb[gg]);
+    voffx[rt] = 4 * ((16 * rt + j) * K + kx);
+  }
+  const int64_t a_bytes = g.M * (int64_t)K * 4;
+  auto fetch = [&](int s, int64_t tile) {
+    const int64_t off = tile * ROWS * (int64_t)K * 4;
+    const int64_t left = a_bytes - off;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(g.A) + off), 0, (int)(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) {
+        const u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[rt][gg], 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) buf[s][rt][gg][e] = __uint_as_float(r[e]);
+      }
+      if constexpr (E) bufx[s][rt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voffx[rt], 0, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the tile is issued before the MFMAs that follow
+  };
+  // TAIL: the matrix's last, partial tile (at most one, after the loop): rows and pieces past the end are predicated there.  The
+  // loop's tiles are whole: every store is unconditional.
+  auto compute = [&](int s, int64_t tile, auto tailc) {
+    constexpr bool TAIL = decltype(tailc)::value;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f4 acc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(breg[gg][t][ct], buf[s][rt][gg][t], acc[ct]);
+      if constexpr (E) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(bx[ct], bufx[s][rt], acc[ct]);
+      }
+      const int64_t row0 = tile * ROWS + 16 * rt;
+      if constexpr (LDSOUT) {
+        // columns past N (the ragged edge of the last column tile) go to a scrap word behind the image: the write itself is
+        // unconditional
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = 16 * ct + 4 * q + e;
+            img[n < N ? j * N + n : 16 * 16 * CT] = acc[ct][e];
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the image = C[row0 * N .. (row0 + 16) * N), 16-byte pieces (row0 % 16 == 0: the base is 64-byte aligned).  A lane
+        // whose piece lies past the image takes the image's last piece again: the same bytes to the same place.
+        float* cb = g.C + row0 * N;
+        constexpr int NP = (16 * 16 * CT / 4 + 63) / 64;  // 16-byte pieces per lane
+        if constexpr (!TAIL) {
+          const int last = 16 * N - 4;
+          f4 old[NP];
+          if constexpr (ACC) {
+#pragma unroll
+            for (int x = 0; x < NP; ++x) {
+              const int f = 4 * (lane + 64 * x);
+              old[x] = *reinterpret_cast<const f4*>(cb + (f < last ? f : last));
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < NP; ++x) {
+            int f = 4 * (lane + 64 * x);
+            f = f < last ? f : last;
+            f4 v = *reinterpret_cast<const f4*>(img + f);
+            if constexpr (ACC) v = old[x] + v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (relu && !(v[e] > 0.f)) ? 0.f : v[e];
+            *reinterpret_cast<f4*>(cb + f) = v;
+          }
+        } else {
+          const int64_t left = cend - row0 * N;
+          const int npc = (int)(left < 0 ? 0 : (left < 16 * N ? left : 16 * N));  // floats of this tile that exist
+          for (int f = lane; f < npc; f += 64) {
+            float v = img[f];
+            if constexpr (ACC) v = cb[f] + v;
+            cb[f] = (relu && !(v > 0.f)) ? 0.f : v;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the image is rewritten by the next tile only after every lane has read it
+      } else {
+        // (N == 16 CT: no column edge)
+        const int64_t row = row0 + j;
+        const bool rok = !TAIL || row < g.M;
+        float* pc = g.C + (rok ? row : 0) * N + 4 * q;
+        f4 old[CT];
+        if constexpr (ACC) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) old[ct] = *reinterpret_cast<const f4*>(pc + 16 * ct);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          f4 v = acc[ct];
+          if constexpr (ACC) v = old[ct] + v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (relu && !(v[e] > 0.f)) ? 0.f : v[e];
+          if constexpr (TAIL) {
+            if (rok) *reinterpret_cast<f4*>(pc + 16 * ct) = v;
+          } else {
+            *reinterpret_cast<f4*>(pc + 16 * ct) = v;
+          }
+        }
+      }
+    }
+  };
+  // Whole tiles dealt round robin: at any time the waves of the chip sweep one compact window of A and C.  This wave's tiles
+  // are wid + x W, x = 0 .. nw - 1, taken in ROUNDS of NBUF through the ring: step b of a round requests the tile NBUF - 1
+  // ahead into the slot the previous step emptied and runs slot b.  The round is straight-line code -- no exit test between its
+  // steps: with one, the compiler's count of outstanding loads at every merge is the minimum over both paths, and the waits it
+  // emits drain the ring (measured in the ISA: vmcnt(12) where 36 are allowed).  A request past the wave's last tile takes that
+  // last tile again (out of the cache, never consumed); the nw % NBUF tiles after the last whole round are already in their
+  // slots.  vmcnt counts 63 at most: (NBUF - 1) (G + E) RT loads + the stores of NBUF - 1 tiles stay below that.
+  const int64_t nfull = g.M / ROWS;
+  const int64_t nw = wid < nfull ? (nfull - wid + W - 1) / W : 0;
+  auto tile_of = [&](int64_t x) { return wid + (x < nw ? x : nw - 1) * W; };
+  if (nw > 0) {
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) fetch(b, tile_of(b));
+    int64_t x = 0;
+    for (; x + NBUF <= nw; x += NBUF) {
+#pragma unroll
+      for (int b = 0; b < NBUF; ++b) {
+        fetch((b + NBUF - 1) % NBUF, tile_of(x + b + NBUF - 1));
+        compute(b, wid + (x + b) * W, std::false_type{});
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+      if (x + b < nw) compute(b, wid + (x + b) * W, std::false_type{});
+  }
+  if (nfull < ntiles && wid == nfull % W) {  // the partial tile
+    fetch(0, nfull);
+    compute(0, nfull, std::true_type{});
+  }
+}
+
+// ---- TN:  C[MW x N] (=|+=) A[K x MW]^T . B[K x N],  K (= g.M here) in the millions, MW <= 128 NH (a multiple of 4), N <= 16 CT
+// -- the weight gradient of the output layer.  Both operands are k-major, so an MFMA fragment is a coalesced global read: lane
+// (i = l & 15, q = l >> 4) loads the float4 A[k + q][64 h + 4 i .. + 3] (16 lanes cover 256 contiguous bytes) and uses element
+// e as the A fragment of row tile (h, e) -- the tile that holds the rows m = 64 h + 4 i + e: which rows a tile holds is free as
+// long as the epilogue knows.  B: lane (j, q) loads B[k + q][16 c + j] for each of the CT column tiles.  A step = 4 rows of k =
+// 8 CT MFMAs.  A wave keeps a 128-row half of the output in 32 CT accumulator registers (two waves per SIMD) and walks its own
+// sets of 4 S rows (dealt round robin over the waves: one compact window over K), the next set in flight while the current one
+// runs on the matrix cores.  NH = 2 (129..256 output rows): waves w and w + 1 of a workgroup take the two halves of the SAME
+// sets -- the second reader of a B line sits on the same CU.  The waves of a workgroup add their outputs in LDS in wave order;
+// one slab per workgroup goes to memory and the slabs are summed in fixed order by skinny_reduce_kernel.
+// B (round 6b): ONE 12-byte load per row instead of three 4-byte ones -- lane j takes the columns 3 j .. 3 j + 2 (16 lanes cover
+// 48 columns: 192 contiguous bytes), element c is the lane's column of tile c.  A lane whose three columns would cross the end
+// of the row (N = 47: lane 15) starts sh = 3 j + 3 - N columns further left; the columns it then shares with its neighbours
+// are computed twice (same operands, same order) and stored by the neighbour only.
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+template <int NH, int S, int WPS, int NBUF>
+__global__ __launch_bounds__(256, WPS) void skinny_tn_kernel(SkinnyArgs g) {
+  constexpr int CT = 3;
+  extern __shared__ __attribute__((aligned(16))) float tn_lds[];  // [128 NH][16 CT]
+  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the tile loop and its bounds run on the SALU
+  const int MW = g.K, N = g.N;  // output rows / columns
+  const int64_t KR = g.M;       // rows of A and B
+  constexpr int SR = 4 * S;     // rows per set
+  constexpr int TPW = 4 / NH;   // K schedules (teams) per workgroup
+  const int half = wv % NH;
+  const int64_t W = (int64_t)gridDim.x * TPW;
+  const int64_t wid = (int64_t)blockIdx.x * TPW + wv / NH;
+  const int64_t nsets = (KR + SR - 1) / SR;
+  int mo[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) mo[h] = (128 * half + 64 * h + 4 * i < MW) ? 128 * half + 64 * h + 4 * i : 0;  // (MW % 4 == 0)
+  const int sh = 3 * i + 3 > N ? 3 * i + 3 - N : 0;  // (N >= 3)
+  const int no = 3 * i - sh;                         // this lane's first column of B
+  f4 acc[2][4][CT];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[h][e][c] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 sa[NBUF][S][2];
+  typedef float f3 __attribute__((ext_vector_type(3)));
+  f3 sb[NBUF][S];
+  // Buffer loads: one descriptor pair per set (base = the set's first row: scalar arithmetic), the lane's byte offsets inside
+  // the set are loop invariants; rows past the end of the matrices (the last, partial set) read as zeros.
+  int voa[S][2], vob[S];
+#pragma unroll
+  for (int st = 0; st < S; ++st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) voa[st][h] = 4 * ((4 * st + q) * MW + mo[h]);
+    vob[st] = 4 * ((4 * st + q) * N + no);
+  }
+  const int64_t a_bytes = KR * (int64_t)MW * 4, b_bytes = KR * (int64_t)N * 4;
+  auto fetch = [&](int set, int64_t s) {
+    const int64_t offa = s * SR * (int64_t)MW * 4, offb = s * SR * (int64_t)N * 4;
+    const int64_t la = a_bytes - offa, lb = b_bytes - offb;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(g.A) + offa), 0, (int)(la < (1 << 30) ? la : (1 << 30)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(g.B) + offb), 0, (int)(lb < (1 << 30) ? lb : (1 << 30)), 0x00020000);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u4_t r = __builtin_amdgcn_raw_buffer_load_b128(ra, voa[st][h], 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sa[set][st][h][e] = __uint_as_float(r[e]);
+      }
+      const u3_t r = __builtin_amdgcn_raw_buffer_load_b96(rb, vob[st], 0, 0);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) sb[set][st][e] = __uint_as_float(r[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute = [&](int set) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < S; ++st)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[h][e][c] = mfma16(sa[set][st][h][e], sb[set][st][c], acc[h][e][c]);
+  };
+  // this team's whole sets: wid + x W, x = 0 .. nw - 1, in rounds of NBUF through a ring of register sets (NBUF - 1 in flight);
+  // a round is straight-line code (see skinny_rows_kernel); a request past the team's last set takes that set again (out of the
+  // cache, never consumed).  The matrix's last, partial set (at most one) is taken afterwards: the rows it lacks read as zeros.
+  const int64_t nfull = KR / SR;
+  const int64_t nw = wid < nfull ? (nfull - wid + W - 1) / W : 0;
+  auto set_of = [&](int64_t x) { return wid + (x < nw ? x : nw - 1) * W; };
+  if (nw > 0) {
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) fetch(b, set_of(b));
+    int64_t x = 0;
+    for (; x + NBUF <= nw; x += NBUF) {
+#pragma unroll
+      for (int b = 0; b < NBUF; ++b) {
+        fetch((b + NBUF - 1) % NBUF, set_of(x + b + NBUF - 1));
+        compute(b);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+      if (x + b < nw) compute(b);
+  }
+  if (nfull < nsets && wid == nfull % W) {
+    fetch(0, nfull);
+    compute(0);
+  }
+  // D[ii][jj] in lane (jj = l & 15, qq = l >> 4), register r: ii = 4 qq + r -> C[128 half + 64 h + 4 ii + e][3 jj - sh + c];
+  // a lane stores the columns that are its own (c >= sh).  The teams of a workgroup add their halves in LDS in team order
+  // (fixed order: deterministic).
+  constexpr int LDN = 16 * CT;
+  for (int w = 0; w < TPW; ++w) {
+    if (wv / NH == w) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = 128 * half + 64 * h + 4 * (4 * q + r) + e;
+              if (c >= sh) {
+                float* p = tn_lds + m * LDN + no + c;
+                *p = (w == 0) ? acc[h][e][c][r] : *p + acc[h][e][c][r];
+              }
+            }
+    }
+    __syncthreads();
+  }
+  float* P = g.slabs + (int64_t)blockIdx.x * MW * N;
+  for (int x = threadIdx.x; x < MW * N; x += 256) {
+    const int m = x / N, n = x - m * N;
+    P[x] = tn_lds[m * LDN + n];
+  }
+}
+
+// C[i] = (accum ? C[i] : 0) + sum_s slab[s][i], s in order (deterministic)
+__global__ void skinny_reduce_kernel(int64_t n, int slabs, const float* partial, int accum, int relu, float* C) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += stride) {
+    float s = accum ? C[x] : 0.f;
+#pragma unroll 8
+    for (int k = 0; k < slabs; ++k) s += partial[(int64_t)k * n + x];
+    C[x] = (relu && !(s > 0.f)) ? 0.f : s;
+  }
+}
+
+struct SkinnyTag {
+  char s[28];
+  SkinnyTag(int64_t M, int64_t N, int64_t K) { snprintf(s, sizeof(s), "%lldx%lldx%lld", (long long)M, (long long)N, (long long)K); }
+};
+
+template <int G, int E, int CT, int RT, bool BT, int WPS, bool LDSOUT, int NBUF>
+int launch_rows(gaib_ctx* ctx, const SkinnyArgs& a) {
+  const int64_t ntiles = cdiv64(a.M, 16 * RT);
+  const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus * WPS, cdiv64(ntiles, 4));
+  if (a.accum) skinny_rows_kernel<G, E, CT, RT, BT, WPS, LDSOUT, true, NBUF><<<blocks, 256, 0, ctx->stream>>>(a);
+  else skinny_rows_kernel<G, E, CT, RT, BT, WPS, LDSOUT, false, NBUF><<<blocks, 256, 0, ctx->stream>>>(a);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+template <int NH, int S, int WPS, int NBUF>
+int launch_tn(gaib_ctx* ctx, SkinnyArgs a) {
+  const int64_t nsets = cdiv64(a.M, 4 * S);
+  const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus * WPS, cdiv64(nsets, 4 / NH));
+  const int64_t n = (int64_t)a.K * a.N;
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)blocks * (size_t)n));
+  a.slabs = (float*)ctx->ws;
+  const size_t lds = sizeof(float) * (size_t)128 * NH * 48;
+  skinny_tn_kernel<NH, S, WPS, NBUF><<<blocks, 256, lds, ctx->stream>>>(a);
+  GAIB_LAUNCH_CHECK();
+  const unsigned rg = (unsigned)std::min<int64_t>(cdiv64(n, 256), 1024);
+  skinny_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, (int)blocks, a.slabs, a.accum, a.relu, a.C);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
+}  // namespace
+
+// Called by gaib_sgemm_ex before its own rules.  *handled = 1: the product was launched here.  Shapes (sgemm_variant 61 turns
+// the family off, 62 / 63 the row-stream / TN half only):
+//   NN  rows x (33..48) x 64 | 128 | 256      forward of the output layer (64: the GAT models' dense head)
+//   NT  rows x 64 | 128 | 256 x (33..48)      input gradient of the output layer
+//   NN  rows x 128 x 100                      forward of the first layer (K = 16 G + 4)
+//   TN  (68..128 | 196..256, % 4) x (33..48) x rows   weight gradient of the output layer
+int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* d_A,
+                          const float* d_B, int flags, float* d_C, int* handled) {
+  *handled = 0;
+  const int sv = ctx->sgemm_variant;
+  if (sv != 0 && sv != 60 && sv != 62 && sv != 63) return GAIB_OK;
+  if ((((uintptr_t)d_A | (uintptr_t)d_B) & 3) != 0 || (((uintptr_t)d_C) & 15) != 0) return GAIB_OK;
+  SkinnyArgs a;
+  a.A = d_A;
+  a.B = d_B;
+  a.C = d_C;
+  a.accum = (flags & GAIB_ACCUMULATE) ? 1 : 0;
+  a.relu = (flags & GAIB_RELU) ? 1 : 0;
+  a.slabs = nullptr;
+  const double bytes = 4.0 * ((double)M * K + (double)K * N + (double)M * N * (a.accum ? 2.0 : 1.0));
+  const double flops = 2.0 * (double)M * (double)N * (double)K;
+  if (!transA && M >= 65536 && sv != 63) {
+    a.M = M;
+    a.N = (int)N;
+    a.K = (int)K;
+    const int ct = (int)cdiv64(N, 16);
+#define GAIB_ROWS(G_, E_, CT_, RT_, BT_, WPS_, LO_, NB_)                           \
+  do {                                                                             \
+    GAIB_HIP(hipSetDevice(ctx->device));                                           \
+    ProfScope ps(ctx, "sgemm", bytes, flops, 0, SkinnyTag(M, N, K).s);             \
+    *handled = 1;                                                                  \
+    return launch_rows<G_, E_, CT_, RT_, BT_, WPS_, LO_, NB_>(ctx, a);             \
+  } while (0)
+    // Schedules as measured at 2.45 M rows (scripts/gemm_narrow.py; ring depth NBUF, waves per SIMD WPS, row tiles per step RT;
+    // profiles/r06/gemm_skinny_sweep.jsonl): a deeper ring pays where a wave alone on its SIMD has the registers for it;
+    // non-temporal loads / stores changed nothing (0.34-0.36 either way) and are not built.
+    if (!transB && ct == 3 && K == 64) GAIB_ROWS(4, 0, 3, 1, false, 2, true, 4);     // 47 x 64 (the GAT models' dense head)
+    if (!transB && ct == 3 && K == 128) GAIB_ROWS(8, 0, 3, 1, false, 1, true, 5);    // 0.349 (WPS 2, NBUF 2) -> 0.32 ms (NBUF 4: 0.324, 6: 0.317 with 52-68 registers spilled)
+    if (!transB && ct == 3 && K == 256) GAIB_ROWS(16, 0, 3, 1, false, 1, true, 2);   // 0.600 (NBUF 3: 0.605)
+    if (transB && N == 64 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 4, 2, true, 2, false, 3);
+    if (transB && N == 128 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 8, 2, true, 1, false, 3);   // 0.445 (WPS 2, NBUF 2) -> 0.36-0.40
+    if (transB && N == 256 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 16, 1, true, 1, false, 4);  // 0.712 (RT 2, NBUF 2) -> 0.69 (RT 2, NBUF 3: its C += form spills 46 registers)
+    if (!transB && N == 128 && K == 100) GAIB_ROWS(6, 1, 8, 1, false, 1, false, 2);  // 0.571 (NBUF 3: 0.569)
+#undef GAIB_ROWS
+    return GAIB_OK;
+  }
+  if (transA && !transB && K >= 65536 && sv != 62 && M % 4 == 0 && (((uintptr_t)d_A & 15) == 0) && N > 32 && N <= 48) {
+    // C[M x N] = A[K x M]^T . B[K x N]: the kernel's names: rows KR = K, output MW = M
+    a.M = K;
+    a.K = (int)M;
+    a.N = (int)N;
+#define GAIB_TNS(NH_, S_, WPS_, NB_)                                               \
+  do {                                                                             \
+    GAIB_HIP(hipSetDevice(ctx->device));                                           \
+    ProfScope ps(ctx, "sgemm", bytes, flops, 0, SkinnyTag(M, N, K).s);             \
+    *handled = 1;                                                                  \
+    return launch_tn<NH_, S_, WPS_, NB_>(ctx, a);                                  \
+  } while (0)
+    // (one wave per SIMD with rings of 4-6 sets measured the same 0.34-0.36 / 0.60-0.62 ms: not latency-bound any more)
+    if (M <= 128 && M > 64) GAIB_TNS(1, 4, 2, 2);
+    if (M <= 256 && M > 192) GAIB_TNS(2, 4, 2, 2);
+#undef GAIB_TNS
+  }
+  return GAIB_OK;
+}

@@ -31,8 +31,10 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", nargs="*", default=None, help="e.g. TN:128x47 NN:47x128 (form:MxN or form:NxK with the vertex count left out)")
     ap.add_argument("--nv", type=int, default=NV)
+    ap.add_argument("--variant", type=int, default=0, help="gaib_set_option sgemm_variant (61: round 5's kernels for the shapes of sgemm_skinny.hip)")
     args = ap.parse_args()
     ctx = capi.Context(0)
+    ctx.set_option("sgemm_variant", args.variant)
     peak = ctx.probe_stream_copy(1 << 30, 20)
     for form, M, N, K in SHAPES:
         M, K = (args.nv if M == NV else M), (args.nv if K == NV else K)
@@ -65,7 +67,7 @@ def main():
         alg = 4.0 * (M * K + K * N + M * N)
         flops = 2.0 * M * N * K
         roof = max(alg / 8e12, flops / 157.3e12) * 1e3
-        print(json.dumps({"shape": tag, "key": f"sgemm@{M}x{N}x{K}", "ms": round(ms, 4), "alg_gb": round(alg / 1e9, 3),
+        print(json.dumps({"shape": tag, "variant": args.variant, "key": f"sgemm@{M}x{N}x{K}", "ms": round(ms, 4), "alg_gb": round(alg / 1e9, 3),
                           "gflop": round(flops / 1e9, 1), "roof_ms": round(roof, 4), "frac": round(roof / ms, 3),
                           "tb_s": round(alg / ms / 1e9, 3), "frac_of_stream_copy": round(alg / (ms * 1e-3) / 1e9 / peak, 3),
                           "stream_copy_gbs": round(peak, 1), "launch_keys": {k: v["count"] // args.reps for k, v in tab.items()}}), flush=True)

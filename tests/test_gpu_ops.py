@@ -1236,6 +1236,49 @@ def test_sgemm_tn_odd_width_matches_the_tiled_kernel_and_reads_nothing_past_the_
     assert torch.equal(again, C1)  # fixed summation order
 
 
+@pytest.mark.parametrize("form,m,n,k", [
+    ("NN", 65537, 47, 128), ("NN", 70001, 47, 256), ("NN", 65536, 41, 128), ("NN", 65551, 33, 256), ("NN", 66000, 48, 128),
+    ("NT", 65537, 128, 47), ("NT", 70001, 256, 47), ("NT", 65540, 128, 48), ("NT", 65551, 256, 45),
+    ("NN", 65537, 128, 100), ("NN", 65551, 41, 64), ("NT", 65537, 64, 41),
+    ("TN", 128, 47, 65537), ("TN", 256, 47, 70001), ("TN", 100, 47, 65551), ("TN", 128, 41, 65536), ("TN", 200, 33, 66001),
+    ("TN", 256, 48, 65540)])
+@pytest.mark.parametrize("accum,relu", [(0, 0), (1, 1)])
+def test_sgemm_skinny_family(ctx, form, m, n, k, accum, relu):
+    """round 6: the products whose output or inner width is the class / input feature count (sgemm_skinny.hip: operand
+    fragments of the small matrix in registers, 16 x 16 x 4 tiles, whole row tiles requested ahead) at row counts that are no
+    whole number of tiles or register sets: fp64 on the device, the round-5 kernels (sgemm_variant 61) next to them, nothing
+    written past C, and the same bits twice"""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(m + n + k)
+    tA, tB = form == "TN", form == "NT"
+    A = torch.randn((k, m) if tA else (m, k), device="cuda", generator=gen)
+    B = torch.randn((n, k) if tB else (k, n), device="cuda", generator=gen)
+    flat = torch.full((m * n + 256,), 777.0, device="cuda")  # C at the START of its allocation, a canary behind it
+    C0 = torch.randn(m, n, device="cuda", generator=gen)
+    want = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double())
+    if accum:
+        want = want + C0.double()
+    if relu:
+        want = torch.clamp(want, min=0)
+    got = {}
+    try:
+        for variant in (0, 61, 0):
+            ctx.set_option("sgemm_variant", variant)
+            C = flat[:m * n].view(m, n)
+            C.copy_(C0)
+            ctx.sgemm(A, B, C, tA, tB, bool(accum), relu=bool(relu))
+            ctx.sync()
+            assert bool((flat[m * n:] == 777.0).all())
+            got.setdefault(variant, []).append(C.clone())
+    finally:
+        ctx.set_option("sgemm_variant", 0)
+    scale = float(want.abs().max())
+    for variant, outs in got.items():
+        for out in outs:
+            assert float((out.double() - want).abs().max()) / scale < 2e-5, (variant,)
+    assert torch.equal(got[0][0], got[0][1])  # fixed summation order
+
+
 @pytest.mark.parametrize("variant", [0, 2, 10, 11, 12, 13, 30, 32, 33, 34, 35, 38])
 def test_sgemm_experimental_variants_agree(ctx, variant):
     """the tiling knobs (gaib_set_option sgemm_variant) change the schedule, not the result (round 6: the four-per-CU and
