@@ -37,6 +37,7 @@ struct SkinnyArgs {
   int N, K;   // row-stream: C is [M x N], A is [M x K].  TN: C is [K x N] = A[M x K]^T . B[M x N]
   int accum, relu;
   float* slabs;  // TN: per-workgroup partial outputs
+  int ldn;       // row-stream, direct stores: row stride of C and of a row-major B when blockIdx.y walks column slabs of N (else == N)
 };
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -60,7 +61,8 @@ template <int G, int E, int CT, int RT, bool BT, int WPS, bool LDSOUT, bool ACC,
 __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
   __shared__ __attribute__((aligned(16))) float out_lds[LDSOUT ? 4 * (16 * 16 * CT + 4) : 4];  // per wave: image + scrap word
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-  const int K = g.K, N = g.N;
+  const int K = g.K, N = g.N;  // N: the columns of THIS workgroup's slab (== g.ldn unless the launch has column slabs)
+  const int ldn = LDSOUT ? N : g.ldn, n0 = LDSOUT ? 0 : (int)blockIdx.y * N;
   const int K4 = (K + 3) >> 2;
   int kb[G > 0 ? G : 1];
   float breg[G > 0 ? G : 1][4][CT];
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
         const int n = 16 * ct + j;
         const bool on = live && n < N;  // (unconditional load from a clamped address + select: no branch per register)
         const int nn = on ? n : 0, kk = on ? k : 0;
-        const float v = BT ? g.B[(int64_t)nn * K + kk] : g.B[(int64_t)kk * N + nn];
+        const float v = BT ? g.B[(int64_t)(n0 + nn) * K + kk] : g.B[(int64_t)kk * ldn + n0 + nn];
         breg[gg][t][ct] = on ? v : 0.f;
       }
     }
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
       const int n = 16 * ct + j, k = 16 * G + q;
       const bool on = n < N && k < K;
       const int nn = on ? n : 0, kk = on ? k : 0;
-      const float v = BT ? g.B[(int64_t)nn * K + kk] : g.B[(int64_t)kk * N + nn];
+      const float v = BT ? g.B[(int64_t)(n0 + nn) * K + kk] : g.B[(int64_t)kk * ldn + n0 + nn];
       bx[ct] = on ? v : 0.f;
     }
   }
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
         // (N == 16 CT: no column edge)
         const int64_t row = row0 + j;
         const bool rok = !TAIL || row < g.M;
-        float* pc = g.C + (rok ? row : 0) * N + 4 * q;
+        float* pc = g.C + (rok ? row : 0) * ldn + n0 + 4 * q;
         f4 old[CT];
         if constexpr (ACC) {
 #pragma unroll
@@ -421,9 +423,13 @@ struct SkinnyTag {
 template <int G, int E, int CT, int RT, bool BT, int WPS, bool LDSOUT, int NBUF>
 int launch_rows(gaib_ctx* ctx, const SkinnyArgs& a) {
   const int64_t ntiles = cdiv64(a.M, 16 * RT);
-  const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus * WPS, cdiv64(ntiles, 4));
-  if (a.accum) skinny_rows_kernel<G, E, CT, RT, BT, WPS, LDSOUT, true, NBUF><<<blocks, 256, 0, ctx->stream>>>(a);
-  else skinny_rows_kernel<G, E, CT, RT, BT, WPS, LDSOUT, false, NBUF><<<blocks, 256, 0, ctx->stream>>>(a);
+  // column slabs (a.ldn / a.N of them, blockIdx.y): the workgroups of a row share the CUs' wave slots, and -- launched side by
+  // side -- walk the same tiles of A at the same time: the second reader of a line finds it in the L2
+  const unsigned slabs = (unsigned)(a.ldn / a.N);
+  const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)ctx->num_cus * WPS / slabs, cdiv64(ntiles, 4));
+  const dim3 grid(blocks, slabs);
+  if (a.accum) skinny_rows_kernel<G, E, CT, RT, BT, WPS, LDSOUT, true, NBUF><<<grid, 256, 0, ctx->stream>>>(a);
+  else skinny_rows_kernel<G, E, CT, RT, BT, WPS, LDSOUT, false, NBUF><<<grid, 256, 0, ctx->stream>>>(a);
   GAIB_LAUNCH_CHECK();
   return GAIB_OK;
 }
@@ -447,7 +453,7 @@ int launch_tn(gaib_ctx* ctx, SkinnyArgs a) {
 }  // namespace
 
 // Called by gaib_sgemm_ex before its own rules.  *handled = 1: the product was launched here.  Shapes (sgemm_variant 61 turns
-// the family off, 62 / 63 the row-stream / TN half only):
+// the family off, 62 / 63 the row-stream / TN half only, 64 the column-slab form of rows x 256 x 100):
 //   NN  rows x (33..48) x 64 | 128 | 256      forward of the output layer (64: the GAT models' dense head)
 //   NT  rows x 64 | 128 | 256 x (33..48)      input gradient of the output layer
 //   NN  rows x 128 x 100                      forward of the first layer (K = 16 G + 4)
@@ -456,7 +462,7 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
                           const float* d_B, int flags, float* d_C, int* handled) {
   *handled = 0;
   const int sv = ctx->sgemm_variant;
-  if (sv != 0 && sv != 60 && sv != 62 && sv != 63) return GAIB_OK;
+  if (sv != 0 && sv != 60 && sv != 62 && sv != 63 && sv != 64) return GAIB_OK;
   if ((((uintptr_t)d_A | (uintptr_t)d_B) & 3) != 0 || (((uintptr_t)d_C) & 15) != 0) return GAIB_OK;
   SkinnyArgs a;
   a.A = d_A;
@@ -470,6 +476,7 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
   if (!transA && M >= 65536 && sv != 63) {
     a.M = M;
     a.N = (int)N;
+    a.ldn = (int)N;
     a.K = (int)K;
     const int ct = (int)cdiv64(N, 16);
 #define GAIB_ROWS(G_, E_, CT_, RT_, BT_, WPS_, LO_, NB_)                           \
@@ -489,6 +496,11 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
     if (transB && N == 128 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 8, 2, true, 1, false, 3);   // 0.445 (WPS 2, NBUF 2) -> 0.36-0.40
     if (transB && N == 256 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 16, 1, true, 1, false, 4);  // 0.712 (RT 2, NBUF 2) -> 0.69 (RT 2, NBUF 3: its C += form spills 46 registers)
     if (!transB && N == 128 && K == 100) GAIB_ROWS(6, 1, 8, 1, false, 1, false, 2);  // 0.571 (NBUF 3: 0.569)
+    // two column slabs of 128 (the matrix in registers is 100 x 128): 1.45 -> 1.11-1.14 ms; four slabs of 64 at two waves per SIMD: 1.32
+    if (!transB && N == 256 && K == 100 && sv != 64) {
+      a.N = 128;
+      GAIB_ROWS(6, 1, 8, 1, false, 1, false, 2);
+    }
 #undef GAIB_ROWS
     return GAIB_OK;
   }
@@ -497,6 +509,7 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
     a.M = K;
     a.K = (int)M;
     a.N = (int)N;
+    a.ldn = (int)N;
 #define GAIB_TNS(NH_, S_, WPS_, NB_)                                               \
   do {                                                                             \
     GAIB_HIP(hipSetDevice(ctx->device));                                           \

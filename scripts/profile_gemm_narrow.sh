@@ -25,7 +25,7 @@ if [ "$WHAT" = gemm ] || [ "$WHAT" = all ]; then
   ( cd "$ROOT" && python3 scripts/summarize_rocprof.py stats "$OUT/gemm_stats" "$OUT/gemm_narrow_kernel_stats.csv" > "$OUT/gemm_stats_top.txt" 2>&1
     python3 scripts/summarize_rocprof.py pmc "$OUT/gemm_narrow_pmc_raw.json" fetch="$OUT/gemm_fetch" write="$OUT/gemm_write" sq="$OUT/gemm_sq" tcc="$OUT/gemm_tcc"
     # per SHAPE: gemm_narrow.py launches 3 + 5 main kernels per shape, shape after shape (the split-K reduce and the probe dropped)
-    python3 scripts/summarize_rocprof.py pmcseq "$OUT/gemm_narrow_pmc_by_shape.json" 8 "splitk_reduce|probe|copy_kernel" fetch="$OUT/gemm_fetch" write="$OUT/gemm_write" sq="$OUT/gemm_sq" tcc="$OUT/gemm_tcc" )
+    python3 scripts/summarize_rocprof.py pmcseq "$OUT/gemm_narrow_pmc_by_shape.json" 8 "splitk_reduce|skinny_reduce|probe|copy_kernel" fetch="$OUT/gemm_fetch" write="$OUT/gemm_write" sq="$OUT/gemm_sq" tcc="$OUT/gemm_tcc" )
   rm -rf "$OUT/gemm_stats" "$OUT/gemm_fetch" "$OUT/gemm_write" "$OUT/gemm_sq" "$OUT/gemm_tcc"
 fi
 if [ "$WHAT" = gat ] || [ "$WHAT" = all ]; then
