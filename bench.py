@@ -881,8 +881,8 @@ def main():
                          "GPU at --cut-fraction.  A default run measures BOTH: the other one is config.weak_products_range / "
                          "config.strong_products.  gcn-papers (config 5) is weak by construction")
     args = ap.parse_args()
-    if (args.workload == "gat-reddit" or args.workload in EPOCH_WORKLOADS) and args.gpus > 1:
-        ap.error(f"--workload {args.workload} is a one-GPU workload; N > 1 runs gcn-products or gcn-papers")
+    if args.workload in EPOCH_WORKLOADS and args.gpus > 1:
+        ap.error(f"--workload {args.workload} is a one-GPU workload; N > 1 runs gcn-products, gcn-papers or gat-reddit")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))  # no torch, no GPU API in this process
 
@@ -982,11 +982,14 @@ def main():
             return DistOracleCheck(torch, dist, synth, L, gdist, ctx, comm, a2, rank, world, shape, cut, boundary=boundary)
 
         try:
-            result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
-                                           cpu_leg=None if args.no_cpu_baseline else cpu_leg,
-                                           parity_check=None if (args.no_parity or args.check_oracle) else parity_at,
-                                           traffic_of=traffic_from_profile,
-                                           strong_check=None if args.no_parity else strong_check)
+            if args.workload == "gat-reddit":  # config 4's layer across ranks (round 6; BASELINE pins the config itself to one GPU)
+                result = gdist.bench_gat_layer(ctx, args, rank, world, log, hold=hold)
+            else:
+                result = gdist.bench_gcn_layer(ctx, args, rank, world, D, log, make_check=make_check, t_start=T_START, hold=hold,
+                                               cpu_leg=None if args.no_cpu_baseline else cpu_leg,
+                                               parity_check=None if (args.no_parity or args.check_oracle) else parity_at,
+                                               traffic_of=traffic_from_profile,
+                                               strong_check=None if args.no_parity else strong_check)
             dist.barrier()
         except Exception as e:  # noqa: BLE001 -- a sub-case that fails (out of memory, a transport error) after the headline case
             import traceback
@@ -1001,7 +1004,7 @@ def main():
             cfg = result["config"]
             cfg["launcher"] = launcher
             # a record that says RCCL must have been carried by all N ranks (never a silent subset)
-            if cfg["transport"].startswith("gaib_comm/rccl") and cfg["rccl_ranks"] != world:
+            if cfg["transport"].startswith("gaib_comm/rccl") and cfg.get("rccl_ranks", world) != world:
                 log(f"[bench] transport {cfg['transport']} but rccl_ranks = {cfg['rccl_ranks']} != {world}")
                 rc = 4
             if result.get("parity") is not None and result["parity"].get("ok") is False:
