@@ -1,21 +1,27 @@
 // sgemm_skinny.hip -- the dense products of a layer whose output or inner width is the class count or the input feature
 // count (47 and 100 on the products shape): matmul -> sgemm_gpu -> cublasSgemm (src/utilities/math_functions.cu:321-343; CPU:
-// matmul -> cblas_sgemm, math_functions.cpp:142-171) at   rows x 47 x {128, 256},  rows x {128, 256} x 47 (NT),
-// {128, 256} x 47 x rows (TN)  and  rows x 128 x 100.
+// matmul -> cblas_sgemm, math_functions.cpp:142-171) at   rows x 47 x {64, 128, 256},  rows x {64, 128, 256} x 47 (NT),
+// {128, 256} x 47 x rows (TN),  rows x 128 x 100  and  rows x 256 x 100 (two column slabs).
 //
-// These are HBM-stream shapes (<= 17 flop / B): both operands leave HBM once, the output is written once, and the matrix cores
-// need 0.6-0.9 of the time the bytes need -- IF a tile wastes no columns.  Round 5 ran them through kernels built for 128-wide
-// outputs: 32 x 32 tiles (a 47-wide output pays for 64 columns: 27 % of the matrix-core time), operands requested ONE 8-column
-// step (200 ns of MFMA work) ahead of their use, i.e. a memory latency exposed at every new 128-B line -- 2.1-3.5 TB/s
-// (profiles/r06/gemm_narrow_pmc.json: traffic = 1.0-1.15 x the algorithmic bytes, SQ_WAIT_INST_ANY 35-60 % of the wave time:
-// not over-fetch, under-issue).  Here:
+// These are HBM-stream shapes (<= 17 flop / B, the fp32 MFMA / HBM ridge is at 19.6): both operands leave HBM once, the output
+// is written once, and the matrix cores need 0.6-0.9 of the time the bytes need -- IF a tile wastes no columns.  Round 5 ran
+// them through kernels built for 128-wide outputs: 32 x 32 tiles (a 47-wide output pays for 64 columns: 27 % of the
+// matrix-core time), operands requested ONE 8-column step (200 ns of MFMA work) ahead of their use, i.e. a memory latency
+// exposed at every new 128-B line -- 2.1-3.5 TB/s (profiles/r06/gemm_narrow_pmc.json "before": traffic = 1.0-1.15 x the
+// algorithmic bytes, SQ_WAIT_INST_ANY 35-60 % of the wave time: not over-fetch, under-issue).  Here:
 //   * v_mfma_f32_16x16x4_f32: 47 columns cost 48;
-//   * the SMALL operand (W or its transpose, <= 128 x 48 / 48 x 128 ... 256 x 48) lives in REGISTERS for the life of a
-//     persistent wave, laid out as MFMA operand fragments: the inner loop reads no LDS and has no barrier;
-//   * the STREAMED operand is requested a whole row tile (16 rows x K: 3-16 KB per wave) ahead, 16-byte loads, every row's
-//     lines requested in one burst; two waves per SIMD wherever the registers allow;
+//   * the SMALL operand (W or its transpose, <= 128 x 48 / 48 x 128 / 100 x 128 ... 256 x 48) lives in REGISTERS for the life
+//     of a persistent wave, laid out as MFMA operand fragments: the inner loop reads no LDS and has no barrier;
+//   * the STREAMED operand comes through buffer loads -- one descriptor per row tile, loop-invariant lane offsets, no 64-bit
+//     address arithmetic, rows past the matrix read as zeros -- into a RING of register tiles: NBUF - 1 tiles (3-16 KB each)
+//     are in flight while one runs on the matrix cores, and a round of NBUF steps is straight-line code so that the
+//     compiler's vmcnt waits are exact (with an exit test between the steps they drained the ring);
 //   * row-stream kernel: the product is computed TRANSPOSED (D^T = op(B)^T . A^T), so that a lane ends up with four consecutive
-//     COLUMNS of one output row: 16-byte stores, one per 16 x 16 tile instead of four 4-byte ones.
+//     COLUMNS of one output row: 16-byte stores, one per 16 x 16 tile instead of four 4-byte ones; a 47-wide output leaves
+//     through a compact LDS image as whole 128-B lines.
+// Measured at 2.45 M rows (profiles/r06/gemm_narrow_pmc.json "after", profiles/r06/gemm_skinny/): 0.31-0.37 ms for the
+// 128 x 47 shapes (round 5: 0.49-0.62), 0.60-0.72 for 256 x 47 (0.88-1.17), 0.57 / 1.12 for x 128 / 256 x 100 (0.71 / 1.45):
+// 4.1-5.6 TB/s against an in-run stream copy of 6.0, traffic 1.00-1.05 x the algorithmic bytes.
 // f32-input MFMA is a k-ordered chain of exact fp32 fmas; which k a lane pair carries is free as long as both operands agree,
 // which is what lets a lane load 16 contiguous bytes of a row and use them in four consecutive MFMAs.
 #include "common.h"

@@ -227,7 +227,15 @@ def main():
     W100 = torch.randn(100, 128, device="cuda")
     y128 = torch.empty(nv, 128, device="cuda")
     res["sgemm NN 2.45M x 128 x 100"] = ev_time(lambda: ctx.sgemm(x100, W100, y128))
-    del x100, W100, y128
+    # round 6 (sgemm_skinny.hip): the hidden-256 first layer as two column slabs, the output layer's forward and the 128-wide
+    # input gradient
+    W100b, y256 = torch.randn(100, 256, device="cuda"), torch.empty(nv, 256, device="cuda")
+    res["sgemm NN 2.45M x 256 x 100"] = ev_time(lambda: ctx.sgemm(x100, W100b, y256))
+    del x100, W100, y128, W100b, y256
+    x128, W47b, y47 = torch.randn(nv, 128, device="cuda"), torch.randn(128, 47, device="cuda"), torch.empty(nv, 47, device="cuda")
+    res["sgemm NN 2.45M x 47 x 128"] = ev_time(lambda: ctx.sgemm(x128, W47b, y47))
+    res["sgemm NT 2.45M x 128 x 47"] = ev_time(lambda: ctx.sgemm(y47, W47b, x128, False, True))
+    del x128, W47b, y47
     torch.cuda.empty_cache()
     ctx.close()
     res["GCN 128->128 layer step, products shape (the bench step)"] = layer_step(L.GCN, "ogbn-products", 128, 128, True)
