@@ -1087,7 +1087,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37) || (sv >= 60 && sv <= 64);  // (60 .. 64 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
+  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37) || (sv >= 60 && sv <= 66);  // (60 .. 66 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   // The LDS-tiled kernel loads a ROW-MAJOR A ([M][K], K odd: dX = G [N x 47] . W^T of the output layer) with 16-byte

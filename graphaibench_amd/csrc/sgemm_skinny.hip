@@ -151,6 +151,28 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
     constexpr bool TAIL = decltype(tailc)::value;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
+      const int64_t row0 = tile * ROWS + 16 * rt;
+      // C +=: the tile's old values are requested HERE, behind the next tile's operand loads and before this tile's MFMAs, and
+      // used after them (3-7 us later).  Requested where they are added they are the youngest loads of the wave: the wait for
+      // them drains the ring at every tile (2.45 M x 256 x 256 C += inside the SAGE epoch: 3.07 ms per launch against 2.36 for C =)
+      constexpr int NP = LDSOUT ? (16 * 16 * CT / 4 + 63) / 64 : CT;  // 16-byte pieces of old C per lane
+      f4 old[ACC ? NP : 1];
+      if constexpr (ACC && !TAIL) {
+        if constexpr (LDSOUT) {
+          const float* cb0 = g.C + row0 * N;
+          const int last = 16 * N - 4;
+#pragma unroll
+          for (int x = 0; x < NP; ++x) {
+            const int f = 4 * (lane + 64 * x);
+            old[x] = *reinterpret_cast<const f4*>(cb0 + (f < last ? f : last));
+          }
+        } else {
+          const float* pc0 = g.C + (row0 + j) * ldn + n0 + 4 * q;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) old[ct] = *reinterpret_cast<const f4*>(pc0 + 16 * ct);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       f4 acc[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[ct] = f4{0.f, 0.f, 0.f, 0.f};
@@ -164,7 +186,6 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(bx[ct], bufx[s][rt], acc[ct]);
       }
-      const int64_t row0 = tile * ROWS + 16 * rt;
       if constexpr (LDSOUT) {
         // columns past N (the ragged edge of the last column tile) go to a scrap word behind the image: the write itself is
         // unconditional
@@ -181,17 +202,8 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
         // the image = C[row0 * N .. (row0 + 16) * N), 16-byte pieces (row0 % 16 == 0: the base is 64-byte aligned).  A lane
         // whose piece lies past the image takes the image's last piece again: the same bytes to the same place.
         float* cb = g.C + row0 * N;
-        constexpr int NP = (16 * 16 * CT / 4 + 63) / 64;  // 16-byte pieces per lane
         if constexpr (!TAIL) {
           const int last = 16 * N - 4;
-          f4 old[NP];
-          if constexpr (ACC) {
-#pragma unroll
-            for (int x = 0; x < NP; ++x) {
-              const int f = 4 * (lane + 64 * x);
-              old[x] = *reinterpret_cast<const f4*>(cb + (f < last ? f : last));
-            }
-          }
 #pragma unroll
           for (int x = 0; x < NP; ++x) {
             int f = 4 * (lane + 64 * x);
@@ -218,8 +230,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_rows_kernel(SkinnyArgs g) {
         const int64_t row = row0 + j;
         const bool rok = !TAIL || row < g.M;
         float* pc = g.C + (rok ? row : 0) * ldn + n0 + 4 * q;
-        f4 old[CT];
-        if constexpr (ACC) {
+        if constexpr (ACC && TAIL) {  // (the one partial tile: rows past the end were pointed at row 0)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) old[ct] = *reinterpret_cast<const f4*>(pc + 16 * ct);
         }
@@ -459,16 +470,17 @@ int launch_tn(gaib_ctx* ctx, SkinnyArgs a) {
 }  // namespace
 
 // Called by gaib_sgemm_ex before its own rules.  *handled = 1: the product was launched here.  Shapes (sgemm_variant 61 turns
-// the family off, 62 / 63 the row-stream / TN half only, 64 the column-slab form of rows x 256 x 100):
+// the family off, 62 / 63 the row-stream / TN half only, 64 the column-slab form of rows x 256 x 100, 66 the square products):
 //   NN  rows x (33..48) x 64 | 128 | 256      forward of the output layer (64: the GAT models' dense head)
 //   NT  rows x 64 | 128 | 256 x (33..48)      input gradient of the output layer
-//   NN  rows x 128 x 100                      forward of the first layer (K = 16 G + 4)
+//   NN  rows x 128 x 100                      forward of the first layer (K = 16 G + 4); rows x 256 x 100 as two column slabs
+//   NN / NT  rows x 128 x 128, rows x 256 x 256   the hidden layers' products that are not fused into an aggregation
 //   TN  (68..128 | 196..256, % 4) x (33..48) x rows   weight gradient of the output layer
 int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* d_A,
                           const float* d_B, int flags, float* d_C, int* handled) {
   *handled = 0;
   const int sv = ctx->sgemm_variant;
-  if (sv != 0 && sv != 60 && sv != 62 && sv != 63 && sv != 64) return GAIB_OK;
+  if (sv != 0 && sv != 60 && sv != 62 && sv != 63 && sv != 64 && sv != 66) return GAIB_OK;
   if ((((uintptr_t)d_A | (uintptr_t)d_B) & 3) != 0 || (((uintptr_t)d_C) & 15) != 0) return GAIB_OK;
   SkinnyArgs a;
   a.A = d_A;
@@ -495,13 +507,26 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
     // Schedules as measured at 2.45 M rows (scripts/gemm_narrow.py; ring depth NBUF, waves per SIMD WPS, row tiles per step RT;
     // profiles/r06/gemm_skinny_sweep.jsonl): a deeper ring pays where a wave alone on its SIMD has the registers for it;
     // non-temporal loads / stores changed nothing (0.34-0.36 either way) and are not built.
-    if (!transB && ct == 3 && K == 64) GAIB_ROWS(4, 0, 3, 1, false, 2, true, 4);     // 47 x 64 (the GAT models' dense head)
+    if (!transB && ct == 3 && K == 64) GAIB_ROWS(4, 0, 3, 1, false, 2, true, 3);     // 47 x 64 (the GAT models' dense head)
     if (!transB && ct == 3 && K == 128) GAIB_ROWS(8, 0, 3, 1, false, 1, true, 5);    // 0.349 (WPS 2, NBUF 2) -> 0.32 ms (NBUF 4: 0.324, 6: 0.317 with 52-68 registers spilled)
     if (!transB && ct == 3 && K == 256) GAIB_ROWS(16, 0, 3, 1, false, 1, true, 2);   // 0.600 (NBUF 3: 0.605)
     if (transB && N == 64 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 4, 2, true, 2, false, 3);
     if (transB && N == 128 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 8, 2, true, 1, false, 3);   // 0.445 (WPS 2, NBUF 2) -> 0.36-0.40
     if (transB && N == 256 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 16, 1, true, 1, false, 4);  // 0.712 (RT 2, NBUF 2) -> 0.69 (RT 2, NBUF 3: its C += form spills 46 registers)
     if (!transB && N == 128 && K == 100) GAIB_ROWS(6, 1, 8, 1, false, 1, false, 2);  // 0.571 (NBUF 3: 0.569)
+    // The square hidden-layer products (MFMA-bound: 32 flop / B): the same kernel, no LDS in the loop -- 128 x 128 with the whole
+    // matrix in registers, 256 x 256 as four 64-column slabs (each slab's 256 x 64 piece of op(B) = 256 registers; the slabs of a
+    // row tile run side by side on the same XCD: traffic stays at the algorithmic bytes).  2.45 M x 256 x 256: 2.75 -> 2.45 ms =
+    // 0.83 of the fp32 MFMA peak (the LDS-slab streaming kernel 0.74, rocBLAS 2.51); sgemm_variant 66 keeps the streaming kernel.
+    if (sv != 66 && N == 128 && K == 128) {
+      if (transB) GAIB_ROWS(8, 0, 8, 1, true, 1, false, 2);
+      GAIB_ROWS(8, 0, 8, 1, false, 1, false, 2);
+    }
+    if (sv != 66 && N == 256 && K == 256) {
+      a.N = 64;
+      if (transB) GAIB_ROWS(16, 0, 4, 1, true, 1, false, 2);
+      GAIB_ROWS(16, 0, 4, 1, false, 1, false, 2);
+    }
     // two column slabs of 128 (the matrix in registers is 100 x 128): 1.45 -> 1.11-1.14 ms; four slabs of 64 at two waves per SIMD: 1.32
     if (!transB && N == 256 && K == 100 && sv != 64) {
       a.N = 128;

@@ -23,6 +23,7 @@ SHAPES = [  # (form, M, N, K)
     ("NN", NV, 47, 128), ("NN", NV, 47, 256), ("NN", NV, 128, 100), ("NN", NV, 256, 100), ("NN", NV, 256, 47),
     ("NT", NV, 128, 47), ("NT", NV, 256, 47),          # input gradients of the 47-wide output layer: G[nv x 47] . W[din x 47]^T
     ("NN", NV, 128, 128), ("NN", NV, 256, 256), ("TN", 256, 256, NV),  # the wide ones, for scale
+    ("NT", NV, 128, 128), ("NT", NV, 256, 256),
 ]
 
 
