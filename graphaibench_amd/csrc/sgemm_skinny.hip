@@ -510,6 +510,9 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
     if (!transB && ct == 3 && K == 64) GAIB_ROWS(4, 0, 3, 1, false, 2, true, 3);     // 47 x 64 (the GAT models' dense head)
     if (!transB && ct == 3 && K == 128) GAIB_ROWS(8, 0, 3, 1, false, 1, true, 5);    // 0.349 (WPS 2, NBUF 2) -> 0.32 ms (NBUF 4: 0.324, 6: 0.317 with 52-68 registers spilled)
     if (!transB && ct == 3 && K == 256) GAIB_ROWS(16, 0, 3, 1, false, 1, true, 2);   // 0.600 (NBUF 3: 0.605)
+    // (the same three products with B stored [K x N] -- no layer of the reference has a 47-wide INPUT, but the form costs nothing)
+    if (!transB && N == 128 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 8, 2, false, 1, false, 3);
+    if (!transB && N == 256 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 16, 1, false, 1, false, 4);
     if (transB && N == 64 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 4, 2, true, 2, false, 3);
     if (transB && N == 128 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 8, 2, true, 1, false, 3);   // 0.445 (WPS 2, NBUF 2) -> 0.36-0.40
     if (transB && N == 256 && K > 32 && K <= 48) GAIB_ROWS(3, 0, 16, 1, true, 1, false, 4);  // 0.712 (RT 2, NBUF 2) -> 0.69 (RT 2, NBUF 3: its C += form spills 46 registers)

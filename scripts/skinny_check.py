@@ -15,7 +15,7 @@ from graphaibench_amd import capi  # noqa: E402
 CASES = [  # (form, M, N, K): NN / NT: rows = M; TN: rows = K
     ("NN", 0, 47, 128), ("NN", 0, 47, 256), ("NN", 0, 41, 128), ("NN", 0, 33, 256), ("NN", 0, 48, 128),
     ("NT", 0, 128, 47), ("NT", 0, 256, 47), ("NT", 0, 128, 48), ("NT", 0, 256, 45),
-    ("NN", 0, 128, 100), ("NN", 0, 41, 64), ("NT", 0, 64, 41), ("NN", 0, 256, 100), ("NN", 0, 128, 128), ("NT", 0, 128, 128), ("NN", 0, 256, 256), ("NT", 0, 256, 256),
+    ("NN", 0, 128, 100), ("NN", 0, 41, 64), ("NT", 0, 64, 41), ("NN", 0, 256, 100), ("NN", 0, 128, 47), ("NN", 0, 256, 47), ("NN", 0, 128, 128), ("NT", 0, 128, 128), ("NN", 0, 256, 256), ("NT", 0, 256, 256),
     ("TN", 128, 47, 0), ("TN", 256, 47, 0), ("TN", 100, 47, 0), ("TN", 128, 41, 0), ("TN", 200, 33, 0), ("TN", 256, 48, 0),
 ]
 ROWS = [65536, 65537, 65551, 100_003, 300_001, 1_000_000]

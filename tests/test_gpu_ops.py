@@ -1240,7 +1240,7 @@ def test_sgemm_tn_odd_width_matches_the_tiled_kernel_and_reads_nothing_past_the_
     ("NN", 65537, 47, 128), ("NN", 70001, 47, 256), ("NN", 65536, 41, 128), ("NN", 65551, 33, 256), ("NN", 66000, 48, 128),
     ("NT", 65537, 128, 47), ("NT", 70001, 256, 47), ("NT", 65540, 128, 48), ("NT", 65551, 256, 45),
     ("NN", 65537, 128, 100), ("NN", 65551, 41, 64), ("NT", 65537, 64, 41), ("NN", 65537, 256, 100),
-    ("NN", 65537, 128, 128), ("NT", 65551, 128, 128), ("NN", 65537, 256, 256), ("NT", 66001, 256, 256),
+    ("NN", 65537, 128, 47), ("NN", 65551, 256, 47), ("NN", 65537, 128, 128), ("NT", 65551, 128, 128), ("NN", 65537, 256, 256), ("NT", 66001, 256, 256),
     ("TN", 128, 47, 65537), ("TN", 256, 47, 70001), ("TN", 100, 47, 65551), ("TN", 128, 41, 65536), ("TN", 200, 33, 66001),
     ("TN", 256, 48, 65540)])
 @pytest.mark.parametrize("accum,relu", [(0, 0), (1, 1)])
