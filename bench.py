@@ -37,8 +37,11 @@ inputs resident in HBM when the timed region starts.
     every minute.  The N = 1, GAT and epoch records are held the same way once their GPU measurement is complete.
     --workload gcn-papers: BASELINE config 5's layer (GCN 128 -> 128 on the ogbn-papers100M-shaped graph in vertex ranges
     of 1/8 of it: at N = 8 the whole graph); --check-oracle compares every rank's outputs with the oracle's GLOBAL run.
-    --workload gat-reddit: config 4's layer.  --workload epoch-sage-products | epoch-gcn-products | epoch-gat-reddit: one
-    training EPOCH of the model configs through the trainer CLI per step (bench_epoch).
+    --workload gat-reddit: config 4's layer; with --gpus N (round 6) on a vertex-range partition of the reddit-shaped graph -- the
+    one-rank step of the same layer is taken in the run and rank 0's rows are held to it (dist.bench_gat_layer).
+    --workload epoch-sage-products | epoch-gcn-products | epoch-gat-reddit | epoch-gcn-cora [--hidden H]: one training EPOCH of the
+    model configs through the trainer CLI per step (bench_epoch).  The default N = 1 run appends configs 2-4 as budgeted legs
+    (`other_configs`, --other-configs-s) after the headline record is held.
 
 One JSON line on rank 0.  `roofline` prices the dominant kernel (spmm_gemm_kernel: the one-wave-per-row
 aggregation with the dense product riding on it) by ALGORITHMIC bytes per launch / mean launch time measured
