@@ -376,7 +376,7 @@ template <bool BMASK> struct TnDepth { static constexpr int PD = BMASK ? 4 : 8; 
 // where the bytes need 0.29 (profiles/r06/gemm_narrow_pmc.json: 0.27 of the roof).  Here tile b of B holds the columns 32 b + i:
 // a lane reads B[k][i] and B[k][32 + i] with two 4-byte loads (coalesced: 128 + 60 bytes of the 188-byte row), the row pair
 // costs 4 x NB MFMAs, and the accumulators -- 128 registers instead of 256 -- leave room for two waves per SIMD.  Plain form.
-template <bool BMASK, int QM, int QN, bool NUNAL = false, int NB = 4>
+template <bool BMASK, int QM, int QN, bool NUNAL = false, int NB = 4, bool NTS = false>
 __global__ __launch_bounds__(256, (NB < 4 ? 2 : 1)) void sgemm_tn_reg_kernel(GemmArgs g) {
   static_assert(!(BMASK && NUNAL), "the masked form writes float4s back: N must be a multiple of 4 there");
   static_assert(NB == 4 || (!BMASK && !NUNAL && QN == 1), "the narrow-B form: plain, one column quadrant");
@@ -435,15 +435,15 @@ __global__ __launch_bounds__(256, (NB < 4 ? 2 : 1)) void sgemm_tn_reg_kernel(Gem
       const int64_t k = kp + 2 * s + h;
       const bool kok = full || k < kend;
       const int64_t kr = kok ? phys(kp) + 2 * s + h : 0;
-      f4 va = *reinterpret_cast<const f4*>(g.A + kr * g.M + mo);
+      f4 va = NTS ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(g.A + kr * g.M + mo)) : *reinterpret_cast<const f4*>(g.A + kr * g.M + mo);
       f4 vb;
       if constexpr (NB < 4) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) vb[b] = g.B[kr * g.N + ncl[b]];
       } else if constexpr (NUNAL) vb = *reinterpret_cast<const f4u*>(g.B + kr * g.N + no);
-      else vb = *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
+      else vb = NTS ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(g.B + kr * g.N + no)) : *reinterpret_cast<const f4*>(g.B + kr * g.N + no);
       if constexpr (BMASK) {
-        f4 mk = *reinterpret_cast<const f4*>(g.bmask + kr * g.N + no);
+        f4 mk = NTS ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(g.bmask + kr * g.N + no)) : *reinterpret_cast<const f4*>(g.bmask + kr * g.N + no);
         if (!full) mk = kok ? mk : zero4;  // (a zero mask also keeps the row out of the write-back below)
         sm[set][s] = mk;
       }
@@ -472,7 +472,10 @@ __global__ __launch_bounds__(256, (NB < 4 ? 2 : 1)) void sgemm_tn_reg_kernel(Gem
         for (int e = 0; e < 4; ++e) vb[e] = mk[e] > 0.f ? vb[e] : 0.f;  // d_relu (math_functions.cu:258-268)
         sb[set][s] = vb;
         const int64_t k = kp + 2 * s + h;
-        if (nok && qm == 0 && (full || k < kend)) *reinterpret_cast<f4*>(g.bwrite + (phys(kp) + 2 * s + h) * g.N + no) = vb;
+        if (nok && qm == 0 && (full || k < kend)) {
+          if constexpr (NTS) __builtin_nontemporal_store(vb, reinterpret_cast<f4*>(g.bwrite + (phys(kp) + 2 * s + h) * g.N + no));
+          else *reinterpret_cast<f4*>(g.bwrite + (phys(kp) + 2 * s + h) * g.N + no) = vb;
+        }
       }
     }
   };
@@ -566,7 +569,7 @@ template <bool BMASK> struct TgCfg {
   static constexpr int STAGE_F = ARR * TG_R * 256;           // floats per stage
 };
 
-template <bool BMASK>
+template <bool BMASK, bool NTS = false>  // NTS: non-temporal LDS-DMA pieces and write-back (every line is touched once)
 __global__ __launch_bounds__(256, 1) void sgemm_tn_glds_kernel(GemmArgs g) {
   using Cfg = TgCfg<BMASK>;
   constexpr int STAGES = Cfg::STAGES, NG = Cfg::NG, STAGE_F = Cfg::STAGE_F;
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_glds_kernel(GemmArgs g) {
     k = k < g.K ? k : g.K - 1;  // rows past K: a valid address, zeroed by the reader
     const float* src = arr == 0 ? pa + k * g.M : (arr == 1 ? pb + k * g.N : pm + k * g.N);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(slot + (arr * TG_R + row) * 256), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(slot + (arr * TG_R + row) * 256), 16, 0, NTS ? 2 : 0);
   };
   f16v acc[4][4];
 #pragma unroll
@@ -627,7 +630,10 @@ __global__ __launch_bounds__(256, 1) void sgemm_tn_glds_kernel(GemmArgs g) {
     if constexpr (BMASK) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) fb[s][e] = mk[s][e] > 0.f ? fb[s][e] : 0.f;  // d_relu (math_functions.cu:258-268)
-      if ((s >> 1) == qm && nok && live) *reinterpret_cast<f4*>(g.bwrite + k * g.N + ncol) = fb[s];
+      if ((s >> 1) == qm && nok && live) {
+        if constexpr (NTS) __builtin_nontemporal_store(fb[s], reinterpret_cast<f4*>(g.bwrite + k * g.N + ncol));
+        else *reinterpret_cast<f4*>(g.bwrite + k * g.N + ncol) = fb[s];
+      }
     }
   };
   // one stage: the 64 MFMAs of stage t out of (ca, cb), everything stage t + 1 needs in their shadow, into (na, nb)
@@ -706,15 +712,18 @@ int launch_tn_glds(gaib_ctx* ctx, GemmArgs g) {
   GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)blocks * g.slab));
   g.C = (float*)ctx->ws;
   ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g), 0, GemmTag(g).s);
-#define GAIB_TG(MASK_)                                                                                                 \
+#define GAIB_TG(MASK_, NTS_)                                                                                           \
   do {                                                                                                                 \
     const size_t lds = sizeof(float) * (size_t)TgCfg<MASK_>::STAGES * TgCfg<MASK_>::STAGE_F;                           \
-    GAIB_HIP(hipFuncSetAttribute((const void*)sgemm_tn_glds_kernel<MASK_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    GAIB_HIP(hipFuncSetAttribute((const void*)sgemm_tn_glds_kernel<MASK_, NTS_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  160 * 1024));                                                                         \
-    sgemm_tn_glds_kernel<MASK_><<<blocks, 256, lds, ctx->stream>>>(g);                                                 \
+    sgemm_tn_glds_kernel<MASK_, NTS_><<<blocks, 256, lds, ctx->stream>>>(g);                                           \
   } while (0)
-  if (g.bmask) GAIB_TG(true);
-  else GAIB_TG(false);
+  // (round 6: non-temporal pieces and write-back, which took 0.09 ms off the register-resident masked form at 128 x 128, change
+  // nothing here -- 11.23 vs 11.26 ms for the four products of the SAGE 256 layer step; sgemm_variant 28 runs them for the record)
+  if (g.bmask && ctx->sgemm_variant == 28) GAIB_TG(true, true);
+  else if (g.bmask) GAIB_TG(true, false);
+  else GAIB_TG(false, false);
 #undef GAIB_TG
   GAIB_LAUNCH_CHECK();
   const int64_t n = g.M * g.N;
@@ -751,10 +760,15 @@ int launch_tn_reg(gaib_ctx* ctx, GemmArgs g) {
   g.C = (float*)ctx->ws;
   {
     ProfScope ps(ctx, "sgemm", gemm_bytes(g, accum), gemm_flops(g), 0, GemmTag(g).s);
+  // NTS (round 6): the masked form streams three arrays and writes one back, each touched once: non-temporal loads and stores
+  // (1.00 -> 0.91 ms at 128 x 128 x 2.45 M inside the GCN layer step, four alternations; sgemm_variant 39 = without).  The
+  // plain form is bound by the matrix cores: sgemm_variant 29 runs it non-temporal for the comparison.
 #define GAIB_TN(QM_, QN_)                                                                          \
   do {                                                                                             \
-    if (g.bmask) sgemm_tn_reg_kernel<true, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);          \
+    if (g.bmask && ctx->sgemm_variant != 39) sgemm_tn_reg_kernel<true, QM_, QN_, false, 4, true><<<blocks, 256, 0, ctx->stream>>>(g); \
+    else if (g.bmask) sgemm_tn_reg_kernel<true, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);    \
     else if (g.N % 4 != 0) sgemm_tn_reg_kernel<false, QM_, QN_, true><<<blocks, 256, 0, ctx->stream>>>(g); \
+    else if (ctx->sgemm_variant == 29) sgemm_tn_reg_kernel<false, QM_, QN_, false, 4, true><<<blocks, 256, 0, ctx->stream>>>(g); \
     else sgemm_tn_reg_kernel<false, QM_, QN_><<<blocks, 256, 0, ctx->stream>>>(g);                 \
   } while (0)
     if (narrow && g.N <= 32) {
@@ -1087,7 +1101,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 37) || (sv >= 60 && sv <= 66);  // (60 .. 66 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
+  const bool auto_rule = sv == 0 || sv == 28 || sv == 29 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 39) || (sv >= 60 && sv <= 66);  // (60 .. 66 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   // The LDS-tiled kernel loads a ROW-MAJOR A ([M][K], K odd: dX = G [N x 47] . W^T of the output layer) with 16-byte

@@ -480,7 +480,7 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
                           const float* d_B, int flags, float* d_C, int* handled) {
   *handled = 0;
   const int sv = ctx->sgemm_variant;
-  if (sv != 0 && sv != 60 && sv != 62 && sv != 63 && sv != 64 && sv != 66) return GAIB_OK;
+  if (sv != 0 && sv != 28 && sv != 29 && sv != 39 && sv != 60 && sv != 62 && sv != 63 && sv != 64 && sv != 66) return GAIB_OK;  // (28 / 29 / 39: the weight gradients' cache-policy switches)
   if ((((uintptr_t)d_A | (uintptr_t)d_B) & 3) != 0 || (((uintptr_t)d_C) & 15) != 0) return GAIB_OK;
   SkinnyArgs a;
   a.A = d_A;
