@@ -24,6 +24,8 @@
 // sgemm_skinny.hip: *handled = 1 when the product was launched there
 int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* d_A,
                           const float* d_B, int flags, float* d_C, int* handled);
+int gaib_sgemm_wide_tn_try(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* d_A, float* d_G, const float* d_mask,
+                           int flags, float* d_C, int* handled);
 
 namespace {
 
@@ -1051,6 +1053,10 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
     int handled = 0;
     GAIB_TRY(gaib_sgemm_skinny_try(ctx, transA, transB, M, N, K, d_A, d_B, flags, d_C, &handled));
     if (handled) return GAIB_OK;
+    if (transA && !transB && ctx->sgemm_variant != 67) {  // weight gradients with a 100- / 128-wide input side (wide_tn_kernel)
+      GAIB_TRY(gaib_sgemm_wide_tn_try(ctx, M, N, K, d_A, const_cast<float*>(d_B), nullptr, flags, d_C, &handled));
+      if (handled) return GAIB_OK;
+    }
   }
   GemmArgs g;
   g.A = d_A;
@@ -1101,7 +1107,7 @@ extern "C" int gaib_sgemm_ex(gaib_ctx* ctx, int transA, int transB, int64_t M, i
   // MFMAs (212 VGPRs, four MFMAs per ds_read2 in the listing): 2.97-3.00 ms vs 2.60-2.63.
   const int64_t kmin = ctx->sgemm_variant == 44 ? 129 : (ctx->sgemm_variant == 45 ? 128 : 96);  // (45: the rule before K = 100 was measured)
   const int sv = ctx->sgemm_variant;
-  const bool auto_rule = sv == 0 || sv == 28 || sv == 29 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 39) || (sv >= 60 && sv <= 66);  // (60 .. 66 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
+  const bool auto_rule = sv == 0 || sv == 28 || sv == 29 || sv == 44 || sv == 45 || (sv >= 30 && sv <= 39) || (sv >= 60 && sv <= 67);  // (60 .. 67 switch sgemm_skinny.hip's family only)  // (30 .. 36 concern the weight gradient only, 37 the tiled kernel's loads)
   if (stream_shape && (sv == 41 || (auto_rule && M >= 65536 && K >= kmin)))
     return transB ? launch_stream<true>(ctx, g) : launch_stream<false>(ctx, g);
   // The LDS-tiled kernel loads a ROW-MAJOR A ([M][K], K odd: dX = G [N x 47] . W^T of the output layer) with 16-byte
@@ -1136,6 +1142,11 @@ extern "C" int gaib_sgemm_drelu(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, 
     return gaib_sgemm(ctx, 1, 0, M, N, K, d_A, d_G, accum, d_C);
   }
   GAIB_CHECK(d_C && d_A, "gaib_sgemm_drelu: A/C is NULL");
+  if (ctx->sgemm_variant != 67) {  // round 6: 16 x 16 tiles, 7 of them for a 100-wide input, a deeper ring (sgemm_skinny.hip)
+    int handled = 0;
+    GAIB_TRY(gaib_sgemm_wide_tn_try(ctx, M, N, K, d_A, d_G, d_mask, accum ? GAIB_ACCUMULATE : 0, d_C, &handled));
+    if (handled) return GAIB_OK;
+  }
   GAIB_HIP(hipSetDevice(ctx->device));
   GemmArgs g;
   g.A = d_A;

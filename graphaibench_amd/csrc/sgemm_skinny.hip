@@ -421,6 +421,147 @@ __global__ __launch_bounds__(256, WPS) void skinny_tn_kernel(SkinnyArgs g) {
   }
 }
 
+// ---- wide TN:  C[MW x N] (=|+=) A[K x MW]^T . G[K x N],  K (= g.M) in the millions, MW <= 16 MT (7 tiles: the 100 input
+// features; 8 compiles too and measures like sgemm.hip's kernel: not dispatched), N = 128 NH -- the weight gradients of the layers
+// whose INPUT is 100 wide, plain or with the
+// layer's d_relu folded in (MASK: G <- G where mask > 0 else 0 on the way, written back in place; math_functions.cu:258-268).
+// The 32 x 32 register-resident kernel of sgemm.hip pays 128 rows for 100 (22 % of its MFMAs) and prefetches ONE set of 8 rows;
+// here a wave keeps the whole MW x 128 output of its column half in 16 x 16 accumulators (7 x 8 x 4 = 224 registers), A arrives
+// as one 4-byte load per 16-row tile and step (lane (i, q): A[k + q][16 mt + i]: 64 contiguous bytes per row and tile), G and the
+// mask as two 16-byte loads (lane (j, q): columns 128 half + 64 hb + 4 j .. + 3: which column a tile holds is free as long as the
+// epilogue knows), through a ring of NBUF register sets of S steps.  Loads AND the masked write-back go through buffer
+// descriptors whose size is what is left of the matrices: rows past K read as zeros and their stores are dropped by the
+// hardware, so the last, partial set needs no code of its own.  Every stream is touched once: non-temporal.  NH = 2: the two
+// column halves of a set run in waves w, w + 1 of one workgroup.  Partial outputs go to one slab per team (the halves write
+// disjoint columns) and are summed in fixed order by skinny_reduce_kernel.
+template <int MT, int NH, bool MASK, int S, int NBUF>
+__global__ __launch_bounds__(256, 1) void wide_tn_kernel(SkinnyArgs g, const float* mask, float* gwrite) {
+  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int MW = g.K, N = g.N;  // output rows / columns (N == 128 NH)
+  const int64_t KR = g.M;
+  constexpr int SR = 4 * S;
+  constexpr int TPW = 4 / NH;
+  const int half = wv % NH;
+  const int64_t W = (int64_t)gridDim.x * TPW;
+  const int64_t wid = (int64_t)blockIdx.x * TPW + wv / NH;
+  const int64_t nsets = (KR + SR - 1) / SR;
+  int voa[S][MT], vog[S][2];
+#pragma unroll
+  for (int st = 0; st < S; ++st) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) voa[st][mt] = 4 * ((4 * st + q) * MW + (16 * mt + i < MW ? 16 * mt + i : 0));  // past MW: column 0, rows never stored
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) vog[st][hb] = 4 * ((4 * st + q) * N + 128 * half + 64 * hb + 4 * i);
+  }
+  f4 acc[MT][2][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][hb][e] = f4{0.f, 0.f, 0.f, 0.f};
+  float sa[NBUF][S][MT];
+  f4 sg[NBUF][S][2];
+  f4 sm[MASK ? NBUF : 1][MASK ? S : 1][2];
+  const int64_t a_bytes = KR * (int64_t)MW * 4, g_bytes = KR * (int64_t)N * 4;
+  auto rsrc_at = [&](const float* base, int64_t off, int64_t total) {
+    const int64_t left = total - off;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + off), 0,
+                                            (int)(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+  };
+  auto fetch = [&](int set, int64_t s) {
+    const int64_t offa = s * SR * (int64_t)MW * 4, offg = s * SR * (int64_t)N * 4;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_at(g.A, offa, a_bytes), rg = rsrc_at(g.B, offg, g_bytes);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) sa[set][st][mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, voa[st][mt], 0, 2));
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rg, vog[st][hb], 0, 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sg[set][st][hb][e] = __uint_as_float(r[e]);
+      }
+    }
+    if constexpr (MASK) {
+      const __amdgpu_buffer_rsrc_t rm = rsrc_at(mask, offg, g_bytes);
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const u4_t r = __builtin_amdgcn_raw_buffer_load_b128(rm, vog[st][hb], 0, 2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm[set][st][hb][e] = __uint_as_float(r[e]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute = [&](int set, int64_t s) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MASK) {  // d_relu on the set that is about to be consumed (its loads landed NBUF - 1 sets ago), masked rows written back
+      const __amdgpu_buffer_rsrc_t rw = rsrc_at(gwrite, s * SR * (int64_t)N * 4, g_bytes);
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          u4_t w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = sm[set][st][hb][e] > 0.f ? sg[set][st][hb][e] : 0.f;
+            sg[set][st][hb][e] = v;
+            w[e] = __float_as_uint(v);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(w, rw, vog[st][hb], 0, 2);  // (rows past K: outside the descriptor, dropped)
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < S; ++st)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mt][hb][e] = mfma16(sa[set][st][mt], sg[set][st][hb][e], acc[mt][hb][e]);
+  };
+  // this team's sets wid + x W, x = 0 .. nw - 1 (the matrix's last set may be partial: zeros), in straight-line rounds of NBUF
+  const int64_t nw = wid < nsets ? (nsets - wid + W - 1) / W : 0;
+  auto set_of = [&](int64_t x) { return wid + (x < nw ? x : nw - 1) * W; };
+  if (nw > 0) {
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) fetch(b, set_of(b));
+    int64_t x = 0;
+    for (; x + NBUF <= nw; x += NBUF) {
+#pragma unroll
+      for (int b = 0; b < NBUF; ++b) {
+        fetch((b + NBUF - 1) % NBUF, set_of(x + b + NBUF - 1));
+        compute(b, wid + (x + b) * W);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+      if (x + b < nw) compute(b, wid + (x + b) * W);
+  }
+  // D[ii][jj] in lane (jj = l & 15, qq = l >> 4), register r: ii = 4 qq + r -> C[16 mt + ii][128 half + 64 hb + 4 jj + e]: the
+  // four e of one (mt, hb, r) are four consecutive columns -> one 16-byte store into the team's slab
+  float* P = g.slabs + wid * (int64_t)MW * N;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mt + 4 * q + r;
+      if (m < MW) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          f4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][hb][e][r];
+          *reinterpret_cast<f4*>(P + (int64_t)m * N + 128 * half + 64 * hb + 4 * i) = v;
+        }
+      }
+    }
+}
+
 // C[i] = (accum ? C[i] : 0) + sum_s slab[s][i], s in order (deterministic)
 __global__ void skinny_reduce_kernel(int64_t n, int slabs, const float* partial, int accum, int relu, float* C) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -467,6 +608,23 @@ int launch_tn(gaib_ctx* ctx, SkinnyArgs a) {
   return GAIB_OK;
 }
 
+template <int MT, int NH, bool MASK, int S, int NBUF>
+int launch_wide_tn(gaib_ctx* ctx, SkinnyArgs a, const float* mask, float* gwrite) {
+  const int64_t nsets = cdiv64(a.M, 4 * S);
+  const unsigned blocks = (unsigned)std::min<int64_t>(ctx->num_cus, cdiv64(nsets, 4 / NH));
+  const int64_t n = (int64_t)a.K * a.N;
+  const int64_t teams = (int64_t)blocks * (4 / NH);
+  GAIB_TRY(gaib_ws_reserve(ctx, sizeof(float) * (size_t)teams * (size_t)n));
+  a.slabs = (float*)ctx->ws;
+  // (teams past the last set store a slab of zeros: every slab the reduce reads is written by this launch)
+  wide_tn_kernel<MT, NH, MASK, S, NBUF><<<blocks, 256, 0, ctx->stream>>>(a, mask, gwrite);
+  GAIB_LAUNCH_CHECK();
+  const unsigned rg = (unsigned)std::min<int64_t>(cdiv64(n, 256), 1024);
+  skinny_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(n, (int)teams, a.slabs, a.accum, a.relu, a.C);
+  GAIB_LAUNCH_CHECK();
+  return GAIB_OK;
+}
+
 }  // namespace
 
 // Called by gaib_sgemm_ex before its own rules.  *handled = 1: the product was launched here.  Shapes (sgemm_variant 61 turns
@@ -480,7 +638,7 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
                           const float* d_B, int flags, float* d_C, int* handled) {
   *handled = 0;
   const int sv = ctx->sgemm_variant;
-  if (sv != 0 && sv != 28 && sv != 29 && sv != 39 && sv != 60 && sv != 62 && sv != 63 && sv != 64 && sv != 66) return GAIB_OK;  // (28 / 29 / 39: the weight gradients' cache-policy switches)
+  if (sv != 0 && sv != 28 && sv != 29 && sv != 39 && sv != 60 && sv != 62 && sv != 63 && sv != 64 && sv != 66 && sv != 67) return GAIB_OK;  // (28 / 29 / 39 / 67: switches of the weight gradients only)
   if ((((uintptr_t)d_A | (uintptr_t)d_B) & 3) != 0 || (((uintptr_t)d_C) & 15) != 0) return GAIB_OK;
   SkinnyArgs a;
   a.A = d_A;
@@ -557,4 +715,44 @@ int gaib_sgemm_skinny_try(gaib_ctx* ctx, int transA, int transB, int64_t M, int6
 #undef GAIB_TNS
   }
   return GAIB_OK;
+}
+
+// The weight gradients whose input side is 100 or 128 wide and whose output side is 128 or 256 (wide_tn_kernel), plain (mask ==
+// NULL) or with the d_relu mask folded in (G is rewritten in place).  Called by gaib_sgemm_ex / gaib_sgemm_drelu before their own
+// rules; *handled = 1: launched here.  sgemm_variant 67 turns the form off.
+int gaib_sgemm_wide_tn_try(gaib_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* d_A, float* d_G, const float* d_mask,
+                           int flags, float* d_C, int* handled) {
+  *handled = 0;
+  const int sv = ctx->sgemm_variant;
+  if (sv != 0 && sv != 28 && sv != 29 && !(sv >= 60 && sv <= 66)) return GAIB_OK;  // (39: the masked form without non-temporal hints = sgemm.hip's kernel)
+  // (M <= 112: seven 16-row tiles instead of 128 rows of 32 x 32 tiles.  At 113 .. 128 the two kernels measured the same -- 0.72 / 0.72
+  // plain, 0.886-0.893 / 0.889-0.899 masked inside the GCN layer step -- and sgemm.hip's stays)
+  if (K < 65536 || (N != 128 && N != 256) || M < 68 || M > 112) return GAIB_OK;
+  if ((((uintptr_t)d_A) & 3) != 0 || ((((uintptr_t)d_G | (uintptr_t)d_mask | (uintptr_t)d_C)) & 15) != 0) return GAIB_OK;
+  SkinnyArgs a;
+  a.A = d_A;
+  a.B = d_G;
+  a.C = d_C;
+  a.M = K;
+  a.K = (int)M;
+  a.N = (int)N;
+  a.ldn = (int)N;
+  a.accum = (flags & GAIB_ACCUMULATE) ? 1 : 0;
+  a.relu = (flags & GAIB_RELU) ? 1 : 0;
+  a.slabs = nullptr;
+  const double bytes = 4.0 * ((double)M * K + (double)K * N + (double)M * N * (a.accum ? 2.0 : 1.0) + (d_mask ? 2.0 * (double)K * N : 0.0));
+  const double flops = 2.0 * (double)M * (double)N * (double)K;
+  GAIB_HIP(hipSetDevice(ctx->device));
+  ProfScope ps(ctx, "sgemm", bytes, flops, 0, SkinnyTag(M, N, K).s);
+  *handled = 1;
+  // (S steps of 4 rows per register set, NBUF sets: the deepest ring without register spills whose loads and stores in
+  // flight stay below the 63 that vmcnt counts -- masked, 7 tiles: 4 x 13; masked, 8 tiles: 3 x 14; plain: 3 x 18 / 20)
+#define GAIB_WTN(MT_, NH_)                                                                         \
+  do {                                                                                             \
+    if (d_mask) return launch_wide_tn<MT_, NH_, true, 1, (MT_ == 7 ? 5 : 4)>(ctx, a, d_mask, d_G); \
+    return launch_wide_tn<MT_, NH_, false, 2, 4>(ctx, a, nullptr, nullptr);                        \
+  } while (0)
+  if (N == 128) GAIB_WTN(7, 1);
+  GAIB_WTN(7, 2);
+#undef GAIB_WTN
 }

@@ -1280,6 +1280,43 @@ def test_sgemm_skinny_family(ctx, form, m, n, k, accum, relu):
     assert torch.equal(got[0][0], got[0][1])  # fixed summation order
 
 
+@pytest.mark.parametrize("m,n,k", [(100, 128, 65537), (100, 256, 70003), (72, 128, 65551), (112, 256, 66001)])
+@pytest.mark.parametrize("masked,accum", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sgemm_wide_tn_seven_tiles(ctx, m, n, k, masked, accum):
+    """round 6: the weight gradients with a 100-wide input side (wide_tn_kernel: seven 16-row tiles, buffer loads and a buffer
+    write-back whose descriptors end with the matrices -- the last, partial set has no code of its own), plain and with the d_relu
+    mask folded in: fp64 on the device, the 32 x 32 register-resident kernels (sgemm_variant 67) next to them, G rewritten in
+    place exactly as d_relu would, nothing written past G, the same bits twice"""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(m + n + k)
+    A = torch.randn(k, m, device="cuda", generator=gen)
+    G0 = torch.randn(k, n, device="cuda", generator=gen)
+    mask = torch.randn(k, n, device="cuda", generator=gen)
+    mask[torch.rand(k, n, device="cuda", generator=gen) < 0.1] = 0.0  # exact zeros: (mask > 0) is strict
+    C0 = torch.randn(m, n, device="cuda", generator=gen)
+    Gm = G0 * (mask > 0) if masked else G0
+    want = A.double().t() @ Gm.double() + (C0.double() if accum else 0)
+    outs = []
+    try:
+        for variant in (0, 67, 0):
+            ctx.set_option("sgemm_variant", variant)
+            flat = torch.full((k * n + 1024,), 555.0, device="cuda")  # G at the START of its allocation, a canary behind it
+            G = flat[:k * n].view(k, n)
+            G.copy_(G0)
+            C = C0.clone()
+            if masked:
+                ctx.sgemm_drelu(A, G, mask, C, accum=bool(accum))
+            else:
+                ctx.sgemm(A, G, C, True, False, accum=bool(accum))
+            ctx.sync()
+            assert torch.equal(G, Gm) and bool((flat[k * n:] == 555.0).all())
+            assert float((C.double() - want).abs().max() / want.abs().max()) < 2e-5, variant
+            outs.append(C)
+    finally:
+        ctx.set_option("sgemm_variant", 0)
+    assert torch.equal(outs[0], outs[2])  # fixed summation order
+
+
 @pytest.mark.parametrize("variant", [0, 2, 10, 11, 12, 13, 30, 32, 33, 34, 35, 38])
 def test_sgemm_experimental_variants_agree(ctx, variant):
     """the tiling knobs (gaib_set_option sgemm_variant) change the schedule, not the result (round 6: the four-per-CU and
