@@ -236,6 +236,13 @@ def main():
     res["sgemm NN 2.45M x 47 x 128"] = ev_time(lambda: ctx.sgemm(x128, W47b, y47))
     res["sgemm NT 2.45M x 128 x 47"] = ev_time(lambda: ctx.sgemm(y47, W47b, x128, False, True))
     del x128, W47b, y47
+    # the weight gradients of a layer with 100 input features (wide_tn_kernel: seven 16-row tiles)
+    x100 = torch.randn(nv, 100, device="cuda")
+    for d in (128, 256):
+        gd, dW = torch.randn(nv, d, device="cuda"), torch.empty(100, d, device="cuda")
+        res[f"sgemm TN 100 x {d}, K = 2.45M"] = ev_time(lambda: ctx.sgemm(x100, gd, dW, True, False))
+        del gd, dW
+    del x100
     torch.cuda.empty_cache()
     ctx.close()
     res["GCN 128->128 layer step, products shape (the bench step)"] = layer_step(L.GCN, "ogbn-products", 128, 128, True)
